@@ -1,0 +1,332 @@
+// ORACLE -- test infrastructure only (see oracle.hpp).
+// Certification: dual certificate S(X) = Q - Lambda(X), PSD test, minimum
+// eigenpair by restarted Lanczos, fastVerification and escapeSaddle
+// (ref: src/DCORA_utils.cpp:1713-1982, src/QuadraticProblem.cpp:138-234).
+#include <algorithm>
+#include <functional>
+#include <numeric>
+
+#include "oracle.hpp"
+
+namespace orc {
+
+// ref: src/DCORA_utils.cpp:1898-1931 (PGO) and :1933-1982 (RA-SLAM)
+CSR dual_certificate(const Dims &D, const Mat &X, const CSR &Q) {
+  const int r = D.r, d = D.d;
+  Mat XQ;
+  spmm_right(X, Q, XQ);  // (Q X^T)^T
+  std::vector<int> I, J;
+  std::vector<double> V;
+  for (int i = 0; i < Q.n; ++i)
+    for (int p = Q.rp[i]; p < Q.rp[i + 1]; ++p) {
+      I.push_back(i);
+      J.push_back(Q.ci[p]);
+      V.push_back(Q.v[p]);
+    }
+  for (int i = 0; i < D.n; ++i) {
+    const int c = D.rot_col(i);
+    double P[9];
+    for (int a = 0; a < d; ++a)
+      for (int b = 0; b < d; ++b) {
+        double s = 0;
+        for (int t = 0; t < r; ++t) s += XQ(t, c + a) * X(t, c + b);
+        P[a + b * d] = s;
+      }
+    for (int a = 0; a < d; ++a)
+      for (int b = 0; b < d; ++b) {
+        I.push_back(c + a);
+        J.push_back(c + b);
+        V.push_back(-0.5 * (P[a + b * d] + P[b + a * d]));
+      }
+  }
+  for (int i = 0; i < D.l; ++i) {
+    const int c = D.sphere_col(i);
+    double s = 0;
+    for (int t = 0; t < r; ++t) s += X(t, c) * XQ(t, c);
+    I.push_back(c);
+    J.push_back(c);
+    V.push_back(-s);
+  }
+  return csr_from_triplets(Q.n, I, J, V);
+}
+
+bool is_psd(const CSR &S, int block) {
+  Chol c;
+  return c.factor(S, block);
+}
+
+// cyclic Jacobi eigen-decomposition of a small symmetric matrix (row-major m x m)
+static void jacobi_eig(int m, std::vector<double> &A, std::vector<double> &Z, std::vector<double> &w) {
+  Z.assign((size_t)m * m, 0.0);
+  for (int i = 0; i < m; ++i) Z[(size_t)i * m + i] = 1;
+  for (int sweep = 0; sweep < 100; ++sweep) {
+    double off = 0, diag = 0;
+    for (int i = 0; i < m; ++i) {
+      diag += A[(size_t)i * m + i] * A[(size_t)i * m + i];
+      for (int j = i + 1; j < m; ++j) off += A[(size_t)i * m + j] * A[(size_t)i * m + j];
+    }
+    if (off <= 1e-32 * (diag + off) || off == 0) break;
+    for (int p = 0; p < m - 1; ++p)
+      for (int q = p + 1; q < m; ++q) {
+        const double apq = A[(size_t)p * m + q];
+        if (apq == 0) continue;
+        const double app = A[(size_t)p * m + p], aqq = A[(size_t)q * m + q];
+        const double zeta = (aqq - app) / (2 * apq);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1 + zeta * zeta));
+        const double c = 1 / std::sqrt(1 + t * t), s = c * t;
+        for (int k = 0; k < m; ++k) {
+          const double akp = A[(size_t)k * m + p], akq = A[(size_t)k * m + q];
+          A[(size_t)k * m + p] = c * akp - s * akq;
+          A[(size_t)k * m + q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < m; ++k) {
+          const double apk = A[(size_t)p * m + k], aqk = A[(size_t)q * m + k];
+          A[(size_t)p * m + k] = c * apk - s * aqk;
+          A[(size_t)q * m + k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < m; ++k) {
+          const double zkp = Z[(size_t)k * m + p], zkq = Z[(size_t)k * m + q];
+          Z[(size_t)k * m + p] = c * zkp - s * zkq;
+          Z[(size_t)k * m + q] = s * zkp + c * zkq;
+        }
+      }
+  }
+  w.resize(m);
+  for (int i = 0; i < m; ++i) w[i] = A[(size_t)i * m + i];
+}
+
+using Op = std::function<void(const double *, double *)>;
+
+// Thick-restart symmetric Lanczos, nev = 1, selection = largest magnitude,
+// ncv basis vectors, ncv/2 Ritz vectors kept per restart (the nev_adjusted rule
+// of Spectra/ARPACK for nev = 1), full re-orthogonalisation.  Convergence:
+// |beta_m * y_m| < tol * max(eps^(2/3), |theta|)   (Spectra SymEigsBase).
+static EigResult lanczos_lm(int n, const Op &op, int ncv, int maxit, double tol, const double *x0,
+                            uint64_t seed) {
+  EigResult R;
+  R.v.assign(n, 0.0);
+  if (n == 0) return R;
+  ncv = std::min(ncv, n);
+  const int m = ncv;
+  const int keep = std::max(1, std::min(m - 1, m / 2));
+  std::vector<std::vector<double>> V(m + 1, std::vector<double>(n));
+  std::vector<double> H((size_t)m * m, 0.0), w(n), hcol(m + 1);
+  uint64_t s = seed ? seed : 1;
+  {
+    double nn = 0;
+    for (int i = 0; i < n; ++i) {
+      V[0][i] = x0 ? x0[i] : (u01(s) - 0.5);
+      nn += V[0][i] * V[0][i];
+    }
+    nn = std::sqrt(nn);
+    for (int i = 0; i < n; ++i) V[0][i] /= nn;
+  }
+  const double eps23 = std::pow(2.220446049250313e-16, 2.0 / 3.0);
+  int k = 0;
+  double beta = 0;
+  std::vector<double> Hc, Z, th;
+  std::vector<int> ord(m);
+  for (int it = 0; it <= maxit; ++it) {
+    for (int j = k; j < m; ++j) {
+      op(V[j].data(), w.data());
+      R.matvecs++;
+      std::fill(hcol.begin(), hcol.end(), 0.0);
+      for (int pass = 0; pass < 2; ++pass)
+        for (int i = 0; i <= j; ++i) {
+          double h = 0;
+          for (int t = 0; t < n; ++t) h += V[i][t] * w[t];
+          for (int t = 0; t < n; ++t) w[t] -= h * V[i][t];
+          hcol[i] += h;
+        }
+      for (int i = 0; i <= j; ++i) {
+        H[(size_t)i * m + j] = hcol[i];
+        H[(size_t)j * m + i] = hcol[i];
+      }
+      beta = 0;
+      for (int t = 0; t < n; ++t) beta += w[t] * w[t];
+      beta = std::sqrt(beta);
+      if (beta < 1e-300) {
+        // invariant subspace: continue with a random direction orthogonal to V
+        for (int t = 0; t < n; ++t) w[t] = u01(s) - 0.5;
+        for (int pass = 0; pass < 2; ++pass)
+          for (int i = 0; i <= j; ++i) {
+            double h = 0;
+            for (int t = 0; t < n; ++t) h += V[i][t] * w[t];
+            for (int t = 0; t < n; ++t) w[t] -= h * V[i][t];
+          }
+        double nn = 0;
+        for (int t = 0; t < n; ++t) nn += w[t] * w[t];
+        nn = std::sqrt(nn);
+        if (nn > 0)
+          for (int t = 0; t < n; ++t) V[j + 1][t] = w[t] / nn;
+        beta = 0;
+      } else {
+        for (int t = 0; t < n; ++t) V[j + 1][t] = w[t] / beta;
+      }
+    }
+    Hc = H;
+    jacobi_eig(m, Hc, Z, th);
+    std::iota(ord.begin(), ord.end(), 0);
+    std::sort(ord.begin(), ord.end(), [&](int a, int b) { return std::fabs(th[a]) > std::fabs(th[b]); });
+    const int b0 = ord[0];
+    const double resid = std::fabs(beta * Z[(size_t)(m - 1) * m + b0]);
+    const bool conv = resid < tol * std::max(eps23, std::fabs(th[b0]));
+    if (conv || it == maxit || m == n) {
+      R.ok = conv || (m == n);
+      R.lambda = th[b0];
+      for (int t = 0; t < n; ++t) {
+        double x = 0;
+        for (int i = 0; i < m; ++i) x += V[i][t] * Z[(size_t)i * m + b0];
+        R.v[t] = x;
+      }
+      double nn = 0;
+      for (double x : R.v) nn += x * x;
+      nn = std::sqrt(nn);
+      for (double &x : R.v) x /= nn;
+      return R;
+    }
+    // thick restart
+    std::vector<std::vector<double>> Vn(keep, std::vector<double>(n, 0.0));
+    for (int c = 0; c < keep; ++c) {
+      const int e = ord[c];
+      for (int i = 0; i < m; ++i) {
+        const double z = Z[(size_t)i * m + e];
+        if (z == 0) continue;
+        for (int t = 0; t < n; ++t) Vn[c][t] += z * V[i][t];
+      }
+    }
+    std::fill(H.begin(), H.end(), 0.0);
+    for (int c = 0; c < keep; ++c) {
+      V[c] = Vn[c];
+      H[(size_t)c * m + c] = th[ord[c]];
+    }
+    V[keep] = V[m];
+    k = keep;
+  }
+  return R;
+}
+
+EigResult lanczos_largest_magnitude(const CSR &S, double shift, int ncv, int maxit, double tol,
+                                    const double *x0, uint64_t seed) {
+  Op op = [&](const double *x, double *y) {
+    spmv(S, x, y);
+    if (shift != 0)
+      for (int i = 0; i < S.n; ++i) y[i] -= shift * x[i];
+  };
+  return lanczos_lm(S.n, op, ncv, maxit, tol, x0, seed);
+}
+
+// shift-and-invert fallback (ref: src/DCORA_utils.cpp:1751-1805)
+static EigResult min_eig_shift_invert(const CSR &S, double sigma, double eta, uint64_t seed) {
+  EigResult out;
+  const int ncv = std::min(20, S.n);
+  for (int i = 0; i < 10; ++i) {
+    CSR Ms = csr_add_diag(S, -sigma);
+    Chol c;
+    if (c.factor(Ms, 1)) {
+      Op op = [&](const double *x, double *y) { c.solve_vec(x, y); };
+      EigResult e = lanczos_lm(S.n, op, ncv, 1000, 1e-10, nullptr, seed);
+      if (e.ok) {
+        out = e;
+        out.lambda = sigma + 1.0 / e.lambda;
+        return out;
+      }
+    }
+    sigma /= 2;
+    if (i == 8 || sigma > -2 * eta) sigma = -2 * eta;  // floor used by the reference
+  }
+  return out;
+}
+
+// ref: src/DCORA_utils.cpp:1809-1896
+EigResult min_eig_pair(const CSR &S, int maxit, double min_eig_tol, int ncv, uint64_t seed) {
+  const int k = S.n;
+  ncv = std::min(ncv, k);
+  EigResult lm = lanczos_largest_magnitude(S, 0.0, ncv, maxit, 1e-4, nullptr, seed);
+  if (!lm.ok) return lm;
+  if (lm.lambda < 0) return lm;
+  const double lambda_lm = lm.lambda;
+  // x0 = row 0 of S, perturbed by ~3 %
+  std::vector<double> x0(k, 0.0), pert(k);
+  for (int p = S.rp[0]; p < S.rp[1]; ++p) x0[S.ci[p]] = S.v[p];
+  uint64_t s = seed + 17;
+  double pn = 0, vn = 0;
+  for (int i = 0; i < k; ++i) {
+    pert[i] = 2 * u01(s) - 1;
+    pn += pert[i] * pert[i];
+    vn += x0[i] * x0[i];
+  }
+  pn = std::sqrt(pn);
+  vn = std::sqrt(vn);
+  for (int i = 0; i < k; ++i) x0[i] += 0.03 * vn * pert[i] / pn;
+  EigResult sh = lanczos_largest_magnitude(S, 2 * lambda_lm, ncv, maxit, min_eig_tol / lambda_lm,
+                                           x0.data(), seed);
+  sh.matvecs += lm.matvecs;
+  if (!sh.ok) {
+    EigResult si = min_eig_shift_invert(S, -10.0, min_eig_tol, seed);
+    si.matvecs += sh.matvecs;
+    return si;
+  }
+  sh.lambda += 2 * lambda_lm;
+  return sh;
+}
+
+// ref: src/DCORA_utils.cpp:1713-1735
+bool fast_verification(const CSR &S, double eta, int block, double *theta, std::vector<double> *x,
+                       double *lambda_min, long *matvecs) {
+  CSR M = csr_add_diag(S, eta);
+  if (is_psd(M, block)) return true;
+  EigResult e = min_eig_pair(M, 1000, eta, 20, 12345);
+  std::vector<double> Sv(S.n);
+  spmv(S, e.v.data(), Sv.data());
+  double th = 0;
+  for (int i = 0; i < S.n; ++i) th += e.v[i] * Sv[i];
+  if (theta) *theta = th;
+  if (x) *x = e.v;
+  if (lambda_min) *lambda_min = e.lambda;
+  if (matvecs) *matvecs = e.matvecs;
+  return false;
+}
+
+// ref: src/QuadraticProblem.cpp:138-234
+bool escape_saddle(const Problem &Pn, const Mat &Xopt, double theta, const std::vector<double> &v,
+                   double grad_tol, double pgrad_tol, Mat &Xout) {
+  const int r = Pn.D.r, k = Pn.D.k();
+  Mat Xp(r, k), Xd(r, k);
+  for (int j = 0; j < k; ++j) {
+    for (int t = 0; t < r - 1; ++t) Xp(t, j) = Xopt(t, j);
+    Xd(r - 1, j) = v[j];
+  }
+  const double alpha_min = 1e-6;
+  const bool isSecondOrder = false;  // default argument of the reference header
+  double alpha = isSecondOrder ? std::max(16 * alpha_min, 100 * grad_tol / std::fabs(theta)) : 1.0;
+  std::vector<double> alphas, fvals;
+  const double FX = Pn.f(Xp);
+  Mat Xtest, step(r, k), g, pg;
+  while (alpha >= alpha_min) {
+    for (size_t i = 0; i < step.a.size(); ++i) step.a[i] = alpha * Xd.a[i];
+    retract(Pn.D, Xp, step, Xtest);
+    const double FXt = Pn.f(Xtest);
+    Pn.rgrad(Xtest, g);
+    const double gn = norm(g);
+    Pn.precondition(Xtest, g, pg);
+    const double pgn = norm(pg);
+    alphas.push_back(alpha);
+    fvals.push_back(FXt);
+    if (FXt < FX && gn > grad_tol && pgn > pgrad_tol) {
+      Xout = Xtest;
+      return true;
+    }
+    alpha /= 2;
+  }
+  auto it = std::min_element(fvals.begin(), fvals.end());
+  const size_t idx = it - fvals.begin();
+  if (fvals[idx] < FX) {
+    for (size_t i = 0; i < step.a.size(); ++i) step.a[i] = alphas[idx] * Xd.a[i];
+    retract(Pn.D, Xp, step, Xout);
+    return true;
+  }
+  return false;
+}
+
+}  // namespace orc

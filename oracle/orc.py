@@ -1,0 +1,326 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.
+
+ctypes binding of oracle/_build/liboracle.so (the CPU restatement of the DCORA
+hot path, see oracle/oracle.hpp).  Only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import this module; the product
+(dcora_amd/) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_build", "liboracle.so")
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB):
+        subprocess.check_call(["make", "-C", _HERE, "-j8"], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+_lib = None
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB)
+        L.orc_g2o_load.restype = C.c_void_p
+        L.orc_g2o_load.argtypes = [C.c_char_p]
+        L.orc_ds_create.restype = C.c_void_p
+        L.orc_ds_create.argtypes = [C.c_int, C.c_int, C.c_int, _ip, _dp]
+        L.orc_ds_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 3
+        L.orc_ds_copy.argtypes = [C.c_void_p, _ip, _dp]
+        L.orc_ds_free.argtypes = [C.c_void_p]
+        L.orc_csr_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_csr_copy.argtypes = [C.c_void_p, _ip, _ip, _dp]
+        L.orc_csr_free.argtypes = [C.c_void_p]
+        L.orc_build_Q_pgo.restype = C.c_void_p
+        L.orc_build_Q_pgo.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _ip, _dp]
+        L.orc_build_G_pgo.restype = C.c_int
+        L.orc_build_G_pgo.argtypes = [C.c_int] * 5 + [_ip, _dp, C.c_int, _ip, _dp, _dp]
+        L.orc_problem_create.restype = C.c_void_p
+        L.orc_problem_create.argtypes = [C.c_int] * 6 + [_ip, _ip, _dp, C.c_void_p, C.c_double]
+        L.orc_problem_free.argtypes = [C.c_void_p]
+        L.orc_problem_nnzL.restype = C.c_long
+        L.orc_problem_nnzL.argtypes = [C.c_void_p]
+        L.orc_f.restype = C.c_double
+        L.orc_f.argtypes = [C.c_void_p, _dp]
+        L.orc_egrad.argtypes = [C.c_void_p, _dp, _dp]
+        L.orc_rgrad.restype = C.c_double
+        L.orc_rgrad.argtypes = [C.c_void_p, _dp, _dp]
+        L.orc_hess.argtypes = [C.c_void_p, _dp, _dp, _dp]
+        L.orc_precondition.argtypes = [C.c_void_p, _dp, _dp, _dp]
+        L.orc_precon_solve.argtypes = [C.c_void_p, _dp, _dp]
+        for name in ("orc_tangent_project", "orc_retract"):
+            getattr(L, name).argtypes = [C.c_int] * 5 + [_dp, _dp, _dp]
+        L.orc_project_to_manifold.argtypes = [C.c_int] * 5 + [_dp, _dp]
+        L.orc_project_to_rotation_group.argtypes = [C.c_int, _dp, _dp]
+        L.orc_optimize.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
+        L.orc_dual_certificate.restype = C.c_void_p
+        L.orc_dual_certificate.argtypes = [C.c_int] * 5 + [_dp, C.c_int, _ip, _ip, _dp]
+        L.orc_is_psd.restype = C.c_int
+        L.orc_is_psd.argtypes = [C.c_int, _ip, _ip, _dp, C.c_int]
+        L.orc_min_eig.restype = C.c_int
+        L.orc_min_eig.argtypes = [C.c_int, _ip, _ip, _dp, C.c_int, C.c_double, C.c_int, C.c_ulonglong,
+                                  C.POINTER(C.c_double), _dp, C.POINTER(C.c_long)]
+        L.orc_lanczos_lm.restype = C.c_int
+        L.orc_lanczos_lm.argtypes = [C.c_int, _ip, _ip, _dp, C.c_double, C.c_int, C.c_int, C.c_double,
+                                     C.c_ulonglong, C.POINTER(C.c_double), _dp, C.POINTER(C.c_long)]
+        L.orc_fast_verification.restype = C.c_int
+        L.orc_fast_verification.argtypes = [C.c_int, _ip, _ip, _dp, C.c_double, C.c_int,
+                                            C.POINTER(C.c_double), _dp, C.POINTER(C.c_double)]
+        L.orc_escape_saddle.restype = C.c_int
+        L.orc_escape_saddle.argtypes = [C.c_void_p, _dp, C.c_double, _dp, C.c_double, C.c_double, _dp]
+        L.orc_run_rbcd.restype = C.c_void_p
+        L.orc_run_rbcd.argtypes = [C.c_void_p, _dp, _dp, C.c_int]
+        L.orc_trace_info.argtypes = [C.c_void_p, _dp]
+        L.orc_trace_copy.argtypes = [C.c_void_p, _dp, _dp, _ip, _ip, C.c_void_p]
+        L.orc_trace_free.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def F(a):
+    """column-major (Fortran) float64 copy flattened in memory order"""
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64).T).reshape(-1)
+
+
+def unF(flat, rows, cols):
+    return np.asarray(flat).reshape(cols, rows).T.copy()
+
+
+class CSR:
+    def __init__(self, n, rp, ci, v):
+        self.n = int(n)
+        self.rp = np.ascontiguousarray(rp, dtype=np.int32)
+        self.ci = np.ascontiguousarray(ci, dtype=np.int32)
+        self.v = np.ascontiguousarray(v, dtype=np.float64)
+
+    @property
+    def nnz(self):
+        return int(self.rp[-1])
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        return sp.csr_matrix((self.v, self.ci, self.rp), shape=(self.n, self.n))
+
+    @staticmethod
+    def from_scipy(A):
+        A = A.tocsr()
+        A.sort_indices()
+        return CSR(A.shape[0], A.indptr, A.indices, A.data)
+
+
+def _take_csr(h):
+    L = lib()
+    n, nnz = C.c_int(), C.c_int()
+    L.orc_csr_info(h, C.byref(n), C.byref(nnz))
+    rp = np.zeros(n.value + 1, np.int32)
+    ci = np.zeros(nnz.value, np.int32)
+    v = np.zeros(nnz.value, np.float64)
+    L.orc_csr_copy(h, rp, ci, v)
+    L.orc_csr_free(h)
+    return CSR(n.value, rp, ci, v)
+
+
+class Dataset:
+    """ids: m x 4 int32 (r1,p1,r2,p2); vals: m x (d*d+d+3) (R col-major, t, kappa, tau, weight)"""
+
+    def __init__(self, d, n, ids, vals):
+        self.d, self.n = int(d), int(n)
+        self.ids = np.ascontiguousarray(ids, dtype=np.int32)
+        self.vals = np.ascontiguousarray(vals, dtype=np.float64)
+
+    @property
+    def m(self):
+        return self.ids.shape[0]
+
+
+def read_g2o(path):
+    L = lib()
+    h = L.orc_g2o_load(path.encode())
+    if not h:
+        raise IOError(path)
+    d, n, m = C.c_int(), C.c_int(), C.c_int()
+    L.orc_ds_info(h, C.byref(d), C.byref(n), C.byref(m))
+    ids = np.zeros((m.value, 4), np.int32)
+    vals = np.zeros((m.value, d.value * d.value + d.value + 3), np.float64)
+    L.orc_ds_copy(h, ids, vals)
+    L.orc_ds_free(h)
+    return Dataset(d.value, n.value, ids, vals)
+
+
+def build_Q_pgo(ds, n=None, agent=0, ids=None, vals=None):
+    L = lib()
+    ids = ds.ids if ids is None else np.ascontiguousarray(ids, np.int32)
+    vals = ds.vals if vals is None else np.ascontiguousarray(vals, np.float64)
+    h = L.orc_build_Q_pgo(ds.d, ds.n if n is None else n, agent, ids.shape[0], ids, vals)
+    return _take_csr(h)
+
+
+def build_G_pgo(r, d, n, agent, ids, vals, keys, poses):
+    """poses: list of r x (d+1) arrays"""
+    L = lib()
+    ids = np.ascontiguousarray(ids, np.int32)
+    vals = np.ascontiguousarray(vals, np.float64)
+    keys = np.ascontiguousarray(keys, np.int32).reshape(-1, 2)
+    flat = np.concatenate([F(p) for p in poses]) if len(poses) else np.zeros(0)
+    G = np.zeros(r * (d + 1) * n)
+    ok = L.orc_build_G_pgo(r, d, n, agent, ids.shape[0], ids, vals, keys.shape[0], keys, flat, G)
+    return (unF(G, r, (d + 1) * n) if ok else None)
+
+
+class Problem:
+    def __init__(self, r, d, n, Q, G=None, reg=0.1, l=0, b=0):
+        L = lib()
+        self.r, self.d, self.n, self.l, self.b = r, d, n, l, b
+        self.k = (d + 1) * n + l + b
+        assert Q.n == self.k
+        self._G = None if G is None else F(G)
+        gp = None if G is None else self._G.ctypes.data_as(C.c_void_p)
+        self.h = L.orc_problem_create(r, d, n, l, b, self.k, Q.rp, Q.ci, Q.v, gp, float(reg))
+
+    def __del__(self):
+        try:
+            lib().orc_problem_free(self.h)
+        except Exception:
+            pass
+
+    def f(self, X):
+        return lib().orc_f(self.h, F(X))
+
+    def egrad(self, X):
+        out = np.zeros(self.r * self.k)
+        lib().orc_egrad(self.h, F(X), out)
+        return unF(out, self.r, self.k)
+
+    def rgrad(self, X):
+        out = np.zeros(self.r * self.k)
+        lib().orc_rgrad(self.h, F(X), out)
+        return unF(out, self.r, self.k)
+
+    def hess(self, X, V):
+        out = np.zeros(self.r * self.k)
+        lib().orc_hess(self.h, F(X), F(V), out)
+        return unF(out, self.r, self.k)
+
+    def precondition(self, X, V):
+        out = np.zeros(self.r * self.k)
+        lib().orc_precondition(self.h, F(X), F(V), out)
+        return unF(out, self.r, self.k)
+
+    def precon_solve(self, V):
+        out = np.zeros(self.r * self.k)
+        lib().orc_precon_solve(self.h, F(V), out)
+        return unF(out, self.r, self.k)
+
+    def nnzL(self):
+        return lib().orc_problem_nnzL(self.h)
+
+    def optimize(self, X0, method=0, gradnorm_tol=1e-2, RGD_stepsize=1e-3, RGD_use_precond=1,
+                 RTR_iterations=3, RTR_tCG_iterations=50, RTR_initial_radius=100.0):
+        prm = np.array([method, gradnorm_tol, RGD_stepsize, RGD_use_precond, RTR_iterations,
+                        RTR_tCG_iterations, RTR_initial_radius], dtype=np.float64)
+        out = np.zeros(self.r * self.k)
+        res = np.zeros(10)
+        lib().orc_optimize(self.h, prm, F(X0), out, res)
+        keys = ["success", "fInit", "gradNormInit", "fOpt", "gradNormOpt", "elapsedMs", "tcg_status",
+                "outer_iters", "inner_iters", "accepted"]
+        return unF(out, self.r, self.k), dict(zip(keys, res.tolist()))
+
+    def escape_saddle(self, Xopt, theta, v, gtol=1e-6, pgtol=1e-6):
+        out = np.zeros(self.r * self.k)
+        ok = lib().orc_escape_saddle(self.h, F(Xopt), float(theta), np.ascontiguousarray(v, np.float64), gtol,
+                                     pgtol, out)
+        return (unF(out, self.r, self.k) if ok else None)
+
+
+def tangent_project(r, d, n, X, V, l=0, b=0):
+    k = (d + 1) * n + l + b
+    out = np.zeros(r * k)
+    lib().orc_tangent_project(r, d, n, l, b, F(X), F(V), out)
+    return unF(out, r, k)
+
+
+def retract(r, d, n, X, V, l=0, b=0):
+    k = (d + 1) * n + l + b
+    out = np.zeros(r * k)
+    lib().orc_retract(r, d, n, l, b, F(X), F(V), out)
+    return unF(out, r, k)
+
+
+def project_to_manifold(r, d, n, M, l=0, b=0):
+    k = (d + 1) * n + l + b
+    out = np.zeros(r * k)
+    lib().orc_project_to_manifold(r, d, n, l, b, F(M), out)
+    return unF(out, r, k)
+
+
+def project_to_rotation_group(M):
+    d = M.shape[0]
+    out = np.zeros(d * d)
+    lib().orc_project_to_rotation_group(d, F(M), out)
+    return unF(out, d, d)
+
+
+def dual_certificate(r, d, n, X, Q, l=0, b=0):
+    h = lib().orc_dual_certificate(r, d, n, l, b, F(X), Q.n, Q.rp, Q.ci, Q.v)
+    return _take_csr(h)
+
+
+def is_psd(S, block=1):
+    return bool(lib().orc_is_psd(S.n, S.rp, S.ci, S.v, block))
+
+
+def min_eig(S, maxit=1000, tol=1e-3, ncv=20, seed=12345):
+    lam, mv = C.c_double(), C.c_long()
+    v = np.zeros(S.n)
+    ok = lib().orc_min_eig(S.n, S.rp, S.ci, S.v, maxit, tol, ncv, seed, C.byref(lam), v, C.byref(mv))
+    return bool(ok), lam.value, v, mv.value
+
+
+def lanczos_lm(S, shift=0.0, ncv=20, maxit=1000, tol=1e-4, seed=12345):
+    lam, mv = C.c_double(), C.c_long()
+    v = np.zeros(S.n)
+    ok = lib().orc_lanczos_lm(S.n, S.rp, S.ci, S.v, shift, ncv, maxit, tol, seed, C.byref(lam), v, C.byref(mv))
+    return bool(ok), lam.value, v, mv.value
+
+
+def fast_verification(S, eta, block=1):
+    th, lm = C.c_double(), C.c_double()
+    v = np.zeros(S.n)
+    ok = lib().orc_fast_verification(S.n, S.rp, S.ci, S.v, eta, block, C.byref(th), v, C.byref(lm))
+    return bool(ok), th.value, v, lm.value
+
+
+def run_rbcd(ds, X0, num_robots=5, r_min=5, r_max=100, max_iters=1000, min_eig_tol=1e-3, rgrad_tol=0.1,
+             acceleration=1, staircase=1, verbose=0, method=0, gradnorm_tol=1e-2, RGD_stepsize=1e-3,
+             RGD_use_precond=1, RTR_iterations=3, RTR_tCG_iterations=50, RTR_initial_radius=100.0):
+    L = lib()
+    h = L.orc_ds_create(ds.d, ds.n, ds.m, ds.ids, ds.vals)
+    opts = np.array([num_robots, r_min, r_max, max_iters, min_eig_tol, rgrad_tol, acceleration, staircase, verbose,
+                     method, gradnorm_tol, RGD_stepsize, RGD_use_precond, RTR_iterations, RTR_tCG_iterations,
+                     RTR_initial_radius], dtype=np.float64)
+    X0 = np.asarray(X0, dtype=np.float64)
+    t = L.orc_run_rbcd(h, opts, F(X0), X0.shape[0])
+    info = np.zeros(8)
+    L.orc_trace_info(t, info)
+    it = int(info[0])
+    cost, gn = np.zeros(it), np.zeros(it)
+    sel, rk = np.zeros(it, np.int32), np.zeros(it, np.int32)
+    rfin = int(info[1])
+    k = (ds.d + 1) * ds.n
+    Xf = np.zeros(rfin * k)
+    L.orc_trace_copy(t, cost, gn, sel, rk, Xf.ctypes.data_as(C.c_void_p))
+    L.orc_trace_free(t)
+    L.orc_ds_free(h)
+    return dict(total_iters=it, final_rank=rfin, certified=int(info[2]), theta=info[3], lambda_min=info[4],
+                rbcd_seconds=info[5], cert_seconds=info[6], setup_seconds=info[7], cost=cost, gradnorm=gn,
+                selected=sel, rank=rk, X=unF(Xf, rfin, k))
