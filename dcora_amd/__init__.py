@@ -1,0 +1,367 @@
+"""dcora_amd -- MI355X-native implementation of DCORA's per-agent Riemannian local solver, certification and
+RBCD loop.  This package is a thin Python view (for tests and bench.py) of the C ABI in include/dcora_hip.h;
+the product is libdcora_hip.so (HIP kernels for gfx950 + C++ host code).  Class and method names mirror the
+reference's C++ API (QuadraticProblem / QuadraticOptimizer / ROptParameters, ref include/DCORA/*.h).
+"""
+import ctypes as C
+import gzip
+import os
+import shutil
+import tempfile
+
+import numpy as np
+
+from . import capi
+from .capi import DcoraError, Dims, ROptParams, ROptResult, RbcdOptions, F, unF, check
+
+__all__ = ["QuadraticProblem", "QuadraticOptimizer", "ROptParameters", "Dataset", "Csr", "RbcdSession", "DcoraError",
+           "build_Q_pgo", "dual_certificate", "is_psd", "min_eig", "fast_verification", "manifold_project",
+           "device_count"]
+
+
+def device_count():
+    return capi.lib().dcora_device_count()
+
+
+class Csr:
+    """row-major CSR, int32 indices (ref include/DCORA/DCORA_types.h:36)"""
+
+    def __init__(self, n, rp, ci, v):
+        self.n = int(n)
+        self.rp = np.ascontiguousarray(rp, dtype=np.int32)
+        self.ci = np.ascontiguousarray(ci, dtype=np.int32)
+        self.v = np.ascontiguousarray(v, dtype=np.float64)
+
+    @property
+    def nnz(self):
+        return int(self.rp[-1])
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        return sp.csr_matrix((self.v, self.ci, self.rp), shape=(self.n, self.n))
+
+    @staticmethod
+    def from_scipy(A):
+        A = A.tocsr()
+        A.sort_indices()
+        return Csr(A.shape[0], A.indptr, A.indices, A.data)
+
+
+class Dataset:
+    """measurement list: ids m x 4 (r1,p1,r2,p2), vals m x (d*d+d+3) (R col-major, t, kappa, tau, weight)"""
+
+    def __init__(self, d, n, ids, vals):
+        self.d, self.n = int(d), int(n)
+        self.ids = np.ascontiguousarray(ids, dtype=np.int32).reshape(-1, 4)
+        self.vals = np.ascontiguousarray(vals, dtype=np.float64).reshape(self.ids.shape[0], -1)
+
+    @property
+    def m(self):
+        return self.ids.shape[0]
+
+    @staticmethod
+    def load_g2o(path):
+        """read_g2o_file (ref src/DCORA_utils.cpp:179-375); accepts .g2o and .g2o.gz"""
+        L = capi.lib()
+        tmp = None
+        if str(path).endswith(".gz"):
+            fd, tmp = tempfile.mkstemp(suffix=".g2o")
+            with os.fdopen(fd, "wb") as out, gzip.open(path, "rb") as src:
+                shutil.copyfileobj(src, out)
+            path = tmp
+        try:
+            h = C.c_void_p()
+            check(L.dcora_dataset_load_g2o(str(path).encode(), C.byref(h)))
+        finally:
+            if tmp:
+                os.unlink(tmp)
+        d, n, m = C.c_int(), C.c_int(), C.c_int()
+        check(L.dcora_dataset_info(h, C.byref(d), C.byref(n), C.byref(m)))
+        ids = np.zeros((m.value, 4), np.int32)
+        vals = np.zeros((m.value, d.value * d.value + d.value + 3), np.float64)
+        check(L.dcora_dataset_copy(h, ids, vals))
+        L.dcora_dataset_destroy(h)
+        return Dataset(d.value, n.value, ids, vals)
+
+    def handle(self):
+        h = C.c_void_p()
+        check(capi.lib().dcora_dataset_create(self.d, self.n, self.m, self.ids, self.vals, C.byref(h)))
+        return h
+
+
+def build_Q_pgo(ds, n=None, agent=0, ids=None, vals=None):
+    """Graph::constructQuadraticCostTermPGO (ref src/Graph.cpp:579-683)"""
+    ids = ds.ids if ids is None else np.ascontiguousarray(ids, np.int32)
+    vals = ds.vals if vals is None else np.ascontiguousarray(vals, np.float64)
+    h = C.c_void_p()
+    check(capi.lib().dcora_graph_build_Q_pgo(ds.d, ds.n if n is None else n, agent, ids.shape[0], ids, vals,
+                                             C.byref(h)))
+    return Csr(*capi.take_csr(h))
+
+
+class ROptParameters:
+    """ref include/DCORA/DCORA_types.h:152-168"""
+    RTR, RGD = 0, 1
+
+    def __init__(self, **kw):
+        self.c = ROptParams()
+        capi.lib().dcora_ropt_params_default(C.byref(self.c))
+        for k, v in kw.items():
+            setattr(self.c, k, v)
+
+    def __getattr__(self, k):
+        return getattr(self.__dict__["c"], k)
+
+
+class QuadraticProblem:
+    """ref include/DCORA/QuadraticProblem.h: f, RieGrad, RieGradNorm, Retract, PreCondition, escapeSaddle"""
+
+    def __init__(self, r, d, n, Q, G=None, reg=0.1, l=0, b=0, device=0):
+        self.r, self.d, self.n, self.l, self.b = r, d, n, l, b
+        self.k = (d + 1) * n + l + b
+        if Q.n != self.k:
+            raise ValueError("Q is %d x %d, expected %d" % (Q.n, Q.n, self.k))
+        dims = Dims(r, d, n, l, b)
+        g = None
+        if G is not None:
+            self._G = F(G)
+            g = self._G.ctypes.data_as(C.c_void_p)
+        self.h = C.c_void_p()
+        check(capi.lib().dcora_problem_create(C.byref(dims), Q.rp, Q.ci, Q.v, g, float(reg), device, C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            capi.lib().dcora_problem_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def relaxation_rank(self):
+        return self.r
+
+    def problem_dimension(self):
+        return self.k
+
+    def _out(self):
+        return np.zeros(self.r * self.k)
+
+    def set_linear_term(self, G):
+        g = None
+        if G is not None:
+            self._G = F(G)
+            g = self._G.ctypes.data_as(C.c_void_p)
+        check(capi.lib().dcora_problem_set_linear_term(self.h, g))
+
+    def f(self, Y):
+        out = C.c_double()
+        check(capi.lib().dcora_problem_cost(self.h, F(Y), C.byref(out)))
+        return out.value
+
+    def EucGrad(self, Y):
+        out = self._out()
+        check(capi.lib().dcora_problem_eucgrad(self.h, F(Y), out))
+        return unF(out, self.r, self.k)
+
+    def RieGrad(self, Y):
+        out = self._out()
+        nrm = C.c_double()
+        check(capi.lib().dcora_problem_riegrad(self.h, F(Y), out.ctypes.data_as(C.c_void_p), C.byref(nrm)))
+        return unF(out, self.r, self.k)
+
+    def RieGradNorm(self, Y):
+        nrm = C.c_double()
+        check(capi.lib().dcora_problem_riegrad(self.h, F(Y), None, C.byref(nrm)))
+        return nrm.value
+
+    def HessVec(self, Y, V):
+        out = self._out()
+        check(capi.lib().dcora_problem_hessvec(self.h, F(Y), F(V), out))
+        return unF(out, self.r, self.k)
+
+    def PreCondition(self, Y, V):
+        out = self._out()
+        check(capi.lib().dcora_problem_precondition(self.h, F(Y), F(V), out))
+        return unF(out, self.r, self.k)
+
+    def Retract(self, Y, V):
+        out = self._out()
+        check(capi.lib().dcora_problem_retract(self.h, F(Y), F(V), out))
+        return unF(out, self.r, self.k)
+
+    def projectToTangentSpace(self, Y, V):
+        out = self._out()
+        check(capi.lib().dcora_problem_tangent_project(self.h, F(Y), F(V), out))
+        return unF(out, self.r, self.k)
+
+    def escapeSaddle(self, Xopt, theta, v, gradient_tolerance=1e-6, preconditioned_gradient_tolerance=1e-6):
+        out = self._out()
+        ok = C.c_int()
+        check(capi.lib().dcora_problem_escape_saddle(self.h, F(Xopt), float(theta),
+                                                     np.ascontiguousarray(v, np.float64), gradient_tolerance,
+                                                     preconditioned_gradient_tolerance, out, C.byref(ok)))
+        return (unF(out, self.r, self.k) if ok.value else None)
+
+    def time_qapply(self, reps=100):
+        ms, by = C.c_double(), C.c_double()
+        check(capi.lib().dcora_problem_time_qapply(self.h, reps, C.byref(ms), C.byref(by)))
+        return ms.value, by.value
+
+
+class QuadraticOptimizer:
+    """ref include/DCORA/QuadraticOptimizer.h: optimize(Y), getOptResult()"""
+
+    def __init__(self, problem, params=None):
+        self.problem = problem
+        self.params = params or ROptParameters()
+        self.result = ROptResult()
+
+    def optimize(self, Y):
+        out = np.zeros(self.problem.r * self.problem.k)
+        check(capi.lib().dcora_optimizer_optimize(self.problem.h, C.byref(self.params.c), F(Y), out,
+                                                  C.byref(self.result)))
+        return unF(out, self.problem.r, self.problem.k)
+
+    def getOptResult(self):
+        return self.result.as_dict()
+
+
+def manifold_project(r, d, n, M, l=0, b=0, device=0):
+    """projectToSEMatrix / projectToRAMatrix (ref src/DCORA_utils.cpp:2201-2220)"""
+    dims = Dims(r, d, n, l, b)
+    k = (d + 1) * n + l + b
+    out = np.zeros(r * k)
+    check(capi.lib().dcora_manifold_project(C.byref(dims), F(M), out, device))
+    return unF(out, r, k)
+
+
+def dual_certificate(r, d, n, X, Q, l=0, b=0, device=0):
+    """constructDualCertificateMatrixPGO / RASLAM (ref src/DCORA_utils.cpp:1898-1982)"""
+    dims = Dims(r, d, n, l, b)
+    h = C.c_void_p()
+    check(capi.lib().dcora_cert_dual_matrix(C.byref(dims), F(X), Q.rp, Q.ci, Q.v, device, C.byref(h)))
+    return Csr(*capi.take_csr(h))
+
+
+def is_psd(S, block=1):
+    out = C.c_int()
+    check(capi.lib().dcora_cert_is_psd(S.n, S.rp, S.ci, S.v, block, C.byref(out)))
+    return bool(out.value)
+
+
+def min_eig(S, max_iterations=1000, tol=1e-3, ncv=20, seed=12345, device=0):
+    lam, mv = C.c_double(), C.c_long()
+    v = np.zeros(S.n)
+    st = capi.lib().dcora_cert_min_eig(S.n, S.rp, S.ci, S.v, max_iterations, tol, ncv, seed, device, C.byref(lam), v,
+                                       C.byref(mv))
+    if st not in (0, 5):
+        check(st)
+    return st == 0, lam.value, v, mv.value
+
+
+def fast_verification(S, eta, block=1, device=0):
+    psd, th, lm = C.c_int(), C.c_double(), C.c_double()
+    v = np.zeros(S.n)
+    st = capi.lib().dcora_cert_fast_verification(S.n, S.rp, S.ci, S.v, float(eta), block, device, C.byref(psd),
+                                                 C.byref(th), v, C.byref(lm))
+    if st not in (0, 5):
+        check(st)
+    return bool(psd.value), th.value, v, lm.value
+
+
+class RbcdSession:
+    """Agents + synchronous RBCD++ driver on the device (ref examples/MultiRobotExample.cpp:121-307)"""
+
+    def __init__(self, ds, num_robots=5, r=5, acceleration=True, restart_interval=30, params=None, rank=0,
+                 world_size=1, device=0):
+        self.ds, self.R, self.r = ds, num_robots, r
+        self.k = (ds.d + 1) * ds.n
+        o = RbcdOptions()
+        capi.lib().dcora_rbcd_options_default(C.byref(o))
+        o.num_robots, o.r, o.acceleration, o.restart_interval = num_robots, r, int(acceleration), restart_interval
+        if params is not None:
+            o.local = params.c
+        o.rank, o.world_size, o.device = rank, world_size, device
+        dsh = ds.handle()
+        self.h = C.c_void_p()
+        try:
+            check(capi.lib().dcora_rbcd_create(dsh, C.byref(o), C.byref(self.h)))
+        finally:
+            capi.lib().dcora_dataset_destroy(dsh)
+
+    def close(self):
+        if getattr(self, "h", None):
+            capi.lib().dcora_rbcd_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_X(self, X):
+        check(capi.lib().dcora_rbcd_set_X(self.h, F(X)))
+
+    def get_X(self):
+        out = np.zeros(self.r * self.k)
+        check(capi.lib().dcora_rbcd_get_X(self.h, out))
+        return unF(out, self.r, self.k)
+
+    def iterate(self, selected):
+        c2, gn, nxt = C.c_double(), C.c_double(), C.c_int()
+        bn = np.zeros(self.R)
+        check(capi.lib().dcora_rbcd_iterate(self.h, selected, C.byref(c2), C.byref(gn),
+                                            bn.ctypes.data_as(C.c_void_p), C.byref(nxt)))
+        return c2.value, gn.value, bn, nxt.value
+
+    def run(self, max_iters=1000, rgrad_tol=0.1):
+        it = C.c_int()
+        cost, gn = np.zeros(max_iters), np.zeros(max_iters)
+        sel = np.zeros(max_iters, np.int32)
+        check(capi.lib().dcora_rbcd_run(self.h, max_iters, rgrad_tol, C.byref(it), cost.ctypes.data_as(C.c_void_p),
+                                        gn.ctypes.data_as(C.c_void_p), sel.ctypes.data_as(C.c_void_p)))
+        n = it.value
+        return dict(iters=n, cost=cost[:n], gradnorm=gn[:n], selected=sel[:n])
+
+    def last_result(self):
+        r = ROptResult()
+        check(capi.lib().dcora_rbcd_last_result(self.h, C.byref(r)))
+        return r.as_dict()
+
+    # ---- multi-process pieces ----
+    def X_device_ptr(self):
+        p = C.c_void_p()
+        check(capi.lib().dcora_rbcd_X_device_ptr(self.h, C.byref(p)))
+        return p.value
+
+    def public_count(self, agent):
+        c = C.c_int()
+        check(capi.lib().dcora_rbcd_public_count(self.h, agent, C.byref(c)))
+        return c.value
+
+    def public_indices(self, agent):
+        idx = np.zeros(max(self.public_count(agent), 1), np.int32)
+        check(capi.lib().dcora_rbcd_public_indices(self.h, agent, idx))
+        return idx[:self.public_count(agent)]
+
+    def pack_public_dev(self, agent, ptr):
+        check(capi.lib().dcora_rbcd_pack_public_dev(self.h, agent, C.c_void_p(ptr)))
+
+    def unpack_public_dev(self, agent, ptr):
+        check(capi.lib().dcora_rbcd_unpack_public_dev(self.h, agent, C.c_void_p(ptr)))
+
+    def phase_nonselected(self, selected):
+        check(capi.lib().dcora_rbcd_phase_nonselected(self.h, selected))
+
+    def phase_selected(self, selected):
+        check(capi.lib().dcora_rbcd_phase_selected(self.h, selected))
+
+    def phase_evaluate_dev(self, ptr):
+        check(capi.lib().dcora_rbcd_phase_evaluate_dev(self.h, C.c_void_p(ptr)))
+
+    def synchronize(self):
+        check(capi.lib().dcora_rbcd_synchronize(self.h))

@@ -1,0 +1,425 @@
+// extern "C" surface of libdcora_hip.so (declared in include/dcora_hip.h).
+#include <cstring>
+#include <new>
+
+#include "../../include/dcora_hip.h"
+#include "cert.h"
+#include "device_problem.h"
+#include "host_graph.h"
+#include "rbcd.h"
+
+namespace dcora {
+const std::string &get_last_error();
+}
+using namespace dcora;
+
+struct dcora_problem_s {
+  DeviceProblem p;
+};
+struct dcora_csr_s {
+  HostCsr m;
+};
+struct dcora_dataset_s {
+  HostDataset ds;
+};
+struct dcora_rbcd_s {
+  RbcdSession s;
+  std::vector<int> sel_trace;
+};
+
+namespace {
+HostCsr view_csr(int n, const int *rp, const int *ci, const double *v) {
+  HostCsr A;
+  A.n = n;
+  A.ncols = n;
+  A.rp.assign(rp, rp + n + 1);
+  A.ci.assign(ci, ci + rp[n]);
+  A.v.assign(v, v + rp[n]);
+  return A;
+}
+std::vector<PoseMeas> view_meas(int d, int m, const int *ids, const double *vals) {
+  const int stride = d * d + d + 3;
+  std::vector<PoseMeas> out(m);
+  for (int k = 0; k < m; ++k) {
+    PoseMeas &e = out[k];
+    e.r1 = ids[4 * k];
+    e.p1 = ids[4 * k + 1];
+    e.r2 = ids[4 * k + 2];
+    e.p2 = ids[4 * k + 3];
+    const double *q = vals + (size_t)k * stride;
+    for (int i = 0; i < d * d; ++i) e.R[i] = q[i];
+    for (int i = 0; i < d; ++i) e.t[i] = q[d * d + i];
+    e.kappa = q[d * d + d];
+    e.tau = q[d * d + d + 1];
+    e.weight = q[d * d + d + 2];
+  }
+  return out;
+}
+int bad(const char *msg) {
+  set_last_error(msg);
+  return DCORA_ERR_BAD_ARG;
+}
+}  // namespace
+
+#define DCORA_TRY try {
+#define DCORA_CATCH                                   \
+  }                                                   \
+  catch (const std::bad_alloc &) {                    \
+    set_last_error("host allocation failed");         \
+    return DCORA_ERR_HIP;                             \
+  }                                                   \
+  catch (const std::exception &e) {                   \
+    set_last_error(std::string("exception: ") + e.what()); \
+    return DCORA_ERR_HIP;                             \
+  }
+
+extern "C" {
+
+const char *dcora_status_string(int s) {
+  switch (s) {
+    case DCORA_OK: return "ok";
+    case DCORA_ERR_BAD_ARG: return "bad argument";
+    case DCORA_ERR_NO_DEVICE: return "no HIP device (no CPU fallback)";
+    case DCORA_ERR_HIP: return "HIP runtime error";
+    case DCORA_ERR_NOT_PD: return "matrix not positive definite";
+    case DCORA_ERR_NO_CONVERGENCE: return "eigensolver did not converge";
+    case DCORA_ERR_NO_PRECONDITIONER: return "preconditioner missing";
+    case DCORA_ERR_IO: return "I/O error";
+    case DCORA_ERR_UNSUPPORTED: return "unsupported configuration";
+  }
+  return "unknown";
+}
+const char *dcora_last_error(void) { return get_last_error().c_str(); }
+int dcora_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+void dcora_ropt_params_default(dcora_ropt_params *p) {
+  p->method = 0;
+  p->verbose = 0;
+  p->gradnorm_tol = 1e-2;
+  p->RGD_stepsize = 1e-3;
+  p->RGD_use_preconditioner = 1;
+  p->RTR_iterations = 3;
+  p->RTR_tCG_iterations = 50;
+  p->RTR_initial_radius = 100;
+}
+
+// ---- problem ----------------------------------------------------------------------------------------------
+int dcora_problem_create(const dcora_dims *dims, const int *rowptr, const int *colidx, const double *vals,
+                         const double *G, double precond_reg, int device, dcora_problem_t *out) {
+  if (!dims || !rowptr || !colidx || !vals || !out) return bad("null argument");
+  DCORA_TRY
+  const int k = (dims->d + 1) * dims->n + dims->l + dims->b;
+  dcora_problem_s *h = new dcora_problem_s;
+  const int rc = h->p.init(*dims, view_csr(k, rowptr, colidx, vals), G, precond_reg, device, nullptr);
+  if (rc) {
+    delete h;
+    return rc;
+  }
+  *out = h;
+  return DCORA_OK;
+  DCORA_CATCH
+}
+int dcora_problem_destroy(dcora_problem_t p) {
+  delete p;
+  return DCORA_OK;
+}
+int dcora_problem_set_linear_term(dcora_problem_t p, const double *G) { return p ? p->p.set_G_host(G) : bad("null"); }
+int dcora_problem_cost(dcora_problem_t p, const double *X, double *f) { return p ? p->p.cost(X, f) : bad("null"); }
+int dcora_problem_eucgrad(dcora_problem_t p, const double *X, double *out) {
+  return p ? p->p.eucgrad(X, out) : bad("null");
+}
+int dcora_problem_riegrad(dcora_problem_t p, const double *X, double *out, double *norm) {
+  return p ? p->p.riegrad(X, out, norm) : bad("null");
+}
+int dcora_problem_hessvec(dcora_problem_t p, const double *X, const double *V, double *out) {
+  return p ? p->p.hessvec(X, V, out) : bad("null");
+}
+int dcora_problem_precondition(dcora_problem_t p, const double *X, const double *V, double *out) {
+  return p ? p->p.precondition(X, V, out) : bad("null");
+}
+int dcora_problem_retract(dcora_problem_t p, const double *X, const double *V, double *out) {
+  return p ? p->p.retract(X, V, out) : bad("null");
+}
+int dcora_problem_tangent_project(dcora_problem_t p, const double *X, const double *V, double *out) {
+  return p ? p->p.tangent_project(X, V, out) : bad("null");
+}
+int dcora_problem_escape_saddle(dcora_problem_t p, const double *Xopt, double theta, const double *v, double gtol,
+                                double pgtol, double *Xout, int *success) {
+  if (!p) return bad("null");
+  DCORA_TRY
+  return p->p.escape_saddle(Xopt, theta, v, gtol, pgtol, Xout, success);
+  DCORA_CATCH
+}
+int dcora_manifold_project(const dcora_dims *dims, const double *M, double *out, int device) {
+  if (!dims || !M || !out) return bad("null argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_last_error("no HIP device available: libdcora_hip has no CPU fallback");
+    return DCORA_ERR_NO_DEVICE;
+  }
+  DCORA_HIP(hipSetDevice(device));
+  const ManiDesc m = make_mani(dims->r, dims->d, dims->n, dims->l, dims->b);
+  const size_t N = (size_t)m.r * m.k;
+  DevBuf<double> a, b;
+  DCORA_HIP(a.alloc(N));
+  DCORA_HIP(b.alloc(N));
+  DCORA_HIP(hipMemcpy(a.p, M, N * sizeof(double), hipMemcpyHostToDevice));
+  launch_polar(nullptr, m, 1.0, a.p, 0.0, nullptr, 0.0, nullptr, b.p);
+  DCORA_HIP(hipDeviceSynchronize());
+  DCORA_HIP(hipMemcpy(out, b.p, N * sizeof(double), hipMemcpyDeviceToHost));
+  return DCORA_OK;
+}
+int dcora_optimizer_optimize(dcora_problem_t p, const dcora_ropt_params *params, const double *X0, double *Xout,
+                             dcora_ropt_result *result) {
+  if (!p || !params || !X0 || !Xout) return bad("null argument");
+  DCORA_TRY
+  return p->p.optimize(*params, X0, Xout, result);
+  DCORA_CATCH
+}
+int dcora_problem_time_qapply(dcora_problem_t p, int reps, double *avg_ms, double *bytes) {
+  return p ? p->p.time_qapply(reps, avg_ms, bytes) : bad("null");
+}
+
+// ---- CSR handles --------------------------------------------------------------------------------------------
+int dcora_csr_info(dcora_csr_t m, int *n, int *nnz) {
+  if (!m) return bad("null");
+  *n = m->m.n;
+  *nnz = m->m.nnz();
+  return DCORA_OK;
+}
+int dcora_csr_copy(dcora_csr_t m, int *rp, int *ci, double *v) {
+  if (!m) return bad("null");
+  std::copy(m->m.rp.begin(), m->m.rp.end(), rp);
+  std::copy(m->m.ci.begin(), m->m.ci.end(), ci);
+  std::copy(m->m.v.begin(), m->m.v.end(), v);
+  return DCORA_OK;
+}
+int dcora_csr_destroy(dcora_csr_t m) {
+  delete m;
+  return DCORA_OK;
+}
+
+// ---- certification --------------------------------------------------------------------------------------------
+int dcora_cert_dual_matrix(const dcora_dims *dims, const double *X, const int *rp, const int *ci, const double *v,
+                           int device, dcora_csr_t *S) {
+  if (!dims || !X || !rp || !S) return bad("null argument");
+  DCORA_TRY
+  const int k = (dims->d + 1) * dims->n + dims->l + dims->b;
+  dcora_csr_s *h = new dcora_csr_s;
+  const int rc = device_dual_certificate(*dims, X, view_csr(k, rp, ci, v), device, &h->m);
+  if (rc) {
+    delete h;
+    return rc;
+  }
+  *S = h;
+  return DCORA_OK;
+  DCORA_CATCH
+}
+int dcora_cert_is_psd(int k, const int *rp, const int *ci, const double *v, int block, int *is_psd) {
+  DCORA_TRY
+  bool psd = false;
+  const int rc = host_is_psd(view_csr(k, rp, ci, v), block, &psd);
+  *is_psd = psd ? 1 : 0;
+  return rc;
+  DCORA_CATCH
+}
+int dcora_cert_min_eig(int k, const int *rp, const int *ci, const double *v, int max_iterations, double tol, int ncv,
+                       unsigned long long seed, int device, double *lambda_min, double *vec, long *num_matvecs) {
+  DCORA_TRY
+  LanczosResult e;
+  const int rc = device_min_eig(view_csr(k, rp, ci, v), max_iterations, tol, ncv, seed, device, &e);
+  if (lambda_min) *lambda_min = e.lambda;
+  if (vec && (int)e.v.size() == k) std::copy(e.v.begin(), e.v.end(), vec);
+  if (num_matvecs) *num_matvecs = e.matvecs;
+  return rc;
+  DCORA_CATCH
+}
+int dcora_cert_fast_verification(int k, const int *rp, const int *ci, const double *v, double eta, int block,
+                                 int device, int *is_psd, double *theta, double *x, double *lambda_min) {
+  DCORA_TRY
+  bool psd = false;
+  std::vector<double> vec;
+  double th = 0, lm = 0;
+  long mv = 0;
+  const int rc = device_fast_verification(view_csr(k, rp, ci, v), eta, block, device, &psd, &th, &vec, &lm, &mv);
+  *is_psd = psd ? 1 : 0;
+  if (!psd) {
+    if (theta) *theta = th;
+    if (lambda_min) *lambda_min = lm;
+    if (x && (int)vec.size() == k) std::copy(vec.begin(), vec.end(), x);
+  }
+  return rc;
+  DCORA_CATCH
+}
+
+// ---- data feed ------------------------------------------------------------------------------------------------
+int dcora_dataset_load_g2o(const char *path, dcora_dataset_t *out) {
+  DCORA_TRY
+  dcora_dataset_s *h = new dcora_dataset_s;
+  std::string err;
+  if (!load_g2o(path, h->ds, err)) {
+    delete h;
+    set_last_error(err);
+    return DCORA_ERR_IO;
+  }
+  *out = h;
+  return DCORA_OK;
+  DCORA_CATCH
+}
+int dcora_dataset_create(int d, int n, int m, const int *ids, const double *vals, dcora_dataset_t *out) {
+  if ((d != 2 && d != 3) || n < 1 || m < 0 || !out) return bad("bad dataset shape");
+  DCORA_TRY
+  dcora_dataset_s *h = new dcora_dataset_s;
+  h->ds.d = d;
+  h->ds.n = n;
+  h->ds.meas = view_meas(d, m, ids, vals);
+  *out = h;
+  return DCORA_OK;
+  DCORA_CATCH
+}
+int dcora_dataset_info(dcora_dataset_t ds, int *d, int *n, int *m) {
+  if (!ds) return bad("null");
+  *d = ds->ds.d;
+  *n = ds->ds.n;
+  *m = (int)ds->ds.meas.size();
+  return DCORA_OK;
+}
+int dcora_dataset_copy(dcora_dataset_t h, int *ids, double *vals) {
+  if (!h) return bad("null");
+  const int d = h->ds.d, stride = d * d + d + 3;
+  for (size_t k = 0; k < h->ds.meas.size(); ++k) {
+    const PoseMeas &e = h->ds.meas[k];
+    ids[4 * k] = e.r1;
+    ids[4 * k + 1] = e.p1;
+    ids[4 * k + 2] = e.r2;
+    ids[4 * k + 3] = e.p2;
+    double *q = vals + k * stride;
+    for (int i = 0; i < d * d; ++i) q[i] = e.R[i];
+    for (int i = 0; i < d; ++i) q[d * d + i] = e.t[i];
+    q[d * d + d] = e.kappa;
+    q[d * d + d + 1] = e.tau;
+    q[d * d + d + 2] = e.weight;
+  }
+  return DCORA_OK;
+}
+int dcora_dataset_destroy(dcora_dataset_t ds) {
+  delete ds;
+  return DCORA_OK;
+}
+int dcora_graph_build_Q_pgo(int d, int n, int agent_id, int m, const int *ids, const double *vals, dcora_csr_t *Q) {
+  DCORA_TRY
+  dcora_csr_s *h = new dcora_csr_s;
+  h->m = build_Q_pgo(d, n, agent_id, view_meas(d, m, ids, vals));
+  *Q = h;
+  return DCORA_OK;
+  DCORA_CATCH
+}
+
+// ---- RBCD session -----------------------------------------------------------------------------------------------
+void dcora_rbcd_options_default(dcora_rbcd_options *o) {
+  o->num_robots = 5;
+  o->r = 5;
+  o->acceleration = 1;
+  o->restart_interval = 30;
+  dcora_ropt_params_default(&o->local);
+  o->rank = 0;
+  o->world_size = 1;
+  o->device = 0;
+}
+int dcora_rbcd_create(dcora_dataset_t ds, const dcora_rbcd_options *opt, dcora_rbcd_t *out) {
+  if (!ds || !opt || !out) return bad("null argument");
+  DCORA_TRY
+  dcora_rbcd_s *h = new dcora_rbcd_s;
+  const int rc = h->s.init(ds->ds, *opt);
+  if (rc) {
+    delete h;
+    return rc;
+  }
+  *out = h;
+  return DCORA_OK;
+  DCORA_CATCH
+}
+int dcora_rbcd_destroy(dcora_rbcd_t s) {
+  delete s;
+  return DCORA_OK;
+}
+int dcora_rbcd_set_X(dcora_rbcd_t s, const double *X) { return s ? s->s.set_X(X) : bad("null"); }
+int dcora_rbcd_get_X(dcora_rbcd_t s, double *X) { return s ? s->s.get_X(X) : bad("null"); }
+int dcora_rbcd_iterate(dcora_rbcd_t s, int selected, double *cost2, double *gradnorm, double *block_norms,
+                       int *next_selected) {
+  if (!s) return bad("null");
+  DCORA_TRY
+  return s->s.iterate(selected, cost2, gradnorm, block_norms, next_selected);
+  DCORA_CATCH
+}
+int dcora_rbcd_run(dcora_rbcd_t s, int max_iters, double rgrad_tol, int *iters_done, double *cost2_trace,
+                   double *gradnorm_trace, int *selected_trace) {
+  if (!s) return bad("null");
+  DCORA_TRY
+  int selected = 0, it = 0;
+  for (; it < max_iters; ++it) {
+    double c2 = 0, gn = 0;
+    int nxt = selected;
+    const int rc = s->s.iterate(selected, &c2, &gn, nullptr, &nxt);
+    if (rc) return rc;
+    if (cost2_trace) cost2_trace[it] = c2;
+    if (gradnorm_trace) gradnorm_trace[it] = gn;
+    if (selected_trace) selected_trace[it] = selected;
+    if (gn < rgrad_tol) {
+      ++it;
+      break;
+    }
+    selected = nxt;
+  }
+  if (iters_done) *iters_done = it;
+  return DCORA_OK;
+  DCORA_CATCH
+}
+int dcora_rbcd_last_result(dcora_rbcd_t s, dcora_ropt_result *res) {
+  if (!s || !res) return bad("null");
+  *res = s->s.last;
+  return DCORA_OK;
+}
+int dcora_rbcd_X_device_ptr(dcora_rbcd_t s, double **X_dev) {
+  if (!s) return bad("null");
+  *X_dev = s->s.Xg.p;
+  return DCORA_OK;
+}
+int dcora_rbcd_public_count(dcora_rbcd_t s, int agent, int *count) {
+  if (!s || agent < 0 || agent >= s->s.R) return bad("bad agent");
+  *count = (int)s->s.agents[agent].public_poses.size();
+  return DCORA_OK;
+}
+int dcora_rbcd_public_indices(dcora_rbcd_t s, int agent, int *idx) {
+  if (!s || agent < 0 || agent >= s->s.R) return bad("bad agent");
+  const auto &v = s->s.agents[agent].public_poses;
+  std::copy(v.begin(), v.end(), idx);
+  return DCORA_OK;
+}
+int dcora_rbcd_pack_public_dev(dcora_rbcd_t s, int agent, double *packed_dev) {
+  if (!s || agent < 0 || agent >= s->s.R) return bad("bad agent");
+  return s->s.pack_public(agent, packed_dev);
+}
+int dcora_rbcd_unpack_public_dev(dcora_rbcd_t s, int agent, const double *packed_dev) {
+  if (!s || agent < 0 || agent >= s->s.R) return bad("bad agent");
+  return s->s.unpack_public(agent, packed_dev);
+}
+int dcora_rbcd_phase_nonselected(dcora_rbcd_t s, int selected) { return s ? s->s.phase_nonselected(selected) : bad("null"); }
+int dcora_rbcd_phase_selected(dcora_rbcd_t s, int selected) {
+  if (!s) return bad("null");
+  DCORA_TRY
+  return s->s.phase_selected(selected);
+  DCORA_CATCH
+}
+int dcora_rbcd_phase_evaluate_dev(dcora_rbcd_t s, double *out_dev) { return s ? s->s.phase_evaluate_dev(out_dev) : bad("null"); }
+int dcora_rbcd_synchronize(dcora_rbcd_t s) {
+  if (!s) return bad("null");
+  DCORA_HIP(hipStreamSynchronize(s->s.st));
+  return DCORA_OK;
+}
+
+}  // extern "C"

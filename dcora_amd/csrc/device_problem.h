@@ -1,0 +1,146 @@
+// QuadraticProblem + QuadraticOptimizer on the device: owns Q, G, the preconditioner and the solver workspace
+// in HBM, and drives the RTR / tCG kernel sequence on one HIP stream
+// (replaces src/QuadraticProblem.cpp and src/QuadraticOptimizer.cpp of the reference).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/dcora_hip.h"
+#include "host_sparse.h"
+#include "kernels.h"
+
+namespace dcora {
+
+void set_last_error(const std::string &s);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+#define DCORA_HIP(call)                                                        \
+  do {                                                                         \
+    hipError_t e_ = (call);                                                    \
+    if (e_ != hipSuccess) return ::dcora::hip_fail(e_, #call, __FILE__, __LINE__); \
+  } while (0)
+
+template <class T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) {
+    o.p = nullptr;
+    o.n = 0;
+  }
+  DevBuf &operator=(DevBuf &&o) noexcept {
+    if (this != &o) {
+      release();
+      p = o.p;
+      n = o.n;
+      o.p = nullptr;
+      o.n = 0;
+    }
+    return *this;
+  }
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  hipError_t alloc(size_t count) {
+    release();
+    n = count;
+    if (count == 0) return hipSuccess;
+    return hipMalloc((void **)&p, count * sizeof(T));
+  }
+};
+
+struct DevCsr {
+  int nrows = 0, ncols = 0, nnz = 0;
+  DevBuf<int> rp, ci;
+  DevBuf<double> v;
+  int upload(const HostCsr &A);
+  int upload(int nrows, int ncols, const int *rp, const int *ci, const double *v);
+  CsrDev view() const {
+    CsrDev c;
+    c.nrows = nrows;
+    c.nnz = nnz;
+    c.rp = rp.p;
+    c.ci = ci.p;
+    c.v = v.p;
+    return c;
+  }
+};
+
+class DeviceProblem {
+ public:
+  ManiDesc m{};
+  int device = 0;
+  hipStream_t st = nullptr;
+  bool own_stream = false;
+  DevCsr Q;
+  DevBuf<double> G;     // r x k (always allocated; zero when the problem has no linear term)
+  bool has_G = false;
+  DevBuf<double> Minv;  // k x ldm dense inverse of Q + reg I
+  int ldm = 0;
+  bool has_precond = false;
+  double precond_setup_ms = 0;
+  long precond_nnzL = 0;
+
+  // solver workspace
+  DevBuf<double> X0, X1, EG0, EG1, RG0, RG1, S0, S1;
+  DevBuf<double> delta, eta, Heta, res, z, Hd, W, Zt;
+  DevBuf<double> pA, pB, pC, p1, p2, p3, scal;
+  DevBuf<SolverCtl> ctl;
+  HostFlags *hf = nullptr;      // host-mapped
+  HostFlags *hf_dev = nullptr;  // device view of the same words
+  std::vector<double> stage;    // pageable staging for host <-> device copies
+
+  long nelem() const { return (long)m.r * m.k; }
+  Buf2 Xb() const { return Buf2{{X0.p, X1.p}}; }
+  Buf2 EGb() const { return Buf2{{EG0.p, EG1.p}}; }
+  Buf2 RGb() const { return Buf2{{RG0.p, RG1.p}}; }
+  Buf2 Sb() const { return Buf2{{S0.p, S1.p}}; }
+
+  ~DeviceProblem();
+  // Q as host CSR; G host (may be null); reg < 0 => no preconditioner; stream may be shared (null => own)
+  int init(const dcora_dims &dims, const HostCsr &Qh, const double *Gh, double reg, int device_, hipStream_t shared);
+  int set_G_host(const double *Gh);
+  int build_preconditioner(const HostCsr &Qh, double reg);
+
+  // ---- device-level building blocks (all enqueue on st, no sync) ----
+  // EG = X Q + G, partials pA (npA slots of 2)
+  int npA() const { return spmm_grid(m.k, m.r); }
+  int npPose() const { return pose_grid(m); }
+  int npVec() const { return vec_grid(nelem()); }
+  void enqueue_egrad(const double *X, double *EG, double *partials);
+  void enqueue_precond(const double *X, const double *V, double *out);  // out = Proj_X(V Minv)
+
+  // ---- host-pointer API (upload, run, download, sync) ----
+  int cost(const double *Xh, double *f);
+  int eucgrad(const double *Xh, double *out);
+  int riegrad(const double *Xh, double *out, double *norm);
+  int hessvec(const double *Xh, const double *Vh, double *out);
+  int precondition(const double *Xh, const double *Vh, double *out);
+  int retract(const double *Xh, const double *Vh, double *out);
+  int tangent_project(const double *Xh, const double *Vh, double *out);
+  int optimize(const dcora_ropt_params &prm, const double *X0h, double *Xout, dcora_ropt_result *res);
+  int escape_saddle(const double *Xopt, double theta, const double *v, double gtol, double pgtol, double *Xout,
+                    int *success);
+
+  // ---- device-resident solve: X0.p holds the start point; on return *Xres points at the result buffer ----
+  int optimize_dev(const dcora_ropt_params &prm, dcora_ropt_result *res, double **Xres);
+  // scalars of an arbitrary point on device: f and |rgrad| (synchronises)
+  int eval_dev(const double *Xd, double *f, double *gradnorm);
+
+  int time_qapply(int reps, double *avg_ms, double *bytes);
+
+ private:
+  int rtr_dev(const dcora_ropt_params &prm, dcora_ropt_result *res, double **Xres);
+  int rgd_dev(const dcora_ropt_params &prm, dcora_ropt_result *res, double **Xres);
+  int upload(const double *h, double *d, size_t n);
+  int download(const double *d, double *h, size_t n);
+};
+
+}  // namespace dcora

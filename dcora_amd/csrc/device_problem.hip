@@ -1,0 +1,504 @@
+// DeviceProblem: QuadraticProblem / QuadraticOptimizer on the MI355X (see device_problem.h).
+#include "device_problem.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+
+namespace dcora {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string &s) { g_last_error = s; }
+const std::string &get_last_error() { return g_last_error; }
+int hip_fail(hipError_t e, const char *what, const char *file, int line) {
+  char buf[512];
+  std::snprintf(buf, sizeof buf, "HIP error %d (%s) at %s:%d in %s", (int)e, hipGetErrorString(e), file, line, what);
+  set_last_error(buf);
+  return (e == hipErrorNoDevice || e == hipErrorInvalidDevice) ? DCORA_ERR_NO_DEVICE : DCORA_ERR_HIP;
+}
+
+int DevCsr::upload(int nr, int nc, const int *rph, const int *cih, const double *vh) {
+  nrows = nr;
+  ncols = nc;
+  nnz = rph[nr];
+  DCORA_HIP(rp.alloc(nr + 1));
+  DCORA_HIP(ci.alloc(std::max(nnz, 1)));
+  DCORA_HIP(v.alloc(std::max(nnz, 1)));
+  DCORA_HIP(hipMemcpy(rp.p, rph, sizeof(int) * (nr + 1), hipMemcpyHostToDevice));
+  if (nnz) {
+    DCORA_HIP(hipMemcpy(ci.p, cih, sizeof(int) * nnz, hipMemcpyHostToDevice));
+    DCORA_HIP(hipMemcpy(v.p, vh, sizeof(double) * nnz, hipMemcpyHostToDevice));
+  }
+  return DCORA_OK;
+}
+int DevCsr::upload(const HostCsr &A) { return upload(A.n, A.ncols, A.rp.data(), A.ci.data(), A.v.data()); }
+
+DeviceProblem::~DeviceProblem() {
+  if (hf) (void)hipHostFree((void *)hf);
+  if (own_stream && st) (void)hipStreamDestroy(st);
+}
+
+int DeviceProblem::upload(const double *h, double *d, size_t n) {
+  DCORA_HIP(hipMemcpyAsync(d, h, n * sizeof(double), hipMemcpyHostToDevice, st));
+  return DCORA_OK;
+}
+int DeviceProblem::download(const double *d, double *h, size_t n) {
+  DCORA_HIP(hipMemcpyAsync(h, d, n * sizeof(double), hipMemcpyDeviceToHost, st));
+  DCORA_HIP(hipStreamSynchronize(st));
+  return DCORA_OK;
+}
+
+int DeviceProblem::init(const dcora_dims &dims, const HostCsr &Qh, const double *Gh, double reg, int device_,
+                        hipStream_t shared) {
+  if (dims.r < 1 || dims.r > 16 || (dims.d != 2 && dims.d != 3) || dims.n < 0 || dims.l < 0 || dims.b < 0) {
+    set_last_error("bad dims (need 1 <= r <= 16, d in {2,3})");
+    return DCORA_ERR_BAD_ARG;
+  }
+  m = make_mani(dims.r, dims.d, dims.n, dims.l, dims.b);
+  if (Qh.n != m.k) {
+    set_last_error("Q dimension does not match (d+1) n + l + b");
+    return DCORA_ERR_BAD_ARG;
+  }
+  device = device_;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    set_last_error("no HIP device available: libdcora_hip has no CPU fallback");
+    return DCORA_ERR_NO_DEVICE;
+  }
+  DCORA_HIP(hipSetDevice(device));
+  if (shared) {
+    st = shared;
+    own_stream = false;
+  } else {
+    DCORA_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    own_stream = true;
+  }
+  int rc = Q.upload(Qh);
+  if (rc) return rc;
+  const size_t N = (size_t)nelem();
+  const size_t NS = (size_t)m.n * m.d * m.d + m.l + 1;
+  DCORA_HIP(G.alloc(N));
+  DCORA_HIP(hipMemset(G.p, 0, N * sizeof(double)));
+  for (DevBuf<double> *b : {&X0, &X1, &EG0, &EG1, &RG0, &RG1, &delta, &eta, &Heta, &res, &z, &Hd, &W, &Zt})
+    DCORA_HIP(b->alloc(N));
+  DCORA_HIP(S0.alloc(NS));
+  DCORA_HIP(S1.alloc(NS));
+  for (DevBuf<double> *b : {&pA, &pB, &pC, &p1, &p2, &p3}) DCORA_HIP(b->alloc(2 * kMaxPartials));
+  DCORA_HIP(scal.alloc(64));
+  DCORA_HIP(ctl.alloc(1));
+  DCORA_HIP(hipHostMalloc((void **)&hf, sizeof(HostFlags), hipHostMallocMapped));
+  std::memset((void *)hf, 0, sizeof(HostFlags));
+  DCORA_HIP(hipHostGetDevicePointer((void **)&hf_dev, (void *)hf, 0));
+  if (Gh) {
+    rc = set_G_host(Gh);
+    if (rc) return rc;
+  }
+  if (reg >= 0) {
+    rc = build_preconditioner(Qh, reg);
+    if (rc) return rc;
+  }
+  return DCORA_OK;
+}
+
+int DeviceProblem::set_G_host(const double *Gh) {
+  DCORA_HIP(hipSetDevice(device));
+  if (Gh) {
+    DCORA_HIP(hipMemcpy(G.p, Gh, (size_t)nelem() * sizeof(double), hipMemcpyHostToDevice));
+    has_G = true;
+  } else {
+    DCORA_HIP(hipMemset(G.p, 0, (size_t)nelem() * sizeof(double)));
+    has_G = false;
+  }
+  return DCORA_OK;
+}
+
+// (Q + reg I)^-1 as a dense symmetric matrix in HBM: host sparse Cholesky once per Q (Q is reused across all
+// RBCD iterations and staircase levels), k independent solves on host threads, one upload.
+int DeviceProblem::build_preconditioner(const HostCsr &Qh, double reg) {
+  const auto t0 = std::chrono::steady_clock::now();
+  const int k = m.k;
+  if ((size_t)k > 60000) {
+    set_last_error("dense preconditioner limited to k <= 60000 in this build");
+    return DCORA_ERR_UNSUPPORTED;
+  }
+  HostCsr M = csr_shift_diag(Qh, reg);
+  SparseChol chol;
+  if (!chol.factor(M, m.se ? m.d + 1 : 1)) {
+    set_last_error("preconditioner: Q + reg I is not positive definite");
+    return DCORA_ERR_NOT_PD;
+  }
+  precond_nnzL = chol.nnzL();
+  ldm = ((k + 15) / 16) * 16;
+  std::vector<double> inv((size_t)k * ldm, 0.0);
+  unsigned hw = std::thread::hardware_concurrency();
+  chol.dense_inverse(inv.data(), (size_t)ldm, (int)std::max(1u, std::min(hw, 32u)));
+  DCORA_HIP(hipSetDevice(device));
+  DCORA_HIP(Minv.alloc((size_t)k * ldm + 16));
+  DCORA_HIP(hipMemcpy(Minv.p, inv.data(), (size_t)k * ldm * sizeof(double), hipMemcpyHostToDevice));
+  has_precond = true;
+  precond_setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return DCORA_OK;
+}
+
+void DeviceProblem::enqueue_egrad(const double *X, double *EG, double *partials) {
+  launch_spmm(st, m.r, Q.view(), buf1(X), 0, has_G ? G.p : nullptr, buf1(EG), 0, partials, Gate{});
+}
+
+void DeviceProblem::enqueue_precond(const double *X, const double *V, double *out) {
+  launch_dense_apply(st, m.r, m.k, ldm, Minv.p, buf1(V), Zt.p, nullptr, 0, Gate{});
+  launch_tangent(st, m, buf1(X), Zt.p, out, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host-pointer API
+// ---------------------------------------------------------------------------------------------------------
+int DeviceProblem::cost(const double *Xh, double *f) {
+  DCORA_HIP(hipSetDevice(device));
+  int rc = upload(Xh, X0.p, nelem());
+  if (rc) return rc;
+  enqueue_egrad(X0.p, EG0.p, pA.p);
+  launch_sum_partials(st, pA.p, npA(), 2, 2, scal.p);
+  double s[2];
+  rc = download(scal.p, s, 2);
+  if (rc) return rc;
+  *f = 0.5 * s[0] + s[1];
+  return DCORA_OK;
+}
+int DeviceProblem::eucgrad(const double *Xh, double *out) {
+  DCORA_HIP(hipSetDevice(device));
+  int rc = upload(Xh, X0.p, nelem());
+  if (rc) return rc;
+  enqueue_egrad(X0.p, EG0.p, nullptr);
+  return download(EG0.p, out, nelem());
+}
+int DeviceProblem::riegrad(const double *Xh, double *out, double *norm) {
+  DCORA_HIP(hipSetDevice(device));
+  int rc = upload(Xh, X0.p, nelem());
+  if (rc) return rc;
+  enqueue_egrad(X0.p, EG0.p, nullptr);
+  launch_rgrad(st, m, buf1(X0.p), buf1(EG0.p), buf1(RG0.p), buf1(S0.p), 0, pB.p, Gate{});
+  launch_sum_partials(st, pB.p, npPose(), 1, 1, scal.p);
+  double s;
+  rc = download(scal.p, &s, 1);
+  if (rc) return rc;
+  if (norm) *norm = std::sqrt(s);
+  if (out) return download(RG0.p, out, nelem());
+  return DCORA_OK;
+}
+int DeviceProblem::hessvec(const double *Xh, const double *Vh, double *out) {
+  DCORA_HIP(hipSetDevice(device));
+  int rc = upload(Xh, X0.p, nelem());
+  if (rc) return rc;
+  rc = upload(Vh, delta.p, nelem());
+  if (rc) return rc;
+  enqueue_egrad(X0.p, EG0.p, nullptr);
+  launch_rgrad(st, m, buf1(X0.p), buf1(EG0.p), buf1(RG0.p), buf1(S0.p), 0, pB.p, Gate{});
+  launch_spmm(st, m.r, Q.view(), buf1(delta.p), 0, nullptr, buf1(W.p), 0, nullptr, Gate{});
+  launch_hessfix(st, m, buf1(X0.p), buf1(S0.p), delta.p, W.p, Hd.p, p1.p, Gate{});
+  return download(Hd.p, out, nelem());
+}
+int DeviceProblem::precondition(const double *Xh, const double *Vh, double *out) {
+  if (!has_precond) {
+    set_last_error("problem has no preconditioner");
+    return DCORA_ERR_NO_PRECONDITIONER;
+  }
+  DCORA_HIP(hipSetDevice(device));
+  int rc = upload(Xh, X0.p, nelem());
+  if (rc) return rc;
+  rc = upload(Vh, res.p, nelem());
+  if (rc) return rc;
+  enqueue_precond(X0.p, res.p, z.p);
+  return download(z.p, out, nelem());
+}
+int DeviceProblem::retract(const double *Xh, const double *Vh, double *out) {
+  DCORA_HIP(hipSetDevice(device));
+  int rc = upload(Xh, X0.p, nelem());
+  if (rc) return rc;
+  rc = upload(Vh, eta.p, nelem());
+  if (rc) return rc;
+  launch_retract(st, m, buf1(X0.p), eta.p, 1.0, buf1(X1.p), 0, buf1(RG0.p), nullptr, nullptr, Gate{});
+  return download(X1.p, out, nelem());
+}
+int DeviceProblem::tangent_project(const double *Xh, const double *Vh, double *out) {
+  DCORA_HIP(hipSetDevice(device));
+  int rc = upload(Xh, X0.p, nelem());
+  if (rc) return rc;
+  rc = upload(Vh, eta.p, nelem());
+  if (rc) return rc;
+  launch_tangent(st, m, buf1(X0.p), eta.p, z.p, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0);
+  return download(z.p, out, nelem());
+}
+
+int DeviceProblem::eval_dev(const double *Xd, double *f, double *gradnorm) {
+  enqueue_egrad(Xd, EG1.p, pA.p);
+  launch_rgrad(st, m, buf1(Xd), buf1(EG1.p), Buf2{{nullptr, nullptr}}, Buf2{{nullptr, nullptr}}, 0, pB.p, Gate{});
+  launch_sum_partials(st, pA.p, npA(), 2, 2, scal.p);
+  launch_sum_partials(st, pB.p, npPose(), 1, 1, scal.p + 2);
+  double s[3];
+  int rc = download(scal.p, s, 3);
+  if (rc) return rc;
+  if (f) *f = 0.5 * s[0] + s[1];
+  if (gradnorm) *gradnorm = std::sqrt(s[2]);
+  return DCORA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// QuadraticOptimizer::optimize
+// ---------------------------------------------------------------------------------------------------------
+int DeviceProblem::optimize(const dcora_ropt_params &prm, const double *X0h, double *Xout, dcora_ropt_result *res_out) {
+  DCORA_HIP(hipSetDevice(device));
+  int rc = upload(X0h, X0.p, nelem());
+  if (rc) return rc;
+  double *Xres = nullptr;
+  dcora_ropt_result r{};
+  rc = optimize_dev(prm, &r, &Xres);
+  if (rc) return rc;
+  if (res_out) *res_out = r;
+  return download(Xres, Xout, nelem());
+}
+
+int DeviceProblem::optimize_dev(const dcora_ropt_params &prm, dcora_ropt_result *res_out, double **Xres) {
+  if (prm.method == 0) return rtr_dev(prm, res_out, Xres);
+  return rgd_dev(prm, res_out, Xres);
+}
+
+// one preconditioned Riemannian gradient step (ref src/QuadraticOptimizer.cpp:123-150)
+int DeviceProblem::rgd_dev(const dcora_ropt_params &prm, dcora_ropt_result *res_out, double **Xres) {
+  const auto t0 = std::chrono::steady_clock::now();
+  double f0 = 0, g0 = 0;
+  int rc = eval_dev(X0.p, &f0, &g0);
+  if (rc) return rc;
+  enqueue_egrad(X0.p, EG0.p, nullptr);
+  launch_rgrad(st, m, buf1(X0.p), buf1(EG0.p), buf1(RG0.p), buf1(S0.p), 0, pB.p, Gate{});
+  const double *dir = RG0.p;
+  if (prm.RGD_use_preconditioner) {
+    if (!has_precond) {
+      set_last_error("RGD with preconditioning requested but the problem has none");
+      return DCORA_ERR_NO_PRECONDITIONER;
+    }
+    enqueue_precond(X0.p, RG0.p, z.p);
+    dir = z.p;
+  }
+  launch_retract(st, m, buf1(X0.p), dir, -prm.RGD_stepsize, buf1(X1.p), 0, buf1(RG0.p), nullptr, nullptr, Gate{});
+  double f1 = 0, g1 = 0;
+  rc = eval_dev(X1.p, &f1, &g1);
+  if (rc) return rc;
+  if (res_out) {
+    res_out->success = 1;
+    res_out->fInit = f0;
+    res_out->gradNormInit = g0;
+    res_out->fOpt = f1;
+    res_out->gradNormOpt = g1;
+    res_out->elapsedMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    res_out->tCGStatus = 4;
+    res_out->outer_iterations = 1;
+    res_out->inner_iterations = 0;
+    res_out->accepted_steps = 1;
+  }
+  *Xres = X1.p;
+  return DCORA_OK;
+}
+
+namespace {
+// spin on host-mapped words; never blocks inside the HIP runtime
+template <class Pred>
+bool spin_until(Pred p, double timeout_s) {
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned it = 0;
+  while (!p()) {
+    if ((++it & 1023u) == 0) {
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return false;
+    }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+  return true;
+}
+}  // namespace
+
+// RTRNewton with preconditioned Steihaug-Toint tCG, fully device-resident: the host enqueues the kernel
+// sequence, stays at most kLookahead tCG iterations ahead of the GPU and learns about terminations from
+// host-mapped flags.  (ref src/QuadraticOptimizer.cpp:52-108, 234-280; ROPTLIB semantics: SURVEY.md 3.4)
+int DeviceProblem::rtr_dev(const dcora_ropt_params &prm, dcora_ropt_result *res_out, double **Xres) {
+  if (!has_precond) {
+    set_last_error("RTR requires the preconditioner (ref src/QuadraticProblem.cpp:78-82)");
+    return DCORA_ERR_NO_PRECONDITIONER;
+  }
+  constexpr int kLookahead = 2;
+  const auto t0 = std::chrono::steady_clock::now();
+  const bool single = (prm.RTR_iterations == 1);
+  SolverCtl h;
+  std::memset(&h, 0, sizeof h);
+  h.tol = prm.gradnorm_tol;
+  h.Delta = prm.RTR_initial_radius;
+  h.maxDelta = single ? prm.RTR_initial_radius : 5 * prm.RTR_initial_radius;  // :240-241, :259-260
+  h.max_outer = single ? 12 : prm.RTR_iterations;                              // :254-273 (<= 11 retries)
+  h.stop_on_accept = single ? 1 : 0;
+  h.max_inner = prm.RTR_tCG_iterations;
+  h.outer_done_stamp = INT_MAX;
+  h.tcg_done_stamp = INT_MAX;
+  h.tcg_status = 4;
+  DCORA_HIP(hipMemcpyAsync(ctl.p, &h, sizeof h, hipMemcpyHostToDevice, st));
+  DCORA_HIP(hipStreamSynchronize(st));  // h lives on this stack frame
+  hf->last_seq_done = 0;
+  hf->tcg_done_seq = 0;
+  hf->outer_done_seq = 0;
+  SolverCtl *c = ctl.p;
+  const long N = nelem();
+  const CsrDev Qv = Q.view();
+  const double *Gp = has_G ? G.p : nullptr;
+  const int nA = npA(), nP = npPose(), nV = npVec();
+  int seq = 0;
+  auto timed_out = [&]() {
+    set_last_error("rtr_dev: device did not make progress (spin timeout)");
+    return DCORA_ERR_HIP;
+  };
+
+  // f(x0), grad(x0)
+  launch_spmm(st, m.r, Qv, Xb(), 0, Gp, EGb(), 0, pA.p, Gate{c, ++seq, 0});
+  launch_rgrad(st, m, Xb(), EGb(), RGb(), Sb(), 0, pB.p, Gate{c, ++seq, 0});
+  launch_rtr_init(st, pA.p, nA, pB.p, nP, c, hf_dev, ++seq);
+  int last_pace_seq = seq;
+
+  std::vector<int> upd2_seq((size_t)std::max(1, h.max_inner));
+  for (int outer = 0; outer < h.max_outer; ++outer) {
+    // wait for the previous decision (rtr_init / rtr_decide) before committing to another outer iteration
+    if (!spin_until([&] { return hf->last_seq_done >= last_pace_seq || hf->outer_done_seq != 0; }, 20.0))
+      return timed_out();
+    if (hf->outer_done_seq != 0) break;
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0) break;  // TimeBound :252
+
+    // ---- tCG ----
+    launch_tcg_begin(st, N, RGb(), eta.p, Heta.p, res.p, c, ++seq);
+    const int tcg_first_seq = seq;
+    launch_dense_apply(st, m.r, m.k, ldm, Minv.p, buf1(res.p), Zt.p, nullptr, 0, Gate{c, ++seq, 1});
+    launch_tangent(st, m, Xb(), Zt.p, z.p, res.p, p3.p, nullptr, 0, c, hf_dev, ++seq, 1, 0);
+    launch_tcg_init(st, N, z.p, p3.p, nP, delta.p, c, ++seq);
+    for (int j = 0; j < h.max_inner; ++j) {
+      if (j >= kLookahead) {
+        const int need = upd2_seq[j - kLookahead];
+        if (!spin_until(
+                [&] {
+                  return hf->last_seq_done >= need || hf->tcg_done_seq >= tcg_first_seq || hf->outer_done_seq != 0;
+                },
+                20.0))
+          return timed_out();
+      }
+      if (hf->tcg_done_seq >= tcg_first_seq) break;
+      launch_spmm(st, m.r, Qv, buf1(delta.p), 0, nullptr, buf1(W.p), 0, nullptr, Gate{c, ++seq, 2});
+      launch_hessfix(st, m, Xb(), Sb(), delta.p, W.p, Hd.p, p1.p, Gate{c, ++seq, 2});
+      launch_tcg_update1(st, N, delta.p, Hd.p, eta.p, Heta.p, res.p, p1.p, nP, p2.p, c, hf_dev, ++seq, j);
+      launch_dense_apply(st, m.r, m.k, ldm, Minv.p, buf1(res.p), Zt.p, p2.p, nV, Gate{c, ++seq, 2});
+      launch_tangent(st, m, Xb(), Zt.p, z.p, res.p, p3.p, p2.p, nV, c, hf_dev, ++seq, 2, j);
+      launch_tcg_update2(st, N, z.p, delta.p, p3.p, nP, c, hf_dev, ++seq, j);
+      upd2_seq[j] = seq;
+    }
+    // ---- trial point, model ratio, acceptance ----
+    launch_retract(st, m, Xb(), eta.p, 1.0, Xb(), 1, RGb(), Heta.p, pC.p, Gate{c, ++seq, 1});
+    launch_spmm(st, m.r, Qv, Xb(), 1, Gp, EGb(), 1, pA.p, Gate{c, ++seq, 1});
+    launch_rgrad(st, m, Xb(), EGb(), RGb(), Sb(), 1, pB.p, Gate{c, ++seq, 1});
+    launch_rtr_decide(st, pA.p, nA, pB.p, nP, pC.p, nP, c, hf_dev, ++seq);
+    last_pace_seq = seq;
+  }
+  DCORA_HIP(hipMemcpyAsync(&h, ctl.p, sizeof h, hipMemcpyDeviceToHost, st));
+  DCORA_HIP(hipStreamSynchronize(st));
+  DCORA_HIP(hipGetLastError());
+  *Xres = (h.cur & 1) ? X1.p : X0.p;
+  if (res_out) {
+    res_out->success = 1;
+    res_out->fInit = h.fInit;
+    res_out->gradNormInit = h.gradNormInit;
+    res_out->fOpt = h.f1;
+    res_out->gradNormOpt = h.ngf;
+    res_out->elapsedMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    res_out->tCGStatus = h.tcg_status;
+    res_out->outer_iterations = h.outer_it;
+    res_out->inner_iterations = h.inner_total;
+    res_out->accepted_steps = h.accepted;
+  }
+  return DCORA_OK;
+}
+
+// ref src/QuadraticProblem.cpp:138-234 (rare path, host-paced: one scalar read-back per trial step)
+int DeviceProblem::escape_saddle(const double *Xopt, double theta, const double *v, double gtol, double pgtol,
+                                 double *Xout, int *success) {
+  if (!has_precond) {
+    set_last_error("escapeSaddle needs the preconditioner");
+    return DCORA_ERR_NO_PRECONDITIONER;
+  }
+  DCORA_HIP(hipSetDevice(device));
+  const int r = m.r, k = m.k;
+  std::vector<double> Xp((size_t)r * k, 0.0), Xd((size_t)r * k, 0.0);
+  for (int j = 0; j < k; ++j) {
+    for (int t = 0; t < r - 1; ++t) Xp[(size_t)j * r + t] = Xopt[(size_t)j * (r - 1) + t];
+    Xd[(size_t)j * r + (r - 1)] = v[j];
+  }
+  int rc = upload(Xp.data(), X0.p, nelem());
+  if (rc) return rc;
+  rc = upload(Xd.data(), eta.p, nelem());
+  if (rc) return rc;
+  DCORA_HIP(hipStreamSynchronize(st));
+  double FX = 0;
+  rc = eval_dev(X0.p, &FX, nullptr);
+  if (rc) return rc;
+  const double alpha_min = 1e-6;
+  double alpha = 1.0;  // isSecondOrder = false (header default)
+  (void)theta;
+  std::vector<double> alphas, fvals;
+  *success = 0;
+  while (alpha >= alpha_min) {
+    launch_retract(st, m, buf1(X0.p), eta.p, alpha, buf1(X1.p), 0, buf1(RG0.p), nullptr, nullptr, Gate{});
+    enqueue_egrad(X1.p, EG1.p, pA.p);
+    launch_rgrad(st, m, buf1(X1.p), buf1(EG1.p), buf1(RG1.p), buf1(S1.p), 0, pB.p, Gate{});
+    enqueue_precond(X1.p, RG1.p, z.p);
+    launch_dot(st, nelem(), z.p, z.p, p3.p);
+    launch_sum_partials(st, pA.p, npA(), 2, 2, scal.p);
+    launch_sum_partials(st, pB.p, npPose(), 1, 1, scal.p + 2);
+    launch_sum_partials(st, p3.p, npVec(), 1, 1, scal.p + 3);
+    double s[4];
+    rc = download(scal.p, s, 4);
+    if (rc) return rc;
+    const double FXt = 0.5 * s[0] + s[1], gn = std::sqrt(s[2]), pgn = std::sqrt(s[3]);
+    alphas.push_back(alpha);
+    fvals.push_back(FXt);
+    if (FXt < FX && gn > gtol && pgn > pgtol) {
+      *success = 1;
+      return download(X1.p, Xout, nelem());
+    }
+    alpha /= 2;
+  }
+  const size_t idx = std::min_element(fvals.begin(), fvals.end()) - fvals.begin();
+  if (fvals[idx] < FX) {
+    launch_retract(st, m, buf1(X0.p), eta.p, alphas[idx], buf1(X1.p), 0, buf1(RG0.p), nullptr, nullptr, Gate{});
+    *success = 1;
+    return download(X1.p, Xout, nelem());
+  }
+  return DCORA_OK;
+}
+
+int DeviceProblem::time_qapply(int reps, double *avg_ms, double *bytes) {
+  DCORA_HIP(hipSetDevice(device));
+  hipEvent_t e0, e1;
+  DCORA_HIP(hipEventCreate(&e0));
+  DCORA_HIP(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) enqueue_egrad(X0.p, EG0.p, nullptr);
+  DCORA_HIP(hipEventRecord(e0, st));
+  for (int i = 0; i < reps; ++i) enqueue_egrad(X0.p, EG0.p, nullptr);
+  DCORA_HIP(hipEventRecord(e1, st));
+  DCORA_HIP(hipEventSynchronize(e1));
+  float ms = 0;
+  DCORA_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *avg_ms = (double)ms / reps;
+  // nnz (8+4) + (k+1) 4 + r k 8 (read X) + r k 8 (write Y) [+ r k 8 for G]
+  *bytes = 12.0 * Q.nnz + 4.0 * (m.k + 1) + 16.0 * m.r * m.k + (has_G ? 8.0 * m.r * m.k : 0.0);
+  return DCORA_OK;
+}
+
+}  // namespace dcora

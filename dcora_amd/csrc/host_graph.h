@@ -1,0 +1,42 @@
+// Host-side data feed of the product: measurement list, g2o reader, and direct (closed-form, per-edge block)
+// assembly of the PGO data matrices that the GPU path consumes:
+//   Q   (ref src/Graph.cpp:579-683)     -- connection Laplacian of one agent / of the whole graph
+//   C   (ref src/Graph.cpp:685-822)     -- the coupling blocks: G_b = X_global * C_b, i.e. the linear term of
+//                                          agent b as a sparse product with the neighbours' public poses
+#pragma once
+#include <string>
+#include <vector>
+
+#include "host_sparse.h"
+
+namespace dcora {
+
+// ref include/DCORA/Measurements.h RelativePosePoseMeasurement
+struct PoseMeas {
+  int r1 = 0, p1 = 0, r2 = 0, p2 = 0;
+  double R[9] = {0}, t[3] = {0};
+  double kappa = 0, tau = 0, weight = 1;
+};
+struct HostDataset {
+  int d = 0, n = 0;
+  std::vector<PoseMeas> meas;
+};
+
+bool load_g2o(const std::string &path, HostDataset &out, std::string &err);
+
+// Q of agent `id` over its n local poses from every measurement that touches it
+HostCsr build_Q_pgo(int d, int n, int id, const std::vector<PoseMeas> &meas);
+
+// contiguous partition of the reference driver (ref examples/MultiRobotExample.cpp:56-83)
+struct Partition {
+  int R = 1, n = 0, per = 0;
+  int robot_of(int idx) const { return std::min(idx / per, R - 1); }
+  int start(int rb) const { return rb * per; }
+  int end(int rb) const { return rb == R - 1 ? n : (rb + 1) * per; }
+};
+
+// Coupling matrix of agent b with GLOBAL column indices: rows = (d+1) n_b local columns of G_b, columns =
+// (d+1) n global columns of X.  G_b = X * C_b^T in the SpMM convention Y(:, j) = sum_c A(j, c) X(:, c).
+HostCsr build_coupling_pgo(int d, const Partition &P, int b, const std::vector<PoseMeas> &global_meas);
+
+}  // namespace dcora

@@ -1,0 +1,384 @@
+// Host-side sparse helpers of the product (setup-time only; see host_sparse.h).
+#include "host_sparse.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <queue>
+#include <thread>
+
+namespace dcora {
+
+HostCsr csr_from_coo(int nrows, int ncols, const std::vector<int> &I, const std::vector<int> &J,
+                     const std::vector<double> &V) {
+  HostCsr A;
+  A.n = nrows;
+  A.ncols = ncols;
+  const size_t m = I.size();
+  std::vector<int> cnt(nrows + 1, 0);
+  for (size_t e = 0; e < m; ++e) cnt[I[e] + 1]++;
+  for (int i = 0; i < nrows; ++i) cnt[i + 1] += cnt[i];
+  std::vector<size_t> order(m);
+  {
+    std::vector<int> pos(cnt.begin(), cnt.end() - 1);
+    for (size_t e = 0; e < m; ++e) order[pos[I[e]]++] = e;
+  }
+  A.rp.assign(nrows + 1, 0);
+  A.ci.reserve(m);
+  A.v.reserve(m);
+  std::vector<std::pair<int, double>> row;
+  for (int i = 0; i < nrows; ++i) {
+    row.clear();
+    for (int p = cnt[i]; p < cnt[i + 1]; ++p) row.emplace_back(J[order[p]], V[order[p]]);
+    std::stable_sort(row.begin(), row.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+    for (size_t q = 0; q < row.size();) {
+      const int c = row[q].first;
+      double s = 0;
+      while (q < row.size() && row[q].first == c) s += row[q++].second;
+      A.ci.push_back(c);
+      A.v.push_back(s);
+    }
+    A.rp[i + 1] = (int)A.ci.size();
+  }
+  return A;
+}
+
+HostCsr csr_shift_diag(const HostCsr &A, double s) {
+  HostCsr B;
+  B.n = A.n;
+  B.ncols = A.ncols;
+  B.rp.assign(A.n + 1, 0);
+  for (int i = 0; i < A.n; ++i) {
+    bool seen = false;
+    for (int p = A.rp[i]; p < A.rp[i + 1]; ++p) {
+      const int c = A.ci[p];
+      if (!seen && c > i) {
+        B.ci.push_back(i);
+        B.v.push_back(s);
+        seen = true;
+      }
+      B.ci.push_back(c);
+      B.v.push_back(A.v[p] + ((c == i) ? s : 0.0));
+      if (c == i) seen = true;
+    }
+    if (!seen) {
+      B.ci.push_back(i);
+      B.v.push_back(s);
+    }
+    B.rp[i + 1] = (int)B.ci.size();
+  }
+  return B;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Ordering: automatic nested dissection on the block-compressed graph.  Separators are the middle level of
+// a BFS level structure rooted at a pseudo-peripheral node (George); leaves are ordered by a cheap local
+// minimum-degree pass.  Produces shallow elimination trees, which is what a level-scheduled device
+// triangular solve will want ("next").
+// ---------------------------------------------------------------------------------------------------
+namespace {
+struct NDGraph {
+  int nb;
+  std::vector<int> xadj, adj;
+};
+
+void bfs_levels(const NDGraph &G, const std::vector<int> &comp_id, int cid, int root, std::vector<int> &level,
+                std::vector<int> &order) {
+  order.clear();
+  order.push_back(root);
+  level[root] = 0;
+  for (size_t h = 0; h < order.size(); ++h) {
+    const int u = order[h];
+    for (int p = G.xadj[u]; p < G.xadj[u + 1]; ++p) {
+      const int w = G.adj[p];
+      if (comp_id[w] == cid && level[w] < 0) {
+        level[w] = level[u] + 1;
+        order.push_back(w);
+      }
+    }
+  }
+}
+
+void leaf_order(const NDGraph &G, const std::vector<int> &nodes, std::vector<int> &comp_id, int cid,
+                std::vector<int> &out) {
+  // greedy minimum (static) degree inside the leaf; small sets only
+  std::vector<std::pair<int, int>> dn;
+  for (int u : nodes) {
+    int dg = 0;
+    for (int p = G.xadj[u]; p < G.xadj[u + 1]; ++p)
+      if (comp_id[G.adj[p]] == cid) ++dg;
+    dn.emplace_back(dg, u);
+  }
+  std::sort(dn.begin(), dn.end());
+  for (auto &e : dn) out.push_back(e.second);
+}
+
+void nd_recurse(const NDGraph &G, std::vector<int> nodes, std::vector<int> &comp_id, int &next_cid,
+                std::vector<int> &level, std::vector<int> &out) {
+  // iterative worklist: (nodes) ; output order is built back-to-front: separators last
+  struct Item {
+    std::vector<int> nodes;
+  };
+  std::vector<std::vector<int>> stack;
+  std::vector<int> rev;  // reversed elimination order
+  stack.push_back(std::move(nodes));
+  std::vector<int> order;
+  while (!stack.empty()) {
+    std::vector<int> cur = std::move(stack.back());
+    stack.pop_back();
+    if (cur.empty()) continue;
+    const int cid = next_cid++;
+    for (int u : cur) {
+      comp_id[u] = cid;
+      level[u] = -1;
+    }
+    if ((int)cur.size() <= 24) {
+      std::vector<int> lo;
+      leaf_order(G, cur, comp_id, cid, lo);
+      for (auto it = lo.rbegin(); it != lo.rend(); ++it) rev.push_back(*it);
+      for (int u : cur) comp_id[u] = -1;
+      continue;
+    }
+    // pseudo-peripheral root: two BFS sweeps
+    int root = cur[0];
+    bfs_levels(G, comp_id, cid, root, level, order);
+    if (order.size() < cur.size()) {
+      // disconnected: split off the reached component
+      std::vector<int> rest;
+      for (int u : cur)
+        if (level[u] < 0) rest.push_back(u);
+      std::vector<int> reached = order;
+      for (int u : cur) comp_id[u] = -1;
+      stack.push_back(std::move(rest));
+      stack.push_back(std::move(reached));
+      continue;
+    }
+    for (int sweep = 0; sweep < 2; ++sweep) {
+      root = order.back();
+      for (int u : cur) level[u] = -1;
+      bfs_levels(G, comp_id, cid, root, level, order);
+    }
+    const int depth = level[order.back()];
+    if (depth < 2) {
+      std::vector<int> lo;
+      leaf_order(G, cur, comp_id, cid, lo);
+      for (auto it = lo.rbegin(); it != lo.rend(); ++it) rev.push_back(*it);
+      for (int u : cur) comp_id[u] = -1;
+      continue;
+    }
+    // separator = level closest to the median node
+    const int mid = level[order[order.size() / 2]];
+    const int sep_level = std::min(std::max(mid, 1), depth - 1);
+    std::vector<int> left, right;
+    for (int u : order) {
+      if (level[u] == sep_level)
+        rev.push_back(u);  // separators are eliminated last
+      else if (level[u] < sep_level)
+        left.push_back(u);
+      else
+        right.push_back(u);
+    }
+    for (int u : cur) comp_id[u] = -1;
+    stack.push_back(std::move(left));
+    stack.push_back(std::move(right));
+  }
+  for (auto it = rev.rbegin(); it != rev.rend(); ++it) out.push_back(*it);
+}
+}  // namespace
+
+std::vector<int> amd_like_order(const HostCsr &A, int block) {
+  const int n = A.n;
+  if (block < 1) block = 1;
+  const int nb = (n + block - 1) / block;
+  // block graph
+  std::vector<std::vector<int>> nbrs(nb);
+  for (int i = 0; i < n; ++i)
+    for (int p = A.rp[i]; p < A.rp[i + 1]; ++p) {
+      const int a = i / block, b = A.ci[p] / block;
+      if (a != b) nbrs[a].push_back(b);
+    }
+  NDGraph G;
+  G.nb = nb;
+  G.xadj.assign(nb + 1, 0);
+  for (int u = 0; u < nb; ++u) {
+    auto &v = nbrs[u];
+    std::sort(v.begin(), v.end());
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+    G.xadj[u + 1] = G.xadj[u] + (int)v.size();
+  }
+  G.adj.reserve(G.xadj[nb]);
+  for (int u = 0; u < nb; ++u) G.adj.insert(G.adj.end(), nbrs[u].begin(), nbrs[u].end());
+  std::vector<int> comp_id(nb, -1), level(nb, -1), border;
+  std::vector<int> all(nb);
+  std::iota(all.begin(), all.end(), 0);
+  int next_cid = 0;
+  nd_recurse(G, all, comp_id, next_cid, level, border);
+  std::vector<int> perm;
+  perm.reserve(n);
+  for (int bn : border)
+    for (int t = 0; t < block; ++t)
+      if (bn * block + t < n) perm.push_back(bn * block + t);
+  return perm;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Numeric factorisation: up-looking LL^T over the elimination tree
+// ---------------------------------------------------------------------------------------------------
+bool SparseChol::factor(const HostCsr &A, int block) {
+  n_ = A.n;
+  ok_ = false;
+  const int n = n_;
+  perm_ = amd_like_order(A, block);
+  iperm_.assign(n, 0);
+  for (int i = 0; i < n; ++i) iperm_[perm_[i]] = i;
+  // upper triangle of P A P^T by columns
+  std::vector<int> Cp(n + 1, 0);
+  for (int io = 0; io < n; ++io) {
+    const int i = iperm_[io];
+    for (int p = A.rp[io]; p < A.rp[io + 1]; ++p) {
+      const int j = iperm_[A.ci[p]];
+      if (i <= j) Cp[j + 1]++;
+    }
+  }
+  for (int j = 0; j < n; ++j) Cp[j + 1] += Cp[j];
+  std::vector<int> Ci(Cp[n]);
+  std::vector<double> Cx(Cp[n]);
+  {
+    std::vector<int> pos(Cp.begin(), Cp.end() - 1);
+    for (int io = 0; io < n; ++io) {
+      const int i = iperm_[io];
+      for (int p = A.rp[io]; p < A.rp[io + 1]; ++p) {
+        const int j = iperm_[A.ci[p]];
+        if (i <= j) {
+          Ci[pos[j]] = i;
+          Cx[pos[j]++] = A.v[p];
+        }
+      }
+    }
+  }
+  std::vector<int> parent(n, -1), anc(n, -1);
+  for (int k = 0; k < n; ++k)
+    for (int p = Cp[k]; p < Cp[k + 1]; ++p) {
+      int i = Ci[p];
+      while (i != -1 && i < k) {
+        const int nx = anc[i];
+        anc[i] = k;
+        if (nx == -1) parent[i] = k;
+        i = nx;
+      }
+    }
+  std::vector<int> cnt(n, 1), mark(n, -1);
+  for (int k = 0; k < n; ++k) {
+    mark[k] = k;
+    for (int p = Cp[k]; p < Cp[k + 1]; ++p) {
+      int i = Ci[p];
+      while (i < k && mark[i] != k) {
+        cnt[i]++;
+        mark[i] = k;
+        i = parent[i];
+      }
+    }
+  }
+  Lp_.assign(n + 1, 0);
+  for (int j = 0; j < n; ++j) Lp_[j + 1] = Lp_[j] + cnt[j];
+  Li_.assign(Lp_[n], 0);
+  Lx_.assign(Lp_[n], 0.0);
+  std::vector<int> fill(Lp_.begin(), Lp_.end() - 1), stk(n), pat(n);
+  std::vector<double> x(n, 0.0);
+  std::fill(mark.begin(), mark.end(), -1);
+  for (int k = 0; k < n; ++k) {
+    int top = n;
+    mark[k] = k;
+    double dk = 0;
+    for (int p = Cp[k]; p < Cp[k + 1]; ++p) {
+      int i = Ci[p];
+      if (i == k) {
+        dk += Cx[p];
+        continue;
+      }
+      x[i] += Cx[p];
+      int len = 0;
+      while (mark[i] != k) {
+        stk[len++] = i;
+        mark[i] = k;
+        i = parent[i];
+      }
+      while (len > 0) pat[--top] = stk[--len];
+    }
+    for (; top < n; ++top) {
+      const int i = pat[top];
+      const double lki = x[i] / Lx_[Lp_[i]];
+      x[i] = 0;
+      for (int p = Lp_[i] + 1; p < fill[i]; ++p) x[Li_[p]] -= Lx_[p] * lki;
+      dk -= lki * lki;
+      const int q = fill[i]++;
+      Li_[q] = k;
+      Lx_[q] = lki;
+    }
+    if (!(dk > 0)) return false;
+    const int q = fill[k]++;
+    Li_[q] = k;
+    Lx_[q] = std::sqrt(dk);
+  }
+  ok_ = true;
+  return true;
+}
+
+void SparseChol::solve_inplace(double *B, int nrhs) const {
+  const int n = n_;
+  for (int j = 0; j < n; ++j) {
+    double *bj = B + (size_t)j * nrhs;
+    const double inv = 1.0 / Lx_[Lp_[j]];
+    for (int t = 0; t < nrhs; ++t) bj[t] *= inv;
+    for (int p = Lp_[j] + 1; p < Lp_[j + 1]; ++p) {
+      double *bi = B + (size_t)Li_[p] * nrhs;
+      const double l = Lx_[p];
+      for (int t = 0; t < nrhs; ++t) bi[t] -= l * bj[t];
+    }
+  }
+  for (int j = n - 1; j >= 0; --j) {
+    double *bj = B + (size_t)j * nrhs;
+    for (int p = Lp_[j] + 1; p < Lp_[j + 1]; ++p) {
+      const double *bi = B + (size_t)Li_[p] * nrhs;
+      const double l = Lx_[p];
+      for (int t = 0; t < nrhs; ++t) bj[t] -= l * bi[t];
+    }
+    const double inv = 1.0 / Lx_[Lp_[j]];
+    for (int t = 0; t < nrhs; ++t) bj[t] *= inv;
+  }
+}
+
+void SparseChol::solve_vec(const double *b, double *x) const {
+  std::vector<double> y(n_);
+  for (int i = 0; i < n_; ++i) y[i] = b[perm_[i]];
+  solve_inplace(y.data(), 1);
+  for (int i = 0; i < n_; ++i) x[perm_[i]] = y[i];
+}
+
+void SparseChol::dense_inverse(double *out, size_t ld, int nthreads) const {
+  const int n = n_;
+  constexpr int NB = 16;
+  const int nblk = (n + NB - 1) / NB;
+  nthreads = std::max(1, std::min(nthreads, nblk));
+  auto work = [&](int tid) {
+    std::vector<double> B((size_t)n * NB);
+    for (int blk = tid; blk < nblk; blk += nthreads) {
+      const int c0 = blk * NB, nc = std::min(NB, n - c0);
+      std::fill(B.begin(), B.end(), 0.0);
+      // columns c0..c0+nc-1 of the inverse in ORIGINAL numbering: rhs e_c -> permuted position iperm[c]
+      for (int t = 0; t < nc; ++t) B[(size_t)iperm_[c0 + t] * NB + t] = 1.0;
+      solve_inplace(B.data(), NB);
+      for (int t = 0; t < nc; ++t) {
+        double *row = out + (size_t)(c0 + t) * ld;
+        for (int i = 0; i < n; ++i) row[perm_[i]] = B[(size_t)i * NB + t];
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < nthreads; ++t) th.emplace_back(work, t);
+  work(0);
+  for (auto &t : th) t.join();
+}
+
+}  // namespace dcora

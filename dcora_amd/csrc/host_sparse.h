@@ -1,0 +1,49 @@
+// Host-side sparse helpers of the product: CSR containers, a fill-reducing ordering and a sparse Cholesky
+// used (a) once per Q to build the preconditioner (Q + reg I)^-1 that is applied on the GPU
+// (ref src/Graph.cpp:1901-1917) and (b) for the PSD test of the dual certificate
+// (ref src/DCORA_utils.cpp:1737-1747).  Setup-time code; the per-iteration path never comes here.
+#pragma once
+#include <cstddef>
+#include <vector>
+
+namespace dcora {
+
+struct HostCsr {
+  int n = 0;      // rows
+  int ncols = 0;  // columns (== n for square)
+  std::vector<int> rp, ci;
+  std::vector<double> v;
+  int nnz() const { return (int)ci.size(); }
+};
+
+// builds a CSR from (row, col, val) triplets, summing duplicates, columns sorted inside rows
+HostCsr csr_from_coo(int nrows, int ncols, const std::vector<int> &I, const std::vector<int> &J,
+                     const std::vector<double> &V);
+HostCsr csr_shift_diag(const HostCsr &A, double s);
+
+class SparseChol {
+ public:
+  // A symmetric (both triangles); block = size of the index groups that are ordered together (d+1 for pose graphs).
+  // Returns false when a pivot is not positive (matrix not PD): quick return, like CHOLMOD's
+  // quick_return_if_not_posdef.
+  bool factor(const HostCsr &A, int block);
+  bool ok() const { return ok_; }
+  long nnzL() const { return (long)Li_.size(); }
+  int n() const { return n_; }
+  // x = A^-1 b for nrhs right-hand sides stored contiguously per unknown: B[i*nrhs + t]
+  void solve_inplace(double *B, int nrhs) const;  // B in permuted order
+  const std::vector<int> &perm() const { return perm_; }
+  // dense inverse written row-major with leading dimension ld (>= n), using nthreads host threads
+  void dense_inverse(double *out, size_t ld, int nthreads) const;
+  void solve_vec(const double *b, double *x) const;
+
+ private:
+  int n_ = 0;
+  bool ok_ = false;
+  std::vector<int> perm_, iperm_, Lp_, Li_;
+  std::vector<double> Lx_;
+};
+
+std::vector<int> amd_like_order(const HostCsr &A, int block);
+
+}  // namespace dcora

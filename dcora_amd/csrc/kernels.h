@@ -1,0 +1,150 @@
+// Device-side building blocks of the DCORA hot path on gfx950 (MI355X).
+// Launch wrappers only; every wrapper enqueues on `st` and never synchronises.
+//
+// Data layout in HBM:
+//   * lifted variables / tangent vectors: r x k column-major, tight (ld = r), so the
+//     (d+1) columns of one pose are one contiguous run of r(d+1) doubles;
+//   * Q, S, coupling blocks: CSR (int32 rowptr/colidx, fp64 values), rows = output columns;
+//   * dense preconditioner (Q + reg I)^-1: k rows with leading dimension ldm (multiple of 16);
+//   * reductions: per-block partial sums in fixed slots, summed in a fixed order by the consumer
+//     kernel's prologue => bitwise reproducible, no floating-point atomics.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <climits>
+
+namespace dcora {
+
+constexpr int kMaxPartials = 1024;  // upper bound on per-kernel partial-sum slots
+constexpr int kBlock = 256;
+
+struct ManiDesc {
+  int r, d, n, l, b, k, se;
+  __host__ __device__ int rot_col(int i) const { return se ? i * (d + 1) : i * d; }
+  __host__ __device__ int sphere_col(int i) const { return d * n + i; }
+  __host__ __device__ int num_euc() const { return se ? n : n + b; }
+  __host__ __device__ int euc_col(int e) const { return se ? e * (d + 1) + d : d * n + l + e; }
+};
+inline ManiDesc make_mani(int r, int d, int n, int l, int b) {
+  ManiDesc m;
+  m.r = r; m.d = d; m.n = n; m.l = l; m.b = b;
+  m.se = (l == 0 && b == 0) ? 1 : 0;
+  m.k = (d + 1) * n + l + b;
+  return m;
+}
+
+struct CsrDev {
+  int nrows = 0;
+  int nnz = 0;
+  const int *rp = nullptr;
+  const int *ci = nullptr;
+  const double *v = nullptr;
+};
+
+// two-buffer handle: the RTR solver keeps the accepted iterate and the trial point in a pair of buffers and
+// flips an index in device memory on acceptance, so kernels choose their operand on the device.
+struct Buf2 {
+  double *p[2];
+};
+inline Buf2 buf1(double *x) { return Buf2{{x, x}}; }
+inline Buf2 buf1(const double *x) { return Buf2{{const_cast<double *>(x), const_cast<double *>(x)}}; }
+
+// Device-resident control block of one RTR solve.  Scalars never leave HBM during the solve; the host
+// only paces the launch queue by polling HostFlags (host-mapped) words.
+struct SolverCtl {
+  // trust-region state
+  double f1, ngf, Delta, maxDelta, tol, f2, rho, fInit, gradNormInit;
+  int cur;             // index of the accepted iterate's buffers (0/1)
+  int outer_it, max_outer, accepted, last_accepted, stop_on_accept;
+  int outer_done_stamp;  // kernels with seq > stamp are no-ops
+  // tCG state, double-buffered by iteration parity
+  double z_r[2], d_Pd[2], e_Pe[2], e_Pd[2];
+  double alpha, e_Pe_n, norm_r0;
+  int tcg_done_stamp, tcg_status, tcg_iters, inner_total, max_inner;
+};
+struct HostFlags {
+  volatile int last_seq_done;   // seq of the latest pacing kernel whose block 0 finished
+  volatile int tcg_done_seq;    // seq at which the current/last tCG terminated
+  volatile int outer_done_seq;  // seq at which the RTR loop terminated (0 = running)
+};
+
+// Solver-aware launches carry (ctl, seq, gate): gate 0 = always run, 1 = skip once the RTR loop is done,
+// 2 = skip once the RTR loop or the current tCG is done.  sel: 0 = accepted iterate, 1 = trial point.
+struct Gate {
+  const SolverCtl *ctl = nullptr;
+  int seq = 0;
+  int gate = 0;
+};
+
+// ---- SpMM: Y = X * A (+ G); optional partial dots {sum (X*A) o X, sum X o G}, 2 per block ---------------
+int spmm_grid(int nrows, int r);
+void launch_spmm(hipStream_t st, int r, const CsrDev &A, Buf2 X, int selX, const double *G, Buf2 Y, int selY,
+                 double *partials, Gate g);
+
+// ---- per-pose kernels -------------------------------------------------------------------------------
+int pose_grid(const ManiDesc &m);
+// RG = Proj_X(EG); Sblk_i = sym(Y_i^T EG_i) (spheres: y^T eg); partial |RG|^2 (1 per block)
+void launch_rgrad(hipStream_t st, const ManiDesc &m, Buf2 X, Buf2 EG, Buf2 RG, Buf2 Sblk, int sel,
+                  double *partials, Gate g);
+// out = Proj_X(V); partial <out, R> when R != null.  When p2 != null the prologue evaluates the tCG
+// residual stopping rule |r| <= |r0| min(|r0|^theta, kappa) from the np2 partials of |r|^2.
+void launch_tangent(hipStream_t st, const ManiDesc &m, Buf2 X, const double *V, double *out, const double *R,
+                    double *partials, const double *p2, int np2, SolverCtl *ctl, HostFlags *hf, int seq,
+                    int gate, int iter);
+// HV = Proj_X(W - V S); partial <V, HV>
+void launch_hessfix(hipStream_t st, const ManiDesc &m, Buf2 X, Buf2 Sblk, const double *V, const double *W,
+                    double *HV, double *partials, Gate g);
+// out = Retr_X(alpha V); when grad/HV given: partial {<V,grad>, <V,HV>} (2 per block); out buffer = trial
+void launch_retract(hipStream_t st, const ManiDesc &m, Buf2 X, const double *V, double alpha, Buf2 out,
+                    int selOut, Buf2 grad, const double *HV, double *partials, Gate g);
+// out = metric projection (polar / normalise) of c0 A + c1 B + c2 C   (B, C may be null)
+void launch_polar(hipStream_t st, const ManiDesc &m, double c0, const double *A, double c1, const double *B,
+                  double c2, const double *C, double *out);
+
+// RBCD++ Nesterov bookkeeping on a pose range (modes: see kernels.hip k_nesterov)
+void launch_nesterov(hipStream_t st, const ManiDesc &m, int mode, int restart, int skip_lo, int skip_hi, double alpha,
+                     double gamma, double *X, double *V, double *Y, double *XPrev, double *Yloc,
+                     const double *Xloc);
+
+// ---- dense preconditioner apply: Z = R * Minv (Minv symmetric, k x k, leading dimension ldm) -------------
+void launch_dense_apply(hipStream_t st, int r, int k, int ldm, const double *Minv, Buf2 R, double *Z,
+                        const double *p2, int np2, Gate g);
+
+// ---- tCG / RTR scalar+vector kernels --------------------------------------------------------------------
+int vec_grid(long nelem);
+void launch_rtr_init(hipStream_t st, const double *pA, int npA, const double *pB, int npB, SolverCtl *ctl,
+                     HostFlags *hf, int seq);
+void launch_tcg_begin(hipStream_t st, long nelem, Buf2 grad, double *eta, double *Heta, double *res,
+                      SolverCtl *ctl, int seq);
+void launch_tcg_init(hipStream_t st, long nelem, const double *z, const double *p3, int np3, double *delta,
+                     SolverCtl *ctl, int seq);
+void launch_tcg_update1(hipStream_t st, long nelem, const double *delta, const double *Hd, double *eta,
+                        double *Heta, double *res, const double *p1, int np1, double *p2, SolverCtl *ctl,
+                        HostFlags *hf, int seq, int iter);
+void launch_tcg_update2(hipStream_t st, long nelem, const double *z, double *delta, const double *p3, int np3,
+                        SolverCtl *ctl, HostFlags *hf, int seq, int iter);
+void launch_rtr_decide(hipStream_t st, const double *pA, int npA, const double *pB, int npB, const double *pC,
+                       int npC, SolverCtl *ctl, HostFlags *hf, int seq);
+
+// ---- plain vector helpers ------------------------------------------------------------------------------
+void launch_axpby(hipStream_t st, long nelem, double a, const double *x, double b, const double *y, double *out);
+// out[c] = sum_i partials[i*stride + c], i < np, c < count
+void launch_sum_partials(hipStream_t st, const double *partials, int np, int stride, int count, double *out);
+void launch_dot(hipStream_t st, long nelem, const double *x, const double *y, double *partials);
+void launch_gather_cols(hipStream_t st, int r, int ncols, const int *src_col, const double *X, double *out);
+void launch_scatter_cols(hipStream_t st, int r, int ncols, const int *dst_col, const double *in, double *X);
+// out[2a] = |A[:, cs[a]:cs[a+1]]|^2, out[2a+1] = <A, B> over the same columns (B may be null)
+void launch_block_dots(hipStream_t st, int r, int nagents, const int *col_start, const double *A, const double *B,
+                       double *out);
+
+// ---- certification ------------------------------------------------------------------------------------
+// Lambda blocks: L_i = sym( (XQ)_i^T X_i ) per Stiefel block (d x d), spheres: x^T (xq)
+void launch_lambda_blocks(hipStream_t st, const ManiDesc &m, const double *X, const double *XQ, double *Lblk);
+// Lanczos helpers: partial h = V^T w over nv basis vectors (nv per block), w -= V h, y -= shift x
+void launch_lanczos_proj(hipStream_t st, int n, int nv, const double *V, const double *w, double *partials);
+void launch_lanczos_sub(hipStream_t st, int n, int nv, const double *V, const double *h, double *w);
+void launch_scale_shift(hipStream_t st, int n, double shift, const double *x, double *y);
+void launch_scale(hipStream_t st, int n, const double *alpha_dev_inv_sqrt /*device: w /= sqrt(*p)*/,
+                  const double *w, double *out);
+
+}  // namespace dcora

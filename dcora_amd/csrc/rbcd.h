@@ -1,0 +1,57 @@
+// RBCD++ session: the agents of one process, their device-resident state and the synchronous driver loop
+// (replaces Agent::iterate / updateX / getSharedStateDicts / updateNeighborStates, ref src/Agent.cpp:113-152,
+// 535-596, 844-906, 1158-1278, and the loop body of examples/MultiRobotExample.cpp:223-307).
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "device_problem.h"
+#include "host_graph.h"
+
+namespace dcora {
+
+struct AgentDev {
+  int id = 0, n = 0, col0 = 0;  // poses, first global column
+  bool hosted = false;
+  std::unique_ptr<DeviceProblem> prob;  // Q_bb, (Q_bb + 0.1 I)^-1, solver workspace (hosted agents only)
+  DevCsr coupling;                      // rows: local columns, cols: global columns (hosted agents only)
+  std::vector<int> public_poses;        // global pose indices of my public poses (all agents)
+  DevBuf<int> public_cols;              // their global columns, (d+1) per pose (all agents)
+};
+
+class RbcdSession {
+ public:
+  int d = 0, r = 0, n = 0, R = 1;
+  Partition P;
+  dcora_rbcd_options opt{};
+  hipStream_t st = nullptr;
+  ManiDesc mg{};  // global manifold (n poses)
+  std::vector<AgentDev> agents;
+  std::unique_ptr<DeviceProblem> central;  // global Q (evaluation); world_size == 1 only
+  DevBuf<double> Xg, Vg, Yg, XPrevg;       // r x (d+1) n global mirrors
+  DevBuf<int> col_start;                   // R + 1 global column offsets
+  DevBuf<double> evalbuf;
+  double gamma = 0, alpha = 0;
+  int iteration = 0;
+  dcora_ropt_result last{};
+  double setup_ms = 0;
+
+  ~RbcdSession();
+  int init(const HostDataset &ds, const dcora_rbcd_options &o);
+  int set_X(const double *Xh);
+  int get_X(double *Xh);
+  int phase_nonselected(int selected);
+  int phase_selected(int selected);
+  int evaluate_central(double *cost2, double *gradnorm, double *block_norms, int *next_selected);
+  int phase_evaluate_dev(double *out_dev);
+  int iterate(int selected, double *cost2, double *gradnorm, double *block_norms, int *next_selected);
+  int pack_public(int agent, double *packed_dev);
+  int unpack_public(int agent, const double *packed_dev);
+
+ private:
+  bool restart_now() const { return opt.acceleration && ((iteration + 1) % opt.restart_interval == 0); }
+  void advance_sequences();
+  bool seq_advanced_ = false;
+};
+
+}  // namespace dcora

@@ -1,0 +1,286 @@
+// RBCD++ session on the device (see rbcd.h).
+#include "rbcd.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <set>
+
+namespace dcora {
+
+RbcdSession::~RbcdSession() {
+  agents.clear();
+  central.reset();
+  if (st) (void)hipStreamDestroy(st);
+}
+
+int RbcdSession::init(const HostDataset &ds, const dcora_rbcd_options &o) {
+  const auto t0 = std::chrono::steady_clock::now();
+  opt = o;
+  d = ds.d;
+  n = ds.n;
+  r = o.r;
+  R = o.num_robots;
+  if (R < 1 || n / R < 1 || o.world_size < 1 || o.rank < 0 || o.rank >= o.world_size) {
+    set_last_error("rbcd: bad num_robots / rank / world_size");
+    return DCORA_ERR_BAD_ARG;
+  }
+  P.R = R;
+  P.n = n;
+  P.per = n / R;
+  const int dh = d + 1;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_last_error("no HIP device available: libdcora_hip has no CPU fallback");
+    return DCORA_ERR_NO_DEVICE;
+  }
+  DCORA_HIP(hipSetDevice(o.device));
+  DCORA_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  mg = make_mani(r, d, n, 0, 0);
+  const size_t N = (size_t)r * dh * n;
+  DCORA_HIP(Xg.alloc(N));
+  DCORA_HIP(Vg.alloc(N));
+  DCORA_HIP(Yg.alloc(N));
+  DCORA_HIP(XPrevg.alloc(N));
+  DCORA_HIP(evalbuf.alloc(2 * R + 16));
+  DCORA_HIP(hipMemset(evalbuf.p, 0, sizeof(double) * (2 * R + 16)));
+
+  // partition (ref examples/MultiRobotExample.cpp:56-118)
+  std::vector<std::vector<PoseMeas>> touching(R);
+  std::vector<std::set<int>> pub(R);
+  for (const PoseMeas &mi : ds.meas) {
+    PoseMeas e = mi;
+    e.r1 = P.robot_of(mi.p1);
+    e.r2 = P.robot_of(mi.p2);
+    e.p1 = mi.p1 - P.start(e.r1);
+    e.p2 = mi.p2 - P.start(e.r2);
+    touching[e.r1].push_back(e);
+    if (e.r2 != e.r1) {
+      touching[e.r2].push_back(e);
+      pub[e.r1].insert(mi.p1);
+      pub[e.r2].insert(mi.p2);
+    }
+  }
+  std::vector<PoseMeas> global = ds.meas;
+  for (PoseMeas &e : global) e.r1 = e.r2 = 0;
+
+  agents.resize(R);
+  std::vector<int> cs(R + 1);
+  for (int b = 0; b < R; ++b) {
+    AgentDev &a = agents[b];
+    a.id = b;
+    a.n = P.end(b) - P.start(b);
+    a.col0 = P.start(b) * dh;
+    cs[b] = a.col0;
+    a.hosted = (b % o.world_size) == o.rank;
+    a.public_poses.assign(pub[b].begin(), pub[b].end());
+    std::vector<int> cols;
+    for (int p : a.public_poses)
+      for (int c = 0; c < dh; ++c) cols.push_back(p * dh + c);
+    DCORA_HIP(a.public_cols.alloc(std::max<size_t>(cols.size(), 1)));
+    if (!cols.empty())
+      DCORA_HIP(hipMemcpy(a.public_cols.p, cols.data(), sizeof(int) * cols.size(), hipMemcpyHostToDevice));
+    if (!a.hosted) continue;
+    HostCsr Qb = build_Q_pgo(d, a.n, b, touching[b]);
+    a.prob.reset(new DeviceProblem);
+    dcora_dims dims{r, d, a.n, 0, 0};
+    int rc = a.prob->init(dims, Qb, nullptr, 0.1, o.device, st);  // reg = 1e-1, ref src/Graph.cpp:1906
+    if (rc) return rc;
+    HostCsr C = build_coupling_pgo(d, P, b, global);
+    rc = a.coupling.upload(C);
+    if (rc) return rc;
+  }
+  cs[R] = dh * n;
+  DCORA_HIP(col_start.alloc(R + 1));
+  DCORA_HIP(hipMemcpy(col_start.p, cs.data(), sizeof(int) * (R + 1), hipMemcpyHostToDevice));
+  if (o.world_size == 1) {
+    HostCsr Qc = build_Q_pgo(d, n, 0, global);
+    central.reset(new DeviceProblem);
+    dcora_dims dims{r, d, n, 0, 0};
+    int rc = central->init(dims, Qc, nullptr, -1.0, o.device, st);
+    if (rc) return rc;
+  }
+  iteration = 0;
+  gamma = alpha = 0;
+  setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return DCORA_OK;
+}
+
+// Agent::setX + initializeAcceleration for every agent (ref src/Agent.cpp:64-77, 1178-1187)
+int RbcdSession::set_X(const double *Xh) {
+  DCORA_HIP(hipSetDevice(opt.device));
+  const size_t B = sizeof(double) * (size_t)r * (d + 1) * n;
+  DCORA_HIP(hipMemcpyAsync(Xg.p, Xh, B, hipMemcpyHostToDevice, st));
+  DCORA_HIP(hipMemcpyAsync(Vg.p, Xg.p, B, hipMemcpyDeviceToDevice, st));
+  DCORA_HIP(hipMemcpyAsync(Yg.p, Xg.p, B, hipMemcpyDeviceToDevice, st));
+  DCORA_HIP(hipMemcpyAsync(XPrevg.p, Xg.p, B, hipMemcpyDeviceToDevice, st));
+  DCORA_HIP(hipStreamSynchronize(st));
+  gamma = alpha = 0;
+  iteration = 0;
+  seq_advanced_ = false;
+  return DCORA_OK;
+}
+int RbcdSession::get_X(double *Xh) {
+  DCORA_HIP(hipSetDevice(opt.device));
+  DCORA_HIP(hipMemcpyAsync(Xh, Xg.p, sizeof(double) * (size_t)r * (d + 1) * n, hipMemcpyDeviceToHost, st));
+  DCORA_HIP(hipStreamSynchronize(st));
+  return DCORA_OK;
+}
+
+// updateGamma / updateAlpha (ref src/Agent.cpp:1189-1200); the sequences are data-independent and identical for
+// every agent, so they live on the host
+void RbcdSession::advance_sequences() {
+  iteration++;
+  if (opt.acceleration) {
+    gamma = (1 + std::sqrt(1 + 4.0 * R * R * gamma * gamma)) / (2.0 * R);
+    alpha = 1.0 / (gamma * R);
+  }
+  seq_advanced_ = true;
+}
+
+// Agent::iterate(false) for every hosted agent except `selected`
+int RbcdSession::phase_nonselected(int selected) {
+  DCORA_HIP(hipSetDevice(opt.device));
+  advance_sequences();
+  if (!opt.acceleration) return DCORA_OK;
+  const int restart = restart_now() ? 1 : 0;
+  if (opt.world_size == 1) {
+    // one launch over the whole graph, skipping the selected agent's poses
+    launch_nesterov(st, mg, 0, restart, P.start(selected), P.end(selected), alpha, gamma, Xg.p, Vg.p, Yg.p, XPrevg.p,
+                    nullptr, nullptr);
+  } else {
+    for (AgentDev &a : agents) {
+      if (!a.hosted || a.id == selected) continue;
+      const size_t off = (size_t)a.col0 * r;
+      launch_nesterov(st, a.prob->m, 0, restart, -1, -1, alpha, gamma, Xg.p + off, Vg.p + off, Yg.p + off,
+                      XPrevg.p + off, nullptr, nullptr);
+    }
+  }
+  return DCORA_OK;
+}
+
+// Agent::iterate(true) for `selected` when hosted here (ref src/Agent.cpp:535-551, 1158-1176, 1216-1278)
+int RbcdSession::phase_selected(int selected) {
+  DCORA_HIP(hipSetDevice(opt.device));
+  if (!seq_advanced_) advance_sequences();
+  seq_advanced_ = false;
+  const bool restart = restart_now();
+  AgentDev &a = agents[selected];
+  int rc = DCORA_OK;
+  if (a.hosted) {
+    DeviceProblem &pb = *a.prob;
+    const size_t off = (size_t)a.col0 * r;
+    const size_t B = sizeof(double) * (size_t)pb.nelem();
+    // Graph::constructLinearCostTermPGO: G_b = sum_c X_c Q_cb from the neighbours' public poses
+    // (ref src/Graph.cpp:685-822); the mirror Xg holds them after the pull / unpack
+    launch_spmm(st, r, a.coupling.view(), buf1(Xg.p), 0, nullptr, buf1(pb.G.p), 0, nullptr, Gate{});
+    pb.has_G = true;
+    double *Xres = nullptr;
+    if (opt.acceleration) {
+      launch_nesterov(st, pb.m, 1, 0, -1, -1, alpha, gamma, Xg.p + off, Vg.p + off, Yg.p + off, XPrevg.p + off,
+                      pb.X0.p, nullptr);
+      rc = pb.optimize_dev(opt.local, &last, &Xres);
+      if (rc) return rc;
+      launch_nesterov(st, pb.m, 2, 0, -1, -1, alpha, gamma, Xg.p + off, Vg.p + off, Yg.p + off, XPrevg.p + off,
+                      nullptr, Xres);
+      if (restart) {
+        // restartNesterovAcceleration: X = XPrev; updateX(true, false); V = X; Y = X
+        DCORA_HIP(hipMemcpyAsync(pb.X0.p, XPrevg.p + off, B, hipMemcpyDeviceToDevice, st));
+        rc = pb.optimize_dev(opt.local, &last, &Xres);
+        if (rc) return rc;
+        launch_nesterov(st, pb.m, 3, 0, -1, -1, alpha, gamma, Xg.p + off, Vg.p + off, Yg.p + off, XPrevg.p + off,
+                        nullptr, Xres);
+      }
+    } else {
+      DCORA_HIP(hipMemcpyAsync(XPrevg.p + off, Xg.p + off, B, hipMemcpyDeviceToDevice, st));
+      DCORA_HIP(hipMemcpyAsync(pb.X0.p, Xg.p + off, B, hipMemcpyDeviceToDevice, st));
+      rc = pb.optimize_dev(opt.local, &last, &Xres);
+      if (rc) return rc;
+      DCORA_HIP(hipMemcpyAsync(Xg.p + off, Xres, B, hipMemcpyDeviceToDevice, st));
+    }
+  }
+  if (restart) gamma = alpha = 0;
+  return DCORA_OK;
+}
+
+// central evaluation of the driver (ref examples/MultiRobotExample.cpp:264-305): 2 f, |rgrad|, greedy selection
+int RbcdSession::evaluate_central(double *cost2, double *gradnorm, double *block_norms, int *next_selected) {
+  if (!central) {
+    set_last_error("central evaluation needs world_size == 1");
+    return DCORA_ERR_UNSUPPORTED;
+  }
+  DeviceProblem &c = *central;
+  c.enqueue_egrad(Xg.p, c.EG0.p, c.pA.p);
+  launch_rgrad(st, mg, buf1(Xg.p), buf1(c.EG0.p), buf1(c.RG0.p), Buf2{{nullptr, nullptr}}, 0, c.pB.p, Gate{});
+  launch_block_dots(st, r, R, col_start.p, c.RG0.p, nullptr, evalbuf.p);
+  launch_sum_partials(st, c.pA.p, c.npA(), 2, 2, evalbuf.p + 2 * R);
+  std::vector<double> h(2 * R + 2);
+  DCORA_HIP(hipMemcpyAsync(h.data(), evalbuf.p, sizeof(double) * (2 * R + 2), hipMemcpyDeviceToHost, st));
+  DCORA_HIP(hipStreamSynchronize(st));
+  double g2 = 0, best = -1;
+  int arg = 0;
+  for (int b = 0; b < R; ++b) {
+    const double nb = std::sqrt(h[2 * b]);
+    if (block_norms) block_norms[b] = nb;
+    g2 += h[2 * b];
+    if (nb > best) {
+      best = nb;
+      arg = b;
+    }
+  }
+  if (cost2) *cost2 = 2.0 * (0.5 * h[2 * R] + h[2 * R + 1]);
+  if (gradnorm) *gradnorm = std::sqrt(g2);
+  if (next_selected) *next_selected = arg;
+  return DCORA_OK;
+}
+
+// distributed form of the same evaluation: per hosted agent |Proj(X_b Q_bb + G_b)|^2 and <X_b, X_b Q_bb + G_b>
+int RbcdSession::phase_evaluate_dev(double *out_dev) {
+  DCORA_HIP(hipSetDevice(opt.device));
+  DCORA_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * 2 * R, st));
+  for (AgentDev &a : agents) {
+    if (!a.hosted) continue;
+    DeviceProblem &pb = *a.prob;
+    const double *Xb = Xg.p + (size_t)a.col0 * r;
+    launch_spmm(st, r, a.coupling.view(), buf1(Xg.p), 0, nullptr, buf1(pb.G.p), 0, nullptr, Gate{});
+    pb.has_G = true;
+    pb.enqueue_egrad(Xb, pb.EG1.p, nullptr);
+    launch_rgrad(st, pb.m, buf1(Xb), buf1(pb.EG1.p), buf1(pb.RG1.p), Buf2{{nullptr, nullptr}}, 0, pb.pB.p, Gate{});
+    launch_sum_partials(st, pb.pB.p, pb.npPose(), 1, 1, out_dev + 2 * a.id);
+    launch_dot(st, pb.nelem(), Xb, pb.EG1.p, pb.p3.p);
+    launch_sum_partials(st, pb.p3.p, pb.npVec(), 1, 1, out_dev + 2 * a.id + 1);
+  }
+  return DCORA_OK;
+}
+
+int RbcdSession::iterate(int selected, double *cost2, double *gradnorm, double *block_norms, int *next_selected) {
+  if (selected < 0 || selected >= R) {
+    set_last_error("rbcd: selected agent out of range");
+    return DCORA_ERR_BAD_ARG;
+  }
+  int rc = phase_nonselected(selected);
+  if (rc) return rc;
+  // world_size == 1: the "pull" of public poses (ref examples/MultiRobotExample.cpp:236-258) is the identity,
+  // all agents' blocks live in the same mirror Xg
+  rc = phase_selected(selected);
+  if (rc) return rc;
+  int nxt = selected;
+  rc = evaluate_central(cost2, gradnorm, block_norms, &nxt);
+  if (rc) return rc;
+  // greedy selection only when the selected agent has neighbours (:290-292)
+  if (next_selected) *next_selected = (agents[selected].coupling.nnz > 0) ? nxt : selected;
+  return DCORA_OK;
+}
+
+int RbcdSession::pack_public(int agent, double *packed_dev) {
+  AgentDev &a = agents[agent];
+  launch_gather_cols(st, r, (int)a.public_poses.size() * (d + 1), a.public_cols.p, Xg.p, packed_dev);
+  return DCORA_OK;
+}
+int RbcdSession::unpack_public(int agent, const double *packed_dev) {
+  AgentDev &a = agents[agent];
+  launch_scatter_cols(st, r, (int)a.public_poses.size() * (d + 1), a.public_cols.p, packed_dev, Xg.p);
+  return DCORA_OK;
+}
+
+}  // namespace dcora

@@ -1,0 +1,218 @@
+/*
+ * dcora_hip.h -- C ABI of the MI355X (gfx950) implementation of DCORA's hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.
+ * Every entry point names the reference interface it replaces (paths relative
+ * to the reference tree).  Conventions shared by all calls:
+ *
+ *   - dense matrices are column-major double with leading dimension = rows
+ *     (Eigen::MatrixXd layout, ref include/DCORA/DCORA_types.h:34);
+ *   - sparse matrices are row-major CSR, int32 indices, both triangles stored
+ *     (ref include/DCORA/DCORA_types.h:36);
+ *   - column ordering of the lifted variable X (r x k): SE ordering
+ *     [Y1 p1 ... Yn pn] when l == b == 0, otherwise RA ordering
+ *     [Y1..Yn | s1..sl | p1..pn | L1..Lb]
+ *     (ref src/manifold/LiftedVariable.cpp:74-106, 257-295);
+ *   - host pointers are borrowed for the duration of the call only; handles own
+ *     their device memory; *_dev variants take device pointers and enqueue on
+ *     the handle's HIP stream without synchronising;
+ *   - every function returns a dcora_status (0 = ok); nothing throws across
+ *     the ABI.  The library fails loudly (DCORA_ERR_NO_DEVICE / DCORA_ERR_HIP)
+ *     when no gfx950 device is usable: there is no CPU fallback.
+ */
+#ifndef DCORA_HIP_H_
+#define DCORA_HIP_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  DCORA_OK = 0,
+  DCORA_ERR_BAD_ARG = 1,
+  DCORA_ERR_NO_DEVICE = 2,
+  DCORA_ERR_HIP = 3,
+  DCORA_ERR_NOT_PD = 4,          /* Cholesky hit a non-positive pivot */
+  DCORA_ERR_NO_CONVERGENCE = 5,  /* Lanczos did not converge */
+  DCORA_ERR_NO_PRECONDITIONER = 6,
+  DCORA_ERR_IO = 7,
+  DCORA_ERR_UNSUPPORTED = 8
+} dcora_status;
+
+const char *dcora_status_string(int status);
+const char *dcora_last_error(void);
+/* number of usable HIP devices (0 when there is none; never initialises more than the runtime) */
+int dcora_device_count(void);
+
+/* Manifold shape (ref src/manifold/LiftedManifold.cpp:18-89). */
+typedef struct {
+  int r; /* relaxation rank */
+  int d; /* 2 or 3 */
+  int n; /* poses (Stiefel blocks) */
+  int l; /* unit spheres (oblique columns) */
+  int b; /* landmarks */
+} dcora_dims;
+
+/* ref include/DCORA/DCORA_types.h:152-168 ROptParameters (same defaults via dcora_ropt_params_default) */
+typedef struct {
+  int method; /* 0 = RTR, 1 = RGD */
+  int verbose;
+  double gradnorm_tol;
+  double RGD_stepsize;
+  int RGD_use_preconditioner;
+  int RTR_iterations;
+  int RTR_tCG_iterations;
+  double RTR_initial_radius;
+} dcora_ropt_params;
+void dcora_ropt_params_default(dcora_ropt_params *p);
+
+/* ref include/DCORA/DCORA_types.h:203-233 ROPTResult (+ solver counters) */
+typedef struct {
+  int success;
+  double fInit, gradNormInit, fOpt, gradNormOpt, elapsedMs;
+  int tCGStatus; /* 0 NEGCURVTURE, 1 EXCREGION, 2 LCON, 3 SCON, 4 MAXITER */
+  int outer_iterations, inner_iterations, accepted_steps;
+} dcora_ropt_result;
+
+/* ------------------------------------------------------------------------- *
+ * QuadraticProblem  (replaces src/QuadraticProblem.cpp)
+ * ------------------------------------------------------------------------- */
+typedef struct dcora_problem_s *dcora_problem_t;
+
+/* QuadraticProblem(shared_ptr<Graph>) (ref src/QuadraticProblem.cpp:19-34): uploads Q (k x k CSR) and G
+ * (r x k, may be NULL = zero) and, when precond_reg >= 0, builds the preconditioner (Q + reg I)^-1
+ * (ref src/Graph.cpp:1901-1917; reg = 0.1 for PGO).  device = HIP device ordinal. */
+int dcora_problem_create(const dcora_dims *dims, const int *rowptr, const int *colidx, const double *vals,
+                         const double *G, double precond_reg, int device, dcora_problem_t *out);
+int dcora_problem_destroy(dcora_problem_t p);
+/* Graph::linearMatrix() changed (ref src/Graph.cpp:535-540, 685-822) */
+int dcora_problem_set_linear_term(dcora_problem_t p, const double *G);
+/* f(Y) (ref src/QuadraticProblem.cpp:38-44) */
+int dcora_problem_cost(dcora_problem_t p, const double *X, double *f);
+/* EucGrad = X Q + G (ref :53-59) */
+int dcora_problem_eucgrad(dcora_problem_t p, const double *X, double *out);
+/* RieGrad / RieGradNorm (ref :86-123); out may be NULL */
+int dcora_problem_riegrad(dcora_problem_t p, const double *X, double *out, double *norm);
+/* Riemannian Hessian-vector product: EucHessianEta (ref :61-68) followed by ROPTLIB's EucHvToHv */
+int dcora_problem_hessvec(dcora_problem_t p, const double *X, const double *V, double *out);
+/* PreCondition (ref :70-84, 261-297) */
+int dcora_problem_precondition(dcora_problem_t p, const double *X, const double *V, double *out);
+/* Retract (ref :125-136, 236-259) */
+int dcora_problem_retract(dcora_problem_t p, const double *X, const double *V, double *out);
+/* projectToTangentSpace (ref :299-307; src/manifold/LiftedManifold.cpp:37-41, 104-108) */
+int dcora_problem_tangent_project(dcora_problem_t p, const double *X, const double *V, double *out);
+/* escapeSaddle (ref :138-234): p is the problem at rank r, Xopt is (r-1) x k */
+int dcora_problem_escape_saddle(dcora_problem_t p, const double *Xopt, double theta, const double *v,
+                                double gradient_tolerance, double preconditioned_gradient_tolerance, double *Xout,
+                                int *success);
+/* LiftedSEManifold::project / LiftedRAManifold::project, projectToSEMatrix / projectToRAMatrix
+ * (ref src/manifold/LiftedManifold.cpp:28-35, 91-102; src/DCORA_utils.cpp:2201-2220) */
+int dcora_manifold_project(const dcora_dims *dims, const double *M, double *out, int device);
+
+/* ------------------------------------------------------------------------- *
+ * QuadraticOptimizer  (replaces src/QuadraticOptimizer.cpp)
+ * ------------------------------------------------------------------------- */
+/* optimize(Y) (ref src/QuadraticOptimizer.cpp:28-50): RTR (ref :52-108, 234-280) or one RGD step (ref :110-180) */
+int dcora_optimizer_optimize(dcora_problem_t p, const dcora_ropt_params *params, const double *X0, double *Xout,
+                             dcora_ropt_result *result);
+
+/* ------------------------------------------------------------------------- *
+ * Certification  (replaces src/DCORA_utils.cpp:1713-1982)
+ * ------------------------------------------------------------------------- */
+typedef struct dcora_csr_s *dcora_csr_t; /* host-side CSR returned by the library */
+int dcora_csr_info(dcora_csr_t m, int *n, int *nnz);
+int dcora_csr_copy(dcora_csr_t m, int *rowptr, int *colidx, double *vals);
+int dcora_csr_destroy(dcora_csr_t m);
+
+/* constructDualCertificateMatrixPGO / ...RASLAM (ref :1898-1982): S = Q - Lambda(X) */
+int dcora_cert_dual_matrix(const dcora_dims *dims, const double *X, const int *rowptr, const int *colidx,
+                           const double *vals, int device, dcora_csr_t *S);
+/* isSparseSymmetricMatrixPSD (ref :1737-1747) */
+int dcora_cert_is_psd(int k, const int *rowptr, const int *colidx, const double *vals, int block, int *is_psd);
+/* computeMinimumEigenPair(S, max_iterations, min_eig_num_tol, num_Lanczos_vectors) (ref :1809-1896) */
+int dcora_cert_min_eig(int k, const int *rowptr, const int *colidx, const double *vals, int max_iterations,
+                       double min_eig_num_tol, int num_lanczos_vectors, unsigned long long seed, int device,
+                       double *lambda_min, double *v, long *num_matvecs);
+/* fastVerification(S, eta, &theta, &x) (ref :1713-1735) */
+int dcora_cert_fast_verification(int k, const int *rowptr, const int *colidx, const double *vals, double eta,
+                                 int block, int device, int *is_psd, double *theta, double *x, double *lambda_min);
+
+/* ------------------------------------------------------------------------- *
+ * Data feed  (replaces the parts of src/Graph.cpp / src/DCORA_utils.cpp that
+ * produce Q, G and the measurement list)
+ * ------------------------------------------------------------------------- */
+/* measurement arrays: ids m x 4 int32 (r1, p1, r2, p2); vals m x (d*d + d + 3) double
+ * (R column-major, t, kappa, tau, weight)  (ref include/DCORA/Measurements.h RelativePosePoseMeasurement) */
+typedef struct dcora_dataset_s *dcora_dataset_t;
+/* read_g2o_file (ref src/DCORA_utils.cpp:179-375); .gz not handled here */
+int dcora_dataset_load_g2o(const char *path, dcora_dataset_t *out);
+int dcora_dataset_create(int d, int n, int m, const int *ids, const double *vals, dcora_dataset_t *out);
+int dcora_dataset_info(dcora_dataset_t ds, int *d, int *n, int *m);
+int dcora_dataset_copy(dcora_dataset_t ds, int *ids, double *vals);
+int dcora_dataset_destroy(dcora_dataset_t ds);
+/* Graph::constructQuadraticCostTermPGO (ref src/Graph.cpp:579-683) for agent `agent_id` owning n poses */
+int dcora_graph_build_Q_pgo(int d, int n, int agent_id, int m, const int *ids, const double *vals, dcora_csr_t *Q);
+
+/* ------------------------------------------------------------------------- *
+ * RBCD session: Agents + synchronous driver on device
+ * (replaces Agent::iterate/updateX/getSharedStateDicts/updateNeighborStates, ref src/Agent.cpp:113-152,
+ *  535-596, 844-906, 1158-1278, and the loop body of examples/MultiRobotExample.cpp:223-307)
+ * ------------------------------------------------------------------------- */
+typedef struct dcora_rbcd_s *dcora_rbcd_t;
+typedef struct {
+  int num_robots;
+  int r;
+  int acceleration;     /* AgentParameters::acceleration */
+  int restart_interval; /* AgentParameters::restartInterval (30) */
+  dcora_ropt_params local; /* AgentParameters::localOptimizationParams */
+  int rank, world_size; /* this process hosts agents a with a % world_size == rank */
+  int device;
+} dcora_rbcd_options;
+void dcora_rbcd_options_default(dcora_rbcd_options *o);
+
+/* partition (ref examples/MultiRobotExample.cpp:56-118), per-agent Q / preconditioner, central Q */
+int dcora_rbcd_create(dcora_dataset_t ds, const dcora_rbcd_options *opt, dcora_rbcd_t *out);
+int dcora_rbcd_destroy(dcora_rbcd_t s);
+/* Agent::setX for every agent from the global r x (d+1)n matrix (ref examples/MultiRobotExample.cpp:209-217) */
+int dcora_rbcd_set_X(dcora_rbcd_t s, const double *X);
+int dcora_rbcd_get_X(dcora_rbcd_t s, double *X);
+/* one pass of the loop body :223-307 with `selected` as the optimising agent: non-selected iterate(false),
+ * public-pose pull, selected iterate(true), central evaluation.  Outputs: 2 f, |rgrad|, per-agent |rgrad_b|
+ * (num_robots doubles, may be NULL) and the greedy next selection. */
+int dcora_rbcd_iterate(dcora_rbcd_t s, int selected, double *cost2, double *gradnorm, double *block_norms,
+                       int *next_selected);
+/* runs up to max_iters passes, stopping when |rgrad| < rgrad_tol; fills the trace arrays (may be NULL) */
+int dcora_rbcd_run(dcora_rbcd_t s, int max_iters, double rgrad_tol, int *iters_done, double *cost2_trace,
+                   double *gradnorm_trace, int *selected_trace);
+/* statistics of the last selected agent's local solve */
+int dcora_rbcd_last_result(dcora_rbcd_t s, dcora_ropt_result *res);
+
+/* --- multi-process pieces (one process per GPU, exchange through RCCL by the caller) --- */
+/* device pointer of the session's global lifted variable (r x (d+1)n, column-major, resident in HBM) */
+int dcora_rbcd_X_device_ptr(dcora_rbcd_t s, double **X_dev);
+/* number of public poses of agent a, and their global pose indices (ref src/Graph.h myPublicPoseIDs) */
+int dcora_rbcd_public_count(dcora_rbcd_t s, int agent, int *count);
+int dcora_rbcd_public_indices(dcora_rbcd_t s, int agent, int *global_pose_idx);
+/* getSharedStateDicts: gather agent's public poses into a packed r x (d+1)count device buffer */
+int dcora_rbcd_pack_public_dev(dcora_rbcd_t s, int agent, double *packed_dev);
+/* updateNeighborStates: scatter a packed buffer received from agent's owner into the local mirror of X */
+int dcora_rbcd_unpack_public_dev(dcora_rbcd_t s, int agent, const double *packed_dev);
+/* the three phases of dcora_rbcd_iterate for callers that exchange between them */
+int dcora_rbcd_phase_nonselected(dcora_rbcd_t s, int selected);
+int dcora_rbcd_phase_selected(dcora_rbcd_t s, int selected);
+/* local part of the evaluation: for every hosted agent b, |Proj(X_b Q_bb + G_b)|^2 and <X_b, X_b Q_bb + G_b>
+ * written to out_dev[2*b], out_dev[2*b+1] (device, 2*num_robots doubles, entries of non-hosted agents zero) */
+int dcora_rbcd_phase_evaluate_dev(dcora_rbcd_t s, double *out_dev);
+int dcora_rbcd_synchronize(dcora_rbcd_t s);
+
+/* ------------------------------------------------------------------------- *
+ * Bench / profiling hooks
+ * ------------------------------------------------------------------------- */
+/* times `reps` launches of the Q-apply kernel Y = X Q + G of a problem with HIP events on the handle's
+ * stream; returns average milliseconds per launch and the algorithmic bytes of one launch */
+int dcora_problem_time_qapply(dcora_problem_t p, int reps, double *avg_ms, double *algorithmic_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCORA_HIP_H_ */

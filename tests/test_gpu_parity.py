@@ -1,0 +1,181 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+Tolerances: fp64 everywhere; element-wise ops agree to ~1e-12 relative (summation order differs), converged
+solver outputs to 1e-6 relative (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+import common
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env(built):
+    import dcora_amd as da
+    from oracle import orc
+    if da.device_count() < 1:
+        pytest.fail("no GPU visible: the product has no CPU fallback")
+    return da, orc
+
+
+def _setup(env, name, r):
+    da, orc = env
+    ds, dso = common.product_dataset(name), common.oracle_dataset(name)
+    Q, Qo = da.build_Q_pgo(ds), orc.build_Q_pgo(dso)
+    rng = np.random.default_rng(11)
+    G = rng.standard_normal((r, (ds.d + 1) * ds.n))
+    P = da.QuadraticProblem(r, ds.d, ds.n, Q, G=G)
+    Po = orc.Problem(r, ds.d, ds.n, Qo, G=G)
+    X = common.random_point(r, ds.d, ds.n, 5, orc.project_to_manifold)
+    V = common.random_tangent(r, ds.d, ds.n, 6)
+    return ds, P, Po, X, V
+
+
+@pytest.mark.parametrize("name,r", [("pose_graph_optimization_test_2d", 2), ("pose_graph_optimization_test_3d", 3),
+                                    ("tinyGrid3D", 4), ("smallGrid3D", 5), ("smallGrid3D", 7),
+                                    ("smallGrid3D", 9), ("sphere2500", 5)])
+def test_problem_ops(env, name, r):
+    da, orc = env
+    ds, P, Po, X, V = _setup(env, name, r)
+    d, n = ds.d, ds.n
+    assert abs(P.f(X) - Po.f(X)) <= 1e-12 * abs(Po.f(X))
+    assert common.rel(P.EucGrad(X), Po.egrad(X)) < 1e-13
+    assert common.rel(P.RieGrad(X), Po.rgrad(X)) < 1e-12
+    assert abs(P.RieGradNorm(X) - np.linalg.norm(Po.rgrad(X))) < 1e-10 * np.linalg.norm(Po.rgrad(X))
+    assert common.rel(P.projectToTangentSpace(X, V), orc.tangent_project(r, d, n, X, V)) < 1e-13
+    Vt = orc.tangent_project(r, d, n, X, V)
+    assert common.rel(P.HessVec(X, Vt), Po.hess(X, Vt)) < 1e-12
+    assert common.rel(P.Retract(X, 0.3 * Vt), orc.retract(r, d, n, X, 0.3 * Vt)) < 1e-13
+    assert common.rel(P.PreCondition(X, Vt), Po.precondition(X, Vt)) < 1e-9
+    M = X + 0.2 * V
+    assert common.rel(da.manifold_project(r, d, n, M), orc.project_to_manifold(r, d, n, M)) < 1e-12
+
+
+def test_retraction_properties(env):
+    da, orc = env
+    ds, P, Po, X, V = _setup(env, "smallGrid3D", 5)
+    d, n, r = ds.d, ds.n, 5
+    Y = P.Retract(X, np.zeros_like(X))
+    assert common.rel(Y, X) < 1e-14  # Retract(Y, 0) = Y
+    Z = P.Retract(X, V)
+    for i in range(n):
+        B = Z[:, 4 * i:4 * i + 3]
+        assert np.abs(B.T @ B - np.eye(3)).max() < 1e-13
+
+
+@pytest.mark.parametrize("name,r,R", [("smallGrid3D", 5, 3), ("sphere2500", 5, 3)])
+def test_rtr_matches_oracle(env, name, r, R):
+    """same RTR configuration on device and in the oracle: converged cost within 1e-6 relative"""
+    da, orc = env
+    ds, dso = common.product_dataset(name), common.oracle_dataset(name)
+    # an agent-sized block: first n/R poses with their private measurements
+    nb = ds.n // R
+    keep = (ds.ids[:, 1] < nb) & (ds.ids[:, 3] < nb)
+    Q = da.build_Q_pgo(ds, n=nb, ids=ds.ids[keep], vals=ds.vals[keep])
+    Qo = orc.build_Q_pgo(dso, n=nb, ids=dso.ids[keep], vals=dso.vals[keep])
+    rng = np.random.default_rng(2)
+    G = 0.1 * rng.standard_normal((r, (ds.d + 1) * nb))
+    P = da.QuadraticProblem(r, ds.d, nb, Q, G=G)
+    Po = orc.Problem(r, ds.d, nb, Qo, G=G)
+    X0 = common.random_point(r, ds.d, nb, 9, orc.project_to_manifold)
+    # default parameters: 3 outer x 50 tCG, tol 1e-2 (ref DCORA_types.h:160-168)
+    opt = da.QuadraticOptimizer(P, da.ROptParameters())
+    X = opt.optimize(X0)
+    res = opt.getOptResult()
+    Xo, reso = Po.optimize(X0)
+    assert abs(res["fInit"] - reso["fInit"]) <= 1e-11 * abs(reso["fInit"])
+    assert abs(res["gradNormInit"] - reso["gradNormInit"]) <= 1e-10 * reso["gradNormInit"]
+    assert res["outer_iterations"] == reso["outer_iters"]
+    assert res["inner_iterations"] == reso["inner_iters"]
+    assert abs(res["fOpt"] - reso["fOpt"]) <= 1e-8 * abs(reso["fOpt"])
+    assert common.rel(X, Xo) < 1e-6
+    assert abs(Po.f(X) - res["fOpt"]) <= 1e-10 * abs(res["fOpt"])
+    # long run to convergence
+    prm = da.ROptParameters(RTR_iterations=60, RTR_tCG_iterations=200, gradnorm_tol=1e-6)
+    opt = da.QuadraticOptimizer(P, prm)
+    X = opt.optimize(X0)
+    res = opt.getOptResult()
+    Xo, reso = Po.optimize(X0, RTR_iterations=60, RTR_tCG_iterations=200, gradnorm_tol=1e-6)
+    assert abs(res["fOpt"] - reso["fOpt"]) <= 1e-6 * abs(reso["fOpt"])
+    assert res["gradNormOpt"] < 1e-5 or reso["gradNormOpt"] >= 1e-6
+
+
+def test_rtr_single_iteration_mode_and_early_return(env):
+    da, orc = env
+    ds, P, Po, X, V = _setup(env, "smallGrid3D", 5)
+    opt = da.QuadraticOptimizer(P, da.ROptParameters(RTR_iterations=1))
+    X1 = opt.optimize(X)
+    res = opt.getOptResult()
+    Xo, reso = Po.optimize(X, RTR_iterations=1)
+    assert res["accepted_steps"] == 1 and abs(res["fOpt"] - reso["fOpt"]) <= 1e-8 * abs(reso["fOpt"])
+    # gradient already below tolerance => input returned unchanged (ref QuadraticOptimizer.cpp:54-55)
+    opt = da.QuadraticOptimizer(P, da.ROptParameters(gradnorm_tol=1e9))
+    X2 = opt.optimize(X)
+    assert np.array_equal(X2, X)
+    # one preconditioned RGD step (ref QuadraticOptimizer.cpp:123-150)
+    opt = da.QuadraticOptimizer(P, da.ROptParameters(method=1))
+    X3 = opt.optimize(X)
+    Xo3, _ = Po.optimize(X, method=1)
+    assert common.rel(X3, Xo3) < 1e-10
+
+
+def test_noiseless_fixed_point(env):
+    """reference fixture (tests/testAgent.cpp:23-28): ground truth of the noiseless datasets has cost 0, zero
+    gradient, and is a fixed point of the local solver"""
+    da, orc = env
+    import g2o_np
+    for name in ("pose_graph_optimization_test_2d", "pose_graph_optimization_test_3d"):
+        g = g2o_np.read_g2o(common.data_path(name))
+        ds = common.product_dataset(name)
+        X = g2o_np.ground_truth_X(g)
+        P = da.QuadraticProblem(ds.d, ds.d, ds.n, da.build_Q_pgo(ds))
+        assert abs(P.f(X)) < 1e-14
+        assert P.RieGradNorm(X) < 1e-7
+        Xn = da.QuadraticOptimizer(P).optimize(X)
+        assert np.abs(Xn - X).max() < 1e-9
+
+
+def test_rbcd_matches_oracle(env):
+    """RBCD++ loop (5 agents, acceleration, restarts, greedy selection): same trace as the oracle"""
+    da, orc = env
+    ds, dso = common.product_dataset("smallGrid3D"), common.oracle_dataset("smallGrid3D")
+    r = 5
+    X0 = common.random_point(r, ds.d, ds.n, 1, orc.project_to_manifold)
+    iters = 70  # crosses two restarts (interval 30)
+    tr = orc.run_rbcd(dso, X0, num_robots=5, r_min=r, max_iters=iters, staircase=0, rgrad_tol=1e-12)
+    s = da.RbcdSession(ds, num_robots=5, r=r)
+    s.set_X(X0)
+    out = s.run(max_iters=iters, rgrad_tol=1e-12)
+    assert out["iters"] == iters
+    assert np.array_equal(out["selected"], tr["selected"])
+    assert np.allclose(out["cost"], tr["cost"], rtol=1e-7)
+    assert np.allclose(out["gradnorm"], tr["gradnorm"], rtol=1e-5, atol=1e-8)
+    assert common.rel(s.get_X(), tr["X"]) < 1e-6
+
+
+def test_certification(env):
+    da, orc = env
+    ds, dso = common.product_dataset("smallGrid3D"), common.oracle_dataset("smallGrid3D")
+    r = 5
+    Q, Qo = da.build_Q_pgo(ds), orc.build_Q_pgo(dso)
+    X = common.random_point(r, ds.d, ds.n, 4, orc.project_to_manifold)
+    S = da.dual_certificate(r, ds.d, ds.n, X, Q)
+    So = orc.dual_certificate(r, ds.d, ds.n, X, Qo)
+    assert abs(S.to_scipy() - So.to_scipy()).max() < 1e-9
+    # at a random point S is indefinite: min eigenpair vs dense eigh
+    ok, lam, v, mv = da.min_eig(S, tol=1e-3)
+    w = np.linalg.eigvalsh(S.to_scipy().toarray())
+    assert ok and abs(lam - w[0]) < 2e-3 * max(1.0, abs(w[0]))
+    Sv = S.to_scipy() @ v
+    assert abs(v @ Sv - lam) < 1e-6 * max(1, abs(lam)) and abs(np.linalg.norm(v) - 1) < 1e-12
+    psd, theta, x, lmin = da.fast_verification(S, 1e-3, block=ds.d + 1)
+    psdo, thetao, xo, lmino = orc.fast_verification(So, 1e-3, block=ds.d + 1)
+    assert psd == psdo == False
+    assert abs(theta - thetao) < 2e-3 * abs(thetao)
+    # escape from a (fake) saddle one rank up: both must decrease the cost
+    P6 = da.QuadraticProblem(r + 1, ds.d, ds.n, Q)
+    Po6 = orc.Problem(r + 1, ds.d, ds.n, Qo)
+    Xn = P6.escapeSaddle(X, theta, x)
+    Xno = Po6.escape_saddle(X, theta, x)
+    assert Xn is not None and Xno is not None
+    assert common.rel(Xn, Xno) < 1e-9
