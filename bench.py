@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py -- RBCD iterations/sec of the MI355X path on BASELINE.json's headline workload.
+
+Workload (config.workload): sphere2500.g2o split across 5 agents (contiguous n/R partition of the reference
+driver), rank r = 5, RBCD++ with Nesterov acceleration and restarts every 30, local solver = RTR with the
+reference defaults (3 outer iterations, <= 50 tCG, Delta0 = 100, tol 1e-2).  One "step" = one pass of the loop
+body of examples/MultiRobotExample.cpp:223-307 (non-selected Nesterov updates, public-pose pull, the selected
+agent's QuadraticOptimizer::optimize, central cost / gradient evaluation, greedy selection).  The start point is
+a seeded uniform-random matrix projected onto the manifold, as the reference driver's Random initialisation;
+all inputs (Q, preconditioner, X) are resident in HBM when the timed region starts.
+
+Launch: `python bench.py --gpus N --steps K --warmup W`; for N > 1 under torch.distributed.run, one rank per
+GPU over RCCL: agents are dealt round-robin to ranks (agent a lives on rank a % N), public poses travel through
+all_gather / broadcast of packed device buffers, and the evaluation becomes a block-wise all_reduce.
+
+Prints ONE JSON line on rank 0 (see the task contract) with two extra objects:
+  roofline     -- Q-apply kernel (Y = X Q + G, the connection-Laplacian SpMM) timed live with HIP events
+  cpu_baseline -- the CPU oracle (oracle/, a port of the reference algorithm) on a bounded sample of the same
+                  workload, 1 host thread (the reference ships single-threaded: OpenMP off)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--dataset", default="sphere2500")
+    ap.add_argument("--robots", type=int, default=5)
+    ap.add_argument("--rank-r", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=0, help="oracle iterations for cpu_baseline (0 = auto)")
+    return ap.parse_args()
+
+
+def initial_point(da, ds, r, seed=20250310):
+    rng = np.random.default_rng(seed)
+    M = rng.uniform(-1.0, 1.0, (r, (ds.d + 1) * ds.n))
+    return da.manifold_project(r, ds.d, ds.n, M)
+
+
+def run_single(args, da, torch, ds, X0):
+    s = da.RbcdSession(ds, num_robots=args.robots, r=args.rank_r)
+    s.set_X(X0)
+    out = s.run(max_iters=args.warmup, rgrad_tol=0.0)
+    sel_next = 0
+    # continue the trajectory: dcora_rbcd_run restarts selection at agent 0, so drive iterate() from here
+    selected = int(out["selected"][-1]) if args.warmup > 0 else 0
+    # one untimed pass to recover the greedy choice after warmup
+    c2, gn, bn, selected = s.iterate(selected)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    costs = []
+    for _ in range(args.steps):
+        c2, gn, bn, selected = s.iterate(selected)
+    s.synchronize()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return s, dt, c2, gn
+
+
+def run_multi(args, da, torch, dist, ds, X0, rank, world):
+    """one process per GPU; agent a is hosted by rank a % world"""
+    import ctypes as C
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    R, r, dh = args.robots, args.rank_r, ds.d + 1
+    s = da.RbcdSession(ds, num_robots=R, r=r, rank=rank, world_size=world, device=dev.index)
+    s.set_X(X0)
+    counts = [s.public_count(a) for a in range(R)]
+    maxc = max(counts)
+    owner = [a % world for a in range(R)]
+    send = torch.zeros(r * dh * maxc, dtype=torch.float64, device=dev)
+    recv = [torch.zeros(r * dh * maxc, dtype=torch.float64, device=dev) for _ in range(R)]
+    evalbuf = torch.zeros(2 * R, dtype=torch.float64, device=dev)
+
+    def exchange(agents):
+        # getSharedStateDicts -> packed buffer -> broadcast from the owner -> updateNeighborStates
+        for a in agents:
+            buf = recv[a]
+            if owner[a] == rank:
+                s.pack_public_dev(a, buf.data_ptr())
+                s.synchronize()
+            dist.broadcast(buf, src=owner[a])
+            if owner[a] != rank:
+                torch.cuda.current_stream().synchronize()
+                s.unpack_public_dev(a, buf.data_ptr())
+        s.synchronize()
+
+    def step(selected):
+        s.phase_nonselected(selected)
+        s.synchronize()
+        exchange([a for a in range(R) if a != selected])  # selected pulls everyone's public poses
+        s.phase_selected(selected)
+        s.synchronize()
+        exchange([selected])  # the others need the new block for the evaluation / their next G
+        s.phase_evaluate_dev(evalbuf.data_ptr())
+        s.synchronize()
+        dist.all_reduce(evalbuf)
+        h = evalbuf.cpu().numpy()
+        bn = np.sqrt(h[0::2])
+        cost2 = float(h[1::2].sum())  # 2 f = sum_b <X_b, X_b Q_bb + G_b>
+        gn = float(np.sqrt(h[0::2].sum()))
+        return cost2, gn, int(np.argmax(bn))
+
+    selected = 0
+    for _ in range(args.warmup):
+        c2, gn, selected = step(selected)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        c2, gn, selected = step(selected)
+    dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return s, float(t.item()), c2, gn
+
+
+def roofline(da, ds, r):
+    """Q-apply kernel Y = X Q + G on the whole graph, timed with HIP events on its own stream"""
+    Q = da.build_Q_pgo(ds)
+    k = (ds.d + 1) * ds.n
+    P = da.QuadraticProblem(r, ds.d, ds.n, Q, G=np.zeros((r, k)), reg=-1.0)
+    P.f(np.zeros((r, k)))
+    ms, nbytes = P.time_qapply(reps=200)
+    achieved = nbytes / (ms * 1e-3) / 1e9
+    P.close()
+    return {"bound": "hbm", "kernel": "k_spmm (Q-apply, Y = X Q + G)", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "bytes_per_launch": nbytes,
+            "avg_launch_us": ms * 1e3, "k": k, "nnz": Q.nnz}
+
+
+def cpu_baseline(args, ds_name, X0, gpu_ms_per_step):
+    """the CPU oracle on a bounded sample (first iterations of the same trajectory), 1 thread"""
+    import common
+    from oracle import orc
+    dso = common.oracle_dataset(ds_name)
+    n_it = args.cpu_steps or 200
+    # ~21 ms / iteration on a 2 GHz core => 200 iterations ~ 4-6 s; scale up to stay in the 10-30 s window
+    t0 = time.perf_counter()
+    tr = orc.run_rbcd(dso, X0, num_robots=args.robots, r_min=args.rank_r, max_iters=n_it, staircase=0,
+                      rgrad_tol=0.0)
+    if not args.cpu_steps:
+        per = tr["rbcd_seconds"] / max(1, tr["total_iters"])
+        n_it = int(max(200, min(2000, 15.0 / max(per, 1e-6))))
+        tr = orc.run_rbcd(dso, X0, num_robots=args.robots, r_min=args.rank_r, max_iters=n_it, staircase=0,
+                          rgrad_tol=0.0)
+    val = tr["total_iters"] / tr["rbcd_seconds"]
+    return {"value": val, "unit": "RBCD iterations/s", "cores": 1, "kind": "port",
+            "sample": "first %d RBCD iterations of the same workload and start point (loop time only)" %
+                      tr["total_iters"], "ms_per_step": 1e3 / val}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    import torch
+    import common
+    import dcora_amd as da
+    if da.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: libdcora_hip has no CPU fallback")
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    ds = common.product_dataset(args.dataset)
+    X0 = initial_point(da, ds, args.rank_r) if world == 1 else None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl")
+        X0 = initial_point(da, ds, args.rank_r)
+        s, dt, c2, gn = run_multi(args, da, torch, dist, ds, X0, rank, world)
+    else:
+        s, dt, c2, gn = run_single(args, da, torch, ds, X0)
+    if rank != 0:
+        return
+    ms = 1e3 * dt / args.steps
+    line = {
+        "metric": "RBCD iterations/sec, sphere2500 5-agent split",
+        "value": args.steps / dt,
+        "unit": "RBCD iterations/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "%s.g2o (public dataset shipped as a fixture), seeded random start point" % args.dataset,
+        "config": {"workload": "%s.g2o, %d agents, r=%d, RBCD++ (accel, restart 30), RTR 3x50 tCG" %
+                               (args.dataset, args.robots, args.rank_r),
+                   "parallelism": "agents round-robin over %d rank(s)" % world,
+                   "final_cost_2f": c2, "final_gradnorm": gn},
+    }
+    line["roofline"] = roofline(da, ds, args.rank_r)
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(args, args.dataset, X0, ms)
+        line["config"]["speedup_vs_cpu_port"] = line["value"] / line["cpu_baseline"]["value"]
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()
