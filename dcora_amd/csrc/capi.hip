@@ -423,3 +423,29 @@ int dcora_rbcd_synchronize(dcora_rbcd_t s) {
 }
 
 }  // extern "C"
+
+// debug / test hook (not part of the public header): runs one Nesterov bookkeeping kernel on host arrays.
+// flavour 0 = thread-per-pose kernel, 1 = 8-lanes-per-pose kernel.  Arrays are r x (d+1) n, updated in place.
+extern "C" int dcora_debug_nesterov(int flavour, int r, int d, int n, int mode, int restart, int skip_lo, int skip_hi,
+                                    double alpha, double gamma, double *X, double *V, double *Y, double *XPrev,
+                                    double *Yloc, const double *Xloc) {
+  const ManiDesc m = make_mani(r, d, n, 0, 0);
+  const size_t N = (size_t)r * m.k, B = N * sizeof(double);
+  DevBuf<double> dX, dV, dY, dP, dYl, dXl;
+  for (DevBuf<double> *b : {&dX, &dV, &dY, &dP, &dYl, &dXl}) DCORA_HIP(b->alloc(N));
+  DCORA_HIP(hipMemcpy(dX.p, X, B, hipMemcpyHostToDevice));
+  DCORA_HIP(hipMemcpy(dV.p, V, B, hipMemcpyHostToDevice));
+  DCORA_HIP(hipMemcpy(dY.p, Y, B, hipMemcpyHostToDevice));
+  DCORA_HIP(hipMemcpy(dP.p, XPrev, B, hipMemcpyHostToDevice));
+  DCORA_HIP(hipMemcpy(dYl.p, Yloc, B, hipMemcpyHostToDevice));
+  DCORA_HIP(hipMemcpy(dXl.p, Xloc, B, hipMemcpyHostToDevice));
+  (flavour ? launch_g_nesterov : launch_nesterov)(nullptr, m, mode, restart, skip_lo, skip_hi, alpha, gamma, dX.p, dV.p,
+                                                  dY.p, dP.p, dYl.p, dXl.p);
+  DCORA_HIP(hipDeviceSynchronize());
+  DCORA_HIP(hipMemcpy(X, dX.p, B, hipMemcpyDeviceToHost));
+  DCORA_HIP(hipMemcpy(V, dV.p, B, hipMemcpyDeviceToHost));
+  DCORA_HIP(hipMemcpy(Y, dY.p, B, hipMemcpyDeviceToHost));
+  DCORA_HIP(hipMemcpy(XPrev, dP.p, B, hipMemcpyDeviceToHost));
+  DCORA_HIP(hipMemcpy(Yloc, dYl.p, B, hipMemcpyDeviceToHost));
+  return DCORA_OK;
+}

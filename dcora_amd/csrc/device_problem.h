@@ -91,6 +91,8 @@ class DeviceProblem {
   // solver workspace
   DevBuf<double> X0, X1, EG0, EG1, RG0, RG1, S0, S1;
   DevBuf<double> delta, eta, Heta, res, z, Hd, W, Zt;
+  DevBuf<double> delta2, res2, Zpart;  // fused path: ping-pong direction / residual, split-K slices
+  bool fused = false;                  // SE layout, r <= 8: three-launch tCG iteration (solver_fused.hip)
   DevBuf<double> pA, pB, pC, p1, p2, p3, scal;
   DevBuf<SolverCtl> ctl;
   HostFlags *hf = nullptr;      // host-mapped
@@ -113,6 +115,10 @@ class DeviceProblem {
   // EG = X Q + G, partials pA (npA slots of 2)
   int npA() const { return spmm_grid(m.k, m.r); }
   int npPose() const { return pose_grid(m); }
+  // rgrad / retract with the kernel flavour of this problem; return the number of partial slots written
+  int enq_rgrad(Buf2 X, Buf2 EG, Buf2 RG, Buf2 S, int sel, double *partials, Gate g);
+  int enq_retract(Buf2 X, const double *V, double alpha, Buf2 out, int selOut, Buf2 grad, const double *HV,
+                  double *partials, Gate g);
   int npVec() const { return vec_grid(nelem()); }
   void enqueue_egrad(const double *X, double *EG, double *partials);
   void enqueue_precond(const double *X, const double *V, double *out);  // out = Proj_X(V Minv)
@@ -138,6 +144,7 @@ class DeviceProblem {
 
  private:
   int rtr_dev(const dcora_ropt_params &prm, dcora_ropt_result *res, double **Xres);
+  int rtr_dev_fused(const dcora_ropt_params &prm, dcora_ropt_result *res, double **Xres);
   int rgd_dev(const dcora_ropt_params &prm, dcora_ropt_result *res, double **Xres);
   int upload(const double *h, double *d, size_t n);
   int download(const double *d, double *h, size_t n);

@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -85,6 +86,15 @@ int DeviceProblem::init(const dcora_dims &dims, const HostCsr &Qh, const double 
   DCORA_HIP(hipMemset(G.p, 0, N * sizeof(double)));
   for (DevBuf<double> *b : {&X0, &X1, &EG0, &EG1, &RG0, &RG1, &delta, &eta, &Heta, &res, &z, &Hd, &W, &Zt})
     DCORA_HIP(b->alloc(N));
+  fused = fused_supported(m) && (std::getenv("DCORA_SOLVER_V1") == nullptr);
+  if (fused) {
+    DCORA_HIP(delta2.alloc(N));
+    DCORA_HIP(res2.alloc(N));
+    DCORA_HIP(Zpart.alloc((size_t)fused_nsplit(m) * N));
+    DCORA_HIP(hipMemset(delta2.p, 0, N * sizeof(double)));
+  }
+  for (DevBuf<double> *b : {&delta, &eta, &Heta, &res, &z, &Hd, &W, &Zt})
+    DCORA_HIP(hipMemset(b->p, 0, N * sizeof(double)));
   DCORA_HIP(S0.alloc(NS));
   DCORA_HIP(S1.alloc(NS));
   for (DevBuf<double> *b : {&pA, &pB, &pC, &p1, &p2, &p3}) DCORA_HIP(b->alloc(2 * kMaxPartials));
@@ -132,7 +142,7 @@ int DeviceProblem::build_preconditioner(const HostCsr &Qh, double reg) {
     return DCORA_ERR_NOT_PD;
   }
   precond_nnzL = chol.nnzL();
-  ldm = ((k + 15) / 16) * 16;
+  ldm = ((k + 127) / 128) * 128;  // rows padded so every 16-byte column-pair load of a 128-column chunk is in bounds
   std::vector<double> inv((size_t)k * ldm, 0.0);
   unsigned hw = std::thread::hardware_concurrency();
   chol.dense_inverse(inv.data(), (size_t)ldm, (int)std::max(1u, std::min(hw, 32u)));
@@ -146,6 +156,18 @@ int DeviceProblem::build_preconditioner(const HostCsr &Qh, double reg) {
 
 void DeviceProblem::enqueue_egrad(const double *X, double *EG, double *partials) {
   launch_spmm(st, m.r, Q.view(), buf1(X), 0, has_G ? G.p : nullptr, buf1(EG), 0, partials, Gate{});
+}
+
+int DeviceProblem::enq_rgrad(Buf2 X, Buf2 EG, Buf2 RG, Buf2 S, int sel, double *partials, Gate g) {
+  if (fused) return launch_g_rgrad(st, m, X, EG, RG, S, sel, partials, g);
+  launch_rgrad(st, m, X, EG, RG, S, sel, partials, g);
+  return pose_grid(m);
+}
+int DeviceProblem::enq_retract(Buf2 X, const double *V, double alpha, Buf2 out, int selOut, Buf2 grad,
+                               const double *HV, double *partials, Gate g) {
+  if (fused) return launch_g_retract(st, m, X, V, alpha, out, selOut, grad, HV, partials, g);
+  launch_retract(st, m, X, V, alpha, out, selOut, grad, HV, partials, g);
+  return pose_grid(m);
 }
 
 void DeviceProblem::enqueue_precond(const double *X, const double *V, double *out) {
@@ -329,6 +351,7 @@ int DeviceProblem::rtr_dev(const dcora_ropt_params &prm, dcora_ropt_result *res_
     set_last_error("RTR requires the preconditioner (ref src/QuadraticProblem.cpp:78-82)");
     return DCORA_ERR_NO_PRECONDITIONER;
   }
+  if (fused) return rtr_dev_fused(prm, res_out, Xres);
   constexpr int kLookahead = 2;
   const auto t0 = std::chrono::steady_clock::now();
   const bool single = (prm.RTR_iterations == 1);
@@ -403,6 +426,99 @@ int DeviceProblem::rtr_dev(const dcora_ropt_params &prm, dcora_ropt_result *res_
     launch_spmm(st, m.r, Qv, Xb(), 1, Gp, EGb(), 1, pA.p, Gate{c, ++seq, 1});
     launch_rgrad(st, m, Xb(), EGb(), RGb(), Sb(), 1, pB.p, Gate{c, ++seq, 1});
     launch_rtr_decide(st, pA.p, nA, pB.p, nP, pC.p, nP, c, hf_dev, ++seq);
+    last_pace_seq = seq;
+  }
+  DCORA_HIP(hipMemcpyAsync(&h, ctl.p, sizeof h, hipMemcpyDeviceToHost, st));
+  DCORA_HIP(hipStreamSynchronize(st));
+  DCORA_HIP(hipGetLastError());
+  *Xres = (h.cur & 1) ? X1.p : X0.p;
+  if (res_out) {
+    res_out->success = 1;
+    res_out->fInit = h.fInit;
+    res_out->gradNormInit = h.gradNormInit;
+    res_out->fOpt = h.f1;
+    res_out->gradNormOpt = h.ngf;
+    res_out->elapsedMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    res_out->tCGStatus = h.tcg_status;
+    res_out->outer_iterations = h.outer_it;
+    res_out->inner_iterations = h.inner_total;
+    res_out->accepted_steps = h.accepted;
+  }
+  return DCORA_OK;
+}
+
+// Same algorithm with the fused kernels of solver_fused.hip: per tCG iteration
+//   A (direction update + Q-apply + Riemannian Hessian correction + <d,Hd>)
+//   B (step length + vector updates + |r|^2 + dense preconditioner slices)
+//   C (stopping rule + slice sum + tangent projection + <z,r>)
+int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm, dcora_ropt_result *res_out, double **Xres) {
+  constexpr int kLookahead = 2;
+  const auto t0 = std::chrono::steady_clock::now();
+  const bool single = (prm.RTR_iterations == 1);
+  SolverCtl h;
+  std::memset(&h, 0, sizeof h);
+  h.tol = prm.gradnorm_tol;
+  h.Delta = prm.RTR_initial_radius;
+  h.maxDelta = single ? prm.RTR_initial_radius : 5 * prm.RTR_initial_radius;
+  h.max_outer = single ? 12 : prm.RTR_iterations;
+  h.stop_on_accept = single ? 1 : 0;
+  h.max_inner = prm.RTR_tCG_iterations;
+  h.outer_done_stamp = INT_MAX;
+  h.tcg_done_stamp = INT_MAX;
+  h.tcg_status = 4;
+  DCORA_HIP(hipMemcpyAsync(ctl.p, &h, sizeof h, hipMemcpyHostToDevice, st));
+  DCORA_HIP(hipStreamSynchronize(st));
+  hf->last_seq_done = 0;
+  hf->tcg_done_seq = 0;
+  hf->outer_done_seq = 0;
+  SolverCtl *c = ctl.p;
+  const CsrDev Qv = Q.view();
+  const double *Gp = has_G ? G.p : nullptr;
+  const int nA = npA(), nPB = fused_pose_blocks(m), nPG = fused_precond_grid(m);
+  double *dbuf[2] = {delta.p, delta2.p};
+  double *rbuf[2] = {res.p, res2.p};
+  int seq = 0;
+  auto timed_out = [&]() {
+    set_last_error("rtr_dev_fused: device did not make progress (spin timeout)");
+    return DCORA_ERR_HIP;
+  };
+  launch_spmm(st, m.r, Qv, Xb(), 0, Gp, EGb(), 0, pA.p, Gate{c, ++seq, 0});
+  int nG = enq_rgrad(Xb(), EGb(), RGb(), Sb(), 0, pB.p, Gate{c, ++seq, 0});
+  launch_rtr_init(st, pA.p, nA, pB.p, nG, c, hf_dev, ++seq);
+  int last_pace_seq = seq;
+  std::vector<int> fin_seq((size_t)std::max(1, h.max_inner));
+  for (int outer = 0; outer < h.max_outer; ++outer) {
+    if (!spin_until([&] { return hf->last_seq_done >= last_pace_seq || hf->outer_done_seq != 0; }, 20.0))
+      return timed_out();
+    if (hf->outer_done_seq != 0) break;
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0) break;
+    // z0 = P(grad): B in "first" mode streams the preconditioner over grad, C projects and forms <z0, r0>
+    launch_fused_precond(st, m, ldm, Minv.p, RGb(), nullptr, nullptr, eta.p, Heta.p, nullptr, rbuf[0], Zpart.p,
+                         nullptr, 0, p2.p, c, hf_dev, ++seq, 0, 1);
+    const int tcg_first_seq = seq;
+    launch_fused_finish(st, m, Xb(), Zpart.p, rbuf[0], z.p, nullptr, 0, p3.p, c, hf_dev, ++seq, 0, 1);
+    for (int j = 0; j < h.max_inner; ++j) {
+      if (j >= kLookahead) {
+        const int need = fin_seq[j - kLookahead];
+        if (!spin_until(
+                [&] {
+                  return hf->last_seq_done >= need || hf->tcg_done_seq >= tcg_first_seq || hf->outer_done_seq != 0;
+                },
+                20.0))
+          return timed_out();
+      }
+      if (hf->tcg_done_seq >= tcg_first_seq) break;
+      const int par = j & 1;
+      launch_fused_hess(st, m, Qv, z.p, dbuf[par ^ 1], dbuf[par], Xb(), Sb(), Hd.p, p3.p, nPB, p1.p, c, ++seq, j);
+      launch_fused_precond(st, m, ldm, Minv.p, RGb(), dbuf[par], Hd.p, eta.p, Heta.p, rbuf[par], rbuf[par ^ 1],
+                           Zpart.p, p1.p, nPB, p2.p, c, hf_dev, ++seq, j, 0);
+      launch_fused_finish(st, m, Xb(), Zpart.p, rbuf[par ^ 1], z.p, p2.p, nPG, p3.p, c, hf_dev, ++seq, j, 0);
+      fin_seq[j] = seq;
+    }
+    const int nR = enq_retract(Xb(), eta.p, 1.0, Xb(), 1, RGb(), Heta.p, pC.p, Gate{c, ++seq, 1});
+    launch_spmm(st, m.r, Qv, Xb(), 1, Gp, EGb(), 1, pA.p, Gate{c, ++seq, 1});
+    nG = enq_rgrad(Xb(), EGb(), RGb(), Sb(), 1, pB.p, Gate{c, ++seq, 1});
+    launch_rtr_decide(st, pA.p, nA, pB.p, nG, pC.p, nR, c, hf_dev, ++seq);
     last_pace_seq = seq;
   }
   DCORA_HIP(hipMemcpyAsync(&h, ctl.p, sizeof h, hipMemcpyDeviceToHost, st));

@@ -147,4 +147,28 @@ void launch_scale_shift(hipStream_t st, int n, double shift, const double *x, do
 void launch_scale(hipStream_t st, int n, const double *alpha_dev_inv_sqrt /*device: w /= sqrt(*p)*/,
                   const double *w, double *out);
 
+// ---- fused SE-layout solver kernels (solver_fused.hip): 8 lanes per pose, three launches per tCG iteration ----
+bool fused_supported(const ManiDesc &m);
+int fused_pose_blocks(const ManiDesc &m);   // partial slots written by hess / finish
+int fused_nsplit(const ManiDesc &m);        // row slices of the dense preconditioner product
+int fused_precond_grid(const ManiDesc &m);  // partial slots written by precond
+void launch_fused_hess(hipStream_t st, const ManiDesc &m, const CsrDev &Q, const double *z, const double *d_old,
+                       double *d_new, Buf2 X, Buf2 S, double *Hd, const double *p3, int np3, double *p1,
+                       SolverCtl *ctl, int seq, int iter);
+void launch_fused_precond(hipStream_t st, const ManiDesc &m, int ldm, const double *Minv, Buf2 grad,
+                          const double *delta, const double *Hd, double *eta, double *Heta, const double *res_old,
+                          double *res_new, double *Zpart, const double *p1, int np1, double *p2, SolverCtl *ctl,
+                          HostFlags *hf, int seq, int iter, int first);
+void launch_fused_finish(hipStream_t st, const ManiDesc &m, Buf2 X, const double *Zpart, const double *res,
+                         double *z, const double *p2, int np2, double *p3, SolverCtl *ctl, HostFlags *hf, int seq,
+                         int iter, int first);
+// group-style (8 lanes per pose) rgrad / retract / Nesterov; return the number of partial slots written
+int launch_g_rgrad(hipStream_t st, const ManiDesc &m, Buf2 X, Buf2 EG, Buf2 RG, Buf2 Sblk, int sel, double *partials,
+                   Gate g);
+int launch_g_retract(hipStream_t st, const ManiDesc &m, Buf2 X, const double *V, double alpha, Buf2 out, int selOut,
+                     Buf2 grad, const double *HV, double *partials, Gate g);
+void launch_g_nesterov(hipStream_t st, const ManiDesc &m, int mode, int restart, int skip_lo, int skip_hi,
+                       double alpha, double gamma, double *X, double *V, double *Y, double *XPrev, double *Yloc,
+                       const double *Xloc);
+
 }  // namespace dcora

@@ -4,9 +4,15 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <set>
 
 namespace dcora {
+
+static bool group_kernels(const ManiDesc &m) {
+  static const bool v1 = std::getenv("DCORA_NESTEROV_V1") != nullptr;
+  return fused_supported(m) && !v1;
+}
 
 RbcdSession::~RbcdSession() {
   agents.clear();
@@ -146,14 +152,16 @@ int RbcdSession::phase_nonselected(int selected) {
   const int restart = restart_now() ? 1 : 0;
   if (opt.world_size == 1) {
     // one launch over the whole graph, skipping the selected agent's poses
-    launch_nesterov(st, mg, 0, restart, P.start(selected), P.end(selected), alpha, gamma, Xg.p, Vg.p, Yg.p, XPrevg.p,
-                    nullptr, nullptr);
+    (group_kernels(mg) ? launch_g_nesterov : launch_nesterov)(st, mg, 0, restart, P.start(selected),
+                                                                 P.end(selected), alpha, gamma, Xg.p, Vg.p, Yg.p,
+                                                                 XPrevg.p, nullptr, nullptr);
   } else {
     for (AgentDev &a : agents) {
       if (!a.hosted || a.id == selected) continue;
       const size_t off = (size_t)a.col0 * r;
-      launch_nesterov(st, a.prob->m, 0, restart, -1, -1, alpha, gamma, Xg.p + off, Vg.p + off, Yg.p + off,
-                      XPrevg.p + off, nullptr, nullptr);
+      (group_kernels(a.prob->m) ? launch_g_nesterov : launch_nesterov)(st, a.prob->m, 0, restart, -1, -1, alpha,
+                                                                         gamma, Xg.p + off, Vg.p + off, Yg.p + off,
+                                                                         XPrevg.p + off, nullptr, nullptr);
     }
   }
   return DCORA_OK;
@@ -176,19 +184,20 @@ int RbcdSession::phase_selected(int selected) {
     launch_spmm(st, r, a.coupling.view(), buf1(Xg.p), 0, nullptr, buf1(pb.G.p), 0, nullptr, Gate{});
     pb.has_G = true;
     double *Xres = nullptr;
+    auto nest = group_kernels(pb.m) ? launch_g_nesterov : launch_nesterov;
     if (opt.acceleration) {
-      launch_nesterov(st, pb.m, 1, 0, -1, -1, alpha, gamma, Xg.p + off, Vg.p + off, Yg.p + off, XPrevg.p + off,
+      nest(st, pb.m, 1, 0, -1, -1, alpha, gamma, Xg.p + off, Vg.p + off, Yg.p + off, XPrevg.p + off,
                       pb.X0.p, nullptr);
       rc = pb.optimize_dev(opt.local, &last, &Xres);
       if (rc) return rc;
-      launch_nesterov(st, pb.m, 2, 0, -1, -1, alpha, gamma, Xg.p + off, Vg.p + off, Yg.p + off, XPrevg.p + off,
+      nest(st, pb.m, 2, 0, -1, -1, alpha, gamma, Xg.p + off, Vg.p + off, Yg.p + off, XPrevg.p + off,
                       nullptr, Xres);
       if (restart) {
         // restartNesterovAcceleration: X = XPrev; updateX(true, false); V = X; Y = X
         DCORA_HIP(hipMemcpyAsync(pb.X0.p, XPrevg.p + off, B, hipMemcpyDeviceToDevice, st));
         rc = pb.optimize_dev(opt.local, &last, &Xres);
         if (rc) return rc;
-        launch_nesterov(st, pb.m, 3, 0, -1, -1, alpha, gamma, Xg.p + off, Vg.p + off, Yg.p + off, XPrevg.p + off,
+        nest(st, pb.m, 3, 0, -1, -1, alpha, gamma, Xg.p + off, Vg.p + off, Yg.p + off, XPrevg.p + off,
                         nullptr, Xres);
       }
     } else {
@@ -211,7 +220,7 @@ int RbcdSession::evaluate_central(double *cost2, double *gradnorm, double *block
   }
   DeviceProblem &c = *central;
   c.enqueue_egrad(Xg.p, c.EG0.p, c.pA.p);
-  launch_rgrad(st, mg, buf1(Xg.p), buf1(c.EG0.p), buf1(c.RG0.p), Buf2{{nullptr, nullptr}}, 0, c.pB.p, Gate{});
+  c.enq_rgrad(buf1(Xg.p), buf1(c.EG0.p), buf1(c.RG0.p), Buf2{{nullptr, nullptr}}, 0, c.pB.p, Gate{});
   launch_block_dots(st, r, R, col_start.p, c.RG0.p, nullptr, evalbuf.p);
   launch_sum_partials(st, c.pA.p, c.npA(), 2, 2, evalbuf.p + 2 * R);
   std::vector<double> h(2 * R + 2);
