@@ -381,8 +381,7 @@ int dcora_rbcd_run(dcora_rbcd_t s, int max_iters, double rgrad_tol, int *iters_d
 }
 int dcora_rbcd_last_result(dcora_rbcd_t s, dcora_ropt_result *res) {
   if (!s || !res) return bad("null");
-  *res = s->s.last;
-  return DCORA_OK;
+  return s->s.last_result(res);
 }
 int dcora_rbcd_X_device_ptr(dcora_rbcd_t s, double **X_dev) {
   if (!s) return bad("null");
@@ -439,8 +438,11 @@ extern "C" int dcora_debug_nesterov(int flavour, int r, int d, int n, int mode, 
   DCORA_HIP(hipMemcpy(dP.p, XPrev, B, hipMemcpyHostToDevice));
   DCORA_HIP(hipMemcpy(dYl.p, Yloc, B, hipMemcpyHostToDevice));
   DCORA_HIP(hipMemcpy(dXl.p, Xloc, B, hipMemcpyHostToDevice));
-  (flavour ? launch_g_nesterov : launch_nesterov)(nullptr, m, mode, restart, skip_lo, skip_hi, alpha, gamma, dX.p, dV.p,
-                                                  dY.p, dP.p, dYl.p, dXl.p);
+  if (flavour)
+    launch_g_nesterov(nullptr, m, mode, restart, skip_lo, skip_hi, alpha, gamma, dX.p, dV.p, dY.p, dP.p, dYl.p,
+                      buf1(dXl.p), nullptr);
+  else
+    launch_nesterov(nullptr, m, mode, restart, skip_lo, skip_hi, alpha, gamma, dX.p, dV.p, dY.p, dP.p, dYl.p, dXl.p);
   DCORA_HIP(hipDeviceSynchronize());
   DCORA_HIP(hipMemcpy(X, dX.p, B, hipMemcpyDeviceToHost));
   DCORA_HIP(hipMemcpy(V, dV.p, B, hipMemcpyDeviceToHost));

@@ -116,7 +116,7 @@ class DeviceProblem {
   int npA() const { return spmm_grid(m.k, m.r); }
   int npPose() const { return pose_grid(m); }
   // rgrad / retract with the kernel flavour of this problem; return the number of partial slots written
-  int enq_rgrad(Buf2 X, Buf2 EG, Buf2 RG, Buf2 S, int sel, double *partials, Gate g);
+  int enq_rgrad(Buf2 X, Buf2 EG, Buf2 RG, Buf2 S, int sel, double *partials, Gate g, double *posenorm = nullptr);
   int enq_retract(Buf2 X, const double *V, double alpha, Buf2 out, int selOut, Buf2 grad, const double *HV,
                   double *partials, Gate g);
   int npVec() const { return vec_grid(nelem()); }
@@ -136,7 +136,12 @@ class DeviceProblem {
                     int *success);
 
   // ---- device-resident solve: X0.p holds the start point; on return *Xres points at the result buffer ----
-  int optimize_dev(const dcora_ropt_params &prm, dcora_ropt_result *res, double **Xres);
+  // The fused path returns without synchronising: the result lives in Xres->p[(*ctl_out)->cur] (device-side
+  // pick), statistics are fetched later with fetch_result().  Other paths return ctl_out = nullptr and a
+  // resolved pointer in Xres->p[0].
+  int optimize_dev(const dcora_ropt_params &prm, Buf2 *Xres, const SolverCtl **ctl_out);
+  int fetch_result(dcora_ropt_result *res);
+  int result_index() const { return cur_after_fetch_; }  // synchronises when a fused solve is still in flight
   // scalars of an arbitrary point on device: f and |rgrad| (synchronises)
   int eval_dev(const double *Xd, double *f, double *gradnorm);
 
@@ -144,8 +149,13 @@ class DeviceProblem {
 
  private:
   int rtr_dev(const dcora_ropt_params &prm, dcora_ropt_result *res, double **Xres);
-  int rtr_dev_fused(const dcora_ropt_params &prm, dcora_ropt_result *res, double **Xres);
+  int rtr_dev_fused(const dcora_ropt_params &prm);
   int rgd_dev(const dcora_ropt_params &prm, dcora_ropt_result *res, double **Xres);
+  int seq_ = 0;            // launch sequence number, monotonic across solves (HostFlags words are never reset)
+  bool pending_ = false;   // a fused solve has been enqueued and its statistics not yet fetched
+  double t0_ms_ = 0;
+  dcora_ropt_result last_res_{};
+  int cur_after_fetch_ = 0;
   int upload(const double *h, double *d, size_t n);
   int download(const double *d, double *h, size_t n);
 };

@@ -158,8 +158,9 @@ void DeviceProblem::enqueue_egrad(const double *X, double *EG, double *partials)
   launch_spmm(st, m.r, Q.view(), buf1(X), 0, has_G ? G.p : nullptr, buf1(EG), 0, partials, Gate{});
 }
 
-int DeviceProblem::enq_rgrad(Buf2 X, Buf2 EG, Buf2 RG, Buf2 S, int sel, double *partials, Gate g) {
-  if (fused) return launch_g_rgrad(st, m, X, EG, RG, S, sel, partials, g);
+int DeviceProblem::enq_rgrad(Buf2 X, Buf2 EG, Buf2 RG, Buf2 S, int sel, double *partials, Gate g,
+                             double *posenorm) {
+  if (fused) return launch_g_rgrad(st, m, X, EG, RG, S, sel, partials, posenorm, g);
   launch_rgrad(st, m, X, EG, RG, S, sel, partials, g);
   return pose_grid(m);
 }
@@ -275,17 +276,61 @@ int DeviceProblem::optimize(const dcora_ropt_params &prm, const double *X0h, dou
   DCORA_HIP(hipSetDevice(device));
   int rc = upload(X0h, X0.p, nelem());
   if (rc) return rc;
-  double *Xres = nullptr;
+  Buf2 Xres{{nullptr, nullptr}};
+  const SolverCtl *c = nullptr;
+  rc = optimize_dev(prm, &Xres, &c);
+  if (rc) return rc;
   dcora_ropt_result r{};
-  rc = optimize_dev(prm, &r, &Xres);
+  rc = fetch_result(&r);  // synchronises; also resolves which buffer holds the accepted iterate
   if (rc) return rc;
   if (res_out) *res_out = r;
-  return download(Xres, Xout, nelem());
+  return download(c ? (cur_after_fetch_ ? X1.p : X0.p) : Xres.p[0], Xout, nelem());
 }
 
-int DeviceProblem::optimize_dev(const dcora_ropt_params &prm, dcora_ropt_result *res_out, double **Xres) {
-  if (prm.method == 0) return rtr_dev(prm, res_out, Xres);
-  return rgd_dev(prm, res_out, Xres);
+int DeviceProblem::optimize_dev(const dcora_ropt_params &prm, Buf2 *Xres, const SolverCtl **ctl_out) {
+  *ctl_out = nullptr;
+  pending_ = false;
+  if (prm.method == 0 && fused) {
+    if (!has_precond) {
+      set_last_error("RTR requires the preconditioner (ref src/QuadraticProblem.cpp:78-82)");
+      return DCORA_ERR_NO_PRECONDITIONER;
+    }
+    const int rc = rtr_dev_fused(prm);
+    if (rc) return rc;
+    *Xres = Xb();
+    *ctl_out = ctl.p;
+    pending_ = true;
+    return DCORA_OK;
+  }
+  double *p = nullptr;
+  const int rc = (prm.method == 0) ? rtr_dev(prm, &last_res_, &p) : rgd_dev(prm, &last_res_, &p);
+  *Xres = Buf2{{p, p}};
+  return rc;
+}
+
+int DeviceProblem::fetch_result(dcora_ropt_result *res_out) {
+  if (pending_) {
+    SolverCtl h;
+    DCORA_HIP(hipMemcpyAsync(&h, ctl.p, sizeof h, hipMemcpyDeviceToHost, st));
+    DCORA_HIP(hipStreamSynchronize(st));
+    DCORA_HIP(hipGetLastError());
+    const double now = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch())
+                           .count();
+    cur_after_fetch_ = h.cur & 1;
+    last_res_.success = 1;
+    last_res_.fInit = h.fInit;
+    last_res_.gradNormInit = h.gradNormInit;
+    last_res_.fOpt = h.f1;
+    last_res_.gradNormOpt = h.ngf;
+    last_res_.elapsedMs = now - t0_ms_;
+    last_res_.tCGStatus = h.tcg_status;
+    last_res_.outer_iterations = h.outer_it;
+    last_res_.inner_iterations = h.inner_total;
+    last_res_.accepted_steps = h.accepted;
+    pending_ = false;
+  }
+  if (res_out) *res_out = last_res_;
+  return DCORA_OK;
 }
 
 // one preconditioned Riemannian gradient step (ref src/QuadraticOptimizer.cpp:123-150)
@@ -351,7 +396,6 @@ int DeviceProblem::rtr_dev(const dcora_ropt_params &prm, dcora_ropt_result *res_
     set_last_error("RTR requires the preconditioner (ref src/QuadraticProblem.cpp:78-82)");
     return DCORA_ERR_NO_PRECONDITIONER;
   }
-  if (fused) return rtr_dev_fused(prm, res_out, Xres);
   constexpr int kLookahead = 2;
   const auto t0 = std::chrono::steady_clock::now();
   const bool single = (prm.RTR_iterations == 1);
@@ -451,60 +495,54 @@ int DeviceProblem::rtr_dev(const dcora_ropt_params &prm, dcora_ropt_result *res_
 //   A (direction update + Q-apply + Riemannian Hessian correction + <d,Hd>)
 //   B (step length + vector updates + |r|^2 + dense preconditioner slices)
 //   C (stopping rule + slice sum + tangent projection + <z,r>)
-int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm, dcora_ropt_result *res_out, double **Xres) {
+int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
   constexpr int kLookahead = 2;
   const auto t0 = std::chrono::steady_clock::now();
+  t0_ms_ = std::chrono::duration<double, std::milli>(t0.time_since_epoch()).count();
   const bool single = (prm.RTR_iterations == 1);
-  SolverCtl h;
-  std::memset(&h, 0, sizeof h);
-  h.tol = prm.gradnorm_tol;
-  h.Delta = prm.RTR_initial_radius;
-  h.maxDelta = single ? prm.RTR_initial_radius : 5 * prm.RTR_initial_radius;
-  h.max_outer = single ? 12 : prm.RTR_iterations;
-  h.stop_on_accept = single ? 1 : 0;
-  h.max_inner = prm.RTR_tCG_iterations;
-  h.outer_done_stamp = INT_MAX;
-  h.tcg_done_stamp = INT_MAX;
-  h.tcg_status = 4;
-  DCORA_HIP(hipMemcpyAsync(ctl.p, &h, sizeof h, hipMemcpyHostToDevice, st));
-  DCORA_HIP(hipStreamSynchronize(st));
-  hf->last_seq_done = 0;
-  hf->tcg_done_seq = 0;
-  hf->outer_done_seq = 0;
+  const int max_outer = single ? 12 : prm.RTR_iterations;  // ref :254-273 (<= 11 retries)
+  const int max_inner = prm.RTR_tCG_iterations;
+  if (seq_ > 1500000000) {  // keep the monotonic sequence far from INT_MAX
+    DCORA_HIP(hipStreamSynchronize(st));
+    hf->last_seq_done = 0;
+    hf->tcg_done_seq = 0;
+    hf->outer_done_seq = 0;
+    seq_ = 0;
+  }
+  int &seq = seq_;
   SolverCtl *c = ctl.p;
+  launch_ctl_init(st, c, prm.gradnorm_tol, prm.RTR_initial_radius,
+                  single ? prm.RTR_initial_radius : 5 * prm.RTR_initial_radius, max_outer, single ? 1 : 0, max_inner);
+  const int solve_first = seq + 1;
   const CsrDev Qv = Q.view();
   const double *Gp = has_G ? G.p : nullptr;
   const int nA = npA(), nPB = fused_pose_blocks(m), nPG = fused_precond_grid(m);
   double *dbuf[2] = {delta.p, delta2.p};
   double *rbuf[2] = {res.p, res2.p};
-  int seq = 0;
   auto timed_out = [&]() {
     set_last_error("rtr_dev_fused: device did not make progress (spin timeout)");
     return DCORA_ERR_HIP;
   };
+  auto outer_done = [&]() { return hf->outer_done_seq >= solve_first; };
   launch_spmm(st, m.r, Qv, Xb(), 0, Gp, EGb(), 0, pA.p, Gate{c, ++seq, 0});
   int nG = enq_rgrad(Xb(), EGb(), RGb(), Sb(), 0, pB.p, Gate{c, ++seq, 0});
   launch_rtr_init(st, pA.p, nA, pB.p, nG, c, hf_dev, ++seq);
   int last_pace_seq = seq;
-  std::vector<int> fin_seq((size_t)std::max(1, h.max_inner));
-  for (int outer = 0; outer < h.max_outer; ++outer) {
-    if (!spin_until([&] { return hf->last_seq_done >= last_pace_seq || hf->outer_done_seq != 0; }, 20.0))
-      return timed_out();
-    if (hf->outer_done_seq != 0) break;
-    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0) break;
+  std::vector<int> fin_seq((size_t)std::max(1, max_inner));
+  for (int outer = 0; outer < max_outer; ++outer) {
+    if (!spin_until([&] { return hf->last_seq_done >= last_pace_seq || outer_done(); }, 20.0)) return timed_out();
+    if (outer_done()) break;
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0) break;  // TimeBound :252
     // z0 = P(grad): B in "first" mode streams the preconditioner over grad, C projects and forms <z0, r0>
     launch_fused_precond(st, m, ldm, Minv.p, RGb(), nullptr, nullptr, eta.p, Heta.p, nullptr, rbuf[0], Zpart.p,
                          nullptr, 0, p2.p, c, hf_dev, ++seq, 0, 1);
     const int tcg_first_seq = seq;
     launch_fused_finish(st, m, Xb(), Zpart.p, rbuf[0], z.p, nullptr, 0, p3.p, c, hf_dev, ++seq, 0, 1);
-    for (int j = 0; j < h.max_inner; ++j) {
+    for (int j = 0; j < max_inner; ++j) {
       if (j >= kLookahead) {
         const int need = fin_seq[j - kLookahead];
         if (!spin_until(
-                [&] {
-                  return hf->last_seq_done >= need || hf->tcg_done_seq >= tcg_first_seq || hf->outer_done_seq != 0;
-                },
-                20.0))
+                [&] { return hf->last_seq_done >= need || hf->tcg_done_seq >= tcg_first_seq || outer_done(); }, 20.0))
           return timed_out();
       }
       if (hf->tcg_done_seq >= tcg_first_seq) break;
@@ -520,22 +558,6 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm, dcora_ropt_result
     nG = enq_rgrad(Xb(), EGb(), RGb(), Sb(), 1, pB.p, Gate{c, ++seq, 1});
     launch_rtr_decide(st, pA.p, nA, pB.p, nG, pC.p, nR, c, hf_dev, ++seq);
     last_pace_seq = seq;
-  }
-  DCORA_HIP(hipMemcpyAsync(&h, ctl.p, sizeof h, hipMemcpyDeviceToHost, st));
-  DCORA_HIP(hipStreamSynchronize(st));
-  DCORA_HIP(hipGetLastError());
-  *Xres = (h.cur & 1) ? X1.p : X0.p;
-  if (res_out) {
-    res_out->success = 1;
-    res_out->fInit = h.fInit;
-    res_out->gradNormInit = h.gradNormInit;
-    res_out->fOpt = h.f1;
-    res_out->gradNormOpt = h.ngf;
-    res_out->elapsedMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    res_out->tCGStatus = h.tcg_status;
-    res_out->outer_iterations = h.outer_it;
-    res_out->inner_iterations = h.inner_total;
-    res_out->accepted_steps = h.accepted;
   }
   return DCORA_OK;
 }

@@ -62,6 +62,14 @@ struct SolverCtl {
   double alpha, e_Pe_n, norm_r0;
   int tcg_done_stamp, tcg_status, tcg_iters, inner_total, max_inner;
 };
+constexpr int kMaxAgents = 64;
+// results of one evaluation pass, in host-mapped memory
+struct EvalOut {
+  double cost2, gradnorm;
+  double block_norms[kMaxAgents];
+  int next;
+  volatile int seq;
+};
 struct HostFlags {
   volatile int last_seq_done;   // seq of the latest pacing kernel whose block 0 finished
   volatile int tcg_done_seq;    // seq at which the current/last tCG terminated
@@ -164,11 +172,15 @@ void launch_fused_finish(hipStream_t st, const ManiDesc &m, Buf2 X, const double
                          int iter, int first);
 // group-style (8 lanes per pose) rgrad / retract / Nesterov; return the number of partial slots written
 int launch_g_rgrad(hipStream_t st, const ManiDesc &m, Buf2 X, Buf2 EG, Buf2 RG, Buf2 Sblk, int sel, double *partials,
-                   Gate g);
+                   double *posenorm, Gate g);
+void launch_ctl_init(hipStream_t st, SolverCtl *c, double tol, double Delta, double maxDelta, int max_outer,
+                     int stop_on_accept, int max_inner);
+void launch_eval_finish(hipStream_t st, int R, const int *pose_start, const double *posenorm, const double *pA,
+                        int npA, EvalOut *out_dev, int seq);
 int launch_g_retract(hipStream_t st, const ManiDesc &m, Buf2 X, const double *V, double alpha, Buf2 out, int selOut,
                      Buf2 grad, const double *HV, double *partials, Gate g);
 void launch_g_nesterov(hipStream_t st, const ManiDesc &m, int mode, int restart, int skip_lo, int skip_hi,
                        double alpha, double gamma, double *X, double *V, double *Y, double *XPrev, double *Yloc,
-                       const double *Xloc);
+                       Buf2 Xloc, const SolverCtl *ctl);
 
 }  // namespace dcora

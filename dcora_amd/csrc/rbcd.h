@@ -30,10 +30,16 @@ class RbcdSession {
   std::unique_ptr<DeviceProblem> central;  // global Q (evaluation); world_size == 1 only
   DevBuf<double> Xg, Vg, Yg, XPrevg;       // r x (d+1) n global mirrors
   DevBuf<int> col_start;                   // R + 1 global column offsets
-  DevBuf<double> evalbuf;
+  DevBuf<double> evalbuf, posenorm;
+  DevBuf<int> pose_start;          // R + 1 global pose offsets
+  EvalOut *eval_host = nullptr;    // host-mapped results of the evaluation epilogue
+  EvalOut *eval_dev = nullptr;
+  int eval_seq = 0;
+  DeviceProblem *last_solver = nullptr;
   double gamma = 0, alpha = 0;
   int iteration = 0;
   dcora_ropt_result last{};
+  int last_result(dcora_ropt_result *res);
   double setup_ms = 0;
 
   ~RbcdSession();

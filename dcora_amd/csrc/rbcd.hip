@@ -2,9 +2,11 @@
 #include "rbcd.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <set>
 
 namespace dcora {
@@ -14,7 +16,17 @@ static bool group_kernels(const ManiDesc &m) {
   return fused_supported(m) && !v1;
 }
 
+static void nesterov(hipStream_t st, const ManiDesc &m, int mode, int restart, int skip_lo, int skip_hi, double alpha,
+                     double gamma, double *X, double *V, double *Y, double *XPrev, double *Yloc, Buf2 Xloc,
+                     const SolverCtl *ctl) {
+  if (group_kernels(m))
+    launch_g_nesterov(st, m, mode, restart, skip_lo, skip_hi, alpha, gamma, X, V, Y, XPrev, Yloc, Xloc, ctl);
+  else  // thread-per-pose kernels: the caller resolved the result pointer (ctl == nullptr)
+    launch_nesterov(st, m, mode, restart, skip_lo, skip_hi, alpha, gamma, X, V, Y, XPrev, Yloc, Xloc.p[0]);
+}
+
 RbcdSession::~RbcdSession() {
+  if (eval_host) (void)hipHostFree((void *)eval_host);
   agents.clear();
   central.reset();
   if (st) (void)hipStreamDestroy(st);
@@ -48,6 +60,14 @@ int RbcdSession::init(const HostDataset &ds, const dcora_rbcd_options &o) {
   DCORA_HIP(Vg.alloc(N));
   DCORA_HIP(Yg.alloc(N));
   DCORA_HIP(XPrevg.alloc(N));
+  if (R > kMaxAgents) {
+    set_last_error("rbcd: more agents than kMaxAgents");
+    return DCORA_ERR_UNSUPPORTED;
+  }
+  DCORA_HIP(posenorm.alloc(n));
+  DCORA_HIP(hipHostMalloc((void **)&eval_host, sizeof(EvalOut), hipHostMallocMapped));
+  std::memset((void *)eval_host, 0, sizeof(EvalOut));
+  DCORA_HIP(hipHostGetDevicePointer((void **)&eval_dev, (void *)eval_host, 0));
   DCORA_HIP(evalbuf.alloc(2 * R + 16));
   DCORA_HIP(hipMemset(evalbuf.p, 0, sizeof(double) * (2 * R + 16)));
 
@@ -97,6 +117,12 @@ int RbcdSession::init(const HostDataset &ds, const dcora_rbcd_options &o) {
     if (rc) return rc;
   }
   cs[R] = dh * n;
+  {
+    std::vector<int> ps(R + 1);
+    for (int b = 0; b <= R; ++b) ps[b] = cs[b] / dh;
+    DCORA_HIP(pose_start.alloc(R + 1));
+    DCORA_HIP(hipMemcpy(pose_start.p, ps.data(), sizeof(int) * (R + 1), hipMemcpyHostToDevice));
+  }
   DCORA_HIP(col_start.alloc(R + 1));
   DCORA_HIP(hipMemcpy(col_start.p, cs.data(), sizeof(int) * (R + 1), hipMemcpyHostToDevice));
   if (o.world_size == 1) {
@@ -152,16 +178,14 @@ int RbcdSession::phase_nonselected(int selected) {
   const int restart = restart_now() ? 1 : 0;
   if (opt.world_size == 1) {
     // one launch over the whole graph, skipping the selected agent's poses
-    (group_kernels(mg) ? launch_g_nesterov : launch_nesterov)(st, mg, 0, restart, P.start(selected),
-                                                                 P.end(selected), alpha, gamma, Xg.p, Vg.p, Yg.p,
-                                                                 XPrevg.p, nullptr, nullptr);
+    nesterov(st, mg, 0, restart, P.start(selected), P.end(selected), alpha, gamma, Xg.p, Vg.p, Yg.p, XPrevg.p, nullptr,
+             Buf2{{nullptr, nullptr}}, nullptr);
   } else {
     for (AgentDev &a : agents) {
       if (!a.hosted || a.id == selected) continue;
       const size_t off = (size_t)a.col0 * r;
-      (group_kernels(a.prob->m) ? launch_g_nesterov : launch_nesterov)(st, a.prob->m, 0, restart, -1, -1, alpha,
-                                                                         gamma, Xg.p + off, Vg.p + off, Yg.p + off,
-                                                                         XPrevg.p + off, nullptr, nullptr);
+      nesterov(st, a.prob->m, 0, restart, -1, -1, alpha, gamma, Xg.p + off, Vg.p + off, Yg.p + off, XPrevg.p + off,
+               nullptr, Buf2{{nullptr, nullptr}}, nullptr);
     }
   }
   return DCORA_OK;
@@ -183,29 +207,36 @@ int RbcdSession::phase_selected(int selected) {
     // (ref src/Graph.cpp:685-822); the mirror Xg holds them after the pull / unpack
     launch_spmm(st, r, a.coupling.view(), buf1(Xg.p), 0, nullptr, buf1(pb.G.p), 0, nullptr, Gate{});
     pb.has_G = true;
-    double *Xres = nullptr;
-    auto nest = group_kernels(pb.m) ? launch_g_nesterov : launch_nesterov;
+    Buf2 Xres{{nullptr, nullptr}};
+    const SolverCtl *cs = nullptr;
+    last_solver = &pb;
     if (opt.acceleration) {
-      nest(st, pb.m, 1, 0, -1, -1, alpha, gamma, Xg.p + off, Vg.p + off, Yg.p + off, XPrevg.p + off,
-                      pb.X0.p, nullptr);
-      rc = pb.optimize_dev(opt.local, &last, &Xres);
+      nesterov(st, pb.m, 1, 0, -1, -1, alpha, gamma, Xg.p + off, Vg.p + off, Yg.p + off, XPrevg.p + off, pb.X0.p,
+               Buf2{{nullptr, nullptr}}, nullptr);
+      rc = pb.optimize_dev(opt.local, &Xres, &cs);
       if (rc) return rc;
-      nest(st, pb.m, 2, 0, -1, -1, alpha, gamma, Xg.p + off, Vg.p + off, Yg.p + off, XPrevg.p + off,
-                      nullptr, Xres);
+      nesterov(st, pb.m, 2, 0, -1, -1, alpha, gamma, Xg.p + off, Vg.p + off, Yg.p + off, XPrevg.p + off, nullptr, Xres,
+               cs);
       if (restart) {
         // restartNesterovAcceleration: X = XPrev; updateX(true, false); V = X; Y = X
         DCORA_HIP(hipMemcpyAsync(pb.X0.p, XPrevg.p + off, B, hipMemcpyDeviceToDevice, st));
-        rc = pb.optimize_dev(opt.local, &last, &Xres);
+        rc = pb.optimize_dev(opt.local, &Xres, &cs);
         if (rc) return rc;
-        nest(st, pb.m, 3, 0, -1, -1, alpha, gamma, Xg.p + off, Vg.p + off, Yg.p + off, XPrevg.p + off,
-                        nullptr, Xres);
+        nesterov(st, pb.m, 3, 0, -1, -1, alpha, gamma, Xg.p + off, Vg.p + off, Yg.p + off, XPrevg.p + off, nullptr,
+                 Xres, cs);
       }
     } else {
       DCORA_HIP(hipMemcpyAsync(XPrevg.p + off, Xg.p + off, B, hipMemcpyDeviceToDevice, st));
       DCORA_HIP(hipMemcpyAsync(pb.X0.p, Xg.p + off, B, hipMemcpyDeviceToDevice, st));
-      rc = pb.optimize_dev(opt.local, &last, &Xres);
+      rc = pb.optimize_dev(opt.local, &Xres, &cs);
       if (rc) return rc;
-      DCORA_HIP(hipMemcpyAsync(Xg.p + off, Xres, B, hipMemcpyDeviceToDevice, st));
+      if (cs) {  // resolve the device-side pick on the host (non-accelerated path is not latency critical)
+        dcora_ropt_result tmp;
+        rc = pb.fetch_result(&tmp);
+        if (rc) return rc;
+        Xres.p[0] = tmp.success && pb.result_index() ? pb.X1.p : pb.X0.p;
+      }
+      DCORA_HIP(hipMemcpyAsync(Xg.p + off, Xres.p[0], B, hipMemcpyDeviceToDevice, st));
     }
   }
   if (restart) gamma = alpha = 0;
@@ -220,7 +251,28 @@ int RbcdSession::evaluate_central(double *cost2, double *gradnorm, double *block
   }
   DeviceProblem &c = *central;
   c.enqueue_egrad(Xg.p, c.EG0.p, c.pA.p);
-  c.enq_rgrad(buf1(Xg.p), buf1(c.EG0.p), buf1(c.RG0.p), Buf2{{nullptr, nullptr}}, 0, c.pB.p, Gate{});
+  if (c.fused) {
+    c.enq_rgrad(buf1(Xg.p), buf1(c.EG0.p), buf1(c.RG0.p), Buf2{{nullptr, nullptr}}, 0, c.pB.p, Gate{}, posenorm.p);
+    const int want = ++eval_seq;
+    launch_eval_finish(st, R, pose_start.p, posenorm.p, c.pA.p, c.npA(), eval_dev, want);
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (eval_host->seq != want) {
+      if ((++spins & 4095u) == 0 &&
+          std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 20.0) {
+        set_last_error("rbcd: evaluation epilogue did not complete (spin timeout)");
+        return DCORA_ERR_HIP;
+      }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (block_norms)
+      for (int b = 0; b < R; ++b) block_norms[b] = eval_host->block_norms[b];
+    if (cost2) *cost2 = eval_host->cost2;
+    if (gradnorm) *gradnorm = eval_host->gradnorm;
+    if (next_selected) *next_selected = eval_host->next;
+    return DCORA_OK;
+  }
+  launch_rgrad(st, mg, buf1(Xg.p), buf1(c.EG0.p), buf1(c.RG0.p), Buf2{{nullptr, nullptr}}, 0, c.pB.p, Gate{});
   launch_block_dots(st, r, R, col_start.p, c.RG0.p, nullptr, evalbuf.p);
   launch_sum_partials(st, c.pA.p, c.npA(), 2, 2, evalbuf.p + 2 * R);
   std::vector<double> h(2 * R + 2);
@@ -240,6 +292,12 @@ int RbcdSession::evaluate_central(double *cost2, double *gradnorm, double *block
   if (cost2) *cost2 = 2.0 * (0.5 * h[2 * R] + h[2 * R + 1]);
   if (gradnorm) *gradnorm = std::sqrt(g2);
   if (next_selected) *next_selected = arg;
+  return DCORA_OK;
+}
+
+int RbcdSession::last_result(dcora_ropt_result *res) {
+  if (last_solver) return last_solver->fetch_result(res);
+  *res = last;
   return DCORA_OK;
 }
 

@@ -9,6 +9,8 @@
 // Every global reduction of the CG recurrence sits exactly on a kernel boundary, so an iteration costs three
 // dependent launches instead of six.  Per-pose arithmetic uses 8 lanes per pose: lane t
 // of a group owns row t of the pose's r x (d+1) block, d x d Gram matrices are reduced with 3 xor-shuffles.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace dcora {
@@ -170,11 +172,20 @@ __device__ __forceinline__ void row_polar(Row<D> &A, bool live) {
   }
 }
 
-constexpr int kPosesPerBlock = kBlock / GW;  // 32
-constexpr int kHessTile = 2560;              // nnz staged per pass (30 KiB of LDS)
+constexpr int kPosesPerBlock = kBlock / GW;  // 32 (pure per-pose kernels)
+constexpr int kHessTile = 1536;              // nnz staged per pass (18 KiB of LDS)
+
+// poses per block of the two-phase kernels: phase 1 runs one thread per output element (pose, column, row),
+// phase 2 eight lanes per pose
+__host__ __device__ inline int fused_pb(int r, int dh) {
+  const int pb = kBlock / (dh * r);
+  return pb > kPosesPerBlock ? kPosesPerBlock : pb;
+}
 
 // ------------------------------------------------------------------------------------------------------
-// A: Hessian-vector product of the tCG direction, with the direction update folded into the gather
+// A: Hessian-vector product of the tCG direction, with the direction update folded into the gather.
+//    Phase 1: W = delta Q, one thread per output element, CSR rows of the block staged in LDS.
+//    Phase 2: H delta = Proj_X(W - delta S) with 8 lanes per pose, operands handed over through LDS.
 // ------------------------------------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(kBlock) void k_fused_hess(ManiDesc m, CsrDev Q, const double *__restrict__ z,
@@ -183,17 +194,73 @@ __global__ __launch_bounds__(kBlock) void k_fused_hess(ManiDesc m, CsrDev Q, con
                                                        double *__restrict__ Hd, const double *__restrict__ p3,
                                                        int np3, double *__restrict__ p1, SolverCtl *ctl, int seq,
                                                        int iter) {
-  if (f_gated(ctl, seq, 2)) return;
+  // control scalars first (one batch of scalar loads); the gate itself is evaluated after the data loads below
+  // have been issued, so a kernel pays one memory round trip, not two
+  const int par = iter & 1;
+  const int st_o = ctl->outer_done_stamp, st_t = ctl->tcg_done_stamp, cur = ctl->cur & 1;
+  const double c_zr = ctl->z_r[par ^ 1], c_alpha = ctl->alpha, c_dPd = ctl->d_Pd[par ^ 1], c_ePd = ctl->e_Pd[par ^ 1],
+               c_ePen = ctl->e_Pe_n;
   __shared__ int s_ci[kHessTile];
   __shared__ double s_v[kHessTile];
+  __shared__ double s_W[kBlock], s_D[kBlock];
   __shared__ double s_red[16];
   constexpr int DH = D + 1;
   const int r = m.r;
+  const int PB = fused_pb(r, DH);
+  const int pose0 = blockIdx.x * PB;
+  const int npose = min(PB, m.n - pose0);
+  const int j0 = pose0 * DH, ncol = npose * DH, nout = ncol * r;
+  // ---- independent loads first: first CSR tile into LDS, own entries, pose operands (latency overlaps the
+  //      dependent scalar prologue below) ----
+  const int e = threadIdx.x;
+  const bool act = e < nout;
+  const int lc = e / r, t = e - lc * r;
+  const int j = j0 + lc;
+  const int pbeg = Q.rp[j0], pend = Q.rp[j0 + ncol];
+  const int myb = act ? Q.rp[j] : 0, mye = act ? Q.rp[j + 1] : 0;
+  {
+    const int cnt = min(kHessTile, pend - pbeg);
+    for (int i = threadIdx.x; i < cnt; i += kBlock) {
+      s_ci[i] = Q.ci[pbeg + i];
+      s_v[i] = Q.v[pbeg + i];
+    }
+  }
+  const size_t oown = (size_t)j * r + t;
+  const double z_own = act ? z[oown] : 0.0;
+  const double d_own = (act && iter > 0) ? d_old[oown] : 0.0;
+  const int g = threadIdx.x >> 3, tt = threadIdx.x & (GW - 1);
+  const bool pact = (g < npose) && (tt < r);
+  const size_t o = (size_t)(pose0 + g) * DH * r;
+  const double *__restrict__ X = Xb.p[cur];
+  const double *__restrict__ Sblk = Sb.p[cur];
+  Row<D> Y;
+  ld_row<D>(X + o, r, tt, pact, Y);
+  double S[D][D];
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int b = 0; b < D; ++b) S[a][b] = (g < npose) ? Sblk[(size_t)(pose0 + g) * D * D + a + b * D] : 0.0;
+  double myp = 0;  // this thread's share of the <z, r> partials (loads in flight with everything above)
+  for (int i = threadIdx.x; i < np3; i += kBlock) myp += p3[i];
+  if (seq > st_o || seq > st_t) return;  // solve or tCG already finished: no-op (uniform over the grid)
+  __syncthreads();  // first tile staged
+  // first batch of gathers: addresses do not depend on beta, so the loads are issued before the reduction
+  constexpr int GB = 16;
+  double ga[GB], gz[GB], gw[GB];
+  const int lo0 = myb - pbeg;
+  const int hi0 = min(mye, pbeg + kHessTile) - pbeg;
+#pragma unroll
+  for (int q = 0; q < GB; ++q) {
+    const bool ok = act && (lo0 + q < hi0);
+    const size_t oo = ok ? (size_t)s_ci[lo0 + q] * r + t : 0;
+    gw[q] = ok ? s_v[lo0 + q] : 0.0;
+    gz[q] = z[oo];
+    ga[q] = (iter > 0) ? d_old[oo] : 0.0;
+  }
   // ---- scalar recurrence (ROPTLIB tCG_TR): beta, e_Pd, d_Pd ----
-  const double z_r_new = f_sum_partials(p3, np3, 1, 0, s_red);
+  const double z_r_new = f_block_sum(myp, s_red);
   double beta = 0;
-  const int par = iter & 1;
-  if (iter > 0) beta = z_r_new / ctl->z_r[par ^ 1];
+  if (iter > 0) beta = z_r_new / c_zr;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (iter == 0) {
       ctl->z_r[0] = z_r_new;
@@ -201,77 +268,76 @@ __global__ __launch_bounds__(kBlock) void k_fused_hess(ManiDesc m, CsrDev Q, con
       ctl->e_Pe[0] = 0;
       ctl->e_Pd[0] = 0;
     } else {
-      const double alpha = ctl->alpha, d_Pd = ctl->d_Pd[par ^ 1], e_Pd = ctl->e_Pd[par ^ 1];
       ctl->z_r[par] = z_r_new;
-      ctl->e_Pd[par] = beta * (e_Pd + alpha * d_Pd);
-      ctl->d_Pd[par] = z_r_new + beta * beta * d_Pd;
-      ctl->e_Pe[par] = ctl->e_Pe_n;
+      ctl->e_Pd[par] = beta * (c_ePd + c_alpha * c_dPd);
+      ctl->d_Pd[par] = z_r_new + beta * beta * c_dPd;
+      ctl->e_Pe[par] = c_ePen;
     }
   }
-  const double *__restrict__ X = f_pick(Xb, ctl, 0);
-  const double *__restrict__ Sblk = f_pick(Sb, ctl, 0);
-  const int t = threadIdx.x & (GW - 1);
-  const int pose = blockIdx.x * kPosesPerBlock + (threadIdx.x >> 3);
-  const bool active = (pose < m.n) && (t < r);
-  const int j0 = blockIdx.x * kPosesPerBlock * DH;
-  const int j1 = min(m.k, j0 + kPosesPerBlock * DH);
-  const int pbeg = Q.rp[j0], pend = Q.rp[j1];
-  int rb[DH], re[DH];
-#pragma unroll
-  for (int a = 0; a < DH; ++a) {
-    rb[a] = active ? Q.rp[pose * DH + a] : 0;
-    re[a] = active ? Q.rp[pose * DH + a + 1] : 0;
-  }
-  Row<D> W;
-#pragma unroll
-  for (int a = 0; a < DH; ++a) W.e[a] = 0;
-  for (int base = pbeg; base < pend; base += kHessTile) {
-    const int cnt = min(kHessTile, pend - base);
-    __syncthreads();
-    for (int i = threadIdx.x; i < cnt; i += kBlock) {
-      s_ci[i] = Q.ci[base + i];
-      s_v[i] = Q.v[base + i];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int a = 0; a < DH; ++a) {
-      const int lo = max(rb[a], base) - base, hi = min(re[a], base + cnt) - base;
-      double acc = 0;
-      for (int p = lo; p < hi; ++p) {
-        const size_t o = (size_t)s_ci[p] * r + t;
-        acc += s_v[p] * (iter > 0 ? beta * d_old[o] - z[o] : -z[o]);
-      }
-      W.e[a] += acc;
-    }
-  }
-  // own rows: direction, correction, projection, dot
-  const size_t o = (size_t)pose * DH * r;
-  Row<D> Y, V;
-  ld_row<D>(X + o, r, t, active, Y);
-#pragma unroll
-  for (int a = 0; a < DH; ++a)
-    V.e[a] = active ? (iter > 0 ? beta * d_old[o + a * r + t] - z[o + a * r + t] : -z[o + a * r + t]) : 0.0;
-  st_row<D>(d_new + o, r, t, active, V);
-  double S[D][D];
-#pragma unroll
-  for (int a = 0; a < D; ++a)
-#pragma unroll
-    for (int b = 0; b < D; ++b) S[a][b] = (pose < m.n) ? Sblk[(size_t)pose * D * D + a + b * D] : 0.0;
-  row_sub_AS<D>(W, V, S);
-  row_tangent<D>(Y, W);
-  st_row<D>(Hd + o, r, t, active, W);
+  // ---- phase 1 ----
   double acc = 0;
 #pragma unroll
-  for (int a = 0; a < DH; ++a) acc += V.e[a] * W.e[a];
-  const double tot = f_block_sum(acc, s_red);
+  for (int q = 0; q < GB; ++q) acc += gw[q] * (beta * ga[q] - gz[q]);
+  for (int base = pbeg; base < pend; base += kHessTile) {
+    const int cnt = min(kHessTile, pend - base);
+    if (base != pbeg) {
+      __syncthreads();
+      for (int i = threadIdx.x; i < cnt; i += kBlock) {
+        s_ci[i] = Q.ci[base + i];
+        s_v[i] = Q.v[base + i];
+      }
+      __syncthreads();
+    }
+    int lo = max(myb, base) - base;
+    const int hi = min(mye, base + cnt) - base;
+    if (base == pbeg) lo += GB;  // already consumed above
+    for (int p = lo; p < hi; p += 8) {
+      double a8[8], b8[8], w8[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const bool ok = p + q < hi;
+        const size_t oo = ok ? (size_t)s_ci[p + q] * r + t : 0;
+        w8[q] = ok ? s_v[p + q] : 0.0;
+        b8[q] = z[oo];
+        a8[q] = (iter > 0) ? d_old[oo] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc += w8[q] * (beta * a8[q] - b8[q]);
+    }
+  }
+  if (act) {
+    const double dn = (iter > 0) ? beta * d_own - z_own : -z_own;
+    d_new[oown] = dn;
+    s_W[e] = acc;
+    s_D[e] = dn;
+  }
+  __syncthreads();
+  // ---- phase 2 ----
+  Row<D> V, W;
+#pragma unroll
+  for (int a = 0; a < DH; ++a) {
+    W.e[a] = pact ? s_W[(g * DH + a) * r + tt] : 0.0;
+    V.e[a] = pact ? s_D[(g * DH + a) * r + tt] : 0.0;
+  }
+  row_sub_AS<D>(W, V, S);
+  row_tangent<D>(Y, W);
+  st_row<D>(Hd + o, r, tt, pact, W);
+  double dacc = 0;
+#pragma unroll
+  for (int a = 0; a < DH; ++a) dacc += V.e[a] * W.e[a];
+  const double tot = f_block_sum(dacc, s_red);
   if (threadIdx.x == 0) p1[blockIdx.x] = tot;
 }
 
 // ------------------------------------------------------------------------------------------------------
 // B: step length, vector updates and the dense preconditioner product, split over row slices of Minv.
 //    first != 0: start of a tCG run (res = grad, eta = H eta = 0, no step).
+//    The updated residual slice is staged once in LDS; each wave then streams whole rows of the symmetric
+//    inverse with 16-byte loads (lane l owns output columns 2l, 2l+1 of the block's 128-column chunk),
+//    eight rows in flight per lane, and reads the residual entries as LDS broadcasts.
 // ------------------------------------------------------------------------------------------------------
-constexpr int kJChunk = 128;  // output columns per block (16-byte loads: 2 columns per lane)
+constexpr int kJChunk = 128;  // output columns per block
+constexpr int kRowChunk = 256;  // residual rows staged per pass
 
 template <int RM>
 __global__ __launch_bounds__(kBlock) void k_fused_precond(int r, int k, int ldm, int nsplit,
@@ -283,21 +349,74 @@ __global__ __launch_bounds__(kBlock) void k_fused_precond(int r, int k, int ldm,
                                                           double *__restrict__ res_new,
                                                           double *__restrict__ Zpart, const double *__restrict__ p1,
                                                           int np1, double *__restrict__ p2, SolverCtl *ctl,
-                                                          HostFlags *hf, int seq, int iter, int first) {
-  if (f_gated(ctl, seq, first ? 1 : 2)) return;
+                                                          HostFlags *hf, int seq, int iter, int first,
+                                                          int dbg) {
+  const int par = iter & 1;
+  const int st_o = ctl->outer_done_stamp, st_t = ctl->tcg_done_stamp, cur = ctl->cur & 1;
+  const double c_zr = ctl->z_r[par], c_dPd = ctl->d_Pd[par], c_ePe = ctl->e_Pe[par], c_ePd = ctl->e_Pd[par],
+               c_Delta = ctl->Delta, c_ngf = ctl->ngf;
   __shared__ double s_red[16];
-  __shared__ double s_acc[(kBlock / 64) * RM * kJChunk];
+  __shared__ double s_buf[(kBlock / 64) * RM * kJChunk];  // residual slice, then the cross-wave reduction
   const long N = (long)r * k;
+  // ---- row slice of this block / wave, and the first kPre rows of the inverse preloaded into registers: the
+  //      loads do not depend on the step length, so their latency overlaps the scalar prologue ----
+  constexpr int kPre = 16;
+  const int njc = (k + kJChunk - 1) / kJChunk;
+  const int jc = blockIdx.x % njc, s = blockIdx.x / njc;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int rows_per_split = (k + nsplit - 1) / nsplit;
+  const int c_lo = min(k, s * rows_per_split), c_hi = min(k, c_lo + rows_per_split);
+  const int col = jc * kJChunk + 2 * lane;
+  const int cn0 = min(kRowChunk, c_hi - c_lo);
+  const int per_wave0 = (cn0 + 3) / 4;
+  const int w_lo0 = min(cn0, wave * per_wave0), w_hi0 = min(cn0, w_lo0 + per_wave0);
+  double2 pre[kPre];
+  {
+    const double *__restrict__ mp0 = Minv + (size_t)(c_lo + w_lo0) * ldm + col;
+#pragma unroll
+    for (int q = 0; q < kPre; ++q) {
+      if (w_lo0 + q < w_hi0 && dbg != 2) {
+        pre[q] = *reinterpret_cast<const double2 *>(mp0 + (size_t)q * ldm);
+      } else {
+        pre[q].x = 0.0;
+        pre[q].y = 0.0;
+      }
+    }
+  }
+  const double *__restrict__ rsrc = first ? gradb.p[cur] : res_old;
+  // own element of the vector updates and own entries of the residual slice: loaded before alpha is known
+  const long i0 = (long)blockIdx.x * kBlock + threadIdx.x;
+  const bool own = i0 < N;
+  double o_h = 0, o_d = 0, o_eta = 0, o_Heta = 0, o_r = 0;
+  if (own) {
+    o_r = rsrc[i0];
+    if (!first) {
+      o_h = Hd[i0];
+      o_d = delta[i0];
+      o_eta = eta[i0];
+      o_Heta = Heta[i0];
+    }
+  }
+  constexpr int kStagePre = 2;  // staged residual entries preloaded per thread
+  double st_r[kStagePre], st_h[kStagePre];
+#pragma unroll
+  for (int u = 0; u < kStagePre; ++u) {
+    const int i = threadIdx.x + u * kBlock;
+    const bool ok = i < cn0 * r;
+    const size_t idx = (size_t)c_lo * r + (ok ? i : 0);
+    st_r[u] = ok ? rsrc[idx] : 0.0;
+    st_h[u] = (ok && !first) ? Hd[idx] : 0.0;
+  }
+  double myp = 0;
+  if (!first)
+    for (int i = threadIdx.x; i < np1; i += kBlock) myp += p1[i];
+  if (seq > st_o || (!first && seq > st_t)) return;  // finished: no-op (uniform over the grid)
   double alpha = 0, step = 0;
   bool boundary = false;
-  const double *__restrict__ rsrc = res_old;
-  if (first) {
-    rsrc = f_pick(gradb, ctl, 0);
-  } else {
-    const int par = iter & 1;
-    const double d_Hd = f_sum_partials(p1, np1, 1, 0, s_red);
-    const double z_r = ctl->z_r[par], d_Pd = ctl->d_Pd[par], e_Pe = ctl->e_Pe[par], e_Pd = ctl->e_Pd[par];
-    const double Delta = ctl->Delta;
+  if (!first) {
+    const double d_Hd = f_block_sum(myp, s_red);
+    const double z_r = c_zr, d_Pd = c_dPd, e_Pe = c_ePe, e_Pd = c_ePd;
+    const double Delta = c_Delta;
     alpha = z_r / d_Hd;
     const double e_Pe_new = e_Pe + 2.0 * alpha * e_Pd + alpha * alpha * d_Pd;
     boundary = (d_Hd <= 0) || (e_Pe_new >= Delta * Delta);
@@ -315,14 +434,29 @@ __global__ __launch_bounds__(kBlock) void k_fused_precond(int r, int k, int ldm,
     }
   }
   if (first && blockIdx.x == 0 && threadIdx.x == 0) {
-    ctl->norm_r0 = ctl->ngf;
+    ctl->norm_r0 = c_ngf;
     ctl->tcg_status = 4;
     ctl->tcg_iters = 0;
     ctl->tcg_done_stamp = INT_MAX;
   }
   // ---- element-wise updates (each element exactly once over the grid) ----
   double acc2 = 0;
-  for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < N; i += (long)gridDim.x * kBlock) {
+  if (own) {
+    if (first) {
+      eta[i0] = 0;
+      Heta[i0] = 0;
+      res_new[i0] = o_r;
+    } else {
+      eta[i0] = o_eta + step * o_d;
+      Heta[i0] = o_Heta + step * o_h;
+      if (!boundary) {
+        const double rr = o_r + alpha * o_h;
+        res_new[i0] = rr;
+        acc2 += rr * rr;
+      }
+    }
+  }
+  for (long i = i0 + (long)gridDim.x * kBlock; i < N; i += (long)gridDim.x * kBlock) {
     if (first) {
       eta[i] = 0;
       Heta[i] = 0;
@@ -343,59 +477,79 @@ __global__ __launch_bounds__(kBlock) void k_fused_precond(int r, int k, int ldm,
     if (threadIdx.x == 0) p2[blockIdx.x] = tot;
   }
   if (boundary) return;
+  if (dbg == 1) return;
   // ---- dense product slice: Z_s(:, j) = sum_{c in slice} r(:, c) Minv(c, j) ----
-  const int njc = (k + kJChunk - 1) / kJChunk;
-  const int jc = blockIdx.x % njc, s = blockIdx.x / njc;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int rows_per_split = (k + nsplit - 1) / nsplit;
-  const int c_lo = s * rows_per_split, c_hi = min(k, c_lo + rows_per_split);
-  const int rows_per_wave = (rows_per_split + 3) / 4;
-  const int w_lo = min(c_hi, c_lo + wave * rows_per_wave), w_hi = min(c_hi, w_lo + rows_per_wave);
-  const int col = jc * kJChunk + 2 * lane;
   double a0[RM], a1[RM];
 #pragma unroll
   for (int t = 0; t < RM; ++t) a0[t] = a1[t] = 0;
-  const double *__restrict__ mp = Minv + (size_t)w_lo * ldm + col;
-  int c = w_lo;
-  for (; c + 4 <= w_hi; c += 4) {
-    const double2 m0 = *reinterpret_cast<const double2 *>(mp);
-    const double2 m1 = *reinterpret_cast<const double2 *>(mp + ldm);
-    const double2 m2 = *reinterpret_cast<const double2 *>(mp + 2 * (size_t)ldm);
-    const double2 m3 = *reinterpret_cast<const double2 *>(mp + 3 * (size_t)ldm);
-    mp += 4 * (size_t)ldm;
-    const double *__restrict__ r0 = rsrc + (size_t)c * r;
-    const double *__restrict__ h0 = Hd + (size_t)c * r;
+  for (int c0 = c_lo; c0 < c_hi; c0 += kRowChunk) {
+    const int cn = min(kRowChunk, c_hi - c0);
+    __syncthreads();
+    if (c0 == c_lo) {
 #pragma unroll
-    for (int t = 0; t < RM; ++t)
-      if (t < r) {
-        double x0 = r0[t], x1 = r0[r + t], x2 = r0[2 * r + t], x3 = r0[3 * r + t];
-        if (!first) {
-          x0 += alpha * h0[t];
-          x1 += alpha * h0[r + t];
-          x2 += alpha * h0[2 * r + t];
-          x3 += alpha * h0[3 * r + t];
+      for (int u = 0; u < kStagePre; ++u) {
+        const int i = threadIdx.x + u * kBlock;
+        if (i < cn * r) s_buf[i] = st_r[u] + alpha * st_h[u];
+      }
+    }
+    for (int i = threadIdx.x + (c0 == c_lo ? kStagePre * kBlock : 0); i < cn * r; i += kBlock) {
+      const size_t idx = (size_t)c0 * r + i;
+      double x = rsrc[idx];
+      if (!first) x += alpha * Hd[idx];
+      s_buf[i] = x;
+    }
+    __syncthreads();
+    const int per_wave = (cn + 3) / 4;
+    const int w_lo = min(cn, wave * per_wave), w_hi = min(cn, w_lo + per_wave);
+    int c = w_lo;
+    if (c0 == c_lo) {
+      // rows preloaded before the prologue
+#pragma unroll
+      for (int q = 0; q < kPre; ++q) {
+        const bool ok = (w_lo + q < w_hi);
+#pragma unroll
+        for (int t = 0; t < RM; ++t)
+          if (t < r) {
+            const double x = ok ? s_buf[(w_lo + q) * r + t] : 0.0;
+            a0[t] += x * pre[q].x;
+            a1[t] += x * pre[q].y;
+          }
+      }
+      c = min(w_hi, w_lo + kPre);
+    }
+    const double *__restrict__ mp = Minv + (size_t)(c0 + c) * ldm + col;
+    for (; c + 8 <= w_hi; c += 8) {
+      double2 mm[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) mm[q] = *reinterpret_cast<const double2 *>(mp + (size_t)q * ldm);
+      mp += 8 * (size_t)ldm;
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int t = 0; t < RM; ++t)
+          if (t < r) {
+            const double x = s_buf[(c + q) * r + t];
+            a0[t] += x * mm[q].x;
+            a1[t] += x * mm[q].y;
+          }
+    }
+    for (; c < w_hi; ++c) {
+      const double2 m0 = *reinterpret_cast<const double2 *>(mp);
+      mp += ldm;
+#pragma unroll
+      for (int t = 0; t < RM; ++t)
+        if (t < r) {
+          const double x = s_buf[c * r + t];
+          a0[t] += x * m0.x;
+          a1[t] += x * m0.y;
         }
-        a0[t] += x0 * m0.x + x1 * m1.x + x2 * m2.x + x3 * m3.x;
-        a1[t] += x0 * m0.y + x1 * m1.y + x2 * m2.y + x3 * m3.y;
-      }
-  }
-  for (; c < w_hi; ++c) {
-    const double2 m0 = *reinterpret_cast<const double2 *>(mp);
-    mp += ldm;
-#pragma unroll
-    for (int t = 0; t < RM; ++t)
-      if (t < r) {
-        double x0 = rsrc[(size_t)c * r + t];
-        if (!first) x0 += alpha * Hd[(size_t)c * r + t];
-        a0[t] += x0 * m0.x;
-        a1[t] += x0 * m0.y;
-      }
+    }
   }
   __syncthreads();
 #pragma unroll
   for (int t = 0; t < RM; ++t) {
-    s_acc[(wave * RM + t) * kJChunk + 2 * lane] = a0[t];
-    s_acc[(wave * RM + t) * kJChunk + 2 * lane + 1] = a1[t];
+    s_buf[(wave * RM + t) * kJChunk + 2 * lane] = a0[t];
+    s_buf[(wave * RM + t) * kJChunk + 2 * lane + 1] = a1[t];
   }
   __syncthreads();
   const int ncol = min(kJChunk, k - jc * kJChunk);
@@ -404,13 +558,14 @@ __global__ __launch_bounds__(kBlock) void k_fused_precond(int r, int k, int ldm,
     const int cc = e / r, t = e - cc * r;
     double v = 0;
 #pragma unroll
-    for (int w = 0; w < kBlock / 64; ++w) v += s_acc[(w * RM + t) * kJChunk + cc];
+    for (int w = 0; w < kBlock / 64; ++w) v += s_buf[(w * RM + t) * kJChunk + cc];
     zp[e] = v;
   }
 }
 
 // ------------------------------------------------------------------------------------------------------
 // C: residual stopping rule, z = Proj_X(sum of the split-K slices), partial <z, r>
+//    Phase 1 sums the slices with one thread per element (coalesced), phase 2 projects with 8 lanes per pose.
 // ------------------------------------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(kBlock) void k_fused_finish(ManiDesc m, int nsplit, Buf2 Xb,
@@ -419,13 +574,47 @@ __global__ __launch_bounds__(kBlock) void k_fused_finish(ManiDesc m, int nsplit,
                                                          const double *__restrict__ p2, int np2,
                                                          double *__restrict__ p3, SolverCtl *ctl, HostFlags *hf,
                                                          int seq, int iter, int first) {
-  if (f_gated(ctl, seq, first ? 1 : 2)) return;
+  const int st_o = ctl->outer_done_stamp, st_t = ctl->tcg_done_stamp, cur = ctl->cur & 1;
+  const double c_n0 = ctl->norm_r0;
+  const int c_max_inner = ctl->max_inner;
   __shared__ double s_red[16];
+  __shared__ double s_Z[kBlock], s_R[kBlock];
   constexpr int DH = D + 1;
   const int r = m.r;
+  const long N = (long)r * m.k;
+  const int PB = fused_pb(r, DH);
+  const int pose0 = blockIdx.x * PB;
+  const int npose = min(PB, m.n - pose0);
+  const int nout = npose * DH * r;
+  const size_t base = (size_t)pose0 * DH * r;
+  // ---- phase 1 first (independent of the stopping rule): slice sum, residual entry ----
+  {
+    const int e = threadIdx.x;
+    if (e < nout) {
+      double zs = 0;
+      double q[32];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) q[u] = (u < nsplit) ? Zpart[(size_t)u * N + base + e] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 32; ++u) zs += q[u];
+      for (int s = 32; s < nsplit; ++s) zs += Zpart[(size_t)s * N + base + e];
+      s_Z[e] = zs;
+      s_R[e] = res[base + e];
+    }
+  }
+  const double *__restrict__ X = Xb.p[cur];
+  const int g = threadIdx.x >> 3, tt = threadIdx.x & (GW - 1);
+  const bool pact = (g < npose) && (tt < r);
+  const size_t o = base + (size_t)g * DH * r;
+  Row<D> Y, Zr, Rr;
+  ld_row<D>(X + o, r, tt, pact, Y);
+  double myp = 0;
+  if (!first)
+    for (int i = threadIdx.x; i < np2; i += kBlock) myp += p2[i];
+  if (seq > st_o || (!first && seq > st_t)) return;  // finished: no-op (uniform over the grid)
   if (!first) {
-    const double nr = sqrt(f_sum_partials(p2, np2, 1, 0, s_red));
-    const double n0 = ctl->norm_r0;
+    const double nr = sqrt(f_block_sum(myp, s_red));
+    const double n0 = c_n0;
     const double kappa = 0.1, tempnum = n0;  // theta = 1
     if (nr <= n0 * fmin(tempnum, kappa)) {
       if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -438,32 +627,22 @@ __global__ __launch_bounds__(kBlock) void k_fused_finish(ManiDesc m, int nsplit,
       return;
     }
   }
-  const double *__restrict__ X = f_pick(Xb, ctl, 0);
-  const long N = (long)r * m.k;
-  const int t = threadIdx.x & (GW - 1);
-  const int pose = blockIdx.x * kPosesPerBlock + (threadIdx.x >> 3);
-  const bool active = (pose < m.n) && (t < r);
-  const size_t o = (size_t)pose * DH * r;
-  Row<D> Y, Zr, Rr;
-  ld_row<D>(X + o, r, t, active, Y);
-  ld_row<D>(res + o, r, t, active, Rr);
+  __syncthreads();
+  // ---- phase 2 ----
 #pragma unroll
-  for (int a = 0; a < DH; ++a) Zr.e[a] = 0;
-  if (active)
-    for (int s = 0; s < nsplit; ++s) {
-      const double *__restrict__ zp = Zpart + (size_t)s * N + o;
-#pragma unroll
-      for (int a = 0; a < DH; ++a) Zr.e[a] += zp[a * r + t];
-    }
+  for (int a = 0; a < DH; ++a) {
+    Zr.e[a] = pact ? s_Z[(g * DH + a) * r + tt] : 0.0;
+    Rr.e[a] = pact ? s_R[(g * DH + a) * r + tt] : 0.0;
+  }
   row_tangent<D>(Y, Zr);
-  st_row<D>(z + o, r, t, active, Zr);
+  st_row<D>(z + o, r, tt, pact, Zr);
   double acc = 0;
 #pragma unroll
   for (int a = 0; a < DH; ++a) acc += Zr.e[a] * Rr.e[a];
   const double tot = f_block_sum(acc, s_red);
   if (threadIdx.x == 0) p3[blockIdx.x] = tot;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (!first && iter + 1 >= ctl->max_inner) {  // inner loop exhausted: status stays TR_MAXITER
+    if (!first && iter + 1 >= c_max_inner) {  // inner loop exhausted: status stays TR_MAXITER
       ctl->tcg_iters = iter + 1;
       ctl->inner_total += iter + 1;
       ctl->tcg_done_stamp = seq;
@@ -479,7 +658,8 @@ __global__ __launch_bounds__(kBlock) void k_fused_finish(ManiDesc m, int nsplit,
 // RG = Proj_X(EG), S_i = sym(Y_i^T EG_i), partial |RG|^2
 template <int D>
 __global__ __launch_bounds__(kBlock) void k_g_rgrad(ManiDesc m, Buf2 Xb, Buf2 EGb, Buf2 RGb, Buf2 Sb, int sel,
-                                                    double *__restrict__ partials, Gate g) {
+                                                    double *__restrict__ partials, double *__restrict__ posenorm,
+                                                    Gate g) {
   if (g.ctl && g.gate && f_gated(g.ctl, g.seq, g.gate)) return;
   __shared__ double s_red[16];
   constexpr int DH = D + 1;
@@ -506,8 +686,14 @@ __global__ __launch_bounds__(kBlock) void k_g_rgrad(ManiDesc m, Buf2 Xb, Buf2 EG
 #pragma unroll
         for (int b = 0; b < D; ++b) Sblk[(size_t)pose * D * D + a + b * D] = S[a][b];
     row_sub_AS<D>(E, Y, S);
+    double pa = 0;
 #pragma unroll
-    for (int a = 0; a < DH; ++a) acc += E.e[a] * E.e[a];
+    for (int a = 0; a < DH; ++a) pa += E.e[a] * E.e[a];
+    acc += pa;
+    if (posenorm) {  // |RG_i|^2 per pose, for the per-agent block norms of the evaluation
+      const double ps = grp_sum(pa);
+      if (pose < m.n && t == 0) posenorm[pose] = ps;
+    }
     if (RG) st_row<D>(RG + o, r, t, active, E);
   }
   const double tot = f_block_sum(acc, s_red);
@@ -567,10 +753,12 @@ struct GNesterovArgs {
   int mode, restart, skip_lo, skip_hi;
   double alpha, gamma;
   double *X, *V, *Y, *XPrev, *Yloc;
-  const double *Xloc;
+  Buf2 Xloc;              // result buffers of the local solve
+  const SolverCtl *ctl;   // picks Xloc.p[ctl->cur] when non-null
 };
 template <int D>
 __global__ __launch_bounds__(kBlock) void k_g_nesterov(ManiDesc m, GNesterovArgs a) {
+  const double *__restrict__ Xloc = a.Xloc.p[a.ctl ? (a.ctl->cur & 1) : 0];
   constexpr int DH = D + 1;
   const int r = m.r;
   const int t = threadIdx.x & (GW - 1);
@@ -605,7 +793,7 @@ __global__ __launch_bounds__(kBlock) void k_g_nesterov(ManiDesc m, GNesterovArgs
         st_row<D>(a.V + o, r, t, active, v);
       }
     } else {
-      ld_row<D>(a.Xloc + o, r, t, active, x);
+      ld_row<D>(Xloc + o, r, t, active, x);
       st_row<D>(a.X + o, r, t, active, x);
       if (a.mode == 2) {
         ld_row<D>(a.V + o, r, t, active, v);
@@ -633,8 +821,88 @@ int group_grid(int n) {
 
 }  // namespace
 
-bool fused_supported(const ManiDesc &m) { return m.se && m.r <= GW && m.n > 0; }
-int fused_pose_blocks(const ManiDesc &m) { return (m.n + kPosesPerBlock - 1) / kPosesPerBlock; }
+// start-of-solve control block, written on the device so that a solve needs no host-to-device copy
+__global__ void k_ctl_init(SolverCtl *c, double tol, double Delta, double maxDelta, int max_outer, int stop_on_accept,
+                           int max_inner) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  c->f1 = c->ngf = c->f2 = c->rho = c->fInit = c->gradNormInit = 0;
+  c->Delta = Delta;
+  c->maxDelta = maxDelta;
+  c->tol = tol;
+  c->cur = 0;
+  c->outer_it = 0;
+  c->max_outer = max_outer;
+  c->accepted = 0;
+  c->last_accepted = 0;
+  c->stop_on_accept = stop_on_accept;
+  c->outer_done_stamp = INT_MAX;
+  c->alpha = c->e_Pe_n = c->norm_r0 = 0;
+  c->tcg_done_stamp = INT_MAX;
+  c->tcg_status = 4;
+  c->tcg_iters = 0;
+  c->inner_total = 0;
+  c->max_inner = max_inner;
+}
+void launch_ctl_init(hipStream_t st, SolverCtl *c, double tol, double Delta, double maxDelta, int max_outer,
+                     int stop_on_accept, int max_inner) {
+  hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(64), 0, st, c, tol, Delta, maxDelta, max_outer, stop_on_accept,
+                     max_inner);
+}
+
+// Evaluation epilogue of one RBCD pass (ref examples/MultiRobotExample.cpp:264-305): per-agent |rgrad_b| from the
+// per-pose squared norms, 2 f from the Q-apply partials, greedy argmax; results go to host-mapped memory and are
+// published by a sequence word, so the host never calls into the runtime to read them.
+__global__ __launch_bounds__(kBlock) void k_eval_finish(int R, const int *__restrict__ pose_start,
+                                                        const double *__restrict__ posenorm,
+                                                        const double *__restrict__ pA, int npA, EvalOut *out,
+                                                        int seq) {
+  __shared__ double s_red[16];
+  __shared__ double s_bn[kMaxAgents];
+  for (int b = 0; b < R; ++b) {
+    double v = 0;
+    for (int i = pose_start[b] + threadIdx.x; i < pose_start[b + 1]; i += kBlock) v += posenorm[i];
+    const double tot = f_block_sum(v, s_red);
+    if (threadIdx.x == 0) s_bn[b] = tot;
+  }
+  double q0 = 0, q1 = 0;
+  for (int i = threadIdx.x; i < npA; i += kBlock) {
+    q0 += pA[2 * i];
+    q1 += pA[2 * i + 1];
+  }
+  const double fq = f_block_sum(q0, s_red);
+  const double fg = f_block_sum(q1, s_red);
+  if (threadIdx.x == 0) {
+    double g2 = 0, best = -1;
+    int arg = 0;
+    for (int b = 0; b < R; ++b) {
+      const double nb = sqrt(s_bn[b]);
+      out->block_norms[b] = nb;
+      g2 += s_bn[b];
+      if (nb > best) {
+        best = nb;
+        arg = b;
+      }
+    }
+    out->cost2 = 2.0 * (0.5 * fq + fg);
+    out->gradnorm = sqrt(g2);
+    out->next = arg;
+    __threadfence_system();
+    __hip_atomic_store(const_cast<int *>(&out->seq), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+void launch_eval_finish(hipStream_t st, int R, const int *pose_start, const double *posenorm, const double *pA,
+                        int npA, EvalOut *out_dev, int seq) {
+  hipLaunchKernelGGL(k_eval_finish, dim3(1), dim3(kBlock), 0, st, R, pose_start, posenorm, pA, npA, out_dev, seq);
+}
+
+bool fused_supported(const ManiDesc &m) {
+  // hess / finish leave one partial slot per block in 2 * kMaxPartials-slot buffers
+  return m.se && m.r <= GW && m.n > 0 && (m.n + fused_pb(m.r, m.d + 1) - 1) / fused_pb(m.r, m.d + 1) <= 2 * kMaxPartials;
+}
+int fused_pose_blocks(const ManiDesc &m) {
+  const int pb = fused_pb(m.r, m.d + 1);
+  return (m.n + pb - 1) / pb;
+}
 int fused_nsplit(const ManiDesc &m) {
   const int njc = (m.k + kJChunk - 1) / kJChunk;
   int ns = (512 + njc - 1) / njc;  // aim for ~512 blocks of 4 waves
@@ -662,12 +930,13 @@ void launch_fused_precond(hipStream_t st, const ManiDesc &m, int ldm, const doub
                           HostFlags *hf, int seq, int iter, int first) {
   const int grid = fused_precond_grid(m);
   const int ns = fused_nsplit(m);
+  static const int dbg = std::getenv("DCORA_DBG_PRECOND") ? atoi(std::getenv("DCORA_DBG_PRECOND")) : 0;
   if (m.r <= 4)
     hipLaunchKernelGGL(k_fused_precond<4>, dim3(grid), dim3(kBlock), 0, st, m.r, m.k, ldm, ns, Minv, grad, delta, Hd,
-                       eta, Heta, res_old, res_new, Zpart, p1, np1, p2, ctl, hf, seq, iter, first);
+                       eta, Heta, res_old, res_new, Zpart, p1, np1, p2, ctl, hf, seq, iter, first, dbg);
   else
     hipLaunchKernelGGL(k_fused_precond<8>, dim3(grid), dim3(kBlock), 0, st, m.r, m.k, ldm, ns, Minv, grad, delta, Hd,
-                       eta, Heta, res_old, res_new, Zpart, p1, np1, p2, ctl, hf, seq, iter, first);
+                       eta, Heta, res_old, res_new, Zpart, p1, np1, p2, ctl, hf, seq, iter, first, dbg);
 }
 void launch_fused_finish(hipStream_t st, const ManiDesc &m, Buf2 X, const double *Zpart, const double *res,
                          double *z, const double *p2, int np2, double *p3, SolverCtl *ctl, HostFlags *hf, int seq,
@@ -683,12 +952,12 @@ void launch_fused_finish(hipStream_t st, const ManiDesc &m, Buf2 X, const double
 }
 
 int launch_g_rgrad(hipStream_t st, const ManiDesc &m, Buf2 X, Buf2 EG, Buf2 RG, Buf2 Sblk, int sel, double *partials,
-                   Gate g) {
+                   double *posenorm, Gate g) {
   const int grid = group_grid(m.n);
   if (m.d == 3)
-    hipLaunchKernelGGL(k_g_rgrad<3>, dim3(grid), dim3(kBlock), 0, st, m, X, EG, RG, Sblk, sel, partials, g);
+    hipLaunchKernelGGL(k_g_rgrad<3>, dim3(grid), dim3(kBlock), 0, st, m, X, EG, RG, Sblk, sel, partials, posenorm, g);
   else
-    hipLaunchKernelGGL(k_g_rgrad<2>, dim3(grid), dim3(kBlock), 0, st, m, X, EG, RG, Sblk, sel, partials, g);
+    hipLaunchKernelGGL(k_g_rgrad<2>, dim3(grid), dim3(kBlock), 0, st, m, X, EG, RG, Sblk, sel, partials, posenorm, g);
   return grid;
 }
 int launch_g_retract(hipStream_t st, const ManiDesc &m, Buf2 X, const double *V, double alpha, Buf2 out, int selOut,
@@ -704,8 +973,8 @@ int launch_g_retract(hipStream_t st, const ManiDesc &m, Buf2 X, const double *V,
 }
 void launch_g_nesterov(hipStream_t st, const ManiDesc &m, int mode, int restart, int skip_lo, int skip_hi,
                        double alpha, double gamma, double *X, double *V, double *Y, double *XPrev, double *Yloc,
-                       const double *Xloc) {
-  GNesterovArgs a{mode, restart, skip_lo, skip_hi, alpha, gamma, X, V, Y, XPrev, Yloc, Xloc};
+                       Buf2 Xloc, const SolverCtl *ctl) {
+  GNesterovArgs a{mode, restart, skip_lo, skip_hi, alpha, gamma, X, V, Y, XPrev, Yloc, Xloc, ctl};
   const int grid = group_grid(m.n);
   if (m.d == 3)
     hipLaunchKernelGGL(k_g_nesterov<3>, dim3(grid), dim3(kBlock), 0, st, m, a);
