@@ -1,0 +1,119 @@
+"""world_size-2 gloo test (CPU) of the one-process-per-GPU RBCD protocol used by bench.py: ownership a % world,
+public-pose pack -> broadcast -> unpack, block-wise evaluation + all-reduce, greedy selection.  The GPU session is
+replaced by a numpy model with the same interface whose local solve is the oracle, so the distributed result must
+equal the single-process oracle run bit-for-bit in its selection sequence."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import common
+
+WORLD = 2
+
+
+def _worker(rank, world, port, tmpdir):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(common.HERE))
+    sys.path.insert(0, common.HERE)
+    import g2o_np
+    from oracle import orc
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    name, R, r, iters = "smallGrid3D", 5, 5, 12
+    ds = common.oracle_dataset(name)
+    g = g2o_np.read_g2o(common.data_path(name))
+    d, n, dh = ds.d, ds.n, ds.d + 1
+    per = n // R
+    start = [b * per for b in range(R)]
+    end = [n if b == R - 1 else (b + 1) * per for b in range(R)]
+    robot = lambda i: min(i // per, R - 1)
+    Qg = g2o_np.dense_Q(g)
+    import scipy.sparse as sp
+    pub = [set() for _ in range(R)]
+    for (i, j, *_r) in g["edges"]:
+        if robot(i) != robot(j):
+            pub[robot(i)].add(i)
+            pub[robot(j)].add(j)
+    pub = [sorted(p) for p in pub]
+    cols = lambda b: slice(start[b] * dh, end[b] * dh)
+    X0 = np.load(os.path.join(tmpdir, "X0.npy"))
+    X = X0.copy()                      # every rank keeps a mirror; only owned blocks + public poses are authoritative
+    hosted = [b for b in range(R) if b % world == rank]
+    probs = {}
+    for b in hosted:
+        Qbb = orc.CSR.from_scipy(sp.csr_matrix(Qg[cols(b), cols(b)]))
+        probs[b] = Qbb
+    V = {b: X[:, cols(b)].copy() for b in hosted}
+    gamma = alpha = 0.0
+    trace = []
+    selected = 0
+
+    def G_of(b):
+        Qcb = Qg[:, cols(b)].copy()
+        Qcb[cols(b), :] = 0
+        return X @ Qcb
+
+    def exchange(agents):
+        for a in agents:
+            idx = np.array([p * dh + c for p in pub[a] for c in range(dh)], dtype=np.int64)
+            buf = torch.zeros(r * len(idx), dtype=torch.float64)
+            if a % world == rank:
+                buf = torch.from_numpy(np.ascontiguousarray(X[:, idx].T).reshape(-1).copy())
+            dist.broadcast(buf, src=a % world)
+            if a % world != rank:
+                X[:, idx] = buf.numpy().reshape(len(idx), r).T
+
+    for it in range(iters):
+        gamma = (1 + np.sqrt(1 + 4.0 * R * R * gamma * gamma)) / (2.0 * R)
+        alpha = 1.0 / (gamma * R)
+        for b in hosted:
+            if b == selected:
+                continue
+            nb = end[b] - start[b]
+            Y = orc.project_to_manifold(r, d, nb, (1 - alpha) * X[:, cols(b)] + alpha * V[b])
+            X[:, cols(b)] = Y
+            V[b] = orc.project_to_manifold(r, d, nb, V[b])
+        exchange([a for a in range(R) if a != selected])
+        if selected in hosted:
+            b = selected
+            nb = end[b] - start[b]
+            Y = orc.project_to_manifold(r, d, nb, (1 - alpha) * X[:, cols(b)] + alpha * V[b])
+            P = orc.Problem(r, d, nb, probs[b], G=G_of(b))
+            Xn, _ = P.optimize(Y)
+            V[b] = orc.project_to_manifold(r, d, nb, V[b] + gamma * (Xn - Y))
+            X[:, cols(b)] = Xn
+        exchange([selected])
+        ev = torch.zeros(2 * R, dtype=torch.float64)
+        for b in hosted:
+            nb = end[b] - start[b]
+            Xb = X[:, cols(b)]
+            EG = Xb @ Qg[cols(b), cols(b)] + G_of(b)
+            RG = orc.tangent_project(r, d, nb, Xb, EG)
+            ev[2 * b] = float(np.sum(RG * RG))
+            ev[2 * b + 1] = float(np.sum(Xb * EG))
+        dist.all_reduce(ev)
+        h = ev.numpy()
+        trace.append((selected, float(h[1::2].sum()), float(np.sqrt(h[0::2].sum()))))
+        selected = int(np.argmax(np.sqrt(h[0::2])))
+    if rank == 0:
+        np.save(os.path.join(tmpdir, "trace.npy"), np.array(trace))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_protocol_matches_single_process(built, tmp_path):
+    import torch.multiprocessing as mp
+    from oracle import orc
+    ds = common.oracle_dataset("smallGrid3D")
+    X0 = common.random_point(5, ds.d, ds.n, 3, orc.project_to_manifold)
+    np.save(tmp_path / "X0.npy", X0)
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(WORLD, port, str(tmp_path)), nprocs=WORLD, join=True)
+    tr = np.load(tmp_path / "trace.npy")
+    ref = orc.run_rbcd(ds, X0, num_robots=5, r_min=5, max_iters=12, staircase=0, rgrad_tol=0.0)
+    # restart interval 30 is not crossed in 12 iterations
+    assert np.array_equal(tr[:, 0].astype(int), ref["selected"])
+    assert np.allclose(tr[:, 1], ref["cost"], rtol=1e-9)
+    assert np.allclose(tr[:, 2], ref["gradnorm"], rtol=1e-7)

@@ -1,0 +1,101 @@
+"""Committed golden vectors (tests/golden/vectors.npz, made by tests/golden/make_golden.py): the oracle must keep
+reproducing them (CPU), and the HIP path must match them through the C ABI (GPU)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import common
+
+GOLD = np.load(os.path.join(common.HERE, "golden", "vectors.npz"))
+CASES = ["tinyGrid3D", "smallGrid3D", "pose_graph_optimization_test_2d"]
+
+
+def _case(name):
+    g = {k.split("/", 1)[1]: GOLD[k] for k in GOLD.files if k.startswith(name + "/")}
+    g["r"] = int(g["r"])
+    return g
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_reproduces_golden(built, name):
+    from oracle import orc
+    g = _case(name)
+    ds = common.oracle_dataset(name)
+    r, d, n = g["r"], ds.d, ds.n
+    P = orc.Problem(r, d, n, orc.build_Q_pgo(ds), G=g["G"])
+    assert np.isclose(P.f(g["X"]), g["f"], rtol=1e-13)
+    assert common.rel(P.rgrad(g["X"]), g["rgrad"]) < 1e-13
+    assert common.rel(P.hess(g["X"], g["Vt"]), g["hess"]) < 1e-13
+    assert common.rel(P.precondition(g["X"], g["Vt"]), g["precond"]) < 1e-12
+    assert common.rel(orc.retract(r, d, n, g["X"], 0.3 * g["Vt"]), g["retract"]) < 1e-14
+    assert common.rel(orc.project_to_manifold(r, d, n, g["M"]), g["polar"]) < 1e-13
+    Xo, res = P.optimize(g["X"])
+    assert res["outer_iters"] == int(g["rtr_outer"]) and res["inner_iters"] == int(g["rtr_inner"])
+    assert np.isclose(res["fOpt"], g["rtr_fOpt"], rtol=1e-12)
+
+
+def test_oracle_rbcd_golden_trace(built):
+    from oracle import orc
+    ds = common.oracle_dataset("smallGrid3D")
+    tr = orc.run_rbcd(ds, GOLD["rbcd/X0"], num_robots=5, r_min=5, max_iters=40, staircase=0, rgrad_tol=0.0)
+    assert np.array_equal(tr["selected"], GOLD["rbcd/selected"])
+    assert np.allclose(tr["cost"], GOLD["rbcd/cost"], rtol=1e-10)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_hip_matches_golden(built, name):
+    import dcora_amd as da
+    g = _case(name)
+    ds = common.product_dataset(name)
+    r, d, n = g["r"], ds.d, ds.n
+    Q = da.build_Q_pgo(ds)
+    P = da.QuadraticProblem(r, d, n, Q, G=g["G"])
+    assert np.isclose(P.f(g["X"]), g["f"], rtol=1e-12)
+    assert common.rel(P.EucGrad(g["X"]), g["egrad"]) < 1e-13
+    assert common.rel(P.RieGrad(g["X"]), g["rgrad"]) < 1e-12
+    assert common.rel(P.projectToTangentSpace(g["X"], g["V"]), g["Vt"]) < 1e-13
+    assert common.rel(P.HessVec(g["X"], g["Vt"]), g["hess"]) < 1e-12
+    assert common.rel(P.PreCondition(g["X"], g["Vt"]), g["precond"]) < 1e-9
+    assert common.rel(P.Retract(g["X"], 0.3 * g["Vt"]), g["retract"]) < 1e-13
+    assert common.rel(da.manifold_project(r, d, n, g["M"]), g["polar"]) < 1e-12
+    opt = da.QuadraticOptimizer(P)
+    X = opt.optimize(g["X"])
+    res = opt.getOptResult()
+    assert res["outer_iterations"] == int(g["rtr_outer"]) and res["inner_iterations"] == int(g["rtr_inner"])
+    assert np.isclose(res["fOpt"], g["rtr_fOpt"], rtol=1e-9)
+    assert common.rel(X, g["rtr_X"]) < 1e-6
+    S = da.dual_certificate(r, d, n, g["X"], Q)
+    ok, lam, v, mv = da.min_eig(S, tol=1e-4)
+    assert ok and abs(lam - float(g["lambda_min_S"])) < 1e-3 * abs(float(g["lambda_min_S"]))
+
+
+@pytest.mark.gpu
+def test_hip_rbcd_golden_trace_and_certified_optimum(built):
+    import dcora_amd as da
+    ds = common.product_dataset("smallGrid3D")
+    s = da.RbcdSession(ds, num_robots=5, r=5)
+    s.set_X(GOLD["rbcd/X0"])
+    out = s.run(max_iters=40, rgrad_tol=0.0)
+    assert np.array_equal(out["selected"], GOLD["rbcd/selected"])
+    assert np.allclose(out["cost"], GOLD["rbcd/cost"], rtol=1e-7)
+    # run to the stopping rule of the reference driver, then certify (ref examples/MultiRobotExample.cpp:284, 321-335)
+    s.set_X(GOLD["rbcd/X0"])
+    out = s.run(max_iters=1000, rgrad_tol=0.1)
+    assert out["gradnorm"][-1] < 0.1
+    assert abs(out["cost"][-1] - float(GOLD["rbcd/final_cost"])) <= 1e-6 * float(GOLD["rbcd/final_cost"])
+    X = s.get_X()
+    S = da.dual_certificate(5, ds.d, ds.n, X, da.build_Q_pgo(ds))
+    psd, theta, v, lmin = da.fast_verification(S, 1e-3, block=ds.d + 1)
+    assert psd
+
+
+@pytest.mark.gpu
+def test_cpp_facade_testprior(built):
+    """the C++ host classes (reference-shaped API) over the C ABI: ref tests/testRobust.cpp:162-226"""
+    exe = os.path.join(common.HERE, "cpp", "_build", "test_facade")
+    assert os.path.exists(exe), "build() compiles tests/cpp/test_facade.cpp"
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
