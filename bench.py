@@ -75,16 +75,33 @@ def run_single(args, da, torch, ds, X0):
 def run_multi(args, da, torch, dist, ds, X0, rank, world):
     """one process per GPU; agent a is hosted by rank a % world"""
     import ctypes as C
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    ndev = torch.cuda.device_count()
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)) % max(ndev, 1))
+    staged = dist.get_backend() != "nccl"  # rehearsal on one GPU: collectives over gloo through host staging
     R, r, dh = args.robots, args.rank_r, ds.d + 1
     s = da.RbcdSession(ds, num_robots=R, r=r, rank=rank, world_size=world, device=dev.index)
     s.set_X(X0)
     counts = [s.public_count(a) for a in range(R)]
     maxc = max(counts)
     owner = [a % world for a in range(R)]
-    send = torch.zeros(r * dh * maxc, dtype=torch.float64, device=dev)
     recv = [torch.zeros(r * dh * maxc, dtype=torch.float64, device=dev) for _ in range(R)]
     evalbuf = torch.zeros(2 * R, dtype=torch.float64, device=dev)
+
+    def bcast(t, src):
+        if staged:
+            h = t.cpu()
+            dist.broadcast(h, src=src)
+            t.copy_(h)
+        else:
+            dist.broadcast(t, src=src)
+
+    def allreduce(t):
+        if staged:
+            h = t.cpu()
+            dist.all_reduce(h)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t)
 
     def exchange(agents):
         # getSharedStateDicts -> packed buffer -> broadcast from the owner -> updateNeighborStates
@@ -93,9 +110,9 @@ def run_multi(args, da, torch, dist, ds, X0, rank, world):
             if owner[a] == rank:
                 s.pack_public_dev(a, buf.data_ptr())
                 s.synchronize()
-            dist.broadcast(buf, src=owner[a])
+            bcast(buf, owner[a])
             if owner[a] != rank:
-                torch.cuda.current_stream().synchronize()
+                torch.cuda.synchronize()
                 s.unpack_public_dev(a, buf.data_ptr())
         s.synchronize()
 
@@ -108,7 +125,7 @@ def run_multi(args, da, torch, dist, ds, X0, rank, world):
         exchange([selected])  # the others need the new block for the evaluation / their next G
         s.phase_evaluate_dev(evalbuf.data_ptr())
         s.synchronize()
-        dist.all_reduce(evalbuf)
+        allreduce(evalbuf)
         h = evalbuf.cpu().numpy()
         bn = np.sqrt(h[0::2])
         cost2 = float(h[1::2].sum())  # 2 f = sum_b <X_b, X_b Q_bb + G_b>
@@ -126,23 +143,75 @@ def run_multi(args, da, torch, dist, ds, X0, rank, world):
     dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt], dtype=torch.float64, device="cpu" if staged else dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return s, float(t.item()), c2, gn
 
 
-def roofline(da, ds, r):
-    """Q-apply kernel Y = X Q + G on the whole graph, timed with HIP events on its own stream"""
+def agent_block(ds, R, b):
+    """measurement arrays of agent b under the reference driver's contiguous partition (local indices, robot ids)"""
+    per = ds.n // R
+    robot = np.minimum(ds.ids[:, [1, 3]] // per, R - 1)
+    start = robot * per
+    ids = ds.ids.copy()
+    ids[:, 0], ids[:, 2] = robot[:, 0], robot[:, 1]
+    ids[:, 1] -= start[:, 0]
+    ids[:, 3] -= start[:, 1]
+    keep = (robot[:, 0] == b) | (robot[:, 1] == b)
+    nb = ds.n - b * per if b == R - 1 else per
+    return nb, ids[keep], ds.vals[keep]
+
+
+def roofline(da, ds, r, robots):
+    """HIP-event timing of the two kernels that carry the bytes of the loop, each on its own stream:
+    - the dominant kernel of the timed loop: k_fused_precond, the dense (Q_bb + 0.1 I)^-1 application of one agent;
+    - the Q-apply kernel k_spmm (Y = X Q + G) on the whole sphere2500 graph and on the synthetic 100k-pose lattice
+      (BASELINE.json config 5), where it is HBM-bound."""
+    out = {}
+    nb, ids, vals = agent_block(ds, robots, 0)
+    Qb = da.build_Q_pgo(ds, n=nb, agent=0, ids=ids, vals=vals)
+    kb = (ds.d + 1) * nb
+    Pb = da.QuadraticProblem(r, ds.d, nb, Qb, G=np.zeros((r, kb)), reg=0.1)
+    Pb.f(np.zeros((r, kb)))
+    ms, nbytes = Pb.time_precond(reps=300)
+    ach = nbytes / (ms * 1e-3) / 1e9
+    main = {"bound": "hbm", "kernel": "k_fused_precond (dense preconditioner application, one agent, k=%d)" % kb,
+            "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+            "bytes_per_launch": nbytes, "avg_launch_us": ms * 1e3}
+    Pb.close()
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            main["traffic"] = json.load(open(pmc)).get("k_fused_precond_bytes_per_launch")
+        except Exception:
+            pass
     Q = da.build_Q_pgo(ds)
     k = (ds.d + 1) * ds.n
     P = da.QuadraticProblem(r, ds.d, ds.n, Q, G=np.zeros((r, k)), reg=-1.0)
     P.f(np.zeros((r, k)))
     ms, nbytes = P.time_qapply(reps=200)
-    achieved = nbytes / (ms * 1e-3) / 1e9
+    ach = nbytes / (ms * 1e-3) / 1e9
     P.close()
-    return {"bound": "hbm", "kernel": "k_spmm (Q-apply, Y = X Q + G)", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "bytes_per_launch": nbytes,
-            "avg_launch_us": ms * 1e3, "k": k, "nnz": Q.nnz}
+    out["qapply_sphere2500"] = {"kernel": "k_spmm (Y = X Q + G)", "achieved": ach, "peak": HBM_PEAK_GBPS,
+                                "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "bytes_per_launch": nbytes,
+                                "avg_launch_us": ms * 1e3, "k": k, "nnz": Q.nnz}
+    try:
+        from dcora_amd import synth
+        big = synth.lattice_se3()
+        Qg = da.build_Q_pgo(big)
+        kg = (big.d + 1) * big.n
+        Pg = da.QuadraticProblem(r, big.d, big.n, Qg, G=np.zeros((r, kg)), reg=-1.0)
+        Pg.f(np.zeros((r, kg)))
+        ms, nbytes = Pg.time_qapply(reps=50)
+        ach = nbytes / (ms * 1e-3) / 1e9
+        Pg.close()
+        out["qapply_lattice100k"] = {"kernel": "k_spmm (Y = X Q + G)", "achieved": ach, "peak": HBM_PEAK_GBPS,
+                                     "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "bytes_per_launch": nbytes,
+                                     "avg_launch_us": ms * 1e3, "k": kg, "nnz": Qg.nnz,
+                                     "workload": "synthetic 50x50x40 SE(3) lattice, seed 20250310, r=%d" % r}
+    except Exception as e:  # the headline line must not depend on the side measurement
+        out["qapply_lattice100k"] = {"error": str(e)}
+    return main, out
 
 
 def cpu_baseline(args, ds_name, X0, gpu_ms_per_step):
@@ -175,13 +244,13 @@ def main():
     import dcora_amd as da
     if da.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: libdcora_hip has no CPU fallback")
-    local = int(os.environ.get("LOCAL_RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0)) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     ds = common.product_dataset(args.dataset)
     X0 = initial_point(da, ds, args.rank_r) if world == 1 else None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl")
+        dist.init_process_group(os.environ.get("DCORA_DIST_BACKEND", "nccl"))
         X0 = initial_point(da, ds, args.rank_r)
         s, dt, c2, gn = run_multi(args, da, torch, dist, ds, X0, rank, world)
     else:
@@ -207,7 +276,7 @@ def main():
                    "parallelism": "agents round-robin over %d rank(s)" % world,
                    "final_cost_2f": c2, "final_gradnorm": gn},
     }
-    line["roofline"] = roofline(da, ds, args.rank_r)
+    line["roofline"], line["roofline_qapply"] = roofline(da, ds, args.rank_r, args.robots)
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args, args.dataset, X0, ms)
         line["config"]["speedup_vs_cpu_port"] = line["value"] / line["cpu_baseline"]["value"]

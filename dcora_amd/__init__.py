@@ -211,6 +211,15 @@ class QuadraticProblem:
         return ms.value, by.value
 
 
+def _time_precond(self, reps=100):
+    ms, by = C.c_double(), C.c_double()
+    check(capi.lib().dcora_problem_time_precond(self.h, reps, C.byref(ms), C.byref(by)))
+    return ms.value, by.value
+
+
+QuadraticProblem.time_precond = _time_precond
+
+
 class QuadraticOptimizer:
     """ref include/DCORA/QuadraticOptimizer.h: optimize(Y), getOptResult()"""
 

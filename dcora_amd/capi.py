@@ -109,6 +109,7 @@ SIGNATURES = {
     "dcora_rbcd_phase_evaluate_dev": (C.c_int, [_vp, _vp]),
     "dcora_rbcd_synchronize": (C.c_int, [_vp]),
     "dcora_problem_time_qapply": (C.c_int, [_vp, C.c_int, _PD, _PD]),
+    "dcora_problem_time_precond": (C.c_int, [_vp, C.c_int, _PD, _PD]),
 }
 
 _lib = None

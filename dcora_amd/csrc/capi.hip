@@ -184,6 +184,10 @@ int dcora_problem_time_qapply(dcora_problem_t p, int reps, double *avg_ms, doubl
   return p ? p->p.time_qapply(reps, avg_ms, bytes) : bad("null");
 }
 
+int dcora_problem_time_precond(dcora_problem_t p, int reps, double *avg_ms, double *bytes) {
+  return p ? p->p.time_precond(reps, avg_ms, bytes) : bad("null");
+}
+
 // ---- CSR handles --------------------------------------------------------------------------------------------
 int dcora_csr_info(dcora_csr_t m, int *n, int *nnz) {
   if (!m) return bad("null");

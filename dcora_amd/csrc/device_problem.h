@@ -56,6 +56,22 @@ struct DevBuf {
   }
 };
 
+struct DevBsr {
+  int nbrows = 0, nblocks = 0;
+  DevBuf<int> bp, bc;
+  DevBuf<double> bv;
+  int upload(const HostBsr &B);
+  BsrDev view() const {
+    BsrDev v;
+    v.nbrows = nbrows;
+    v.nblocks = nblocks;
+    v.bp = bp.p;
+    v.bc = bc.p;
+    v.bv = bv.p;
+    return v;
+  }
+};
+
 struct DevCsr {
   int nrows = 0, ncols = 0, nnz = 0;
   DevBuf<int> rp, ci;
@@ -80,6 +96,10 @@ class DeviceProblem {
   hipStream_t st = nullptr;
   bool own_stream = false;
   DevCsr Q;
+  DevBsr Qb;          // block form of Q (SE layout): the Q-apply fast path
+  bool has_bsr = false;
+  // Y = X Q (+G) with optional {<XQ,X>, <X,G>} partials; returns the number of partial slots written
+  int enq_qapply(Buf2 X, int selX, const double *Gp, Buf2 Y, int selY, double *partials, Gate g);
   DevBuf<double> G;     // r x k (always allocated; zero when the problem has no linear term)
   bool has_G = false;
   DevBuf<double> Minv;  // k x ldm dense inverse of Q + reg I
@@ -113,7 +133,7 @@ class DeviceProblem {
 
   // ---- device-level building blocks (all enqueue on st, no sync) ----
   // EG = X Q + G, partials pA (npA slots of 2)
-  int npA() const { return spmm_grid(m.k, m.r); }
+  int npA() const { return has_bsr ? spmm_bsr_grid(m.n) : spmm_grid(m.k, m.r); }
   int npPose() const { return pose_grid(m); }
   // rgrad / retract with the kernel flavour of this problem; return the number of partial slots written
   int enq_rgrad(Buf2 X, Buf2 EG, Buf2 RG, Buf2 S, int sel, double *partials, Gate g, double *posenorm = nullptr);
@@ -146,6 +166,7 @@ class DeviceProblem {
   int eval_dev(const double *Xd, double *f, double *gradnorm);
 
   int time_qapply(int reps, double *avg_ms, double *bytes);
+  int time_precond(int reps, double *avg_ms, double *bytes);
 
  private:
   int rtr_dev(const dcora_ropt_params &prm, dcora_ropt_result *res, double **Xres);

@@ -35,6 +35,19 @@ int DevCsr::upload(int nr, int nc, const int *rph, const int *cih, const double 
   }
   return DCORA_OK;
 }
+int DevBsr::upload(const HostBsr &B) {
+  nbrows = B.nbrows;
+  nblocks = B.nblocks();
+  DCORA_HIP(bp.alloc(nbrows + 1));
+  DCORA_HIP(bc.alloc(std::max(nblocks, 1)));
+  DCORA_HIP(bv.alloc(std::max<size_t>(B.bv.size(), 1)));
+  DCORA_HIP(hipMemcpy(bp.p, B.bp.data(), sizeof(int) * (nbrows + 1), hipMemcpyHostToDevice));
+  if (nblocks) {
+    DCORA_HIP(hipMemcpy(bc.p, B.bc.data(), sizeof(int) * nblocks, hipMemcpyHostToDevice));
+    DCORA_HIP(hipMemcpy(bv.p, B.bv.data(), sizeof(double) * B.bv.size(), hipMemcpyHostToDevice));
+  }
+  return DCORA_OK;
+}
 int DevCsr::upload(const HostCsr &A) { return upload(A.n, A.ncols, A.rp.data(), A.ci.data(), A.v.data()); }
 
 DeviceProblem::~DeviceProblem() {
@@ -80,6 +93,15 @@ int DeviceProblem::init(const dcora_dims &dims, const HostCsr &Qh, const double 
   }
   int rc = Q.upload(Qh);
   if (rc) return rc;
+  // block form of Q for graphs large enough to be bandwidth-bound (the scalar-CSR kernel exposes more parallelism
+  // and wins while the launch is latency-bound); DCORA_QAPPLY=bsr|csr overrides
+  const char *qa = std::getenv("DCORA_QAPPLY");
+  const bool want_bsr = qa ? (std::string(qa) == "bsr") : (m.n >= 8192);
+  if (m.se && m.r <= 8 && m.n > 0 && want_bsr && std::getenv("DCORA_SOLVER_V1") == nullptr) {
+    rc = Qb.upload(bsr_from_csr(Qh, m.d + 1));
+    if (rc) return rc;
+    has_bsr = true;
+  }
   const size_t N = (size_t)nelem();
   const size_t NS = (size_t)m.n * m.d * m.d + m.l + 1;
   DCORA_HIP(G.alloc(N));
@@ -154,8 +176,16 @@ int DeviceProblem::build_preconditioner(const HostCsr &Qh, double reg) {
   return DCORA_OK;
 }
 
+int DeviceProblem::enq_qapply(Buf2 X, int selX, const double *Gp, Buf2 Y, int selY, double *partials, Gate g) {
+  if (has_bsr) {
+    launch_spmm_bsr(st, m.r, m.d, Qb.view(), X, selX, Gp, Y, selY, partials, g);
+    return spmm_bsr_grid(m.n);
+  }
+  launch_spmm(st, m.r, Q.view(), X, selX, Gp, Y, selY, partials, g);
+  return spmm_grid(m.k, m.r);
+}
 void DeviceProblem::enqueue_egrad(const double *X, double *EG, double *partials) {
-  launch_spmm(st, m.r, Q.view(), buf1(X), 0, has_G ? G.p : nullptr, buf1(EG), 0, partials, Gate{});
+  enq_qapply(buf1(X), 0, has_G ? G.p : nullptr, buf1(EG), 0, partials, Gate{});
 }
 
 int DeviceProblem::enq_rgrad(Buf2 X, Buf2 EG, Buf2 RG, Buf2 S, int sel, double *partials, Gate g,
@@ -524,7 +554,7 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
     return DCORA_ERR_HIP;
   };
   auto outer_done = [&]() { return hf->outer_done_seq >= solve_first; };
-  launch_spmm(st, m.r, Qv, Xb(), 0, Gp, EGb(), 0, pA.p, Gate{c, ++seq, 0});
+  enq_qapply(Xb(), 0, Gp, EGb(), 0, pA.p, Gate{c, ++seq, 0});
   int nG = enq_rgrad(Xb(), EGb(), RGb(), Sb(), 0, pB.p, Gate{c, ++seq, 0});
   launch_rtr_init(st, pA.p, nA, pB.p, nG, c, hf_dev, ++seq);
   int last_pace_seq = seq;
@@ -554,7 +584,7 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
       fin_seq[j] = seq;
     }
     const int nR = enq_retract(Xb(), eta.p, 1.0, Xb(), 1, RGb(), Heta.p, pC.p, Gate{c, ++seq, 1});
-    launch_spmm(st, m.r, Qv, Xb(), 1, Gp, EGb(), 1, pA.p, Gate{c, ++seq, 1});
+    enq_qapply(Xb(), 1, Gp, EGb(), 1, pA.p, Gate{c, ++seq, 1});
     nG = enq_rgrad(Xb(), EGb(), RGb(), Sb(), 1, pB.p, Gate{c, ++seq, 1});
     launch_rtr_decide(st, pA.p, nA, pB.p, nG, pC.p, nR, c, hf_dev, ++seq);
     last_pace_seq = seq;
@@ -639,4 +669,37 @@ int DeviceProblem::time_qapply(int reps, double *avg_ms, double *bytes) {
   return DCORA_OK;
 }
 
+}  // namespace dcora
+
+namespace dcora {
+// times the dense-preconditioner kernel of the solver (k_fused_precond in its start-of-tCG form: residual = grad,
+// no step) with HIP events on the problem's stream
+int DeviceProblem::time_precond(int reps, double *avg_ms, double *bytes) {
+  if (!has_precond || !fused) {
+    set_last_error("time_precond: needs the fused solver path and a preconditioner");
+    return DCORA_ERR_UNSUPPORTED;
+  }
+  DCORA_HIP(hipSetDevice(device));
+  launch_ctl_init(st, ctl.p, 1e-2, 100, 500, 3, 0, 50);
+  hipEvent_t e0, e1;
+  DCORA_HIP(hipEventCreate(&e0));
+  DCORA_HIP(hipEventCreate(&e1));
+  auto run = [&]() {
+    launch_fused_precond(st, m, ldm, Minv.p, RGb(), nullptr, nullptr, eta.p, Heta.p, nullptr, res.p, Zpart.p, nullptr,
+                         0, p2.p, ctl.p, hf_dev, 1, 0, 1);
+  };
+  for (int i = 0; i < 3; ++i) run();
+  DCORA_HIP(hipEventRecord(e0, st));
+  for (int i = 0; i < reps; ++i) run();
+  DCORA_HIP(hipEventRecord(e1, st));
+  DCORA_HIP(hipEventSynchronize(e1));
+  float ms = 0;
+  DCORA_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *avg_ms = (double)ms / reps;
+  // algorithmic bytes: the k x k inverse once, the residual in, the split-K slices out
+  *bytes = 8.0 * m.k * (double)m.k + 8.0 * m.r * m.k + 8.0 * m.r * m.k * fused_nsplit(m);
+  return DCORA_OK;
+}
 }  // namespace dcora

@@ -44,6 +44,37 @@ HostCsr csr_from_coo(int nrows, int ncols, const std::vector<int> &I, const std:
   return A;
 }
 
+HostBsr bsr_from_csr(const HostCsr &A, int bs) {
+  HostBsr B;
+  B.bs = bs;
+  B.nbrows = A.n / bs;
+  B.bp.assign(B.nbrows + 1, 0);
+  std::vector<int> slot;  // block column -> position in the current block row
+  std::vector<int> cols;
+  for (int bi = 0; bi < B.nbrows; ++bi) {
+    cols.clear();
+    for (int a = 0; a < bs; ++a) {
+      const int i = bi * bs + a;
+      for (int p = A.rp[i]; p < A.rp[i + 1]; ++p) cols.push_back(A.ci[p] / bs);
+    }
+    std::sort(cols.begin(), cols.end());
+    cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+    const size_t first = B.bc.size();
+    B.bc.insert(B.bc.end(), cols.begin(), cols.end());
+    B.bv.resize(B.bc.size() * (size_t)bs * bs, 0.0);
+    for (int a = 0; a < bs; ++a) {
+      const int i = bi * bs + a;
+      for (int p = A.rp[i]; p < A.rp[i + 1]; ++p) {
+        const int bcj = A.ci[p] / bs, c = A.ci[p] - bcj * bs;
+        const size_t pos = first + (std::lower_bound(cols.begin(), cols.end(), bcj) - cols.begin());
+        B.bv[pos * bs * bs + (size_t)a * bs + c] += A.v[p];
+      }
+    }
+    B.bp[bi + 1] = (int)B.bc.size();
+  }
+  return B;
+}
+
 HostCsr csr_shift_diag(const HostCsr &A, double s) {
   HostCsr B;
   B.n = A.n;

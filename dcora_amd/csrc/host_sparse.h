@@ -16,6 +16,15 @@ struct HostCsr {
   int nnz() const { return (int)ci.size(); }
 };
 
+// block-CSR with dense bs x bs blocks (row-major inside a block), pattern = union of the scalar entries' blocks
+struct HostBsr {
+  int nbrows = 0, bs = 0;
+  std::vector<int> bp, bc;
+  std::vector<double> bv;
+  int nblocks() const { return (int)bc.size(); }
+};
+HostBsr bsr_from_csr(const HostCsr &A, int bs);
+
 // builds a CSR from (row, col, val) triplets, summing duplicates, columns sorted inside rows
 HostCsr csr_from_coo(int nrows, int ncols, const std::vector<int> &I, const std::vector<int> &J,
                      const std::vector<double> &V);

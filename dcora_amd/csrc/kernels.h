@@ -41,6 +41,15 @@ struct CsrDev {
   const double *v = nullptr;
 };
 
+// block-CSR view of a pose-graph matrix: (d+1) x (d+1) dense blocks, row-major inside a block
+struct BsrDev {
+  int nbrows = 0;
+  int nblocks = 0;
+  const int *bp = nullptr;   // block row pointers (nbrows + 1)
+  const int *bc = nullptr;   // block column indices
+  const double *bv = nullptr;  // (d+1)^2 values per block
+};
+
 // two-buffer handle: the RTR solver keeps the accepted iterate and the trial point in a pair of buffers and
 // flips an index in device memory on acceptance, so kernels choose their operand on the device.
 struct Buf2 {
@@ -88,6 +97,12 @@ struct Gate {
 int spmm_grid(int nrows, int r);
 void launch_spmm(hipStream_t st, int r, const CsrDev &A, Buf2 X, int selX, const double *G, Buf2 Y, int selY,
                  double *partials, Gate g);
+
+// BSR flavour for the SE layout (8 lanes per pose, one gather of the neighbour's r x (d+1) block per matrix block);
+// returns the number of partial slots written (2 doubles each)
+int spmm_bsr_grid(int nbrows);
+void launch_spmm_bsr(hipStream_t st, int r, int d, const BsrDev &A, Buf2 X, int selX, const double *G, Buf2 Y,
+                     int selY, double *partials, Gate g);
 
 // ---- per-pose kernels -------------------------------------------------------------------------------
 int pose_grid(const ManiDesc &m);

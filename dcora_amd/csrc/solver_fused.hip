@@ -812,6 +812,93 @@ __global__ __launch_bounds__(kBlock) void k_g_nesterov(ManiDesc m, GNesterovArgs
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Q-apply on the block structure of the connection Laplacian: Y = X Q (+ G), Q in BSR with (d+1)^2 blocks.
+// 8 lanes per block row (pose): lane t gathers row t of the neighbour's r x (d+1) block once per matrix block
+// (4 loads of 8 B, the r lanes reading r contiguous doubles) and applies the whole (d+1)^2 block to it; block
+// values and column indices of the workgroup's 32 block rows are staged in LDS with coalesced loads and read back
+// as broadcasts.  Four times fewer gather instructions and ~25 % fewer bytes than the scalar-CSR kernel.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kBsrTile = 160;  // matrix blocks staged per pass (20 KiB at (d+1)^2 = 16)
+
+template <int D, bool DOTS>
+__global__ __launch_bounds__(kBlock) void k_spmm_bsr(int r, BsrDev A, Buf2 Xb, int selX,
+                                                     const double *__restrict__ G, Buf2 Yb, int selY,
+                                                     double *__restrict__ partials, Gate g) {
+  if (g.ctl && g.gate && f_gated(g.ctl, g.seq, g.gate)) return;
+  constexpr int DH = D + 1, BS = DH * DH;
+  __shared__ double s_bv[kBsrTile * BS];
+  __shared__ int s_bc[kBsrTile];
+  __shared__ double s_red[16];
+  const int cur = g.ctl ? (g.ctl->cur & 1) : 0;
+  const double *__restrict__ X = Xb.p[g.ctl ? ((cur ^ selX) & 1) : 0];
+  double *__restrict__ Y = Yb.p[g.ctl ? ((cur ^ selY) & 1) : 0];
+  const int t = threadIdx.x & (GW - 1);
+  double d0 = 0, d1 = 0;
+  for (int pose0 = blockIdx.x * kPosesPerBlock; pose0 < A.nbrows; pose0 += gridDim.x * kPosesPerBlock) {
+    const int pose = pose0 + (threadIdx.x >> 3);
+    const bool inr = pose < A.nbrows;
+    const bool active = inr && (t < r);
+    const int pend_pose = min(A.nbrows, pose0 + kPosesPerBlock);
+    const int bbeg = A.bp[pose0], bend = A.bp[pend_pose];
+    const int myb = inr ? A.bp[pose] : 0, mye = inr ? A.bp[pose + 1] : 0;
+    double acc[DH];
+#pragma unroll
+    for (int a = 0; a < DH; ++a) acc[a] = 0;
+    for (int base = bbeg; base < bend; base += kBsrTile) {
+      const int cnt = min(kBsrTile, bend - base);
+      __syncthreads();
+      for (int i = threadIdx.x; i < cnt * BS; i += kBlock) s_bv[i] = A.bv[(size_t)base * BS + i];
+      for (int i = threadIdx.x; i < cnt; i += kBlock) s_bc[i] = A.bc[base + i];
+      __syncthreads();
+      const int lo = max(myb, base) - base, hi = min(mye, base + cnt) - base;
+      for (int b = lo; b < hi; b += 2) {
+        // two matrix blocks per step: 2 (d+1) independent gathers in flight
+        const bool two = b + 1 < hi;
+        const size_t o0 = (size_t)s_bc[b] * DH * r + t;
+        const size_t o1 = two ? (size_t)s_bc[b + 1] * DH * r + t : o0;
+        double x0[DH], x1[DH];
+#pragma unroll
+        for (int c = 0; c < DH; ++c) {
+          x0[c] = active ? X[o0 + c * r] : 0.0;
+          x1[c] = (active && two) ? X[o1 + c * r] : 0.0;
+        }
+        const double *__restrict__ B0 = s_bv + b * BS;
+        const double *__restrict__ B1 = s_bv + (two ? b + 1 : b) * BS;
+#pragma unroll
+        for (int a = 0; a < DH; ++a) {
+          double s = 0;
+#pragma unroll
+          for (int c = 0; c < DH; ++c) s += B0[a * DH + c] * x0[c] + B1[a * DH + c] * x1[c];
+          acc[a] += s;
+        }
+      }
+    }
+    if (active) {
+      const size_t o = (size_t)pose * DH * r + t;
+#pragma unroll
+      for (int a = 0; a < DH; ++a) {
+        double y = acc[a];
+        if (DOTS) {
+          const double x = X[o + a * r];
+          d0 += acc[a] * x;
+          if (G) d1 += x * G[o + a * r];
+        }
+        if (G) y += G[o + a * r];
+        Y[o + a * r] = y;
+      }
+    }
+  }
+  if (DOTS) {
+    const double a = f_block_sum(d0, s_red);
+    const double b = f_block_sum(d1, s_red);
+    if (threadIdx.x == 0) {
+      partials[2 * blockIdx.x] = a;
+      partials[2 * blockIdx.x + 1] = b;
+    }
+  }
+}
+
 int group_grid(int n) {
   long g = ((long)n + kPosesPerBlock - 1) / kPosesPerBlock;
   if (g < 1) g = 1;
@@ -893,6 +980,25 @@ __global__ __launch_bounds__(kBlock) void k_eval_finish(int R, const int *__rest
 void launch_eval_finish(hipStream_t st, int R, const int *pose_start, const double *posenorm, const double *pA,
                         int npA, EvalOut *out_dev, int seq) {
   hipLaunchKernelGGL(k_eval_finish, dim3(1), dim3(kBlock), 0, st, R, pose_start, posenorm, pA, npA, out_dev, seq);
+}
+
+int spmm_bsr_grid(int nbrows) { return group_grid(nbrows); }
+void launch_spmm_bsr(hipStream_t st, int r, int d, const BsrDev &A, Buf2 X, int selX, const double *G, Buf2 Y,
+                     int selY, double *partials, Gate g) {
+  const int grid = spmm_bsr_grid(A.nbrows);
+  if (d == 3) {
+    if (partials)
+      hipLaunchKernelGGL((k_spmm_bsr<3, true>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials, g);
+    else
+      hipLaunchKernelGGL((k_spmm_bsr<3, false>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials,
+                         g);
+  } else {
+    if (partials)
+      hipLaunchKernelGGL((k_spmm_bsr<2, true>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials, g);
+    else
+      hipLaunchKernelGGL((k_spmm_bsr<2, false>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials,
+                         g);
+  }
 }
 
 bool fused_supported(const ManiDesc &m) {

@@ -211,6 +211,8 @@ int dcora_rbcd_synchronize(dcora_rbcd_t s);
 /* times `reps` launches of the Q-apply kernel Y = X Q + G of a problem with HIP events on the handle's
  * stream; returns average milliseconds per launch and the algorithmic bytes of one launch */
 int dcora_problem_time_qapply(dcora_problem_t p, int reps, double *avg_ms, double *algorithmic_bytes);
+/* same for the preconditioner application kernel z = Proj_X(r (Q + reg I)^-1) (dense-inverse streaming part) */
+int dcora_problem_time_precond(dcora_problem_t p, int reps, double *avg_ms, double *algorithmic_bytes);
 
 #ifdef __cplusplus
 }
