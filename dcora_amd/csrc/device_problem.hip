@@ -526,7 +526,7 @@ int DeviceProblem::rtr_dev(const dcora_ropt_params &prm, dcora_ropt_result *res_
 //   B (step length + vector updates + |r|^2 + dense preconditioner slices)
 //   C (stopping rule + slice sum + tangent projection + <z,r>)
 int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
-  constexpr int kLookahead = 2;
+  static const int kLookahead = std::getenv("DCORA_LOOKAHEAD") ? std::max(1, atoi(std::getenv("DCORA_LOOKAHEAD"))) : 2;
   const auto t0 = std::chrono::steady_clock::now();
   t0_ms_ = std::chrono::duration<double, std::milli>(t0.time_since_epoch()).count();
   const bool single = (prm.RTR_iterations == 1);
