@@ -99,6 +99,45 @@ def build_Q_pgo(ds, n=None, agent=0, ids=None, vals=None):
     return Csr(*capi.take_csr(h))
 
 
+class RADataset:
+    """centralised range-aided SLAM problem read from a .pyfg file (ref src/DCORA_utils.cpp:437-1167, 1169-1365;
+    Q: ref src/Graph.cpp:824-1188).  X is r x k in the RA ordering [Y1..Yn | s1..sl | p1..pn | L1..Lb]."""
+
+    def __init__(self, path):
+        L = capi.lib()
+        tmp = None
+        if str(path).endswith(".gz"):
+            fd, tmp = tempfile.mkstemp(suffix=".pyfg")
+            with os.fdopen(fd, "wb") as out, gzip.open(path, "rb") as src:
+                shutil.copyfileobj(src, out)
+            path = tmp
+        try:
+            h = C.c_void_p()
+            check(L.dcora_radataset_load_pyfg(str(path).encode(), C.byref(h)))
+        finally:
+            if tmp:
+                os.unlink(tmp)
+        info = np.zeros(7, np.int32)
+        check(L.dcora_radataset_info(h, info))
+        self.d, self.n, self.l, self.b = (int(x) for x in info[:4])
+        self.num_pose_pose, self.num_pose_landmark, self.num_range = (int(x) for x in info[4:])
+        self.k = (self.d + 1) * self.n + self.l + self.b
+        gt = np.zeros(self.d * self.k)
+        check(L.dcora_radataset_ground_truth(h, gt))
+        self.gt = unF(gt, self.d, self.k)
+        q = C.c_void_p()
+        check(L.dcora_radataset_build_Q(h, C.byref(q)))
+        self.Q = Csr(*capi.take_csr(q))
+        L.dcora_radataset_destroy(h)
+
+
+def precond_regularization(Q, device=0):
+    """Graph::computePreconditionerRegularization (ref src/Graph.cpp:1921-1960)"""
+    reg = C.c_double()
+    check(capi.lib().dcora_graph_precond_regularization(Q.n, Q.rp, Q.ci, Q.v, device, C.byref(reg)))
+    return reg.value
+
+
 class ROptParameters:
     """ref include/DCORA/DCORA_types.h:152-168"""
     RTR, RGD = 0, 1

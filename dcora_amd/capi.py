@@ -91,6 +91,12 @@ SIGNATURES = {
     "dcora_dataset_copy": (C.c_int, [_vp, _ip, _dp]),
     "dcora_dataset_destroy": (C.c_int, [_vp]),
     "dcora_graph_build_Q_pgo": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _ip, _dp, C.POINTER(_vp)]),
+    "dcora_radataset_load_pyfg": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
+    "dcora_radataset_info": (C.c_int, [_vp, _ip]),
+    "dcora_radataset_ground_truth": (C.c_int, [_vp, _dp]),
+    "dcora_radataset_build_Q": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "dcora_radataset_destroy": (C.c_int, [_vp]),
+    "dcora_graph_precond_regularization": (C.c_int, [C.c_int, _ip, _ip, _dp, C.c_int, _PD]),
     "dcora_rbcd_options_default": (None, [C.POINTER(RbcdOptions)]),
     "dcora_rbcd_create": (C.c_int, [_vp, C.POINTER(RbcdOptions), C.POINTER(_vp)]),
     "dcora_rbcd_destroy": (C.c_int, [_vp]),

@@ -323,6 +323,68 @@ int dcora_graph_build_Q_pgo(int d, int n, int agent_id, int m, const int *ids, c
   DCORA_CATCH
 }
 
+// ---- range-aided SLAM data feed (centralised) -----------------------------------------------------------------------
+struct dcora_radataset_s {
+  HostRADataset ds;
+};
+int dcora_radataset_load_pyfg(const char *path, dcora_radataset_t *out) {
+  if (!path || !out) return bad("null argument");
+  DCORA_TRY
+  dcora_radataset_s *h = new dcora_radataset_s;
+  std::string err;
+  if (!load_pyfg(path, h->ds, err)) {
+    delete h;
+    set_last_error(err);
+    return DCORA_ERR_IO;
+  }
+  *out = h;
+  return DCORA_OK;
+  DCORA_CATCH
+}
+int dcora_radataset_info(dcora_radataset_t h, int *info) {
+  if (!h || !info) return bad("null");
+  info[0] = h->ds.d;
+  info[1] = h->ds.n;
+  info[2] = h->ds.l;
+  info[3] = h->ds.b;
+  info[4] = (int)h->ds.pose_pose.size();
+  info[5] = (int)h->ds.pose_landmark.size();
+  info[6] = (int)h->ds.ranges.size();
+  return DCORA_OK;
+}
+int dcora_radataset_ground_truth(dcora_radataset_t h, double *gt) {
+  if (!h || !gt) return bad("null");
+  std::copy(h->ds.gt.begin(), h->ds.gt.end(), gt);
+  return DCORA_OK;
+}
+int dcora_radataset_build_Q(dcora_radataset_t h, dcora_csr_t *Q) {
+  if (!h || !Q) return bad("null");
+  DCORA_TRY
+  dcora_csr_s *c = new dcora_csr_s;
+  c->m = build_Q_ra(h->ds);
+  *Q = c;
+  return DCORA_OK;
+  DCORA_CATCH
+}
+int dcora_radataset_destroy(dcora_radataset_t h) {
+  delete h;
+  return DCORA_OK;
+}
+int dcora_graph_precond_regularization(int k, const int *rp, const int *ci, const double *v, int device, double *reg) {
+  if (!rp || !ci || !v || !reg) return bad("null argument");
+  DCORA_TRY
+  *reg = 1e-1;  // default when the eigenvalue computation is unsuccessful (ref src/Graph.cpp:1923, 1932-1939)
+  DeviceLanczos L;
+  int rc = L.init(view_csr(k, rp, ci, v), device);
+  if (rc) return rc;
+  LanczosResult e;
+  rc = L.largest_magnitude(0.0, std::min(6, k), 10000, 1e-3, nullptr, 1, &e);
+  if (rc) return rc;
+  if (e.ok && e.lambda > 0) *reg = e.lambda / (1e6 - 1);
+  return DCORA_OK;
+  DCORA_CATCH
+}
+
 // ---- RBCD session -----------------------------------------------------------------------------------------------
 void dcora_rbcd_options_default(dcora_rbcd_options *o) {
   o->num_robots = 5;

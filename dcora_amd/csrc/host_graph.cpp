@@ -206,3 +206,275 @@ HostCsr build_coupling_pgo(int d, const Partition &P, int b, const std::vector<P
 }
 
 }  // namespace dcora
+
+// ---------------------------------------------------------------------------------------------------------------
+// Range-aided SLAM (centralised agent)
+// ---------------------------------------------------------------------------------------------------------------
+#include <map>
+#include <set>
+#include <tuple>
+
+namespace dcora {
+namespace {
+struct SymH {
+  int type, robot, id;
+};
+// 'A'.. = robots, 'L' + upper-case = that robot's landmark, 'L' + digits = map landmark (robot 'M')
+// (ref src/DCORA_utils.cpp:584-616)
+bool parse_sym(const std::string &s, SymH &o) {
+  if (s.empty()) return false;
+  o = SymH{0, 0, 0};
+  if (s[0] == 'L') {
+    o.type = 1;
+    if (s.size() > 1 && std::isupper((unsigned char)s[1])) {
+      o.robot = s[1] - 'A';
+      o.id = std::atoi(s.c_str() + 2);
+    } else {
+      o.robot = 'M' - 'A';
+      o.id = std::atoi(s.c_str() + 1);
+    }
+    return true;
+  }
+  if (std::isupper((unsigned char)s[0])) {
+    o.robot = s[0] - 'A';
+    o.id = std::atoi(s.c_str() + 1);
+    return true;
+  }
+  return false;
+}
+void quat_to_R(double x, double y, double z, double w, double *R) {
+  R[0] = 1 - 2 * (y * y + z * z);
+  R[1] = 2 * (x * y + z * w);
+  R[2] = 2 * (x * z - y * w);
+  R[3] = 2 * (x * y - z * w);
+  R[4] = 1 - 2 * (x * x + z * z);
+  R[5] = 2 * (y * z + x * w);
+  R[6] = 2 * (x * z + y * w);
+  R[7] = 2 * (y * z - x * w);
+  R[8] = 1 - 2 * (x * x + y * y);
+}
+}  // namespace
+
+bool load_pyfg(const std::string &path, HostRADataset &ds, std::string &err) {
+  std::ifstream in(path);
+  if (!in) {
+    err = "cannot open " + path;
+    return false;
+  }
+  ds = HostRADataset();
+  using Key = std::pair<int, int>;
+  std::map<Key, std::vector<double>> poses, lms;  // (robot, id) -> [R (d*d, col-major) | t] resp. [t]
+  struct EPP { SymH a, b; PoseMeas m; };
+  struct EPL { SymH a, b; PoseLandmarkMeasH m; };
+  struct ERG { SymH a, b; RangeMeasH m; int robot_l; };
+  std::vector<EPP> pps;
+  std::vector<EPL> pls;
+  std::vector<ERG> rgs;
+  std::map<int, int> nsph;
+  std::set<std::tuple<int, int, int, int, int, int>> seen;
+  std::string line, tok, s1, s2;
+  double ts;
+  while (std::getline(in, line)) {
+    std::istringstream ss(line);
+    if (!(ss >> tok)) continue;
+    SymH a, b;
+    if (tok == "VERTEX_SE2" || tok == "VERTEX_SE3:QUAT") {
+      const int d = tok == "VERTEX_SE2" ? 2 : 3;
+      ds.d = d;
+      ss >> ts >> s1;
+      if (!parse_sym(s1, a)) { err = "bad symbol " + s1; return false; }
+      std::vector<double> rec(d * d + d);
+      if (d == 2) {
+        double x, y, th;
+        ss >> x >> y >> th;
+        rec = {std::cos(th), std::sin(th), -std::sin(th), std::cos(th), x, y};
+      } else {
+        double x, y, z, qx, qy, qz, qw;
+        ss >> x >> y >> z >> qx >> qy >> qz >> qw;
+        quat_to_R(qx, qy, qz, qw, rec.data());
+        rec[9] = x; rec[10] = y; rec[11] = z;
+      }
+      poses[{a.robot, a.id}] = rec;
+    } else if (tok == "VERTEX_XY" || tok == "VERTEX_XYZ") {
+      const int d = tok == "VERTEX_XY" ? 2 : 3;
+      ss >> s1;
+      if (!parse_sym(s1, a)) { err = "bad symbol " + s1; return false; }
+      std::vector<double> t(d);
+      for (double &q : t) ss >> q;
+      lms[{a.robot, a.id}] = t;
+    } else if (tok == "EDGE_SE2" || tok == "EDGE_SE3:QUAT") {
+      const int d = tok == "EDGE_SE2" ? 2 : 3;
+      EPP e;
+      ss >> ts >> s1 >> s2;
+      if (!parse_sym(s1, e.a) || !parse_sym(s2, e.b)) { err = "bad symbol in " + line; return false; }
+      if (d == 2) {
+        double x, y, th, c[6];
+        ss >> x >> y >> th;
+        for (double &q : c) ss >> q;
+        e.m.t[0] = x; e.m.t[1] = y;
+        e.m.R[0] = std::cos(th); e.m.R[1] = std::sin(th); e.m.R[2] = -std::sin(th); e.m.R[3] = std::cos(th);
+        e.m.tau = 2.0 / (c[0] + c[3]);   // 2 / trace(cov_t)  (ref :546-557)
+        e.m.kappa = 1.0 / c[5];          // 1 / cov_theta     (ref :566-573)
+      } else {
+        double x, y, z, qx, qy, qz, qw, c[21];
+        ss >> x >> y >> z >> qx >> qy >> qz >> qw;
+        for (double &q : c) ss >> q;
+        e.m.t[0] = x; e.m.t[1] = y; e.m.t[2] = z;
+        quat_to_R(qx, qy, qz, qw, e.m.R);
+        e.m.tau = 3.0 / (c[0] + c[6] + c[11]);
+        e.m.kappa = 3.0 / (2.0 * (c[15] + c[18] + c[20]));
+      }
+      pps.push_back(e);
+    } else if (tok == "EDGE_SE2_XY" || tok == "EDGE_SE3_XYZ") {
+      const int d = tok == "EDGE_SE2_XY" ? 2 : 3;
+      EPL e;
+      ss >> ts >> s1 >> s2;
+      if (!parse_sym(s1, e.a) || !parse_sym(s2, e.b)) { err = "bad symbol in " + line; return false; }
+      for (int i = 0; i < d; ++i) ss >> e.m.t[i];
+      std::vector<double> c(d * (d + 1) / 2);
+      for (double &q : c) ss >> q;
+      e.m.tau = d / (d == 2 ? c[0] + c[2] : c[0] + c[3] + c[5]);
+      pls.push_back(e);
+    } else if (tok == "EDGE_RANGE") {
+      ERG e;
+      double range, cov;
+      ss >> ts >> s1 >> s2 >> range >> cov;
+      if (!parse_sym(s1, e.a) || !parse_sym(s2, e.b)) { err = "bad symbol in " + line; return false; }
+      if (!seen.insert(std::make_tuple(e.a.type, e.a.robot, e.a.id, e.b.type, e.b.robot, e.b.id)).second) continue;
+      e.m.range = range;
+      e.m.precision = 1.0 / cov;
+      e.robot_l = nsph[e.a.robot]++;  // unit sphere owned by the source robot (ref :1092-1097)
+      rgs.push_back(e);
+    }
+  }
+  if (ds.d != 2 && ds.d != 3) {
+    err = "no pose vertices in " + path;
+    return false;
+  }
+  const int d = ds.d;
+  std::map<Key, int> pidx, lidx;
+  for (auto &kv : poses) { const int i = (int)pidx.size(); pidx[kv.first] = i; }
+  for (auto &kv : lms) { const int i = (int)lidx.size(); lidx[kv.first] = i; }
+  std::map<int, int> sbase;
+  int acc = 0;
+  for (auto &kv : nsph) {
+    sbase[kv.first] = acc;
+    acc += kv.second;
+  }
+  ds.n = (int)pidx.size();
+  ds.b = (int)lidx.size();
+  ds.l = acc;
+  auto state = [&](const SymH &s, int &idx) {
+    auto &mp = s.type ? lidx : pidx;
+    auto it = mp.find({s.robot, s.id});
+    if (it == mp.end()) return false;
+    idx = it->second;
+    return true;
+  };
+  for (auto &e : pps) {
+    PoseMeas m = e.m;
+    m.r1 = m.r2 = 0;
+    m.weight = 1;
+    if (!state(e.a, m.p1) || !state(e.b, m.p2)) { err = "edge refers to an unknown vertex"; return false; }
+    ds.pose_pose.push_back(m);
+  }
+  for (auto &e : pls) {
+    PoseLandmarkMeasH m = e.m;
+    if (!state(e.a, m.i) || !state(e.b, m.j)) { err = "edge refers to an unknown vertex"; return false; }
+    ds.pose_landmark.push_back(m);
+  }
+  for (auto &e : rgs) {
+    RangeMeasH m = e.m;
+    m.type1 = e.a.type;
+    m.type2 = e.b.type;
+    if (!state(e.a, m.i) || !state(e.b, m.j)) { err = "edge refers to an unknown vertex"; return false; }
+    m.l = sbase[e.a.robot] + e.robot_l;
+    ds.ranges.push_back(m);
+  }
+  const int k = ds.k();
+  ds.gt.assign((size_t)d * k, 0.0);
+  std::vector<const std::vector<double> *> prec(ds.n), lrec(ds.b);
+  for (auto &kv : poses) prec[pidx[kv.first]] = &kv.second;
+  for (auto &kv : lms) lrec[lidx[kv.first]] = &kv.second;
+  for (int i = 0; i < ds.n; ++i) {
+    const std::vector<double> &r = *prec[i];
+    for (int c = 0; c < d; ++c)
+      for (int a = 0; a < d; ++a) ds.gt[(size_t)(i * d + c) * d + a] = r[a + c * d];
+    for (int a = 0; a < d; ++a) ds.gt[(size_t)(d * ds.n + ds.l + i) * d + a] = r[d * d + a];
+  }
+  for (int i = 0; i < ds.b; ++i)
+    for (int a = 0; a < d; ++a) ds.gt[(size_t)(d * ds.n + ds.l + ds.n + i) * d + a] = (*lrec[i])[a];
+  for (const RangeMeasH &m : ds.ranges) {
+    double v[3] = {0, 0, 0}, nn = 0;
+    for (int a = 0; a < d; ++a) {
+      const double t1 = m.type1 ? (*lrec[m.i])[a] : (*prec[m.i])[d * d + a];
+      const double t2 = m.type2 ? (*lrec[m.j])[a] : (*prec[m.j])[d * d + a];
+      v[a] = t1 - t2;
+      nn += v[a] * v[a];
+    }
+    nn = std::sqrt(nn);
+    for (int a = 0; a < d; ++a) ds.gt[(size_t)(d * ds.n + m.l) * d + a] = nn > 0 ? v[a] / nn : 0.0;
+  }
+  return true;
+}
+
+// Closed-form blocks per factor (X = [Y | s | p | L]):
+//   pose-pose (i -> j):      1/2 kappa |Y_j - Y_i R|^2 + 1/2 tau |p_j - p_i - Y_i t|^2
+//   pose-landmark (i -> L):  1/2 tau |L - p_i - Y_i t|^2
+//   range (x_i, x_j, s):     1/2 omega |x_j - x_i + rho s|^2      (s = direction from x_j to x_i)
+HostCsr build_Q_ra(const HostRADataset &ds) {
+  const int d = ds.d, n = ds.n, l = ds.l;
+  const int oS = d * n, oP = d * n + l, oL = d * n + l + n;
+  std::vector<int> I, J;
+  std::vector<double> V;
+  auto put = [&](int i, int j, double v) {
+    I.push_back(i);
+    J.push_back(j);
+    V.push_back(v);
+  };
+  auto put_sym = [&](int i, int j, double v) {
+    put(i, j, v);
+    put(j, i, v);
+  };
+  auto trans_terms = [&](int yi, const double *t, double tau, int ci, int cj) {
+    // tau |x_cj - x_ci - Y_i t|^2 expanded
+    for (int a = 0; a < d; ++a)
+      for (int b = 0; b < d; ++b) put(yi * d + a, yi * d + b, tau * t[a] * t[b]);
+    for (int a = 0; a < d; ++a) {
+      put_sym(yi * d + a, ci, tau * t[a]);
+      put_sym(yi * d + a, cj, -tau * t[a]);
+    }
+    put(ci, ci, tau);
+    put(cj, cj, tau);
+    put_sym(ci, cj, -tau);
+  };
+  for (const PoseMeas &e : ds.pose_pose) {
+    const int i = e.p1, j = e.p2;
+    const double kap = e.weight * e.kappa, tau = e.weight * e.tau;
+    for (int a = 0; a < d; ++a)
+      for (int b = 0; b < d; ++b) {
+        double rrt = 0;
+        for (int c = 0; c < d; ++c) rrt += e.R[a + c * d] * e.R[b + c * d];
+        put(i * d + a, i * d + b, kap * rrt);
+        put_sym(i * d + a, j * d + b, -kap * e.R[a + b * d]);
+      }
+    for (int a = 0; a < d; ++a) put(j * d + a, j * d + a, kap);
+    trans_terms(i, e.t, tau, oP + i, oP + j);
+  }
+  for (const PoseLandmarkMeasH &e : ds.pose_landmark) trans_terms(e.i, e.t, e.weight * e.tau, oP + e.i, oL + e.j);
+  for (const RangeMeasH &e : ds.ranges) {
+    const double w = e.weight * e.precision, rho = e.range;
+    const int ci = (e.type1 ? oL : oP) + e.i, cj = (e.type2 ? oL : oP) + e.j, cs = oS + e.l;
+    put(cs, cs, w * rho * rho);
+    put_sym(cs, cj, w * rho);
+    put_sym(cs, ci, -w * rho);
+    put(ci, ci, w);
+    put(cj, cj, w);
+    put_sym(ci, cj, -w);
+  }
+  const int k = ds.k();
+  for (int q = 0; q < k; ++q) put(q, q, 0.0);
+  return csr_from_coo(k, k, I, J, V);
+}
+
+}  // namespace dcora

@@ -40,3 +40,26 @@ struct Partition {
 HostCsr build_coupling_pgo(int d, const Partition &P, int b, const std::vector<PoseMeas> &global_meas);
 
 }  // namespace dcora
+
+namespace dcora {
+// ---- range-aided SLAM, centralised agent (ref src/Graph.cpp:824-1188; src/DCORA_utils.cpp:437-1167, 1169-1365) ----
+struct PoseLandmarkMeasH {
+  int i = 0, j = 0;
+  double t[3] = {0}, tau = 0, weight = 1;
+};
+struct RangeMeasH {
+  int type1 = 0, i = 0, type2 = 0, j = 0, l = 0;  // type: 0 pose, 1 landmark
+  double range = 0, precision = 0, weight = 1;
+};
+struct HostRADataset {
+  int d = 0, n = 0, l = 0, b = 0;
+  std::vector<PoseMeas> pose_pose;  // global pose indices in p1 / p2
+  std::vector<PoseLandmarkMeasH> pose_landmark;
+  std::vector<RangeMeasH> ranges;
+  std::vector<double> gt;  // d x k ground truth, RA ordering, column-major
+  int k() const { return (d + 1) * n + l + b; }
+};
+bool load_pyfg(const std::string &path, HostRADataset &out, std::string &err);
+// Q in the RA ordering [Y1..Yn | s1..sl | p1..pn | L1..Lb], assembled from the closed-form blocks of each factor
+HostCsr build_Q_ra(const HostRADataset &ds);
+}  // namespace dcora

@@ -153,6 +153,22 @@ int dcora_dataset_destroy(dcora_dataset_t ds);
 /* Graph::constructQuadraticCostTermPGO (ref src/Graph.cpp:579-683) for agent `agent_id` owning n poses */
 int dcora_graph_build_Q_pgo(int d, int n, int agent_id, int m, const int *ids, const double *vals, dcora_csr_t *Q);
 
+/* Range-aided SLAM, centralised agent (CORA flow of examples/SingleRobotExample_RASLAM.cpp:59-130):
+ * read_pyfg_file + getGlobalMeasurements (ref src/DCORA_utils.cpp:437-1167, 1169-1365) and
+ * Graph::constructQuadraticCostTermRASLAM (ref src/Graph.cpp:824-1188).  Column ordering of X is the RA ordering. */
+typedef struct dcora_radataset_s *dcora_radataset_t;
+int dcora_radataset_load_pyfg(const char *path, dcora_radataset_t *out);
+/* info[7] = {d, n poses, l unit spheres, b landmarks, #pose-pose, #pose-landmark, #range measurements} */
+int dcora_radataset_info(dcora_radataset_t ds, int *info);
+/* ground truth of the VERTEX records in RA ordering, d x k column-major (unit spheres = normalised state1 - state2) */
+int dcora_radataset_ground_truth(dcora_radataset_t ds, double *gt);
+int dcora_radataset_build_Q(dcora_radataset_t ds, dcora_csr_t *Q);
+int dcora_radataset_destroy(dcora_radataset_t ds);
+/* Graph::computePreconditionerRegularization (ref src/Graph.cpp:1921-1960): reg = lambda_max(Q) / (1e6 - 1), lambda_max
+ * by Lanczos (nev 1, ncv 6, tol 1e-3) on the device; falls back to 0.1 when the eigensolver does not converge */
+int dcora_graph_precond_regularization(int k, const int *rowptr, const int *colidx, const double *vals, int device,
+                                       double *reg);
+
 /* ------------------------------------------------------------------------- *
  * RBCD session: Agents + synchronous driver on device
  * (replaces Agent::iterate/updateX/getSharedStateDicts/updateNeighborStates, ref src/Agent.cpp:113-152,

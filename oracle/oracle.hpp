@@ -171,6 +171,31 @@ using PoseDict = std::map<PoseKey, std::vector<double>>;  // r x (d+1) col-major
 bool build_G_pgo(int r, int d, int n, int id, const std::vector<Meas> &shared,
                  const PoseDict &nbr, Mat &G);
 
+// ---- range-aided SLAM data feed (centralised: one agent owns everything) -----------------------------------
+// ref: include/DCORA/Measurements.h RelativePoseLandmarkMeasurement / RangeMeasurement
+struct PoseLandmarkMeas {
+  int i = 0, j = 0;  // pose index, landmark index
+  double t[3] = {0};
+  double tau = 0, weight = 1;
+};
+struct RangeMeas {
+  int type1 = 0, i = 0, type2 = 0, j = 0;  // type: 0 pose, 1 landmark (global indices)
+  int l = 0;                               // unit-sphere index
+  double range = 0, precision = 0, weight = 1;
+};
+struct RADataset {
+  int d = 0, n = 0, l = 0, b = 0;
+  std::vector<Meas> pose_pose;  // r1 = r2 = 0, global pose indices in p1 / p2
+  std::vector<PoseLandmarkMeas> pose_landmark;
+  std::vector<RangeMeas> ranges;
+  Mat gt;  // ground truth in RA ordering, d x k (rotations | unit spheres | translations | landmarks)
+};
+// read_pyfg_file + getGlobalMeasurements (ref: src/DCORA_utils.cpp:437-1167, 1169-1365): robots merged into one
+// agent, poses ordered by (robot, state id), unit spheres by (source robot, order of appearance)
+RADataset read_pyfg(const std::string &path);
+// Graph::constructQuadraticCostTermRASLAM for the centralised agent (ref: src/Graph.cpp:824-1188)
+CSR build_Q_ra(const RADataset &ds);
+
 // ---- certification (ref: src/DCORA_utils.cpp:1713-1982) ---------------------
 CSR dual_certificate(const Dims &D, const Mat &X, const CSR &Q);  // :1898-1982
 bool is_psd(const CSR &S, int block);                             // :1737-1747

@@ -284,6 +284,69 @@ int orc_escape_saddle(void *hnext, const double *Xopt, double theta, const doubl
   return ok ? 1 : 0;
 }
 
+// ---- range-aided SLAM (centralised) -------------------------------------------------------------------------------
+void *orc_pyfg_load(const char *path) {
+  try {
+    return new RADataset(read_pyfg(path));
+  } catch (const std::exception &e) {
+    std::fprintf(stderr, "orc_pyfg_load: %s\n", e.what());
+    return nullptr;
+  }
+}
+// info: [d, n, l, b, m_pose_pose, m_pose_landmark, m_range]
+void orc_ra_info(void *h, int *info) {
+  RADataset *ds = (RADataset *)h;
+  info[0] = ds->d;
+  info[1] = ds->n;
+  info[2] = ds->l;
+  info[3] = ds->b;
+  info[4] = (int)ds->pose_pose.size();
+  info[5] = (int)ds->pose_landmark.size();
+  info[6] = (int)ds->ranges.size();
+}
+// pp_ids m x 2, pp_vals m x (d*d+d+3); pl_ids m x 2, pl_vals m x (d+2) (t, tau, weight);
+// r_ids m x 5 (type1, i, type2, j, l), r_vals m x 3 (range, precision, weight); gt d x k column-major
+void orc_ra_copy(void *h, int *pp_ids, double *pp_vals, int *pl_ids, double *pl_vals, int *r_ids, double *r_vals,
+                 double *gt) {
+  RADataset *ds = (RADataset *)h;
+  const int d = ds->d, st = d * d + d + 3;
+  for (size_t k = 0; k < ds->pose_pose.size(); ++k) {
+    const Meas &e = ds->pose_pose[k];
+    pp_ids[2 * k] = e.p1;
+    pp_ids[2 * k + 1] = e.p2;
+    double *q = pp_vals + k * st;
+    for (int i = 0; i < d * d; ++i) q[i] = e.R[i];
+    for (int i = 0; i < d; ++i) q[d * d + i] = e.t[i];
+    q[d * d + d] = e.kappa;
+    q[d * d + d + 1] = e.tau;
+    q[d * d + d + 2] = e.weight;
+  }
+  for (size_t k = 0; k < ds->pose_landmark.size(); ++k) {
+    const PoseLandmarkMeas &e = ds->pose_landmark[k];
+    pl_ids[2 * k] = e.i;
+    pl_ids[2 * k + 1] = e.j;
+    double *q = pl_vals + k * (d + 2);
+    for (int i = 0; i < d; ++i) q[i] = e.t[i];
+    q[d] = e.tau;
+    q[d + 1] = e.weight;
+  }
+  for (size_t k = 0; k < ds->ranges.size(); ++k) {
+    const RangeMeas &e = ds->ranges[k];
+    int *q = r_ids + 5 * k;
+    q[0] = e.type1;
+    q[1] = e.i;
+    q[2] = e.type2;
+    q[3] = e.j;
+    q[4] = e.l;
+    r_vals[3 * k] = e.range;
+    r_vals[3 * k + 1] = e.precision;
+    r_vals[3 * k + 2] = e.weight;
+  }
+  std::copy(ds->gt.a.begin(), ds->gt.a.end(), gt);
+}
+void *orc_build_Q_ra(void *h) { return new CSR(build_Q_ra(*(RADataset *)h)); }
+void orc_ra_free(void *h) { delete (RADataset *)h; }
+
 // ---- RBCD driver ---------------------------------------------------------------
 // opts: [num_robots, r_min, r_max, max_iters, min_eig_tol, rgrad_tol, acceleration, staircase, verbose,
 //        method, gradnorm_tol, RGD_stepsize, RGD_use_precond, RTR_iterations, RTR_tCG_iterations, RTR_initial_radius]

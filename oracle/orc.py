@@ -78,6 +78,13 @@ def lib():
                                             C.POINTER(C.c_double), _dp, C.POINTER(C.c_double)]
         L.orc_escape_saddle.restype = C.c_int
         L.orc_escape_saddle.argtypes = [C.c_void_p, _dp, C.c_double, _dp, C.c_double, C.c_double, _dp]
+        L.orc_pyfg_load.restype = C.c_void_p
+        L.orc_pyfg_load.argtypes = [C.c_char_p]
+        L.orc_ra_info.argtypes = [C.c_void_p, _ip]
+        L.orc_ra_copy.argtypes = [C.c_void_p, _ip, _dp, _ip, _dp, _ip, _dp, _dp]
+        L.orc_build_Q_ra.restype = C.c_void_p
+        L.orc_build_Q_ra.argtypes = [C.c_void_p]
+        L.orc_ra_free.argtypes = [C.c_void_p]
         L.orc_run_rbcd.restype = C.c_void_p
         L.orc_run_rbcd.argtypes = [C.c_void_p, _dp, _dp, C.c_int]
         L.orc_trace_info.argtypes = [C.c_void_p, _dp]
@@ -324,3 +331,32 @@ def run_rbcd(ds, X0, num_robots=5, r_min=5, r_max=100, max_iters=1000, min_eig_t
     return dict(total_iters=it, final_rank=rfin, certified=int(info[2]), theta=info[3], lambda_min=info[4],
                 rbcd_seconds=info[5], cert_seconds=info[6], setup_seconds=info[7], cost=cost, gradnorm=gn,
                 selected=sel, rank=rk, X=unF(Xf, rfin, k))
+
+
+class RADataset:
+    """centralised range-aided SLAM dataset (global indices, RA ordering of the ground truth)"""
+
+    def __init__(self, path):
+        L = lib()
+        h = L.orc_pyfg_load(str(path).encode())
+        if not h:
+            raise IOError(path)
+        info = np.zeros(7, np.int32)
+        L.orc_ra_info(h, info)
+        self.d, self.n, self.l, self.b = (int(x) for x in info[:4])
+        mpp, mpl, mr = (int(x) for x in info[4:])
+        d = self.d
+        self.k = (d + 1) * self.n + self.l + self.b
+        self.pp_ids = np.zeros((mpp, 2), np.int32)
+        self.pp_vals = np.zeros((mpp, d * d + d + 3))
+        self.pl_ids = np.zeros((max(mpl, 1), 2), np.int32)
+        self.pl_vals = np.zeros((max(mpl, 1), d + 2))
+        self.r_ids = np.zeros((max(mr, 1), 5), np.int32)
+        self.r_vals = np.zeros((max(mr, 1), 3))
+        gt = np.zeros(d * self.k)
+        L.orc_ra_copy(h, self.pp_ids, self.pp_vals, self.pl_ids, self.pl_vals, self.r_ids, self.r_vals, gt)
+        self.pl_ids, self.pl_vals = self.pl_ids[:mpl], self.pl_vals[:mpl]
+        self.r_ids, self.r_vals = self.r_ids[:mr], self.r_vals[:mr]
+        self.gt = unF(gt, d, self.k)
+        self.Q = _take_csr(L.orc_build_Q_ra(h))
+        L.orc_ra_free(h)

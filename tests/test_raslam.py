@@ -1,0 +1,208 @@
+"""Range-aided SLAM (Stiefel x oblique x Euclidean manifold, RA column ordering).
+CPU: the oracle's pyfg reader / Q builder against an independent numpy parser and the factor-wise cost, and against
+the reference's noiseless fixtures (tests/testAgent.cpp:157-242: ground truth = optimum, cost 0).
+GPU: the HIP path on the RA layout against the oracle."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import common
+
+RA = ["range_aided_slam_test_2d", "range_aided_slam_test_3d"]
+
+
+def ra_path(name):
+    return os.path.join(common.DATA, name + ".pyfg.gz")
+
+
+_plain = {}
+
+
+def ra_plain(name):
+    import shutil
+    import tempfile
+    if name not in _plain:
+        fd, p = tempfile.mkstemp(suffix="_%s.pyfg" % name)
+        with os.fdopen(fd, "wb") as out, gzip.open(ra_path(name), "rb") as src:
+            shutil.copyfileobj(src, out)
+        _plain[name] = p
+    return _plain[name]
+
+
+def parse_pyfg_np(path):
+    """independent reader: returns factor lists with symbolic state names"""
+    poses, lms, pp, rg = {}, {}, [], []
+    d = 0
+    with gzip.open(path, "rt") as fh:
+        for line in fh:
+            t = line.split()
+            if not t:
+                continue
+            if t[0] == "VERTEX_SE2":
+                d = 2
+                th = float(t[5])
+                poses[t[2]] = (np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]]),
+                               np.array([float(t[3]), float(t[4])]))
+            elif t[0] == "VERTEX_SE3:QUAT":
+                d = 3
+                import g2o_np
+                v = list(map(float, t[3:10]))
+                poses[t[2]] = (g2o_np.quat_R(*v[3:7]), np.array(v[0:3]))
+            elif t[0] in ("VERTEX_XY", "VERTEX_XYZ"):
+                lms[t[1]] = np.array(list(map(float, t[2:])))
+            elif t[0] == "EDGE_SE2":
+                x, y, th = map(float, t[4:7])
+                c = list(map(float, t[7:13]))
+                R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+                pp.append((t[2], t[3], R, np.array([x, y]), 1.0 / c[5], 2.0 / (c[0] + c[3])))
+            elif t[0] == "EDGE_SE3:QUAT":
+                import g2o_np
+                v = list(map(float, t[4:11]))
+                c = list(map(float, t[11:32]))
+                pp.append((t[2], t[3], g2o_np.quat_R(*v[3:7]), np.array(v[0:3]), 3.0 / (2 * (c[15] + c[18] + c[20])),
+                           3.0 / (c[0] + c[6] + c[11])))
+            elif t[0] == "EDGE_RANGE":
+                rg.append((t[2], t[3], float(t[4]), 1.0 / float(t[5])))
+    return d, poses, lms, pp, rg
+
+
+def factor_cost(g, ds, X):
+    """f(X) factor by factor in the RA ordering, with the global indexing rule of the reference
+    (poses sorted by (robot, id), unit spheres by (source robot, order of appearance))"""
+    d, poses, lms, pp, rg = g
+    pnames = sorted(poses, key=lambda s: (s[0], int(s[1:])))
+    lnames = sorted(lms, key=lambda s: (s[1], int(s[2:])) if s[1].isupper() else ("M", int(s[1:])))
+    pi = {s: i for i, s in enumerate(pnames)}
+    li = {s: i for i, s in enumerate(lnames)}
+    n, l = ds.n, ds.l
+    Y = lambda i: X[:, d * i:d * i + d]
+    p = lambda i: X[:, d * n + l + i]
+    L = lambda i: X[:, d * n + l + n + i]
+    f = 0.0
+    for (a, b, R, t, kappa, tau) in pp:
+        i, j = pi[a], pi[b]
+        f += 0.5 * kappa * np.sum((Y(j) - Y(i) @ R) ** 2) + 0.5 * tau * np.sum((p(j) - p(i) - Y(i) @ t) ** 2)
+    count, base = {}, {}
+    for (a, b, rho, w) in rg:
+        count[a[0]] = count.get(a[0], 0) + 1
+    acc = 0
+    for rb in sorted(count):
+        base[rb] = acc
+        acc += count[rb]
+    seen = {}
+    for (a, b, rho, w) in rg:
+        k = base[a[0]] + seen.get(a[0], 0)
+        seen[a[0]] = seen.get(a[0], 0) + 1
+        xi = L(li[a]) if a[0] == "L" else p(pi[a])
+        xj = L(li[b]) if b[0] == "L" else p(pi[b])
+        s = X[:, d * n + k]
+        f += 0.5 * w * np.sum((xj - xi + rho * s) ** 2)
+    return f
+
+
+@pytest.mark.parametrize("name", RA)
+def test_oracle_ra_feed_against_numpy_and_noiseless_fixture(built, name):
+    from oracle import orc
+    import dcora_amd as da
+    g = parse_pyfg_np(ra_path(name))
+    ds = orc.RADataset(ra_plain(name))
+    dsp = da.RADataset(ra_path(name))
+    assert (ds.d, ds.n, ds.l, ds.b) == (dsp.d, dsp.n, dsp.l, dsp.b) == (g[0], 6, 10, 2)
+    assert abs(ds.Q.to_scipy() - dsp.Q.to_scipy()).max() < 1e-12
+    assert np.abs(ds.gt - dsp.gt).max() == 0
+    d, n, l, b = ds.d, ds.n, ds.l, ds.b
+    r = d + 2
+    rng = np.random.default_rng(0)
+    X = orc.project_to_manifold(r, d, n, rng.standard_normal((r, ds.k)), l=l, b=b)
+    P = orc.Problem(r, d, n, ds.Q, reg=-1, l=l, b=b)
+    assert np.isclose(P.f(X), factor_cost(g, ds, X), rtol=1e-12)
+    # noiseless fixture: ground truth (VERTEX records) is the optimum with cost 0 and zero gradient
+    Pd = orc.Problem(d, d, n, ds.Q, reg=1e-3, l=l, b=b)
+    assert abs(Pd.f(ds.gt)) < 1e-13
+    assert np.linalg.norm(Pd.rgrad(ds.gt)) < 1e-7
+    Xn, res = Pd.optimize(ds.gt)
+    assert np.abs(Xn - ds.gt).max() < 1e-9
+    # certificate: Lambda = 0 at cost 0, so S = Q is PSD
+    S = orc.dual_certificate(d, d, n, ds.gt, ds.Q, l=l, b=b)
+    assert abs(S.to_scipy() - ds.Q.to_scipy()).max() < 1e-7
+    assert orc.fast_verification(S, 1e-4, block=1)[0]
+
+
+def test_tiers_sizes_match_survey(built):
+    """tiers.pyfg has k = 37 094 and nnz(Q) = 279 108 -- checked on single_drone (shipped fixture)
+    through both builders, and on tiers itself when the reference tree is mounted"""
+    from oracle import orc
+    import dcora_amd as da
+    ds = da.RADataset(ra_path("single_drone"))
+    assert (ds.d, ds.n, ds.l, ds.b, ds.k) == (3, 1754, 1754, 1, 8771)
+    assert abs(ds.Q.to_scipy() - ds.Q.to_scipy().T).max() < 1e-9
+    tiers = "/root/reference/data/tiers.pyfg"
+    if os.path.exists(tiers):
+        t = da.RADataset(tiers)
+        assert (t.d, t.n, t.l, t.b, t.k, t.Q.nnz) == (2, 9768, 7789, 1, 37094, 279108)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,r", [("range_aided_slam_test_2d", 2), ("range_aided_slam_test_2d", 4),
+                                    ("range_aided_slam_test_3d", 3), ("range_aided_slam_test_3d", 5),
+                                    ("single_drone", 4)])
+def test_hip_ra_layout_ops(built, name, r):
+    import dcora_amd as da
+    from oracle import orc
+    ds = da.RADataset(ra_path(name))
+    d, n, l, b, k = ds.d, ds.n, ds.l, ds.b, ds.k
+    Qo = orc.CSR.from_scipy(ds.Q.to_scipy())
+    rng = np.random.default_rng(3)
+    X = orc.project_to_manifold(r, d, n, rng.standard_normal((r, k)), l=l, b=b)
+    V = rng.standard_normal((r, k))
+    reg = 1e-2
+    P = da.QuadraticProblem(r, d, n, ds.Q, reg=reg, l=l, b=b)
+    Po = orc.Problem(r, d, n, Qo, reg=reg, l=l, b=b)
+    assert np.isclose(P.f(X), Po.f(X), rtol=1e-12)
+    assert common.rel(P.RieGrad(X), Po.rgrad(X)) < 1e-12
+    Vt = orc.tangent_project(r, d, n, X, V, l=l, b=b)
+    assert common.rel(P.projectToTangentSpace(X, V), Vt) < 1e-13
+    assert common.rel(P.HessVec(X, Vt), Po.hess(X, Vt)) < 1e-11
+    assert common.rel(P.Retract(X, 0.2 * Vt), orc.retract(r, d, n, X, 0.2 * Vt, l=l, b=b)) < 1e-13
+    assert common.rel(P.PreCondition(X, Vt), Po.precondition(X, Vt)) < 1e-8
+    M = X + 0.3 * V
+    assert common.rel(da.manifold_project(r, d, n, M, l=l, b=b), orc.project_to_manifold(r, d, n, M, l=l, b=b)) < 1e-12
+    S = da.dual_certificate(r, d, n, X, ds.Q, l=l, b=b)
+    So = orc.dual_certificate(r, d, n, X, Qo, l=l, b=b)
+    assert abs(S.to_scipy() - So.to_scipy()).max() < 1e-9 * max(1.0, abs(So.to_scipy()).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", RA)
+def test_hip_ra_noiseless_fixed_point_and_solve(built, name):
+    """ref tests/testAgent.cpp:157-242: ground truth of the noiseless RA-SLAM fixtures is a fixed point; from a
+    perturbed start the RTR solve (CORA parameters: 200 x 200, tol 1e-4) returns to cost ~0 and the certificate passes"""
+    import dcora_amd as da
+    from oracle import orc
+    ds = da.RADataset(ra_path(name))
+    d, n, l, b, k = ds.d, ds.n, ds.l, ds.b, ds.k
+    reg = da.precond_regularization(ds.Q)
+    w = np.linalg.eigvalsh(ds.Q.to_scipy().toarray())
+    assert abs(reg - w[-1] / (1e6 - 1)) < 5e-3 * w[-1] / (1e6 - 1)
+    P = da.QuadraticProblem(d, d, n, ds.Q, reg=reg, l=l, b=b)
+    assert abs(P.f(ds.gt)) < 1e-12 and P.RieGradNorm(ds.gt) < 1e-6
+    Xn = da.QuadraticOptimizer(P).optimize(ds.gt)
+    assert np.abs(Xn - ds.gt).max() < 1e-9
+    r = d + 1
+    rng = np.random.default_rng(5)
+    lift = np.linalg.qr(rng.standard_normal((r, d)))[0]
+    X0 = orc.project_to_manifold(r, d, n, lift @ ds.gt + 0.05 * rng.standard_normal((r, k)), l=l, b=b)
+    Pr = da.QuadraticProblem(r, d, n, ds.Q, reg=reg, l=l, b=b)
+    opt = da.QuadraticOptimizer(Pr, da.ROptParameters(RTR_iterations=200, RTR_tCG_iterations=200, gradnorm_tol=1e-4))
+    X = opt.optimize(X0)
+    res = opt.getOptResult()
+    assert res["fOpt"] < 1e-8 and res["gradNormOpt"] < 1e-4
+    Po = orc.Problem(r, d, n, orc.CSR.from_scipy(ds.Q.to_scipy()), reg=reg, l=l, b=b)
+    Xo, reso = Po.optimize(X0, RTR_iterations=200, RTR_tCG_iterations=200, gradnorm_tol=1e-4)
+    assert abs(res["fOpt"] - reso["fOpt"]) < 1e-8
+    S = da.dual_certificate(r, d, n, X, ds.Q, l=l, b=b)
+    psd, theta, v, lmin = da.fast_verification(S, 1e-4, block=1)
+    assert psd
