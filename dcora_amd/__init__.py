@@ -89,6 +89,17 @@ class Dataset:
         return h
 
 
+def chordal_initialization(ds):
+    """chordalInitialization (ref src/DCORA_solver.cpp:218-268); returns T, d x (d+1) n"""
+    h = ds.handle()
+    out = np.zeros(ds.d * (ds.d + 1) * ds.n)
+    try:
+        check(capi.lib().dcora_dataset_chordal_init(h, out))
+    finally:
+        capi.lib().dcora_dataset_destroy(h)
+    return unF(out, ds.d, (ds.d + 1) * ds.n)
+
+
 def build_Q_pgo(ds, n=None, agent=0, ids=None, vals=None):
     """Graph::constructQuadraticCostTermPGO (ref src/Graph.cpp:579-683)"""
     ids = ds.ids if ids is None else np.ascontiguousarray(ids, np.int32)

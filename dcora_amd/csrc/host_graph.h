@@ -59,6 +59,8 @@ struct HostRADataset {
   std::vector<double> gt;  // d x k ground truth, RA ordering, column-major
   int k() const { return (d + 1) * n + l + b; }
 };
+// chordalInitialization (ref src/DCORA_solver.cpp:218-268): T is d x (d+1) n column-major, pose 0 = identity
+bool chordal_initialization(const HostDataset &ds, std::vector<double> &T);
 bool load_pyfg(const std::string &path, HostRADataset &out, std::string &err);
 // Q in the RA ordering [Y1..Yn | s1..sl | p1..pn | L1..Lb], assembled from the closed-form blocks of each factor
 HostCsr build_Q_ra(const HostRADataset &ds);

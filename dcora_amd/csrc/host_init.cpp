@@ -1,0 +1,165 @@
+// Chordal initialisation (ref src/DCORA_solver.cpp:218-268; B matrices src/DCORA_utils.cpp:1542-1630;
+// recoverTranslations :1632-1659).  Setup-time host code of the product: the start point of the RBCD loop for the
+// reference driver's InitializationMethod::Chordal (ref examples/MultiRobotExample.cpp:150-153).
+//
+// The reference solves two sparse linear least-squares problems with SPQR,
+//     min_R sum_e kappa_e |R_j - R_i R_ij|_F^2   with R_0 = I,       min_t sum_e tau_e |t_j - t_i - R_i t_ij|^2   with t_0 = 0;
+// here their normal equations are solved block-wise: the rotation system is the reduced rotation connection Laplacian
+// (d x d blocks, d right-hand sides), the translation system the reduced weighted graph Laplacian.
+#include <cmath>
+
+#include "host_graph.h"
+
+namespace dcora {
+
+namespace {
+double det_small(int d, const double *M) {
+  if (d == 2) return M[0] * M[3] - M[2] * M[1];
+  return M[0] * (M[4] * M[8] - M[7] * M[5]) - M[3] * (M[1] * M[8] - M[7] * M[2]) + M[6] * (M[1] * M[5] - M[4] * M[2]);
+}
+// projectToRotationGroup (ref src/DCORA_utils.cpp:1661-1675): U V^T with the last column of U flipped when
+// det(U) det(V) < 0; SVD by two-sided use of the symmetric eigen-decomposition of M^T M (d <= 3, well-conditioned input)
+void project_so(int d, const double *M, double *out) {
+  // one-sided Jacobi on the columns of M
+  double A[9], V[9];
+  for (int i = 0; i < d * d; ++i) A[i] = M[i];
+  for (int a = 0; a < d; ++a)
+    for (int b = 0; b < d; ++b) V[a + b * d] = (a == b);
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0;
+    for (int p = 0; p < d - 1; ++p)
+      for (int q = p + 1; q < d; ++q) {
+        double app = 0, aqq = 0, apq = 0;
+        for (int i = 0; i < d; ++i) {
+          app += A[p * d + i] * A[p * d + i];
+          aqq += A[q * d + i] * A[q * d + i];
+          apq += A[p * d + i] * A[q * d + i];
+        }
+        const double sc = std::sqrt(app * aqq);
+        if (!(std::fabs(apq) > 1e-16 * sc) || std::fabs(apq) < 1e-300) continue;
+        off = std::fmax(off, std::fabs(apq) / sc);
+        const double zeta = (aqq - app) / (2 * apq);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1 + zeta * zeta));
+        const double c = 1 / std::sqrt(1 + t * t), s = c * t;
+        for (int i = 0; i < d; ++i) {
+          double x = A[p * d + i], y = A[q * d + i];
+          A[p * d + i] = c * x - s * y;
+          A[q * d + i] = s * x + c * y;
+          x = V[p * d + i];
+          y = V[q * d + i];
+          V[p * d + i] = c * x - s * y;
+          V[q * d + i] = s * x + c * y;
+        }
+      }
+    if (off < 1e-15) break;
+  }
+  int jmin = 0;
+  double smin = 1e300;
+  for (int j = 0; j < d; ++j) {
+    double nn = 0;
+    for (int i = 0; i < d; ++i) nn += A[j * d + i] * A[j * d + i];
+    nn = std::sqrt(nn);
+    if (nn < smin) {
+      smin = nn;
+      jmin = j;
+    }
+    if (nn > 0)
+      for (int i = 0; i < d; ++i) A[j * d + i] /= nn;
+  }
+  if (det_small(d, A) * det_small(d, V) < 0)
+    for (int i = 0; i < d; ++i) A[jmin * d + i] = -A[jmin * d + i];
+  for (int c = 0; c < d; ++c)
+    for (int i = 0; i < d; ++i) {
+      double s = 0;
+      for (int j = 0; j < d; ++j) s += A[j * d + i] * V[j * d + c];
+      out[c * d + i] = s;
+    }
+}
+}  // namespace
+
+// T (d x (d+1) n, column-major, SE ordering); returns false when a reduced Laplacian is not positive definite
+// (disconnected measurement graph)
+bool chordal_initialization(const HostDataset &ds, std::vector<double> &T) {
+  const int d = ds.d, n = ds.n, dh = d + 1;
+  T.assign((size_t)d * dh * n, 0.0);
+  for (int a = 0; a < d; ++a) T[(size_t)a * d + a] = 1.0;
+  if (n == 1) return true;
+  // ---- rotations ----
+  std::vector<int> I, J;
+  std::vector<double> V;
+  const int m = d * (n - 1);
+  std::vector<double> rhs((size_t)m * d, 0.0);  // rhs[(col) * d + row]: d right-hand sides, contiguous per unknown
+  for (const PoseMeas &e : ds.meas) {
+    const int i = e.p1, j = e.p2;
+    const double k = e.kappa;
+    for (int a = 0; a < d; ++a) {
+      if (i > 0) { I.push_back((i - 1) * d + a); J.push_back((i - 1) * d + a); V.push_back(k); }
+      if (j > 0) { I.push_back((j - 1) * d + a); J.push_back((j - 1) * d + a); V.push_back(k); }
+      for (int b = 0; b < d; ++b) {
+        const double v = -k * e.R[a + b * d];  // L(i*d + a, j*d + b)
+        if (i > 0 && j > 0) {
+          I.push_back((i - 1) * d + a); J.push_back((j - 1) * d + b); V.push_back(v);
+          I.push_back((j - 1) * d + b); J.push_back((i - 1) * d + a); V.push_back(v);
+        } else if (i == 0 && j > 0) {
+          rhs[(size_t)((j - 1) * d + b) * d + a] -= v;  // -(R_0 L_{0,red}), R_0 = I
+        } else if (j == 0 && i > 0) {
+          rhs[(size_t)((i - 1) * d + a) * d + b] -= v;
+        }
+      }
+    }
+  }
+  {
+    HostCsr L = csr_from_coo(m, m, I, J, V);
+    SparseChol ch;
+    if (!ch.factor(L, d)) return false;
+    std::vector<double> y((size_t)m * d);
+    const std::vector<int> &perm = ch.perm();
+    for (int q = 0; q < m; ++q)
+      for (int a = 0; a < d; ++a) y[(size_t)q * d + a] = rhs[(size_t)perm[q] * d + a];
+    ch.solve_inplace(y.data(), d);
+    std::vector<double> sol((size_t)m * d);
+    for (int q = 0; q < m; ++q)
+      for (int a = 0; a < d; ++a) sol[(size_t)perm[q] * d + a] = y[(size_t)q * d + a];
+    for (int i = 1; i < n; ++i) {
+      double blk[9], out[9];
+      for (int c = 0; c < d; ++c)
+        for (int a = 0; a < d; ++a) blk[a + c * d] = sol[(size_t)((i - 1) * d + c) * d + a];
+      project_so(d, blk, out);
+      for (int c = 0; c < d; ++c)
+        for (int a = 0; a < d; ++a) T[(size_t)(i * dh + c) * d + a] = out[a + c * d];
+    }
+  }
+  // ---- translations ----
+  I.clear();
+  J.clear();
+  V.clear();
+  std::vector<double> b((size_t)(n - 1) * d, 0.0);
+  for (const PoseMeas &e : ds.meas) {
+    const int i = e.p1, j = e.p2;
+    if (i > 0) { I.push_back(i - 1); J.push_back(i - 1); V.push_back(e.tau); }
+    if (j > 0) { I.push_back(j - 1); J.push_back(j - 1); V.push_back(e.tau); }
+    if (i > 0 && j > 0) {
+      I.push_back(i - 1); J.push_back(j - 1); V.push_back(-e.tau);
+      I.push_back(j - 1); J.push_back(i - 1); V.push_back(-e.tau);
+    }
+    for (int a = 0; a < d; ++a) {
+      double rt = 0;
+      for (int c = 0; c < d; ++c) rt += T[(size_t)(i * dh + c) * d + a] * e.t[c];
+      if (j > 0) b[(size_t)(j - 1) * d + a] += e.tau * rt;
+      if (i > 0) b[(size_t)(i - 1) * d + a] -= e.tau * rt;
+    }
+  }
+  HostCsr Lt = csr_from_coo(n - 1, n - 1, I, J, V);
+  SparseChol ct;
+  if (!ct.factor(Lt, 1)) return false;
+  std::vector<double> y((size_t)(n - 1) * d);
+  const std::vector<int> &perm = ct.perm();
+  for (int q = 0; q < n - 1; ++q)
+    for (int a = 0; a < d; ++a) y[(size_t)q * d + a] = b[(size_t)perm[q] * d + a];
+  ct.solve_inplace(y.data(), d);
+  for (int q = 0; q < n - 1; ++q)
+    for (int a = 0; a < d; ++a) T[(size_t)((perm[q] + 1) * dh + d) * d + a] = y[(size_t)q * d + a];
+  return true;
+}
+
+}  // namespace dcora

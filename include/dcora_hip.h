@@ -150,6 +150,9 @@ int dcora_dataset_create(int d, int n, int m, const int *ids, const double *vals
 int dcora_dataset_info(dcora_dataset_t ds, int *d, int *n, int *m);
 int dcora_dataset_copy(dcora_dataset_t ds, int *ids, double *vals);
 int dcora_dataset_destroy(dcora_dataset_t ds);
+/* chordalInitialization (ref src/DCORA_solver.cpp:218-268): T is d x (d+1) n column-major (SE ordering), the start
+ * point of the reference driver's InitializationMethod::Chordal (ref examples/MultiRobotExample.cpp:150-153) */
+int dcora_dataset_chordal_init(dcora_dataset_t ds, double *T);
 /* Graph::constructQuadraticCostTermPGO (ref src/Graph.cpp:579-683) for agent `agent_id` owning n poses */
 int dcora_graph_build_Q_pgo(int d, int n, int agent_id, int m, const int *ids, const double *vals, dcora_csr_t *Q);
 

@@ -171,6 +171,9 @@ using PoseDict = std::map<PoseKey, std::vector<double>>;  // r x (d+1) col-major
 bool build_G_pgo(int r, int d, int n, int id, const std::vector<Meas> &shared,
                  const PoseDict &nbr, Mat &G);
 
+// chordalInitialization (ref: src/DCORA_solver.cpp:218-268); returns d x (d+1) n, empty on failure
+Mat chordal_initialization(const Dataset &ds);
+
 // ---- range-aided SLAM data feed (centralised: one agent owns everything) -----------------------------------
 // ref: include/DCORA/Measurements.h RelativePoseLandmarkMeasurement / RangeMeasurement
 struct PoseLandmarkMeas {

@@ -284,6 +284,14 @@ int orc_escape_saddle(void *hnext, const double *Xopt, double theta, const doubl
   return ok ? 1 : 0;
 }
 
+int orc_chordal_init(void *dsh, double *Tout) {
+  Dataset *ds = (Dataset *)dsh;
+  Mat T = chordal_initialization(*ds);
+  if (T.a.empty()) return 0;
+  std::copy(T.a.begin(), T.a.end(), Tout);
+  return 1;
+}
+
 // ---- range-aided SLAM (centralised) -------------------------------------------------------------------------------
 void *orc_pyfg_load(const char *path) {
   try {

@@ -197,3 +197,92 @@ bool build_G_pgo(int r, int d, int n, int id, const std::vector<Meas> &shared, c
 }
 
 }  // namespace orc
+
+namespace orc {
+// chordalInitialization (ref: src/DCORA_solver.cpp:218-268, B matrices src/DCORA_utils.cpp:1542-1630,
+// recoverTranslations :1632-1659).  The two linear least-squares problems
+//   min sum_e kappa_e |R_j - R_i R_ij|_F^2   (R_0 = I)       and      min sum_e tau_e |t_j - t_i - R_i t_ij|^2  (t_0 = 0)
+// are solved through their normal equations (reduced rotation / translation Laplacians) with the sparse Cholesky of
+// this oracle instead of SPQR; the minimisers are the same.
+Mat chordal_initialization(const Dataset &ds) {
+  const int d = ds.d, n = ds.n, dh = d + 1;
+  // rotation Laplacian (d n x d n), row-vector convention: cost = tr(R L R^T), R = [R_0 ... R_{n-1}] (d x d n)
+  std::vector<int> I, J;
+  std::vector<double> V;
+  for (const Meas &e : ds.meas) {
+    const int i = e.p1, j = e.p2;
+    const double k = e.kappa;
+    for (int a = 0; a < d; ++a) {
+      I.push_back(i * d + a); J.push_back(i * d + a); V.push_back(k);
+      I.push_back(j * d + a); J.push_back(j * d + a); V.push_back(k);
+      for (int b = 0; b < d; ++b) {
+        I.push_back(i * d + a); J.push_back(j * d + b); V.push_back(-k * e.R[a + b * d]);
+        I.push_back(j * d + b); J.push_back(i * d + a); V.push_back(-k * e.R[a + b * d]);
+      }
+    }
+  }
+  CSR L = csr_from_triplets(d * n, I, J, V);
+  // reduced system: unknown columns d..dn-1; rhs = -(R_0 L_{0,red}) with R_0 = I
+  const int m = d * (n - 1);
+  std::vector<int> I2, J2;
+  std::vector<double> V2;
+  Mat rhs(d, m);
+  for (int row = 0; row < d * n; ++row)
+    for (int p = L.rp[row]; p < L.rp[row + 1]; ++p) {
+      const int c = L.ci[p];
+      if (row >= d && c >= d) {
+        I2.push_back(row - d); J2.push_back(c - d); V2.push_back(L.v[p]);
+      } else if (row < d && c >= d) {
+        rhs(row, c - d) -= L.v[p];  // R_0 = I: row `row` of R_0 has a 1 in column `row`
+      }
+    }
+  CSR Lr = csr_from_triplets(m, I2, J2, V2);
+  Chol ch;
+  if (!ch.factor(Lr, d)) return Mat();
+  Mat Rred;
+  ch.solve_rows(rhs, Rred);
+  Mat T(d, dh * n);
+  for (int a = 0; a < d; ++a) T(a, a) = 1;
+  for (int i = 1; i < n; ++i) {
+    double blk[9], out[9];
+    for (int c = 0; c < d; ++c)
+      for (int a = 0; a < d; ++a) blk[a + c * d] = Rred(a, (i - 1) * d + c);
+    project_to_rotation_group(d, blk, out);
+    for (int c = 0; c < d; ++c)
+      for (int a = 0; a < d; ++a) T(a, i * dh + c) = out[a + c * d];
+  }
+  // translations: weighted graph Laplacian, t_0 = 0
+  I.clear(); J.clear(); V.clear();
+  Mat b(d, n);
+  for (const Meas &e : ds.meas) {
+    const int i = e.p1, j = e.p2;
+    I.push_back(i); J.push_back(i); V.push_back(e.tau);
+    I.push_back(j); J.push_back(j); V.push_back(e.tau);
+    I.push_back(i); J.push_back(j); V.push_back(-e.tau);
+    I.push_back(j); J.push_back(i); V.push_back(-e.tau);
+    for (int a = 0; a < d; ++a) {
+      double rt = 0;
+      for (int c = 0; c < d; ++c) rt += T(a, i * dh + c) * e.t[c];
+      b(a, j) += e.tau * rt;
+      b(a, i) -= e.tau * rt;
+    }
+  }
+  CSR Lt = csr_from_triplets(n, I, J, V);
+  I2.clear(); J2.clear(); V2.clear();
+  for (int row = 1; row < n; ++row)
+    for (int p = Lt.rp[row]; p < Lt.rp[row + 1]; ++p)
+      if (Lt.ci[p] >= 1) {
+        I2.push_back(row - 1); J2.push_back(Lt.ci[p] - 1); V2.push_back(Lt.v[p]);
+      }
+  CSR Ltr = csr_from_triplets(n - 1, I2, J2, V2);
+  Mat bred(d, n - 1), tred;
+  for (int j = 1; j < n; ++j)
+    for (int a = 0; a < d; ++a) bred(a, j - 1) = b(a, j);
+  Chol ct;
+  if (!ct.factor(Ltr, 1)) return Mat();
+  ct.solve_rows(bred, tred);
+  for (int j = 1; j < n; ++j)
+    for (int a = 0; a < d; ++a) T(a, j * dh + d) = tred(a, j - 1);
+  return T;
+}
+}  // namespace orc

@@ -78,6 +78,8 @@ def lib():
                                             C.POINTER(C.c_double), _dp, C.POINTER(C.c_double)]
         L.orc_escape_saddle.restype = C.c_int
         L.orc_escape_saddle.argtypes = [C.c_void_p, _dp, C.c_double, _dp, C.c_double, C.c_double, _dp]
+        L.orc_chordal_init.restype = C.c_int
+        L.orc_chordal_init.argtypes = [C.c_void_p, _dp]
         L.orc_pyfg_load.restype = C.c_void_p
         L.orc_pyfg_load.argtypes = [C.c_char_p]
         L.orc_ra_info.argtypes = [C.c_void_p, _ip]
@@ -360,3 +362,13 @@ class RADataset:
         self.gt = unF(gt, d, self.k)
         self.Q = _take_csr(L.orc_build_Q_ra(h))
         L.orc_ra_free(h)
+
+
+def chordal_initialization(ds):
+    """ref src/DCORA_solver.cpp:218-268; returns d x (d+1) n"""
+    L = lib()
+    h = L.orc_ds_create(ds.d, ds.n, ds.m, ds.ids, ds.vals)
+    out = np.zeros(ds.d * (ds.d + 1) * ds.n)
+    ok = L.orc_chordal_init(h, out)
+    L.orc_ds_free(h)
+    return unF(out, ds.d, (ds.d + 1) * ds.n) if ok else None

@@ -185,3 +185,31 @@ def test_certification(env):
     Xno = Po6.escape_saddle(X, theta, x)
     assert Xn is not None and Xno is not None
     assert common.rel(Xn, Xno) < 1e-9
+
+
+def test_chordal_start_to_certified_optimum_of_sphere2500(env):
+    """the headline flow (BASELINE configs[1]): chordal initialisation -> 5-agent RBCD++ at r=5 -> certificate.
+    The oracle takes 240 iterations from this start to 2 f = 1687.02 (SE-Sync's published optimum), certified."""
+    da, orc = env
+    ds = common.product_dataset("sphere2500")
+    T = da.chordal_initialization(ds)
+    r = 5
+    X0 = np.zeros((r, 4 * ds.n))
+    X0[:3] = T
+    s = da.RbcdSession(ds, num_robots=5, r=r)
+    s.set_X(X0)
+    out = s.run(max_iters=1000, rgrad_tol=0.1)
+    assert out["iters"] < 400 and out["gradnorm"][-1] < 0.1
+    assert abs(out["cost"][-1] - 1687.02) < 0.05
+    X = s.get_X()
+    Q = da.build_Q_pgo(ds)
+    S = da.dual_certificate(r, ds.d, ds.n, X, Q)
+    psd, theta, x, lmin = da.fast_verification(S, 1e-3, block=ds.d + 1)
+    assert psd
+    # the oracle agrees on cost and certificate at the device's solution
+    dso = common.oracle_dataset("sphere2500")
+    Qo = orc.build_Q_pgo(dso)
+    Po = orc.Problem(r, ds.d, ds.n, Qo)
+    assert abs(2 * Po.f(X) - out["cost"][-1]) < 1e-6
+    So = orc.dual_certificate(r, ds.d, ds.n, X, Qo)
+    assert orc.fast_verification(So, 1e-3, block=ds.d + 1)[0]
