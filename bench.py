@@ -82,10 +82,22 @@ def run_multi(args, da, torch, dist, ds, X0, rank, world):
     s = da.RbcdSession(ds, num_robots=R, r=r, rank=rank, world_size=world, device=dev.index)
     s.set_X(X0)
     counts = [s.public_count(a) for a in range(R)]
-    maxc = max(counts)
+    slot = r * dh * max(counts)              # doubles per agent in the exchange buffers
+    per_rank = (R + world - 1) // world      # agent a lives on rank a % world, in slot a // world of that rank
     owner = [a % world for a in range(R)]
-    recv = [torch.zeros(r * dh * maxc, dtype=torch.float64, device=dev) for _ in range(R)]
+    mine = torch.zeros(per_rank * slot, dtype=torch.float64, device=dev)
+    everyone = torch.zeros(world * per_rank * slot, dtype=torch.float64, device=dev)
+    one = torch.zeros(slot, dtype=torch.float64, device=dev)
     evalbuf = torch.zeros(2 * R, dtype=torch.float64, device=dev)
+    esz = mine.element_size()
+
+    def allgather(dst, src):
+        if staged:
+            parts = [torch.zeros(src.numel(), dtype=src.dtype) for _ in range(world)]
+            dist.all_gather(parts, src.cpu())
+            dst.copy_(torch.cat(parts))
+        else:
+            dist.all_gather_into_tensor(dst, src)
 
     def bcast(t, src):
         if staged:
@@ -103,26 +115,34 @@ def run_multi(args, da, torch, dist, ds, X0, rank, world):
         else:
             dist.all_reduce(t)
 
-    def exchange(agents):
-        # getSharedStateDicts -> packed buffer -> broadcast from the owner -> updateNeighborStates
-        for a in agents:
-            buf = recv[a]
-            if owner[a] == rank:
-                s.pack_public_dev(a, buf.data_ptr())
-                s.synchronize()
-            bcast(buf, owner[a])
-            if owner[a] != rank:
-                torch.cuda.synchronize()
-                s.unpack_public_dev(a, buf.data_ptr())
+    def pull_all_but(selected):
+        # getSharedStateDicts of every agent but the selected one -> ONE all_gather of the packed public poses ->
+        # updateNeighborStates on the ranks that do not host them (ref examples/MultiRobotExample.cpp:236-258)
+        for a in range(R):
+            if a != selected and owner[a] == rank:
+                s.pack_public_dev(a, mine.data_ptr() + (a // world) * slot * esz)
         s.synchronize()
+        allgather(everyone, mine)
+        torch.cuda.synchronize()
+        for a in range(R):
+            if a != selected and owner[a] != rank:
+                s.unpack_public_dev(a, everyone.data_ptr() + (owner[a] * per_rank + a // world) * slot * esz)
+
+    def push(selected):
+        # the new block of the selected agent goes to everyone (their evaluation and their next G need it)
+        if owner[selected] == rank:
+            s.pack_public_dev(selected, one.data_ptr())
+            s.synchronize()
+        bcast(one, owner[selected])
+        if owner[selected] != rank:
+            torch.cuda.synchronize()
+            s.unpack_public_dev(selected, one.data_ptr())
 
     def step(selected):
         s.phase_nonselected(selected)
-        s.synchronize()
-        exchange([a for a in range(R) if a != selected])  # selected pulls everyone's public poses
+        pull_all_but(selected)
         s.phase_selected(selected)
-        s.synchronize()
-        exchange([selected])  # the others need the new block for the evaluation / their next G
+        push(selected)
         s.phase_evaluate_dev(evalbuf.data_ptr())
         s.synchronize()
         allreduce(evalbuf)
@@ -277,6 +297,11 @@ def cpu_baseline(args, ds_name, X0, gpu_ms_per_step):
 
 def main():
     args = parse()
+    # stdout carries exactly one JSON line: native libraries (RCCL prints a version banner) write to fd 1 too, so
+    # point fd 1 at stderr for the run and keep the real stdout for the result
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     import torch
@@ -288,11 +313,14 @@ def main():
     torch.cuda.set_device(local)
     ds = common.product_dataset(args.dataset)
     X0 = initial_point(da, ds, args.rank_r) if world == 1 else None
-    if world > 1:
+    multi = world > 1 or bool(os.environ.get("DCORA_FORCE_MULTI"))  # the latter: 1-rank rehearsal of the N>1 path
+    if multi:
         import torch.distributed as dist
         dist.init_process_group(os.environ.get("DCORA_DIST_BACKEND", "nccl"))
         X0 = initial_point(da, ds, args.rank_r)
         s, dt, c2, gn = run_multi(args, da, torch, dist, ds, X0, rank, world)
+        dist.barrier()
+        dist.destroy_process_group()
     else:
         s, dt, c2, gn = run_single(args, da, torch, ds, X0)
     if rank != 0:
@@ -322,10 +350,11 @@ def main():
             line["ms_to_certified_optimum"] = certified_run(args, da, torch, ds, not args.no_cpu_baseline)
         except Exception as e:  # never lose the headline line to the second measurement
             line["ms_to_certified_optimum"] = {"error": str(e)}
-    if not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args, args.dataset, X0, ms)
         line["config"]["speedup_vs_cpu_port"] = line["value"] / line["cpu_baseline"]["value"]
-    print(json.dumps(line))
+    real_stdout.write(json.dumps(line) + "\n")
+    real_stdout.flush()
 
 
 if __name__ == "__main__":

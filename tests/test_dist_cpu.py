@@ -1,5 +1,5 @@
 """world_size-2 gloo test (CPU) of the one-process-per-GPU RBCD protocol used by bench.py: ownership a % world,
-public-pose pack -> broadcast -> unpack, block-wise evaluation + all-reduce, greedy selection.  The GPU session is
+public-pose pack -> all_gather (pull) / broadcast (push) -> unpack, block-wise evaluation + all-reduce, greedy selection.  The GPU session is
 replaced by a numpy model with the same interface whose local solve is the oracle, so the distributed result must
 equal the single-process oracle run bit-for-bit in its selection sequence."""
 import os
@@ -55,15 +55,30 @@ def _worker(rank, world, port, tmpdir):
         Qcb[cols(b), :] = 0
         return X @ Qcb
 
-    def exchange(agents):
-        for a in agents:
-            idx = np.array([p * dh + c for p in pub[a] for c in range(dh)], dtype=np.int64)
-            buf = torch.zeros(r * len(idx), dtype=torch.float64)
-            if a % world == rank:
-                buf = torch.from_numpy(np.ascontiguousarray(X[:, idx].T).reshape(-1).copy())
-            dist.broadcast(buf, src=a % world)
-            if a % world != rank:
-                X[:, idx] = buf.numpy().reshape(len(idx), r).T
+    pidx = [np.array([p * dh + c for p in pub[a] for c in range(dh)], dtype=np.int64) for a in range(R)]
+    slot = r * max(len(i) for i in pidx)
+    per_rank = (R + world - 1) // world      # agent a: rank a % world, slot a // world (as bench.py run_multi)
+
+    def pull_all_but(sel):
+        mine = torch.zeros(per_rank * slot, dtype=torch.float64)
+        for a in hosted:
+            if a != sel:
+                v = np.ascontiguousarray(X[:, pidx[a]].T).reshape(-1)
+                mine[(a // world) * slot:(a // world) * slot + v.size] = torch.from_numpy(v.copy())
+        parts = [torch.zeros(per_rank * slot, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        for a in range(R):
+            if a != sel and a % world != rank:
+                v = parts[a % world][(a // world) * slot:(a // world) * slot + r * len(pidx[a])].numpy()
+                X[:, pidx[a]] = v.reshape(len(pidx[a]), r).T
+
+    def push(a):
+        buf = torch.zeros(r * len(pidx[a]), dtype=torch.float64)
+        if a % world == rank:
+            buf = torch.from_numpy(np.ascontiguousarray(X[:, pidx[a]].T).reshape(-1).copy())
+        dist.broadcast(buf, src=a % world)
+        if a % world != rank:
+            X[:, pidx[a]] = buf.numpy().reshape(len(pidx[a]), r).T
 
     for it in range(iters):
         gamma = (1 + np.sqrt(1 + 4.0 * R * R * gamma * gamma)) / (2.0 * R)
@@ -75,7 +90,7 @@ def _worker(rank, world, port, tmpdir):
             Y = orc.project_to_manifold(r, d, nb, (1 - alpha) * X[:, cols(b)] + alpha * V[b])
             X[:, cols(b)] = Y
             V[b] = orc.project_to_manifold(r, d, nb, V[b])
-        exchange([a for a in range(R) if a != selected])
+        pull_all_but(selected)
         if selected in hosted:
             b = selected
             nb = end[b] - start[b]
@@ -84,7 +99,7 @@ def _worker(rank, world, port, tmpdir):
             Xn, _ = P.optimize(Y)
             V[b] = orc.project_to_manifold(r, d, nb, V[b] + gamma * (Xn - Y))
             X[:, cols(b)] = Xn
-        exchange([selected])
+        push(selected)
         ev = torch.zeros(2 * R, dtype=torch.float64)
         for b in hosted:
             nb = end[b] - start[b]
