@@ -270,6 +270,17 @@ def _time_precond(self, reps=100):
 QuadraticProblem.time_precond = _time_precond
 
 
+def _precond_info(self):
+    """how (Q + reg I)^-1 is held on the device: dense inverse or partitioned sparse inverse"""
+    info = np.zeros(5)
+    check(capi.lib().dcora_problem_precond_info(self.h, info))
+    return {"kind": {0: "none", 1: "dense", 2: "sparse"}[int(info[0])], "launches": int(info[1]),
+            "nnzL": int(info[2]), "setup_ms": float(info[3]), "stored_doubles_per_apply": float(info[4])}
+
+
+QuadraticProblem.precond_info = _precond_info
+
+
 class QuadraticOptimizer:
     """ref include/DCORA/QuadraticOptimizer.h: optimize(Y), getOptResult()"""
 

@@ -117,6 +117,7 @@ SIGNATURES = {
     "dcora_rbcd_synchronize": (C.c_int, [_vp]),
     "dcora_problem_time_qapply": (C.c_int, [_vp, C.c_int, _PD, _PD]),
     "dcora_problem_time_precond": (C.c_int, [_vp, C.c_int, _PD, _PD]),
+    "dcora_problem_precond_info": (C.c_int, [_vp, _dp]),
 }
 
 _lib = None

@@ -187,6 +187,16 @@ int dcora_problem_time_qapply(dcora_problem_t p, int reps, double *avg_ms, doubl
 int dcora_problem_time_precond(dcora_problem_t p, int reps, double *avg_ms, double *bytes) {
   return p ? p->p.time_precond(reps, avg_ms, bytes) : bad("null");
 }
+int dcora_problem_precond_info(dcora_problem_t p, double *info) {
+  if (!p || !info) return bad("null");
+  const DeviceProblem &P = p->p;
+  info[0] = !P.has_precond ? 0 : (P.sparse_precond ? 2 : 1);
+  info[1] = !P.has_precond ? 0 : (P.sparse_precond ? P.sp.launches() : 1);
+  info[2] = (double)P.precond_nnzL;
+  info[3] = P.precond_setup_ms;
+  info[4] = !P.has_precond ? 0 : (P.sparse_precond ? P.sp.weights_per_apply : (double)P.m.k * P.m.k);
+  return DCORA_OK;
+}
 
 // ---- CSR handles --------------------------------------------------------------------------------------------
 int dcora_csr_info(dcora_csr_t m, int *n, int *nnz) {
@@ -527,5 +537,75 @@ extern "C" int dcora_debug_nesterov(int flavour, int r, int d, int n, int mode, 
   DCORA_HIP(hipMemcpy(Y, dY.p, B, hipMemcpyDeviceToHost));
   DCORA_HIP(hipMemcpy(XPrev, dP.p, B, hipMemcpyDeviceToHost));
   DCORA_HIP(hipMemcpy(Yloc, dYl.p, B, hipMemcpyDeviceToHost));
+  return DCORA_OK;
+}
+
+// debug / test hook (not part of the public header): builds the partitioned inverse of an SPD matrix on the host
+// and replays its schedule on the host against a plain sparse Cholesky solve -- checks the builder without a GPU.
+// info = {levels (forward + backward), pieces, nnz(L), stored weights per apply}
+extern "C" int dcora_debug_partinv_selftest(int n, const int *rp, const int *ci, const double *v, int block, int r,
+                                            double *max_rel_err, double *info) {
+  HostCsr A;
+  A.n = A.ncols = n;
+  A.rp.assign(rp, rp + n + 1);
+  A.ci.assign(ci, ci + rp[n]);
+  A.v.assign(v, v + rp[n]);
+  PartInvHost P;
+  if (!build_partitioned_inverse(A, block, 4, &P)) {
+    set_last_error("matrix is not positive definite");
+    return DCORA_ERR_NOT_PD;
+  }
+  SparseChol chol;
+  if (!chol.factor(A, block)) return DCORA_ERR_NOT_PD;
+  std::vector<double> R((size_t)n * r), Z((size_t)n * r), col((size_t)n), sol((size_t)n);
+  unsigned long long s = 88172645463325252ull;
+  for (double &x : R) {
+    s ^= s << 13;
+    s ^= s >> 7;
+    s ^= s << 17;
+    x = (double)(s >> 11) / 9007199254740992.0 - 0.5;
+  }
+  partitioned_inverse_apply_host(P, r, R.data(), Z.data());
+  double err = 0, ref = 0;
+  for (int t = 0; t < r; ++t) {
+    for (int i = 0; i < n; ++i) col[i] = R[(size_t)i * r + t];
+    chol.solve_vec(col.data(), sol.data());
+    for (int i = 0; i < n; ++i) {
+      err = std::max(err, std::fabs(sol[i] - Z[(size_t)i * r + t]));
+      ref = std::max(ref, std::fabs(sol[i]));
+    }
+  }
+  *max_rel_err = err / std::max(ref, 1e-300);
+  info[0] = (double)P.levels.size();
+  info[1] = (double)P.npieces;
+  info[2] = (double)P.nnzL;
+  info[3] = P.weights_read_per_apply;
+  return DCORA_OK;
+}
+
+// debug / test hook: per-level shape of the partitioned-inverse schedule: out[4 * lev + {0,1,2,3}] =
+// {row tasks, segments, stored weights streamed, lanes per task}; returns the number of levels in *nlev
+extern "C" int dcora_debug_partinv_levels(int n, const int *rp, const int *ci, const double *v, int block, int max_levels,
+                                          int *nlev, double *out) {
+  HostCsr A;
+  A.n = A.ncols = n;
+  A.rp.assign(rp, rp + n + 1);
+  A.ci.assign(ci, ci + rp[n]);
+  A.v.assign(v, v + rp[n]);
+  PartInvHost P;
+  if (!build_partitioned_inverse(A, block, 8, &P)) return DCORA_ERR_NOT_PD;
+  *nlev = (int)P.levels.size();
+  for (int l = 0; l < *nlev && l < max_levels; ++l) {
+    const SpLevel &lv = P.levels[l];
+    double segs = 0, w = 0;
+    for (int t = lv.task0; t < lv.task0 + lv.ntasks; ++t) {
+      segs += P.tasks[t].nseg;
+      for (int s = P.tasks[t].seg0; s < P.tasks[t].seg0 + P.tasks[t].nseg; ++s) w += P.segs[s].len;
+    }
+    out[4 * l] = lv.ntasks;
+    out[4 * l + 1] = segs;
+    out[4 * l + 2] = w;
+    out[4 * l + 3] = lv.lanes;
+  }
   return DCORA_OK;
 }

@@ -10,6 +10,7 @@
 #include "../../include/dcora_hip.h"
 #include "host_sparse.h"
 #include "kernels.h"
+#include "sparse_precond.h"
 
 namespace dcora {
 
@@ -89,6 +90,26 @@ struct DevCsr {
   }
 };
 
+// device image of the partitioned inverse (sparse_precond.h) and its level-by-level replay
+constexpr int kDensePrecondMaxK = 12000;  // above this the preconditioner is the partitioned sparse inverse
+
+class SparsePrecond {
+ public:
+  int k = 0, rcap = 0, npieces = 0;
+  long nnzL = 0, ntasks_total = 0, nsegs_total = 0;
+  double weights_per_apply = 0, rows_total = 0;
+  std::vector<SpLevel> levels;
+  DevBuf<double> vals, y;
+  DevBuf<int> idxs, perm, out_off;
+  DevBuf<PTask> tasks;
+  DevBuf<PSeg> segs;
+  int upload(const PartInvHost &P, int rcap);
+  int launches() const { return (int)levels.size() + 2; }
+  // Z = R A^-1 for r <= rcap right-hand sides (r x k column-major); R is picked by ctl->cur when g.ctl is set
+  void apply(hipStream_t st, int r, Buf2 R, double *Z, Gate g) const;
+  double bytes_per_apply(int r) const;
+};
+
 class DeviceProblem {
  public:
   ManiDesc m{};
@@ -102,8 +123,10 @@ class DeviceProblem {
   int enq_qapply(Buf2 X, int selX, const double *Gp, Buf2 Y, int selY, double *partials, Gate g);
   DevBuf<double> G;     // r x k (always allocated; zero when the problem has no linear term)
   bool has_G = false;
-  DevBuf<double> Minv;  // k x ldm dense inverse of Q + reg I
+  DevBuf<double> Minv;  // k x ldm dense inverse of Q + reg I (small blocks)
   int ldm = 0;
+  SparsePrecond sp;     // partitioned sparse inverse (large blocks)
+  bool sparse_precond = false;
   bool has_precond = false;
   double precond_setup_ms = 0;
   long precond_nnzL = 0;
@@ -142,6 +165,9 @@ class DeviceProblem {
   int npVec() const { return vec_grid(nelem()); }
   void enqueue_egrad(const double *X, double *EG, double *partials);
   void enqueue_precond(const double *X, const double *V, double *out);  // out = Proj_X(V Minv)
+  // Z = R (Q + reg I)^-1 with whichever preconditioner form this problem holds (p2 / np2: the dense kernel's
+  // early-out on the residual rule)
+  void enq_minv(Buf2 R, double *Z, const double *p2, int np2, Gate g);
 
   // ---- host-pointer API (upload, run, download, sync) ----
   int cost(const double *Xh, double *f);

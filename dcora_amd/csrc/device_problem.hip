@@ -112,7 +112,7 @@ int DeviceProblem::init(const dcora_dims &dims, const HostCsr &Qh, const double 
   if (fused) {
     DCORA_HIP(delta2.alloc(N));
     DCORA_HIP(res2.alloc(N));
-    DCORA_HIP(Zpart.alloc((size_t)fused_nsplit(m) * N));
+    DCORA_HIP(Zpart.alloc((size_t)fused_nsplit(m) * N));  // slice 0 doubles as Z of the sparse preconditioner
     DCORA_HIP(hipMemset(delta2.p, 0, N * sizeof(double)));
   }
   for (DevBuf<double> *b : {&delta, &eta, &Heta, &res, &z, &Hd, &W, &Zt})
@@ -153,11 +153,36 @@ int DeviceProblem::set_G_host(const double *Gh) {
 int DeviceProblem::build_preconditioner(const HostCsr &Qh, double reg) {
   const auto t0 = std::chrono::steady_clock::now();
   const int k = m.k;
+  HostCsr M = csr_shift_diag(Qh, reg);
+  unsigned hw = std::thread::hardware_concurrency();
+  const int nthreads = (int)std::max(1u, std::min(hw, 32u));
+  // Large blocks: partitioned sparse inverse replayed level by level (sparse_precond.h).  Small blocks: the dense
+  // inverse streams faster than 2 * depth + 2 dependent launches.  DCORA_PRECOND=dense|sparse overrides.
+  const char *pc = std::getenv("DCORA_PRECOND");
+  const bool want_sparse = pc ? (std::string(pc) == "sparse") : (k > kDensePrecondMaxK);
+  if (want_sparse) {
+    if (m.r > 16) {
+      set_last_error("sparse preconditioner supports r <= 16");
+      return DCORA_ERR_UNSUPPORTED;
+    }
+    PartInvHost P;
+    if (!build_partitioned_inverse(M, m.se ? m.d + 1 : 1, nthreads, &P)) {
+      set_last_error("preconditioner: Q + reg I is not positive definite");
+      return DCORA_ERR_NOT_PD;
+    }
+    DCORA_HIP(hipSetDevice(device));
+    int rc = sp.upload(P, m.r);
+    if (rc) return rc;
+    precond_nnzL = P.nnzL;
+    sparse_precond = true;
+    has_precond = true;
+    precond_setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return DCORA_OK;
+  }
   if ((size_t)k > 60000) {
-    set_last_error("dense preconditioner limited to k <= 60000 in this build");
+    set_last_error("dense preconditioner limited to k <= 60000");
     return DCORA_ERR_UNSUPPORTED;
   }
-  HostCsr M = csr_shift_diag(Qh, reg);
   SparseChol chol;
   if (!chol.factor(M, m.se ? m.d + 1 : 1)) {
     set_last_error("preconditioner: Q + reg I is not positive definite");
@@ -166,8 +191,7 @@ int DeviceProblem::build_preconditioner(const HostCsr &Qh, double reg) {
   precond_nnzL = chol.nnzL();
   ldm = ((k + 127) / 128) * 128;  // rows padded so every 16-byte column-pair load of a 128-column chunk is in bounds
   std::vector<double> inv((size_t)k * ldm, 0.0);
-  unsigned hw = std::thread::hardware_concurrency();
-  chol.dense_inverse(inv.data(), (size_t)ldm, (int)std::max(1u, std::min(hw, 32u)));
+  chol.dense_inverse(inv.data(), (size_t)ldm, nthreads);
   DCORA_HIP(hipSetDevice(device));
   DCORA_HIP(Minv.alloc((size_t)k * ldm + 16));
   DCORA_HIP(hipMemcpy(Minv.p, inv.data(), (size_t)k * ldm * sizeof(double), hipMemcpyHostToDevice));
@@ -201,8 +225,14 @@ int DeviceProblem::enq_retract(Buf2 X, const double *V, double alpha, Buf2 out, 
   return pose_grid(m);
 }
 
+void DeviceProblem::enq_minv(Buf2 R, double *Z, const double *p2, int np2, Gate g) {
+  if (sparse_precond)
+    sp.apply(st, m.r, R, Z, g);
+  else
+    launch_dense_apply(st, m.r, m.k, ldm, Minv.p, R, Z, p2, np2, g);
+}
 void DeviceProblem::enqueue_precond(const double *X, const double *V, double *out) {
-  launch_dense_apply(st, m.r, m.k, ldm, Minv.p, buf1(V), Zt.p, nullptr, 0, Gate{});
+  enq_minv(buf1(V), Zt.p, nullptr, 0, Gate{});
   launch_tangent(st, m, buf1(X), Zt.p, out, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0);
 }
 
@@ -473,7 +503,7 @@ int DeviceProblem::rtr_dev(const dcora_ropt_params &prm, dcora_ropt_result *res_
     // ---- tCG ----
     launch_tcg_begin(st, N, RGb(), eta.p, Heta.p, res.p, c, ++seq);
     const int tcg_first_seq = seq;
-    launch_dense_apply(st, m.r, m.k, ldm, Minv.p, buf1(res.p), Zt.p, nullptr, 0, Gate{c, ++seq, 1});
+    enq_minv(buf1(res.p), Zt.p, nullptr, 0, Gate{c, ++seq, 1});
     launch_tangent(st, m, Xb(), Zt.p, z.p, res.p, p3.p, nullptr, 0, c, hf_dev, ++seq, 1, 0);
     launch_tcg_init(st, N, z.p, p3.p, nP, delta.p, c, ++seq);
     for (int j = 0; j < h.max_inner; ++j) {
@@ -490,7 +520,7 @@ int DeviceProblem::rtr_dev(const dcora_ropt_params &prm, dcora_ropt_result *res_
       launch_spmm(st, m.r, Qv, buf1(delta.p), 0, nullptr, buf1(W.p), 0, nullptr, Gate{c, ++seq, 2});
       launch_hessfix(st, m, Xb(), Sb(), delta.p, W.p, Hd.p, p1.p, Gate{c, ++seq, 2});
       launch_tcg_update1(st, N, delta.p, Hd.p, eta.p, Heta.p, res.p, p1.p, nP, p2.p, c, hf_dev, ++seq, j);
-      launch_dense_apply(st, m.r, m.k, ldm, Minv.p, buf1(res.p), Zt.p, p2.p, nV, Gate{c, ++seq, 2});
+      enq_minv(buf1(res.p), Zt.p, p2.p, nV, Gate{c, ++seq, 2});
       launch_tangent(st, m, Xb(), Zt.p, z.p, res.p, p3.p, p2.p, nV, c, hf_dev, ++seq, 2, j);
       launch_tcg_update2(st, N, z.p, delta.p, p3.p, nP, c, hf_dev, ++seq, j);
       upd2_seq[j] = seq;
@@ -546,7 +576,10 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
   const int solve_first = seq + 1;
   const CsrDev Qv = Q.view();
   const double *Gp = has_G ? G.p : nullptr;
-  const int nA = npA(), nPB = fused_pose_blocks(m), nPG = fused_precond_grid(m);
+  const int nA = npA(), nPB = fused_pose_blocks(m);
+  const int nPG = sparse_precond ? fused_update_grid(m) : fused_precond_grid(m);
+  const double *Mi = sparse_precond ? nullptr : Minv.p;  // null: B only updates, the sparse levels follow
+  const int nsl = sparse_precond ? 1 : -1;
   double *dbuf[2] = {delta.p, delta2.p};
   double *rbuf[2] = {res.p, res2.p};
   auto timed_out = [&]() {
@@ -564,10 +597,11 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
     if (outer_done()) break;
     if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0) break;  // TimeBound :252
     // z0 = P(grad): B in "first" mode streams the preconditioner over grad, C projects and forms <z0, r0>
-    launch_fused_precond(st, m, ldm, Minv.p, RGb(), nullptr, nullptr, eta.p, Heta.p, nullptr, rbuf[0], Zpart.p,
+    launch_fused_precond(st, m, ldm, Mi, RGb(), nullptr, nullptr, eta.p, Heta.p, nullptr, rbuf[0], Zpart.p,
                          nullptr, 0, p2.p, c, hf_dev, ++seq, 0, 1);
     const int tcg_first_seq = seq;
-    launch_fused_finish(st, m, Xb(), Zpart.p, rbuf[0], z.p, nullptr, 0, p3.p, c, hf_dev, ++seq, 0, 1);
+    if (sparse_precond) sp.apply(st, m.r, buf1(rbuf[0]), Zpart.p, Gate{c, ++seq, 1});
+    launch_fused_finish(st, m, Xb(), Zpart.p, rbuf[0], z.p, nullptr, 0, p3.p, c, hf_dev, ++seq, 0, 1, nsl);
     for (int j = 0; j < max_inner; ++j) {
       if (j >= kLookahead) {
         const int need = fin_seq[j - kLookahead];
@@ -578,9 +612,10 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
       if (hf->tcg_done_seq >= tcg_first_seq) break;
       const int par = j & 1;
       launch_fused_hess(st, m, Qv, z.p, dbuf[par ^ 1], dbuf[par], Xb(), Sb(), Hd.p, p3.p, nPB, p1.p, c, ++seq, j);
-      launch_fused_precond(st, m, ldm, Minv.p, RGb(), dbuf[par], Hd.p, eta.p, Heta.p, rbuf[par], rbuf[par ^ 1],
+      launch_fused_precond(st, m, ldm, Mi, RGb(), dbuf[par], Hd.p, eta.p, Heta.p, rbuf[par], rbuf[par ^ 1],
                            Zpart.p, p1.p, nPB, p2.p, c, hf_dev, ++seq, j, 0);
-      launch_fused_finish(st, m, Xb(), Zpart.p, rbuf[par ^ 1], z.p, p2.p, nPG, p3.p, c, hf_dev, ++seq, j, 0);
+      if (sparse_precond) sp.apply(st, m.r, buf1(rbuf[par ^ 1]), Zpart.p, Gate{c, ++seq, 2});
+      launch_fused_finish(st, m, Xb(), Zpart.p, rbuf[par ^ 1], z.p, p2.p, nPG, p3.p, c, hf_dev, ++seq, j, 0, nsl);
       fin_seq[j] = seq;
     }
     const int nR = enq_retract(Xb(), eta.p, 1.0, Xb(), 1, RGb(), Heta.p, pC.p, Gate{c, ++seq, 1});
@@ -675,8 +710,8 @@ namespace dcora {
 // times the dense-preconditioner kernel of the solver (k_fused_precond in its start-of-tCG form: residual = grad,
 // no step) with HIP events on the problem's stream
 int DeviceProblem::time_precond(int reps, double *avg_ms, double *bytes) {
-  if (!has_precond || !fused) {
-    set_last_error("time_precond: needs the fused solver path and a preconditioner");
+  if (!has_precond || (!fused && !sparse_precond)) {
+    set_last_error("time_precond: needs a preconditioner and the fused solver path or the sparse preconditioner");
     return DCORA_ERR_UNSUPPORTED;
   }
   DCORA_HIP(hipSetDevice(device));
@@ -685,8 +720,11 @@ int DeviceProblem::time_precond(int reps, double *avg_ms, double *bytes) {
   DCORA_HIP(hipEventCreate(&e0));
   DCORA_HIP(hipEventCreate(&e1));
   auto run = [&]() {
-    launch_fused_precond(st, m, ldm, Minv.p, RGb(), nullptr, nullptr, eta.p, Heta.p, nullptr, res.p, Zpart.p, nullptr,
-                         0, p2.p, ctl.p, hf_dev, 1, 0, 1);
+    if (sparse_precond)
+      sp.apply(st, m.r, buf1(RG0.p), Zt.p, Gate{});
+    else
+      launch_fused_precond(st, m, ldm, Minv.p, RGb(), nullptr, nullptr, eta.p, Heta.p, nullptr, res.p, Zpart.p,
+                           nullptr, 0, p2.p, ctl.p, hf_dev, 1, 0, 1);
   };
   for (int i = 0; i < 3; ++i) run();
   DCORA_HIP(hipEventRecord(e0, st));
@@ -699,7 +737,8 @@ int DeviceProblem::time_precond(int reps, double *avg_ms, double *bytes) {
   (void)hipEventDestroy(e1);
   *avg_ms = (double)ms / reps;
   // algorithmic bytes: the k x k inverse once, the residual in, the split-K slices out
-  *bytes = 8.0 * m.k * (double)m.k + 8.0 * m.r * m.k + 8.0 * m.r * m.k * fused_nsplit(m);
+  *bytes = sparse_precond ? sp.bytes_per_apply(m.r)
+                          : 8.0 * m.k * (double)m.k + 8.0 * m.r * m.k + 8.0 * m.r * m.k * fused_nsplit(m);
   return DCORA_OK;
 }
 }  // namespace dcora

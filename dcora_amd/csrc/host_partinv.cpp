@@ -1,0 +1,359 @@
+// Host-side construction of the partitioned inverse of a nested-dissection Cholesky factor (sparse_precond.h).
+// Setup-time code: runs once per Q; the per-iteration path only replays the schedule on the device.
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <thread>
+
+#include "sparse_precond.h"
+
+namespace dcora {
+
+namespace {
+
+struct Piece {
+  int c0 = 0, c = 0;          // columns [c0, c0 + c) in permuted numbering
+  std::vector<int> rows;      // rows of L below the piece, ascending
+  int level = 0;
+  std::vector<double> Dinv;   // D^-1, c x c row-major (lower triangular)
+  std::vector<double> W;      // -B D^-1, m x c row-major
+};
+
+inline int pad2(int x) { return (x + 1) & ~1; }
+
+// lanes per row tile, from the average number of vector entries a tile gathers: a step covers lanes / r of them;
+// aim for a handful of steps per lane so that the loads of a tile are all in flight together (the upper levels
+// have few tiles and are latency-bound otherwise)
+int pick_lanes(double avg_entries_per_tile) {
+  if (avg_entries_per_tile >= 160) return 256;
+  if (avg_entries_per_tile >= 20) return 64;
+  if (avg_entries_per_tile >= 8) return 32;
+  return 16;
+}
+
+}  // namespace
+
+bool build_partitioned_inverse(const HostCsr &A, int block, int nthreads, PartInvHost *out) {
+  SparseChol chol;
+  if (!chol.factor(A, block)) return false;
+  const int k = A.n;
+  const std::vector<int> &Lp = chol.Lp(), &Li = chol.Li();
+  const std::vector<double> &Lx = chol.Lx();
+  const std::vector<int> &cuts = chol.pieces();
+  PartInvHost &P = *out;
+  P = PartInvHost();
+  P.k = k;
+  P.perm = chol.perm();
+  P.nnzL = chol.nnzL();
+  const int np = (int)cuts.size() - 1;
+  P.npieces = np;
+  std::vector<Piece> pc((size_t)np);
+  std::vector<int> piece_of((size_t)k);
+  for (int s = 0; s < np; ++s) {
+    pc[s].c0 = cuts[s];
+    pc[s].c = cuts[s + 1] - cuts[s];
+    for (int j = cuts[s]; j < cuts[s + 1]; ++j) piece_of[j] = s;
+  }
+  // rows below each piece (union over its columns) and dependency levels (longest path from the leaves)
+  {
+    std::vector<int> mark((size_t)k, -1);
+    for (int s = 0; s < np; ++s) {
+      const int hi = pc[s].c0 + pc[s].c;
+      std::vector<int> &rows = pc[s].rows;
+      for (int j = pc[s].c0; j < hi; ++j)
+        for (int p = Lp[j] + 1; p < Lp[j + 1]; ++p) {
+          const int i = Li[p];
+          if (i >= hi && mark[i] != s) {
+            mark[i] = s;
+            rows.push_back(i);
+          }
+        }
+      std::sort(rows.begin(), rows.end());
+      for (int i : rows) {
+        Piece &q = pc[piece_of[i]];
+        q.level = std::max(q.level, pc[s].level + 1);
+      }
+    }
+  }
+  int nlev = 0;
+  for (const Piece &p : pc) nlev = std::max(nlev, p.level + 1);
+  // ---- numeric part: D^-1 and W = -B D^-1 of every piece, pieces in parallel, most expensive first ----
+  {
+    std::vector<int> order((size_t)np);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](int a, int b) {
+      const double wa = (double)pc[a].c * pc[a].c * (pc[a].c + 3.0 * pc[a].rows.size());
+      const double wb = (double)pc[b].c * pc[b].c * (pc[b].c + 3.0 * pc[b].rows.size());
+      return wa > wb;
+    });
+    std::atomic<int> next(0);
+    auto work = [&]() {
+      std::vector<double> D, B;
+      std::vector<int> where((size_t)k, -1);
+      for (;;) {
+        const int t = next.fetch_add(1);
+        if (t >= np) break;
+        Piece &p = pc[order[t]];
+        const int c = p.c, c0 = p.c0, m = (int)p.rows.size();
+        D.assign((size_t)c * c, 0.0);
+        B.assign((size_t)m * c, 0.0);
+        for (int a = 0; a < m; ++a) where[p.rows[a]] = a;
+        for (int j = 0; j < c; ++j)
+          for (int q = Lp[c0 + j]; q < Lp[c0 + j + 1]; ++q) {
+            const int i = Li[q];
+            if (i < c0 + c)
+              D[(size_t)(i - c0) * c + j] = Lx[q];
+            else
+              B[(size_t)where[i] * c + j] = Lx[q];
+          }
+        for (int a = 0; a < m; ++a) where[p.rows[a]] = -1;
+        // Dinv = D^-1 (lower triangular), built row by row: row_i = (e_i - sum_{l<i} D_il row_l) / D_ii
+        std::vector<double> &Dinv = p.Dinv;
+        Dinv.assign((size_t)c * c, 0.0);
+        for (int i = 0; i < c; ++i) {
+          const double *di = &D[(size_t)i * c];
+          double *ri = &Dinv[(size_t)i * c];
+          for (int l = 0; l < i; ++l) {
+            const double coef = di[l];
+            if (coef == 0.0) continue;
+            const double *rl = &Dinv[(size_t)l * c];
+            for (int j = 0; j <= l; ++j) ri[j] += coef * rl[j];
+          }
+          const double inv = 1.0 / di[i];
+          for (int j = 0; j < i; ++j) ri[j] = -ri[j] * inv;
+          ri[i] = inv;
+        }
+        p.W.assign((size_t)m * c, 0.0);
+        for (int a = 0; a < m; ++a) {
+          const double *ba = &B[(size_t)a * c];
+          double *wa = &p.W[(size_t)a * c];
+          for (int l = 0; l < c; ++l) {
+            const double b = ba[l];
+            if (b == 0.0) continue;
+            const double *dl = &Dinv[(size_t)l * c];
+            for (int j = 0; j <= l; ++j) wa[j] -= b * dl[j];
+          }
+        }
+      }
+    };
+    nthreads = std::max(1, std::min(nthreads, np));
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthreads; ++t) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+  }
+  // ---- schedule.  Which buffer holds a piece's current value is static; start: everything in buffer 0.
+  // A task is a tile of up to kSpTile consecutive output rows that gather from the same sources; the weights of
+  // a segment are stored entry-major over the tile's rows:  [entry j][row q]. ----
+  constexpr int RT = kSpTile;
+  std::vector<int> bit((size_t)np, 0);
+  std::vector<std::vector<int>> by_level((size_t)nlev);
+  for (int s = 0; s < np; ++s) by_level[pc[s].level].push_back(s);
+  auto pos = [&](int s_bit, int row) { return s_bit * k + row; };
+  std::vector<int> touched_stamp((size_t)np, -1);
+  std::vector<std::vector<std::pair<int, int>>> hits((size_t)k);  // per row: (piece, local row) of this level
+  double weights = 0;
+  std::vector<double> &vals = P.vals;
+  // appends the interleaved weights of one segment: get(q, j) = weight of tile row q at entry j (j < len)
+  auto emit = [&](int nrows, int len, auto get) -> long long {
+    const long long off = (long long)vals.size();
+    vals.resize(vals.size() + (size_t)len * nrows);
+    double *w = vals.data() + off;
+    for (int j = 0; j < len; ++j)
+      for (int q = 0; q < nrows; ++q) w[(size_t)j * nrows + q] = get(q, j);
+    weights += (double)len * nrows;
+    return off;
+  };
+  // forward: y <- L_t^-1 y, leaves first
+  for (int t = 0; t < nlev; ++t) {
+    SpLevel lv;
+    lv.task0 = (int)P.tasks.size();
+    std::vector<int> affected;
+    for (int s : by_level[t]) {
+      touched_stamp[s] = t;
+      affected.push_back(s);
+    }
+    std::vector<int> hit_rows;
+    for (int s : by_level[t]) {
+      const std::vector<int> &rows = pc[s].rows;
+      for (int a = 0; a < (int)rows.size(); ++a) {
+        const int i = rows[a], q = piece_of[i];
+        if (touched_stamp[q] != t) {
+          touched_stamp[q] = t;
+          affected.push_back(q);
+        }
+        if (hits[i].empty()) hit_rows.push_back(i);
+        hits[i].emplace_back(s, a);
+      }
+    }
+    long long seg_len_sum = 0, seg_cnt = 0;
+    for (int q : affected) {
+      const Piece &p = pc[q];
+      const bool own = (p.level == t);
+      for (int a0 = 0; a0 < p.c;) {
+        int nrows = 1;
+        if (own) {
+          nrows = std::min(RT, p.c - a0);
+        } else {
+          // consecutive rows fed by the same pieces share a tile
+          const auto &h0 = hits[p.c0 + a0];
+          while (nrows < RT && a0 + nrows < p.c) {
+            const auto &h1 = hits[p.c0 + a0 + nrows];
+            bool same = h1.size() == h0.size();
+            for (size_t u = 0; same && u < h0.size(); ++u) same = (h1[u].first == h0[u].first);
+            if (!same) break;
+            ++nrows;
+          }
+        }
+        PTask T;
+        T.out = pos(1 - bit[q], p.c0 + a0);
+        T.nrows = nrows;
+        T.seg0 = (int)P.segs.size();
+        if (own) {
+          T.carry = -1;
+          PSeg S;
+          S.len = pad2(a0 + nrows);
+          S.src = pos(bit[q], p.c0);
+          S.idx = 0;
+          S.pad = 0;
+          const int c = p.c;
+          S.w = emit(nrows, S.len, [&](int r_, int j) {
+            return (j <= a0 + r_ && j < c) ? p.Dinv[(size_t)(a0 + r_) * c + j] : 0.0;
+          });
+          P.segs.push_back(S);
+        } else {
+          T.carry = pos(bit[q], p.c0 + a0);
+          const auto &h0 = hits[p.c0 + a0];
+          for (size_t u = 0; u < h0.size(); ++u) {
+            const int sid = h0[u].first;
+            const Piece &s = pc[sid];
+            int loc[RT];
+            for (int r_ = 0; r_ < nrows; ++r_) loc[r_] = hits[p.c0 + a0 + r_][u].second;
+            PSeg S;
+            S.len = pad2(s.c);
+            S.src = pos(bit[sid], s.c0);
+            S.idx = 0;
+            S.pad = 0;
+            const int c = s.c;
+            S.w = emit(nrows, S.len, [&](int r_, int j) { return j < c ? s.W[(size_t)loc[r_] * c + j] : 0.0; });
+            P.segs.push_back(S);
+          }
+        }
+        T.nseg = (int)P.segs.size() - T.seg0;
+        for (int q2 = T.seg0; q2 < T.seg0 + T.nseg; ++q2) {
+          seg_len_sum += P.segs[q2].len;
+          ++seg_cnt;
+        }
+        P.tasks.push_back(T);
+        a0 += nrows;
+      }
+    }
+    for (int i : hit_rows) hits[i].clear();
+    for (int q : affected) bit[q] ^= 1;
+    lv.ntasks = (int)P.tasks.size() - lv.task0;
+    lv.lanes = pick_lanes(lv.ntasks ? (double)seg_len_sum / lv.ntasks : 1.0);
+    P.levels.push_back(lv);
+  }
+  P.nforward = nlev;
+  // backward: x <- L_t^-T x, root first.  Only the piece's own rows change; they gather from their own old
+  // values and from the (final) values of the rows below.
+  for (int t = nlev - 1; t >= 0; --t) {
+    SpLevel lv;
+    lv.task0 = (int)P.tasks.size();
+    long long seg_len_sum = 0, seg_cnt = 0;
+    for (int s : by_level[t]) {
+      const Piece &p = pc[s];
+      const int m = (int)p.rows.size(), c = p.c;
+      const int idx0 = (int)P.idxs.size();
+      for (int i : p.rows) P.idxs.push_back(pos(bit[piece_of[i]], i));
+      if (m & 1) P.idxs.push_back(P.idxs.back());  // padded pair: weight 0, any valid position
+      for (int a0 = 0; a0 < c; a0 += RT) {
+        const int nrows = std::min(RT, c - a0);
+        PTask T;
+        T.out = pos(1 - bit[s], p.c0 + a0);
+        T.carry = -1;
+        T.nrows = nrows;
+        T.seg0 = (int)P.segs.size();
+        PSeg S;
+        S.len = pad2(c - a0);
+        S.src = pos(bit[s], p.c0 + a0);
+        S.idx = 0;
+        S.pad = 0;
+        // (D^-T)(a0 + q, a0 + j) = Dinv(a0 + j, a0 + q), zero below the diagonal of the transpose
+        S.w = emit(nrows, S.len, [&](int r_, int j) {
+          return (j >= r_ && a0 + j < c) ? p.Dinv[(size_t)(a0 + j) * c + (a0 + r_)] : 0.0;
+        });
+        P.segs.push_back(S);
+        seg_len_sum += S.len;
+        ++seg_cnt;
+        if (m > 0) {
+          PSeg Wt;
+          Wt.len = pad2(m);
+          Wt.src = -1;
+          Wt.idx = idx0;
+          Wt.pad = 0;
+          Wt.w = emit(nrows, Wt.len, [&](int r_, int j) { return j < m ? p.W[(size_t)j * c + (a0 + r_)] : 0.0; });
+          P.segs.push_back(Wt);
+          seg_len_sum += Wt.len;
+          ++seg_cnt;
+        }
+        T.nseg = (int)P.segs.size() - T.seg0;
+        P.tasks.push_back(T);
+      }
+    }
+    for (int s : by_level[t]) bit[s] ^= 1;
+    lv.ntasks = (int)P.tasks.size() - lv.task0;
+    lv.lanes = pick_lanes(lv.ntasks ? (double)seg_len_sum / lv.ntasks : 1.0);
+    P.levels.push_back(lv);
+  }
+  P.out_off.resize((size_t)k);
+  for (int j = 0; j < k; ++j) P.out_off[j] = pos(bit[piece_of[j]], j);
+  P.weights_read_per_apply = weights;
+  if (P.idxs.size() & 1) P.idxs.push_back(0);
+  if (P.idxs.empty()) P.idxs.assign(2, 0);
+  if (vals.empty()) vals.assign(2, 0.0);
+  return true;
+}
+
+void partitioned_inverse_apply_host(const PartInvHost &P, int r, const double *R, double *Z) {
+  const int k = P.k;
+  std::vector<double> y((size_t)(2 * k + 2) * r, 0.0);  // padded pairs may touch one unknown past the end
+  for (int j = 0; j < k; ++j)
+    for (int t = 0; t < r; ++t) y[(size_t)j * r + t] = R[(size_t)P.perm[j] * r + t];
+  std::vector<double> acc;
+  std::vector<double> outv;
+  for (const SpLevel &lv : P.levels) {
+    // every task of a level reads the state before the level: evaluate all, then store
+    outv.assign((size_t)lv.ntasks * kSpTile * r, 0.0);
+    for (int q = 0; q < lv.ntasks; ++q) {
+      const PTask &T = P.tasks[(size_t)lv.task0 + q];
+      acc.assign((size_t)T.nrows * r, 0.0);
+      for (int s = T.seg0; s < T.seg0 + T.nseg; ++s) {
+        const PSeg &S = P.segs[(size_t)s];
+        const double *w = &P.vals[(size_t)S.w];
+        for (int j = 0; j < S.len; ++j) {
+          const size_t u = (S.src >= 0) ? (size_t)S.src + j : (size_t)P.idxs[(size_t)S.idx + j];
+          for (int a = 0; a < T.nrows; ++a) {
+            const double wj = w[(size_t)j * T.nrows + a];
+            for (int t = 0; t < r; ++t) acc[(size_t)a * r + t] += wj * y[u * r + t];
+          }
+        }
+      }
+      for (int a = 0; a < T.nrows; ++a)
+        for (int t = 0; t < r; ++t)
+          outv[((size_t)q * kSpTile + a) * r + t] =
+              acc[(size_t)a * r + t] + (T.carry >= 0 ? y[((size_t)T.carry + a) * r + t] : 0.0);
+    }
+    for (int q = 0; q < lv.ntasks; ++q) {
+      const PTask &T = P.tasks[(size_t)lv.task0 + q];
+      for (int a = 0; a < T.nrows; ++a)
+        for (int t = 0; t < r; ++t) y[((size_t)T.out + a) * r + t] = outv[((size_t)q * kSpTile + a) * r + t];
+    }
+  }
+  for (int j = 0; j < k; ++j)
+    for (int t = 0; t < r; ++t) Z[(size_t)P.perm[j] * r + t] = y[(size_t)P.out_off[j] * r + t];
+}
+
+}  // namespace dcora

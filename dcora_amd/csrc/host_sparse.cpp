@@ -146,7 +146,7 @@ void leaf_order(const NDGraph &G, const std::vector<int> &nodes, std::vector<int
 }
 
 void nd_recurse(const NDGraph &G, std::vector<int> nodes, std::vector<int> &comp_id, int &next_cid,
-                std::vector<int> &level, std::vector<int> &out) {
+                std::vector<int> &level, std::vector<int> &out, std::vector<int> &cuts) {
   // iterative worklist: (nodes) ; output order is built back-to-front: separators last
   struct Item {
     std::vector<int> nodes;
@@ -168,6 +168,7 @@ void nd_recurse(const NDGraph &G, std::vector<int> nodes, std::vector<int> &comp
       std::vector<int> lo;
       leaf_order(G, cur, comp_id, cid, lo);
       for (auto it = lo.rbegin(); it != lo.rend(); ++it) rev.push_back(*it);
+      cuts.push_back((int)rev.size());
       for (int u : cur) comp_id[u] = -1;
       continue;
     }
@@ -195,6 +196,7 @@ void nd_recurse(const NDGraph &G, std::vector<int> nodes, std::vector<int> &comp
       std::vector<int> lo;
       leaf_order(G, cur, comp_id, cid, lo);
       for (auto it = lo.rbegin(); it != lo.rend(); ++it) rev.push_back(*it);
+      cuts.push_back((int)rev.size());
       for (int u : cur) comp_id[u] = -1;
       continue;
     }
@@ -210,15 +212,23 @@ void nd_recurse(const NDGraph &G, std::vector<int> nodes, std::vector<int> &comp
       else
         right.push_back(u);
     }
+    cuts.push_back((int)rev.size());
     for (int u : cur) comp_id[u] = -1;
     stack.push_back(std::move(left));
     stack.push_back(std::move(right));
   }
   for (auto it = rev.rbegin(); it != rev.rend(); ++it) out.push_back(*it);
+  // cuts were taken in the reversed order: position p there is position total - p in the final order
+  const int total = (int)rev.size();
+  for (int &c : cuts) c = total - c;
+  cuts.push_back(0);
+  cuts.push_back(total);
+  std::sort(cuts.begin(), cuts.end());
+  cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
 }
 }  // namespace
 
-std::vector<int> amd_like_order(const HostCsr &A, int block) {
+std::vector<int> amd_like_order(const HostCsr &A, int block, std::vector<int> *pieces) {
   const int n = A.n;
   if (block < 1) block = 1;
   const int nb = (n + block - 1) / block;
@@ -241,10 +251,26 @@ std::vector<int> amd_like_order(const HostCsr &A, int block) {
   G.adj.reserve(G.xadj[nb]);
   for (int u = 0; u < nb; ++u) G.adj.insert(G.adj.end(), nbrs[u].begin(), nbrs[u].end());
   std::vector<int> comp_id(nb, -1), level(nb, -1), border;
-  std::vector<int> all(nb);
-  std::iota(all.begin(), all.end(), 0);
+  // hubs (a landmark ranged from every pose, say) would collapse every BFS level structure to depth 2: take them
+  // out first and eliminate them last, as one top-level separator
+  std::vector<int> all, hubs;
+  {
+    const double mean_deg = nb ? (double)G.xadj[nb] / nb : 0.0;
+    const int thr = std::max(48, (int)(8.0 * mean_deg));
+    for (int u = 0; u < nb; ++u) (G.xadj[u + 1] - G.xadj[u] > thr ? hubs : all).push_back(u);
+  }
   int next_cid = 0;
-  nd_recurse(G, all, comp_id, next_cid, level, border);
+  std::vector<int> cuts;
+  nd_recurse(G, all, comp_id, next_cid, level, border, cuts);
+  if (!hubs.empty()) {
+    border.insert(border.end(), hubs.begin(), hubs.end());
+    cuts.push_back(nb);
+  }
+  if (pieces) {
+    pieces->clear();
+    for (int c : cuts) pieces->push_back(std::min(n, c * block));
+    pieces->erase(std::unique(pieces->begin(), pieces->end()), pieces->end());
+  }
   std::vector<int> perm;
   perm.reserve(n);
   for (int bn : border)
@@ -260,7 +286,7 @@ bool SparseChol::factor(const HostCsr &A, int block) {
   n_ = A.n;
   ok_ = false;
   const int n = n_;
-  perm_ = amd_like_order(A, block);
+  perm_ = amd_like_order(A, block, &pieces_);
   iperm_.assign(n, 0);
   for (int i = 0; i < n; ++i) iperm_[perm_[i]] = i;
   // upper triangle of P A P^T by columns

@@ -42,6 +42,14 @@ class SparseChol {
   // x = A^-1 b for nrhs right-hand sides stored contiguously per unknown: B[i*nrhs + t]
   void solve_inplace(double *B, int nrhs) const;  // B in permuted order
   const std::vector<int> &perm() const { return perm_; }
+  const std::vector<int> &iperm() const { return iperm_; }
+  // factor in compressed columns (diagonal first, then increasing rows), permuted numbering
+  const std::vector<int> &Lp() const { return Lp_; }
+  const std::vector<int> &Li() const { return Li_; }
+  const std::vector<double> &Lx() const { return Lx_; }
+  // boundaries (permuted scalar columns, ascending, first 0, last n) of the dissection pieces: every leaf
+  // sub-domain and every separator is one contiguous column range
+  const std::vector<int> &pieces() const { return pieces_; }
   // dense inverse written row-major with leading dimension ld (>= n), using nthreads host threads
   void dense_inverse(double *out, size_t ld, int nthreads) const;
   void solve_vec(const double *b, double *x) const;
@@ -49,10 +57,11 @@ class SparseChol {
  private:
   int n_ = 0;
   bool ok_ = false;
-  std::vector<int> perm_, iperm_, Lp_, Li_;
+  std::vector<int> perm_, iperm_, Lp_, Li_, pieces_;
   std::vector<double> Lx_;
 };
 
-std::vector<int> amd_like_order(const HostCsr &A, int block);
+// nested-dissection order; pieces (optional) receives the column boundaries of the leaves / separators
+std::vector<int> amd_like_order(const HostCsr &A, int block, std::vector<int> *pieces = nullptr);
 
 }  // namespace dcora

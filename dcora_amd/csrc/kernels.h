@@ -175,6 +175,9 @@ bool fused_supported(const ManiDesc &m);
 int fused_pose_blocks(const ManiDesc &m);   // partial slots written by hess / finish
 int fused_nsplit(const ManiDesc &m);        // row slices of the dense preconditioner product
 int fused_precond_grid(const ManiDesc &m);  // partial slots written by precond
+// Minv == nullptr: the kernel does the step / vector updates only (the sparse preconditioner follows as its own
+// launches); it then writes fused_update_grid(m) partial slots, and finish is called with nsplit = 1
+int fused_update_grid(const ManiDesc &m);
 void launch_fused_hess(hipStream_t st, const ManiDesc &m, const CsrDev &Q, const double *z, const double *d_old,
                        double *d_new, Buf2 X, Buf2 S, double *Hd, const double *p3, int np3, double *p1,
                        SolverCtl *ctl, int seq, int iter);
@@ -184,7 +187,7 @@ void launch_fused_precond(hipStream_t st, const ManiDesc &m, int ldm, const doub
                           HostFlags *hf, int seq, int iter, int first);
 void launch_fused_finish(hipStream_t st, const ManiDesc &m, Buf2 X, const double *Zpart, const double *res,
                          double *z, const double *p2, int np2, double *p3, SolverCtl *ctl, HostFlags *hf, int seq,
-                         int iter, int first);
+                         int iter, int first, int nsplit = -1 /* -1: fused_nsplit(m) */);
 // group-style (8 lanes per pose) rgrad / retract / Nesterov; return the number of partial slots written
 int launch_g_rgrad(hipStream_t st, const ManiDesc &m, Buf2 X, Buf2 EG, Buf2 RG, Buf2 Sblk, int sel, double *partials,
                    double *posenorm, Gate g);

@@ -349,8 +349,7 @@ __global__ __launch_bounds__(kBlock) void k_fused_precond(int r, int k, int ldm,
                                                           double *__restrict__ res_new,
                                                           double *__restrict__ Zpart, const double *__restrict__ p1,
                                                           int np1, double *__restrict__ p2, SolverCtl *ctl,
-                                                          HostFlags *hf, int seq, int iter, int first,
-                                                          int dbg) {
+                                                          HostFlags *hf, int seq, int iter, int first) {
   const int par = iter & 1;
   const int st_o = ctl->outer_done_stamp, st_t = ctl->tcg_done_stamp, cur = ctl->cur & 1;
   const double c_zr = ctl->z_r[par], c_dPd = ctl->d_Pd[par], c_ePe = ctl->e_Pe[par], c_ePd = ctl->e_Pd[par],
@@ -375,7 +374,7 @@ __global__ __launch_bounds__(kBlock) void k_fused_precond(int r, int k, int ldm,
     const double *__restrict__ mp0 = Minv + (size_t)(c_lo + w_lo0) * ldm + col;
 #pragma unroll
     for (int q = 0; q < kPre; ++q) {
-      if (w_lo0 + q < w_hi0 && dbg != 2) {
+      if (w_lo0 + q < w_hi0 && Minv != nullptr) {
         pre[q] = *reinterpret_cast<const double2 *>(mp0 + (size_t)q * ldm);
       } else {
         pre[q].x = 0.0;
@@ -476,8 +475,7 @@ __global__ __launch_bounds__(kBlock) void k_fused_precond(int r, int k, int ldm,
     const double tot = f_block_sum(acc2, s_red);
     if (threadIdx.x == 0) p2[blockIdx.x] = tot;
   }
-  if (boundary) return;
-  if (dbg == 1) return;
+  if (boundary || Minv == nullptr) return;
   // ---- dense product slice: Z_s(:, j) = sum_{c in slice} r(:, c) Minv(c, j) ----
   double a0[RM], a1[RM];
 #pragma unroll
@@ -1018,6 +1016,10 @@ int fused_nsplit(const ManiDesc &m) {
   return ns;
 }
 int fused_precond_grid(const ManiDesc &m) { return ((m.k + kJChunk - 1) / kJChunk) * fused_nsplit(m); }
+int fused_update_grid(const ManiDesc &m) {
+  const long blocks = ((long)m.r * m.k + kBlock - 1) / kBlock;
+  return (int)(blocks < 1024 ? blocks : 1024);
+}
 
 void launch_fused_hess(hipStream_t st, const ManiDesc &m, const CsrDev &Q, const double *z, const double *d_old,
                        double *d_new, Buf2 X, Buf2 S, double *Hd, const double *p3, int np3, double *p1,
@@ -1034,21 +1036,20 @@ void launch_fused_precond(hipStream_t st, const ManiDesc &m, int ldm, const doub
                           const double *delta, const double *Hd, double *eta, double *Heta, const double *res_old,
                           double *res_new, double *Zpart, const double *p1, int np1, double *p2, SolverCtl *ctl,
                           HostFlags *hf, int seq, int iter, int first) {
-  const int grid = fused_precond_grid(m);
-  const int ns = fused_nsplit(m);
-  static const int dbg = std::getenv("DCORA_DBG_PRECOND") ? atoi(std::getenv("DCORA_DBG_PRECOND")) : 0;
+  const int grid = Minv ? fused_precond_grid(m) : fused_update_grid(m);
+  const int ns = Minv ? fused_nsplit(m) : 1;
   if (m.r <= 4)
     hipLaunchKernelGGL(k_fused_precond<4>, dim3(grid), dim3(kBlock), 0, st, m.r, m.k, ldm, ns, Minv, grad, delta, Hd,
-                       eta, Heta, res_old, res_new, Zpart, p1, np1, p2, ctl, hf, seq, iter, first, dbg);
+                       eta, Heta, res_old, res_new, Zpart, p1, np1, p2, ctl, hf, seq, iter, first);
   else
     hipLaunchKernelGGL(k_fused_precond<8>, dim3(grid), dim3(kBlock), 0, st, m.r, m.k, ldm, ns, Minv, grad, delta, Hd,
-                       eta, Heta, res_old, res_new, Zpart, p1, np1, p2, ctl, hf, seq, iter, first, dbg);
+                       eta, Heta, res_old, res_new, Zpart, p1, np1, p2, ctl, hf, seq, iter, first);
 }
 void launch_fused_finish(hipStream_t st, const ManiDesc &m, Buf2 X, const double *Zpart, const double *res,
                          double *z, const double *p2, int np2, double *p3, SolverCtl *ctl, HostFlags *hf, int seq,
-                         int iter, int first) {
+                         int iter, int first, int nsplit) {
   const int grid = fused_pose_blocks(m);
-  const int ns = fused_nsplit(m);
+  const int ns = nsplit > 0 ? nsplit : fused_nsplit(m);
   if (m.d == 3)
     hipLaunchKernelGGL(k_fused_finish<3>, dim3(grid), dim3(kBlock), 0, st, m, ns, X, Zpart, res, z, p2, np2, p3, ctl,
                        hf, seq, iter, first);

@@ -1,0 +1,67 @@
+// Sparse preconditioner application on the device for large blocks:  Z = R (Q + reg I)^-1  without ever forming
+// the dense inverse (replaces the CHOLMOD solve of ref src/QuadraticProblem.cpp:70-84 when k is large; small
+// blocks keep the dense inverse of device_problem.hip, which is faster while k^2 doubles stay cheap to stream).
+//
+// Method: nested-dissection Cholesky  P A P^T = L L^T  on the host (once per Q), then L is written as the ordered
+// product of its block columns  L = L_1 L_2 ... L_N  (one factor per dissection piece: a leaf sub-domain or a
+// separator).  Each factor has an explicit inverse with the same block pattern,
+//     L_s^-1 = I + [ D_s^-1 - I ; -B_s D_s^-1 ]  on the columns of piece s,
+// and factors of pieces that do not feed each other commute, so all pieces of one level of the dissection tree are
+// applied by ONE launch: every output row is an independent gather (dot products of stored weights with the
+// current vector), no atomics, fixed summation order => bitwise reproducible.  A solve is
+//     permute-in, one launch per tree level (forward), one per level (backward), permute-out
+// i.e. 2 * depth + 2 launches with depth ~ log2(k / leaf) instead of the thousands of dependent steps of a
+// row-level triangular solve.  Vectors ping-pong between two buffers per piece; which buffer holds the current
+// value of a piece is known at build time and baked into the gather offsets.
+#pragma once
+#include <cstddef>
+#include <vector>
+
+#include "host_sparse.h"
+
+namespace dcora {
+
+constexpr int kSpTile = 4;  // output rows per task: they share every gathered vector entry
+
+struct PTask {  // a tile of nrows <= kSpTile consecutive output rows of one level
+  int out;      // first destination, in unknowns (buffer * k + permuted row)
+  int carry;    // first old value to keep (same units) or -1
+  int seg0, nseg;
+  int nrows;
+  int pad[3];
+};
+struct PSeg {       // row q of the tile:  sum_j w[q][j] * y[src + j]   or   sum_j w[q][j] * y[idx[j]]
+  long long w;      // offset into the weight array (even => 16-byte aligned); layout [entry j][row q], len even
+  int src;          // >= 0: contiguous run starting here (in unknowns); < 0: indexed through idx
+  int idx;          // offset into the index array when src < 0
+  int len;
+  int pad;
+};
+struct SpLevel {
+  int task0 = 0, ntasks = 0, lanes = 8;  // lanes per task (8, 16, 32 or 64)
+};
+
+// host image of the partitioned inverse: built by build_partitioned_inverse, uploaded by SparsePrecond
+struct PartInvHost {
+  int k = 0;
+  std::vector<SpLevel> levels;   // forward levels (leaves first), then backward levels (root first)
+  int nforward = 0;
+  std::vector<PTask> tasks;
+  std::vector<PSeg> segs;
+  std::vector<double> vals;
+  std::vector<int> idxs;
+  std::vector<int> perm;         // permuted position -> original unknown
+  std::vector<int> out_off;      // permuted position -> where its final value lives (buffer * k + position)
+  long nnzL = 0;
+  int npieces = 0;
+  double weights_read_per_apply = 0;  // doubles of stored weights one solve streams
+};
+
+// A symmetric positive definite (both triangles); block = unknowns ordered together.  false => not PD.
+bool build_partitioned_inverse(const HostCsr &A, int block, int nthreads, PartInvHost *out);
+
+// host reference of the device schedule (tests of the builder without a GPU): Z = R A^-1, R and Z are r x k
+// column-major
+void partitioned_inverse_apply_host(const PartInvHost &P, int r, const double *R, double *Z);
+
+}  // namespace dcora

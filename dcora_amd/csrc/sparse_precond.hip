@@ -1,0 +1,211 @@
+// Device side of the sparse preconditioner (sparse_precond.h): uploads the partitioned inverse and replays its
+// level schedule, one gather kernel per level.
+#include <algorithm>
+
+#include "device_problem.h"
+
+namespace dcora {
+
+namespace {
+
+__device__ __forceinline__ bool sp_gated(const SolverCtl *ctl, int seq, int gate) {
+  if (gate == 0 || ctl == nullptr) return false;
+  if (seq > ctl->outer_done_stamp) return true;
+  if (gate == 2 && seq > ctl->tcg_done_stamp) return true;
+  return false;
+}
+
+// y[0][j] = R[perm[j]]  (k unknowns of r values each)
+__global__ __launch_bounds__(kBlock) void k_sp_permute_in(int r, int k, const int *__restrict__ perm, Buf2 Rb,
+                                                          double *__restrict__ y, Gate g) {
+  if (sp_gated(g.ctl, g.seq, g.gate)) return;
+  const double *__restrict__ R = Rb.p[g.ctl ? (g.ctl->cur & 1) : 0];
+  const long n = (long)r * k;
+  for (long e = (long)blockIdx.x * kBlock + threadIdx.x; e < n; e += (long)gridDim.x * kBlock) {
+    const int j = (int)(e / r), t = (int)(e - (long)j * r);
+    y[e] = R[(size_t)perm[j] * r + t];
+  }
+}
+// Z[perm[j]] = y[out_off[j]]
+__global__ __launch_bounds__(kBlock) void k_sp_permute_out(int r, int k, const int *__restrict__ perm,
+                                                           const int *__restrict__ out_off,
+                                                           const double *__restrict__ y, double *__restrict__ Z,
+                                                           Gate g) {
+  if (sp_gated(g.ctl, g.seq, g.gate)) return;
+  const long n = (long)r * k;
+  for (long e = (long)blockIdx.x * kBlock + threadIdx.x; e < n; e += (long)gridDim.x * kBlock) {
+    const int j = (int)(e / r), t = (int)(e - (long)j * r);
+    Z[(size_t)perm[j] * r + t] = y[(size_t)out_off[j] * r + t];
+  }
+}
+
+// One level: LANES lanes per tile of up to kSpTile output rows (LANES = 256: one block per tile).
+// The r values of JP = LANES / r consecutive vector entries are one contiguous run of JP r doubles, so lane
+// l = j r + t loads exactly one of them (fully coalesced), multiplies it with the nrows weights of entry j (the
+// r lanes of an entry read the same 8 nrows bytes) and keeps nrows running sums for its own t.  The lanes that
+// share a t are summed through LDS in a fixed order => reproducible.  A vector entry is gathered once per tile.
+template <int LANES>
+__global__ __launch_bounds__(kBlock) void k_sp_level(int r, const PTask *__restrict__ tasks, int ntasks,
+                                                     const PSeg *__restrict__ segs,
+                                                     const double *__restrict__ vals,
+                                                     const int *__restrict__ idxs, double *__restrict__ y, Gate g) {
+  if (sp_gated(g.ctl, g.seq, g.gate)) return;
+  constexpr int RT = kSpTile;
+  constexpr int NE = (RT * 16 + LANES - 1) / LANES;  // output elements per lane (r <= 16)
+  __shared__ double s_acc[kBlock][RT];
+  const int tid = threadIdx.x;
+  const int lane = tid & (LANES - 1), grp0 = tid - lane;
+  const int task = (int)(((long)blockIdx.x * kBlock + tid) / LANES);
+  const bool active = task < ntasks;
+  PTask T;
+  T.out = 0; T.carry = -1; T.seg0 = 0; T.nseg = 0; T.nrows = 0;
+  if (active) T = tasks[task];
+  const int nrows = T.nrows, ne = nrows * r;
+  const int JP = LANES / r;            // vector entries per step
+  const int jl = lane / r, t = lane - jl * r;
+  const bool worker = jl < JP;
+  double cv[NE];
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int e = lane + i * LANES;
+    cv[i] = (T.carry >= 0 && e < ne) ? y[(size_t)T.carry * r + e] : 0.0;
+  }
+  double acc[RT];
+#pragma unroll
+  for (int q = 0; q < RT; ++q) acc[q] = 0;
+  for (int s = T.seg0; s < T.seg0 + T.nseg; ++s) {
+    const PSeg S = segs[s];
+    if (!worker) continue;
+    const double *__restrict__ w = vals + S.w;
+    if (S.src >= 0) {
+      const double *__restrict__ ys = y + (size_t)S.src * r + t;
+      if (nrows == RT) {
+#pragma unroll 4
+        for (int j = jl; j < S.len; j += JP) {
+          const double yv = ys[(size_t)j * r];
+          const double2 a0 = *reinterpret_cast<const double2 *>(w + (size_t)j * RT);
+          const double2 a1 = *reinterpret_cast<const double2 *>(w + (size_t)j * RT + 2);
+          acc[0] += a0.x * yv;
+          acc[1] += a0.y * yv;
+          acc[2] += a1.x * yv;
+          acc[3] += a1.y * yv;
+        }
+      } else {
+#pragma unroll 2
+        for (int j = jl; j < S.len; j += JP) {
+          const double yv = ys[(size_t)j * r];
+          const double *__restrict__ wa = w + (size_t)j * nrows;
+#pragma unroll
+          for (int q = 0; q < RT; ++q)
+            if (q < nrows) acc[q] += wa[q] * yv;
+        }
+      }
+    } else {
+      const int *__restrict__ ix = idxs + S.idx;
+      if (nrows == RT) {
+#pragma unroll 4
+        for (int j = jl; j < S.len; j += JP) {
+          const double yv = y[(size_t)ix[j] * r + t];
+          const double2 a0 = *reinterpret_cast<const double2 *>(w + (size_t)j * RT);
+          const double2 a1 = *reinterpret_cast<const double2 *>(w + (size_t)j * RT + 2);
+          acc[0] += a0.x * yv;
+          acc[1] += a0.y * yv;
+          acc[2] += a1.x * yv;
+          acc[3] += a1.y * yv;
+        }
+      } else {
+#pragma unroll 2
+        for (int j = jl; j < S.len; j += JP) {
+          const double yv = y[(size_t)ix[j] * r + t];
+          const double *__restrict__ wa = w + (size_t)j * nrows;
+#pragma unroll
+          for (int q = 0; q < RT; ++q)
+            if (q < nrows) acc[q] += wa[q] * yv;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < RT; ++q) s_acc[tid][q] = acc[q];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int e = lane + i * LANES;
+    if (e < ne) {
+      const int q = e / r, tt = e - q * r;
+      double v = cv[i];
+      for (int u = 0; u < JP; ++u) v += s_acc[grp0 + tt + u * r][q];
+      y[(size_t)T.out * r + e] = v;
+    }
+  }
+}
+
+void launch_level(hipStream_t st, int r, const SpLevel &lv, const PTask *tasks, const PSeg *segs, const double *vals,
+                  const int *idxs, double *y, Gate g) {
+  const int lanes = lv.lanes;
+  const long threads = (long)lv.ntasks * lanes;
+  const int grid = (int)((threads + kBlock - 1) / kBlock);
+  if (grid == 0) return;
+  const PTask *tp = tasks + lv.task0;
+  switch (lanes) {
+    case 256:
+      hipLaunchKernelGGL((k_sp_level<256>), dim3(grid), dim3(kBlock), 0, st, r, tp, lv.ntasks, segs, vals, idxs, y, g);
+      break;
+    case 64:
+      hipLaunchKernelGGL((k_sp_level<64>), dim3(grid), dim3(kBlock), 0, st, r, tp, lv.ntasks, segs, vals, idxs, y, g);
+      break;
+    case 32:
+      hipLaunchKernelGGL((k_sp_level<32>), dim3(grid), dim3(kBlock), 0, st, r, tp, lv.ntasks, segs, vals, idxs, y, g);
+      break;
+    default:
+      hipLaunchKernelGGL((k_sp_level<16>), dim3(grid), dim3(kBlock), 0, st, r, tp, lv.ntasks, segs, vals, idxs, y, g);
+      break;
+  }
+}
+
+}  // namespace
+
+int SparsePrecond::upload(const PartInvHost &P, int rcap_) {
+  k = P.k;
+  rcap = rcap_;
+  levels = P.levels;
+  nnzL = P.nnzL;
+  npieces = P.npieces;
+  weights_per_apply = P.weights_read_per_apply;
+  DCORA_HIP(vals.alloc(P.vals.size()));
+  DCORA_HIP(hipMemcpy(vals.p, P.vals.data(), P.vals.size() * sizeof(double), hipMemcpyHostToDevice));
+  DCORA_HIP(idxs.alloc(P.idxs.size()));
+  DCORA_HIP(hipMemcpy(idxs.p, P.idxs.data(), P.idxs.size() * sizeof(int), hipMemcpyHostToDevice));
+  DCORA_HIP(tasks.alloc(P.tasks.size()));
+  DCORA_HIP(hipMemcpy(tasks.p, P.tasks.data(), P.tasks.size() * sizeof(PTask), hipMemcpyHostToDevice));
+  DCORA_HIP(segs.alloc(P.segs.size()));
+  DCORA_HIP(hipMemcpy(segs.p, P.segs.data(), P.segs.size() * sizeof(PSeg), hipMemcpyHostToDevice));
+  DCORA_HIP(perm.alloc(P.perm.size()));
+  DCORA_HIP(hipMemcpy(perm.p, P.perm.data(), P.perm.size() * sizeof(int), hipMemcpyHostToDevice));
+  DCORA_HIP(out_off.alloc(P.out_off.size()));
+  DCORA_HIP(hipMemcpy(out_off.p, P.out_off.data(), P.out_off.size() * sizeof(int), hipMemcpyHostToDevice));
+  // two ping-pong images of the vector; padded pairs may touch one unknown past the end
+  DCORA_HIP(y.alloc((size_t)(2 * k + 2) * rcap));
+  DCORA_HIP(hipMemset(y.p, 0, (size_t)(2 * k + 2) * rcap * sizeof(double)));
+  ntasks_total = (long)P.tasks.size();
+  rows_total = 0;
+  for (const PTask &t : P.tasks) rows_total += t.nrows;
+  nsegs_total = (long)P.segs.size();
+  return DCORA_OK;
+}
+
+void SparsePrecond::apply(hipStream_t st, int r, Buf2 R, double *Z, Gate g) const {
+  const long n = (long)r * k;
+  const int grid = (int)std::min<long>((n + kBlock - 1) / kBlock, 2048);
+  hipLaunchKernelGGL(k_sp_permute_in, dim3(grid), dim3(kBlock), 0, st, r, k, perm.p, R, y.p, g);
+  for (const SpLevel &lv : levels) launch_level(st, r, lv, tasks.p, segs.p, vals.p, idxs.p, y.p, g);
+  hipLaunchKernelGGL(k_sp_permute_out, dim3(grid), dim3(kBlock), 0, st, r, k, perm.p, out_off.p, y.p, Z, g);
+}
+
+double SparsePrecond::bytes_per_apply(int r) const {
+  // stored weights once, the task / segment tables, the vector in and out of every row tile, permutes
+  return 8.0 * weights_per_apply + 32.0 * ntasks_total + 24.0 * nsegs_total + 16.0 * r * rows_total +
+         32.0 * r * (double)k;
+}
+
+}  // namespace dcora

@@ -232,6 +232,11 @@ int dcora_rbcd_synchronize(dcora_rbcd_t s);
 int dcora_problem_time_qapply(dcora_problem_t p, int reps, double *avg_ms, double *algorithmic_bytes);
 /* same for the preconditioner application kernel z = Proj_X(r (Q + reg I)^-1) (dense-inverse streaming part) */
 int dcora_problem_time_precond(dcora_problem_t p, int reps, double *avg_ms, double *algorithmic_bytes);
+/* how the preconditioner (Q + reg I)^-1 of ref src/Graph.cpp:1901-1917 is held on the device:
+ * info[0] = 0 none, 1 dense inverse, 2 partitioned sparse inverse (sparse_precond.h);
+ * info[1] = kernel launches per application; info[2] = nnz of the Cholesky factor; info[3] = host setup ms;
+ * info[4] = doubles of stored inverse one application streams */
+int dcora_problem_precond_info(dcora_problem_t p, double *info5);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,118 @@
+"""Partitioned sparse inverse of the preconditioner (dcora_amd/csrc/sparse_precond.h), the large-block form of
+(Q + reg I)^-1 (ref src/Graph.cpp:1901-1917, applied in src/QuadraticProblem.cpp:70-84).
+
+CPU: the host builder's schedule replayed on the host equals a plain sparse Cholesky solve.
+GPU: the device replay equals the oracle's CHOLMOD-style solve, alone and inside RTR / RBCD."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import common
+
+
+def _selftest(A, block, r):
+    from dcora_amd import capi
+    L = C.CDLL(capi.LIB_PATH)
+    A = sp.csr_matrix(A)
+    A.sort_indices()
+    rp, ci, v = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+    err, info = C.c_double(), np.zeros(4)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = L.dcora_debug_partinv_selftest(C.c_int(A.shape[0]), vp(rp), vp(ci), vp(v), C.c_int(block), C.c_int(r),
+                                        C.byref(err), vp(info))
+    return rc, err.value, info
+
+
+@pytest.mark.parametrize("name", ["tinyGrid3D", "smallGrid3D", "sphere2500", "pose_graph_optimization_test_2d"])
+def test_schedule_replayed_on_the_host_solves_the_system(built, name):
+    import dcora_amd as da
+    ds = common.product_dataset(name)
+    Q = da.build_Q_pgo(ds).to_scipy()
+    A = Q + 0.1 * sp.identity(Q.shape[0])
+    rc, err, info = _selftest(A, ds.d + 1, 5)
+    assert rc == 0 and err < 1e-12
+    assert info[0] % 2 == 0 and info[0] <= 2 * (2 + np.ceil(np.log2(max(ds.n, 2))))  # shallow: ~log2(n) levels
+
+
+def test_schedule_on_the_range_aided_layout_and_scalar_blocks(built):
+    import dcora_amd as da
+    ra = da.RADataset(os.path.join(common.DATA, "single_drone.pyfg.gz"))
+    Q = ra.Q.to_scipy()
+    A = Q + 0.5 * sp.identity(Q.shape[0])
+    rc, err, info = _selftest(A, 1, 3)
+    assert rc == 0 and err < 1e-11
+
+
+def test_indefinite_matrix_is_reported(built):
+    A = sp.diags([1.0, -1.0, 2.0]).tocsr()
+    rc, err, info = _selftest(A, 1, 1)
+    assert rc != 0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.fixture
+def sparse_env(built):
+    old = os.environ.get("DCORA_PRECOND")
+    os.environ["DCORA_PRECOND"] = "sparse"
+    yield
+    if old is None:
+        del os.environ["DCORA_PRECOND"]
+    else:
+        os.environ["DCORA_PRECOND"] = old
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,r", [("smallGrid3D", 5), ("sphere2500", 5), ("sphere2500", 7),
+                                    ("pose_graph_optimization_test_2d", 3)])
+def test_device_replay_matches_oracle_preconditioner(sparse_env, name, r):
+    import dcora_amd as da
+    from oracle import orc
+    ds, dso = common.product_dataset(name), common.oracle_dataset(name)
+    Q, Qo = da.build_Q_pgo(ds), orc.build_Q_pgo(dso)
+    P = da.QuadraticProblem(r, ds.d, ds.n, Q, reg=0.1)
+    Po = orc.Problem(r, ds.d, ds.n, Qo)
+    assert P.precond_info()["kind"] == "sparse"
+    X = common.random_point(r, ds.d, ds.n, 11, orc.project_to_manifold)
+    V = common.random_tangent(r, ds.d, ds.n, 12)
+    assert common.rel(P.PreCondition(X, V), Po.precondition(X, V)) < 1e-10
+    P.close()
+
+
+@pytest.mark.gpu
+def test_rtr_with_sparse_preconditioner_matches_oracle(sparse_env):
+    import dcora_amd as da
+    from oracle import orc
+    name, r = "smallGrid3D", 5
+    ds, dso = common.product_dataset(name), common.oracle_dataset(name)
+    Q, Qo = da.build_Q_pgo(ds), orc.build_Q_pgo(dso)
+    P = da.QuadraticProblem(r, ds.d, ds.n, Q, reg=0.1)
+    Po = orc.Problem(r, ds.d, ds.n, Qo)
+    X0 = common.random_point(r, ds.d, ds.n, 5, orc.project_to_manifold)
+    opt = da.QuadraticOptimizer(P)
+    X = opt.optimize(X0)
+    res = opt.getOptResult()
+    Xo, reso = Po.optimize(X0)
+    assert res["outer_iterations"] == reso["outer_iters"], (res, reso)
+    assert res["inner_iterations"] == reso["inner_iters"]
+    assert abs(res["fOpt"] - reso["fOpt"]) <= 1e-9 * abs(reso["fOpt"])
+    assert common.rel(X, Xo) < 1e-7
+    P.close()
+
+
+@pytest.mark.gpu
+def test_rbcd_with_sparse_preconditioner_matches_oracle(sparse_env):
+    import dcora_amd as da
+    from oracle import orc
+    ds, dso = common.product_dataset("smallGrid3D"), common.oracle_dataset("smallGrid3D")
+    r, iters = 5, 40
+    X0 = common.random_point(r, ds.d, ds.n, 1, orc.project_to_manifold)
+    tr = orc.run_rbcd(dso, X0, num_robots=5, r_min=r, max_iters=iters, staircase=0, rgrad_tol=1e-12)
+    s = da.RbcdSession(ds, num_robots=5, r=r)
+    s.set_X(X0)
+    out = s.run(max_iters=iters, rgrad_tol=1e-12)
+    assert np.array_equal(out["selected"], tr["selected"])
+    assert np.allclose(out["cost"], tr["cost"], rtol=1e-7)
+    assert common.rel(s.get_X(), tr["X"]) < 1e-6
