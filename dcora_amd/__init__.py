@@ -435,3 +435,34 @@ class RbcdSession:
 
     def synchronize(self):
         check(capi.lib().dcora_rbcd_synchronize(self.h))
+
+
+def align_lifted_trajectory_to_frame(X, anchor, d, n, global_alignment=True, device=0):
+    """alignLiftedTrajectoryToFrame (ref src/DCORA_utils.cpp:2262-2289): X r x (d+1) n (SE ordering), anchor
+    r x (d+1) -> d x (d+1) n with rotation blocks in SO(d)"""
+    X = np.asarray(X, dtype=np.float64)
+    dims = Dims(X.shape[0], d, n, 0, 0)
+    out = np.zeros(d * (d + 1) * n)
+    a = None if anchor is None else F(anchor)
+    check(capi.lib().dcora_round_align_trajectory(C.byref(dims), F(X), None if a is None else a.ctypes.data_as(C.c_void_p),
+                                                  int(global_alignment), out, None, None, device))
+    return unF(out, d, (d + 1) * n)
+
+
+def ra_states_in_local_frame(X, r, d, n, l, b, device=0):
+    """Agent::getStatesInLocalFrame (ref src/Agent.cpp:950-1003): X r x k (RA ordering) -> (trajectory d x (d+1) n in
+    the SE ordering, unit spheres d x l, landmarks d x b), all in the frame of pose 0"""
+    dims = Dims(r, d, n, l, b)
+    T, S, Lm = np.zeros(d * (d + 1) * n), np.zeros(max(d * l, 1)), np.zeros(max(d * b, 1))
+    check(capi.lib().dcora_round_align_trajectory(C.byref(dims), F(X), None, 0, T, S.ctypes.data_as(C.c_void_p),
+                                                  Lm.ctypes.data_as(C.c_void_p), device))
+    return unF(T, d, (d + 1) * n), unF(S[:d * l], d, l), unF(Lm[:d * b], d, b)
+
+
+def project_solution_raslam(X, r, d, n, l, b, device=0):
+    """projectSolutionRASLAM (ref src/DCORA_utils.cpp:1984-2031): r x k -> d x k"""
+    dims = Dims(r, d, n, l, b)
+    k = (d + 1) * n + l + b
+    out = np.zeros(d * k)
+    check(capi.lib().dcora_round_project_solution_raslam(C.byref(dims), F(X), out, device))
+    return unF(out, d, k)

@@ -118,6 +118,8 @@ SIGNATURES = {
     "dcora_problem_time_qapply": (C.c_int, [_vp, C.c_int, _PD, _PD]),
     "dcora_problem_time_precond": (C.c_int, [_vp, C.c_int, _PD, _PD]),
     "dcora_problem_precond_info": (C.c_int, [_vp, _dp]),
+    "dcora_round_align_trajectory": (C.c_int, [C.POINTER(Dims), _dp, _vp, C.c_int, _dp, _vp, _vp, C.c_int]),
+    "dcora_round_project_solution_raslam": (C.c_int, [C.POINTER(Dims), _dp, _dp, C.c_int]),
 }
 
 _lib = None

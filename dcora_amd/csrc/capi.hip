@@ -7,6 +7,7 @@
 #include "device_problem.h"
 #include "host_graph.h"
 #include "rbcd.h"
+#include "round.h"
 
 namespace dcora {
 const std::string &get_last_error();
@@ -507,6 +508,21 @@ int dcora_rbcd_synchronize(dcora_rbcd_t s) {
   if (!s) return bad("null");
   DCORA_HIP(hipStreamSynchronize(s->s.st));
   return DCORA_OK;
+}
+
+// ---- rounding ----------------------------------------------------------------------------------------------
+int dcora_round_align_trajectory(const dcora_dims *dims, const double *X, const double *anchor, int global_alignment,
+                                 double *trajectory, double *unit_spheres, double *landmarks, int device) {
+  if (!dims || !X || !trajectory) return bad("null argument");
+  DCORA_TRY
+  return round_align(*dims, X, anchor, global_alignment, trajectory, unit_spheres, landmarks, device);
+  DCORA_CATCH
+}
+int dcora_round_project_solution_raslam(const dcora_dims *dims, const double *X, double *out, int device) {
+  if (!dims || !X || !out) return bad("null argument");
+  DCORA_TRY
+  return round_project_solution(*dims, X, out, device);
+  DCORA_CATCH
 }
 
 }  // extern "C"

@@ -225,6 +225,22 @@ int dcora_rbcd_phase_evaluate_dev(dcora_rbcd_t s, double *out_dev);
 int dcora_rbcd_synchronize(dcora_rbcd_t s);
 
 /* ------------------------------------------------------------------------- *
+ * Rounding / solution recovery
+ * ------------------------------------------------------------------------- */
+/* alignLiftedTrajectoryToFrame (ref src/DCORA_utils.cpp:2262-2289), Agent::getTrajectoryInGlobalFrame /
+ * getStatesInLocalFrame (ref src/Agent.cpp:950-1034).  X is r x k in the layout of dims (SE ordering when
+ * l = b = 0, RA ordering otherwise); anchor is the lifted pose [Y0 p0], r x (d+1), or NULL for pose 0 of X.
+ * global_alignment != 0: the anchor's translation is the origin; 0: pose 0 of X is the origin.
+ * trajectory: d x (d+1) n in the SE ordering, every rotation block projected to SO(d);
+ * unit_spheres (d x l, rotated) and landmarks (d x b, rotated and translated) may be NULL. */
+int dcora_round_align_trajectory(const dcora_dims *dims, const double *X, const double *anchor, int global_alignment,
+                                 double *trajectory, double *unit_spheres, double *landmarks, int device);
+/* projectSolutionRASLAM (ref src/DCORA_utils.cpp:1984-2031): rank-d truncation of X (r x k), reflection test,
+ * SO(d) / unit-sphere projection; out is d x k in the same column layout.  Defined up to the sign convention of
+ * the SVD, i.e. up to a global orthogonal transformation that the caller's refinement / alignment removes. */
+int dcora_round_project_solution_raslam(const dcora_dims *dims, const double *X, double *out, int device);
+
+/* ------------------------------------------------------------------------- *
  * Bench / profiling hooks
  * ------------------------------------------------------------------------- */
 /* times `reps` launches of the Q-apply kernel Y = X Q + G of a problem with HIP events on the handle's

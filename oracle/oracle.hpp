@@ -174,6 +174,10 @@ bool build_G_pgo(int r, int d, int n, int id, const std::vector<Meas> &shared,
 // chordalInitialization (ref: src/DCORA_solver.cpp:218-268); returns d x (d+1) n, empty on failure
 Mat chordal_initialization(const Dataset &ds);
 
+// ---- rounding / solution recovery (oracle_round.cpp) ----------------------------------------------------------
+// alignLiftedTrajectoryToFrame (ref: src/DCORA_utils.cpp:2262-2289; local frame: src/Agent.cpp:963-980)
+void align_lifted_trajectory_to_frame(const Mat &X, const Mat &Tw0, int d, int n, bool global, Mat &out);
+
 // ---- range-aided SLAM data feed (centralised: one agent owns everything) -----------------------------------
 // ref: include/DCORA/Measurements.h RelativePoseLandmarkMeasurement / RangeMeasurement
 struct PoseLandmarkMeas {
@@ -277,5 +281,9 @@ inline uint64_t splitmix64(uint64_t &s) {
   return z ^ (z >> 31);
 }
 inline double u01(uint64_t &s) { return (splitmix64(s) >> 11) * (1.0 / 9007199254740992.0); }
+
+// getStatesInLocalFrame (ref: src/Agent.cpp:950-1003) and projectSolutionRASLAM (ref: src/DCORA_utils.cpp:1984-2031)
+void ra_states_in_local_frame(const Mat &X, const Dims &dm, Mat &traj, Mat &spheres, Mat &landmarks);
+void project_solution_raslam(const Mat &X, const Dims &dm, Mat &out);
 
 }  // namespace orc

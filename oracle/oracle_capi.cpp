@@ -402,4 +402,31 @@ void orc_trace_copy(void *h, double *cost, double *gradnorm, int *selected, int 
 }
 void orc_trace_free(void *h) { delete (RBCDTrace *)h; }
 
+// ---- rounding ------------------------------------------------------------------------------------------------------
+// X r x (d+1) n (SE ordering), anchor r x (d+1); out d x (d+1) n
+void orc_align_lifted_trajectory(int r, int d, int n, const double *X, const double *anchor, int global, double *out) {
+  Mat T;
+  align_lifted_trajectory_to_frame(view_mat(r, (d + 1) * n, X), view_mat(r, d + 1, anchor), d, n, global != 0, T);
+  std::copy(T.a.begin(), T.a.end(), out);
+}
+// X r x k (RA ordering); out d x k
+void orc_project_solution_raslam(int r, int d, int n, int l, int b, const double *X, double *out) {
+  Dims dm;
+  dm.r = r; dm.d = d; dm.n = n; dm.l = l; dm.b = b;
+  Mat P;
+  project_solution_raslam(view_mat(r, dm.k(), X), dm, P);
+  std::copy(P.a.begin(), P.a.end(), out);
+}
+// X r x k (RA ordering); traj d x (d+1) n (SE ordering), spheres d x l, landmarks d x b
+void orc_ra_states_in_local_frame(int r, int d, int n, int l, int b, const double *X, double *traj, double *spheres,
+                                  double *landmarks) {
+  Dims dm;
+  dm.r = r; dm.d = d; dm.n = n; dm.l = l; dm.b = b;
+  Mat T, S, Lm;
+  ra_states_in_local_frame(view_mat(r, dm.k(), X), dm, T, S, Lm);
+  std::copy(T.a.begin(), T.a.end(), traj);
+  std::copy(S.a.begin(), S.a.end(), spheres);
+  std::copy(Lm.a.begin(), Lm.a.end(), landmarks);
+}
+
 }  // extern "C"

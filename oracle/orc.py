@@ -78,6 +78,9 @@ def lib():
                                             C.POINTER(C.c_double), _dp, C.POINTER(C.c_double)]
         L.orc_escape_saddle.restype = C.c_int
         L.orc_escape_saddle.argtypes = [C.c_void_p, _dp, C.c_double, _dp, C.c_double, C.c_double, _dp]
+        L.orc_align_lifted_trajectory.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int, _dp]
+        L.orc_project_solution_raslam.argtypes = [C.c_int] * 5 + [_dp, _dp]
+        L.orc_ra_states_in_local_frame.argtypes = [C.c_int] * 5 + [_dp, _dp, _dp, _dp]
         L.orc_chordal_init.restype = C.c_int
         L.orc_chordal_init.argtypes = [C.c_void_p, _dp]
         L.orc_pyfg_load.restype = C.c_void_p
@@ -372,3 +375,26 @@ def chordal_initialization(ds):
     ok = L.orc_chordal_init(h, out)
     L.orc_ds_free(h)
     return unF(out, ds.d, (ds.d + 1) * ds.n) if ok else None
+
+
+def align_lifted_trajectory_to_frame(X, anchor, d, n, global_alignment=True):
+    """ref src/DCORA_utils.cpp:2262-2289 (global) / src/Agent.cpp:963-980 (local); returns d x (d+1) n"""
+    r = X.shape[0]
+    out = np.zeros(d * (d + 1) * n)
+    lib().orc_align_lifted_trajectory(r, d, n, F(X), F(anchor), int(global_alignment), out)
+    return unF(out, d, (d + 1) * n)
+
+
+def project_solution_raslam(X, r, d, n, l, b):
+    """ref src/DCORA_utils.cpp:1984-2031; returns d x k"""
+    k = (d + 1) * n + l + b
+    out = np.zeros(d * k)
+    lib().orc_project_solution_raslam(r, d, n, l, b, F(X), out)
+    return unF(out, d, k)
+
+
+def ra_states_in_local_frame(X, r, d, n, l, b):
+    """ref src/Agent.cpp:950-1003; returns (trajectory d x (d+1) n, unit spheres d x l, landmarks d x b)"""
+    T, S, Lm = np.zeros(d * (d + 1) * n), np.zeros(max(d * l, 1)), np.zeros(max(d * b, 1))
+    lib().orc_ra_states_in_local_frame(r, d, n, l, b, F(X), T, S, Lm)
+    return unF(T, d, (d + 1) * n), unF(S[:d * l], d, l), unF(Lm[:d * b], d, b)
