@@ -114,7 +114,7 @@ class RADataset:
     """centralised range-aided SLAM problem read from a .pyfg file (ref src/DCORA_utils.cpp:437-1167, 1169-1365;
     Q: ref src/Graph.cpp:824-1188).  X is r x k in the RA ordering [Y1..Yn | s1..sl | p1..pn | L1..Lb]."""
 
-    def __init__(self, path):
+    def __init__(self, path, init_seed=20250310):
         L = capi.lib()
         tmp = None
         if str(path).endswith(".gz"):
@@ -139,6 +139,10 @@ class RADataset:
         q = C.c_void_p()
         check(L.dcora_radataset_build_Q(h, C.byref(q)))
         self.Q = Csr(*capi.take_csr(q))
+        # start point of the centralised CORA driver (ref examples/SingleRobotExample_RASLAM.cpp:92-150), d x k
+        x0 = np.zeros(self.d * self.k)
+        check(L.dcora_radataset_odometry_init(h, init_seed, x0))
+        self.X_odom = unF(x0, self.d, self.k)
         L.dcora_radataset_destroy(h)
 
 
@@ -247,12 +251,14 @@ class QuadraticProblem:
         check(capi.lib().dcora_problem_tangent_project(self.h, F(Y), F(V), out))
         return unF(out, self.r, self.k)
 
-    def escapeSaddle(self, Xopt, theta, v, gradient_tolerance=1e-6, preconditioned_gradient_tolerance=1e-6):
+    def escapeSaddle(self, Xopt, theta, v, gradient_tolerance=1e-6, preconditioned_gradient_tolerance=1e-6,
+                     isSecondOrder=False):
         out = self._out()
         ok = C.c_int()
         check(capi.lib().dcora_problem_escape_saddle(self.h, F(Xopt), float(theta),
                                                      np.ascontiguousarray(v, np.float64), gradient_tolerance,
-                                                     preconditioned_gradient_tolerance, out, C.byref(ok)))
+                                                     preconditioned_gradient_tolerance, int(isSecondOrder), out,
+                                                     C.byref(ok)))
         return (unF(out, self.r, self.k) if ok.value else None)
 
     def time_qapply(self, reps=100):

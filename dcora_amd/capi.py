@@ -73,7 +73,7 @@ SIGNATURES = {
     "dcora_problem_precondition": (C.c_int, [_vp, _dp, _dp, _dp]),
     "dcora_problem_retract": (C.c_int, [_vp, _dp, _dp, _dp]),
     "dcora_problem_tangent_project": (C.c_int, [_vp, _dp, _dp, _dp]),
-    "dcora_problem_escape_saddle": (C.c_int, [_vp, _dp, C.c_double, _dp, C.c_double, C.c_double, _dp, _PI]),
+    "dcora_problem_escape_saddle": (C.c_int, [_vp, _dp, C.c_double, _dp, C.c_double, C.c_double, C.c_int, _dp, _PI]),
     "dcora_manifold_project": (C.c_int, [C.POINTER(Dims), _dp, _dp, C.c_int]),
     "dcora_optimizer_optimize": (C.c_int, [_vp, C.POINTER(ROptParams), _dp, _dp, C.POINTER(ROptResult)]),
     "dcora_csr_info": (C.c_int, [_vp, _PI, _PI]),
@@ -96,6 +96,7 @@ SIGNATURES = {
     "dcora_radataset_info": (C.c_int, [_vp, _ip]),
     "dcora_radataset_ground_truth": (C.c_int, [_vp, _dp]),
     "dcora_radataset_build_Q": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "dcora_radataset_odometry_init": (C.c_int, [_vp, C.c_ulonglong, _dp]),
     "dcora_radataset_destroy": (C.c_int, [_vp]),
     "dcora_graph_precond_regularization": (C.c_int, [C.c_int, _ip, _ip, _dp, C.c_int, _PD]),
     "dcora_rbcd_options_default": (None, [C.POINTER(RbcdOptions)]),

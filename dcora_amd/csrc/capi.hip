@@ -149,10 +149,10 @@ int dcora_problem_tangent_project(dcora_problem_t p, const double *X, const doub
   return p ? p->p.tangent_project(X, V, out) : bad("null");
 }
 int dcora_problem_escape_saddle(dcora_problem_t p, const double *Xopt, double theta, const double *v, double gtol,
-                                double pgtol, double *Xout, int *success) {
+                                double pgtol, int is_second_order, double *Xout, int *success) {
   if (!p) return bad("null");
   DCORA_TRY
-  return p->p.escape_saddle(Xopt, theta, v, gtol, pgtol, Xout, success);
+  return p->p.escape_saddle(Xopt, theta, v, gtol, pgtol, is_second_order != 0, Xout, success);
   DCORA_CATCH
 }
 int dcora_manifold_project(const dcora_dims *dims, const double *M, double *out, int device) {
@@ -386,6 +386,15 @@ int dcora_radataset_build_Q(dcora_radataset_t h, dcora_csr_t *Q) {
   dcora_csr_s *c = new dcora_csr_s;
   c->m = build_Q_ra(h->ds);
   *Q = c;
+  return DCORA_OK;
+  DCORA_CATCH
+}
+int dcora_radataset_odometry_init(dcora_radataset_t h, unsigned long long seed, double *X0) {
+  if (!h || !X0) return bad("null");
+  DCORA_TRY
+  std::vector<double> x;
+  ra_odometry_initialization(h->ds, seed, x);
+  std::copy(x.begin(), x.end(), X0);
   return DCORA_OK;
   DCORA_CATCH
 }

@@ -74,8 +74,8 @@ struct DevBsr {
 };
 
 struct DevCsr {
-  int nrows = 0, ncols = 0, nnz = 0;
-  DevBuf<int> rp, ci;
+  int nrows = 0, ncols = 0, nnz = 0, n_long = 0;
+  DevBuf<int> rp, ci, long_rows;
   DevBuf<double> v;
   int upload(const HostCsr &A);
   int upload(int nrows, int ncols, const int *rp, const int *ci, const double *v);
@@ -86,6 +86,8 @@ struct DevCsr {
     c.rp = rp.p;
     c.ci = ci.p;
     c.v = v.p;
+    c.n_long = n_long;
+    c.long_rows = long_rows.p;
     return c;
   }
 };
@@ -105,8 +107,13 @@ class SparsePrecond {
   DevBuf<int> idxs, perm, out_off;
   DevBuf<PTask> tasks;
   DevBuf<PSeg> segs;
+  // hubs (PartInvHub): Schur complement data
+  int nhub = 0;
+  long hub_nnz = 0;
+  DevBuf<int> hub_idx, hub_ap, hub_apos;
+  DevBuf<double> hub_aval, hub_U, hub_Sinv, hub_w;
   int upload(const PartInvHost &P, int rcap);
-  int launches() const { return (int)levels.size() + 2; }
+  int launches() const { return (int)levels.size() + 2 + (nhub > 0 ? 1 : 0); }
   // Z = R A^-1 for r <= rcap right-hand sides (r x k column-major); R is picked by ctl->cur when g.ctl is set
   void apply(hipStream_t st, int r, Buf2 R, double *Z, Gate g) const;
   double bytes_per_apply(int r) const;
@@ -158,7 +165,7 @@ class DeviceProblem {
 
   // ---- device-level building blocks (all enqueue on st, no sync) ----
   // EG = X Q + G, partials pA (npA slots of 2)
-  int npA() const { return has_bsr ? spmm_bsr_grid(m.n) : spmm_grid(m.k, m.r); }
+  int npA() const { return has_bsr ? spmm_bsr_grid(m.n) : spmm_grid(m.k, m.r) + Q.n_long; }
   int npPose() const { return pose_grid(m); }
   // rgrad / retract with the kernel flavour of this problem; return the number of partial slots written
   int enq_rgrad(Buf2 X, Buf2 EG, Buf2 RG, Buf2 S, int sel, double *partials, Gate g, double *posenorm = nullptr);
@@ -180,8 +187,8 @@ class DeviceProblem {
   int retract(const double *Xh, const double *Vh, double *out);
   int tangent_project(const double *Xh, const double *Vh, double *out);
   int optimize(const dcora_ropt_params &prm, const double *X0h, double *Xout, dcora_ropt_result *res);
-  int escape_saddle(const double *Xopt, double theta, const double *v, double gtol, double pgtol, double *Xout,
-                    int *success);
+  int escape_saddle(const double *Xopt, double theta, const double *v, double gtol, double pgtol, bool second_order,
+                    double *Xout, int *success);
 
   // ---- device-resident solve: X0.p holds the start point; on return *Xres points at the result buffer ----
   // The fused path returns without synchronising: the result lives in Xres->p[(*ctl_out)->cur] (device-side

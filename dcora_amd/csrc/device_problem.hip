@@ -33,6 +33,16 @@ int DevCsr::upload(int nr, int nc, const int *rph, const int *cih, const double 
     DCORA_HIP(hipMemcpy(ci.p, cih, sizeof(int) * nnz, hipMemcpyHostToDevice));
     DCORA_HIP(hipMemcpy(v.p, vh, sizeof(double) * nnz, hipMemcpyHostToDevice));
   }
+  std::vector<int> lr;
+  for (int i = 0; i < nr; ++i)
+    if (rph[i + 1] - rph[i] > kLongRow) lr.push_back(i);
+  n_long = (int)lr.size();
+  if (n_long > kMaxPartials / 2) {  // not a hub structure any more: let the row-parallel path handle everything
+    n_long = 0;
+    lr.clear();
+  }
+  DCORA_HIP(long_rows.alloc(std::max(n_long, 1)));
+  if (n_long) DCORA_HIP(hipMemcpy(long_rows.p, lr.data(), sizeof(int) * n_long, hipMemcpyHostToDevice));
   return DCORA_OK;
 }
 int DevBsr::upload(const HostBsr &B) {
@@ -119,7 +129,8 @@ int DeviceProblem::init(const dcora_dims &dims, const HostCsr &Qh, const double 
     DCORA_HIP(hipMemset(b->p, 0, N * sizeof(double)));
   DCORA_HIP(S0.alloc(NS));
   DCORA_HIP(S1.alloc(NS));
-  for (DevBuf<double> *b : {&pA, &pB, &pC, &p1, &p2, &p3}) DCORA_HIP(b->alloc(2 * kMaxPartials));
+  // 2 doubles per slot; the Q-apply may add up to kMaxPartials / 2 long-row blocks to its kMaxPartials row blocks
+  for (DevBuf<double> *b : {&pA, &pB, &pC, &p1, &p2, &p3}) DCORA_HIP(b->alloc(4 * kMaxPartials));
   DCORA_HIP(scal.alloc(64));
   DCORA_HIP(ctl.alloc(1));
   DCORA_HIP(hipHostMalloc((void **)&hf, sizeof(HostFlags), hipHostMallocMapped));
@@ -206,7 +217,7 @@ int DeviceProblem::enq_qapply(Buf2 X, int selX, const double *Gp, Buf2 Y, int se
     return spmm_bsr_grid(m.n);
   }
   launch_spmm(st, m.r, Q.view(), X, selX, Gp, Y, selY, partials, g);
-  return spmm_grid(m.k, m.r);
+  return spmm_grid(m.k, m.r) + Q.n_long;
 }
 void DeviceProblem::enqueue_egrad(const double *X, double *EG, double *partials) {
   enq_qapply(buf1(X), 0, has_G ? G.p : nullptr, buf1(EG), 0, partials, Gate{});
@@ -629,7 +640,7 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
 
 // ref src/QuadraticProblem.cpp:138-234 (rare path, host-paced: one scalar read-back per trial step)
 int DeviceProblem::escape_saddle(const double *Xopt, double theta, const double *v, double gtol, double pgtol,
-                                 double *Xout, int *success) {
+                                 bool second_order, double *Xout, int *success) {
   if (!has_precond) {
     set_last_error("escapeSaddle needs the preconditioner");
     return DCORA_ERR_NO_PRECONDITIONER;
@@ -650,8 +661,8 @@ int DeviceProblem::escape_saddle(const double *Xopt, double theta, const double 
   rc = eval_dev(X0.p, &FX, nullptr);
   if (rc) return rc;
   const double alpha_min = 1e-6;
-  double alpha = 1.0;  // isSecondOrder = false (header default)
-  (void)theta;
+  // ref :165-169: SE-Sync's second-order step when asked for, else Algorithm 7 of the DC2-PGO report
+  double alpha = second_order ? std::max(16 * alpha_min, 100 * gtol / std::fabs(theta)) : 1.0;
   std::vector<double> alphas, fvals;
   *success = 0;
   while (alpha >= alpha_min) {

@@ -62,6 +62,9 @@ struct HostRADataset {
 // chordalInitialization (ref src/DCORA_solver.cpp:218-268): T is d x (d+1) n column-major, pose 0 = identity
 bool chordal_initialization(const HostDataset &ds, std::vector<double> &T);
 bool load_pyfg(const std::string &path, HostRADataset &out, std::string &err);
+// start point of the centralised CORA driver (ref examples/SingleRobotExample_RASLAM.cpp:92-150): odometry chains
+// anchored at their ground-truth first pose, ground-truth unit spheres, seeded uniform(-1, 1) landmarks; d x k
+void ra_odometry_initialization(const HostRADataset &ds, unsigned long long seed, std::vector<double> &X0);
 // Q in the RA ordering [Y1..Yn | s1..sl | p1..pn | L1..Lb], assembled from the closed-form blocks of each factor
 HostCsr build_Q_ra(const HostRADataset &ds);
 }  // namespace dcora

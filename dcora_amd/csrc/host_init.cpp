@@ -163,3 +163,55 @@ bool chordal_initialization(const HostDataset &ds, std::vector<double> &T) {
 }
 
 }  // namespace dcora
+
+namespace dcora {
+namespace {
+inline unsigned long long splitmix64_next(unsigned long long &s) {
+  unsigned long long z = (s += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+}  // namespace
+
+// Start point of the centralised CORA driver (ref examples/SingleRobotExample_RASLAM.cpp:92-150, odometryInitialization
+// ref src/DCORA_solver.cpp:270-302): odometry chains anchored at their ground-truth first pose, ground-truth unit
+// spheres, landmarks uniform in (-1, 1) from a seeded splitmix64 stream.  X0 is d x k, RA ordering, column-major.
+void ra_odometry_initialization(const HostRADataset &ds, unsigned long long seed, std::vector<double> &X0) {
+  const int d = ds.d, n = ds.n, l = ds.l, b = ds.b, k = ds.k();
+  X0.assign((size_t)d * k, 0.0);
+  auto X = [&](int a, int c) -> double & { return X0[(size_t)c * d + a]; };
+  auto G = [&](int a, int c) { return ds.gt[(size_t)c * d + a]; };
+  std::vector<int> into((size_t)n, -1);
+  for (int e = 0; e < (int)ds.pose_pose.size(); ++e) {
+    const PoseMeas &m = ds.pose_pose[e];
+    if (m.p1 + 1 == m.p2 && into[m.p2] < 0) into[m.p2] = e;
+  }
+  const int ot = d * n + l;
+  for (int i = 0; i < n; ++i) {
+    if (into[i] < 0) {
+      for (int c = 0; c < d; ++c)
+        for (int a = 0; a < d; ++a) X(a, d * i + c) = G(a, d * i + c);
+      for (int a = 0; a < d; ++a) X(a, ot + i) = G(a, ot + i);
+      continue;
+    }
+    const PoseMeas &m = ds.pose_pose[into[i]];
+    for (int c = 0; c < d; ++c)
+      for (int a = 0; a < d; ++a) {
+        double s = 0;
+        for (int q = 0; q < d; ++q) s += X(a, d * (i - 1) + q) * m.R[q + c * d];
+        X(a, d * i + c) = s;
+      }
+    for (int a = 0; a < d; ++a) {
+      double s = X(a, ot + i - 1);
+      for (int q = 0; q < d; ++q) s += X(a, d * (i - 1) + q) * m.t[q];
+      X(a, ot + i) = s;
+    }
+  }
+  for (int j = 0; j < l; ++j)
+    for (int a = 0; a < d; ++a) X(a, d * n + j) = G(a, d * n + j);
+  unsigned long long s = seed;
+  for (int j = 0; j < b; ++j)
+    for (int a = 0; a < d; ++a) X(a, ot + n + j) = 2.0 * ((splitmix64_next(s) >> 11) * (1.0 / 9007199254740992.0)) - 1.0;
+}
+}  // namespace dcora

@@ -38,16 +38,21 @@ int pick_lanes(double avg_entries_per_tile) {
 bool build_partitioned_inverse(const HostCsr &A, int block, int nthreads, PartInvHost *out) {
   SparseChol chol;
   if (!chol.factor(A, block)) return false;
-  const int k = A.n;
+  const int kfull = A.n;
+  // hubs are the trailing columns of the order and the last piece: they stay out of the replay (Schur complement,
+  // see PartInvHub); the leading k x k block of L is the factor of A11
+  const int h = (chol.nhub() > 0 && chol.nhub() <= 64 && chol.nhub() < kfull) ? chol.nhub() : 0;
+  const int k = kfull - h;
   const std::vector<int> &Lp = chol.Lp(), &Li = chol.Li();
   const std::vector<double> &Lx = chol.Lx();
   const std::vector<int> &cuts = chol.pieces();
   PartInvHost &P = *out;
   P = PartInvHost();
   P.k = k;
-  P.perm = chol.perm();
+  P.kfull = kfull;
+  P.perm.assign(chol.perm().begin(), chol.perm().begin() + k);
   P.nnzL = chol.nnzL();
-  const int np = (int)cuts.size() - 1;
+  const int np = (int)cuts.size() - 1 - (h > 0 ? 1 : 0);
   P.npieces = np;
   std::vector<Piece> pc((size_t)np);
   std::vector<int> piece_of((size_t)k);
@@ -65,7 +70,7 @@ bool build_partitioned_inverse(const HostCsr &A, int block, int nthreads, PartIn
       for (int j = pc[s].c0; j < hi; ++j)
         for (int p = Lp[j] + 1; p < Lp[j + 1]; ++p) {
           const int i = Li[p];
-          if (i >= hi && mark[i] != s) {
+          if (i >= hi && i < k && mark[i] != s) {
             mark[i] = s;
             rows.push_back(i);
           }
@@ -105,7 +110,7 @@ bool build_partitioned_inverse(const HostCsr &A, int block, int nthreads, PartIn
             const int i = Li[q];
             if (i < c0 + c)
               D[(size_t)(i - c0) * c + j] = Lx[q];
-            else
+            else if (i < k)
               B[(size_t)where[i] * c + j] = Lx[q];
           }
         for (int a = 0; a < m; ++a) where[p.rows[a]] = -1;
@@ -311,6 +316,77 @@ bool build_partitioned_inverse(const HostCsr &A, int block, int nthreads, PartIn
   P.out_off.resize((size_t)k);
   for (int j = 0; j < k; ++j) P.out_off[j] = pos(bit[piece_of[j]], j);
   P.weights_read_per_apply = weights;
+  // ---- hubs: U = A11^-1 a with the leading block of L, Sc = alpha - a^T U ----
+  if (h > 0) {
+    PartInvHub &H = P.hub;
+    H.h = h;
+    const std::vector<int> &perm = chol.perm(), &iperm = chol.iperm();
+    H.idx.assign(perm.begin() + k, perm.end());
+    H.ap.assign(1, 0);
+    H.U.assign((size_t)k * h, 0.0);
+    std::vector<double> alpha((size_t)h * h, 0.0), u((size_t)k), acol((size_t)k);
+    for (int q = 0; q < h; ++q) {
+      const int hq = H.idx[q];
+      std::fill(acol.begin(), acol.end(), 0.0);
+      for (int p = A.rp[hq]; p < A.rp[hq + 1]; ++p) {
+        const int j = iperm[A.ci[p]];
+        if (j < k) {
+          acol[j] = A.v[p];
+          H.apos.push_back(P.out_off[j]);
+          H.aval.push_back(A.v[p]);
+        } else {
+          alpha[(size_t)q * h + (j - k)] = A.v[p];
+        }
+      }
+      H.ap.push_back((int)H.apos.size());
+      u = acol;
+      for (int j = 0; j < k; ++j) {
+        u[j] /= Lx[Lp[j]];
+        const double uj = u[j];
+        if (uj == 0.0) continue;
+        for (int p = Lp[j] + 1; p < Lp[j + 1]; ++p)
+          if (Li[p] < k) u[Li[p]] -= Lx[p] * uj;
+      }
+      for (int j = k - 1; j >= 0; --j) {
+        double s = u[j];
+        for (int p = Lp[j] + 1; p < Lp[j + 1]; ++p)
+          if (Li[p] < k) s -= Lx[p] * u[Li[p]];
+        u[j] = s / Lx[Lp[j]];
+      }
+      for (int j = 0; j < k; ++j) H.U[(size_t)j * h + q] = u[j];
+    }
+    // Sc = alpha - a^T U (symmetric positive definite), inverted by Gauss-Jordan (h is tiny)
+    std::vector<double> Sc((size_t)h * h), Inv((size_t)h * h, 0.0);
+    for (int q = 0; q < h; ++q)
+      for (int q2 = 0; q2 < h; ++q2) {
+        double s = alpha[(size_t)q * h + q2];
+        const int hq = H.idx[q];
+        for (int p = A.rp[hq]; p < A.rp[hq + 1]; ++p) {
+          const int j = iperm[A.ci[p]];
+          if (j < k) s -= A.v[p] * H.U[(size_t)j * h + q2];
+        }
+        Sc[(size_t)q * h + q2] = s;
+      }
+    for (int q = 0; q < h; ++q) Inv[(size_t)q * h + q] = 1.0;
+    for (int c = 0; c < h; ++c) {
+      const double piv = Sc[(size_t)c * h + c];
+      if (!(piv > 0)) return false;
+      for (int j = 0; j < h; ++j) {
+        Sc[(size_t)c * h + j] /= piv;
+        Inv[(size_t)c * h + j] /= piv;
+      }
+      for (int i = 0; i < h; ++i) {
+        if (i == c) continue;
+        const double fct = Sc[(size_t)i * h + c];
+        if (fct == 0.0) continue;
+        for (int j = 0; j < h; ++j) {
+          Sc[(size_t)i * h + j] -= fct * Sc[(size_t)c * h + j];
+          Inv[(size_t)i * h + j] -= fct * Inv[(size_t)c * h + j];
+        }
+      }
+    }
+    H.Sinv = Inv;
+  }
   if (P.idxs.size() & 1) P.idxs.push_back(0);
   if (P.idxs.empty()) P.idxs.assign(2, 0);
   if (vals.empty()) vals.assign(2, 0.0);
@@ -352,8 +428,30 @@ void partitioned_inverse_apply_host(const PartInvHost &P, int r, const double *R
         for (int t = 0; t < r; ++t) y[((size_t)T.out + a) * r + t] = outv[((size_t)q * kSpTile + a) * r + t];
     }
   }
+  const PartInvHub &H = P.hub;
+  std::vector<double> x2((size_t)H.h * r, 0.0);
+  if (H.h > 0) {
+    std::vector<double> w((size_t)H.h * r);
+    for (int q = 0; q < H.h; ++q)
+      for (int t = 0; t < r; ++t) {
+        double s = R[(size_t)H.idx[q] * r + t];
+        for (int p = H.ap[q]; p < H.ap[q + 1]; ++p) s -= H.aval[p] * y[(size_t)H.apos[p] * r + t];
+        w[(size_t)q * r + t] = s;
+      }
+    for (int q = 0; q < H.h; ++q)
+      for (int t = 0; t < r; ++t) {
+        double s = 0;
+        for (int q2 = 0; q2 < H.h; ++q2) s += H.Sinv[(size_t)q * H.h + q2] * w[(size_t)q2 * r + t];
+        x2[(size_t)q * r + t] = s;
+        Z[(size_t)H.idx[q] * r + t] = s;
+      }
+  }
   for (int j = 0; j < k; ++j)
-    for (int t = 0; t < r; ++t) Z[(size_t)P.perm[j] * r + t] = y[(size_t)P.out_off[j] * r + t];
+    for (int t = 0; t < r; ++t) {
+      double v = y[(size_t)P.out_off[j] * r + t];
+      for (int q = 0; q < H.h; ++q) v -= H.U[(size_t)j * H.h + q] * x2[(size_t)q * r + t];
+      Z[(size_t)P.perm[j] * r + t] = v;
+    }
 }
 
 }  // namespace dcora

@@ -228,7 +228,7 @@ void nd_recurse(const NDGraph &G, std::vector<int> nodes, std::vector<int> &comp
 }
 }  // namespace
 
-std::vector<int> amd_like_order(const HostCsr &A, int block, std::vector<int> *pieces) {
+std::vector<int> amd_like_order(const HostCsr &A, int block, std::vector<int> *pieces, int *nhub_cols) {
   const int n = A.n;
   if (block < 1) block = 1;
   const int nb = (n + block - 1) / block;
@@ -273,9 +273,16 @@ std::vector<int> amd_like_order(const HostCsr &A, int block, std::vector<int> *p
   }
   std::vector<int> perm;
   perm.reserve(n);
-  for (int bn : border)
+  int hub_cols = 0;
+  for (size_t q = 0; q < border.size(); ++q) {
+    const int bn = border[q];
     for (int t = 0; t < block; ++t)
-      if (bn * block + t < n) perm.push_back(bn * block + t);
+      if (bn * block + t < n) {
+        perm.push_back(bn * block + t);
+        if (q >= border.size() - hubs.size()) ++hub_cols;
+      }
+  }
+  if (nhub_cols) *nhub_cols = hub_cols;
   return perm;
 }
 
@@ -286,7 +293,7 @@ bool SparseChol::factor(const HostCsr &A, int block) {
   n_ = A.n;
   ok_ = false;
   const int n = n_;
-  perm_ = amd_like_order(A, block, &pieces_);
+  perm_ = amd_like_order(A, block, &pieces_, &nhub_);
   iperm_.assign(n, 0);
   for (int i = 0; i < n; ++i) iperm_[perm_[i]] = i;
   // upper triangle of P A P^T by columns

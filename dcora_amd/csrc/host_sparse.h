@@ -50,18 +50,22 @@ class SparseChol {
   // boundaries (permuted scalar columns, ascending, first 0, last n) of the dissection pieces: every leaf
   // sub-domain and every separator is one contiguous column range
   const std::vector<int> &pieces() const { return pieces_; }
+  // hubs (unknowns coupled to a large share of all others, e.g. a landmark ranged from every pose) are ordered
+  // last and form the last piece: the trailing nhub() columns
+  int nhub() const { return nhub_; }
   // dense inverse written row-major with leading dimension ld (>= n), using nthreads host threads
   void dense_inverse(double *out, size_t ld, int nthreads) const;
   void solve_vec(const double *b, double *x) const;
 
  private:
-  int n_ = 0;
+  int n_ = 0, nhub_ = 0;
   bool ok_ = false;
   std::vector<int> perm_, iperm_, Lp_, Li_, pieces_;
   std::vector<double> Lx_;
 };
 
 // nested-dissection order; pieces (optional) receives the column boundaries of the leaves / separators
-std::vector<int> amd_like_order(const HostCsr &A, int block, std::vector<int> *pieces = nullptr);
+std::vector<int> amd_like_order(const HostCsr &A, int block, std::vector<int> *pieces = nullptr,
+                                int *nhub_cols = nullptr);
 
 }  // namespace dcora

@@ -33,12 +33,15 @@ inline ManiDesc make_mani(int r, int d, int n, int l, int b) {
   return m;
 }
 
+constexpr int kLongRow = 512;  // rows with more entries (a landmark ranged from every pose) get a block of their own
 struct CsrDev {
   int nrows = 0;
   int nnz = 0;
   const int *rp = nullptr;
   const int *ci = nullptr;
   const double *v = nullptr;
+  int n_long = 0;                  // rows with more than kLongRow entries ...
+  const int *long_rows = nullptr;  // ... and their indices
 };
 
 // block-CSR view of a pose-graph matrix: (d+1) x (d+1) dense blocks, row-major inside a block
@@ -95,6 +98,7 @@ struct Gate {
 
 // ---- SpMM: Y = X * A (+ G); optional partial dots {sum (X*A) o X, sum X o G}, 2 per block ---------------
 int spmm_grid(int nrows, int r);
+inline int spmm_slots(const CsrDev &A, int r) { return spmm_grid(A.nrows, r) + A.n_long; }  // partial slots written
 void launch_spmm(hipStream_t st, int r, const CsrDev &A, Buf2 X, int selX, const double *G, Buf2 Y, int selY,
                  double *partials, Gate g);
 

@@ -73,7 +73,8 @@ int spmm_grid(int nrows, int r) {
 
 template <bool DOTS>
 __global__ __launch_bounds__(kBlock) void k_spmm(int r, CsrDev A, Buf2 Xb, int selX, const double *__restrict__ G,
-                                                 Buf2 Yb, int selY, double *__restrict__ partials, Gate g) {
+                                                 Buf2 Yb, int selY, double *__restrict__ partials, Gate g,
+                                                 int main_grid) {
   if (gated(g.ctl, g.seq, g.gate)) return;
   __shared__ int s_ci[kSpmmTile];
   __shared__ double s_v[kSpmmTile];
@@ -84,13 +85,48 @@ __global__ __launch_bounds__(kBlock) void k_spmm(int r, CsrDev A, Buf2 Xb, int s
   const int nrb = (A.nrows + RB - 1) / RB;
   const int lj = threadIdx.x / r, t = threadIdx.x - lj * r;
   double d0 = 0, d1 = 0;
-  for (int rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+  if ((int)blockIdx.x >= main_grid) {
+    // one block for one long row: the RB entry groups stride over the row, partial sums meet in LDS
+    const int j = A.long_rows[blockIdx.x - main_grid];
+    const int pb = A.rp[j], pe = A.rp[j + 1];
+    double acc = 0;
+    if (lj < RB)
+      for (int p = pb + lj; p < pe; p += RB) acc += A.v[p] * X[(size_t)A.ci[p] * r + t];
+    double *s_part = s_v;  // kBlock doubles
+    __syncthreads();
+    s_part[threadIdx.x] = (lj < RB) ? acc : 0.0;
+    __syncthreads();
+    if (threadIdx.x < r) {
+      double y = 0;
+      for (int q = 0; q < RB; ++q) y += s_part[q * r + threadIdx.x];
+      const size_t o = (size_t)j * r + threadIdx.x;
+      if (DOTS) {
+        const double x = X[o];
+        d0 = y * x;
+        if (G) d1 = x * G[o];
+      }
+      if (G) y += G[o];
+      Y[o] = y;
+    }
+    if (DOTS) {
+      const double a = block_sum(d0, s_red);
+      const double b = block_sum(d1, s_red);
+      if (threadIdx.x == 0) {
+        partials[2 * blockIdx.x] = a;
+        partials[2 * blockIdx.x + 1] = b;
+      }
+    }
+    return;
+  }
+  for (int rb = blockIdx.x; rb < nrb; rb += main_grid) {
     const int j0 = rb * RB;
     const int j1 = min(A.nrows, j0 + RB);
     const int j = j0 + lj;
     const bool active = (lj < RB) && (j < j1);
     const int pbeg = A.rp[j0], pend = A.rp[j1];
-    const int myb = active ? A.rp[j] : 0, mye = active ? A.rp[j + 1] : 0;
+    int myb = active ? A.rp[j] : 0, mye = active ? A.rp[j + 1] : 0;
+    const bool is_long = A.n_long > 0 && (mye - myb > kLongRow);  // served by its own block
+    if (is_long) mye = myb;
     double acc = 0;
     for (int base = pbeg; base < pend; base += kSpmmTile) {
       const int cnt = min(kSpmmTile, pend - base);
@@ -112,7 +148,7 @@ __global__ __launch_bounds__(kBlock) void k_spmm(int r, CsrDev A, Buf2 Xb, int s
       }
       for (; p < hi; ++p) acc += s_v[p] * X[(size_t)s_ci[p] * r + t];
     }
-    if (active) {
+    if (active && !is_long) {
       const size_t o = (size_t)j * r + t;
       double y = acc;
       if (DOTS) {
@@ -136,11 +172,14 @@ __global__ __launch_bounds__(kBlock) void k_spmm(int r, CsrDev A, Buf2 Xb, int s
 
 void launch_spmm(hipStream_t st, int r, const CsrDev &A, Buf2 X, int selX, const double *G, Buf2 Y, int selY,
                  double *partials, Gate g) {
-  const int grid = spmm_grid(A.nrows, r);
+  const int main_grid = spmm_grid(A.nrows, r);
+  const int grid = main_grid + A.n_long;
   if (partials)
-    hipLaunchKernelGGL(k_spmm<true>, dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials, g);
+    hipLaunchKernelGGL(k_spmm<true>, dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials, g,
+                       main_grid);
   else
-    hipLaunchKernelGGL(k_spmm<false>, dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials, g);
+    hipLaunchKernelGGL(k_spmm<false>, dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials, g,
+                       main_grid);
 }
 
 // ------------------------------------------------------------------------------------------------------

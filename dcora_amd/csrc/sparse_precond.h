@@ -42,8 +42,24 @@ struct SpLevel {
 };
 
 // host image of the partitioned inverse: built by build_partitioned_inverse, uploaded by SparsePrecond
+// Hubs: h unknowns coupled to a large share of all others (a landmark ranged from every pose).  They are kept
+// out of the dissection and handled by a Schur complement: with A = [A11 a; a^T alpha],
+//     y1 = A11^-1 b1,   x2 = Sc^-1 (b2 - a^T y1),   x1 = y1 - U x2,   U = A11^-1 a,   Sc = alpha - a^T U,
+// i.e. one sparse dot per hub after the level replay and a rank-h correction folded into the final permutation.
+struct PartInvHub {
+  int h = 0;
+  std::vector<int> idx;       // original index of each hub unknown
+  std::vector<int> ap;        // h + 1 offsets into apos / aval: column q of a
+  std::vector<int> apos;      // where the entry's y1 value lives (buffer * k + permuted position)
+  std::vector<double> aval;
+  std::vector<double> U;      // k x h, row j = permuted position j
+  std::vector<double> Sinv;   // h x h, row-major
+};
+
 struct PartInvHost {
-  int k = 0;
+  int k = 0;                     // unknowns handled by the level replay (hubs excluded)
+  int kfull = 0;                 // size of the system
+  PartInvHub hub;
   std::vector<SpLevel> levels;   // forward levels (leaves first), then backward levels (root first)
   int nforward = 0;
   std::vector<PTask> tasks;

@@ -39,6 +39,58 @@ __global__ __launch_bounds__(kBlock) void k_sp_permute_out(int r, int k, const i
   }
 }
 
+// ---- hubs (PartInvHub): Schur complement on top of the replay ----
+struct HubDev {
+  int h;
+  const int *idx, *ap, *apos;
+  const double *aval, *U, *Sinv;
+  double *w;  // h x r scratch: b2 - a^T y1
+};
+// w(q, :) = R(hub_q, :) - sum_p a_q[p] y1(pos_p, :)   -- one block per hub unknown
+__global__ __launch_bounds__(kBlock) void k_sp_hub_dot(int r, HubDev H, Buf2 Rb, const double *__restrict__ y,
+                                                       Gate g) {
+  if (sp_gated(g.ctl, g.seq, g.gate)) return;
+  __shared__ double s_part[kBlock];
+  const double *__restrict__ R = Rb.p[g.ctl ? (g.ctl->cur & 1) : 0];
+  const int q = blockIdx.x;
+  const int RB = kBlock / r;
+  const int lj = threadIdx.x / r, t = threadIdx.x - lj * r;
+  double acc = 0;
+  if (lj < RB)
+    for (int p = H.ap[q] + lj; p < H.ap[q + 1]; p += RB) acc += H.aval[p] * y[(size_t)H.apos[p] * r + t];
+  s_part[threadIdx.x] = (lj < RB) ? acc : 0.0;
+  __syncthreads();
+  if ((int)threadIdx.x < r) {
+    double s = 0;
+    for (int u = 0; u < RB; ++u) s += s_part[u * r + threadIdx.x];
+    H.w[(size_t)q * r + threadIdx.x] = R[(size_t)H.idx[q] * r + threadIdx.x] - s;
+  }
+}
+// x2 = Sinv w (recomputed by every block: h r values);  Z[perm[j]] = y1[j] - U(j, :) x2;  Z[hub_q] = x2(q, :)
+__global__ __launch_bounds__(kBlock) void k_sp_permute_out_hub(int r, int k, const int *__restrict__ perm,
+                                                               const int *__restrict__ out_off,
+                                                               const double *__restrict__ y,
+                                                               double *__restrict__ Z, HubDev H, Gate g) {
+  if (sp_gated(g.ctl, g.seq, g.gate)) return;
+  __shared__ double s_x2[64 * 16];
+  const int h = H.h;
+  for (int e = threadIdx.x; e < h * r; e += kBlock) {
+    const int q = e / r, t = e - q * r;
+    double s = 0;
+    for (int q2 = 0; q2 < h; ++q2) s += H.Sinv[(size_t)q * h + q2] * H.w[(size_t)q2 * r + t];
+    s_x2[e] = s;
+    if (blockIdx.x == 0) Z[(size_t)H.idx[q] * r + t] = s;
+  }
+  __syncthreads();
+  const long n = (long)r * k;
+  for (long e = (long)blockIdx.x * kBlock + threadIdx.x; e < n; e += (long)gridDim.x * kBlock) {
+    const int j = (int)(e / r), t = (int)(e - (long)j * r);
+    double v = y[(size_t)out_off[j] * r + t];
+    for (int q = 0; q < h; ++q) v -= H.U[(size_t)j * h + q] * s_x2[q * r + t];
+    Z[(size_t)perm[j] * r + t] = v;
+  }
+}
+
 // One level: LANES lanes per tile of up to kSpTile output rows (LANES = 256: one block per tile).
 // The r values of JP = LANES / r consecutive vector entries are one contiguous run of JP r doubles, so lane
 // l = j r + t loads exactly one of them (fully coalesced), multiplies it with the nrows weights of entry j (the
@@ -191,6 +243,27 @@ int SparsePrecond::upload(const PartInvHost &P, int rcap_) {
   rows_total = 0;
   for (const PTask &t : P.tasks) rows_total += t.nrows;
   nsegs_total = (long)P.segs.size();
+  nhub = P.hub.h;
+  hub_nnz = (long)P.hub.aval.size();
+  if (nhub > 0) {
+    const PartInvHub &H = P.hub;
+    DCORA_HIP(hub_idx.alloc(H.idx.size()));
+    DCORA_HIP(hipMemcpy(hub_idx.p, H.idx.data(), H.idx.size() * sizeof(int), hipMemcpyHostToDevice));
+    DCORA_HIP(hub_ap.alloc(H.ap.size()));
+    DCORA_HIP(hipMemcpy(hub_ap.p, H.ap.data(), H.ap.size() * sizeof(int), hipMemcpyHostToDevice));
+    DCORA_HIP(hub_apos.alloc(std::max<size_t>(H.apos.size(), 1)));
+    DCORA_HIP(hub_aval.alloc(std::max<size_t>(H.aval.size(), 1)));
+    if (!H.apos.empty()) {
+      DCORA_HIP(hipMemcpy(hub_apos.p, H.apos.data(), H.apos.size() * sizeof(int), hipMemcpyHostToDevice));
+      DCORA_HIP(hipMemcpy(hub_aval.p, H.aval.data(), H.aval.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    DCORA_HIP(hub_U.alloc(H.U.size()));
+    DCORA_HIP(hipMemcpy(hub_U.p, H.U.data(), H.U.size() * sizeof(double), hipMemcpyHostToDevice));
+    DCORA_HIP(hub_Sinv.alloc(H.Sinv.size()));
+    DCORA_HIP(hipMemcpy(hub_Sinv.p, H.Sinv.data(), H.Sinv.size() * sizeof(double), hipMemcpyHostToDevice));
+    DCORA_HIP(hub_w.alloc((size_t)nhub * rcap));
+    DCORA_HIP(hipMemset(hub_w.p, 0, (size_t)nhub * rcap * sizeof(double)));
+  }
   return DCORA_OK;
 }
 
@@ -199,13 +272,19 @@ void SparsePrecond::apply(hipStream_t st, int r, Buf2 R, double *Z, Gate g) cons
   const int grid = (int)std::min<long>((n + kBlock - 1) / kBlock, 2048);
   hipLaunchKernelGGL(k_sp_permute_in, dim3(grid), dim3(kBlock), 0, st, r, k, perm.p, R, y.p, g);
   for (const SpLevel &lv : levels) launch_level(st, r, lv, tasks.p, segs.p, vals.p, idxs.p, y.p, g);
-  hipLaunchKernelGGL(k_sp_permute_out, dim3(grid), dim3(kBlock), 0, st, r, k, perm.p, out_off.p, y.p, Z, g);
+  if (nhub > 0) {
+    HubDev H{nhub, hub_idx.p, hub_ap.p, hub_apos.p, hub_aval.p, hub_U.p, hub_Sinv.p, hub_w.p};
+    hipLaunchKernelGGL(k_sp_hub_dot, dim3(nhub), dim3(kBlock), 0, st, r, H, R, y.p, g);
+    hipLaunchKernelGGL(k_sp_permute_out_hub, dim3(grid), dim3(kBlock), 0, st, r, k, perm.p, out_off.p, y.p, Z, H, g);
+  } else {
+    hipLaunchKernelGGL(k_sp_permute_out, dim3(grid), dim3(kBlock), 0, st, r, k, perm.p, out_off.p, y.p, Z, g);
+  }
 }
 
 double SparsePrecond::bytes_per_apply(int r) const {
-  // stored weights once, the task / segment tables, the vector in and out of every row tile, permutes
+  // stored weights once, the task / segment tables, the vector in and out of every row tile, permutes, hub terms
   return 8.0 * weights_per_apply + 32.0 * ntasks_total + 24.0 * nsegs_total + 16.0 * r * rows_total +
-         32.0 * r * (double)k;
+         32.0 * r * (double)k + 12.0 * hub_nnz + 8.0 * (double)nhub * k;
 }
 
 }  // namespace dcora

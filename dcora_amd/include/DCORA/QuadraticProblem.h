@@ -65,11 +65,10 @@ class QuadraticProblem {
   // ref src/QuadraticProblem.cpp:138-234; *X is written only on success
   bool escapeSaddle(const Matrix &Xopt, double theta, const Vector &v, double gradient_tolerance,
                     double preconditioned_gradient_tolerance, Matrix *X, bool isSecondOrder = false) {
-    (void)isSecondOrder;
     Matrix out(r_, problem_dimension());
     int ok = 0;
     check_status(dcora_problem_escape_saddle(h_, Xopt.data(), theta, v.data(), gradient_tolerance,
-                                             preconditioned_gradient_tolerance, out.data(), &ok),
+                                             preconditioned_gradient_tolerance, isSecondOrder ? 1 : 0, out.data(), &ok),
                  "escapeSaddle");
     if (ok) *X = out;
     return ok != 0;

@@ -101,10 +101,11 @@ int dcora_problem_precondition(dcora_problem_t p, const double *X, const double 
 int dcora_problem_retract(dcora_problem_t p, const double *X, const double *V, double *out);
 /* projectToTangentSpace (ref :299-307; src/manifold/LiftedManifold.cpp:37-41, 104-108) */
 int dcora_problem_tangent_project(dcora_problem_t p, const double *X, const double *V, double *out);
-/* escapeSaddle (ref :138-234): p is the problem at rank r, Xopt is (r-1) x k */
+/* escapeSaddle (ref :138-234): p is the problem at rank r, Xopt is (r-1) x k.  is_second_order selects the first
+ * trial step: 0 => 1 (the header's default), 1 => max(16e-6, 100 gradient_tolerance / |theta|) (ref :165-169) */
 int dcora_problem_escape_saddle(dcora_problem_t p, const double *Xopt, double theta, const double *v,
-                                double gradient_tolerance, double preconditioned_gradient_tolerance, double *Xout,
-                                int *success);
+                                double gradient_tolerance, double preconditioned_gradient_tolerance,
+                                int is_second_order, double *Xout, int *success);
 /* LiftedSEManifold::project / LiftedRAManifold::project, projectToSEMatrix / projectToRAMatrix
  * (ref src/manifold/LiftedManifold.cpp:28-35, 91-102; src/DCORA_utils.cpp:2201-2220) */
 int dcora_manifold_project(const dcora_dims *dims, const double *M, double *out, int device);
@@ -166,6 +167,11 @@ int dcora_radataset_info(dcora_radataset_t ds, int *info);
 /* ground truth of the VERTEX records in RA ordering, d x k column-major (unit spheres = normalised state1 - state2) */
 int dcora_radataset_ground_truth(dcora_radataset_t ds, double *gt);
 int dcora_radataset_build_Q(dcora_radataset_t ds, dcora_csr_t *Q);
+/* start point of the centralised CORA driver (ref examples/SingleRobotExample_RASLAM.cpp:92-150 with
+ * odometryInitialization, ref src/DCORA_solver.cpp:270-302): odometry chains anchored at their ground-truth first
+ * pose, ground-truth unit spheres, landmarks uniform in (-1, 1) from a splitmix64 stream seeded with `seed`
+ * (the reference draws them with Matrix::Random).  X0 is d x k in the RA ordering. */
+int dcora_radataset_odometry_init(dcora_radataset_t ds, unsigned long long seed, double *X0);
 int dcora_radataset_destroy(dcora_radataset_t ds);
 /* Graph::computePreconditionerRegularization (ref src/Graph.cpp:1921-1960): reg = lambda_max(Q) / (1e6 - 1), lambda_max
  * by Lanczos (nev 1, ncv 6, tol 1e-3) on the device; falls back to 0.1 when the eigensolver does not converge */

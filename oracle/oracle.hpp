@@ -220,7 +220,7 @@ bool fast_verification(const CSR &S, double eta, int block, double *theta,
 // ref: src/QuadraticProblem.cpp:138-234
 bool escape_saddle(const Problem &Pnext, const Mat &Xopt, double theta,
                    const std::vector<double> &v, double grad_tol,
-                   double pgrad_tol, Mat &Xout);
+                   double pgrad_tol, Mat &Xout, bool isSecondOrder = false);
 
 // ---- agent + RBCD driver (ref: src/Agent.cpp:535-596, 1158-1278;
 // examples/MultiRobotExample.cpp:121-364) -------------------------------------
@@ -272,6 +272,9 @@ struct RBCDTrace {
   Mat Xfinal;
 };
 RBCDTrace run_rbcd(const Dataset &ds, const RBCDOptions &o, const Mat &X0);
+
+// start point of the centralised CORA driver (ref: examples/SingleRobotExample_RASLAM.cpp:92-150); d x k
+Mat ra_odometry_initialization(const RADataset &ds, uint64_t seed);
 
 // deterministic RNG shared with the product (splitmix64)
 inline uint64_t splitmix64(uint64_t &s) {

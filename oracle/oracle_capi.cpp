@@ -274,12 +274,12 @@ int orc_fast_verification(int kdim, const int *rp, const int *ci, const double *
   return ok ? 1 : 0;
 }
 int orc_escape_saddle(void *hnext, const double *Xopt, double theta, const double *v, double gtol, double pgtol,
-                      double *Xout) {
+                      int second_order, double *Xout) {
   ProblemBox *B = (ProblemBox *)hnext;
   const int k = B->D.k();
   Mat Xo;
   const bool ok = escape_saddle(B->P, view_mat(B->D.r - 1, k, Xopt), theta, std::vector<double>(v, v + k), gtol,
-                                pgtol, Xo);
+                                pgtol, Xo, second_order != 0);
   if (ok) std::copy(Xo.a.begin(), Xo.a.end(), Xout);
   return ok ? 1 : 0;
 }
@@ -353,6 +353,11 @@ void orc_ra_copy(void *h, int *pp_ids, double *pp_vals, int *pl_ids, double *pl_
   std::copy(ds->gt.a.begin(), ds->gt.a.end(), gt);
 }
 void *orc_build_Q_ra(void *h) { return new CSR(build_Q_ra(*(RADataset *)h)); }
+// out: d x k, RA ordering
+void orc_ra_odometry_init(void *h, unsigned long long seed, double *out) {
+  const Mat X = ra_odometry_initialization(*(RADataset *)h, seed);
+  std::copy(X.a.begin(), X.a.end(), out);
+}
 void orc_ra_free(void *h) { delete (RADataset *)h; }
 
 // ---- RBCD driver ---------------------------------------------------------------

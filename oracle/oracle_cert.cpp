@@ -290,7 +290,7 @@ bool fast_verification(const CSR &S, double eta, int block, double *theta, std::
 
 // ref: src/QuadraticProblem.cpp:138-234
 bool escape_saddle(const Problem &Pn, const Mat &Xopt, double theta, const std::vector<double> &v,
-                   double grad_tol, double pgrad_tol, Mat &Xout) {
+                   double grad_tol, double pgrad_tol, Mat &Xout, bool isSecondOrder) {
   const int r = Pn.D.r, k = Pn.D.k();
   Mat Xp(r, k), Xd(r, k);
   for (int j = 0; j < k; ++j) {
@@ -298,7 +298,6 @@ bool escape_saddle(const Problem &Pn, const Mat &Xopt, double theta, const std::
     Xd(r - 1, j) = v[j];
   }
   const double alpha_min = 1e-6;
-  const bool isSecondOrder = false;  // default argument of the reference header
   double alpha = isSecondOrder ? std::max(16 * alpha_min, 100 * grad_tol / std::fabs(theta)) : 1.0;
   std::vector<double> alphas, fvals;
   const double FX = Pn.f(Xp);

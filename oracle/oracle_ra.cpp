@@ -291,3 +291,48 @@ CSR build_Q_ra(const RADataset &ds) {
 }
 
 }  // namespace orc
+
+namespace orc {
+// Odometry initialisation of the centralised CORA driver (ref: examples/SingleRobotExample_RASLAM.cpp:92-150 with
+// odometryInitialization, src/DCORA_solver.cpp:270-302): every chain of consecutive-index pose-pose edges starts at
+// its ground-truth first pose and is propagated T_dst = T_src * T_meas; unit spheres = ground truth; landmarks =
+// uniform(-1, 1) (Matrix::Random in the reference; here a seeded splitmix64 stream so the start point is
+// reproducible).  Returns d x k in the RA ordering.  The pyfg reader merges the robots into one index range, so a
+// chain starts wherever pose i has no edge (i-1 -> i).
+Mat ra_odometry_initialization(const RADataset &ds, uint64_t seed) {
+  const int d = ds.d, n = ds.n, l = ds.l, b = ds.b;
+  Mat X(d, (d + 1) * n + l + b);
+  std::vector<int> into((size_t)n, -1);
+  for (int e = 0; e < (int)ds.pose_pose.size(); ++e) {
+    const Meas &m = ds.pose_pose[e];
+    if (m.p1 + 1 == m.p2 && into[m.p2] < 0) into[m.p2] = e;
+  }
+  const int ot = d * n + l;
+  for (int i = 0; i < n; ++i) {
+    if (into[i] < 0) {
+      for (int c = 0; c < d; ++c)
+        for (int a = 0; a < d; ++a) X(a, d * i + c) = ds.gt(a, d * i + c);
+      for (int a = 0; a < d; ++a) X(a, ot + i) = ds.gt(a, ot + i);
+      continue;
+    }
+    const Meas &m = ds.pose_pose[into[i]];
+    for (int c = 0; c < d; ++c)
+      for (int a = 0; a < d; ++a) {
+        double s = 0;
+        for (int q = 0; q < d; ++q) s += X(a, d * (i - 1) + q) * m.R[q + c * d];
+        X(a, d * i + c) = s;
+      }
+    for (int a = 0; a < d; ++a) {
+      double s = X(a, ot + i - 1);
+      for (int q = 0; q < d; ++q) s += X(a, d * (i - 1) + q) * m.t[q];
+      X(a, ot + i) = s;
+    }
+  }
+  for (int j = 0; j < l; ++j)
+    for (int a = 0; a < d; ++a) X(a, d * n + j) = ds.gt(a, d * n + j);
+  uint64_t s = seed;
+  for (int j = 0; j < b; ++j)
+    for (int a = 0; a < d; ++a) X(a, ot + n + j) = 2.0 * u01(s) - 1.0;
+  return X;
+}
+}  // namespace orc

@@ -77,7 +77,7 @@ def lib():
         L.orc_fast_verification.argtypes = [C.c_int, _ip, _ip, _dp, C.c_double, C.c_int,
                                             C.POINTER(C.c_double), _dp, C.POINTER(C.c_double)]
         L.orc_escape_saddle.restype = C.c_int
-        L.orc_escape_saddle.argtypes = [C.c_void_p, _dp, C.c_double, _dp, C.c_double, C.c_double, _dp]
+        L.orc_escape_saddle.argtypes = [C.c_void_p, _dp, C.c_double, _dp, C.c_double, C.c_double, C.c_int, _dp]
         L.orc_align_lifted_trajectory.argtypes = [C.c_int, C.c_int, C.c_int, _dp, _dp, C.c_int, _dp]
         L.orc_project_solution_raslam.argtypes = [C.c_int] * 5 + [_dp, _dp]
         L.orc_ra_states_in_local_frame.argtypes = [C.c_int] * 5 + [_dp, _dp, _dp, _dp]
@@ -87,6 +87,7 @@ def lib():
         L.orc_pyfg_load.argtypes = [C.c_char_p]
         L.orc_ra_info.argtypes = [C.c_void_p, _ip]
         L.orc_ra_copy.argtypes = [C.c_void_p, _ip, _dp, _ip, _dp, _ip, _dp, _dp]
+        L.orc_ra_odometry_init.argtypes = [C.c_void_p, C.c_ulonglong, _dp]
         L.orc_build_Q_ra.restype = C.c_void_p
         L.orc_build_Q_ra.argtypes = [C.c_void_p]
         L.orc_ra_free.argtypes = [C.c_void_p]
@@ -247,10 +248,10 @@ class Problem:
                 "outer_iters", "inner_iters", "accepted"]
         return unF(out, self.r, self.k), dict(zip(keys, res.tolist()))
 
-    def escape_saddle(self, Xopt, theta, v, gtol=1e-6, pgtol=1e-6):
+    def escape_saddle(self, Xopt, theta, v, gtol=1e-6, pgtol=1e-6, second_order=False):
         out = np.zeros(self.r * self.k)
         ok = lib().orc_escape_saddle(self.h, F(Xopt), float(theta), np.ascontiguousarray(v, np.float64), gtol,
-                                     pgtol, out)
+                                     pgtol, int(second_order), out)
         return (unF(out, self.r, self.k) if ok else None)
 
 
@@ -341,7 +342,7 @@ def run_rbcd(ds, X0, num_robots=5, r_min=5, r_max=100, max_iters=1000, min_eig_t
 class RADataset:
     """centralised range-aided SLAM dataset (global indices, RA ordering of the ground truth)"""
 
-    def __init__(self, path):
+    def __init__(self, path, init_seed=20250310):
         L = lib()
         h = L.orc_pyfg_load(str(path).encode())
         if not h:
@@ -364,6 +365,9 @@ class RADataset:
         self.r_ids, self.r_vals = self.r_ids[:mr], self.r_vals[:mr]
         self.gt = unF(gt, d, self.k)
         self.Q = _take_csr(L.orc_build_Q_ra(h))
+        x0 = np.zeros(d * self.k)
+        L.orc_ra_odometry_init(h, init_seed, x0)
+        self.X_odom = unF(x0, d, self.k)  # ref examples/SingleRobotExample_RASLAM.cpp:92-150
         L.orc_ra_free(h)
 
 

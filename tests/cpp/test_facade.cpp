@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdio>
 
+#include "DCORA/DCORA_utils.h"
 #include "DCORA/QuadraticOptimizer.h"
 
 int main() {
@@ -61,5 +62,25 @@ int main() {
   const DCORA::ROPTResult res = optimizer.getOptResult();
   std::printf("testPrior facade: err0 %.3e err1 %.3e f %.6f -> %.6f |g| %.2e\n", std::sqrt(e0), std::sqrt(e1), res.fInit,
               res.fOpt, res.gradNormOpt);
-  return (std::sqrt(e0) < 1e-6 && std::sqrt(e1) < 1e-6) ? 0 : 1;
+  bool ok = std::sqrt(e0) < 1e-6 && std::sqrt(e1) < 1e-6;
+  // rounding through the facade (ref src/DCORA_utils.cpp:2262-2289): in the frame of pose 0 both poses are the
+  // identity rotation (the edge says R = I) and the relative translation is zero
+  DCORA::Matrix anchor(r, 4);
+  for (int c = 0; c < 4; ++c)
+    for (int i = 0; i < r; ++i) anchor(i, c) = Topt(i, c);
+  const DCORA::Matrix Tr = DCORA::alignLiftedTrajectoryToFrame(Topt, anchor, d, n, true);
+  double e2 = 0;
+  for (int p = 0; p < n; ++p)
+    for (int c = 0; c < 4; ++c)
+      for (int i = 0; i < 3; ++i) e2 += std::pow(Tr(i, 4 * p + c) - ((c < 3 && i == c) ? 1.0 : 0.0), 2);
+  // certificate of the (noiseless) two-pose problem without the prior: S = Q - Lambda is PSD at the optimum
+  DCORA::Matrix Tid(r, 4 * n);
+  for (int i = 0; i < 3; ++i) Tid(i, i) = Tid(i, 4 + i) = 1.0;
+  const DCORA::SparseMatrix S = DCORA::constructDualCertificateMatrixPGO(Tid, pd.Q, d, n);
+  double theta = 0;
+  DCORA::Vector v;
+  const bool psd = DCORA::fastVerification(S, 1e-3, &theta, &v, d + 1);
+  std::printf("rounding err %.3e, certificate PSD %d\n", std::sqrt(e2), (int)psd);
+  ok = ok && std::sqrt(e2) < 1e-6 && psd;
+  return ok ? 0 : 1;
 }

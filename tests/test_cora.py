@@ -1,0 +1,76 @@
+"""Centralised CORA flow (ref examples/SingleRobotExample_RASLAM.cpp:48-283) on single_drone.pyfg: odometry start,
+RTR 200 x 200 at rank d, certificate, escapeSaddle with the second-order step, rank d + 1, ..., certified; then
+projectSolutionRASLAM and the refinement at rank d.  The GPU flow and the CPU oracle flow must visit the same
+ranks and agree on every converged quantity (cost per level, verdict of the certificate, rounded cost)."""
+import gzip
+import os
+import shutil
+import tempfile
+
+import numpy as np
+import pytest
+
+import common
+import cora_flow
+
+
+def _plain(name):
+    fd, tmp = tempfile.mkstemp(suffix=".pyfg")
+    with os.fdopen(fd, "wb") as out, gzip.open(os.path.join(common.DATA, name + ".pyfg.gz"), "rb") as src:
+        shutil.copyfileobj(src, out)
+    return tmp
+
+
+def test_odometry_start_point_is_shared_and_anchored_at_ground_truth(built):
+    import dcora_amd as da
+    from oracle import orc
+    for name in ["range_aided_slam_test_2d", "range_aided_slam_test_3d", "single_drone"]:
+        ra = da.RADataset(os.path.join(common.DATA, name + ".pyfg.gz"))
+        ro = orc.RADataset(_plain(name))
+        d, n, l = ra.d, ra.n, ra.l
+        assert np.array_equal(ra.X_odom, ro.X_odom)
+        # first pose and the unit spheres come from the ground truth (ref SingleRobotExample_RASLAM.cpp:117-138)
+        assert np.array_equal(ra.X_odom[:, :d], ra.gt[:, :d])
+        assert np.array_equal(ra.X_odom[:, d * n:d * n + l], ra.gt[:, d * n:d * n + l])
+        assert np.all(np.abs(ra.X_odom[:, d * n + l + n:]) <= 1.0)
+        if name.startswith("range_aided"):
+            # noiseless fixtures: odometry reproduces the ground-truth trajectory
+            # (to the precision the file prints its measurements with)
+            assert np.allclose(ra.X_odom[:, :d * n], ra.gt[:, :d * n], atol=1e-7)
+            assert np.allclose(ra.X_odom[:, d * n + l:d * n + l + n], ra.gt[:, d * n + l:d * n + l + n], atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_cora_flow_on_single_drone_matches_oracle(built):
+    import dcora_amd as da
+    from oracle import orc
+    ra = da.RADataset(os.path.join(common.DATA, "single_drone.pyfg.gz"))
+    ro = orc.RADataset(_plain("single_drone"))
+    hip = cora_flow.ProductBackend(ra)
+    P = hip.problem(ra.d)
+    assert P.precond_info()["kind"] == "sparse"  # k = 8771: the partitioned sparse inverse carries this flow
+    P.close()
+    out = cora_flow.cora(hip, ra.X_odom, ra.d)
+    ref = cora_flow.cora(cora_flow.OracleBackend(ro, hip.reg), ro.X_odom, ro.d)
+    assert out["certified"] and ref["certified"]
+    assert [lv["r"] for lv in out["levels"]] == [lv["r"] for lv in ref["levels"]]
+    for a, b in zip(out["levels"], ref["levels"]):
+        assert a["psd"] == b["psd"]
+        assert abs(a["f"] - b["f"]) <= 1e-6 * abs(b["f"])
+        assert a["gradnorm"] < 1e-4
+        if not a["psd"]:
+            # the escape curvature is NOT a converged quantity: Spectra's test stops the Lanczos run at a residual
+            # of tol * |largest shifted eigenvalue|, orders of magnitude above |theta| here, so two correct runs
+            # return different negative Ritz values.  The driver's own sanity check is what both must satisfy
+            # (ref examples/SingleRobotExample_RASLAM.cpp:207-209).
+            assert a["theta"] < -cora_flow.MIN_EIG_TOL / 2 and b["theta"] < -cora_flow.MIN_EIG_TOL / 2
+    assert abs(out["f_rounded"] - ref["f_rounded"]) <= 1e-6 * abs(ref["f_rounded"])
+    # the certified value is a lower bound of every feasible rank-d point
+    assert out["levels"][-1]["f"] <= out["f_rounded"] + 1e-9
+    d, n, l = ra.d, ra.n, ra.l
+    Xr = out["X_rounded"]
+    for i in range(0, n, 97):
+        R = Xr[:, d * i:d * i + d]
+        assert np.allclose(R.T @ R, np.eye(d), atol=1e-9)
+    print("single_drone CORA: hip %.0f ms, cpu %.0f ms, levels %s" %
+          (out["ms_total"], ref["ms_total"], [(lv["r"], round(lv["f"], 6), lv["inner"]) for lv in out["levels"]]))
