@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--rank-r", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config5", action="store_true", help="skip the 100k-pose side measurement")
+    ap.add_argument("--no-config4", action="store_true", help="skip the tiers.pyfg side measurement")
     ap.add_argument("--cpu-steps", type=int, default=0, help="oracle iterations for cpu_baseline (0 = auto)")
     return ap.parse_args()
 
@@ -328,6 +329,64 @@ def config5_run(da, with_cpu, iters=60, cpu_iters=4):
     return res
 
 
+def config4_run(da, with_cpu):
+    """BASELINE.json config 4 as a side measurement (never `value`): tiers.pyfg (d = 2, 9768 poses, 7789 ranges, one
+    landmark: k = 37 094), the first level of the centralised CORA flow -- RTR with the driver's parameters
+    (200 x 200 tCG, tol 1e-4, ref examples/SingleRobotExample_RASLAM.cpp:59-79) at rank d from the odometry start.
+    The range-aided layout runs the unfused solver path with the partitioned sparse preconditioner (the landmark
+    is a hub: Schur complement).  Both sides keep the reference's 5 s TimeBound of one RTR run
+    (ref src/QuadraticOptimizer.cpp:252): the CPU oracle stops on it, the GPU finishes its 200 outer iterations."""
+    import common
+    import cora_flow
+    path = os.path.join(common.DATA, "tiers.pyfg.gz")
+    ra = da.RADataset(path)
+    hip = cora_flow.ProductBackend(ra)
+    t0 = time.perf_counter()
+    P = hip.problem(ra.d)
+    setup_s = time.perf_counter() - t0
+    info = P.precond_info()
+    t0 = time.perf_counter()
+    X, f, gn, outer, inner = hip.optimize(P, ra.X_odom)
+    dt = time.perf_counter() - t0
+    P.close()
+    res = {"workload": "tiers.pyfg, centralised CORA level r = d = 2: RTR 200 x 200, tol 1e-4, odometry start",
+           "k": ra.k, "nnz_Q": ra.Q.nnz, "f": f, "gradnorm": gn, "outer_iterations": outer, "tcg_iterations": inner,
+           "seconds": dt, "tcg_iterations_per_s": inner / dt, "problem_setup_s": setup_s,
+           "preconditioner": {"kind": info["kind"], "launches": info["launches"], "nnz_L": info["nnzL"]}}
+    if with_cpu:
+        import gzip
+        import shutil
+        import tempfile
+        from oracle import orc
+        fd, tmp = tempfile.mkstemp(suffix=".pyfg")
+        with os.fdopen(fd, "wb") as out, gzip.open(path, "rb") as src:
+            shutil.copyfileobj(src, out)
+        ro = orc.RADataset(tmp)
+        os.unlink(tmp)
+        cpu = cora_flow.OracleBackend(ro, hip.reg)
+        Po = cpu.problem(ro.d)
+        t0 = time.perf_counter()
+        Xo, fo, gno, oo, io = cpu.optimize(Po, ro.X_odom)
+        dtc = time.perf_counter() - t0
+        res["cpu_port"] = {"f": fo, "gradnorm": gno, "outer_iterations": oo, "tcg_iterations": io, "seconds": dtc,
+                           "tcg_iterations_per_s": io / dtc, "cores": 1,
+                           "note": "stopped by the reference's 5 s TimeBound of one RTR run"}
+        # like for like: the GPU run cut at the number of outer iterations the CPU completed
+        P = hip.problem(ra.d)
+        opt = da.QuadraticOptimizer(P, da.ROptParameters(RTR_iterations=int(oo), RTR_tCG_iterations=200,
+                                                         gradnorm_tol=1e-4))
+        t0 = time.perf_counter()
+        opt.optimize(ra.X_odom)
+        dts = time.perf_counter() - t0
+        rs = opt.getOptResult()
+        P.close()
+        res["same_outer_iterations_as_cpu"] = {"f": rs["fOpt"], "gradnorm": rs["gradNormOpt"],
+                                               "outer_iterations": rs["outer_iterations"],
+                                               "tcg_iterations": rs["inner_iterations"], "seconds": dts,
+                                               "speedup_vs_cpu_port": dtc / dts}
+    return res
+
+
 def cpu_baseline(args, ds_name, X0, gpu_ms_per_step):
     """the CPU oracle on a bounded sample (first iterations of the same trajectory), 1 thread"""
     import common
@@ -409,6 +468,11 @@ def main():
                 line["config5_lattice100k"] = config5_run(da, not args.no_cpu_baseline)
             except Exception as e:
                 line["config5_lattice100k"] = {"error": str(e)}
+        if not args.no_config4:
+            try:
+                line["config4_tiers"] = config4_run(da, not args.no_cpu_baseline)
+            except Exception as e:
+                line["config4_tiers"] = {"error": str(e)}
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args, args.dataset, X0, ms)
         line["config"]["speedup_vs_cpu_port"] = line["value"] / line["cpu_baseline"]["value"]

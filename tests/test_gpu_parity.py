@@ -213,3 +213,19 @@ def test_chordal_start_to_certified_optimum_of_sphere2500(env):
     assert abs(2 * Po.f(X) - out["cost"][-1]) < 1e-6
     So = orc.dual_certificate(r, ds.d, ds.n, X, Qo)
     assert orc.fast_verification(So, 1e-3, block=ds.d + 1)[0]
+
+
+def test_rbcd_torus3D_eight_agents_matches_oracle(env):
+    """BASELINE configs[2]: torus3D split over 8 agents (625 poses each, ring of neighbours)"""
+    da, orc = env
+    ds, dso = common.product_dataset("torus3D"), common.oracle_dataset("torus3D")
+    r, R, iters = 5, 8, 24
+    X0 = common.random_point(r, ds.d, ds.n, 2, orc.project_to_manifold)
+    tr = orc.run_rbcd(dso, X0, num_robots=R, r_min=r, max_iters=iters, staircase=0, rgrad_tol=1e-12)
+    s = da.RbcdSession(ds, num_robots=R, r=r)
+    s.set_X(X0)
+    out = s.run(max_iters=iters, rgrad_tol=1e-12)
+    assert np.array_equal(out["selected"], tr["selected"])
+    assert np.allclose(out["cost"], tr["cost"], rtol=1e-8)
+    assert np.allclose(out["gradnorm"], tr["gradnorm"], rtol=1e-6)
+    assert common.rel(s.get_X(), tr["X"]) < 1e-6
