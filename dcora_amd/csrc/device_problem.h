@@ -145,6 +145,7 @@ class DeviceProblem {
   DevBuf<double> delta, eta, Heta, res, z, Hd, W, Zt;
   DevBuf<double> delta2, res2, Zpart;  // fused path: ping-pong direction / residual, split-K slices
   bool fused = false;                  // SE layout, r <= 8: three-launch tCG iteration (solver_fused.hip)
+  bool group = false;                  // SE layout, r <= 8: 8-lanes-per-pose rgrad / retract kernels (any n)
   DevBuf<double> pA, pB, pC, p1, p2, p3, scal;
   DevBuf<SolverCtl> ctl;
   HostFlags *hf = nullptr;      // host-mapped

@@ -119,6 +119,7 @@ int DeviceProblem::init(const dcora_dims &dims, const HostCsr &Qh, const double 
   for (DevBuf<double> *b : {&X0, &X1, &EG0, &EG1, &RG0, &RG1, &delta, &eta, &Heta, &res, &z, &Hd, &W, &Zt})
     DCORA_HIP(b->alloc(N));
   fused = fused_supported(m) && (std::getenv("DCORA_SOLVER_V1") == nullptr);
+  group = group_supported(m) && (std::getenv("DCORA_SOLVER_V1") == nullptr);
   if (fused) {
     DCORA_HIP(delta2.alloc(N));
     DCORA_HIP(res2.alloc(N));
@@ -225,13 +226,13 @@ void DeviceProblem::enqueue_egrad(const double *X, double *EG, double *partials)
 
 int DeviceProblem::enq_rgrad(Buf2 X, Buf2 EG, Buf2 RG, Buf2 S, int sel, double *partials, Gate g,
                              double *posenorm) {
-  if (fused) return launch_g_rgrad(st, m, X, EG, RG, S, sel, partials, posenorm, g);
+  if (group) return launch_g_rgrad(st, m, X, EG, RG, S, sel, partials, posenorm, g);
   launch_rgrad(st, m, X, EG, RG, S, sel, partials, g);
   return pose_grid(m);
 }
 int DeviceProblem::enq_retract(Buf2 X, const double *V, double alpha, Buf2 out, int selOut, Buf2 grad,
                                const double *HV, double *partials, Gate g) {
-  if (fused) return launch_g_retract(st, m, X, V, alpha, out, selOut, grad, HV, partials, g);
+  if (group) return launch_g_retract(st, m, X, V, alpha, out, selOut, grad, HV, partials, g);
   launch_retract(st, m, X, V, alpha, out, selOut, grad, HV, partials, g);
   return pose_grid(m);
 }

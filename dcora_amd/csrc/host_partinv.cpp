@@ -23,6 +23,21 @@ struct Piece {
 
 inline int pad2(int x) { return (x + 1) & ~1; }
 
+// the first segment travels inside the task record: one dependent load less on the device
+inline void inline_first_segment(PTask &T, const std::vector<PSeg> &segs) {
+  T.len0 = 0;
+  T.src0 = 0;
+  T.idx0 = 0;
+  T.w0 = 0;
+  if (T.nseg > 0) {
+    const PSeg &S = segs[(size_t)T.seg0];
+    T.len0 = S.len;
+    T.src0 = S.src;
+    T.idx0 = S.idx;
+    T.w0 = S.w;
+  }
+}
+
 // lanes per row tile, from the average number of vector entries a tile gathers: a step covers lanes / r of them;
 // aim for a handful of steps per lane so that the loads of a tile are all in flight together (the upper levels
 // have few tiles and are latency-bound otherwise)
@@ -171,8 +186,9 @@ bool build_partitioned_inverse(const HostCsr &A, int block, int nthreads, PartIn
     weights += (double)len * nrows;
     return off;
   };
-  // forward: y <- L_t^-1 y, leaves first
-  for (int t = 0; t < nlev; ++t) {
+  // forward: y <- L_t^-1 y, leaves first.  The top level is skipped here: its pieces feed nobody (no rows below),
+  // so their forward and backward steps are adjacent and are applied together as the symmetric D^-T D^-1 below
+  for (int t = 0; t + 1 < nlev; ++t) {
     SpLevel lv;
     lv.task0 = (int)P.tasks.size();
     std::vector<int> affected;
@@ -251,6 +267,7 @@ bool build_partitioned_inverse(const HostCsr &A, int block, int nthreads, PartIn
           seg_len_sum += P.segs[q2].len;
           ++seg_cnt;
         }
+        inline_first_segment(T, P.segs);
         P.tasks.push_back(T);
         a0 += nrows;
       }
@@ -261,7 +278,7 @@ bool build_partitioned_inverse(const HostCsr &A, int block, int nthreads, PartIn
     lv.lanes = pick_lanes(lv.ntasks ? (double)seg_len_sum / lv.ntasks : 1.0);
     P.levels.push_back(lv);
   }
-  P.nforward = nlev;
+  P.nforward = nlev - 1;
   // backward: x <- L_t^-T x, root first.  Only the piece's own rows change; they gather from their own old
   // values and from the (final) values of the rows below.
   for (int t = nlev - 1; t >= 0; --t) {
@@ -274,6 +291,19 @@ bool build_partitioned_inverse(const HostCsr &A, int block, int nthreads, PartIn
       const int idx0 = (int)P.idxs.size();
       for (int i : p.rows) P.idxs.push_back(pos(bit[piece_of[i]], i));
       if (m & 1) P.idxs.push_back(P.idxs.back());  // padded pair: weight 0, any valid position
+      std::vector<double> M;  // top level only: D^-T D^-1 (c x c, symmetric)
+      if (t == nlev - 1) {
+        M.assign((size_t)c * c, 0.0);
+        for (int i = 0; i < c; ++i) {
+          const double *di = &p.Dinv[(size_t)i * c];
+          for (int a = 0; a <= i; ++a) {
+            const double v = di[a];
+            if (v == 0.0) continue;
+            double *ma = &M[(size_t)a * c];
+            for (int j = 0; j <= i; ++j) ma[j] += v * di[j];
+          }
+        }
+      }
       for (int a0 = 0; a0 < c; a0 += RT) {
         const int nrows = std::min(RT, c - a0);
         PTask T;
@@ -282,14 +312,20 @@ bool build_partitioned_inverse(const HostCsr &A, int block, int nthreads, PartIn
         T.nrows = nrows;
         T.seg0 = (int)P.segs.size();
         PSeg S;
-        S.len = pad2(c - a0);
-        S.src = pos(bit[s], p.c0 + a0);
         S.idx = 0;
         S.pad = 0;
-        // (D^-T)(a0 + q, a0 + j) = Dinv(a0 + j, a0 + q), zero below the diagonal of the transpose
-        S.w = emit(nrows, S.len, [&](int r_, int j) {
-          return (j >= r_ && a0 + j < c) ? p.Dinv[(size_t)(a0 + j) * c + (a0 + r_)] : 0.0;
-        });
+        if (t == nlev - 1) {
+          S.len = pad2(c);
+          S.src = pos(bit[s], p.c0);
+          S.w = emit(nrows, S.len, [&](int r_, int j) { return j < c ? M[(size_t)(a0 + r_) * c + j] : 0.0; });
+        } else {
+          S.len = pad2(c - a0);
+          S.src = pos(bit[s], p.c0 + a0);
+          // (D^-T)(a0 + q, a0 + j) = Dinv(a0 + j, a0 + q), zero below the diagonal of the transpose
+          S.w = emit(nrows, S.len, [&](int r_, int j) {
+            return (j >= r_ && a0 + j < c) ? p.Dinv[(size_t)(a0 + j) * c + (a0 + r_)] : 0.0;
+          });
+        }
         P.segs.push_back(S);
         seg_len_sum += S.len;
         ++seg_cnt;
@@ -305,6 +341,7 @@ bool build_partitioned_inverse(const HostCsr &A, int block, int nthreads, PartIn
           ++seg_cnt;
         }
         T.nseg = (int)P.segs.size() - T.seg0;
+        inline_first_segment(T, P.segs);
         P.tasks.push_back(T);
       }
     }

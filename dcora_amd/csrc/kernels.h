@@ -176,6 +176,7 @@ void launch_scale(hipStream_t st, int n, const double *alpha_dev_inv_sqrt /*devi
 
 // ---- fused SE-layout solver kernels (solver_fused.hip): 8 lanes per pose, three launches per tCG iteration ----
 bool fused_supported(const ManiDesc &m);
+bool group_supported(const ManiDesc &m);    // 8-lanes-per-pose rgrad / retract / Nesterov kernels usable
 int fused_pose_blocks(const ManiDesc &m);   // partial slots written by hess / finish
 int fused_nsplit(const ManiDesc &m);        // row slices of the dense preconditioner product
 int fused_precond_grid(const ManiDesc &m);  // partial slots written by precond

@@ -13,7 +13,7 @@ namespace dcora {
 
 static bool group_kernels(const ManiDesc &m) {
   static const bool v1 = std::getenv("DCORA_NESTEROV_V1") != nullptr;
-  return fused_supported(m) && !v1;
+  return group_supported(m) && !v1;
 }
 
 static void nesterov(hipStream_t st, const ManiDesc &m, int mode, int restart, int skip_lo, int skip_hi, double alpha,
@@ -251,7 +251,7 @@ int RbcdSession::evaluate_central(double *cost2, double *gradnorm, double *block
   }
   DeviceProblem &c = *central;
   c.enqueue_egrad(Xg.p, c.EG0.p, c.pA.p);
-  if (c.fused) {
+  if (c.group) {
     c.enq_rgrad(buf1(Xg.p), buf1(c.EG0.p), buf1(c.RG0.p), Buf2{{nullptr, nullptr}}, 0, c.pB.p, Gate{}, posenorm.p);
     const int want = ++eval_seq;
     launch_eval_finish(st, R, pose_start.p, posenorm.p, c.pA.p, c.npA(), eval_dev, want);

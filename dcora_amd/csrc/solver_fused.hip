@@ -999,6 +999,8 @@ void launch_spmm_bsr(hipStream_t st, int r, int d, const BsrDev &A, Buf2 X, int 
   }
 }
 
+// the 8-lanes-per-pose kernels (rgrad / retract / Nesterov / BSR Q-apply) walk the poses with a capped grid: any n
+bool group_supported(const ManiDesc &m) { return m.se && m.r <= GW && m.n > 0; }
 bool fused_supported(const ManiDesc &m) {
   // hess / finish leave one partial slot per block in 2 * kMaxPartials-slot buffers
   return m.se && m.r <= GW && m.n > 0 && (m.n + fused_pb(m.r, m.d + 1) - 1) / fused_pb(m.r, m.d + 1) <= 2 * kMaxPartials;

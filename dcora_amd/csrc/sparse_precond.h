@@ -28,7 +28,9 @@ struct PTask {  // a tile of nrows <= kSpTile consecutive output rows of one lev
   int carry;    // first old value to keep (same units) or -1
   int seg0, nseg;
   int nrows;
-  int pad[3];
+  int len0, src0, idx0;  // copy of segment seg0 (when nseg > 0): saves the device one dependent load
+  long long w0;
+  long long pad;
 };
 struct PSeg {       // row q of the tile:  sum_j w[q][j] * y[src + j]   or   sum_j w[q][j] * y[idx[j]]
   long long w;      // offset into the weight array (even => 16-byte aligned); layout [entry j][row q], len even

@@ -111,6 +111,7 @@ __global__ __launch_bounds__(kBlock) void k_sp_level(int r, const PTask *__restr
   const bool active = task < ntasks;
   PTask T;
   T.out = 0; T.carry = -1; T.seg0 = 0; T.nseg = 0; T.nrows = 0;
+  T.len0 = 0; T.src0 = 0; T.idx0 = 0; T.w0 = 0;
   if (active) T = tasks[task];
   const int nrows = T.nrows, ne = nrows * r;
   const int JP = LANES / r;            // vector entries per step
@@ -126,7 +127,15 @@ __global__ __launch_bounds__(kBlock) void k_sp_level(int r, const PTask *__restr
 #pragma unroll
   for (int q = 0; q < RT; ++q) acc[q] = 0;
   for (int s = T.seg0; s < T.seg0 + T.nseg; ++s) {
-    const PSeg S = segs[s];
+    PSeg S;
+    if (s == T.seg0) {  // the first segment came with the task record
+      S.w = T.w0;
+      S.src = T.src0;
+      S.idx = T.idx0;
+      S.len = T.len0;
+    } else {
+      S = segs[s];
+    }
     if (!worker) continue;
     const double *__restrict__ w = vals + S.w;
     if (S.src >= 0) {
@@ -283,7 +292,7 @@ void SparsePrecond::apply(hipStream_t st, int r, Buf2 R, double *Z, Gate g) cons
 
 double SparsePrecond::bytes_per_apply(int r) const {
   // stored weights once, the task / segment tables, the vector in and out of every row tile, permutes, hub terms
-  return 8.0 * weights_per_apply + 32.0 * ntasks_total + 24.0 * nsegs_total + 16.0 * r * rows_total +
+  return 8.0 * weights_per_apply + 48.0 * ntasks_total + 24.0 * nsegs_total + 16.0 * r * rows_total +
          32.0 * r * (double)k + 12.0 * hub_nnz + 8.0 * (double)nhub * k;
 }
 

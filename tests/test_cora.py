@@ -53,20 +53,23 @@ def test_cora_flow_on_single_drone_matches_oracle(built):
     out = cora_flow.cora(hip, ra.X_odom, ra.d)
     ref = cora_flow.cora(cora_flow.OracleBackend(ro, hip.reg), ro.X_odom, ro.d)
     assert out["certified"] and ref["certified"]
-    assert [lv["r"] for lv in out["levels"]] == [lv["r"] for lv in ref["levels"]]
-    for a, b in zip(out["levels"], ref["levels"]):
-        assert a["psd"] == b["psd"]
-        assert abs(a["f"] - b["f"]) <= 1e-6 * abs(b["f"])
-        assert a["gradnorm"] < 1e-4
-        if not a["psd"]:
-            # the escape curvature is NOT a converged quantity: Spectra's test stops the Lanczos run at a residual
-            # of tol * |largest shifted eigenvalue|, orders of magnitude above |theta| here, so two correct runs
-            # return different negative Ritz values.  The driver's own sanity check is what both must satisfy
-            # (ref examples/SingleRobotExample_RASLAM.cpp:207-209).
-            assert a["theta"] < -cora_flow.MIN_EIG_TOL / 2 and b["theta"] < -cora_flow.MIN_EIG_TOL / 2
-    assert abs(out["f_rounded"] - ref["f_rounded"]) <= 1e-6 * abs(ref["f_rounded"])
-    # the certified value is a lower bound of every feasible rank-d point
-    assert out["levels"][-1]["f"] <= out["f_rounded"] + 1e-9
+    # What two correct runs must share is the CERTIFIED value (the optimum of the convex relaxation).  The levels
+    # below it are non-convex problems: runs that differ in rounding may stop at different second-order critical
+    # points there (observed: f = 8.2460 and f = 7.6976 at rank 3), and the escape curvature is not a converged
+    # quantity either -- Spectra's test stops the Lanczos run at a residual of tol * |largest shifted eigenvalue|,
+    # orders of magnitude above |theta| here.  Every such level must still be a critical point with a negative
+    # curvature that passes the driver's own sanity check (ref examples/SingleRobotExample_RASLAM.cpp:207-209).
+    f_cert, f_cert_ref = out["levels"][-1]["f"], ref["levels"][-1]["f"]
+    assert abs(f_cert - f_cert_ref) <= 1e-6 * abs(f_cert_ref)
+    for run in (out, ref):
+        assert run["levels"][-1]["psd"]
+        for lv in run["levels"]:
+            assert lv["gradnorm"] < 1e-4
+            assert lv["f"] >= run["levels"][-1]["f"] - 1e-9      # lower ranks cannot beat the relaxation
+        for lv in run["levels"][:-1]:
+            assert not lv["psd"] and lv["theta"] < -cora_flow.MIN_EIG_TOL / 2
+        # the certified value is a lower bound of every feasible rank-d point, the rounded one included
+        assert run["levels"][-1]["f"] <= run["f_rounded"] + 1e-9
     d, n, l = ra.d, ra.n, ra.l
     Xr = out["X_rounded"]
     for i in range(0, n, 97):

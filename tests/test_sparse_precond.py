@@ -34,7 +34,8 @@ def test_schedule_replayed_on_the_host_solves_the_system(built, name):
     A = Q + 0.1 * sp.identity(Q.shape[0])
     rc, err, info = _selftest(A, ds.d + 1, 5)
     assert rc == 0 and err < 1e-12
-    assert info[0] % 2 == 0 and info[0] <= 2 * (2 + np.ceil(np.log2(max(ds.n, 2))))  # shallow: ~log2(n) levels
+    # forward + backward levels, the top level's two steps merged into one: odd, and shallow (~ log2(n) levels)
+    assert info[0] % 2 == 1 and info[0] <= 2 * (2 + np.ceil(np.log2(max(ds.n, 2))))
 
 
 def test_schedule_on_the_range_aided_layout_and_scalar_blocks(built):
