@@ -40,6 +40,12 @@ class ROptResult(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class RobustParams(C.Structure):
+    _fields_ = [("cost_type", C.c_int), ("GNCMaxNumIters", C.c_int), ("GNCBarc", C.c_double),
+                ("GNCMuStep", C.c_double), ("GNCInitMu", C.c_double), ("HuberThreshold", C.c_double),
+                ("TLSThreshold", C.c_double)]
+
+
 class RbcdOptions(C.Structure):
     _fields_ = [("num_robots", C.c_int), ("r", C.c_int), ("acceleration", C.c_int), ("restart_interval", C.c_int),
                 ("local", ROptParams), ("rank", C.c_int), ("world_size", C.c_int), ("device", C.c_int)]
@@ -119,6 +125,16 @@ SIGNATURES = {
     "dcora_problem_time_qapply": (C.c_int, [_vp, C.c_int, _PD, _PD]),
     "dcora_problem_time_precond": (C.c_int, [_vp, C.c_int, _PD, _PD]),
     "dcora_problem_precond_info": (C.c_int, [_vp, _dp]),
+    "dcora_robust_params_default": (None, [C.POINTER(RobustParams)]),
+    "dcora_robust_weights": (C.c_int, [C.POINTER(RobustParams), C.c_int, C.c_int, _dp, _dp]),
+    "dcora_chi2inv": (C.c_int, [C.c_double, C.c_int, _PD]),
+    "dcora_robust_error_threshold_at_quantile": (C.c_int, [C.c_double, C.c_int, _PD]),
+    "dcora_robust_single_rotation_averaging": (C.c_int, [C.c_int, C.c_int, _dp, _vp, C.c_double, _dp, _ip]),
+    "dcora_robust_single_pose_averaging": (C.c_int, [C.c_int, C.c_int, _dp, _dp, _vp, _vp, C.c_double, _dp, _dp, _ip]),
+    "dcora_measurement_errors": (C.c_int, [_vp, C.c_int, _dp, _dp, C.c_int]),
+    "dcora_solve_pgo": (C.c_int, [_vp, C.POINTER(ROptParams), _vp, _dp, C.POINTER(ROptResult), C.c_int]),
+    "dcora_solve_robust_pgo": (C.c_int, [_vp, C.POINTER(ROptParams), C.POINTER(RobustParams), _vp, _vp, _dp, _vp,
+                                         C.c_int]),
     "dcora_round_align_trajectory": (C.c_int, [C.POINTER(Dims), _dp, _vp, C.c_int, _dp, _vp, _vp, C.c_int]),
     "dcora_round_project_solution_raslam": (C.c_int, [C.POINTER(Dims), _dp, _dp, C.c_int]),
 }

@@ -7,6 +7,8 @@
 #include "device_problem.h"
 #include "host_graph.h"
 #include "rbcd.h"
+#include "host_robust.h"
+#include "robust.h"
 #include "round.h"
 
 namespace dcora {
@@ -517,6 +519,79 @@ int dcora_rbcd_synchronize(dcora_rbcd_t s) {
   if (!s) return bad("null");
   DCORA_HIP(hipStreamSynchronize(s->s.st));
   return DCORA_OK;
+}
+
+// ---- robust estimation ---------------------------------------------------------------------------------------
+void dcora_robust_params_default(dcora_robust_params *p) {
+  p->cost_type = DCORA_ROBUST_L2;
+  p->GNCMaxNumIters = 20;
+  p->GNCBarc = 5.0;
+  p->GNCMuStep = 1.4;
+  p->GNCInitMu = 1e-4;
+  p->HuberThreshold = 3;
+  p->TLSThreshold = 10;
+}
+int dcora_robust_weights(const dcora_robust_params *p, int num_updates, int n, const double *r, double *w) {
+  if (!p || !r || !w) return bad("null argument");
+  if (p->cost_type < DCORA_ROBUST_L2 || p->cost_type > DCORA_ROBUST_GNC_TLS) return bad("unknown robust cost type");
+  RobustCost c(*p);
+  for (int i = 0; i < num_updates; ++i) c.update();
+  for (int i = 0; i < n; ++i) w[i] = c.weight(r[i]);
+  return DCORA_OK;
+}
+int dcora_chi2inv(double quantile, int dof, double *out) {
+  if (!out || !(quantile > 0) || !(quantile < 1) || dof < 1) return bad("chi2inv: need 0 < quantile < 1, dof >= 1");
+  *out = chi2inv(quantile, dof);
+  return DCORA_OK;
+}
+int dcora_robust_error_threshold_at_quantile(double quantile, int dimension, double *out) {
+  if (!out) return bad("null argument");
+  if (!error_threshold_at_quantile(quantile, dimension, out))
+    return bad("quantile function currently only supports 3D problems and quantile > 0");
+  return DCORA_OK;
+}
+int dcora_robust_single_rotation_averaging(int d, int n, const double *R, const double *kappa, double thr,
+                                           double *Ropt, int *inlier) {
+  if (!R || !Ropt || !inlier || n < 1 || (d != 2 && d != 3)) return bad("bad argument");
+  DCORA_TRY
+  std::vector<int> in;
+  robust_single_rotation_averaging(d, n, R, kappa, thr, Ropt, in);
+  std::fill(inlier, inlier + n, 0);
+  for (int i : in) inlier[i] = 1;
+  return DCORA_OK;
+  DCORA_CATCH
+}
+int dcora_robust_single_pose_averaging(int d, int n, const double *R, const double *t, const double *kappa,
+                                       const double *tau, double thr, double *Ropt, double *topt, int *inlier) {
+  if (!R || !t || !Ropt || !topt || !inlier || n < 1 || (d != 2 && d != 3)) return bad("bad argument");
+  DCORA_TRY
+  std::vector<int> in;
+  robust_single_pose_averaging(d, n, R, t, kappa, tau, thr, Ropt, topt, in);
+  std::fill(inlier, inlier + n, 0);
+  for (int i : in) inlier[i] = 1;
+  return DCORA_OK;
+  DCORA_CATCH
+}
+int dcora_measurement_errors(dcora_dataset_t ds, int r, const double *X, double *out, int device) {
+  if (!ds || !X || !out) return bad("null argument");
+  if (r < ds->ds.d || r > 16) return bad("measurement_errors: need d <= r <= 16");
+  DCORA_TRY
+  return measurement_errors(ds->ds, r, X, out, device);
+  DCORA_CATCH
+}
+int dcora_solve_pgo(dcora_dataset_t ds, const dcora_ropt_params *params, const double *T0, double *Tout,
+                    dcora_ropt_result *result, int device) {
+  if (!ds || !params || !Tout) return bad("null argument");
+  DCORA_TRY
+  return solve_pgo(ds->ds, *params, T0, Tout, device, result);
+  DCORA_CATCH
+}
+int dcora_solve_robust_pgo(dcora_dataset_t ds, const dcora_ropt_params *params, const dcora_robust_params *robust,
+                           const int *fixed_weight, const double *T0, double *Tout, double *weights_out, int device) {
+  if (!ds || !params || !robust || !Tout) return bad("null argument");
+  DCORA_TRY
+  return solve_robust_pgo(ds->ds, *params, *robust, fixed_weight, T0, Tout, weights_out, device);
+  DCORA_CATCH
 }
 
 // ---- rounding ----------------------------------------------------------------------------------------------

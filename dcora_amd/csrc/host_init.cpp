@@ -77,6 +77,9 @@ void project_so(int d, const double *M, double *out) {
 }
 }  // namespace
 
+// projectToRotationGroup for other host code (host_robust.cpp)
+void project_to_rotation_group_host(int d, const double *M, double *out) { project_so(d, M, out); }
+
 // T (d x (d+1) n, column-major, SE ordering); returns false when a reduced Laplacian is not positive definite
 // (disconnected measurement graph)
 bool chordal_initialization(const HostDataset &ds, std::vector<double> &T) {

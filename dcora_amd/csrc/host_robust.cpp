@@ -1,0 +1,170 @@
+// Robust estimation, host side (see host_robust.h).
+#include "host_robust.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace dcora {
+
+// ---- chi-square quantile: the reference calls boost::math::quantile(chi_squared(dof), q); here the regularised
+// lower incomplete gamma function (series / Lentz continued fraction) inverted by bisection ----
+namespace {
+double gamma_p(double a, double x) {
+  if (x <= 0) return 0.0;
+  const double lg = std::lgamma(a);
+  if (x < a + 1.0) {
+    double ap = a, sum = 1.0 / a, del = sum;
+    for (int n = 0; n < 1000; ++n) {
+      ap += 1.0;
+      del *= x / ap;
+      sum += del;
+      if (std::fabs(del) < std::fabs(sum) * 1e-16) break;
+    }
+    return sum * std::exp(-x + a * std::log(x) - lg);
+  }
+  double b = x + 1.0 - a, c = 1.0 / 1e-300, d = 1.0 / b, h = d;
+  for (int i = 1; i < 1000; ++i) {
+    const double an = -i * (i - a);
+    b += 2.0;
+    d = an * d + b;
+    if (std::fabs(d) < 1e-300) d = 1e-300;
+    c = b + an / c;
+    if (std::fabs(c) < 1e-300) c = 1e-300;
+    d = 1.0 / d;
+    const double del = d * c;
+    h *= del;
+    if (std::fabs(del - 1.0) < 1e-16) break;
+  }
+  return 1.0 - std::exp(-x + a * std::log(x) - lg) * h;
+}
+}  // namespace
+
+double chi2inv(double quantile, int dof) {
+  const double a = 0.5 * dof;
+  double lo = 0.0, hi = std::max(4.0 * dof, 10.0);
+  while (gamma_p(a, 0.5 * hi) < quantile) hi *= 2.0;
+  for (int it = 0; it < 200; ++it) {
+    const double mid = 0.5 * (lo + hi);
+    (gamma_p(a, 0.5 * mid) < quantile ? lo : hi) = mid;
+    if (hi - lo < 1e-14 * std::max(1.0, hi)) break;
+  }
+  return 0.5 * (lo + hi);
+}
+
+bool error_threshold_at_quantile(double quantile, int dimension, double *out) {
+  if (dimension != 3 || !(quantile > 0)) return false;  // CHECKs of the reference
+  *out = quantile < 1 ? std::sqrt(chi2inv(quantile, 6)) : 1e5;
+  return true;
+}
+
+double RobustCost::weight(double r) const {
+  switch (p_.cost_type) {
+    case DCORA_ROBUST_L2: return 1;
+    case DCORA_ROBUST_L1: return 1 / r;
+    case DCORA_ROBUST_HUBER: return r < p_.HuberThreshold ? 1 : p_.HuberThreshold / r;
+    case DCORA_ROBUST_TLS: return r < p_.TLSThreshold ? 1 : 0;
+    case DCORA_ROBUST_GM: {
+      const double a = 1 + r * r;
+      return 1 / (a * a);
+    }
+    case DCORA_ROBUST_GNC_TLS: {  // eq. (14) of the GNC paper
+      const double rSq = r * r, bSq = p_.GNCBarc * p_.GNCBarc;
+      const double ub = (mu_ + 1) / mu_ * bSq, lb = mu_ / (mu_ + 1) * bSq;
+      if (rSq >= ub) return 0;
+      if (rSq <= lb) return 1;
+      return std::sqrt(bSq * mu_ * (mu_ + 1) / rSq) - mu_;
+    }
+  }
+  return 1;
+}
+void RobustCost::reset() {
+  if (p_.cost_type == DCORA_ROBUST_GNC_TLS) {
+    mu_ = p_.GNCInitMu;
+    iteration_ = 0;
+  }
+}
+void RobustCost::update() {
+  if (p_.cost_type != DCORA_ROBUST_GNC_TLS) return;
+  iteration_++;
+  if (iteration_ > p_.GNCMaxNumIters) return;
+  mu_ = p_.GNCMuStep * mu_;
+}
+
+// ---- averaging ----
+namespace {
+double sqdist(int m, const double *a, const double *b) {
+  double s = 0;
+  for (int e = 0; e < m; ++e) s += (a[e] - b[e]) * (a[e] - b[e]);
+  return s;
+}
+// singleRotationAveraging / singleTranslationAveraging (ref src/DCORA_solver.cpp:28-72) and the GNC loop shared by
+// robustSingleRotationAveraging (:76-141) and robustSinglePoseAveraging (:143-216)
+void robust_average(int d, int n, const double *R, const double *t, const double *kappa, const double *tau,
+                    double barc, int max_iters, double *Ropt, double *topt, std::vector<int> &inliers) {
+  const double w_tol = 1e-8;
+  std::vector<double> w((size_t)n, 1.0);
+  auto solve = [&]() {
+    double M[9] = {0}, s[3] = {0, 0, 0}, ws = 0;
+    for (int i = 0; i < n; ++i) {
+      const double kw = kappa[i] * w[i];
+      for (int e = 0; e < d * d; ++e) M[e] += kw * R[(size_t)i * d * d + e];
+      if (t) {
+        const double tw = tau[i] * w[i];
+        for (int a = 0; a < d; ++a) s[a] += tw * t[(size_t)i * d + a];
+        ws += tw;
+      }
+    }
+    if (t)
+      for (int a = 0; a < d; ++a) topt[a] = s[a] / ws;
+    project_to_rotation_group_host(d, M, Ropt);
+  };
+  auto rsq = [&](int i) {
+    double s = kappa[i] * sqdist(d * d, Ropt, R + (size_t)i * d * d);
+    if (t) s += tau[i] * sqdist(d, topt, t + (size_t)i * d);
+    return s;
+  };
+  solve();
+  double rmax = 0;
+  for (int i = 0; i < n; ++i) rmax = std::max(rmax, rsq(i));
+  const double barcSq = barc * barc;
+  double muInit = barcSq / (2 * rmax - barcSq);
+  muInit = std::min(muInit, 1e-5);
+  if (muInit > 0) {  // negative: residuals already small, GNC is skipped
+    dcora_robust_params prm;
+    dcora_robust_params_default(&prm);
+    prm.cost_type = DCORA_ROBUST_GNC_TLS;
+    prm.GNCBarc = barc;
+    prm.GNCMaxNumIters = max_iters;
+    prm.GNCInitMu = muInit;
+    RobustCost cost(prm);
+    for (int iter = 0; iter < max_iters; ++iter) {
+      solve();
+      int nc = 0;
+      for (int i = 0; i < n; ++i) {
+        const double wi = cost.weight(std::sqrt(rsq(i)));
+        if (wi < w_tol || wi > 1 - w_tol) nc++;
+        w[i] = wi;
+      }
+      if (nc == n) break;
+      cost.update();
+    }
+  }
+  inliers.clear();
+  for (int i = 0; i < n; ++i)
+    if (w[i] > 1 - w_tol) inliers.push_back(i);
+}
+}  // namespace
+
+void robust_single_rotation_averaging(int d, int n, const double *R, const double *kappa, double threshold,
+                                      double *Ropt, std::vector<int> &inliers) {
+  std::vector<double> k1((size_t)n, 1.0);
+  robust_average(d, n, R, nullptr, kappa ? kappa : k1.data(), nullptr, threshold, 1000, Ropt, nullptr, inliers);
+}
+void robust_single_pose_averaging(int d, int n, const double *R, const double *t, const double *kappa,
+                                  const double *tau, double threshold, double *Ropt, double *topt,
+                                  std::vector<int> &inliers) {
+  std::vector<double> k1((size_t)n, 10000.0), t1((size_t)n, 100.0);
+  robust_average(d, n, R, t, kappa ? kappa : k1.data(), tau ? tau : t1.data(), threshold, 10000, Ropt, topt, inliers);
+}
+
+}  // namespace dcora

@@ -1,0 +1,36 @@
+// Robust estimation around the hot path (host side): RobustCost (M-estimators and GNC-TLS), chi-square quantile,
+// single rotation / pose averaging with GNC (ref include/DCORA/DCORA_robust.h, src/DCORA_robust.cpp,
+// src/DCORA_solver.cpp:28-216).  Scalar / d x d arithmetic: host code in the reference, host code here.
+#pragma once
+#include <vector>
+
+#include "../../include/dcora_hip.h"
+
+namespace dcora {
+
+class RobustCost {
+ public:
+  explicit RobustCost(const dcora_robust_params &p) : p_(p), mu_(p.GNCInitMu) { reset(); }
+  double weight(double r) const;  // ref src/DCORA_robust.cpp:56-100
+  void reset();                   // :102-114
+  void update();                  // :116-136
+  double mu() const { return mu_; }
+
+ private:
+  dcora_robust_params p_;
+  double mu_;
+  int iteration_ = 0;
+};
+
+double chi2inv(double quantile, int dof);                                        // ref src/DCORA_utils.cpp:2103-2106
+bool error_threshold_at_quantile(double quantile, int dimension, double *out);   // ref src/DCORA_robust.cpp:138-148
+void project_to_rotation_group_host(int d, const double *M, double *out);        // host_init.cpp
+
+// R: n rotations d x d column-major; t: n translations; kappa / tau may be null (defaults of the reference)
+void robust_single_rotation_averaging(int d, int n, const double *R, const double *kappa, double threshold,
+                                      double *Ropt, std::vector<int> &inliers);
+void robust_single_pose_averaging(int d, int n, const double *R, const double *t, const double *kappa,
+                                  const double *tau, double threshold, double *Ropt, double *topt,
+                                  std::vector<int> &inliers);
+
+}  // namespace dcora

@@ -231,6 +231,52 @@ int dcora_rbcd_phase_evaluate_dev(dcora_rbcd_t s, double *out_dev);
 int dcora_rbcd_synchronize(dcora_rbcd_t s);
 
 /* ------------------------------------------------------------------------- *
+ * Robust estimation (replaces src/DCORA_robust.cpp and the robust parts of src/DCORA_solver.cpp)
+ * ------------------------------------------------------------------------- */
+/* RobustCostParameters::Type (ref include/DCORA/DCORA_robust.h:28-35) */
+typedef enum {
+  DCORA_ROBUST_L2 = 0,
+  DCORA_ROBUST_L1 = 1,
+  DCORA_ROBUST_TLS = 2,
+  DCORA_ROBUST_HUBER = 3,
+  DCORA_ROBUST_GM = 4,
+  DCORA_ROBUST_GNC_TLS = 5
+} dcora_robust_type;
+/* RobustCostParameters (ref :25-60); defaults: L2, 20 GNC iterations, barc 5, mu step 1.4, mu init 1e-4, Huber 3, TLS 10 */
+typedef struct {
+  int cost_type;
+  int GNCMaxNumIters;
+  double GNCBarc, GNCMuStep, GNCInitMu;
+  double HuberThreshold, TLSThreshold;
+} dcora_robust_params;
+void dcora_robust_params_default(dcora_robust_params *p);
+/* RobustCost::weight(r) for n residuals after num_updates calls of RobustCost::update() (ref src/DCORA_robust.cpp:56-136) */
+int dcora_robust_weights(const dcora_robust_params *p, int num_updates, int n, const double *r, double *w);
+/* chi2inv (ref src/DCORA_utils.cpp:2103-2106), RobustCost::computeErrorThresholdAtQuantile (ref src/DCORA_robust.cpp:138-148) */
+int dcora_chi2inv(double quantile, int dof, double *out);
+int dcora_robust_error_threshold_at_quantile(double quantile, int dimension, double *out);
+/* robustSingleRotationAveraging / robustSinglePoseAveraging (ref src/DCORA_solver.cpp:76-216): R holds n rotations
+ * d x d column-major back to back, t n translations; kappa / tau may be NULL (1 resp. 10000 / 100 as in the
+ * reference); inlier receives n flags */
+int dcora_robust_single_rotation_averaging(int d, int n, const double *R, const double *kappa, double error_threshold,
+                                           double *Ropt, int *inlier);
+int dcora_robust_single_pose_averaging(int d, int n, const double *R, const double *t, const double *kappa,
+                                       const double *tau, double error_threshold, double *Ropt, double *topt,
+                                       int *inlier);
+/* computeMeasurementError of every measurement of the dataset at once (ref src/DCORA_utils.cpp:2095-2101;
+ * Agent::computeMeasurementResidual, ref src/Agent.cpp:1342-1389): X is r x (d+1) n (SE ordering, r >= d, lifted or
+ * not); out[i] = kappa |Y1 R - Y2|^2 + tau |p2 - p1 - Y1 t|^2, weights not applied */
+int dcora_measurement_errors(dcora_dataset_t ds, int r, const double *X, double *out, int device);
+/* solvePGO (ref src/DCORA_solver.cpp:304-328): T0 (d x (d+1) n) or NULL for the chordal start; one optimize() at
+ * rank d with params */
+int dcora_solve_pgo(dcora_dataset_t ds, const dcora_ropt_params *params, const double *T0, double *Tout,
+                    dcora_ropt_result *result, int device);
+/* solveRobustPGO (ref :330-409): GNC-TLS around solvePGO; fixed_weight: one flag per measurement (NULL = none
+ * fixed); the final weights are written into the dataset handle and to weights_out (may be NULL) */
+int dcora_solve_robust_pgo(dcora_dataset_t ds, const dcora_ropt_params *params, const dcora_robust_params *robust,
+                           const int *fixed_weight, const double *T0, double *Tout, double *weights_out, int device);
+
+/* ------------------------------------------------------------------------- *
  * Rounding / solution recovery
  * ------------------------------------------------------------------------- */
 /* alignLiftedTrajectoryToFrame (ref src/DCORA_utils.cpp:2262-2289), Agent::getTrajectoryInGlobalFrame /

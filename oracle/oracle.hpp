@@ -273,6 +273,36 @@ struct RBCDTrace {
 };
 RBCDTrace run_rbcd(const Dataset &ds, const RBCDOptions &o, const Mat &X0);
 
+// ---- robust estimation (oracle_robust.cpp) ------------------------------------------------------------------
+// ref: include/DCORA/DCORA_robust.h:25-140, src/DCORA_robust.cpp:51-148
+enum class RobustType { L2 = 0, L1 = 1, TLS = 2, Huber = 3, GM = 4, GNC_TLS = 5 };
+struct RobustParams {
+  RobustType type = RobustType::L2;
+  int GNCMaxNumIters = 20;
+  double GNCBarc = 5.0, GNCMuStep = 1.4, GNCInitMu = 1e-4, HuberThreshold = 3, TLSThreshold = 10;
+};
+struct RobustCost {
+  RobustParams p;
+  double mu;
+  int iteration = 0;
+  explicit RobustCost(const RobustParams &prm) : p(prm), mu(prm.GNCInitMu) { reset(); }
+  double weight(double r) const;
+  void reset();
+  void update();
+};
+double chi2inv(double quantile, int dof);                          // ref: src/DCORA_utils.cpp:2103-2106
+double error_threshold_at_quantile(double quantile, int dimension);  // ref: src/DCORA_robust.cpp:138-148
+// ref: src/DCORA_solver.cpp:76-216; R: n rotations d x d column-major, t: n translations; kappa / tau may be null
+void robust_single_rotation_averaging(int d, int n, const double *R, const double *kappa, double threshold,
+                                      double *Ropt, std::vector<int> &inliers);
+void robust_single_pose_averaging(int d, int n, const double *R, const double *t, const double *kappa,
+                                  const double *tau, double threshold, double *Ropt, double *topt,
+                                  std::vector<int> &inliers);
+double measurement_error(const Meas &m, int d, const Mat &T);      // ref: src/DCORA_utils.cpp:2095-2101
+Mat solve_pgo(const Dataset &ds, const ROptParams &prm, const Mat *T0);  // ref: src/DCORA_solver.cpp:304-328
+Mat solve_robust_pgo(Dataset &ds, const ROptParams &prm, const RobustParams &rp, const std::vector<char> &fixed,
+                     const Mat *T0);                                // ref: src/DCORA_solver.cpp:330-409
+
 // start point of the centralised CORA driver (ref: examples/SingleRobotExample_RASLAM.cpp:92-150); d x k
 Mat ra_odometry_initialization(const RADataset &ds, uint64_t seed);
 

@@ -407,6 +407,76 @@ void orc_trace_copy(void *h, double *cost, double *gradnorm, int *selected, int 
 }
 void orc_trace_free(void *h) { delete (RBCDTrace *)h; }
 
+// ---- robust estimation ------------------------------------------------------------------------------------------------
+// prm: [type, GNCMaxNumIters, GNCBarc, GNCMuStep, GNCInitMu, HuberThreshold, TLSThreshold]
+static RobustParams view_robust(const double *prm) {
+  RobustParams p;
+  p.type = (RobustType)(int)prm[0];
+  p.GNCMaxNumIters = (int)prm[1];
+  p.GNCBarc = prm[2];
+  p.GNCMuStep = prm[3];
+  p.GNCInitMu = prm[4];
+  p.HuberThreshold = prm[5];
+  p.TLSThreshold = prm[6];
+  return p;
+}
+// weights of n residuals after `updates` calls of RobustCost::update()
+void orc_robust_weights(const double *prm, int updates, int n, const double *r, double *w) {
+  RobustCost c(view_robust(prm));
+  for (int i = 0; i < updates; ++i) c.update();
+  for (int i = 0; i < n; ++i) w[i] = c.weight(r[i]);
+}
+double orc_chi2inv(double q, int dof) { return chi2inv(q, dof); }
+double orc_error_threshold_at_quantile(double q, int dim) { return error_threshold_at_quantile(q, dim); }
+// inlier: n flags
+void orc_robust_rotation_averaging(int d, int n, const double *R, const double *kappa, double thr, double *Ropt,
+                                   int *inlier) {
+  std::vector<int> in;
+  robust_single_rotation_averaging(d, n, R, kappa, thr, Ropt, in);
+  for (int i = 0; i < n; ++i) inlier[i] = 0;
+  for (int i : in) inlier[i] = 1;
+}
+void orc_robust_pose_averaging(int d, int n, const double *R, const double *t, const double *kappa, const double *tau,
+                               double thr, double *Ropt, double *topt, int *inlier) {
+  std::vector<int> in;
+  robust_single_pose_averaging(d, n, R, t, kappa, tau, thr, Ropt, topt, in);
+  for (int i = 0; i < n; ++i) inlier[i] = 0;
+  for (int i : in) inlier[i] = 1;
+}
+void orc_measurement_errors(void *dsh, const double *T, double *out) {
+  Dataset *ds = (Dataset *)dsh;
+  const Mat Tm = view_mat(ds->d, (ds->d + 1) * ds->n, T);
+  for (size_t i = 0; i < ds->meas.size(); ++i) out[i] = measurement_error(ds->meas[i], ds->d, Tm);
+}
+// opt: [gradnorm_tol, RTR_iterations, RTR_tCG_iterations, RTR_initial_radius]; T0 may be null (chordal start)
+static ROptParams view_opt(const double *opt) {
+  ROptParams p;
+  p.gradnorm_tol = opt[0];
+  p.RTR_iterations = (int)opt[1];
+  p.RTR_tCG_iterations = (int)opt[2];
+  p.RTR_initial_radius = opt[3];
+  return p;
+}
+void orc_solve_pgo(void *dsh, const double *opt, const double *T0, double *Tout) {
+  Dataset *ds = (Dataset *)dsh;
+  Mat T0m;
+  if (T0) T0m = view_mat(ds->d, (ds->d + 1) * ds->n, T0);
+  const Mat T = solve_pgo(*ds, view_opt(opt), T0 ? &T0m : nullptr);
+  std::copy(T.a.begin(), T.a.end(), Tout);
+}
+// fixed: m flags (fixedWeight); weights_out: m
+void orc_solve_robust_pgo(void *dsh, const double *opt, const double *rprm, const int *fixed, const double *T0,
+                          double *Tout, double *weights_out) {
+  Dataset *ds = (Dataset *)dsh;
+  Mat T0m;
+  if (T0) T0m = view_mat(ds->d, (ds->d + 1) * ds->n, T0);
+  std::vector<char> fx(ds->meas.size());
+  for (size_t i = 0; i < fx.size(); ++i) fx[i] = fixed[i] ? 1 : 0;
+  const Mat T = solve_robust_pgo(*ds, view_opt(opt), view_robust(rprm), fx, T0 ? &T0m : nullptr);
+  std::copy(T.a.begin(), T.a.end(), Tout);
+  for (size_t i = 0; i < ds->meas.size(); ++i) weights_out[i] = ds->meas[i].weight;
+}
+
 // ---- rounding ------------------------------------------------------------------------------------------------------
 // X r x (d+1) n (SE ordering), anchor r x (d+1); out d x (d+1) n
 void orc_align_lifted_trajectory(int r, int d, int n, const double *X, const double *anchor, int global, double *out) {

@@ -402,3 +402,112 @@ def ra_states_in_local_frame(X, r, d, n, l, b):
     T, S, Lm = np.zeros(d * (d + 1) * n), np.zeros(max(d * l, 1)), np.zeros(max(d * b, 1))
     lib().orc_ra_states_in_local_frame(r, d, n, l, b, F(X), T, S, Lm)
     return unF(T, d, (d + 1) * n), unF(S[:d * l], d, l), unF(Lm[:d * b], d, b)
+
+
+# ---- robust estimation (oracle_robust.cpp) ----------------------------------------------------------------------------
+ROBUST_TYPES = {"L2": 0, "L1": 1, "TLS": 2, "Huber": 3, "GM": 4, "GNC_TLS": 5}
+
+
+def _robust_prm(cost_type="L2", GNCMaxNumIters=20, GNCBarc=5.0, GNCMuStep=1.4, GNCInitMu=1e-4, HuberThreshold=3.0,
+                TLSThreshold=10.0):
+    """ref include/DCORA/DCORA_robust.h:50-60 (defaults)"""
+    return np.array([ROBUST_TYPES[cost_type], GNCMaxNumIters, GNCBarc, GNCMuStep, GNCInitMu, HuberThreshold,
+                     TLSThreshold], dtype=np.float64)
+
+
+def _bind_robust():
+    L = lib()
+    if getattr(L, "_robust_bound", False):
+        return L
+    L.orc_robust_weights.argtypes = [_dp, C.c_int, C.c_int, _dp, _dp]
+    L.orc_chi2inv.restype = C.c_double
+    L.orc_chi2inv.argtypes = [C.c_double, C.c_int]
+    L.orc_error_threshold_at_quantile.restype = C.c_double
+    L.orc_error_threshold_at_quantile.argtypes = [C.c_double, C.c_int]
+    L.orc_robust_rotation_averaging.argtypes = [C.c_int, C.c_int, _dp, C.c_void_p, C.c_double, _dp, _ip]
+    L.orc_robust_pose_averaging.argtypes = [C.c_int, C.c_int, _dp, _dp, C.c_void_p, C.c_void_p, C.c_double, _dp, _dp,
+                                            _ip]
+    L.orc_measurement_errors.argtypes = [C.c_void_p, _dp, _dp]
+    L.orc_solve_pgo.argtypes = [C.c_void_p, _dp, C.c_void_p, _dp]
+    L.orc_solve_robust_pgo.argtypes = [C.c_void_p, _dp, _dp, _ip, C.c_void_p, _dp, _dp]
+    L._robust_bound = True
+    return L
+
+
+def robust_weights(r, updates=0, **prm):
+    """RobustCost::weight after `updates` calls of update() (ref src/DCORA_robust.cpp:56-137)"""
+    r = np.ascontiguousarray(r, np.float64)
+    w = np.zeros_like(r)
+    _bind_robust().orc_robust_weights(_robust_prm(**prm), updates, r.size, r, w)
+    return w
+
+
+def chi2inv(q, dof):
+    return _bind_robust().orc_chi2inv(q, dof)
+
+
+def error_threshold_at_quantile(q, dim=3):
+    return _bind_robust().orc_error_threshold_at_quantile(q, dim)
+
+
+def _vp(a):
+    return None if a is None else np.ascontiguousarray(a, np.float64).ctypes.data_as(C.c_void_p)
+
+
+def robust_single_rotation_averaging(Rs, kappa=None, threshold=1.0):
+    """Rs: list of d x d; returns (Ropt, inlier indices) (ref src/DCORA_solver.cpp:76-141)"""
+    d, n = Rs[0].shape[0], len(Rs)
+    flat = np.concatenate([F(R) for R in Rs])
+    Ropt, inl = np.zeros(d * d), np.zeros(n, np.int32)
+    k = None if kappa is None else np.ascontiguousarray(kappa, np.float64)
+    _bind_robust().orc_robust_rotation_averaging(d, n, flat, _vp(k), threshold, Ropt, inl)
+    return unF(Ropt, d, d), np.nonzero(inl)[0]
+
+
+def robust_single_pose_averaging(Rs, ts, kappa=None, tau=None, threshold=1.0):
+    """ref src/DCORA_solver.cpp:143-216"""
+    d, n = Rs[0].shape[0], len(Rs)
+    flat = np.concatenate([F(R) for R in Rs])
+    tflat = np.ascontiguousarray(np.concatenate([np.asarray(t, np.float64).reshape(-1) for t in ts]))
+    Ropt, topt, inl = np.zeros(d * d), np.zeros(d), np.zeros(n, np.int32)
+    k = None if kappa is None else np.ascontiguousarray(kappa, np.float64)
+    ta = None if tau is None else np.ascontiguousarray(tau, np.float64)
+    _bind_robust().orc_robust_pose_averaging(d, n, flat, tflat, _vp(k), _vp(ta), threshold, Ropt, topt, inl)
+    return unF(Ropt, d, d), topt, np.nonzero(inl)[0]
+
+
+def measurement_errors(ds, T):
+    """computeMeasurementError of every edge (ref src/DCORA_utils.cpp:2095-2101)"""
+    L = _bind_robust()
+    h = L.orc_ds_create(ds.d, ds.n, ds.m, ds.ids, ds.vals)
+    out = np.zeros(ds.m)
+    L.orc_measurement_errors(h, F(T), out)
+    L.orc_ds_free(h)
+    return out
+
+
+def _opt(gradnorm_tol=1e-2, RTR_iterations=3, RTR_tCG_iterations=50, RTR_initial_radius=100.0):
+    return np.array([gradnorm_tol, RTR_iterations, RTR_tCG_iterations, RTR_initial_radius], dtype=np.float64)
+
+
+def solve_pgo(ds, T0=None, **opt):
+    """solvePGO (ref src/DCORA_solver.cpp:304-328)"""
+    L = _bind_robust()
+    h = L.orc_ds_create(ds.d, ds.n, ds.m, ds.ids, ds.vals)
+    out = np.zeros(ds.d * (ds.d + 1) * ds.n)
+    t0 = None if T0 is None else F(T0)
+    L.orc_solve_pgo(h, _opt(**opt), _vp(t0), out)
+    L.orc_ds_free(h)
+    return unF(out, ds.d, (ds.d + 1) * ds.n)
+
+
+def solve_robust_pgo(ds, fixed, T0=None, robust=None, **opt):
+    """solveRobustPGO (ref src/DCORA_solver.cpp:330-409); returns (T, weights)"""
+    L = _bind_robust()
+    h = L.orc_ds_create(ds.d, ds.n, ds.m, ds.ids, ds.vals)
+    out, w = np.zeros(ds.d * (ds.d + 1) * ds.n), np.zeros(ds.m)
+    t0 = None if T0 is None else F(T0)
+    rp = _robust_prm(**(robust or {"cost_type": "GNC_TLS"}))
+    L.orc_solve_robust_pgo(h, _opt(**opt), rp, np.ascontiguousarray(fixed, np.int32), _vp(t0), out, w)
+    L.orc_ds_free(h)
+    return unF(out, ds.d, (ds.d + 1) * ds.n), w
