@@ -20,6 +20,9 @@ class DeviceLanczos {
   int device = 0, n = 0;
   hipStream_t st = nullptr;
   DevCsr Sd;
+  // shift-and-invert mode: when set, a Lanczos step applies (S - sigma I)^-1 through the partitioned sparse inverse
+  // instead of S - shift I
+  const SparsePrecond *inverse_op = nullptr;
   DevBuf<double> V, Vtmp, w, part, small;
   ~DeviceLanczos();
   int init(const HostCsr &S, int device_);

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstring>
 #include <numeric>
+#include <thread>
 
 #include "cert.h"
 #include "device_problem.h"
@@ -128,8 +129,12 @@ int DeviceLanczos::largest_magnitude(double shift, int ncv, int maxit, double to
   for (int it = 0; it <= maxit; ++it) {
     for (int j = k; j < m; ++j) {
       double *vj = V.p + (size_t)j * n;
-      launch_spmm(st, 1, Sv, buf1(vj), 0, nullptr, buf1(w.p), 0, nullptr, Gate{});
-      if (shift != 0) launch_scale_shift(st, n, shift, vj, w.p);
+      if (inverse_op) {
+        inverse_op->apply(st, 1, buf1(vj), w.p, Gate{});
+      } else {
+        launch_spmm(st, 1, Sv, buf1(vj), 0, nullptr, buf1(w.p), 0, nullptr, Gate{});
+        if (shift != 0) launch_scale_shift(st, n, shift, vj, w.p);
+      }
       out->matvecs++;
       const int nv = j + 1;
       for (int pass = 0; pass < 2; ++pass) {
@@ -246,9 +251,34 @@ int device_min_eig(const HostCsr &S, int maxit, double min_eig_tol, int ncv, uin
   if (rc) return rc;
   sh.matvecs += lm.matvecs;
   if (!sh.ok) {
-    // The reference falls back to shift-and-invert Lanczos (:1878-1888, :1751-1805), which needs a sparse
-    // LDL^T solve per step; not on the device in this build.
-    set_last_error("min_eig: spectrum-shifted Lanczos did not converge (shift-invert fallback not implemented)");
+    // Shift-and-invert fallback (ref :1878-1888 -> :1751-1805): Lanczos on (S - sigma I)^-1, sigma = -10, halved
+    // on failure with the floor -2 eta.  The solve per step is the partitioned sparse inverse of the SPD matrix
+    // S - sigma I replayed on the device (sparse_precond.h), one right-hand side.
+    double sigma = -10.0;
+    unsigned hw = std::thread::hardware_concurrency();
+    const int nthreads = (int)std::max(1u, std::min(hw, 32u));
+    for (int i = 0; i < 10; ++i) {
+      PartInvHost P;
+      if (build_partitioned_inverse(csr_shift_diag(S, -sigma), 1, nthreads, &P)) {
+        SparsePrecond inv;
+        rc = inv.upload(P, 1);
+        if (rc) return rc;
+        L.inverse_op = &inv;
+        LanczosResult si;
+        rc = L.largest_magnitude(0.0, ncv, 1000, 1e-10, nullptr, seed, &si);
+        L.inverse_op = nullptr;
+        if (rc) return rc;
+        if (si.ok) {
+          si.matvecs += sh.matvecs;
+          si.lambda = sigma + 1.0 / si.lambda;
+          *out = si;
+          return DCORA_OK;
+        }
+      }
+      sigma /= 2;
+      if (i == 8 || sigma > -2 * min_eig_tol) sigma = -2 * min_eig_tol;
+    }
+    set_last_error("min_eig: neither the spectrum-shifted nor the shift-and-invert Lanczos run converged");
     *out = sh;
     out->lambda += 2 * lambda_lm;
     return DCORA_ERR_NO_CONVERGENCE;

@@ -229,3 +229,23 @@ def test_rbcd_torus3D_eight_agents_matches_oracle(env):
     assert np.allclose(out["cost"], tr["cost"], rtol=1e-8)
     assert np.allclose(out["gradnorm"], tr["gradnorm"], rtol=1e-6)
     assert common.rel(s.get_X(), tr["X"]) < 1e-6
+
+
+def test_min_eig_shift_invert_fallback(env):
+    """a tiny negative eigenvalue under a huge spectrum (|lambda_min| / lambda_max ~ 5e-10): the spectrum-shifted
+    Lanczos run cannot converge and the shift-and-invert fallback takes over (ref src/DCORA_utils.cpp:1751-1805,
+    1878-1888); on the device its solve per step is the partitioned sparse inverse of S - sigma I"""
+    import os
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as sla
+    da, orc = env
+    ra = da.RADataset(os.path.join(common.DATA, "single_drone.pyfg.gz"))
+    Q = ra.Q.to_scipy()
+    S = da.Csr.from_scipy(Q - 1e-3 * sp.identity(Q.shape[0]))
+    want = sla.eigsh(S.to_scipy(), k=1, sigma=-1.0, which="LM", return_eigenvectors=False)[0]
+    assert abs(want + 1e-3) < 1e-9  # Q is PSD with a translation gauge: lambda_min(Q) = 0
+    ok, lam, v, mv = da.min_eig(S, tol=1e-4)
+    assert ok and abs(lam - want) < 1e-8
+    assert np.linalg.norm(S.to_scipy() @ v - lam * v) < 1e-6 and abs(np.linalg.norm(v) - 1) < 1e-12
+    oko, lamo, vo, mvo = orc.min_eig(orc.CSR.from_scipy(S.to_scipy()), tol=1e-4)
+    assert oko and abs(lamo - want) < 1e-8
