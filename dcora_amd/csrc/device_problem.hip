@@ -131,7 +131,8 @@ int DeviceProblem::init(const dcora_dims &dims, const HostCsr &Qh, const double 
   DCORA_HIP(S0.alloc(NS));
   DCORA_HIP(S1.alloc(NS));
   // 2 doubles per slot; the Q-apply may add up to kMaxPartials / 2 long-row blocks to its kMaxPartials row blocks
-  for (DevBuf<double> *b : {&pA, &pB, &pC, &p1, &p2, &p3}) DCORA_HIP(b->alloc(4 * kMaxPartials));
+  for (DevBuf<double> *b : {&pB, &pC, &p1, &p2, &p3}) DCORA_HIP(b->alloc(4 * kMaxPartials));
+  DCORA_HIP(pA.alloc(2 * (size_t)kBsrMaxGrid));  // the block-CSR Q-apply runs up to kBsrMaxGrid workgroups
   DCORA_HIP(scal.alloc(64));
   DCORA_HIP(ctl.alloc(1));
   DCORA_HIP(hipHostMalloc((void **)&hf, sizeof(HostFlags), hipHostMallocMapped));

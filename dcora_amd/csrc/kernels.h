@@ -16,6 +16,7 @@
 namespace dcora {
 
 constexpr int kMaxPartials = 1024;  // upper bound on per-kernel partial-sum slots
+constexpr int kBsrMaxGrid = 4096;   // workgroups (= partial slots) of the block-CSR Q-apply
 constexpr int kBlock = 256;
 
 struct ManiDesc {
