@@ -146,7 +146,7 @@ void leaf_order(const NDGraph &G, const std::vector<int> &nodes, std::vector<int
 }
 
 void nd_recurse(const NDGraph &G, std::vector<int> nodes, std::vector<int> &comp_id, int &next_cid,
-                std::vector<int> &level, std::vector<int> &out, std::vector<int> &cuts) {
+                std::vector<int> &level, std::vector<int> &out, std::vector<int> &cuts, int leaf_nodes) {
   // iterative worklist: (nodes) ; output order is built back-to-front: separators last
   struct Item {
     std::vector<int> nodes;
@@ -164,7 +164,7 @@ void nd_recurse(const NDGraph &G, std::vector<int> nodes, std::vector<int> &comp
       comp_id[u] = cid;
       level[u] = -1;
     }
-    if ((int)cur.size() <= 24) {
+    if ((int)cur.size() <= leaf_nodes) {
       std::vector<int> lo;
       leaf_order(G, cur, comp_id, cid, lo);
       for (auto it = lo.rbegin(); it != lo.rend(); ++it) rev.push_back(*it);
@@ -261,7 +261,9 @@ std::vector<int> amd_like_order(const HostCsr &A, int block, std::vector<int> *p
   }
   int next_cid = 0;
   std::vector<int> cuts;
-  nd_recurse(G, all, comp_id, next_cid, level, border, cuts);
+  // leaf sub-domains of ~96 unknowns: 24 pose blocks, or 96 scalar unknowns when the graph is not block-compressed
+  const int leaf_nodes = std::max(24, 96 / block);
+  nd_recurse(G, all, comp_id, next_cid, level, border, cuts, leaf_nodes);
   if (!hubs.empty()) {
     border.insert(border.end(), hubs.begin(), hubs.end());
     cuts.push_back(nb);

@@ -1020,9 +1020,11 @@ int fused_pose_blocks(const ManiDesc &m) {
 }
 int fused_nsplit(const ManiDesc &m) {
   const int njc = (m.k + kJChunk - 1) / kJChunk;
-  int ns = (512 + njc - 1) / njc;  // aim for ~512 blocks of 4 waves
+  static const int aim = std::getenv("DCORA_PRECOND_BLOCKS") ? atoi(std::getenv("DCORA_PRECOND_BLOCKS")) : 512;
+  static const int cap = std::getenv("DCORA_PRECOND_NSPLIT_MAX") ? atoi(std::getenv("DCORA_PRECOND_NSPLIT_MAX")) : 32;
+  int ns = (aim + njc - 1) / njc;  // aim for ~512 blocks of 4 waves
   if (ns < 1) ns = 1;
-  if (ns > 32) ns = 32;
+  if (ns > cap) ns = cap;
   while (ns > 1 && (m.k + ns - 1) / ns < 16) --ns;
   return ns;
 }
