@@ -290,17 +290,62 @@ int device_min_eig(const HostCsr &S, int maxit, double min_eig_tol, int ncv, uin
 
 // ref src/DCORA_utils.cpp:1898-1982
 int device_dual_certificate(const dcora_dims &dims, const double *Xh, const HostCsr &Q, int device, HostCsr *S) {
-  DeviceProblem P;
-  int rc = P.init(dims, Q, nullptr, -1.0, device, nullptr);
+  if (dims.r < 1 || dims.r > 16 || (dims.d != 2 && dims.d != 3) || dims.n < 0 || dims.l < 0 || dims.b < 0) {
+    set_last_error("bad dims (need 1 <= r <= 16, d in {2,3})");
+    return DCORA_ERR_BAD_ARG;
+  }
+  const ManiDesc m = make_mani(dims.r, dims.d, dims.n, dims.l, dims.b);
+  if (Q.n != m.k) {
+    set_last_error("Q dimension does not match (d+1) n + l + b");
+    return DCORA_ERR_BAD_ARG;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_last_error("no HIP device available: libdcora_hip has no CPU fallback");
+    return DCORA_ERR_NO_DEVICE;
+  }
+  DCORA_HIP(hipSetDevice(device));
+  // only what the two kernels need: Q, X, X Q and the Lambda blocks (no solver workspace)
+  DevCsr Qd;
+  int rc = Qd.upload(Q);
   if (rc) return rc;
-  const ManiDesc &m = P.m;
-  DCORA_HIP(hipMemcpy(P.X0.p, Xh, sizeof(double) * P.nelem(), hipMemcpyHostToDevice));
-  launch_spmm(P.st, m.r, P.Q.view(), buf1(P.X0.p), 0, nullptr, buf1(P.EG0.p), 0, nullptr, Gate{});
-  launch_lambda_blocks(P.st, m, P.X0.p, P.EG0.p, P.S0.p);
+  const size_t N = (size_t)m.r * m.k;
   const size_t NL = (size_t)m.n * m.d * m.d + m.l;
+  DevBuf<double> dX, dXQ, dL;
+  DCORA_HIP(dX.alloc(N));
+  DCORA_HIP(dXQ.alloc(N));
+  DCORA_HIP(dL.alloc(NL + 1));
+  DCORA_HIP(hipMemcpy(dX.p, Xh, sizeof(double) * N, hipMemcpyHostToDevice));
+  launch_spmm(nullptr, m.r, Qd.view(), buf1(dX.p), 0, nullptr, buf1(dXQ.p), 0, nullptr, Gate{});
+  launch_lambda_blocks(nullptr, m, dX.p, dXQ.p, dL.p);
   std::vector<double> L(NL + 1);
-  DCORA_HIP(hipMemcpyAsync(L.data(), P.S0.p, sizeof(double) * NL, hipMemcpyDeviceToHost, P.st));
-  DCORA_HIP(hipStreamSynchronize(P.st));
+  DCORA_HIP(hipMemcpy(L.data(), dL.p, sizeof(double) * NL, hipMemcpyDeviceToHost));
+  // S = Q - Lambda.  Lambda is block diagonal on entries that Q's own pattern holds (the d x d rotation blocks
+  // and the unit-sphere diagonal): subtract in place on a copy of Q; fall back to a merge when an entry is absent.
+  {
+    HostCsr T = Q;
+    bool all_found = true;
+    auto sub = [&](int i, int j, double val) {
+      const int *lo = T.ci.data() + T.rp[i], *hi = T.ci.data() + T.rp[i + 1];
+      const int *it = std::lower_bound(lo, hi, j);
+      if (it == hi || *it != j) {
+        all_found = false;
+        return;
+      }
+      T.v[it - T.ci.data()] -= val;
+    };
+    const int d = m.d;
+    for (int i = 0; i < m.n && all_found; ++i) {
+      const int c = m.rot_col(i);
+      for (int a = 0; a < d; ++a)
+        for (int b = 0; b < d; ++b) sub(c + a, c + b, L[(size_t)i * d * d + a + b * d]);
+    }
+    for (int i = 0; i < m.l && all_found; ++i) sub(m.sphere_col(i), m.sphere_col(i), L[(size_t)m.n * d * d + i]);
+    if (all_found) {
+      *S = std::move(T);
+      return DCORA_OK;
+    }
+  }
   std::vector<int> I, J;
   std::vector<double> V;
   I.reserve(Q.nnz() + NL);

@@ -33,6 +33,7 @@ class RbcdSession {
   DevBuf<double> evalbuf, posenorm;
   DevBuf<int> pose_start;          // R + 1 global pose offsets
   EvalOut *eval_host = nullptr;    // host-mapped results of the evaluation epilogue
+  double *x_stage = nullptr;       // pinned staging buffer of get_X
   EvalOut *eval_dev = nullptr;
   int eval_seq = 0;
   DeviceProblem *last_solver = nullptr;

@@ -27,6 +27,7 @@ static void nesterov(hipStream_t st, const ManiDesc &m, int mode, int restart, i
 
 RbcdSession::~RbcdSession() {
   if (eval_host) (void)hipHostFree((void *)eval_host);
+  if (x_stage) (void)hipHostFree((void *)x_stage);
   agents.clear();
   central.reset();
   if (st) (void)hipStreamDestroy(st);
@@ -68,6 +69,7 @@ int RbcdSession::init(const HostDataset &ds, const dcora_rbcd_options &o) {
   DCORA_HIP(hipHostMalloc((void **)&eval_host, sizeof(EvalOut), hipHostMallocMapped));
   std::memset((void *)eval_host, 0, sizeof(EvalOut));
   DCORA_HIP(hipHostGetDevicePointer((void **)&eval_dev, (void *)eval_host, 0));
+  DCORA_HIP(hipHostMalloc((void **)&x_stage, sizeof(double) * N, hipHostMallocDefault));
   DCORA_HIP(evalbuf.alloc(2 * R + 16));
   DCORA_HIP(hipMemset(evalbuf.p, 0, sizeof(double) * (2 * R + 16)));
 
@@ -154,8 +156,12 @@ int RbcdSession::set_X(const double *Xh) {
 }
 int RbcdSession::get_X(double *Xh) {
   DCORA_HIP(hipSetDevice(opt.device));
-  DCORA_HIP(hipMemcpyAsync(Xh, Xg.p, sizeof(double) * (size_t)r * (d + 1) * n, hipMemcpyDeviceToHost, st));
+  const size_t B = sizeof(double) * (size_t)r * (d + 1) * n;
+  // through a pinned staging buffer: an asynchronous copy into pageable memory takes milliseconds on this runtime
+  if (!x_stage) DCORA_HIP(hipHostMalloc((void **)&x_stage, B, hipHostMallocDefault));
+  DCORA_HIP(hipMemcpyAsync(x_stage, Xg.p, B, hipMemcpyDeviceToHost, st));
   DCORA_HIP(hipStreamSynchronize(st));
+  std::memcpy(Xh, x_stage, B);
   return DCORA_OK;
 }
 
