@@ -2,7 +2,11 @@
 #include "host_sparse.h"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <queue>
@@ -146,19 +150,27 @@ void leaf_order(const NDGraph &G, const std::vector<int> &nodes, std::vector<int
 }
 
 void nd_recurse(const NDGraph &G, std::vector<int> nodes, std::vector<int> &comp_id, int &next_cid,
-                std::vector<int> &level, std::vector<int> &out, std::vector<int> &cuts, int leaf_nodes) {
-  // iterative worklist: (nodes) ; output order is built back-to-front: separators last
-  struct Item {
-    std::vector<int> nodes;
-  };
+                std::vector<int> &level, std::vector<int> &out, std::vector<int> &cuts, int leaf_nodes,
+                int task_nodes, std::vector<std::pair<int, int>> &tasks) {
+  // iterative worklist: (nodes) ; output order is built back-to-front: separators last.
+  // A component and everything dissected out of it occupy one contiguous run of the order; maximal components of
+  // at most task_nodes nodes are reported as independent tasks (their columns depend on nothing outside the run).
   std::vector<std::vector<int>> stack;
+  std::vector<char> stack_in_task;
   std::vector<int> rev;  // reversed elimination order
   stack.push_back(std::move(nodes));
+  stack_in_task.push_back(0);
   std::vector<int> order;
   while (!stack.empty()) {
     std::vector<int> cur = std::move(stack.back());
+    char in_task = stack_in_task.back();
     stack.pop_back();
+    stack_in_task.pop_back();
     if (cur.empty()) continue;
+    if (!in_task && (int)cur.size() <= task_nodes) {
+      tasks.emplace_back((int)rev.size(), (int)cur.size());
+      in_task = 1;
+    }
     const int cid = next_cid++;
     for (int u : cur) {
       comp_id[u] = cid;
@@ -184,6 +196,8 @@ void nd_recurse(const NDGraph &G, std::vector<int> nodes, std::vector<int> &comp
       for (int u : cur) comp_id[u] = -1;
       stack.push_back(std::move(rest));
       stack.push_back(std::move(reached));
+      stack_in_task.push_back(in_task);
+      stack_in_task.push_back(in_task);
       continue;
     }
     for (int sweep = 0; sweep < 2; ++sweep) {
@@ -216,10 +230,13 @@ void nd_recurse(const NDGraph &G, std::vector<int> nodes, std::vector<int> &comp
     for (int u : cur) comp_id[u] = -1;
     stack.push_back(std::move(left));
     stack.push_back(std::move(right));
+    stack_in_task.push_back(in_task);
+    stack_in_task.push_back(in_task);
   }
   for (auto it = rev.rbegin(); it != rev.rend(); ++it) out.push_back(*it);
   // cuts were taken in the reversed order: position p there is position total - p in the final order
   const int total = (int)rev.size();
+  for (auto &t : tasks) t.first = total - t.first - t.second;  // (start, size) in the final order
   for (int &c : cuts) c = total - c;
   cuts.push_back(0);
   cuts.push_back(total);
@@ -228,7 +245,8 @@ void nd_recurse(const NDGraph &G, std::vector<int> nodes, std::vector<int> &comp
 }
 }  // namespace
 
-std::vector<int> amd_like_order(const HostCsr &A, int block, std::vector<int> *pieces, int *nhub_cols) {
+std::vector<int> amd_like_order(const HostCsr &A, int block, std::vector<int> *pieces, int *nhub_cols,
+                                std::vector<std::pair<int, int>> *col_tasks, int want_tasks) {
   const int n = A.n;
   if (block < 1) block = 1;
   const int nb = (n + block - 1) / block;
@@ -263,7 +281,14 @@ std::vector<int> amd_like_order(const HostCsr &A, int block, std::vector<int> *p
   std::vector<int> cuts;
   // leaf sub-domains of ~96 unknowns: 24 pose blocks, or 96 scalar unknowns when the graph is not block-compressed
   const int leaf_nodes = std::max(24, 96 / block);
-  nd_recurse(G, all, comp_id, next_cid, level, border, cuts, leaf_nodes);
+  std::vector<std::pair<int, int>> tasks;
+  const int task_nodes = (col_tasks && want_tasks > 1) ? std::max(4 * leaf_nodes, (int)all.size() / want_tasks) : 0;
+  nd_recurse(G, all, comp_id, next_cid, level, border, cuts, leaf_nodes, task_nodes, tasks);
+  if (col_tasks) {
+    col_tasks->clear();
+    for (const auto &t : tasks)
+      col_tasks->emplace_back(std::min(n, t.first * block), std::min(n, (t.first + t.second) * block));
+  }
   if (!hubs.empty()) {
     border.insert(border.end(), hubs.begin(), hubs.end());
     cuts.push_back(nb);
@@ -295,7 +320,16 @@ bool SparseChol::factor(const HostCsr &A, int block) {
   n_ = A.n;
   ok_ = false;
   const int n = n_;
-  perm_ = amd_like_order(A, block, &pieces_, &nhub_);
+  // sub-tree parallel numeric phase for matrices that are worth it
+  unsigned hw = std::thread::hardware_concurrency();
+  int nthreads = (n >= 4096) ? (int)std::max(1u, std::min(hw, 16u)) : 1;
+  if (const char *e = std::getenv("DCORA_FACTOR_THREADS")) nthreads = std::max(1, atoi(e));
+  std::vector<std::pair<int, int>> tasks;
+  perm_ = amd_like_order(A, block, &pieces_, &nhub_, &tasks, 4 * nthreads);
+  const bool timing = std::getenv("DCORA_FACTOR_TIMING") != nullptr;
+  auto tnow = [] { return std::chrono::steady_clock::now(); };
+  auto tms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  const auto T0 = tnow();
   iperm_.assign(n, 0);
   for (int i = 0; i < n; ++i) iperm_[perm_[i]] = i;
   // upper triangle of P A P^T by columns
@@ -323,6 +357,7 @@ bool SparseChol::factor(const HostCsr &A, int block) {
       }
     }
   }
+  const auto T1 = tnow();
   std::vector<int> parent(n, -1), anc(n, -1);
   for (int k = 0; k < n; ++k)
     for (int p = Cp[k]; p < Cp[k + 1]; ++p) {
@@ -346,16 +381,22 @@ bool SparseChol::factor(const HostCsr &A, int block) {
       }
     }
   }
+  const auto T2 = tnow();
   Lp_.assign(n + 1, 0);
   for (int j = 0; j < n; ++j) Lp_[j + 1] = Lp_[j] + cnt[j];
   Li_.assign(Lp_[n], 0);
   Lx_.assign(Lp_[n], 0.0);
-  std::vector<int> fill(Lp_.begin(), Lp_.end() - 1), stk(n), pat(n);
-  std::vector<double> x(n, 0.0);
-  std::fill(mark.begin(), mark.end(), -1);
-  for (int k = 0; k < n; ++k) {
+  std::vector<int> fill(Lp_.begin(), Lp_.end() - 1);
+  // Row k of L only needs the columns of its elimination sub-tree, so disjoint dissection sub-trees (col_tasks) are
+  // factorised by separate threads; the separators above them follow in order on the calling thread.
+  struct Work {
+    std::vector<int> mark, stk, pat;
+    std::vector<double> x;
+    explicit Work(int n) : mark(n, -1), stk(n), pat(n), x(n, 0.0) {}
+  };
+  auto process_row = [&](int k, Work &w) -> bool {
     int top = n;
-    mark[k] = k;
+    w.mark[k] = k;
     double dk = 0;
     for (int p = Cp[k]; p < Cp[k + 1]; ++p) {
       int i = Ci[p];
@@ -363,20 +404,20 @@ bool SparseChol::factor(const HostCsr &A, int block) {
         dk += Cx[p];
         continue;
       }
-      x[i] += Cx[p];
+      w.x[i] += Cx[p];
       int len = 0;
-      while (mark[i] != k) {
-        stk[len++] = i;
-        mark[i] = k;
+      while (w.mark[i] != k) {
+        w.stk[len++] = i;
+        w.mark[i] = k;
         i = parent[i];
       }
-      while (len > 0) pat[--top] = stk[--len];
+      while (len > 0) w.pat[--top] = w.stk[--len];
     }
     for (; top < n; ++top) {
-      const int i = pat[top];
-      const double lki = x[i] / Lx_[Lp_[i]];
-      x[i] = 0;
-      for (int p = Lp_[i] + 1; p < fill[i]; ++p) x[Li_[p]] -= Lx_[p] * lki;
+      const int i = w.pat[top];
+      const double lki = w.x[i] / Lx_[Lp_[i]];
+      w.x[i] = 0;
+      for (int p = Lp_[i] + 1; p < fill[i]; ++p) w.x[Li_[p]] -= Lx_[p] * lki;
       dk -= lki * lki;
       const int q = fill[i]++;
       Li_[q] = k;
@@ -386,7 +427,45 @@ bool SparseChol::factor(const HostCsr &A, int block) {
     const int q = fill[k]++;
     Li_[q] = k;
     Lx_[q] = std::sqrt(dk);
+    return true;
+  };
+  const auto T3 = tnow();
+  std::vector<char> in_task(n, 0);
+  std::atomic<bool> failed(false);
+  if (tasks.size() > 1 && nthreads > 1) {
+    std::sort(tasks.begin(), tasks.end(),
+              [](const auto &a, const auto &b) { return a.second - a.first > b.second - b.first; });
+    for (const auto &t : tasks)
+      for (int k = t.first; k < t.second; ++k) in_task[k] = 1;
+    std::atomic<int> next(0);
+    auto worker = [&]() {
+      Work w(n);
+      for (;;) {
+        const int ti = next.fetch_add(1);
+        if (ti >= (int)tasks.size() || failed.load()) break;
+        for (int k = tasks[ti].first; k < tasks[ti].second; ++k)
+          if (!process_row(k, w)) {
+            failed.store(true);
+            break;
+          }
+      }
+    };
+    const int nt = std::min<int>(nthreads, (int)tasks.size());
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(worker);
+    worker();
+    for (auto &t : th) t.join();
+    if (failed.load()) return false;
   }
+  const auto T4 = tnow();
+  {
+    Work w(n);
+    for (int k = 0; k < n; ++k)
+      if (!in_task[k] && !process_row(k, w)) return false;
+  }
+  if (timing)
+    std::fprintf(stderr, "[factor] n %d nnzL %d: permute %.2f, etree+counts %.2f, alloc %.2f, subtrees (%zu tasks, %d thr) %.2f, top %.2f ms\n",
+                 n, Lp_[n], tms(T0, T1), tms(T1, T2), tms(T2, T3), tasks.size(), nthreads, tms(T3, T4), tms(T4, tnow()));
   ok_ = true;
   return true;
 }

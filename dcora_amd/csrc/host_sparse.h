@@ -4,6 +4,7 @@
 // (ref src/DCORA_utils.cpp:1737-1747).  Setup-time code; the per-iteration path never comes here.
 #pragma once
 #include <cstddef>
+#include <utility>
 #include <vector>
 
 namespace dcora {
@@ -65,7 +66,10 @@ class SparseChol {
 };
 
 // nested-dissection order; pieces (optional) receives the column boundaries of the leaves / separators
+// col_tasks (optional): about want_tasks disjoint column ranges [begin, end) of the order, each closed under
+// elimination dependencies (a dissection sub-tree): they can be factorised independently of each other
 std::vector<int> amd_like_order(const HostCsr &A, int block, std::vector<int> *pieces = nullptr,
-                                int *nhub_cols = nullptr);
+                                int *nhub_cols = nullptr, std::vector<std::pair<int, int>> *col_tasks = nullptr,
+                                int want_tasks = 0);
 
 }  // namespace dcora

@@ -70,6 +70,9 @@ int RbcdSession::init(const HostDataset &ds, const dcora_rbcd_options &o) {
   std::memset((void *)eval_host, 0, sizeof(EvalOut));
   DCORA_HIP(hipHostGetDevicePointer((void **)&eval_dev, (void *)eval_host, 0));
   DCORA_HIP(hipHostMalloc((void **)&x_stage, sizeof(double) * N, hipHostMallocDefault));
+  // the first device-to-host copy of a process pays ~8 ms of runtime set-up: pay it here, not in get_X
+  DCORA_HIP(hipMemcpyAsync(x_stage, Xg.p, sizeof(double) * N, hipMemcpyDeviceToHost, st));
+  DCORA_HIP(hipStreamSynchronize(st));
   DCORA_HIP(evalbuf.alloc(2 * R + 16));
   DCORA_HIP(hipMemset(evalbuf.p, 0, sizeof(double) * (2 * R + 16)));
 

@@ -11,7 +11,10 @@ X0 = np.zeros((r, 4 * ds.n)); X0[:3] = T
 s = da.RbcdSession(ds, num_robots=5, r=r)
 s.set_X(X0)
 t = time.perf_counter(); out = s.run(max_iters=1000, rgrad_tol=0.1); t_run = time.perf_counter() - t
+t = time.perf_counter(); s.synchronize(); t_sync = time.perf_counter() - t
 t = time.perf_counter(); X = s.get_X(); t_get = time.perf_counter() - t
+t = time.perf_counter(); X = s.get_X(); t_get2 = time.perf_counter() - t
+print("sync after run %.2f ms, get_X %.2f ms, get_X again %.2f ms" % (1e3 * t_sync, 1e3 * t_get, 1e3 * t_get2))
 Q = da.build_Q_pgo(ds)
 for rep in range(3):
     t = time.perf_counter(); S = da.dual_certificate(r, ds.d, ds.n, X, Q); t_s = time.perf_counter() - t
