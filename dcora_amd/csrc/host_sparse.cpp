@@ -151,21 +151,33 @@ void leaf_order(const NDGraph &G, const std::vector<int> &nodes, std::vector<int
 
 void nd_recurse(const NDGraph &G, std::vector<int> nodes, std::vector<int> &comp_id, int &next_cid,
                 std::vector<int> &level, std::vector<int> &out, std::vector<int> &cuts, int leaf_nodes,
-                int task_nodes, std::vector<std::pair<int, int>> &tasks) {
+                int task_nodes, std::vector<std::pair<int, int>> &tasks,
+                std::vector<std::vector<std::pair<int, int>>> &sep_waves) {
   // iterative worklist: (nodes) ; output order is built back-to-front: separators last.
   // A component and everything dissected out of it occupy one contiguous run of the order; maximal components of
   // at most task_nodes nodes are reported as independent tasks (their columns depend on nothing outside the run).
+  // Separators above the tasks are reported by depth (sep_waves[depth]): separators of one depth head disjoint
+  // sub-trees, so a wave can be factorised concurrently once everything deeper is done.
   std::vector<std::vector<int>> stack;
   std::vector<char> stack_in_task;
+  std::vector<int> stack_depth;
   std::vector<int> rev;  // reversed elimination order
   stack.push_back(std::move(nodes));
   stack_in_task.push_back(0);
+  stack_depth.push_back(0);
   std::vector<int> order;
+  auto note_sep = [&](int dep, int start, int count) {
+    if (task_nodes <= 0 || count <= 0) return;
+    if ((int)sep_waves.size() <= dep) sep_waves.resize(dep + 1);
+    sep_waves[dep].emplace_back(start, count);
+  };
   while (!stack.empty()) {
     std::vector<int> cur = std::move(stack.back());
     char in_task = stack_in_task.back();
+    const int dep = stack_depth.back();
     stack.pop_back();
     stack_in_task.pop_back();
+    stack_depth.pop_back();
     if (cur.empty()) continue;
     if (!in_task && (int)cur.size() <= task_nodes) {
       tasks.emplace_back((int)rev.size(), (int)cur.size());
@@ -198,6 +210,8 @@ void nd_recurse(const NDGraph &G, std::vector<int> nodes, std::vector<int> &comp
       stack.push_back(std::move(reached));
       stack_in_task.push_back(in_task);
       stack_in_task.push_back(in_task);
+      stack_depth.push_back(dep);
+      stack_depth.push_back(dep);
       continue;
     }
     for (int sweep = 0; sweep < 2; ++sweep) {
@@ -209,6 +223,7 @@ void nd_recurse(const NDGraph &G, std::vector<int> nodes, std::vector<int> &comp
     if (depth < 2) {
       std::vector<int> lo;
       leaf_order(G, cur, comp_id, cid, lo);
+      if (!in_task) note_sep(dep, (int)rev.size(), (int)lo.size());
       for (auto it = lo.rbegin(); it != lo.rend(); ++it) rev.push_back(*it);
       cuts.push_back((int)rev.size());
       for (int u : cur) comp_id[u] = -1;
@@ -218,6 +233,7 @@ void nd_recurse(const NDGraph &G, std::vector<int> nodes, std::vector<int> &comp
     const int mid = level[order[order.size() / 2]];
     const int sep_level = std::min(std::max(mid, 1), depth - 1);
     std::vector<int> left, right;
+    const int sep_start = (int)rev.size();
     for (int u : order) {
       if (level[u] == sep_level)
         rev.push_back(u);  // separators are eliminated last
@@ -227,16 +243,21 @@ void nd_recurse(const NDGraph &G, std::vector<int> nodes, std::vector<int> &comp
         right.push_back(u);
     }
     cuts.push_back((int)rev.size());
+    if (!in_task) note_sep(dep, sep_start, (int)rev.size() - sep_start);
     for (int u : cur) comp_id[u] = -1;
     stack.push_back(std::move(left));
     stack.push_back(std::move(right));
     stack_in_task.push_back(in_task);
     stack_in_task.push_back(in_task);
+    stack_depth.push_back(dep + 1);
+    stack_depth.push_back(dep + 1);
   }
   for (auto it = rev.rbegin(); it != rev.rend(); ++it) out.push_back(*it);
   // cuts were taken in the reversed order: position p there is position total - p in the final order
   const int total = (int)rev.size();
   for (auto &t : tasks) t.first = total - t.first - t.second;  // (start, size) in the final order
+  for (auto &wv : sep_waves)
+    for (auto &t : wv) t.first = total - t.first - t.second;
   for (int &c : cuts) c = total - c;
   cuts.push_back(0);
   cuts.push_back(total);
@@ -246,7 +267,8 @@ void nd_recurse(const NDGraph &G, std::vector<int> nodes, std::vector<int> &comp
 }  // namespace
 
 std::vector<int> amd_like_order(const HostCsr &A, int block, std::vector<int> *pieces, int *nhub_cols,
-                                std::vector<std::pair<int, int>> *col_tasks, int want_tasks) {
+                                std::vector<std::pair<int, int>> *col_tasks, int want_tasks,
+                                std::vector<std::vector<std::pair<int, int>>> *col_waves) {
   const int n = A.n;
   if (block < 1) block = 1;
   const int nb = (n + block - 1) / block;
@@ -283,11 +305,20 @@ std::vector<int> amd_like_order(const HostCsr &A, int block, std::vector<int> *p
   const int leaf_nodes = std::max(24, 96 / block);
   std::vector<std::pair<int, int>> tasks;
   const int task_nodes = (col_tasks && want_tasks > 1) ? std::max(4 * leaf_nodes, (int)all.size() / want_tasks) : 0;
-  nd_recurse(G, all, comp_id, next_cid, level, border, cuts, leaf_nodes, task_nodes, tasks);
+  std::vector<std::vector<std::pair<int, int>>> waves;
+  nd_recurse(G, all, comp_id, next_cid, level, border, cuts, leaf_nodes, task_nodes, tasks, waves);
   if (col_tasks) {
     col_tasks->clear();
     for (const auto &t : tasks)
       col_tasks->emplace_back(std::min(n, t.first * block), std::min(n, (t.first + t.second) * block));
+  }
+  if (col_waves) {
+    col_waves->clear();
+    for (const auto &wv : waves) {
+      col_waves->emplace_back();
+      for (const auto &t : wv)
+        col_waves->back().emplace_back(std::min(n, t.first * block), std::min(n, (t.first + t.second) * block));
+    }
   }
   if (!hubs.empty()) {
     border.insert(border.end(), hubs.begin(), hubs.end());
@@ -325,7 +356,8 @@ bool SparseChol::factor(const HostCsr &A, int block) {
   int nthreads = (n >= 4096) ? (int)std::max(1u, std::min(hw, 16u)) : 1;
   if (const char *e = std::getenv("DCORA_FACTOR_THREADS")) nthreads = std::max(1, atoi(e));
   std::vector<std::pair<int, int>> tasks;
-  perm_ = amd_like_order(A, block, &pieces_, &nhub_, &tasks, 4 * nthreads);
+  std::vector<std::vector<std::pair<int, int>>> waves;  // separators above the tasks, by dissection depth
+  perm_ = amd_like_order(A, block, &pieces_, &nhub_, &tasks, 4 * nthreads, &waves);
   const bool timing = std::getenv("DCORA_FACTOR_TIMING") != nullptr;
   auto tnow = [] { return std::chrono::steady_clock::now(); };
   auto tms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -456,6 +488,32 @@ bool SparseChol::factor(const HostCsr &A, int block) {
     worker();
     for (auto &t : th) t.join();
     if (failed.load()) return false;
+    // the separators above the tasks, deepest wave first; the separators of one wave are independent
+    for (int dep = (int)waves.size() - 1; dep >= 1; --dep) {
+      std::vector<std::pair<int, int>> &wv = waves[dep];
+      if (wv.size() < 2) break;  // from here up the calling thread does the rest in order
+      for (const auto &t : wv)
+        for (int k = t.first; k < t.second; ++k) in_task[k] = 1;
+      std::atomic<int> nxt(0);
+      auto wworker = [&]() {
+        Work w(n);
+        for (;;) {
+          const int ti = nxt.fetch_add(1);
+          if (ti >= (int)wv.size() || failed.load()) break;
+          for (int k = wv[ti].first; k < wv[ti].second; ++k)
+            if (!process_row(k, w)) {
+              failed.store(true);
+              break;
+            }
+        }
+      };
+      const int wt = std::min<int>(nthreads, (int)wv.size());
+      std::vector<std::thread> wth;
+      for (int t = 1; t < wt; ++t) wth.emplace_back(wworker);
+      wworker();
+      for (auto &t : wth) t.join();
+      if (failed.load()) return false;
+    }
   }
   const auto T4 = tnow();
   {

@@ -70,6 +70,7 @@ class SparseChol {
 // elimination dependencies (a dissection sub-tree): they can be factorised independently of each other
 std::vector<int> amd_like_order(const HostCsr &A, int block, std::vector<int> *pieces = nullptr,
                                 int *nhub_cols = nullptr, std::vector<std::pair<int, int>> *col_tasks = nullptr,
-                                int want_tasks = 0);
+                                int want_tasks = 0,
+                                std::vector<std::vector<std::pair<int, int>>> *col_waves = nullptr);
 
 }  // namespace dcora
