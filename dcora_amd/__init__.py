@@ -143,7 +143,36 @@ class RADataset:
         x0 = np.zeros(self.d * self.k)
         check(L.dcora_radataset_odometry_init(h, init_seed, x0))
         self.X_odom = unF(x0, self.d, self.k)
+        # ownership of the merged variables and every robot's columns in its own RA ordering
+        # (ref src/DCORA_utils.cpp:1370-1512, src/Graph.cpp:584-616, 1092-1097)
+        self.pose_robot = np.zeros(max(self.n, 1), np.int32)
+        self.sphere_robot = np.zeros(max(self.l, 1), np.int32)
+        self.landmark_robot = np.zeros(max(self.b, 1), np.int32)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        check(L.dcora_radataset_ownership(h, vp(self.pose_robot), vp(self.sphere_robot), vp(self.landmark_robot)))
+        self.pose_robot, self.sphere_robot = self.pose_robot[:self.n], self.sphere_robot[:self.l]
+        self.landmark_robot = self.landmark_robot[:self.b]
+        self.robots = sorted(set(self.pose_robot.tolist()))
+        self.agent_columns = {}
+        for rb in sorted(set(self.robots) | set(self.landmark_robot.tolist())):
+            dims3, own, ka = np.zeros(3, np.int32), np.zeros(self.k, np.int32), C.c_int()
+            check(L.dcora_radataset_agent_columns(h, rb, dims3, vp(own), C.byref(ka)))
+            self.agent_columns[rb] = (tuple(int(x) for x in dims3), own[:ka.value].copy())
         L.dcora_radataset_destroy(h)
+
+    def agent_blocks(self, robot, Q=None):
+        """(n_a, l_a, b_a), own columns, Q_aa (Csr, agent ordering), coupling C (scipy k_a x k, global columns):
+        the agent's local problem is 1/2 <Q_aa, X_a^T X_a> + <X_a, X_global C^T>"""
+        import scipy.sparse as sp
+        Q = self.Q if Q is None else Q
+        dims3, own = self.agent_columns[robot]
+        own = np.ascontiguousarray(own, np.int32)
+        qa, cc = C.c_void_p(), C.c_void_p()
+        check(capi.lib().dcora_graph_extract_agent_blocks(Q.n, Q.rp, Q.ci, Q.v, own.size, own, C.byref(qa),
+                                                          C.byref(cc)))
+        Qaa = Csr(*capi.take_csr(qa))
+        ka, rp, ci, v = capi.take_csr(cc)
+        return dims3, own, Qaa, sp.csr_matrix((v, ci, rp), shape=(ka, Q.n))
 
 
 def precond_regularization(Q, device=0):

@@ -103,6 +103,10 @@ SIGNATURES = {
     "dcora_radataset_ground_truth": (C.c_int, [_vp, _dp]),
     "dcora_radataset_build_Q": (C.c_int, [_vp, C.POINTER(_vp)]),
     "dcora_radataset_odometry_init": (C.c_int, [_vp, C.c_ulonglong, _dp]),
+    "dcora_radataset_ownership": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "dcora_radataset_agent_columns": (C.c_int, [_vp, C.c_int, _ip, _vp, _PI]),
+    "dcora_graph_extract_agent_blocks": (C.c_int, [C.c_int, _ip, _ip, _dp, C.c_int, _ip, C.POINTER(_vp),
+                                                   C.POINTER(_vp)]),
     "dcora_radataset_destroy": (C.c_int, [_vp]),
     "dcora_graph_precond_regularization": (C.c_int, [C.c_int, _ip, _ip, _dp, C.c_int, _PD]),
     "dcora_rbcd_options_default": (None, [C.POINTER(RbcdOptions)]),

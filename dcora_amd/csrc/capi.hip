@@ -400,6 +400,36 @@ int dcora_radataset_odometry_init(dcora_radataset_t h, unsigned long long seed, 
   return DCORA_OK;
   DCORA_CATCH
 }
+int dcora_radataset_ownership(dcora_radataset_t h, int *pose_robot, int *sphere_robot, int *landmark_robot) {
+  if (!h) return bad("null");
+  if (pose_robot) std::copy(h->ds.pose_robot.begin(), h->ds.pose_robot.end(), pose_robot);
+  if (sphere_robot) std::copy(h->ds.sphere_robot.begin(), h->ds.sphere_robot.end(), sphere_robot);
+  if (landmark_robot) std::copy(h->ds.landmark_robot.begin(), h->ds.landmark_robot.end(), landmark_robot);
+  return DCORA_OK;
+}
+int dcora_radataset_agent_columns(dcora_radataset_t h, int robot, int *dims3, int *own, int *k_a) {
+  if (!h || !dims3 || !k_a) return bad("null");
+  DCORA_TRY
+  std::vector<int> o;
+  ra_agent_columns(h->ds, robot, dims3, o);
+  *k_a = (int)o.size();
+  if (own) std::copy(o.begin(), o.end(), own);
+  return DCORA_OK;
+  DCORA_CATCH
+}
+int dcora_graph_extract_agent_blocks(int k, const int *rp, const int *ci, const double *v, int k_a, const int *own,
+                                     dcora_csr_t *Qaa, dcora_csr_t *C) {
+  if (!rp || !ci || !v || !own || !Qaa || !C) return bad("null argument");
+  for (int a = 0; a < k_a; ++a)
+    if (own[a] < 0 || own[a] >= k) return bad("extract_agent_blocks: column index out of range");
+  DCORA_TRY
+  dcora_csr_s *q = new dcora_csr_s, *c = new dcora_csr_s;
+  extract_agent_blocks(view_csr(k, rp, ci, v), std::vector<int>(own, own + k_a), &q->m, &c->m);
+  *Qaa = q;
+  *C = c;
+  return DCORA_OK;
+  DCORA_CATCH
+}
 int dcora_radataset_destroy(dcora_radataset_t h) {
   delete h;
   return DCORA_OK;

@@ -391,6 +391,16 @@ bool load_pyfg(const std::string &path, HostRADataset &ds, std::string &err) {
     m.l = sbase[e.a.robot] + e.robot_l;
     ds.ranges.push_back(m);
   }
+  // ownership (ref src/DCORA_utils.cpp:1370-1512, src/Graph.cpp:584-616, 1092-1097): a pose belongs to the robot
+  // of its symbol, a landmark to the robot named in its symbol ('M' = the map), a unit sphere to the SOURCE robot
+  // of its range measurement
+  ds.pose_robot.assign(ds.n, 0);
+  ds.landmark_robot.assign(ds.b, 0);
+  ds.sphere_robot.assign(ds.l, 0);
+  for (auto &kv : pidx) ds.pose_robot[kv.second] = kv.first.first;
+  for (auto &kv : lidx) ds.landmark_robot[kv.second] = kv.first.first;
+  for (auto &kv : nsph)
+    for (int q = 0; q < kv.second; ++q) ds.sphere_robot[sbase[kv.first] + q] = kv.first;
   const int k = ds.k();
   ds.gt.assign((size_t)d * k, 0.0);
   std::vector<const std::vector<double> *> prec(ds.n), lrec(ds.b);
@@ -477,4 +487,66 @@ HostCsr build_Q_ra(const HostRADataset &ds) {
   return csr_from_coo(k, k, I, J, V);
 }
 
+}  // namespace dcora
+
+namespace dcora {
+void ra_agent_columns(const HostRADataset &ds, int robot, int dims3[3], std::vector<int> &own) {
+  const int d = ds.d, n = ds.n, l = ds.l;
+  own.clear();
+  int na = 0, la = 0, ba = 0;
+  for (int i = 0; i < n; ++i)
+    if (ds.pose_robot[i] == robot) {
+      for (int c = 0; c < d; ++c) own.push_back(d * i + c);
+      ++na;
+    }
+  for (int s = 0; s < l; ++s)
+    if (ds.sphere_robot[s] == robot) {
+      own.push_back(d * n + s);
+      ++la;
+    }
+  for (int i = 0; i < n; ++i)
+    if (ds.pose_robot[i] == robot) own.push_back(d * n + l + i);
+  for (int j = 0; j < ds.b; ++j)
+    if (ds.landmark_robot[j] == robot) {
+      own.push_back(d * n + l + n + j);
+      ++ba;
+    }
+  dims3[0] = na;
+  dims3[1] = la;
+  dims3[2] = ba;
+  if (la == 0 && ba == 0) {
+    // this ABI reads l = b = 0 as the SE ordering [Y1 p1 ... Yn pn]: list the columns that way
+    own.clear();
+    for (int i = 0; i < n; ++i)
+      if (ds.pose_robot[i] == robot) {
+        for (int c = 0; c < d; ++c) own.push_back(d * i + c);
+        own.push_back(d * n + l + i);
+      }
+  }
+}
+
+void extract_agent_blocks(const HostCsr &Q, const std::vector<int> &own, HostCsr *Qaa, HostCsr *C) {
+  const int ka = (int)own.size();
+  std::vector<int> local((size_t)Q.n, -1);
+  for (int a = 0; a < ka; ++a) local[own[a]] = a;
+  std::vector<int> I1, J1, I2, J2;
+  std::vector<double> V1, V2;
+  for (int a = 0; a < ka; ++a) {
+    const int i = own[a];
+    for (int p = Q.rp[i]; p < Q.rp[i + 1]; ++p) {
+      const int j = Q.ci[p];
+      if (local[j] >= 0) {
+        I1.push_back(a);
+        J1.push_back(local[j]);
+        V1.push_back(Q.v[p]);
+      } else {
+        I2.push_back(a);
+        J2.push_back(j);
+        V2.push_back(Q.v[p]);
+      }
+    }
+  }
+  if (Qaa) *Qaa = csr_from_coo(ka, ka, I1, J1, V1);
+  if (C) *C = csr_from_coo(ka, Q.n, I2, J2, V2);
+}
 }  // namespace dcora

@@ -57,8 +57,17 @@ struct HostRADataset {
   std::vector<PoseLandmarkMeasH> pose_landmark;
   std::vector<RangeMeasH> ranges;
   std::vector<double> gt;  // d x k ground truth, RA ordering, column-major
+  // owner robot ('A' = 0, ..., 'M' = 12 the map) of every pose, unit sphere and landmark of the merged problem
+  std::vector<int> pose_robot, sphere_robot, landmark_robot;
   int k() const { return (d + 1) * n + l + b; }
 };
+// Columns (global RA ordering) owned by `robot`, listed in that agent's own RA ordering
+// [rotations of its poses | its unit spheres | translations of its poses | its landmarks]; dims3 = {n_a, l_a, b_a}
+void ra_agent_columns(const HostRADataset &ds, int robot, int dims3[3], std::vector<int> &own);
+// The agent's share of a global quadratic form: Qaa = Q[own, own] in the agent's ordering and the coupling
+// C = Q[own, everything else] with GLOBAL column indices, so that the agent's linear term is G_a = X_global C^T
+// (the same restriction the reference assembles edge by edge, ref src/Graph.cpp:824-1772)
+void extract_agent_blocks(const HostCsr &Q, const std::vector<int> &own, HostCsr *Qaa, HostCsr *C);
 // chordalInitialization (ref src/DCORA_solver.cpp:218-268): T is d x (d+1) n column-major, pose 0 = identity
 bool chordal_initialization(const HostDataset &ds, std::vector<double> &T);
 bool load_pyfg(const std::string &path, HostRADataset &out, std::string &err);

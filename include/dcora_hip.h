@@ -172,6 +172,19 @@ int dcora_radataset_build_Q(dcora_radataset_t ds, dcora_csr_t *Q);
  * pose, ground-truth unit spheres, landmarks uniform in (-1, 1) from a splitmix64 stream seeded with `seed`
  * (the reference draws them with Matrix::Random).  X0 is d x k in the RA ordering. */
 int dcora_radataset_odometry_init(dcora_radataset_t ds, unsigned long long seed, double *X0);
+/* Ownership of the merged problem's variables, as the reference splits a multi-robot pyfg file
+ * (getRobotMeasurements, ref src/DCORA_utils.cpp:1370-1512; landmark symbols, ref src/Graph.cpp:584-616; unit
+ * spheres belong to the SOURCE robot of their range measurement, ref :1092-1097).  Robot ids: 'A' = 0, 'B' = 1,
+ * ..., 'M' = 12 is the map.  Any output may be NULL. */
+int dcora_radataset_ownership(dcora_radataset_t ds, int *pose_robot, int *sphere_robot, int *landmark_robot);
+/* Columns of the global RA ordering owned by `robot`, listed in that agent's own RA ordering
+ * [rotations | unit spheres | translations | landmarks]; dims3 = {n_a, l_a, b_a}; own (k entries of room) may be NULL */
+int dcora_radataset_agent_columns(dcora_radataset_t ds, int robot, int *dims3, int *own, int *k_a);
+/* An agent's share of a global quadratic form Q (k x k): Qaa = Q[own, own] in the agent's ordering and the coupling
+ * C = Q[own, rest] (k_a x k, GLOBAL column indices), so that the agent's linear term is G_a = X_global C^T -- the
+ * restriction the reference assembles measurement by measurement (ref src/Graph.cpp:824-1772) */
+int dcora_graph_extract_agent_blocks(int k, const int *rowptr, const int *colidx, const double *vals, int k_a,
+                                     const int *own, dcora_csr_t *Qaa, dcora_csr_t *C);
 int dcora_radataset_destroy(dcora_radataset_t ds);
 /* Graph::computePreconditionerRegularization (ref src/Graph.cpp:1921-1960): reg = lambda_max(Q) / (1e6 - 1), lambda_max
  * by Lanczos (nev 1, ncv 6, tol 1e-3) on the device; falls back to 0.1 when the eigensolver does not converge */
