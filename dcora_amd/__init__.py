@@ -423,6 +423,23 @@ class RbcdSession:
                                             bn.ctypes.data_as(C.c_void_p), C.byref(nxt)))
         return c2.value, gn.value, bn, nxt.value
 
+    def iterate_set(self, agents, allow_adjacent=False):
+        """the agents of the set update at the same time from one snapshot of their neighbours' states"""
+        a = np.ascontiguousarray(agents, dtype=np.int32)
+        check(capi.lib().dcora_rbcd_iterate_set(self.h, a, a.size, int(allow_adjacent)))
+
+    def colours(self):
+        col, nc = np.zeros(self.R, np.int32), C.c_int()
+        check(capi.lib().dcora_rbcd_agent_colours(self.h, col, C.byref(nc)))
+        return col, nc.value
+
+    def evaluate(self):
+        c2, gn, nxt = C.c_double(), C.c_double(), C.c_int()
+        bn = np.zeros(self.R)
+        check(capi.lib().dcora_rbcd_evaluate(self.h, C.byref(c2), C.byref(gn), bn.ctypes.data_as(C.c_void_p),
+                                             C.byref(nxt)))
+        return c2.value, gn.value, bn, nxt.value
+
     def run(self, max_iters=1000, rgrad_tol=0.1):
         it = C.c_int()
         cost, gn = np.zeros(max_iters), np.zeros(max_iters)

@@ -509,6 +509,22 @@ int dcora_rbcd_run(dcora_rbcd_t s, int max_iters, double rgrad_tol, int *iters_d
   return DCORA_OK;
   DCORA_CATCH
 }
+int dcora_rbcd_iterate_set(dcora_rbcd_t s, const int *set, int count, int allow_adjacent) {
+  if (!s) return bad("null");
+  DCORA_TRY
+  return s->s.iterate_set(set, count, allow_adjacent);
+  DCORA_CATCH
+}
+int dcora_rbcd_agent_colours(dcora_rbcd_t s, int *colours, int *ncolours) {
+  if (!s || !colours) return bad("null");
+  return s->s.agent_colours(colours, ncolours);
+}
+int dcora_rbcd_evaluate(dcora_rbcd_t s, double *cost2, double *gradnorm, double *block_norms, int *next_selected) {
+  if (!s) return bad("null");
+  DCORA_TRY
+  return s->s.evaluate_central(cost2, gradnorm, block_norms, next_selected);
+  DCORA_CATCH
+}
 int dcora_rbcd_last_result(dcora_rbcd_t s, dcora_ropt_result *res) {
   if (!s || !res) return bad("null");
   return s->s.last_result(res);

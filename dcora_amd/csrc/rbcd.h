@@ -3,6 +3,7 @@
 // 535-596, 844-906, 1158-1278, and the loop body of examples/MultiRobotExample.cpp:223-307).
 #pragma once
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "device_problem.h"
@@ -17,6 +18,9 @@ struct AgentDev {
   DevCsr coupling;                      // rows: local columns, cols: global columns (hosted agents only)
   std::vector<int> public_poses;        // global pose indices of my public poses (all agents)
   DevBuf<int> public_cols;              // their global columns, (d+1) per pose (all agents)
+  std::vector<int> neighbors;           // agents sharing a measurement with me (all agents)
+  hipStream_t own = nullptr;            // stream of my solve when several agents update at once (hosted agents only;
+  hipEvent_t done = nullptr;            // both owned by the session)
 };
 
 class RbcdSession {
@@ -52,6 +56,10 @@ class RbcdSession {
   int evaluate_central(double *cost2, double *gradnorm, double *block_norms, int *next_selected);
   int phase_evaluate_dev(double *out_dev);
   int iterate(int selected, double *cost2, double *gradnorm, double *block_norms, int *next_selected);
+  // simultaneous Agent::iterate(true) of a set of agents from one snapshot of the neighbour states
+  int iterate_set(const int *set, int count, int allow_adjacent);
+  // greedy colouring of the agent graph: agents of one colour share no measurement
+  int agent_colours(int *colours, int *ncolours) const;
   int pack_public(int agent, double *packed_dev);
   int unpack_public(int agent, const double *packed_dev);
 
@@ -59,6 +67,8 @@ class RbcdSession {
   bool restart_now() const { return opt.acceleration && ((iteration + 1) % opt.restart_interval == 0); }
   void advance_sequences();
   bool seq_advanced_ = false;
+  hipEvent_t fork_ev_ = nullptr;
+  int solve_block(AgentDev &a, std::string *err);
 };
 
 }  // namespace dcora

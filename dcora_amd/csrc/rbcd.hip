@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <set>
+#include <thread>
 
 namespace dcora {
 
@@ -28,6 +29,11 @@ static void nesterov(hipStream_t st, const ManiDesc &m, int mode, int restart, i
 RbcdSession::~RbcdSession() {
   if (eval_host) (void)hipHostFree((void *)eval_host);
   if (x_stage) (void)hipHostFree((void *)x_stage);
+  for (AgentDev &a : agents) {
+    if (a.own) (void)hipStreamDestroy(a.own);
+    if (a.done) (void)hipEventDestroy(a.done);
+  }
+  if (fork_ev_) (void)hipEventDestroy(fork_ev_);
   agents.clear();
   central.reset();
   if (st) (void)hipStreamDestroy(st);
@@ -78,7 +84,7 @@ int RbcdSession::init(const HostDataset &ds, const dcora_rbcd_options &o) {
 
   // partition (ref examples/MultiRobotExample.cpp:56-118)
   std::vector<std::vector<PoseMeas>> touching(R);
-  std::vector<std::set<int>> pub(R);
+  std::vector<std::set<int>> pub(R), nb(R);
   for (const PoseMeas &mi : ds.meas) {
     PoseMeas e = mi;
     e.r1 = P.robot_of(mi.p1);
@@ -90,6 +96,8 @@ int RbcdSession::init(const HostDataset &ds, const dcora_rbcd_options &o) {
       touching[e.r2].push_back(e);
       pub[e.r1].insert(mi.p1);
       pub[e.r2].insert(mi.p2);
+      nb[e.r1].insert(e.r2);
+      nb[e.r2].insert(e.r1);
     }
   }
   std::vector<PoseMeas> global = ds.meas;
@@ -105,6 +113,7 @@ int RbcdSession::init(const HostDataset &ds, const dcora_rbcd_options &o) {
     cs[b] = a.col0;
     a.hosted = (b % o.world_size) == o.rank;
     a.public_poses.assign(pub[b].begin(), pub[b].end());
+    a.neighbors.assign(nb[b].begin(), nb[b].end());
     std::vector<int> cols;
     for (int p : a.public_poses)
       for (int c = 0; c < dh; ++c) cols.push_back(p * dh + c);
@@ -120,7 +129,10 @@ int RbcdSession::init(const HostDataset &ds, const dcora_rbcd_options &o) {
     HostCsr C = build_coupling_pgo(d, P, b, global);
     rc = a.coupling.upload(C);
     if (rc) return rc;
+    DCORA_HIP(hipStreamCreateWithFlags(&a.own, hipStreamNonBlocking));
+    DCORA_HIP(hipEventCreateWithFlags(&a.done, hipEventDisableTiming));
   }
+  DCORA_HIP(hipEventCreateWithFlags(&fork_ev_, hipEventDisableTiming));
   cs[R] = dh * n;
   {
     std::vector<int> ps(R + 1);
@@ -345,6 +357,130 @@ int RbcdSession::iterate(int selected, double *cost2, double *gradnorm, double *
   if (rc) return rc;
   // greedy selection only when the selected agent has neighbours (:290-292)
   if (next_selected) *next_selected = (agents[selected].coupling.nnz > 0) ? nxt : selected;
+  return DCORA_OK;
+}
+
+// Greedy colouring in agent order (smallest colour not used by a neighbour).  Agents of one colour share no
+// measurement, so their simultaneous updates equal the same updates done one after the other.
+int RbcdSession::agent_colours(int *colours, int *ncolours) const {
+  int nc = 0;
+  for (int b = 0; b < R; ++b) {
+    int c = 0;
+    for (bool clash = true; clash; c += clash) {
+      clash = false;
+      for (int q : agents[b].neighbors)
+        if (q < b && colours[q] == c) clash = true;
+    }
+    colours[b] = c;
+    nc = std::max(nc, c + 1);
+  }
+  if (ncolours) *ncolours = nc;
+  return DCORA_OK;
+}
+
+// local solve of one agent on its own stream, from the G / X0 staged by iterate_set; the accepted iterate goes
+// back into the global mirror without a host round trip when the solver keeps its choice on the device
+int RbcdSession::solve_block(AgentDev &a, std::string *err) {
+  auto fail = [&](int rc) {
+    if (err) *err = dcora_last_error();
+    return rc;
+  };
+  if (hipSetDevice(opt.device) != hipSuccess) return fail(DCORA_ERR_HIP);
+  DeviceProblem &pb = *a.prob;
+  const size_t off = (size_t)a.col0 * r;
+  const size_t B = sizeof(double) * (size_t)pb.nelem();
+  hipStream_t keep = pb.st;
+  pb.st = a.own;
+  Buf2 Xres{{nullptr, nullptr}};
+  const SolverCtl *cs = nullptr;
+  int rc = pb.optimize_dev(opt.local, &Xres, &cs);
+  if (!rc) {
+    if (cs && group_kernels(pb.m)) {
+      nesterov(a.own, pb.m, 3, 0, -1, -1, 0.0, 0.0, Xg.p + off, Vg.p + off, Yg.p + off, XPrevg.p + off, nullptr, Xres,
+               cs);
+    } else {
+      if (cs) {
+        dcora_ropt_result tmp;
+        rc = pb.fetch_result(&tmp);
+        Xres.p[0] = tmp.success && pb.result_index() ? pb.X1.p : pb.X0.p;
+      }
+      if (!rc && hipMemcpyAsync(Xg.p + off, Xres.p[0], B, hipMemcpyDeviceToDevice, a.own) != hipSuccess)
+        rc = DCORA_ERR_HIP;
+    }
+  }
+  if (!rc && hipEventRecord(a.done, a.own) != hipSuccess) rc = DCORA_ERR_HIP;
+  pb.st = keep;
+  return rc ? fail(rc) : DCORA_OK;
+}
+
+// One tick in which the agents of `set` run Agent::iterate(true) at the same time, every one of them seeing the
+// neighbour states as they were when the tick began (what concurrently firing agents of the asynchronous mode see,
+// ref src/Agent.cpp:650-678; non-accelerated like that mode, :651-653).  With a set of mutually non-adjacent
+// agents (one colour of agent_colours) the result equals updating them one after the other.
+int RbcdSession::iterate_set(const int *set, int count, int allow_adjacent) {
+  if (opt.acceleration) {
+    set_last_error("rbcd: simultaneous updates need acceleration off (ref src/Agent.cpp:651-653)");
+    return DCORA_ERR_UNSUPPORTED;
+  }
+  if (!set || count < 1 || count > R) {
+    set_last_error("rbcd: bad agent set");
+    return DCORA_ERR_BAD_ARG;
+  }
+  std::vector<char> in(R, 0);
+  for (int i = 0; i < count; ++i) {
+    if (set[i] < 0 || set[i] >= R || in[set[i]]) {
+      set_last_error("rbcd: agent set has an id out of range or twice");
+      return DCORA_ERR_BAD_ARG;
+    }
+    in[set[i]] = 1;
+  }
+  if (!allow_adjacent)
+    for (int i = 0; i < count; ++i)
+      for (int q : agents[set[i]].neighbors)
+        if (in[q]) {
+          set_last_error("rbcd: agents " + std::to_string(set[i]) + " and " + std::to_string(q) +
+                         " share measurements; pass allow_adjacent to update them from one snapshot anyway");
+          return DCORA_ERR_BAD_ARG;
+        }
+  DCORA_HIP(hipSetDevice(opt.device));
+  iteration++;
+  seq_advanced_ = false;
+  std::vector<AgentDev *> work;
+  for (int i = 0; i < count; ++i)
+    if (agents[set[i]].hosted) work.push_back(&agents[set[i]]);
+  if (work.empty()) return DCORA_OK;
+  // snapshot: every G and every start point is taken before any block is written back
+  for (AgentDev *a : work) {
+    DeviceProblem &pb = *a->prob;
+    const size_t off = (size_t)a->col0 * r;
+    const size_t B = sizeof(double) * (size_t)pb.nelem();
+    launch_spmm(st, r, a->coupling.view(), buf1(Xg.p), 0, nullptr, buf1(pb.G.p), 0, nullptr, Gate{});
+    pb.has_G = true;
+    DCORA_HIP(hipMemcpyAsync(XPrevg.p + off, Xg.p + off, B, hipMemcpyDeviceToDevice, st));
+    DCORA_HIP(hipMemcpyAsync(pb.X0.p, Xg.p + off, B, hipMemcpyDeviceToDevice, st));
+  }
+  DCORA_HIP(hipEventRecord(fork_ev_, st));
+  for (AgentDev *a : work) DCORA_HIP(hipStreamWaitEvent(a->own, fork_ev_, 0));
+  std::vector<int> rcs(work.size(), DCORA_OK);
+  std::vector<std::string> errs(work.size());
+  if (work.size() == 1) {
+    rcs[0] = solve_block(*work[0], &errs[0]);
+  } else {
+    // the solver paces each solve from the host (device_problem.hip): one host thread per concurrent solve
+    std::vector<std::thread> th;
+    for (size_t i = 1; i < work.size(); ++i)
+      th.emplace_back([&, i] { rcs[i] = solve_block(*work[i], &errs[i]); });
+    rcs[0] = solve_block(*work[0], &errs[0]);
+    for (std::thread &t : th) t.join();
+  }
+  last_solver = work.back()->prob.get();
+  for (size_t i = 0; i < work.size(); ++i) {
+    if (rcs[i]) {
+      set_last_error(errs[i]);
+      return rcs[i];
+    }
+    DCORA_HIP(hipStreamWaitEvent(st, work[i]->done, 0));
+  }
   return DCORA_OK;
 }
 

@@ -222,6 +222,18 @@ int dcora_rbcd_iterate(dcora_rbcd_t s, int selected, double *cost2, double *grad
 /* runs up to max_iters passes, stopping when |rgrad| < rgrad_tol; fills the trace arrays (may be NULL) */
 int dcora_rbcd_run(dcora_rbcd_t s, int max_iters, double rgrad_tol, int *iters_done, double *cost2_trace,
                    double *gradnorm_trace, int *selected_trace);
+/* One tick in which the `count` agents of `set` run Agent::iterate(true) at the same time, each on its own HIP
+ * stream, every one of them reading the neighbour states as they were when the tick began: what agents that fire
+ * together see in the asynchronous mode (Agent::runOptimizationLoop, ref src/Agent.cpp:650-678).  Needs
+ * acceleration off, as that mode does (:651-653).  Agents of the set that share measurements are refused unless
+ * allow_adjacent != 0; for mutually non-adjacent agents (one colour of dcora_rbcd_agent_colours) the tick equals
+ * updating them one after the other with dcora_rbcd_iterate.  Multi-process: every rank passes the same set and
+ * solves the agents it hosts; the caller exchanges public poses afterwards. */
+int dcora_rbcd_iterate_set(dcora_rbcd_t s, const int *set, int count, int allow_adjacent);
+/* greedy colouring of the agent graph (agents adjacent when they share a measurement): colours[num_robots] */
+int dcora_rbcd_agent_colours(dcora_rbcd_t s, int *colours, int *ncolours);
+/* the central evaluation of dcora_rbcd_iterate alone (ref examples/MultiRobotExample.cpp:264-305); world_size 1 */
+int dcora_rbcd_evaluate(dcora_rbcd_t s, double *cost2, double *gradnorm, double *block_norms, int *next_selected);
 /* statistics of the last selected agent's local solve */
 int dcora_rbcd_last_result(dcora_rbcd_t s, dcora_ropt_result *res);
 
