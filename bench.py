@@ -74,100 +74,179 @@ def run_single(args, da, torch, ds, X0):
     return s, dt, c2, gn
 
 
-def run_multi(args, da, torch, dist, ds, X0, rank, world):
-    """one process per GPU; agent a is hosted by rank a % world"""
-    import ctypes as C
-    ndev = torch.cuda.device_count()
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)) % max(ndev, 1))
-    staged = dist.get_backend() != "nccl"  # rehearsal on one GPU: collectives over gloo through host staging
-    R, r, dh = args.robots, args.rank_r, ds.d + 1
-    s = da.RbcdSession(ds, num_robots=R, r=r, rank=rank, world_size=world, device=dev.index)
-    s.set_X(X0)
-    counts = [s.public_count(a) for a in range(R)]
-    slot = r * dh * max(counts)              # doubles per agent in the exchange buffers
-    per_rank = (R + world - 1) // world      # agent a lives on rank a % world, in slot a // world of that rank
-    owner = [a % world for a in range(R)]
-    mine = torch.zeros(per_rank * slot, dtype=torch.float64, device=dev)
-    everyone = torch.zeros(world * per_rank * slot, dtype=torch.float64, device=dev)
-    one = torch.zeros(slot, dtype=torch.float64, device=dev)
-    evalbuf = torch.zeros(2 * R, dtype=torch.float64, device=dev)
-    esz = mine.element_size()
+class RankDriver:
+    """one process per GPU; agent a is hosted by rank a % world.  The exchanges between the phases of an iteration
+    are the caller's (this class): RCCL collectives over packed public poses."""
 
-    def allgather(dst, src):
-        if staged:
-            parts = [torch.zeros(src.numel(), dtype=src.dtype) for _ in range(world)]
-            dist.all_gather(parts, src.cpu())
-            dst.copy_(torch.cat(parts))
+    def __init__(self, da, torch, dist, ds, R, r, rank, world, acceleration=True):
+        self.torch, self.dist, self.rank, self.world, self.R = torch, dist, rank, world, R
+        ndev = torch.cuda.device_count()
+        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)) % max(ndev, 1))
+        self.dev = dev
+        self.staged = dist.get_backend() != "nccl"  # rehearsal on one GPU: gloo through host staging
+        dh = ds.d + 1
+        t0 = time.perf_counter()
+        self.s = s = da.RbcdSession(ds, num_robots=R, r=r, acceleration=acceleration, rank=rank, world_size=world,
+                                    device=dev.index)
+        self.setup_s = time.perf_counter() - t0
+        counts = [s.public_count(a) for a in range(R)]
+        self.slot = slot = r * dh * max(counts)       # doubles per agent in the exchange buffers
+        self.per_rank = per_rank = (R + world - 1) // world  # agent a: rank a % world, slot a // world of that rank
+        self.owner = [a % world for a in range(R)]
+        self.mine = torch.zeros(per_rank * slot, dtype=torch.float64, device=dev)
+        self.everyone = torch.zeros(world * per_rank * slot, dtype=torch.float64, device=dev)
+        self.one = torch.zeros(slot, dtype=torch.float64, device=dev)
+        self.evalbuf = torch.zeros(2 * R, dtype=torch.float64, device=dev)
+        self.esz = self.mine.element_size()
+
+    def allgather(self, dst, src):
+        if self.staged:
+            parts = [self.torch.zeros(src.numel(), dtype=src.dtype) for _ in range(self.world)]
+            self.dist.all_gather(parts, src.cpu())
+            dst.copy_(self.torch.cat(parts))
         else:
-            dist.all_gather_into_tensor(dst, src)
+            self.dist.all_gather_into_tensor(dst, src)
 
-    def bcast(t, src):
-        if staged:
+    def bcast(self, t, src):
+        if self.staged:
             h = t.cpu()
-            dist.broadcast(h, src=src)
+            self.dist.broadcast(h, src=src)
             t.copy_(h)
         else:
-            dist.broadcast(t, src=src)
+            self.dist.broadcast(t, src=src)
 
-    def allreduce(t):
-        if staged:
+    def allreduce(self, t):
+        if self.staged:
             h = t.cpu()
-            dist.all_reduce(h)
+            self.dist.all_reduce(h)
             t.copy_(h)
         else:
-            dist.all_reduce(t)
+            self.dist.all_reduce(t)
 
-    def pull_all_but(selected):
-        # getSharedStateDicts of every agent but the selected one -> ONE all_gather of the packed public poses ->
-        # updateNeighborStates on the ranks that do not host them (ref examples/MultiRobotExample.cpp:236-258)
-        for a in range(R):
-            if a != selected and owner[a] == rank:
-                s.pack_public_dev(a, mine.data_ptr() + (a // world) * slot * esz)
+    def exchange(self, agents):
+        """getSharedStateDicts of `agents` -> ONE all_gather of the packed public poses -> updateNeighborStates on the
+        ranks that do not host them (ref examples/MultiRobotExample.cpp:236-258)"""
+        s, world, slot, esz = self.s, self.world, self.slot, self.esz
+        for a in agents:
+            if self.owner[a] == self.rank:
+                s.pack_public_dev(a, self.mine.data_ptr() + (a // world) * slot * esz)
         s.synchronize()
-        allgather(everyone, mine)
-        torch.cuda.synchronize()
-        for a in range(R):
-            if a != selected and owner[a] != rank:
-                s.unpack_public_dev(a, everyone.data_ptr() + (owner[a] * per_rank + a // world) * slot * esz)
+        self.allgather(self.everyone, self.mine)
+        self.torch.cuda.synchronize()
+        for a in agents:
+            if self.owner[a] != self.rank:
+                s.unpack_public_dev(a, self.everyone.data_ptr() + (self.owner[a] * self.per_rank + a // world) * slot * esz)
 
-    def push(selected):
+    def push(self, selected):
         # the new block of the selected agent goes to everyone (their evaluation and their next G need it)
-        if owner[selected] == rank:
-            s.pack_public_dev(selected, one.data_ptr())
+        s = self.s
+        if self.owner[selected] == self.rank:
+            s.pack_public_dev(selected, self.one.data_ptr())
             s.synchronize()
-        bcast(one, owner[selected])
-        if owner[selected] != rank:
-            torch.cuda.synchronize()
-            s.unpack_public_dev(selected, one.data_ptr())
+        self.bcast(self.one, self.owner[selected])
+        if self.owner[selected] != self.rank:
+            self.torch.cuda.synchronize()
+            s.unpack_public_dev(selected, self.one.data_ptr())
 
-    def step(selected):
-        s.phase_nonselected(selected)
-        pull_all_but(selected)
-        s.phase_selected(selected)
-        push(selected)
-        s.phase_evaluate_dev(evalbuf.data_ptr())
+    def evaluate(self):
+        s = self.s
+        s.phase_evaluate_dev(self.evalbuf.data_ptr())
         s.synchronize()
-        allreduce(evalbuf)
-        h = evalbuf.cpu().numpy()
+        self.allreduce(self.evalbuf)
+        h = self.evalbuf.cpu().numpy()
         bn = np.sqrt(h[0::2])
         cost2 = float(h[1::2].sum())  # 2 f = sum_b <X_b, X_b Q_bb + G_b>
-        gn = float(np.sqrt(h[0::2].sum()))
-        return cost2, gn, int(np.argmax(bn))
+        return cost2, float(np.sqrt(h[0::2].sum())), int(np.argmax(bn))
 
-    selected = 0
+    def step(self, selected):
+        """one RBCD++ iteration, the loop body of the reference driver"""
+        s = self.s
+        s.phase_nonselected(selected)
+        self.exchange([a for a in range(self.R) if a != selected])
+        s.phase_selected(selected)
+        self.push(selected)
+        return self.evaluate()
+
+    def tick(self, agents):
+        """the agents of the set update at the same time, each on the GPU of its rank; then their public poses travel"""
+        self.s.iterate_set(agents)
+        if self.world > 1 or self.staged:
+            self.exchange([int(a) for a in agents])
+
+    def timed(self, fn, count):
+        torch, dist = self.torch, self.dist
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = None
+        for _ in range(count):
+            out = fn(out)
+        dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if self.staged else self.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), out
+
+
+def run_multi(args, da, torch, dist, ds, X0, rank, world):
+    drv = RankDriver(da, torch, dist, ds, args.robots, args.rank_r, rank, world)
+    drv.s.set_X(X0)
+    state = (0.0, 0.0, 0)
     for _ in range(args.warmup):
-        c2, gn, selected = step(selected)
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        c2, gn, selected = step(selected)
-    dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device="cpu" if staged else dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return s, float(t.item()), c2, gn
+        state = drv.step(state[2])
+    dt, state = drv.timed(lambda prev: drv.step((prev or state)[2]), args.steps)
+    return drv, dt, state[0], state[1]
+
+
+def coloured_sweeps(drv, X0, sweeps, warm=2):
+    """Block updates per second when the agents of one colour update at the same time (non-accelerated agents, as
+    the reference's asynchronous mode; fixed colour order; one evaluation per sweep).  A separate mode, never
+    `value`: an iteration here is a tick of several block updates."""
+    s = drv.s
+    col, nc = s.colours()
+    sets = [np.flatnonzero(col == c).astype(np.int32) for c in range(nc)]
+    s.set_acceleration(False)
+    s.set_X(X0)
+
+    def sweep(_prev):
+        for S in sets:
+            drv.tick(S)
+        return drv.evaluate() if drv.dist is not None else s.evaluate()[:2]
+
+    first = None
+    for _ in range(warm):
+        first = sweep(None)
+    s.set_X(X0)
+    first = sweep(None)
+    s.set_X(X0)
+    if drv.dist is not None:
+        dt, last = drv.timed(sweep, sweeps)
+    else:
+        s.synchronize()
+        t0 = time.perf_counter()
+        last = None
+        for _ in range(sweeps):
+            last = sweep(last)
+        s.synchronize()
+        dt = time.perf_counter() - t0
+    R = len(col)
+    return {"mode": "coloured simultaneous updates (agents of one colour at once, non-accelerated, fixed order)",
+            "colours": col.tolist(), "sweeps": sweeps, "block_updates": sweeps * R,
+            "block_updates_per_s": sweeps * R / dt, "ms_per_sweep": 1e3 * dt / sweeps,
+            "cost_2f_after_first_sweep": float(first[0]), "cost_2f_last": float(last[0]),
+            "gradnorm_last": float(last[1])}
+
+
+class SingleDriver:
+    """the same interface on one process without a process group"""
+    dist = None
+
+    def __init__(self, s):
+        self.s = s
+
+    def tick(self, agents):
+        self.s.iterate_set(agents)
 
 
 def agent_block(ds, R, b):
@@ -315,6 +394,10 @@ def config5_run(da, with_cpu, iters=60, cpu_iters=4):
     res = {"workload": "synthetic 50x50x40 SE(3) lattice (100000 poses, %d edges, seed 20250310), 8 agents, r=5" % ds.m,
            "iterations": iters, "value": iters / dt, "unit": "RBCD iterations/s", "ms_per_step": 1e3 * dt / iters,
            "setup_s": setup_s, "cost_2f_first": float(out["cost"][0]), "cost_2f_last": float(out["cost"][-1])}
+    try:
+        res["coloured_rbcd"] = coloured_sweeps(SingleDriver(s), X0, sweeps=8, warm=1)
+    except Exception as e:
+        res["coloured_rbcd"] = {"error": str(e)}
     s.close()
     if with_cpu:
         from oracle import orc
@@ -326,6 +409,40 @@ def config5_run(da, with_cpu, iters=60, cpu_iters=4):
                            "same_block_sequence": bool(np.array_equal(tr["selected"][:n], out["selected"][:n])),
                            "max_relative_cost_difference":
                                float(np.max(np.abs(tr["cost"][:n] - out["cost"][:n]) / np.abs(tr["cost"][:n])))}
+    return res
+
+
+def config5_multi(da, torch, dist, rank, world, iters=60, sweeps=8):
+    """the same workload with one process per GPU: agent a on rank a % world, public poses over RCCL"""
+    from dcora_amd import synth
+    R, r = 8, 5
+    ds = synth.lattice_se3()
+    rng = np.random.default_rng(20250310)
+    X0 = da.manifold_project(r, ds.d, ds.n, rng.uniform(-1, 1, (r, (ds.d + 1) * ds.n)))
+    drv = RankDriver(da, torch, dist, ds, R, r, rank, world)
+    drv.s.set_X(X0)
+    state = (0.0, 0.0, 0)
+    for _ in range(3):
+        state = drv.step(state[2])
+    drv.s.set_X(X0)
+    first = (0.0, 0.0, 0)
+    costs = []
+
+    def one(prev):
+        out = drv.step((prev or first)[2])
+        costs.append(out[0])
+        return out
+
+    dt, state = drv.timed(one, iters)
+    res = {"workload": "synthetic 50x50x40 SE(3) lattice (100000 poses, %d edges, seed 20250310), 8 agents, r=5" % ds.m,
+           "parallelism": "agents round-robin over %d rank(s)" % world,
+           "iterations": iters, "value": iters / dt, "unit": "RBCD iterations/s", "ms_per_step": 1e3 * dt / iters,
+           "setup_s": drv.setup_s, "cost_2f_first": float(costs[0]), "cost_2f_last": float(costs[-1])}
+    try:
+        res["coloured_rbcd"] = coloured_sweeps(drv, X0, sweeps=sweeps, warm=1)
+    except Exception as e:
+        res["coloured_rbcd"] = {"error": str(e)}
+    drv.s.close()
     return res
 
 
@@ -431,11 +548,16 @@ def main():
         import torch.distributed as dist
         dist.init_process_group(os.environ.get("DCORA_DIST_BACKEND", "nccl"))
         X0 = initial_point(da, ds, args.rank_r)
-        s, dt, c2, gn = run_multi(args, da, torch, dist, ds, X0, rank, world)
+        drv, dt, c2, gn = run_multi(args, da, torch, dist, ds, X0, rank, world)
+        coloured = coloured_sweeps(drv, X0, sweeps=40)
+        drv.s.close()
+        c5 = None if args.no_config5 else config5_multi(da, torch, dist, rank, world)
         dist.barrier()
         dist.destroy_process_group()
     else:
         s, dt, c2, gn = run_single(args, da, torch, ds, X0)
+        coloured = coloured_sweeps(SingleDriver(s), X0, sweeps=40)
+        c5 = None
     if rank != 0:
         return
     ms = 1e3 * dt / args.steps
@@ -457,6 +579,9 @@ def main():
                    "parallelism": "agents round-robin over %d rank(s)" % world,
                    "final_cost_2f": c2, "final_gradnorm": gn},
     }
+    line["coloured_rbcd"] = coloured
+    if c5 is not None:
+        line["config5_lattice100k"] = c5
     line["roofline"], line["roofline_qapply"] = roofline(da, ds, args.rank_r, args.robots)
     if world == 1:
         try:

@@ -428,6 +428,9 @@ class RbcdSession:
         a = np.ascontiguousarray(agents, dtype=np.int32)
         check(capi.lib().dcora_rbcd_iterate_set(self.h, a, a.size, int(allow_adjacent)))
 
+    def set_acceleration(self, on):
+        check(capi.lib().dcora_rbcd_set_acceleration(self.h, int(bool(on))))
+
     def colours(self):
         col, nc = np.zeros(self.R, np.int32), C.c_int()
         check(capi.lib().dcora_rbcd_agent_colours(self.h, col, C.byref(nc)))

@@ -117,6 +117,7 @@ SIGNATURES = {
     "dcora_rbcd_iterate": (C.c_int, [_vp, C.c_int, _PD, _PD, _vp, _PI]),
     "dcora_rbcd_run": (C.c_int, [_vp, C.c_int, C.c_double, _PI, _vp, _vp, _vp]),
     "dcora_rbcd_iterate_set": (C.c_int, [_vp, _ip, C.c_int, C.c_int]),
+    "dcora_rbcd_set_acceleration": (C.c_int, [_vp, C.c_int]),
     "dcora_rbcd_agent_colours": (C.c_int, [_vp, _ip, _PI]),
     "dcora_rbcd_evaluate": (C.c_int, [_vp, _PD, _PD, _vp, _PI]),
     "dcora_rbcd_last_result": (C.c_int, [_vp, C.POINTER(ROptResult)]),

@@ -515,6 +515,10 @@ int dcora_rbcd_iterate_set(dcora_rbcd_t s, const int *set, int count, int allow_
   return s->s.iterate_set(set, count, allow_adjacent);
   DCORA_CATCH
 }
+int dcora_rbcd_set_acceleration(dcora_rbcd_t s, int acceleration) {
+  if (!s) return bad("null");
+  return s->s.set_acceleration(acceleration != 0);
+}
 int dcora_rbcd_agent_colours(dcora_rbcd_t s, int *colours, int *ncolours) {
   if (!s || !colours) return bad("null");
   return s->s.agent_colours(colours, ncolours);

@@ -51,6 +51,7 @@ class RbcdSession {
   int init(const HostDataset &ds, const dcora_rbcd_options &o);
   int set_X(const double *Xh);
   int get_X(double *Xh);
+  int set_acceleration(bool on);
   int phase_nonselected(int selected);
   int phase_selected(int selected);
   int evaluate_central(double *cost2, double *gradnorm, double *block_norms, int *next_selected);

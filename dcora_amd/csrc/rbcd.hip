@@ -169,6 +169,19 @@ int RbcdSession::set_X(const double *Xh) {
   seq_advanced_ = false;
   return DCORA_OK;
 }
+// initializeAcceleration / acceleration off for every agent (ref src/Agent.cpp:1178-1187)
+int RbcdSession::set_acceleration(bool on) {
+  DCORA_HIP(hipSetDevice(opt.device));
+  opt.acceleration = on ? 1 : 0;
+  const size_t B = sizeof(double) * (size_t)r * (d + 1) * n;
+  DCORA_HIP(hipMemcpyAsync(Vg.p, Xg.p, B, hipMemcpyDeviceToDevice, st));
+  DCORA_HIP(hipMemcpyAsync(Yg.p, Xg.p, B, hipMemcpyDeviceToDevice, st));
+  DCORA_HIP(hipMemcpyAsync(XPrevg.p, Xg.p, B, hipMemcpyDeviceToDevice, st));
+  gamma = alpha = 0;
+  iteration = 0;
+  seq_advanced_ = false;
+  return DCORA_OK;
+}
 int RbcdSession::get_X(double *Xh) {
   DCORA_HIP(hipSetDevice(opt.device));
   const size_t B = sizeof(double) * (size_t)r * (d + 1) * n;

@@ -230,6 +230,8 @@ int dcora_rbcd_run(dcora_rbcd_t s, int max_iters, double rgrad_tol, int *iters_d
  * updating them one after the other with dcora_rbcd_iterate.  Multi-process: every rank passes the same set and
  * solves the agents it hosts; the caller exchanges public poses afterwards. */
 int dcora_rbcd_iterate_set(dcora_rbcd_t s, const int *set, int count, int allow_adjacent);
+/* AgentParameters::acceleration of every agent; restarts the Nesterov sequences (V = Y = X, gamma = alpha = 0) */
+int dcora_rbcd_set_acceleration(dcora_rbcd_t s, int acceleration);
 /* greedy colouring of the agent graph (agents adjacent when they share a measurement): colours[num_robots] */
 int dcora_rbcd_agent_colours(dcora_rbcd_t s, int *colours, int *ncolours);
 /* the central evaluation of dcora_rbcd_iterate alone (ref examples/MultiRobotExample.cpp:264-305); world_size 1 */

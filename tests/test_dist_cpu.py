@@ -13,7 +13,7 @@ import common
 WORLD = 2
 
 
-def _worker(rank, world, port, tmpdir):
+def _worker(rank, world, port, tmpdir, mode="greedy"):
     import torch
     import torch.distributed as dist
     sys.path.insert(0, os.path.dirname(common.HERE))
@@ -72,6 +72,19 @@ def _worker(rank, world, port, tmpdir):
                 v = parts[a % world][(a // world) * slot:(a // world) * slot + r * len(pidx[a])].numpy()
                 X[:, pidx[a]] = v.reshape(len(pidx[a]), r).T
 
+    def exchange_set(agents):
+        mine = torch.zeros(per_rank * slot, dtype=torch.float64)
+        for a in agents:
+            if a in hosted:
+                v = np.ascontiguousarray(X[:, pidx[a]].T).reshape(-1)
+                mine[(a // world) * slot:(a // world) * slot + v.size] = torch.from_numpy(v.copy())
+        parts = [torch.zeros(per_rank * slot, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        for a in agents:
+            if a % world != rank:
+                v = parts[a % world][(a // world) * slot:(a // world) * slot + r * len(pidx[a])].numpy()
+                X[:, pidx[a]] = v.reshape(len(pidx[a]), r).T
+
     def push(a):
         buf = torch.zeros(r * len(pidx[a]), dtype=torch.float64)
         if a % world == rank:
@@ -80,6 +93,35 @@ def _worker(rank, world, port, tmpdir):
         if a % world != rank:
             X[:, pidx[a]] = buf.numpy().reshape(len(pidx[a]), r).T
 
+    def evaluate():
+        ev = torch.zeros(2 * R, dtype=torch.float64)
+        for b in hosted:
+            nb = end[b] - start[b]
+            Xb = X[:, cols(b)]
+            EG = Xb @ Qg[cols(b), cols(b)] + G_of(b)
+            RG = orc.tangent_project(r, d, nb, Xb, EG)
+            ev[2 * b] = float(np.sum(RG * RG))
+            ev[2 * b + 1] = float(np.sum(Xb * EG))
+        dist.all_reduce(ev)
+        return ev.numpy()
+
+    if mode == "coloured":
+        # bench.py RankDriver.tick: the agents of one colour solve at the same time on their ranks from one snapshot
+        # of the neighbour states (non-accelerated), then ONE all_gather moves their public poses
+        sets = np.load(os.path.join(tmpdir, "sets.npy"), allow_pickle=True)
+        for sweep in range(2):
+            for S in sets:
+                new = {}
+                for b in S:
+                    if b in hosted:
+                        P = orc.Problem(r, d, end[b] - start[b], probs[b], G=G_of(b))
+                        new[b] = P.optimize(X[:, cols(b)])[0]
+                for b, Xn in new.items():
+                    X[:, cols(b)] = Xn
+                exchange_set(list(S))
+            h = evaluate()
+            trace.append((sweep, float(h[1::2].sum()), float(np.sqrt(h[0::2].sum()))))
+        iters = 0
     for it in range(iters):
         gamma = (1 + np.sqrt(1 + 4.0 * R * R * gamma * gamma)) / (2.0 * R)
         alpha = 1.0 / (gamma * R)
@@ -132,3 +174,50 @@ def test_two_rank_protocol_matches_single_process(built, tmp_path):
     assert np.array_equal(tr[:, 0].astype(int), ref["selected"])
     assert np.allclose(tr[:, 1], ref["cost"], rtol=1e-9)
     assert np.allclose(tr[:, 2], ref["gradnorm"], rtol=1e-7)
+
+
+def test_two_rank_coloured_ticks_match_one_after_the_other(built, tmp_path):
+    """the N > 1 path of the simultaneous-update mode (dcora_rbcd_iterate_set + one all_gather per tick)"""
+    import scipy.sparse as sp
+    import torch.multiprocessing as mp
+    import g2o_np
+    from oracle import orc
+    name, R, r = "smallGrid3D", 5, 5
+    ds = common.oracle_dataset(name)
+    d, n, dh = ds.d, ds.n, ds.d + 1
+    X0 = common.random_point(r, d, n, 3, orc.project_to_manifold)
+    np.save(tmp_path / "X0.npy", X0)
+    g = g2o_np.read_g2o(common.data_path(name))
+    per = n // R
+    robot = lambda i: min(i // per, R - 1)
+    adj = [set() for _ in range(R)]
+    for (i, j, *_r) in g["edges"]:
+        if robot(i) != robot(j):
+            adj[robot(i)].add(robot(j))
+            adj[robot(j)].add(robot(i))
+    col = []
+    for a in range(R):  # the product's rule (dcora_rbcd_agent_colours): smallest colour free among lower neighbours
+        used = {col[b] for b in adj[a] if b < a}
+        col.append(min(c for c in range(R) if c not in used))
+    sets = np.empty(max(col) + 1, dtype=object)
+    for c in range(max(col) + 1):
+        sets[c] = [a for a in range(R) if col[a] == c]
+    np.save(tmp_path / "sets.npy", sets, allow_pickle=True)
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(WORLD, port, str(tmp_path), "coloured"), nprocs=WORLD, join=True)
+    tr = np.load(tmp_path / "trace.npy")
+    # single process, the same agents one after the other
+    Qg = sp.csc_matrix(g2o_np.dense_Q(g))
+    cols = [np.arange(b * per * dh, (n if b == R - 1 else (b + 1) * per) * dh) for b in range(R)]
+    X = X0.copy()
+    costs = []
+    for sweep in range(2):
+        for S in sets:
+            for b in S:
+                own = cols[b]
+                C = Qg[:, own].toarray()
+                C[own, :] = 0
+                P = orc.Problem(r, d, own.size // dh, orc.CSR.from_scipy(sp.csr_matrix(Qg[own][:, own])), G=X @ C)
+                X[:, own] = P.optimize(X[:, own])[0]
+        costs.append(float(np.sum((X @ Qg) * X)))
+    assert np.allclose(tr[:, 1], costs, rtol=1e-10) and costs[1] < costs[0]
