@@ -86,8 +86,10 @@ class RankDriver:
         self.staged = dist.get_backend() != "nccl"  # rehearsal on one GPU: gloo through host staging
         dh = ds.d + 1
         t0 = time.perf_counter()
+        # the session enqueues on the stream the collectives are ordered on: pack -> RCCL -> unpack without host syncs
+        self.ts = torch.cuda.Stream(device=dev)
         self.s = s = da.RbcdSession(ds, num_robots=R, r=r, acceleration=acceleration, rank=rank, world_size=world,
-                                    device=dev.index)
+                                    device=dev.index, stream=self.ts.cuda_stream)
         self.setup_s = time.perf_counter() - t0
         counts = [s.public_count(a) for a in range(R)]
         self.slot = slot = r * dh * max(counts)       # doubles per agent in the exchange buffers
@@ -98,30 +100,37 @@ class RankDriver:
         self.one = torch.zeros(slot, dtype=torch.float64, device=dev)
         self.evalbuf = torch.zeros(2 * R, dtype=torch.float64, device=dev)
         self.esz = self.mine.element_size()
+        torch.cuda.synchronize()
 
     def allgather(self, dst, src):
         if self.staged:
             parts = [self.torch.zeros(src.numel(), dtype=src.dtype) for _ in range(self.world)]
             self.dist.all_gather(parts, src.cpu())
             dst.copy_(self.torch.cat(parts))
+            self.torch.cuda.synchronize()
         else:
-            self.dist.all_gather_into_tensor(dst, src)
+            with self.torch.cuda.stream(self.ts):
+                self.dist.all_gather_into_tensor(dst, src)
 
     def bcast(self, t, src):
         if self.staged:
             h = t.cpu()
             self.dist.broadcast(h, src=src)
             t.copy_(h)
+            self.torch.cuda.synchronize()
         else:
-            self.dist.broadcast(t, src=src)
+            with self.torch.cuda.stream(self.ts):
+                self.dist.broadcast(t, src=src)
 
     def allreduce(self, t):
         if self.staged:
             h = t.cpu()
             self.dist.all_reduce(h)
             t.copy_(h)
+            self.torch.cuda.synchronize()
         else:
-            self.dist.all_reduce(t)
+            with self.torch.cuda.stream(self.ts):
+                self.dist.all_reduce(t)
 
     def exchange(self, agents):
         """getSharedStateDicts of `agents` -> ONE all_gather of the packed public poses -> updateNeighborStates on the
@@ -130,9 +139,9 @@ class RankDriver:
         for a in agents:
             if self.owner[a] == self.rank:
                 s.pack_public_dev(a, self.mine.data_ptr() + (a // world) * slot * esz)
-        s.synchronize()
+        if self.staged:
+            s.synchronize()
         self.allgather(self.everyone, self.mine)
-        self.torch.cuda.synchronize()
         for a in agents:
             if self.owner[a] != self.rank:
                 s.unpack_public_dev(a, self.everyone.data_ptr() + (self.owner[a] * self.per_rank + a // world) * slot * esz)
@@ -142,18 +151,20 @@ class RankDriver:
         s = self.s
         if self.owner[selected] == self.rank:
             s.pack_public_dev(selected, self.one.data_ptr())
-            s.synchronize()
+            if self.staged:
+                s.synchronize()
         self.bcast(self.one, self.owner[selected])
         if self.owner[selected] != self.rank:
-            self.torch.cuda.synchronize()
             s.unpack_public_dev(selected, self.one.data_ptr())
 
     def evaluate(self):
         s = self.s
         s.phase_evaluate_dev(self.evalbuf.data_ptr())
-        s.synchronize()
+        if self.staged:
+            s.synchronize()
         self.allreduce(self.evalbuf)
-        h = self.evalbuf.cpu().numpy()
+        with self.torch.cuda.stream(self.ts):
+            h = self.evalbuf.cpu().numpy()
         bn = np.sqrt(h[0::2])
         cost2 = float(h[1::2].sum())  # 2 f = sum_b <X_b, X_b Q_bb + G_b>
         return cost2, float(np.sqrt(h[0::2].sum())), int(np.argmax(bn))

@@ -381,7 +381,7 @@ class RbcdSession:
     """Agents + synchronous RBCD++ driver on the device (ref examples/MultiRobotExample.cpp:121-307)"""
 
     def __init__(self, ds, num_robots=5, r=5, acceleration=True, restart_interval=30, params=None, rank=0,
-                 world_size=1, device=0):
+                 world_size=1, device=0, stream=None):
         self.ds, self.R, self.r = ds, num_robots, r
         self.k = (ds.d + 1) * ds.n
         o = RbcdOptions()
@@ -390,6 +390,7 @@ class RbcdSession:
         if params is not None:
             o.local = params.c
         o.rank, o.world_size, o.device = rank, world_size, device
+        o.stream = stream  # raw hipStream_t (int) or None
         dsh = ds.handle()
         self.h = C.c_void_p()
         try:

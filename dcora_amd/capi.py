@@ -48,7 +48,8 @@ class RobustParams(C.Structure):
 
 class RbcdOptions(C.Structure):
     _fields_ = [("num_robots", C.c_int), ("r", C.c_int), ("acceleration", C.c_int), ("restart_interval", C.c_int),
-                ("local", ROptParams), ("rank", C.c_int), ("world_size", C.c_int), ("device", C.c_int)]
+                ("local", ROptParams), ("rank", C.c_int), ("world_size", C.c_int), ("device", C.c_int),
+                ("stream", C.c_void_p)]
 
 
 def build(force=False):

@@ -459,6 +459,7 @@ void dcora_rbcd_options_default(dcora_rbcd_options *o) {
   o->rank = 0;
   o->world_size = 1;
   o->device = 0;
+  o->stream = nullptr;
 }
 int dcora_rbcd_create(dcora_dataset_t ds, const dcora_rbcd_options *opt, dcora_rbcd_t *out) {
   if (!ds || !opt || !out) return bad("null argument");

@@ -68,6 +68,7 @@ class RbcdSession {
   bool restart_now() const { return opt.acceleration && ((iteration + 1) % opt.restart_interval == 0); }
   void advance_sequences();
   bool seq_advanced_ = false;
+  bool own_stream_ = true;
   hipEvent_t fork_ev_ = nullptr;
   int solve_block(AgentDev &a, std::string *err);
 };

@@ -36,7 +36,7 @@ RbcdSession::~RbcdSession() {
   if (fork_ev_) (void)hipEventDestroy(fork_ev_);
   agents.clear();
   central.reset();
-  if (st) (void)hipStreamDestroy(st);
+  if (st && own_stream_) (void)hipStreamDestroy(st);
 }
 
 int RbcdSession::init(const HostDataset &ds, const dcora_rbcd_options &o) {
@@ -60,7 +60,12 @@ int RbcdSession::init(const HostDataset &ds, const dcora_rbcd_options &o) {
     return DCORA_ERR_NO_DEVICE;
   }
   DCORA_HIP(hipSetDevice(o.device));
-  DCORA_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  if (o.stream) {
+    st = (hipStream_t)o.stream;
+    own_stream_ = false;
+  } else {
+    DCORA_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  }
   mg = make_mani(r, d, n, 0, 0);
   const size_t N = (size_t)r * dh * n;
   DCORA_HIP(Xg.alloc(N));

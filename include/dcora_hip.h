@@ -205,6 +205,8 @@ typedef struct {
   dcora_ropt_params local; /* AgentParameters::localOptimizationParams */
   int rank, world_size; /* this process hosts agents a with a % world_size == rank */
   int device;
+  void *stream; /* hipStream_t the session enqueues on (e.g. the stream the caller's RCCL calls are ordered on, so
+                   pack -> collective -> unpack needs no host synchronisation); NULL: the session creates its own */
 } dcora_rbcd_options;
 void dcora_rbcd_options_default(dcora_rbcd_options *o);
 
