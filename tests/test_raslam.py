@@ -32,9 +32,15 @@ def ra_plain(name):
     return _plain[name]
 
 
+PL = {}  # pose-landmark factors per parsed path (kept beside the 5-tuple the other tests unpack)
+
+
 def parse_pyfg_np(path):
-    """independent reader: returns factor lists with symbolic state names"""
+    """independent reader: returns factor lists with symbolic state names (PRIOR records are read by the reference
+    into lists nothing on this path consumes, ref src/DCORA_utils.cpp:773-930: they are skipped here)"""
     poses, lms, pp, rg = {}, {}, [], []
+    pl = PL.setdefault(path, [])
+    del pl[:]
     d = 0
     with gzip.open(path, "rt") as fh:
         for line in fh:
@@ -64,12 +70,17 @@ def parse_pyfg_np(path):
                 c = list(map(float, t[11:32]))
                 pp.append((t[2], t[3], g2o_np.quat_R(*v[3:7]), np.array(v[0:3]), 3.0 / (2 * (c[15] + c[18] + c[20])),
                            3.0 / (c[0] + c[6] + c[11])))
+            elif t[0] in ("EDGE_SE2_XY", "EDGE_SE3_XYZ"):  # pose -> landmark translation, tau = d / trace(cov)
+                dd = 2 if t[0] == "EDGE_SE2_XY" else 3
+                c = list(map(float, t[4 + dd:]))
+                tr = c[0] + c[2] if dd == 2 else c[0] + c[3] + c[5]
+                pl.append((t[2], t[3], np.array(list(map(float, t[4:4 + dd]))), dd / tr))
             elif t[0] == "EDGE_RANGE":
                 rg.append((t[2], t[3], float(t[4]), 1.0 / float(t[5])))
     return d, poses, lms, pp, rg
 
 
-def factor_cost(g, ds, X):
+def factor_cost(g, ds, X, extra_pl=()):
     """f(X) factor by factor in the RA ordering, with the global indexing rule of the reference
     (poses sorted by (robot, id), unit spheres by (source robot, order of appearance))"""
     d, poses, lms, pp, rg = g
@@ -85,6 +96,8 @@ def factor_cost(g, ds, X):
     for (a, b, R, t, kappa, tau) in pp:
         i, j = pi[a], pi[b]
         f += 0.5 * kappa * np.sum((Y(j) - Y(i) @ R) ** 2) + 0.5 * tau * np.sum((p(j) - p(i) - Y(i) @ t) ** 2)
+    for (a, b, t, tau) in extra_pl:
+        f += 0.5 * tau * np.sum((L(li[b]) - p(pi[a]) - Y(pi[a]) @ t) ** 2)
     count, base = {}, {}
     for (a, b, rho, w) in rg:
         count[a[0]] = count.get(a[0], 0) + 1
@@ -131,6 +144,31 @@ def test_oracle_ra_feed_against_numpy_and_noiseless_fixture(built, name):
     assert orc.fast_verification(S, 1e-4, block=1)[0]
 
 
+@pytest.mark.parametrize("name", ["pyfg_se2_test_data", "pyfg_se3_test_data"])
+def test_pyfg_with_priors_and_pose_landmark_edges(built, name):
+    """the reference's pyfg samples with every record type (data/pyfg_se{2,3}_test_data.pyfg): pose priors and
+    landmark priors are parsed and ignored by the Q builder, pose -> landmark translations enter Q, landmarks
+    without a robot letter belong to the map, a landmark-to-landmark range puts its unit sphere with the map"""
+    from oracle import orc
+    import dcora_amd as da
+    path = ra_path(name)
+    g = parse_pyfg_np(path)
+    pl = list(PL[path])
+    ds = orc.RADataset(ra_plain(name))
+    dsp = da.RADataset(path)
+    assert (ds.d, ds.n, ds.l, ds.b) == (dsp.d, dsp.n, dsp.l, dsp.b) == (g[0], 12, 9, 2) and len(pl) == 6
+    assert abs(ds.Q.to_scipy() - dsp.Q.to_scipy()).max() < 1e-12
+    assert np.abs(ds.gt - dsp.gt).max() == 0
+    assert dsp.landmark_robot.tolist() == [12, 12] and dsp.sphere_robot.tolist() == [0] * 4 + [1] * 4 + [12]
+    d, n, l, b = ds.d, ds.n, ds.l, ds.b
+    r = d + 2
+    rng = np.random.default_rng(1)
+    X = orc.project_to_manifold(r, d, n, rng.standard_normal((r, ds.k)), l=l, b=b)
+    P = orc.Problem(r, d, n, ds.Q, reg=-1, l=l, b=b)
+    assert np.isclose(P.f(X), factor_cost(g, ds, X, extra_pl=pl), rtol=1e-12)
+    assert not np.isclose(P.f(X), factor_cost(g, ds, X), rtol=1e-3)  # the pose-landmark terms do count
+
+
 def test_tiers_sizes_match_survey(built):
     """tiers.pyfg has k = 37 094 and nnz(Q) = 279 108 -- checked on single_drone (shipped fixture)
     through both builders, and on tiers itself when the reference tree is mounted"""
@@ -148,7 +186,7 @@ def test_tiers_sizes_match_survey(built):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,r", [("range_aided_slam_test_2d", 2), ("range_aided_slam_test_2d", 4),
                                     ("range_aided_slam_test_3d", 3), ("range_aided_slam_test_3d", 5),
-                                    ("single_drone", 4)])
+                                    ("single_drone", 4), ("pyfg_se2_test_data", 3), ("pyfg_se3_test_data", 4)])
 def test_hip_ra_layout_ops(built, name, r):
     import dcora_amd as da
     from oracle import orc
