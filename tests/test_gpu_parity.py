@@ -249,3 +249,36 @@ def test_min_eig_shift_invert_fallback(env):
     assert np.linalg.norm(S.to_scipy() @ v - lam * v) < 1e-6 and abs(np.linalg.norm(v) - 1) < 1e-12
     oko, lamo, vo, mvo = orc.min_eig(orc.CSR.from_scipy(S.to_scipy()), tol=1e-4)
     assert oko and abs(lamo - want) < 1e-8
+
+
+def test_planar_pose_graph_csail_rbcd_and_certificate(env):
+    """a planar (d = 2) dataset of the reference's data directory through the whole path: CSAIL.g2o (1045 poses, 1171
+    measurements), 4 agents, r = 3: chordal start, RBCD++ trace against the oracle, certificate at the solution"""
+    da, orc = env
+    ds, dso = common.product_dataset("CSAIL"), common.oracle_dataset("CSAIL")
+    assert (ds.d, ds.n, ds.m) == (dso.d, dso.n, dso.m) == (2, 1045, 1171)
+    r, R, iters = 3, 4, 40
+    T = da.chordal_initialization(ds)
+    To = orc.chordal_initialization(dso)
+    assert common.rel(T, To) < 1e-9
+    X0 = np.zeros((r, 3 * ds.n))
+    X0[:2] = T
+    tr = orc.run_rbcd(dso, X0, num_robots=R, r_min=r, max_iters=iters, staircase=0, rgrad_tol=1e-12)
+    s = da.RbcdSession(ds, num_robots=R, r=r)
+    s.set_X(X0)
+    out = s.run(max_iters=iters, rgrad_tol=1e-12)
+    assert np.array_equal(out["selected"], tr["selected"])
+    assert np.allclose(out["cost"], tr["cost"], rtol=1e-8)
+    assert np.allclose(out["gradnorm"], tr["gradnorm"], rtol=1e-5, atol=1e-8)
+    # to convergence, then the certificate (CSAIL is certified at low rank from the chordal start)
+    out = s.run(max_iters=600, rgrad_tol=0.05)
+    assert out["gradnorm"][-1] < 0.05
+    X = s.get_X()
+    Q, Qo = da.build_Q_pgo(ds), orc.build_Q_pgo(dso)
+    assert abs(Q.to_scipy() - Qo.to_scipy()).max() < 1e-10
+    S = da.dual_certificate(r, ds.d, ds.n, X, Q)
+    psd, theta, x, lmin = da.fast_verification(S, 1e-3, block=ds.d + 1)
+    So = orc.dual_certificate(r, ds.d, ds.n, X, Qo)
+    psdo = orc.fast_verification(So, 1e-3, block=ds.d + 1)[0]
+    assert psd == psdo
+    assert abs(2 * orc.Problem(r, ds.d, ds.n, Qo).f(X) - out["cost"][-1]) < 1e-7 * abs(out["cost"][-1])
