@@ -623,6 +623,31 @@ int dcora_robust_single_pose_averaging(int d, int n, const double *R, const doub
   return DCORA_OK;
   DCORA_CATCH
 }
+int dcora_agent_neighbor_transforms(int d, int m, const int *incoming, const double *meas_R, const double *meas_t,
+                                    const double *nbr_pose, const double *my_pose, double *T_out) {
+  if (!incoming || !meas_R || !meas_t || !nbr_pose || !my_pose || !T_out || m < 0 || (d != 2 && d != 3))
+    return bad("bad argument");
+  const int ps = d * (d + 1);
+  for (int i = 0; i < m; ++i)
+    neighbor_transform(d, incoming[i] != 0, meas_R + (size_t)i * d * d, meas_t + (size_t)i * d,
+                       nbr_pose + (size_t)i * ps, my_pose + (size_t)i * ps, T_out + (size_t)i * ps);
+  return DCORA_OK;
+}
+int dcora_agent_robust_neighbor_transform(int d, int m, const double *candidates, int two_stage, int min_inliers,
+                                          double *T_world_robot, int *num_inliers, int *ok) {
+  if (!candidates || !T_world_robot || !ok || m < 0 || (d != 2 && d != 3)) return bad("bad argument");
+  DCORA_TRY
+  *ok = robust_neighbor_transform(d, m, candidates, two_stage != 0, min_inliers, T_world_robot, num_inliers) ? 1 : 0;
+  return DCORA_OK;
+  DCORA_CATCH
+}
+int dcora_agent_initialize_in_global_frame(const dcora_dims *dims, const double *T_world_robot,
+                                           const double *T_local, const double *YLift, double *X) {
+  if (!dims || !T_world_robot || !T_local || !YLift || !X) return bad("null argument");
+  if ((dims->d != 2 && dims->d != 3) || dims->r < dims->d || dims->n < 1) return bad("bad dims");
+  initialize_in_global_frame(dims->r, dims->d, dims->n, dims->l, dims->b, T_world_robot, T_local, YLift, X);
+  return DCORA_OK;
+}
 int dcora_measurement_errors(dcora_dataset_t ds, int r, const double *X, double *out, int device) {
   if (!ds || !X || !out) return bad("null argument");
   if (r < ds->ds.d || r > 16) return bad("measurement_errors: need d <= r <= 16");

@@ -167,4 +167,111 @@ void robust_single_pose_averaging(int d, int n, const double *R, const double *t
   robust_average(d, n, R, t, kappa ? kappa : k1.data(), tau ? tau : t1.data(), threshold, 10000, Ropt, topt, inliers);
 }
 
+// ---- cross-robot frame alignment ----
+namespace {
+// C = A * B for poses [R t] (d x (d+1), column-major)
+void pose_mul(int d, const double *A, const double *B, double *C) {
+  double out[12];
+  for (int c = 0; c <= d; ++c)
+    for (int a = 0; a < d; ++a) {
+      double s = (c == d) ? A[a + d * d] : 0.0;
+      for (int q = 0; q < d; ++q) s += A[a + q * d] * B[q + c * d];
+      out[a + c * d] = s;
+    }
+  for (int e = 0; e < d * (d + 1); ++e) C[e] = out[e];
+}
+void pose_inv(int d, const double *A, double *C) {
+  double out[12];
+  for (int c = 0; c < d; ++c)
+    for (int a = 0; a < d; ++a) out[a + c * d] = A[c + a * d];
+  for (int a = 0; a < d; ++a) {
+    double s = 0;
+    for (int q = 0; q < d; ++q) s += A[q + a * d] * A[q + d * d];
+    out[a + d * d] = -s;
+  }
+  for (int e = 0; e < d * (d + 1); ++e) C[e] = out[e];
+}
+}  // namespace
+
+void neighbor_transform(int d, bool incoming, const double *Rm, const double *tm, const double *T_w2_f2,
+                        const double *T_w1_f1, double *T_out) {
+  double dT[12], f1f2[12], tmp[12], inv[12];
+  for (int e = 0; e < d * d; ++e) dT[e] = Rm[e];
+  for (int a = 0; a < d; ++a) dT[d * d + a] = tm[a];
+  if (incoming) {
+    pose_inv(d, dT, f1f2);
+  } else {
+    for (int e = 0; e < d * (d + 1); ++e) f1f2[e] = dT[e];
+  }
+  pose_inv(d, f1f2, inv);
+  pose_mul(d, T_w2_f2, inv, tmp);      // T_world2_frame1
+  pose_inv(d, T_w1_f1, inv);
+  pose_mul(d, tmp, inv, T_out);        // T_world2_world1
+}
+
+bool robust_neighbor_transform(int d, int m, const double *cand, bool two_stage, int min_inliers, double *T,
+                               int *num_inliers) {
+  if (num_inliers) *num_inliers = 0;
+  if (m < 1) return false;
+  const int ps = d * (d + 1);
+  std::vector<double> R((size_t)m * d * d), t((size_t)m * d);
+  for (int i = 0; i < m; ++i) {
+    for (int e = 0; e < d * d; ++e) R[(size_t)i * d * d + e] = cand[(size_t)i * ps + e];
+    for (int a = 0; a < d; ++a) t[(size_t)i * d + a] = cand[(size_t)i * ps + d * d + a];
+  }
+  std::vector<int> in;
+  double Ropt[9], topt[3] = {0, 0, 0};
+  if (two_stage) {
+    std::vector<double> kappa((size_t)m, 1.0);
+    const double max_rot_err = 2.0 * std::sqrt(2.0) * std::sin(0.5 / 2.0);  // angular2ChordalSO3(0.5)
+    robust_single_rotation_averaging(d, m, R.data(), kappa.data(), max_rot_err, Ropt, in);
+    if (num_inliers) *num_inliers = (int)in.size();
+    if ((int)in.size() < min_inliers) return false;
+    for (int i : in)
+      for (int a = 0; a < d; ++a) topt[a] += t[(size_t)i * d + a];
+    for (int a = 0; a < d; ++a) topt[a] /= (double)in.size();
+  } else {
+    std::vector<double> kappa((size_t)m, 1.82), tau((size_t)m, 0.01);
+    double cbar = 0;
+    if (!error_threshold_at_quantile(0.9, 3, &cbar)) return false;
+    robust_single_pose_averaging(d, m, R.data(), t.data(), kappa.data(), tau.data(), cbar, Ropt, topt, in);
+    if (num_inliers) *num_inliers = (int)in.size();
+    if ((int)in.size() < min_inliers) return false;
+  }
+  for (int e = 0; e < d * d; ++e) T[e] = Ropt[e];
+  for (int a = 0; a < d; ++a) T[d * d + a] = topt[a];
+  return true;
+}
+
+void initialize_in_global_frame(int r, int d, int n, int l, int b, const double *Twr, const double *Tlocal,
+                                const double *YLift, double *X) {
+  const int dh = d + 1;
+  const bool se = (l == 0 && b == 0);
+  const int k = se ? dh * n : dh * n + l + b;
+  auto lifted = [&](int col, const double *g) {  // X(:, col) = YLift g
+    for (int a = 0; a < r; ++a) {
+      double s = 0;
+      for (int q = 0; q < d; ++q) s += YLift[a + q * r] * g[q];
+      X[(size_t)col * r + a] = s;
+    }
+  };
+  auto apply = [&](const double *v, bool point, double *g) {  // g = R_wr v (+ t_wr)
+    for (int a = 0; a < d; ++a) {
+      double s = point ? Twr[d * d + a] : 0.0;
+      for (int q = 0; q < d; ++q) s += Twr[a + q * d] * v[q];
+      g[a] = s;
+    }
+  };
+  double g[3];
+  for (int col = 0; col < k; ++col) {
+    bool point;
+    if (se)
+      point = (col % dh) == d;
+    else
+      point = col >= d * n + l;  // translations and landmarks move with the frame, rotations / unit spheres turn
+    apply(Tlocal + (size_t)col * d, point, g);
+    lifted(col, g);
+  }
+}
+
 }  // namespace dcora

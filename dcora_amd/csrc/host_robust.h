@@ -33,4 +33,20 @@ void robust_single_pose_averaging(int d, int n, const double *R, const double *t
                                   const double *tau, double threshold, double *Ropt, double *topt,
                                   std::vector<int> &inliers);
 
+// ---- cross-robot frame alignment (host logic around the solver, ref src/Agent.cpp:460-520, 694-833) ----
+// poses are d x (d+1) column-major [R t]
+// Agent::computeNeighborTransform: the transform world2 <- world1 implied by one inter-robot loop closure, from the
+// neighbour's pose of that closure in world2 and my pose of it in world1; incoming: I am the measurement's p2
+void neighbor_transform(int d, bool incoming, const double *Rm, const double *tm, const double *T_w2_f2,
+                        const double *T_w1_f1, double *T_out);
+// computeRobustNeighborTransform (two_stage = false: GNC pose averaging, kappa 1.82, tau 0.01, 90 % quantile) and
+// computeRobustNeighborTransformTwoStage (GNC rotation averaging at ~30 deg, then the inliers' mean translation);
+// false when fewer than min_inliers candidates agree
+bool robust_neighbor_transform(int d, int m, const double *cand, bool two_stage, int min_inliers, double *T,
+                               int *num_inliers);
+// Agent::initializeInGlobalFrame: X = YLift * (T_world_robot applied to the local estimate); Tlocal d x k in this
+// ABI's ordering (SE when l = b = 0, RA otherwise), YLift r x d, X r x k
+void initialize_in_global_frame(int r, int d, int n, int l, int b, const double *T_world_robot, const double *Tlocal,
+                                const double *YLift, double *X);
+
 }  // namespace dcora

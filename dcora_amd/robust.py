@@ -105,3 +105,36 @@ def solveRobustPGO(ds, params, robust, fixedWeight=None, T0=None, device=0):
     finally:
         capi.lib().dcora_dataset_destroy(h)
     return unF(out, ds.d, (ds.d + 1) * ds.n), w
+
+
+# ---- cross-robot frame alignment (ref src/Agent.cpp:460-520, 694-833); poses are d x (d+1) arrays [R t] ----
+def computeNeighborTransforms(incoming, meas_R, meas_t, nbr_poses, my_poses):
+    """Agent::computeNeighborTransform for every inter-robot loop closure: list of T_world2_world1"""
+    from .capi import Dims  # noqa: F401
+    m, d = len(meas_R), meas_R[0].shape[0]
+    inc = np.ascontiguousarray(incoming, np.int32)
+    out = np.zeros(m * d * (d + 1))
+    cat = lambda Ms: np.concatenate([F(M) for M in Ms])
+    tflat = np.ascontiguousarray(np.concatenate([np.asarray(t, np.float64).reshape(-1) for t in meas_t]))
+    check(capi.lib().dcora_agent_neighbor_transforms(d, m, inc, cat(meas_R), tflat, cat(nbr_poses), cat(my_poses), out))
+    return [unF(out[i * d * (d + 1):(i + 1) * d * (d + 1)], d, d + 1) for i in range(m)]
+
+
+def computeRobustNeighborTransform(candidates, two_stage=False, robustInitMinInliers=2):
+    """Agent::computeRobustNeighborTransform[TwoStage]: (T_world_robot or None, number of inliers)"""
+    m, d = len(candidates), candidates[0].shape[0]
+    flat = np.concatenate([F(T) for T in candidates])
+    T, nin, ok = np.zeros(d * (d + 1)), C.c_int(), C.c_int()
+    check(capi.lib().dcora_agent_robust_neighbor_transform(d, m, flat, int(two_stage), robustInitMinInliers, T,
+                                                           C.byref(nin), C.byref(ok)))
+    return (unF(T, d, d + 1) if ok.value else None), nin.value
+
+
+def initializeInGlobalFrame(T_world_robot, T_local, YLift, n, l=0, b=0):
+    """Agent::initializeInGlobalFrame: the lifted start point r x k of an agent whose local estimate is T_local"""
+    from .capi import Dims
+    d, r = T_world_robot.shape[0], YLift.shape[0]
+    dims = Dims(r, d, n, l, b)
+    out = np.zeros(r * T_local.shape[1])
+    check(capi.lib().dcora_agent_initialize_in_global_frame(C.byref(dims), F(T_world_robot), F(T_local), F(YLift), out))
+    return unF(out, r, T_local.shape[1])

@@ -295,6 +295,20 @@ int dcora_robust_single_pose_averaging(int d, int n, const double *R, const doub
 /* computeMeasurementError of every measurement of the dataset at once (ref src/DCORA_utils.cpp:2095-2101;
  * Agent::computeMeasurementResidual, ref src/Agent.cpp:1342-1389): X is r x (d+1) n (SE ordering, r >= d, lifted or
  * not); out[i] = kappa |Y1 R - Y2|^2 + tau |p2 - p1 - Y1 t|^2, weights not applied */
+/* ---- cross-robot frame alignment (ref src/Agent.cpp:460-520, 694-833); poses d x (d+1) column-major [R t] ---- */
+/* Agent::computeNeighborTransform for m inter-robot loop closures: incoming[i] != 0 when this robot is the
+ * measurement's second pose; nbr_pose[i] the neighbour's pose of the closure in the neighbour's (world2) frame,
+ * my_pose[i] my pose of it in my (world1) frame; T_out[i] = T_world2_world1 implied by closure i */
+int dcora_agent_neighbor_transforms(int d, int m, const int *incoming, const double *meas_R, const double *meas_t,
+                                    const double *nbr_pose, const double *my_pose, double *T_out);
+/* Agent::computeRobustNeighborTransform (two_stage = 0) / computeRobustNeighborTransformTwoStage (two_stage != 0)
+ * over m candidate transforms; *ok = 0 when fewer than min_inliers (AgentParameters::robustInitMinInliers) agree */
+int dcora_agent_robust_neighbor_transform(int d, int m, const double *candidates, int two_stage, int min_inliers,
+                                          double *T_world_robot, int *num_inliers, int *ok);
+/* Agent::initializeInGlobalFrame: X (r x k) = YLift (r x d) * T_world_robot applied to the local estimate (d x k,
+ * SE ordering when dims.l = dims.b = 0, RA ordering otherwise) */
+int dcora_agent_initialize_in_global_frame(const dcora_dims *dims, const double *T_world_robot,
+                                           const double *T_local, const double *YLift, double *X);
 int dcora_measurement_errors(dcora_dataset_t ds, int r, const double *X, double *out, int device);
 /* solvePGO (ref src/DCORA_solver.cpp:304-328): T0 (d x (d+1) n) or NULL for the chordal start; one optimize() at
  * rank d with params */

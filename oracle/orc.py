@@ -511,3 +511,52 @@ def solve_robust_pgo(ds, fixed, T0=None, robust=None, **opt):
     L.orc_solve_robust_pgo(h, _opt(**opt), rp, np.ascontiguousarray(fixed, np.int32), _vp(t0), out, w)
     L.orc_ds_free(h)
     return unF(out, ds.d, (ds.d + 1) * ds.n), w
+
+
+# ---- cross-robot frame alignment: numpy restatement (ref src/Agent.cpp:460-520, 694-833) ----
+def _pose4(T):
+    d = T.shape[0]
+    M = np.eye(d + 1)
+    M[:d] = T
+    return M
+
+
+def neighbor_transform(incoming, Rm, tm, T_w2_f2, T_w1_f1):
+    """Agent::computeNeighborTransform (:694-727) in homogeneous matrices"""
+    d = Rm.shape[0]
+    dT = np.eye(d + 1)
+    dT[:d, :d], dT[:d, d] = Rm, tm
+    f1f2 = np.linalg.inv(dT) if incoming else dT
+    T_w2_f1 = _pose4(T_w2_f2) @ np.linalg.inv(f1f2)
+    return (T_w2_f1 @ np.linalg.inv(_pose4(T_w1_f1)))[:d]
+
+
+def robust_neighbor_transform(cands, two_stage=False, min_inliers=2):
+    """computeRobustNeighborTransform (:782-833) / ...TwoStage (:729-780) on the oracle's GNC averaging"""
+    d = cands[0].shape[0]
+    Rs, ts = [T[:, :d] for T in cands], [T[:, d] for T in cands]
+    m = len(cands)
+    if two_stage:
+        R, inl = robust_single_rotation_averaging(Rs, kappa=np.ones(m), threshold=2 * np.sqrt(2) * np.sin(0.25))
+        if len(inl) < min_inliers:
+            return None, len(inl)
+        t = np.mean([ts[i] for i in inl], axis=0)
+    else:
+        R, t, inl = robust_single_pose_averaging(Rs, ts, kappa=1.82 * np.ones(m), tau=0.01 * np.ones(m),
+                                                 threshold=error_threshold_at_quantile(0.9, 3))
+        if len(inl) < min_inliers:
+            return None, len(inl)
+    return np.hstack([R, np.asarray(t).reshape(d, 1)]), len(inl)
+
+
+def initialize_in_global_frame(T_world_robot, T_local, YLift, n, l=0, b=0):
+    """Agent::initializeInGlobalFrame (:460-520) with alignTrajectoryToFrame / alignUnitSpheresToFrame /
+    alignLandmarksToFrame (src/DCORA_utils.cpp:2222-2260)"""
+    d = T_world_robot.shape[0]
+    R, t = T_world_robot[:, :d], T_world_robot[:, d:d + 1]
+    G = R @ T_local
+    if l == 0 and b == 0:
+        G[:, d::d + 1] += t
+    else:
+        G[:, d * n + l:] += t
+    return YLift @ G

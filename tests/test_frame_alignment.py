@@ -1,0 +1,114 @@
+"""Cross-robot frame alignment around the solver (host logic, no GPU): Agent::computeNeighborTransform,
+computeRobustNeighborTransform[TwoStage], initializeInGlobalFrame (ref src/Agent.cpp:460-520, 694-833).
+The C ABI against the numpy restatement in oracle/orc.py and against the construction's ground truth: a robot whose
+local frame differs from the world by a known transform, linked to an already-initialised neighbour by inter-robot
+loop closures of which a third are outliers."""
+import numpy as np
+import pytest
+
+import common
+
+
+def _rand_rot(rng, d):
+    Q = np.linalg.qr(rng.standard_normal((d, d)))[0]
+    if np.linalg.det(Q) < 0:
+        Q[:, 0] = -Q[:, 0]
+    return Q
+
+
+def _rand_pose(rng, d, scale=5.0):
+    return np.hstack([_rand_rot(rng, d), scale * rng.standard_normal((d, 1))])
+
+
+def _h(T):
+    d = T.shape[0]
+    M = np.eye(d + 1)
+    M[:d] = T
+    return M
+
+
+def _scenario(d, seed, m=12, outliers=4):
+    rng = np.random.default_rng(seed)
+    T_wr = _rand_pose(rng, d)                       # world <- my local frame (the unknown)
+    mine_world = [_rand_pose(rng, d) for _ in range(m)]
+    nbr_world = [_rand_pose(rng, d) for _ in range(m)]
+    mine_local = [(np.linalg.inv(_h(T_wr)) @ _h(T))[:d] for T in mine_world]
+    incoming = np.array([i % 2 for i in range(m)], np.int32)
+    Rm, tm = [], []
+    for i in range(m):
+        a, b = (nbr_world[i], mine_world[i]) if incoming[i] else (mine_world[i], nbr_world[i])  # p1 -> p2
+        dT = np.linalg.inv(_h(a)) @ _h(b)
+        if i >= m - outliers:  # a wrong closure: 120 degrees and 200 m off (outside the 30 degree / 10 m gates)
+            c, s = np.cos(2 * np.pi / 3), np.sin(2 * np.pi / 3)
+            P = np.eye(d + 1)
+            P[:2, :2] = [[c, -s], [s, c]]
+            P[:d, d] = 200.0 * (1 + rng.random(d))
+            dT = dT @ P
+        Rm.append(dT[:d, :d].copy())
+        tm.append(dT[:d, d].copy())
+    return T_wr, incoming, Rm, tm, nbr_world, mine_local
+
+
+@pytest.mark.parametrize("d", [2, 3])
+def test_neighbor_transform_candidates(built, d):
+    from dcora_amd import robust as rb
+    from oracle import orc
+    T_wr, incoming, Rm, tm, nbr, mine = _scenario(d, 7 + d)
+    got = rb.computeNeighborTransforms(incoming, Rm, tm, nbr, mine)
+    for i, T in enumerate(got):
+        want = orc.neighbor_transform(bool(incoming[i]), Rm[i], tm[i], nbr[i], mine[i])
+        assert np.abs(T - want).max() < 1e-11
+        if i < 8:  # a correct closure implies the true transform exactly
+            assert np.abs(T - T_wr).max() < 1e-10
+    assert max(np.abs(T - T_wr).max() for T in got[8:]) > 0.1
+
+
+@pytest.mark.parametrize("d", [2, 3])
+@pytest.mark.parametrize("two_stage", [False, True])
+def test_robust_neighbor_transform_rejects_outlier_closures(built, d, two_stage):
+    from dcora_amd import robust as rb
+    from oracle import orc
+    T_wr, incoming, Rm, tm, nbr, mine = _scenario(d, 21 + d)
+    rng = np.random.default_rng(3)
+    cands = rb.computeNeighborTransforms(incoming, Rm, tm, nbr, mine)
+    for T in cands[:8]:  # small noise on the correct ones
+        T[:, d] += 0.01 * rng.standard_normal(d)
+    T, nin = rb.computeRobustNeighborTransform(cands, two_stage=two_stage, robustInitMinInliers=2)
+    To, nino = orc.robust_neighbor_transform(cands, two_stage=two_stage, min_inliers=2)
+    assert T is not None and To is not None and nin == nino == 8
+    assert np.abs(T - To).max() < 1e-9
+    # GNC stops once every weight is within 1e-8 of 0 or 1: the rejected closures keep a vanishing pull
+    assert np.abs(T[:, :d] - T_wr[:, :d]).max() < 1e-4 and np.abs(T[:, d] - T_wr[:, d]).max() < 0.1
+    # AgentParameters::robustInitMinInliers above the agreeing set: no initialisation from this neighbour
+    T, nin = rb.computeRobustNeighborTransform(cands, two_stage=two_stage, robustInitMinInliers=9)
+    assert T is None and nin == 8
+
+
+@pytest.mark.parametrize("d,l,b", [(2, 0, 0), (3, 0, 0), (2, 3, 2), (3, 4, 1)])
+def test_initialize_in_global_frame(built, d, l, b):
+    from dcora_amd import robust as rb
+    from oracle import orc
+    rng = np.random.default_rng(5)
+    n, r = 6, d + 2
+    T_wr = _rand_pose(rng, d)
+    poses = [_rand_pose(rng, d) for _ in range(n)]
+    if l == 0 and b == 0:
+        T_local = np.hstack(poses)
+    else:
+        S = rng.standard_normal((d, l))
+        S /= np.linalg.norm(S, axis=0)
+        T_local = np.hstack([np.hstack([P[:, :d] for P in poses]), S, np.hstack([P[:, d:] for P in poses]),
+                             rng.standard_normal((d, b))])
+    YLift = np.linalg.qr(rng.standard_normal((r, d)))[0]
+    X = rb.initializeInGlobalFrame(T_wr, T_local, YLift, n, l=l, b=b)
+    assert np.abs(X - orc.initialize_in_global_frame(T_wr, T_local, YLift, n, l=l, b=b)).max() < 1e-12
+    # pose i of the result is YLift * (T_world_robot * T_i)
+    for i, P in enumerate(poses):
+        W = (_h(T_wr) @ _h(P))[:d]
+        if l == 0 and b == 0:
+            got = X[:, i * (d + 1):(i + 1) * (d + 1)]
+        else:
+            got = np.hstack([X[:, d * i:d * i + d], X[:, d * n + l + i:d * n + l + i + 1]])
+        assert np.abs(got - YLift @ W).max() < 1e-12
+    if l:
+        assert np.allclose(np.linalg.norm(X[:, d * n:d * n + l], axis=0), 1.0)
