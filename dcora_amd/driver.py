@@ -1,0 +1,71 @@
+"""The synchronous multi-robot driver of the reference (examples/MultiRobotExample.cpp:121-372) over the C ABI:
+
+    for r = r_min, r_min + 1, ...:
+        agents at rank r, X = current point                       (:172-217)
+        RBCD++ until |rgrad| < tol or max_iters                   (:223-307)   dcora_rbcd_run
+        S = Q - Lambda(X);  fastVerification(S, min_eig_tol)      (:320-334)   dcora_cert_*
+        certified: done;  else escapeSaddle into rank r + 1       (:352-366)   dcora_problem_escape_saddle
+
+Everything numerical runs on the device; this file is the control flow of the example program."""
+import time
+
+import numpy as np
+
+from . import QuadraticProblem, RbcdSession, build_Q_pgo, dual_certificate, fast_verification
+
+
+def multi_robot_example(ds, X0, num_robots=5, r_min=5, r_max=100, max_iters=1000, rgrad_tol=0.1, min_eig_tol=1e-3,
+                        gradient_tolerance=1e-6, preconditioned_gradient_tolerance=1e-6, acceleration=True,
+                        params=None, device=0):
+    """X0: r_min x (d+1) n start point.  Returns a dict: X (final rank x k), rank, certified, theta, per-level
+    records (rank, iterations, cost 2f, gradnorm, seconds of RBCD / certification / escape) and the traces."""
+    d, n = ds.d, ds.n
+    k = (d + 1) * n
+    Q = build_Q_pgo(ds)
+    X = np.asarray(X0, dtype=np.float64)
+    if X.shape != (r_min, k):
+        raise ValueError("X0 must be r_min x (d+1) n")
+    levels, cost, gradnorm, selected, rank = [], [], [], [], []
+    certified, theta, total = False, 0.0, 0
+    r = r_min
+    while r < r_max:
+        s = RbcdSession(ds, num_robots=num_robots, r=r, acceleration=acceleration, params=params, device=device)
+        s.set_X(X)
+        t0 = time.perf_counter()
+        out = s.run(max_iters=max_iters, rgrad_tol=rgrad_tol)
+        t1 = time.perf_counter()
+        Xopt = s.get_X()
+        s.close()
+        total += out["iters"]
+        cost.append(out["cost"])
+        gradnorm.append(out["gradnorm"])
+        selected.append(out["selected"])
+        rank.append(np.full(out["iters"], r, np.int32))
+        S = dual_certificate(r, d, n, Xopt, Q, device=device)
+        psd, theta, v, lmin = fast_verification(S, min_eig_tol, block=d + 1, device=device)
+        t2 = time.perf_counter()
+        lev = {"rank": r, "iterations": int(out["iters"]), "cost_2f": float(out["cost"][-1]),
+               "gradnorm": float(out["gradnorm"][-1]), "rbcd_s": t1 - t0, "certification_s": t2 - t1,
+               "certified": bool(psd), "theta": float(theta)}
+        levels.append(lev)
+        X = Xopt
+        if psd:
+            certified = True
+            break
+        if theta >= -min_eig_tol / 2:  # :333-335: the eigenvalue computation did not reach the precision to escape
+            raise RuntimeError("escape direction computation did not converge to the desired precision")
+        Pn = QuadraticProblem(r + 1, d, n, Q, device=device)
+        Xn = Pn.escapeSaddle(Xopt, theta, v, gradient_tolerance, preconditioned_gradient_tolerance)
+        Pn.close()
+        lev["escape_s"] = time.perf_counter() - t2
+        if Xn is None:  # :367-370: no descent found along the escape direction
+            lev["escaped"] = False
+            break
+        lev["escaped"] = True
+        X = Xn
+        r += 1
+    cat = lambda parts, dt: np.concatenate(parts) if parts else np.zeros(0, dt)
+    return {"X": X, "rank": X.shape[0], "certified": certified, "theta": float(theta), "total_iters": int(total),
+            "levels": levels, "cost": cat(cost, float), "gradnorm": cat(gradnorm, float),
+            "selected": cat(selected, np.int32), "rank_trace": cat(rank, np.int32)}
+

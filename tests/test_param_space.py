@@ -66,3 +66,30 @@ def test_rbcd_with_rgd_local_solver(env, name, R, r):
     out = s.run(max_iters=iters, rgrad_tol=1e-12)
     assert np.array_equal(out["selected"], tr["selected"])
     assert np.allclose(out["cost"], tr["cost"], rtol=1e-9)
+
+
+@pytest.mark.parametrize("name,R,r_min,seed", [("tinyGrid3D", 3, 3, 21), ("smallGrid3D", 5, 3, 4)])
+def test_riemannian_staircase_of_the_multi_robot_driver(env, name, R, r_min, seed):
+    """examples/MultiRobotExample.cpp:172-372 from a random start at rank d: RBCD++ to a critical point, certificate,
+    escape into the next rank, until fastVerification accepts.  The escape direction is an eigenvector (sign and
+    Lanczos rounding are not canonical), so the two sides are compared on what the flow certifies: the optimum."""
+    da, orc = env
+    from dcora_amd import driver
+    ds, dso = common.product_dataset(name), common.oracle_dataset(name)
+    X0 = common.random_point(r_min, ds.d, ds.n, seed, orc.project_to_manifold)
+    kw = dict(max_iters=400, rgrad_tol=0.05)
+    out = driver.multi_robot_example(ds, X0, num_robots=R, r_min=r_min, r_max=r_min + 6, **kw)
+    tr = orc.run_rbcd(dso, X0, num_robots=R, r_min=r_min, r_max=r_min + 6, max_iters=400, rgrad_tol=0.05, staircase=1)
+    assert out["certified"] and tr["certified"] == 1
+    assert out["rank"] > r_min  # the staircase did climb
+    assert [lv["escaped"] for lv in out["levels"][:-1]] == [True] * (len(out["levels"]) - 1)
+    # the first level has no eigenvector in it: identical trace
+    n0 = out["levels"][0]["iterations"]
+    assert np.array_equal(out["selected"][:n0], tr["selected"][:n0])
+    assert np.allclose(out["cost"][:n0], tr["cost"][:n0], rtol=1e-7)
+    f_gpu, f_cpu = out["levels"][-1]["cost_2f"], tr["cost"][-1]
+    assert abs(f_gpu - f_cpu) < 1e-3 * abs(f_cpu)  # levels end at |rgrad| < 0.05 or 400 iterations: same optimum
+    # the oracle certifies the device's final point as well
+    Qo = orc.build_Q_pgo(dso)
+    So = orc.dual_certificate(out["rank"], ds.d, ds.n, out["X"], Qo)
+    assert orc.fast_verification(So, 1e-3, block=ds.d + 1)[0]
