@@ -69,3 +69,54 @@ def multi_robot_example(ds, X0, num_robots=5, r_min=5, r_max=100, max_iters=1000
             "levels": levels, "cost": cat(cost, float), "gradnorm": cat(gradnorm, float),
             "selected": cat(selected, np.int32), "rank_trace": cat(rank, np.int32)}
 
+
+def loop_closure_mask(ds, num_robots):
+    """measurements the robust outer loop reweights: everything but odometry, i.e. but consecutive poses of one
+    robot under the driver's contiguous partition (ref src/Graph.cpp activeLoopClosures / odometry split)"""
+    per = ds.n // num_robots
+    rob = np.minimum(ds.ids[:, [1, 3]] // per, num_robots - 1)
+    return ~((rob[:, 0] == rob[:, 1]) & (ds.ids[:, 3] == ds.ids[:, 1] + 1))
+
+
+def multi_robot_gnc_example(ds, X0, num_robots=5, r=5, robust=None, num_weight_updates=10, inner_iters=30,
+                            rgrad_tol=0.1, max_final_iters=1000, acceleration=True, params=None, fixed=None,
+                            device=0):
+    """The agents' robust outer loop (ref src/Agent.cpp:1280-1441) around the RBCD session, for all agents at once:
+
+        initializeRobustOptimization: weight 1 on every loop closure that is not fixed, RobustCost reset   (:1332-1346)
+        repeat robustOptNumWeightUpdates times:
+            RBCD++ for at most robustOptInnerIters iterations (or until |rgrad| < tol)                    (:1280-1330)
+            updateMeasurementWeights: residual = sqrt(computeMeasurementError) on the lifted iterate,
+                weight = RobustCost::weight(residual); data matrices rebuilt; RobustCost::update;
+                warm start (robustOptNumResets = 0); acceleration re-initialised                          (:1397-1441)
+        RBCD++ to convergence with the final weights
+
+    ds.vals[:, -1] (the weights) is updated in place.  Returns X, weights, per-round records."""
+    from . import robust as rb
+    robust = robust or rb.RobustCostParameters("GNC_TLS")
+    lc = loop_closure_mask(ds, num_robots)
+    if fixed is not None:
+        lc &= ~np.asarray(fixed, bool)
+    w = ds.vals[:, -1]
+    w[lc] = 1.0
+    X = np.asarray(X0, dtype=np.float64)
+    rounds = []
+
+    def rbcd(X, iters):
+        s = RbcdSession(ds, num_robots=num_robots, r=r, acceleration=acceleration, params=params, device=device)
+        s.set_X(X)
+        out = s.run(max_iters=iters, rgrad_tol=rgrad_tol)
+        Xn = s.get_X()
+        s.close()
+        return Xn, out
+
+    for u in range(num_weight_updates):
+        X, out = rbcd(X, inner_iters)
+        e = rb.measurement_errors(ds, X, device=device)
+        w[lc] = rb.robust_weights(np.sqrt(e[lc]), robust, num_updates=u)
+        rounds.append({"iterations": int(out["iters"]), "cost_2f": float(out["cost"][-1]),
+                       "accepted": int(np.sum(w[lc] > 1 - 1e-8)), "rejected": int(np.sum(w[lc] < 1e-8))})
+    X, out = rbcd(X, max_final_iters)
+    return {"X": X, "weights": w.copy(), "loop_closures": lc, "rounds": rounds,
+            "final": {"iterations": int(out["iters"]), "cost_2f": float(out["cost"][-1]),
+                      "gradnorm": float(out["gradnorm"][-1])}}

@@ -443,9 +443,9 @@ void orc_robust_pose_averaging(int d, int n, const double *R, const double *t, c
   for (int i = 0; i < n; ++i) inlier[i] = 0;
   for (int i : in) inlier[i] = 1;
 }
-void orc_measurement_errors(void *dsh, const double *T, double *out) {
+void orc_measurement_errors(void *dsh, int rows, const double *T, double *out) {
   Dataset *ds = (Dataset *)dsh;
-  const Mat Tm = view_mat(ds->d, (ds->d + 1) * ds->n, T);
+  const Mat Tm = view_mat(rows, (ds->d + 1) * ds->n, T);
   for (size_t i = 0; i < ds->meas.size(); ++i) out[i] = measurement_error(ds->meas[i], ds->d, Tm);
 }
 // opt: [gradnorm_tol, RTR_iterations, RTR_tCG_iterations, RTR_initial_radius]; T0 may be null (chordal start)

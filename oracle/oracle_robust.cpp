@@ -173,18 +173,19 @@ void robust_single_pose_averaging(int d, int n, const double *R, const double *t
 }
 
 // ---- residuals and the centralised robust solve ----
-// computeMeasurementError (ref: src/DCORA_utils.cpp:2095-2101) with T d x (d+1) n in the SE ordering
+// computeMeasurementError (ref: src/DCORA_utils.cpp:2095-2101) with T r x (d+1) n in the SE ordering, r >= d
+// (the reference evaluates it on lifted blocks as well, src/Agent.cpp:1342-1395)
 double measurement_error(const Meas &m, int d, const Mat &T) {
-  const int dh = d + 1;
+  const int dh = d + 1, r = T.rows;
   double rot = 0, tr = 0;
   for (int c = 0; c < d; ++c)
-    for (int a = 0; a < d; ++a) {
+    for (int a = 0; a < r; ++a) {
       double s = 0;
       for (int q = 0; q < d; ++q) s += T(a, m.p1 * dh + q) * m.R[q + c * d];
       const double e = s - T(a, m.p2 * dh + c);
       rot += e * e;
     }
-  for (int a = 0; a < d; ++a) {
+  for (int a = 0; a < r; ++a) {
     double s = T(a, m.p2 * dh + d) - T(a, m.p1 * dh + d);
     for (int q = 0; q < d; ++q) s -= T(a, m.p1 * dh + q) * m.t[q];
     tr += s * s;

@@ -427,7 +427,7 @@ def _bind_robust():
     L.orc_robust_rotation_averaging.argtypes = [C.c_int, C.c_int, _dp, C.c_void_p, C.c_double, _dp, _ip]
     L.orc_robust_pose_averaging.argtypes = [C.c_int, C.c_int, _dp, _dp, C.c_void_p, C.c_void_p, C.c_double, _dp, _dp,
                                             _ip]
-    L.orc_measurement_errors.argtypes = [C.c_void_p, _dp, _dp]
+    L.orc_measurement_errors.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
     L.orc_solve_pgo.argtypes = [C.c_void_p, _dp, C.c_void_p, _dp]
     L.orc_solve_robust_pgo.argtypes = [C.c_void_p, _dp, _dp, _ip, C.c_void_p, _dp, _dp]
     L._robust_bound = True
@@ -481,7 +481,7 @@ def measurement_errors(ds, T):
     L = _bind_robust()
     h = L.orc_ds_create(ds.d, ds.n, ds.m, ds.ids, ds.vals)
     out = np.zeros(ds.m)
-    L.orc_measurement_errors(h, F(T), out)
+    L.orc_measurement_errors(h, int(np.asarray(T).shape[0]), F(T), out)
     L.orc_ds_free(h)
     return out
 
