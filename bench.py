@@ -75,7 +75,7 @@ def run_single(args, da, torch, ds, X0):
 
 
 class RankDriver:
-    """one process per GPU; agent a is hosted by rank a % world.  The exchanges between the phases of an iteration
+    """one process per GPU; agent a is hosted by rank a // ceil(R / world) (consecutive agents share a rank).  The exchanges between the phases of an iteration
     are the caller's (this class): RCCL collectives over packed public poses."""
 
     def __init__(self, da, torch, dist, ds, R, r, rank, world, acceleration=True):
@@ -93,8 +93,8 @@ class RankDriver:
         self.setup_s = time.perf_counter() - t0
         counts = [s.public_count(a) for a in range(R)]
         self.slot = slot = r * dh * max(counts)       # doubles per agent in the exchange buffers
-        self.per_rank = per_rank = (R + world - 1) // world  # agent a: rank a % world, slot a // world of that rank
-        self.owner = [a % world for a in range(R)]
+        self.per_rank = per_rank = (R + world - 1) // world  # agent a: rank a // per_rank, slot a % per_rank there
+        self.owner = [a // per_rank for a in range(R)]
         self.mine = torch.zeros(per_rank * slot, dtype=torch.float64, device=dev)
         self.everyone = torch.zeros(world * per_rank * slot, dtype=torch.float64, device=dev)
         self.one = torch.zeros(slot, dtype=torch.float64, device=dev)
@@ -138,13 +138,13 @@ class RankDriver:
         s, world, slot, esz = self.s, self.world, self.slot, self.esz
         for a in agents:
             if self.owner[a] == self.rank:
-                s.pack_public_dev(a, self.mine.data_ptr() + (a // world) * slot * esz)
+                s.pack_public_dev(a, self.mine.data_ptr() + (a % self.per_rank) * slot * esz)
         if self.staged:
             s.synchronize()
         self.allgather(self.everyone, self.mine)
         for a in agents:
             if self.owner[a] != self.rank:
-                s.unpack_public_dev(a, self.everyone.data_ptr() + (self.owner[a] * self.per_rank + a // world) * slot * esz)
+                s.unpack_public_dev(a, self.everyone.data_ptr() + (self.owner[a] * self.per_rank + a % self.per_rank) * slot * esz)
 
     def push(self, selected):
         # the new block of the selected agent goes to everyone (their evaluation and their next G need it)
@@ -407,6 +407,12 @@ def config5_run(da, with_cpu, iters=60, cpu_iters=4):
     except Exception as e:
         res["coloured_rbcd"] = {"error": str(e)}
     s.close()
+    try:  # 16 agents: two per GPU of an 8-GPU node, one of each colour, so that every tick keeps every GPU busy
+        s16 = da.RbcdSession(ds, num_robots=16, r=r, acceleration=False)
+        res["coloured_rbcd_16_agents"] = coloured_sweeps(SingleDriver(s16), X0, sweeps=6, warm=1)
+        s16.close()
+    except Exception as e:
+        res["coloured_rbcd_16_agents"] = {"error": str(e)}
     if with_cpu:
         from oracle import orc
         dso = orc.Dataset(ds.d, ds.n, ds.ids, ds.vals)
@@ -421,7 +427,7 @@ def config5_run(da, with_cpu, iters=60, cpu_iters=4):
 
 
 def config5_multi(da, torch, dist, rank, world, iters=60, sweeps=8):
-    """the same workload with one process per GPU: agent a on rank a % world, public poses over RCCL"""
+    """the same workload with one process per GPU (consecutive agents share a rank), public poses over RCCL"""
     from dcora_amd import synth
     R, r = 8, 5
     ds = synth.lattice_se3()
@@ -443,7 +449,7 @@ def config5_multi(da, torch, dist, rank, world, iters=60, sweeps=8):
 
     dt, state = drv.timed(one, iters)
     res = {"workload": "synthetic 50x50x40 SE(3) lattice (100000 poses, %d edges, seed 20250310), 8 agents, r=5" % ds.m,
-           "parallelism": "agents round-robin over %d rank(s)" % world,
+           "parallelism": "agents in consecutive groups over %d rank(s)" % world,
            "iterations": iters, "value": iters / dt, "unit": "RBCD iterations/s", "ms_per_step": 1e3 * dt / iters,
            "setup_s": drv.setup_s, "cost_2f_first": float(costs[0]), "cost_2f_last": float(costs[-1])}
     try:
@@ -451,6 +457,12 @@ def config5_multi(da, torch, dist, rank, world, iters=60, sweeps=8):
     except Exception as e:
         res["coloured_rbcd"] = {"error": str(e)}
     drv.s.close()
+    try:  # 16 agents on the chain: at 8 ranks agents 2g and 2g+1 (one of each colour) share rank g
+        drv16 = RankDriver(da, torch, dist, ds, 16, r, rank, world, acceleration=False)
+        res["coloured_rbcd_16_agents"] = coloured_sweeps(drv16, X0, sweeps=6, warm=1)
+        drv16.s.close()
+    except Exception as e:
+        res["coloured_rbcd_16_agents"] = {"error": str(e)}
     return res
 
 
@@ -584,7 +596,7 @@ def main():
         "data": "%s.g2o (public dataset shipped as a fixture), seeded random start point" % args.dataset,
         "config": {"workload": "%s.g2o, %d agents, r=%d, RBCD++ (accel, restart 30), RTR 3x50 tCG" %
                                (args.dataset, args.robots, args.rank_r),
-                   "parallelism": "agents round-robin over %d rank(s)" % world,
+                   "parallelism": "agents in consecutive groups over %d rank(s)" % world,
                    "final_cost_2f": c2, "final_gradnorm": gn},
     }
     line["coloured_rbcd"] = coloured

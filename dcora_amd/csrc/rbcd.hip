@@ -116,7 +116,7 @@ int RbcdSession::init(const HostDataset &ds, const dcora_rbcd_options &o) {
     a.n = P.end(b) - P.start(b);
     a.col0 = P.start(b) * dh;
     cs[b] = a.col0;
-    a.hosted = (b % o.world_size) == o.rank;
+    a.hosted = (b / ((R + o.world_size - 1) / o.world_size)) == o.rank;  // consecutive agents share a rank
     a.public_poses.assign(pub[b].begin(), pub[b].end());
     a.neighbors.assign(nb[b].begin(), nb[b].end());
     std::vector<int> cols;

@@ -203,7 +203,8 @@ typedef struct {
   int acceleration;     /* AgentParameters::acceleration */
   int restart_interval; /* AgentParameters::restartInterval (30) */
   dcora_ropt_params local; /* AgentParameters::localOptimizationParams */
-  int rank, world_size; /* this process hosts agents a with a % world_size == rank */
+  int rank, world_size; /* this process hosts the agents a with a / ceil(num_robots / world_size) == rank:
+                           consecutive agents share a rank, so the colours of a chain of agents spread evenly */
   int device;
   void *stream; /* hipStream_t the session enqueues on (e.g. the stream the caller's RCCL calls are ordered on, so
                    pack -> collective -> unpack needs no host synchronisation); NULL: the session creates its own */

@@ -1,4 +1,4 @@
-"""world_size-2 gloo test (CPU) of the one-process-per-GPU RBCD protocol used by bench.py: ownership a % world,
+"""world_size-2 gloo test (CPU) of the one-process-per-GPU RBCD protocol used by bench.py: ownership a // ceil(R / world),
 public-pose pack -> all_gather (pull) / broadcast (push) -> unpack, block-wise evaluation + all-reduce, greedy selection.  The GPU session is
 replaced by a numpy model with the same interface whose local solve is the oracle, so the distributed result must
 equal the single-process oracle run bit-for-bit in its selection sequence."""
@@ -40,7 +40,9 @@ def _worker(rank, world, port, tmpdir, mode="greedy"):
     cols = lambda b: slice(start[b] * dh, end[b] * dh)
     X0 = np.load(os.path.join(tmpdir, "X0.npy"))
     X = X0.copy()                      # every rank keeps a mirror; only owned blocks + public poses are authoritative
-    hosted = [b for b in range(R) if b % world == rank]
+    per_rank = (R + world - 1) // world      # agent a: rank a // per_rank, slot a % per_rank (as bench.py RankDriver)
+    owner = lambda a: a // per_rank
+    hosted = [b for b in range(R) if owner(b) == rank]
     probs = {}
     for b in hosted:
         Qbb = orc.CSR.from_scipy(sp.csr_matrix(Qg[cols(b), cols(b)]))
@@ -57,19 +59,18 @@ def _worker(rank, world, port, tmpdir, mode="greedy"):
 
     pidx = [np.array([p * dh + c for p in pub[a] for c in range(dh)], dtype=np.int64) for a in range(R)]
     slot = r * max(len(i) for i in pidx)
-    per_rank = (R + world - 1) // world      # agent a: rank a % world, slot a // world (as bench.py run_multi)
 
     def pull_all_but(sel):
         mine = torch.zeros(per_rank * slot, dtype=torch.float64)
         for a in hosted:
             if a != sel:
                 v = np.ascontiguousarray(X[:, pidx[a]].T).reshape(-1)
-                mine[(a // world) * slot:(a // world) * slot + v.size] = torch.from_numpy(v.copy())
+                mine[(a % per_rank) * slot:(a % per_rank) * slot + v.size] = torch.from_numpy(v.copy())
         parts = [torch.zeros(per_rank * slot, dtype=torch.float64) for _ in range(world)]
         dist.all_gather(parts, mine)
         for a in range(R):
-            if a != sel and a % world != rank:
-                v = parts[a % world][(a // world) * slot:(a // world) * slot + r * len(pidx[a])].numpy()
+            if a != sel and owner(a) != rank:
+                v = parts[owner(a)][(a % per_rank) * slot:(a % per_rank) * slot + r * len(pidx[a])].numpy()
                 X[:, pidx[a]] = v.reshape(len(pidx[a]), r).T
 
     def exchange_set(agents):
@@ -77,20 +78,20 @@ def _worker(rank, world, port, tmpdir, mode="greedy"):
         for a in agents:
             if a in hosted:
                 v = np.ascontiguousarray(X[:, pidx[a]].T).reshape(-1)
-                mine[(a // world) * slot:(a // world) * slot + v.size] = torch.from_numpy(v.copy())
+                mine[(a % per_rank) * slot:(a % per_rank) * slot + v.size] = torch.from_numpy(v.copy())
         parts = [torch.zeros(per_rank * slot, dtype=torch.float64) for _ in range(world)]
         dist.all_gather(parts, mine)
         for a in agents:
-            if a % world != rank:
-                v = parts[a % world][(a // world) * slot:(a // world) * slot + r * len(pidx[a])].numpy()
+            if owner(a) != rank:
+                v = parts[owner(a)][(a % per_rank) * slot:(a % per_rank) * slot + r * len(pidx[a])].numpy()
                 X[:, pidx[a]] = v.reshape(len(pidx[a]), r).T
 
     def push(a):
         buf = torch.zeros(r * len(pidx[a]), dtype=torch.float64)
-        if a % world == rank:
+        if owner(a) == rank:
             buf = torch.from_numpy(np.ascontiguousarray(X[:, pidx[a]].T).reshape(-1).copy())
-        dist.broadcast(buf, src=a % world)
-        if a % world != rank:
+        dist.broadcast(buf, src=owner(a))
+        if owner(a) != rank:
             X[:, pidx[a]] = buf.numpy().reshape(len(pidx[a]), r).T
 
     def evaluate():
