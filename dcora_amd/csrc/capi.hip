@@ -641,6 +641,11 @@ int dcora_agent_robust_neighbor_transform(int d, int m, const double *candidates
   return DCORA_OK;
   DCORA_CATCH
 }
+int dcora_fixed_stiefel_variable(int r, int d, double *Y) {
+  if (!Y || d < 1 || r < d) return bad("fixed_stiefel_variable: need r >= d >= 1");
+  fixed_stiefel_variable(r, d, Y);
+  return DCORA_OK;
+}
 int dcora_agent_initialize_in_global_frame(const dcora_dims *dims, const double *T_world_robot,
                                            const double *T_local, const double *YLift, double *X) {
   if (!dims || !T_world_robot || !T_local || !YLift || !X) return bad("null argument");

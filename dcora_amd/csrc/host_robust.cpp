@@ -243,6 +243,35 @@ bool robust_neighbor_transform(int d, int m, const double *cand, bool two_stage,
   return true;
 }
 
+void fixed_stiefel_variable(int r, int d, double *Y) {
+  unsigned long long s = 1;  // the reference seeds std::srand(1)
+  auto next = [&]() {
+    unsigned long long z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return 2.0 * ((z >> 11) * (1.0 / 9007199254740992.0)) - 1.0;
+  };
+  for (int c = 0; c < d; ++c) {
+    double *y = Y + (size_t)c * r;
+    double nrm = 0;
+    while (nrm < 1e-3) {  // a draw (numerically) inside the span of the earlier columns is redrawn
+      for (int a = 0; a < r; ++a) y[a] = next();
+      for (int pass = 0; pass < 2; ++pass)
+        for (int p = 0; p < c; ++p) {
+          const double *q = Y + (size_t)p * r;
+          double dot = 0;
+          for (int a = 0; a < r; ++a) dot += q[a] * y[a];
+          for (int a = 0; a < r; ++a) y[a] -= dot * q[a];
+        }
+      nrm = 0;
+      for (int a = 0; a < r; ++a) nrm += y[a] * y[a];
+      nrm = std::sqrt(nrm);
+    }
+    for (int a = 0; a < r; ++a) y[a] /= nrm;
+  }
+}
+
 void initialize_in_global_frame(int r, int d, int n, int l, int b, const double *Twr, const double *Tlocal,
                                 const double *YLift, double *X) {
   const int dh = d + 1;

@@ -44,6 +44,9 @@ void neighbor_transform(int d, bool incoming, const double *Rm, const double *tm
 // false when fewer than min_inliers candidates agree
 bool robust_neighbor_transform(int d, int m, const double *cand, bool two_stage, int min_inliers, double *T,
                                int *num_inliers);
+// fixedStiefelVariable (ref src/DCORA_utils.cpp:2053-2056): the same r x d orthonormal frame on every call and every
+// process (the lifting matrix all agents share); seeded splitmix64 entries, modified Gram-Schmidt
+void fixed_stiefel_variable(int r, int d, double *Y);
 // Agent::initializeInGlobalFrame: X = YLift * (T_world_robot applied to the local estimate); Tlocal d x k in this
 // ABI's ordering (SE when l = b = 0, RA otherwise), YLift r x d, X r x k
 void initialize_in_global_frame(int r, int d, int n, int l, int b, const double *T_world_robot, const double *Tlocal,

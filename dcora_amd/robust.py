@@ -138,3 +138,10 @@ def initializeInGlobalFrame(T_world_robot, T_local, YLift, n, l=0, b=0):
     out = np.zeros(r * T_local.shape[1])
     check(capi.lib().dcora_agent_initialize_in_global_frame(C.byref(dims), F(T_world_robot), F(T_local), F(YLift), out))
     return unF(out, r, T_local.shape[1])
+
+
+def fixedStiefelVariable(r, d):
+    """the shared lifting matrix YLift (ref src/DCORA_utils.cpp:2053-2056)"""
+    out = np.zeros(r * d)
+    check(capi.lib().dcora_fixed_stiefel_variable(r, d, out))
+    return unF(out, r, d)

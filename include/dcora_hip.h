@@ -306,6 +306,9 @@ int dcora_agent_neighbor_transforms(int d, int m, const int *incoming, const dou
  * over m candidate transforms; *ok = 0 when fewer than min_inliers (AgentParameters::robustInitMinInliers) agree */
 int dcora_agent_robust_neighbor_transform(int d, int m, const double *candidates, int two_stage, int min_inliers,
                                           double *T_world_robot, int *num_inliers, int *ok);
+/* fixedStiefelVariable (ref src/DCORA_utils.cpp:2053-2056): the lifting matrix YLift (r x d, orthonormal columns) the
+ * agents share; identical on every call and in every process */
+int dcora_fixed_stiefel_variable(int r, int d, double *Y);
 /* Agent::initializeInGlobalFrame: X (r x k) = YLift (r x d) * T_world_robot applied to the local estimate (d x k,
  * SE ordering when dims.l = dims.b = 0, RA ordering otherwise) */
 int dcora_agent_initialize_in_global_frame(const dcora_dims *dims, const double *T_world_robot,

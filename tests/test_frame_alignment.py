@@ -112,3 +112,45 @@ def test_initialize_in_global_frame(built, d, l, b):
         assert np.abs(got - YLift @ W).max() < 1e-12
     if l:
         assert np.allclose(np.linalg.norm(X[:, d * n:d * n + l], axis=0), 1.0)
+
+
+def test_fixed_stiefel_variable_generation_and_repeat(built):
+    """tests/testUtils.cpp:23-36 (testStiefelGeneration, testStiefelRepeat)"""
+    from dcora_amd import robust as rb
+    import dcora_amd as da
+    Y = rb.fixedStiefelVariable(5, 3)
+    assert np.linalg.norm(Y.T @ Y - np.eye(3)) <= 1e-5
+    for _ in range(10):
+        assert np.array_equal(rb.fixedStiefelVariable(5, 3), Y)
+    for (r, d) in [(2, 2), (3, 3), (8, 2), (16, 3)]:
+        Y = rb.fixedStiefelVariable(r, d)
+        assert np.linalg.norm(Y.T @ Y - np.eye(d)) <= 1e-12
+    with pytest.raises(da.DcoraError):
+        rb.fixedStiefelVariable(2, 3)
+
+
+@pytest.mark.parametrize("d,l,b", [(3, 0, 0), (3, 6, 0), (3, 0, 7), (2, 6, 7)])
+def test_align_to_frame_round_trip(built, d, l, b):
+    """tests/testUtils.cpp:268-331 (testAlignTrajectoryToFrame / UnitSpheres / Landmarks): aligning to a frame and then
+    to its inverse returns the input; unit spheres stay on the oblique manifold.  initializeInGlobalFrame(T) is the
+    alignment to T^-1 (src/Agent.cpp:481-491), taken here at rank d with the identity as lifting matrix."""
+    from dcora_amd import robust as rb
+    rng = np.random.default_rng(11)
+    n = 10
+    poses = [_rand_pose(rng, d) for _ in range(n)]
+    if l == 0 and b == 0:
+        T0 = np.hstack(poses)
+    else:
+        S = rng.standard_normal((d, l))
+        S /= np.maximum(np.linalg.norm(S, axis=0), 1e-300)
+        T0 = np.hstack([np.hstack([P[:, :d] for P in poses]), S, np.hstack([P[:, d:] for P in poses]),
+                        rng.standard_normal((d, b))])
+    Tw0 = _rand_pose(rng, d)
+    Tinv = np.linalg.inv(_h(Tw0))[:d]
+    I = np.eye(d)
+    T1 = rb.initializeInGlobalFrame(Tw0, T0, I, n, l=l, b=b)
+    T2 = rb.initializeInGlobalFrame(Tinv, T1, I, n, l=l, b=b)
+    assert np.abs(T2 - T0).max() < 1e-12 and np.abs(T1 - T0).max() > 1e-3
+    if l:
+        sph = T1[:, d * n:d * n + l]
+        assert np.allclose(np.linalg.norm(sph, axis=0), 1.0, atol=1e-12)

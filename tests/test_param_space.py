@@ -93,3 +93,37 @@ def test_riemannian_staircase_of_the_multi_robot_driver(env, name, R, r_min, see
     Qo = orc.build_Q_pgo(dso)
     So = orc.dual_certificate(out["rank"], ds.d, ds.n, out["X"], Qo)
     assert orc.fast_verification(So, 1e-3, block=ds.d + 1)[0]
+
+
+def test_projection_to_the_manifold_is_feasible(env):
+    """tests/testUtils.cpp:38-48, 82-134 (testStiefelProjection, testObliqueProjection, testProjectToSEMatrix,
+    testProjectToRAMatrix) on the device kernels: d = 3, r = 5, n = 100 (l = 5, b = 7 for the RA layout), 50 draws
+    for the single-block cases"""
+    da, orc = env
+    rng = np.random.default_rng(0)
+    d, r, n, l, b = 3, 5, 100, 5, 7
+    I = np.eye(d)
+    for _ in range(50):  # one pose: Stiefel block; one unit sphere: oblique column
+        M = rng.uniform(-1, 1, (r, d + 1))
+        Y = da.manifold_project(r, d, 1, M)[:, :d]
+        assert np.linalg.norm(Y.T @ Y - I) <= 1e-5
+        M = rng.uniform(-1, 1, (r, d + 1 + 1))
+        s = da.manifold_project(r, d, 1, M, l=1, b=0)[:, d]
+        assert abs(np.linalg.norm(s) - 1.0) <= 1e-5
+    M = rng.uniform(-1, 1, (r, (d + 1) * n))
+    X = da.manifold_project(r, d, n, M)
+    assert X.shape == (r, (d + 1) * n)
+    for i in range(n):
+        Y = X[:, i * (d + 1):i * (d + 1) + d]
+        assert np.linalg.norm(Y.T @ Y - I) <= 1e-5
+        assert np.array_equal(X[:, i * (d + 1) + d], M[:, i * (d + 1) + d])  # translations are left alone
+    M = rng.uniform(-1, 1, (r, (d + 1) * n + l + b))
+    X = da.manifold_project(r, d, n, M, l=l, b=b)
+    assert X.shape == M.shape
+    for i in range(n):
+        Y = X[:, i * d:(i + 1) * d]
+        assert np.linalg.norm(Y.T @ Y - I) <= 1e-5
+    for i in range(l):
+        assert abs(np.linalg.norm(X[:, d * n + i]) - 1.0) <= 1e-5
+    assert np.array_equal(X[:, d * n + l:], M[:, d * n + l:])
+    assert common.rel(X, orc.project_to_manifold(r, d, n, M, l=l, b=b)) < 1e-13
