@@ -522,3 +522,8 @@ def project_solution_raslam(X, r, d, n, l, b, device=0):
     out = np.zeros(d * k)
     check(capi.lib().dcora_round_project_solution_raslam(C.byref(dims), F(X), out, device))
     return unF(out, d, k)
+
+
+def log_trajectory(path, T, d, n):
+    """Logger::logTrajectory (ref src/Logger.cpp:107-145): T is d x (d+1) n"""
+    check(capi.lib().dcora_log_trajectory(str(path).encode(), d, n, F(np.asarray(T, dtype=np.float64))))

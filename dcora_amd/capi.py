@@ -142,6 +142,7 @@ SIGNATURES = {
     "dcora_robust_single_pose_averaging": (C.c_int, [C.c_int, C.c_int, _dp, _dp, _vp, _vp, C.c_double, _dp, _dp, _ip]),
     "dcora_agent_neighbor_transforms": (C.c_int, [C.c_int, C.c_int, _ip, _dp, _dp, _dp, _dp, _dp]),
     "dcora_agent_robust_neighbor_transform": (C.c_int, [C.c_int, C.c_int, _dp, C.c_int, C.c_int, _dp, _PI, _PI]),
+    "dcora_log_trajectory": (C.c_int, [C.c_char_p, C.c_int, C.c_int, _dp]),
     "dcora_fixed_stiefel_variable": (C.c_int, [C.c_int, C.c_int, _dp]),
     "dcora_agent_initialize_in_global_frame": (C.c_int, [C.POINTER(Dims), _dp, _dp, _dp, _dp]),
     "dcora_measurement_errors": (C.c_int, [_vp, C.c_int, _dp, _dp, C.c_int]),

@@ -1,4 +1,5 @@
 // extern "C" surface of libdcora_hip.so (declared in include/dcora_hip.h).
+#include <cstdio>
 #include <cstring>
 #include <new>
 
@@ -640,6 +641,48 @@ int dcora_agent_robust_neighbor_transform(int d, int m, const double *candidates
   *ok = robust_neighbor_transform(d, m, candidates, two_stage != 0, min_inliers, T_world_robot, num_inliers) ? 1 : 0;
   return DCORA_OK;
   DCORA_CATCH
+}
+int dcora_log_trajectory(const char *path, int d, int n, const double *T) {
+  if (!path || !T || n < 0 || (d != 2 && d != 3)) return bad("bad argument");
+  FILE *f = std::fopen(path, "w");
+  if (!f) {
+    set_last_error(std::string("cannot log trajectory to ") + path);
+    return DCORA_ERR_IO;
+  }
+  std::fprintf(f, "# pose_index x y z qx qy qz qw\n");
+  const int dh = d + 1;
+  for (int i = 0; i < n; ++i) {
+    double R[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, t[3] = {0, 0, 0};
+    const double *Ti = T + (size_t)i * dh * d;
+    for (int c = 0; c < d; ++c)
+      for (int a = 0; a < d; ++a) R[a][c] = Ti[a + c * d];
+    for (int a = 0; a < d; ++a) t[a] = Ti[a + d * d];
+    // rotation matrix -> quaternion with the branch rule of Eigen::Quaterniond(Matrix3d) the reference relies on
+    double q[4];  // x y z w
+    double tr = R[0][0] + R[1][1] + R[2][2];
+    if (tr > 0) {
+      double s = std::sqrt(tr + 1.0);
+      q[3] = 0.5 * s;
+      s = 0.5 / s;
+      q[0] = (R[2][1] - R[1][2]) * s;
+      q[1] = (R[0][2] - R[2][0]) * s;
+      q[2] = (R[1][0] - R[0][1]) * s;
+    } else {
+      int a = 0;
+      if (R[1][1] > R[0][0]) a = 1;
+      if (R[2][2] > R[a][a]) a = 2;
+      const int b = (a + 1) % 3, c = (b + 1) % 3;
+      double s = std::sqrt(R[a][a] - R[b][b] - R[c][c] + 1.0);
+      q[a] = 0.5 * s;
+      s = 0.5 / s;
+      q[3] = (R[c][b] - R[b][c]) * s;
+      q[b] = (R[b][a] + R[a][b]) * s;
+      q[c] = (R[c][a] + R[a][c]) * s;
+    }
+    std::fprintf(f, "%d %.9f %.9f %.9f %.9f %.9f %.9f %.9f\n", i, t[0], t[1], t[2], q[0], q[1], q[2], q[3]);
+  }
+  std::fclose(f);
+  return DCORA_OK;
 }
 int dcora_fixed_stiefel_variable(int r, int d, double *Y) {
   if (!Y || d < 1 || r < d) return bad("fixed_stiefel_variable: need r >= d >= 1");

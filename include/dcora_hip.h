@@ -306,6 +306,9 @@ int dcora_agent_neighbor_transforms(int d, int m, const int *incoming, const dou
  * over m candidate transforms; *ok = 0 when fewer than min_inliers (AgentParameters::robustInitMinInliers) agree */
 int dcora_agent_robust_neighbor_transform(int d, int m, const double *candidates, int two_stage, int min_inliers,
                                           double *T_world_robot, int *num_inliers, int *ok);
+/* Logger::logTrajectory (ref src/Logger.cpp:107-145): "# pose_index x y z qx qy qz qw", one line per pose, 9 decimals;
+ * T is d x (d+1) n (SE ordering); planar poses are embedded in 3D (z = 0, rotation about z) */
+int dcora_log_trajectory(const char *path, int d, int n, const double *T);
 /* fixedStiefelVariable (ref src/DCORA_utils.cpp:2053-2056): the lifting matrix YLift (r x d, orthonormal columns) the
  * agents share; identical on every call and in every process */
 int dcora_fixed_stiefel_variable(int r, int d, double *Y);

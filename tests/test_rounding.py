@@ -153,3 +153,49 @@ def test_device_ra_states_and_projection_match_oracle(built, name):
     assert np.allclose(Pp.T @ Pp, Po.T @ Po, atol=1e-8)
     Pp = da.project_solution_raslam(XL, r, d, n, l, b)
     assert np.allclose(Pp.T @ Pp, ra.gt.T @ ra.gt, atol=1e-8)
+
+
+@pytest.mark.parametrize("d", [2, 3])
+def test_trajectory_log_format(built, d, tmp_path):
+    """Logger::logTrajectory (ref src/Logger.cpp:107-145): header, one line per pose, 9 decimals, x y z qx qy qz qw
+    with Eigen's rotation-to-quaternion branch rule; planar poses are embedded in 3D"""
+    import dcora_amd as da
+    import g2o_np
+    rng = np.random.default_rng(3)
+    n = 40
+    T = np.zeros((d, (d + 1) * n))
+    Rs = []
+    for i in range(n):
+        Q = np.linalg.qr(rng.standard_normal((d, d)))[0]
+        if np.linalg.det(Q) < 0:
+            Q[:, 0] = -Q[:, 0]
+        if i == 0:
+            Q = np.eye(d)
+        if i == 1 and d == 3:  # half turn: trace < 0 branch
+            Q = np.diag([1.0, -1.0, -1.0])
+        Rs.append(Q)
+        T[:, i * (d + 1):i * (d + 1) + d] = Q
+        T[:, i * (d + 1) + d] = 10 * rng.standard_normal(d)
+    p = tmp_path / "trajectory.txt"
+    da.log_trajectory(p, T, d, n)
+    lines = p.read_text().splitlines()
+    assert lines[0] == "# pose_index x y z qx qy qz qw" and len(lines) == n + 1
+    for i, line in enumerate(lines[1:]):
+        tok = line.split()
+        assert int(tok[0]) == i and all(len(x.split(".")[1]) == 9 for x in tok[1:])
+        v = np.array(list(map(float, tok[1:])))
+        t3 = np.zeros(3)
+        t3[:d] = T[:, i * (d + 1) + d]
+        assert np.abs(v[:3] - t3).max() < 1e-9
+        R3 = np.eye(3)
+        R3[:d, :d] = Rs[i]
+        assert abs(np.linalg.norm(v[3:]) - 1) < 1e-8
+        assert np.abs(g2o_np.quat_R(*v[3:]) - R3).max() < 1e-8
+        tr = np.trace(R3)
+        if tr > 0:
+            assert v[6] > 0  # w = sqrt(trace + 1) / 2
+        else:
+            a = int(np.argmax(np.diag(R3)))
+            assert v[3 + a] > 0
+    with pytest.raises(da.DcoraError):
+        da.log_trajectory(tmp_path / "no_such_dir" / "t.txt", T, d, n)
