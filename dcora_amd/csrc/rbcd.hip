@@ -26,6 +26,19 @@ static void nesterov(hipStream_t st, const ManiDesc &m, int mode, int restart, i
     launch_nesterov(st, m, mode, restart, skip_lo, skip_hi, alpha, gamma, X, V, Y, XPrev, Yloc, Xloc.p[0]);
 }
 
+// The thread-per-pose Nesterov kernels take one result pointer: when the solver left its choice of buffer on the
+// device (ctl), read it back first.  (The 8-lanes-per-pose kernels pick on the device.)
+static int resolve_pick(DeviceProblem &pb, Buf2 *Xres, const SolverCtl **cs) {
+  if (*cs == nullptr || group_kernels(pb.m)) return DCORA_OK;
+  dcora_ropt_result tmp;
+  const int rc = pb.fetch_result(&tmp);
+  if (rc) return rc;
+  double *picked = pb.result_index() ? pb.X1.p : pb.X0.p;
+  *Xres = Buf2{{picked, picked}};
+  *cs = nullptr;
+  return DCORA_OK;
+}
+
 RbcdSession::~RbcdSession() {
   if (eval_host) (void)hipHostFree((void *)eval_host);
   if (x_stage) (void)hipHostFree((void *)x_stage);
@@ -254,12 +267,16 @@ int RbcdSession::phase_selected(int selected) {
                Buf2{{nullptr, nullptr}}, nullptr);
       rc = pb.optimize_dev(opt.local, &Xres, &cs);
       if (rc) return rc;
+      rc = resolve_pick(pb, &Xres, &cs);
+      if (rc) return rc;
       nesterov(st, pb.m, 2, 0, -1, -1, alpha, gamma, Xg.p + off, Vg.p + off, Yg.p + off, XPrevg.p + off, nullptr, Xres,
                cs);
       if (restart) {
         // restartNesterovAcceleration: X = XPrev; updateX(true, false); V = X; Y = X
         DCORA_HIP(hipMemcpyAsync(pb.X0.p, XPrevg.p + off, B, hipMemcpyDeviceToDevice, st));
         rc = pb.optimize_dev(opt.local, &Xres, &cs);
+        if (rc) return rc;
+        rc = resolve_pick(pb, &Xres, &cs);
         if (rc) return rc;
         nesterov(st, pb.m, 3, 0, -1, -1, alpha, gamma, Xg.p + off, Vg.p + off, Yg.p + off, XPrevg.p + off, nullptr,
                  Xres, cs);
