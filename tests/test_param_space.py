@@ -23,6 +23,8 @@ CASES = [
     ("smallGrid3D", 2, 3, True, 12),
     ("smallGrid3D", 7, 4, True, 20),
     ("smallGrid3D", 5, 8, True, 12),
+    ("smallGrid3D", 5, 9, True, 35),        # beyond the fused kernels' rank limit: general kernels, crosses a restart
+    ("smallGrid3D", 3, 12, False, 10),
     ("smallGrid3D", 5, 5, False, 15),
     ("smallGrid3D", 25, 5, True, 40),       # 5 poses per agent, crosses a restart
     ("tinyGrid3D", 3, 5, True, 10),
