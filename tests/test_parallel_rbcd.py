@@ -64,12 +64,11 @@ def test_colouring_is_proper(built, name, R):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,R", [("sphere2500", 5), ("torus3D", 8)])
-def test_coloured_tick_equals_one_after_the_other(built, name, R):
+@pytest.mark.parametrize("name,R,r", [("sphere2500", 5, 5), ("torus3D", 8, 5), ("torus3D", 8, 9)])
+def test_coloured_tick_equals_one_after_the_other(built, name, R, r):
     import dcora_amd as da
     from oracle import orc
     ds = common.product_dataset(name)
-    r = 5
     X0 = common.random_point(r, ds.d, ds.n, 11, orc.project_to_manifold)
     par = da.RbcdSession(ds, num_robots=R, r=r, acceleration=False)
     seq = da.RbcdSession(ds, num_robots=R, r=r, acceleration=False)
