@@ -297,6 +297,22 @@ def roofline(da, ds, r, robots):
             main["traffic"] = json.load(open(pmc)).get("k_fused_precond_bytes_per_launch")
         except Exception:
             pass
+    try:  # the same kernel on a block 2.5 x larger (sphere2500 split in two, k = 5000): a longer launch
+        nb2, ids2, vals2 = agent_block(ds, 2, 0)
+        Q2 = da.build_Q_pgo(ds, n=nb2, agent=0, ids=ids2, vals=vals2)
+        k2 = (ds.d + 1) * nb2
+        P2 = da.QuadraticProblem(r, ds.d, nb2, Q2, G=np.zeros((r, k2)), reg=0.1)
+        P2.f(np.zeros((r, k2)))
+        ms2, nbytes2 = P2.time_precond(reps=100)
+        kind2 = P2.precond_info()["kind"]
+        P2.close()
+        ach2 = nbytes2 / (ms2 * 1e-3) / 1e9
+        out["precond_dense_k%d" % k2] = {"kernel": "k_fused_precond (%s preconditioner, one agent of 2)" % kind2,
+                                         "achieved": ach2, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                         "frac": ach2 / HBM_PEAK_GBPS, "bytes_per_launch": nbytes2,
+                                         "avg_launch_us": ms2 * 1e3, "k": k2}
+    except Exception as e:
+        out["precond_dense_k5000"] = {"error": str(e)}
     Q = da.build_Q_pgo(ds)
     k = (ds.d + 1) * ds.n
     P = da.QuadraticProblem(r, ds.d, ds.n, Q, G=np.zeros((r, k)), reg=-1.0)
