@@ -14,7 +14,7 @@ import numpy as np
 from . import capi
 from .capi import DcoraError, Dims, ROptParams, ROptResult, RbcdOptions, F, unF, check
 
-__all__ = ["QuadraticProblem", "QuadraticOptimizer", "ROptParameters", "Dataset", "Csr", "RbcdSession", "DcoraError",
+__all__ = ["QuadraticProblem", "QuadraticOptimizer", "ROptParameters", "Dataset", "Csr", "RbcdSession", "RaRbcdSession", "DcoraError",
            "build_Q_pgo", "dual_certificate", "is_psd", "min_eig", "fast_verification", "manifold_project",
            "device_count"]
 
@@ -114,9 +114,10 @@ class RADataset:
     """centralised range-aided SLAM problem read from a .pyfg file (ref src/DCORA_utils.cpp:437-1167, 1169-1365;
     Q: ref src/Graph.cpp:824-1188).  X is r x k in the RA ordering [Y1..Yn | s1..sl | p1..pn | L1..Lb]."""
 
-    def __init__(self, path, init_seed=20250310):
+    def handle(self):
+        """a fresh dcora_radataset_t of the file (the caller destroys it)"""
         L = capi.lib()
-        tmp = None
+        path, tmp = self.path, None
         if str(path).endswith(".gz"):
             fd, tmp = tempfile.mkstemp(suffix=".pyfg")
             with os.fdopen(fd, "wb") as out, gzip.open(path, "rb") as src:
@@ -128,6 +129,12 @@ class RADataset:
         finally:
             if tmp:
                 os.unlink(tmp)
+        return h
+
+    def __init__(self, path, init_seed=20250310):
+        L = capi.lib()
+        self.path = path
+        h = self.handle()
         info = np.zeros(7, np.int32)
         check(L.dcora_radataset_info(h, info))
         self.d, self.n, self.l, self.b = (int(x) for x in info[:4])
@@ -491,6 +498,77 @@ class RbcdSession:
 
     def synchronize(self):
         check(capi.lib().dcora_rbcd_synchronize(self.h))
+
+
+class RaRbcdSession:
+    """the agents of a multi-robot range-aided SLAM problem + the synchronous RBCD++ driver on the device
+    (ref examples/MultiRobotExample_RASLAM.cpp); X is the merged r x k matrix in the RA ordering"""
+
+    def __init__(self, ra, r, acceleration=True, restart_interval=30, params=None, device=0):
+        self.ra, self.r, self.k = ra, r, ra.k
+        o = RbcdOptions()
+        capi.lib().dcora_rbcd_options_default(C.byref(o))
+        o.r, o.acceleration, o.restart_interval, o.device = r, int(acceleration), restart_interval, device
+        if params is not None:
+            o.local = params.c
+        dsh = ra.handle()
+        self.h = C.c_void_p()
+        try:
+            check(capi.lib().dcora_ra_rbcd_create(dsh, C.byref(o), C.byref(self.h)))
+        finally:
+            capi.lib().dcora_radataset_destroy(dsh)
+        n = C.c_int()
+        check(capi.lib().dcora_ra_rbcd_info(self.h, C.byref(n), None))
+        self.R = n.value
+        rb = np.zeros(self.R, np.int32)
+        check(capi.lib().dcora_ra_rbcd_info(self.h, C.byref(n), rb.ctypes.data_as(C.c_void_p)))
+        self.robots = rb.tolist()
+
+    def close(self):
+        if getattr(self, "h", None):
+            capi.lib().dcora_ra_rbcd_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_X(self, X):
+        check(capi.lib().dcora_ra_rbcd_set_X(self.h, F(X)))
+
+    def get_X(self):
+        out = np.zeros(self.r * self.k)
+        check(capi.lib().dcora_ra_rbcd_get_X(self.h, out))
+        return unF(out, self.r, self.k)
+
+    def _eval(self, fn, *first):
+        c2, gn, nxt = C.c_double(), C.c_double(), C.c_int()
+        bn = np.zeros(self.R)
+        check(fn(self.h, *first, C.byref(c2), C.byref(gn), bn.ctypes.data_as(C.c_void_p), C.byref(nxt)))
+        return c2.value, gn.value, bn, nxt.value
+
+    def iterate(self, selected):
+        return self._eval(capi.lib().dcora_ra_rbcd_iterate, selected)
+
+    def evaluate(self):
+        return self._eval(capi.lib().dcora_ra_rbcd_evaluate)
+
+    def run(self, max_iters=1000, rgrad_tol=0.1):
+        it = C.c_int()
+        cost, gn = np.zeros(max_iters), np.zeros(max_iters)
+        sel = np.zeros(max_iters, np.int32)
+        check(capi.lib().dcora_ra_rbcd_run(self.h, max_iters, rgrad_tol, C.byref(it),
+                                           cost.ctypes.data_as(C.c_void_p), gn.ctypes.data_as(C.c_void_p),
+                                           sel.ctypes.data_as(C.c_void_p)))
+        n = it.value
+        return dict(iters=n, cost=cost[:n], gradnorm=gn[:n], selected=sel[:n])
+
+    def last_result(self):
+        r = ROptResult()
+        check(capi.lib().dcora_ra_rbcd_last_result(self.h, C.byref(r)))
+        return r.as_dict()
 
 
 def align_lifted_trajectory_to_frame(X, anchor, d, n, global_alignment=True, device=0):

@@ -131,6 +131,15 @@ SIGNATURES = {
     "dcora_rbcd_phase_selected": (C.c_int, [_vp, C.c_int]),
     "dcora_rbcd_phase_evaluate_dev": (C.c_int, [_vp, _vp]),
     "dcora_rbcd_synchronize": (C.c_int, [_vp]),
+    "dcora_ra_rbcd_create": (C.c_int, [_vp, C.POINTER(RbcdOptions), C.POINTER(_vp)]),
+    "dcora_ra_rbcd_destroy": (C.c_int, [_vp]),
+    "dcora_ra_rbcd_info": (C.c_int, [_vp, _PI, _vp]),
+    "dcora_ra_rbcd_set_X": (C.c_int, [_vp, _dp]),
+    "dcora_ra_rbcd_get_X": (C.c_int, [_vp, _dp]),
+    "dcora_ra_rbcd_iterate": (C.c_int, [_vp, C.c_int, _PD, _PD, _vp, _PI]),
+    "dcora_ra_rbcd_evaluate": (C.c_int, [_vp, _PD, _PD, _vp, _PI]),
+    "dcora_ra_rbcd_run": (C.c_int, [_vp, C.c_int, C.c_double, _PI, _vp, _vp, _vp]),
+    "dcora_ra_rbcd_last_result": (C.c_int, [_vp, C.POINTER(ROptResult)]),
     "dcora_problem_time_qapply": (C.c_int, [_vp, C.c_int, _PD, _PD]),
     "dcora_problem_time_precond": (C.c_int, [_vp, C.c_int, _PD, _PD]),
     "dcora_problem_precond_info": (C.c_int, [_vp, _dp]),

@@ -7,6 +7,7 @@
 #include "cert.h"
 #include "device_problem.h"
 #include "host_graph.h"
+#include "ra_rbcd.h"
 #include "rbcd.h"
 #include "host_robust.h"
 #include "robust.h"
@@ -438,15 +439,7 @@ int dcora_radataset_destroy(dcora_radataset_t h) {
 int dcora_graph_precond_regularization(int k, const int *rp, const int *ci, const double *v, int device, double *reg) {
   if (!rp || !ci || !v || !reg) return bad("null argument");
   DCORA_TRY
-  *reg = 1e-1;  // default when the eigenvalue computation is unsuccessful (ref src/Graph.cpp:1923, 1932-1939)
-  DeviceLanczos L;
-  int rc = L.init(view_csr(k, rp, ci, v), device);
-  if (rc) return rc;
-  LanczosResult e;
-  rc = L.largest_magnitude(0.0, std::min(6, k), 10000, 1e-3, nullptr, 1, &e);
-  if (rc) return rc;
-  if (e.ok && e.lambda > 0) *reg = e.lambda / (1e6 - 1);
-  return DCORA_OK;
+  return device_precond_regularization(view_csr(k, rp, ci, v), device, reg);
   DCORA_CATCH
 }
 
@@ -571,6 +564,78 @@ int dcora_rbcd_synchronize(dcora_rbcd_t s) {
   if (!s) return bad("null");
   DCORA_HIP(hipStreamSynchronize(s->s.st));
   return DCORA_OK;
+}
+
+// ---- RBCD session, range-aided SLAM ----------------------------------------------------------------------------
+struct dcora_ra_rbcd_s {
+  RaRbcdSession s;
+};
+int dcora_ra_rbcd_create(dcora_radataset_t ds, const dcora_rbcd_options *opt, dcora_ra_rbcd_t *out) {
+  if (!ds || !opt || !out) return bad("null argument");
+  DCORA_TRY
+  dcora_ra_rbcd_s *h = new dcora_ra_rbcd_s;
+  const int rc = h->s.init(ds->ds, *opt);
+  if (rc) {
+    delete h;
+    return rc;
+  }
+  *out = h;
+  return DCORA_OK;
+  DCORA_CATCH
+}
+int dcora_ra_rbcd_destroy(dcora_ra_rbcd_t s) {
+  delete s;
+  return DCORA_OK;
+}
+int dcora_ra_rbcd_info(dcora_ra_rbcd_t s, int *num_agents, int *robots) {
+  if (!s || !num_agents) return bad("null");
+  *num_agents = s->s.R;
+  if (robots)
+    for (int i = 0; i < s->s.R; ++i) robots[i] = s->s.agents[i].robot;
+  return DCORA_OK;
+}
+int dcora_ra_rbcd_set_X(dcora_ra_rbcd_t s, const double *X) { return (s && X) ? s->s.set_X(X) : bad("null"); }
+int dcora_ra_rbcd_get_X(dcora_ra_rbcd_t s, double *X) { return (s && X) ? s->s.get_X(X) : bad("null"); }
+int dcora_ra_rbcd_iterate(dcora_ra_rbcd_t s, int selected, double *cost2, double *gradnorm, double *block_norms,
+                          int *next_selected) {
+  if (!s) return bad("null");
+  DCORA_TRY
+  return s->s.iterate(selected, cost2, gradnorm, block_norms, next_selected);
+  DCORA_CATCH
+}
+int dcora_ra_rbcd_evaluate(dcora_ra_rbcd_t s, double *cost2, double *gradnorm, double *block_norms,
+                           int *next_selected) {
+  if (!s) return bad("null");
+  DCORA_TRY
+  return s->s.evaluate(cost2, gradnorm, block_norms, next_selected);
+  DCORA_CATCH
+}
+int dcora_ra_rbcd_run(dcora_ra_rbcd_t s, int max_iters, double rgrad_tol, int *iters_done, double *cost2_trace,
+                      double *gradnorm_trace, int *selected_trace) {
+  if (!s) return bad("null");
+  DCORA_TRY
+  int selected = 0, it = 0;
+  for (; it < max_iters; ++it) {
+    double c2 = 0, gn = 0;
+    int nxt = selected;
+    const int rc = s->s.iterate(selected, &c2, &gn, nullptr, &nxt);
+    if (rc) return rc;
+    if (cost2_trace) cost2_trace[it] = c2;
+    if (gradnorm_trace) gradnorm_trace[it] = gn;
+    if (selected_trace) selected_trace[it] = selected;
+    if (gn < rgrad_tol) {
+      ++it;
+      break;
+    }
+    selected = nxt;
+  }
+  if (iters_done) *iters_done = it;
+  return DCORA_OK;
+  DCORA_CATCH
+}
+int dcora_ra_rbcd_last_result(dcora_ra_rbcd_t s, dcora_ropt_result *res) {
+  if (!s || !res) return bad("null");
+  return s->s.last_result(res);
 }
 
 // ---- robust estimation ---------------------------------------------------------------------------------------

@@ -261,6 +261,30 @@ int dcora_rbcd_phase_evaluate_dev(dcora_rbcd_t s, double *out_dev);
 int dcora_rbcd_synchronize(dcora_rbcd_t s);
 
 /* ------------------------------------------------------------------------- *
+ * RBCD session for multi-robot range-aided SLAM (replaces the Agents on a RangeAidedSLAMGraph and the loop body of
+ * examples/MultiRobotExample_RASLAM.cpp; ref src/Agent.cpp:535-596, 1158-1278, src/Graph.cpp:824-1772).
+ * Agents = the robots of the pyfg file that own poses, in id order; variables are owned as the reference assigns
+ * them (dcora_radataset_ownership); X is the merged problem's r x k matrix in the RA ordering.  Files in which the
+ * passive map agent would own a landmark or a unit sphere are refused (DCORA_ERR_UNSUPPORTED).  One process.
+ * ------------------------------------------------------------------------- */
+typedef struct dcora_ra_rbcd_s *dcora_ra_rbcd_t;
+/* opt->num_robots is ignored (the file decides); opt->local are the agents' localOptimizationParams */
+int dcora_ra_rbcd_create(dcora_radataset_t ds, const dcora_rbcd_options *opt, dcora_ra_rbcd_t *out);
+int dcora_ra_rbcd_destroy(dcora_ra_rbcd_t s);
+/* number of agents and (robots != NULL) their robot ids ('A' = 0, ...) */
+int dcora_ra_rbcd_info(dcora_ra_rbcd_t s, int *num_agents, int *robots);
+int dcora_ra_rbcd_set_X(dcora_ra_rbcd_t s, const double *X);
+int dcora_ra_rbcd_get_X(dcora_ra_rbcd_t s, double *X);
+/* as dcora_rbcd_iterate / _evaluate / _run / _last_result; `selected` indexes the agents of dcora_ra_rbcd_info */
+int dcora_ra_rbcd_iterate(dcora_ra_rbcd_t s, int selected, double *cost2, double *gradnorm, double *block_norms,
+                          int *next_selected);
+int dcora_ra_rbcd_evaluate(dcora_ra_rbcd_t s, double *cost2, double *gradnorm, double *block_norms,
+                           int *next_selected);
+int dcora_ra_rbcd_run(dcora_ra_rbcd_t s, int max_iters, double rgrad_tol, int *iters_done, double *cost2_trace,
+                      double *gradnorm_trace, int *selected_trace);
+int dcora_ra_rbcd_last_result(dcora_ra_rbcd_t s, dcora_ropt_result *res);
+
+/* ------------------------------------------------------------------------- *
  * Robust estimation (replaces src/DCORA_robust.cpp and the robust parts of src/DCORA_solver.cpp)
  * ------------------------------------------------------------------------- */
 /* RobustCostParameters::Type (ref include/DCORA/DCORA_robust.h:28-35) */
