@@ -482,6 +482,40 @@ def config5_multi(da, torch, dist, rank, world, iters=60, sweeps=8):
     return res
 
 
+def config4_multi_robot(da, ra, with_cpu, r=3, iters=40, cpu_iters=3):
+    """tiers.pyfg as the multi-robot driver sees it (examples/MultiRobotExample_RASLAM.cpp): 4 robots, every agent
+    resident on the GPU (dcora_ra_rbcd_*), RBCD++ from the lifted odometry start with the agents' default local
+    solver (RTR 3 x 50); the CPU figure is the same loop over the oracle's local solver for the first iterations"""
+    import cora_flow
+    X0 = np.zeros((r, ra.k))
+    X0[:ra.d] = ra.X_odom
+    t0 = time.perf_counter()
+    s = da.RaRbcdSession(ra, r)
+    setup_s = time.perf_counter() - t0
+    s.set_X(X0)
+    s.run(max_iters=2, rgrad_tol=0.0)
+    s.set_X(X0)
+    t0 = time.perf_counter()
+    out = s.run(max_iters=iters, rgrad_tol=0.0)
+    dt = time.perf_counter() - t0
+    s.close()
+    res = {"workload": "tiers.pyfg, %d robots, r=%d, RBCD++ (accel, restart 30), RTR 3x50 tCG" % (len(ra.robots), r),
+           "iterations": iters, "value": iters / dt, "unit": "RBCD iterations/s", "ms_per_step": 1e3 * dt / iters,
+           "setup_s": setup_s, "cost_2f_first": float(out["cost"][0]), "cost_2f_last": float(out["cost"][-1])}
+    if with_cpu:
+        from oracle import orc
+        opt = dict(RTR_iterations=3, RTR_tCG_iterations=50, gradnorm_tol=1e-2)
+        cora_flow.oracle_ra_rbcd_loop(da, orc, ra, X0, r, 1, True, 30, opt)  # builds / warms what the loop reuses
+        t0 = time.perf_counter()
+        Xo, tr = cora_flow.oracle_ra_rbcd_loop(da, orc, ra, X0, r, cpu_iters, True, 30, opt)
+        dtc = time.perf_counter() - t0
+        res["cpu_port"] = {"iterations": cpu_iters, "value": cpu_iters / dtc, "unit": "RBCD iterations/s", "cores": 1,
+                           "note": "numpy loop over the oracle's local solver, set-up of the agents included",
+                           "same_block_sequence": bool(np.array_equal(tr[:, 0].astype(int),
+                                                                      out["selected"][:cpu_iters]))}
+    return res
+
+
 def config4_run(da, with_cpu):
     """BASELINE.json config 4 as a side measurement (never `value`): tiers.pyfg (d = 2, 9768 poses, 7789 ranges, one
     landmark: k = 37 094), the first level of the centralised CORA flow -- RTR with the driver's parameters
@@ -537,6 +571,10 @@ def config4_run(da, with_cpu):
                                                "outer_iterations": rs["outer_iterations"],
                                                "tcg_iterations": rs["inner_iterations"], "seconds": dts,
                                                "speedup_vs_cpu_port": dtc / dts}
+    try:
+        res["multi_robot"] = config4_multi_robot(da, ra, with_cpu)
+    except Exception as e:
+        res["multi_robot"] = {"error": str(e)}
     return res
 
 
