@@ -120,3 +120,58 @@ def multi_robot_gnc_example(ds, X0, num_robots=5, r=5, robust=None, num_weight_u
     return {"X": X, "weights": w.copy(), "loop_closures": lc, "rounds": rounds,
             "final": {"iterations": int(out["iters"]), "cost_2f": float(out["cost"][-1]),
                       "gradnorm": float(out["gradnorm"][-1])}}
+
+
+def multi_robot_raslam_example(ra, X0, r_min=None, r_max=100, max_iters=1000, rgrad_tol=0.1, min_eig_tol=1e-3,
+                               gradient_tolerance=1e-4, preconditioned_gradient_tolerance=1e-4, acceleration=True,
+                               params=None, device=0):
+    """The multi-robot range-aided SLAM driver (ref examples/MultiRobotExample_RASLAM.cpp) over the C ABI: per level
+    the agents' RBCD++ (dcora_ra_rbcd_*), the merged problem's dual certificate and fastVerification, escapeSaddle of
+    the central problem into the next rank.  Defaults of the example: r_min = d, local RTR 200 x 200 at 1e-4,
+    |rgrad| < 0.1, eigenvalue tolerance 1e-3.  X0: r_min x k (RA ordering)."""
+    from . import RaRbcdSession, ROptParameters, precond_regularization
+    d, n, l, b, k = ra.d, ra.n, ra.l, ra.b, ra.k
+    r_min = d if r_min is None else r_min
+    if params is None:
+        params = ROptParameters(RTR_iterations=200, RTR_tCG_iterations=200, gradnorm_tol=1e-4)
+    X = np.asarray(X0, dtype=np.float64)
+    if X.shape != (r_min, k):
+        raise ValueError("X0 must be r_min x k")
+    reg = None
+    levels, certified, theta, total = [], False, 0.0, 0
+    r = r_min
+    while r < r_max:
+        s = RaRbcdSession(ra, r, acceleration=acceleration, params=params, device=device)
+        s.set_X(X)
+        t0 = time.perf_counter()
+        out = s.run(max_iters=max_iters, rgrad_tol=rgrad_tol)
+        t1 = time.perf_counter()
+        Xopt = s.get_X()
+        s.close()
+        total += out["iters"]
+        S = dual_certificate(r, d, n, Xopt, ra.Q, l=l, b=b, device=device)
+        psd, theta, v, lmin = fast_verification(S, min_eig_tol, block=1, device=device)
+        t2 = time.perf_counter()
+        lev = {"rank": r, "iterations": int(out["iters"]), "cost_2f": float(out["cost"][-1]),
+               "gradnorm": float(out["gradnorm"][-1]), "rbcd_s": t1 - t0, "certification_s": t2 - t1,
+               "certified": bool(psd), "theta": float(theta)}
+        levels.append(lev)
+        X = Xopt
+        if psd:
+            certified = True
+            break
+        if theta >= -min_eig_tol / 2:
+            raise RuntimeError("escape direction computation did not converge to the desired precision")
+        if reg is None:
+            reg = precond_regularization(ra.Q, device=device)
+        Pn = QuadraticProblem(r + 1, d, n, ra.Q, reg=reg, l=l, b=b, device=device)
+        Xn = Pn.escapeSaddle(Xopt, theta, v, gradient_tolerance, preconditioned_gradient_tolerance)
+        Pn.close()
+        lev["escape_s"] = time.perf_counter() - t2
+        lev["escaped"] = Xn is not None
+        if Xn is None:
+            break
+        X = Xn
+        r += 1
+    return {"X": X, "rank": X.shape[0], "certified": certified, "theta": float(theta), "total_iters": int(total),
+            "levels": levels}

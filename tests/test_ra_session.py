@@ -97,3 +97,22 @@ def test_ra_session_refuses_map_owned_variables(env):
     ra = da.RADataset(ra_path("pyfg_se3_test_data"))
     with pytest.raises(da.DcoraError, match="map agent"):
         da.RaRbcdSession(ra, 4)
+
+
+@pytest.mark.parametrize("name", ["range_aided_slam_test_2d", "range_aided_slam_test_3d"])
+def test_multi_robot_raslam_driver_reaches_the_certified_optimum(env, name):
+    """examples/MultiRobotExample_RASLAM.cpp from a random start at rank d on the noiseless fixtures: whatever
+    critical points the levels pass through, the driver must end certified at (numerically) cost 0"""
+    da, orc = env
+    from dcora_amd import driver
+    ra = da.RADataset(ra_path(name))
+    d = ra.d
+    rng = np.random.default_rng(12)
+    X0 = orc.project_to_manifold(d, d, ra.n, rng.standard_normal((d, ra.k)), l=ra.l, b=ra.b)
+    out = driver.multi_robot_raslam_example(ra, X0, max_iters=300, rgrad_tol=1e-3, r_max=d + 5)
+    assert out["certified"], out["levels"]
+    assert out["levels"][-1]["cost_2f"] < 1e-3  # the RBCD loop stops at |rgrad| < 1e-3
+    # the oracle certifies the device's final point too
+    r = out["rank"]
+    So = orc.dual_certificate(r, d, ra.n, out["X"], orc.CSR.from_scipy(ra.Q.to_scipy()), l=ra.l, b=ra.b)
+    assert orc.fast_verification(So, 1e-3, block=1)[0]
