@@ -121,6 +121,10 @@ SIGNATURES = {
     "dcora_rbcd_set_acceleration": (C.c_int, [_vp, C.c_int]),
     "dcora_rbcd_agent_colours": (C.c_int, [_vp, _ip, _PI]),
     "dcora_rbcd_evaluate": (C.c_int, [_vp, _PD, _PD, _vp, _PI]),
+    "dcora_rbcd_agent_iterate": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "dcora_rbcd_agent_get_X": (C.c_int, [_vp, C.c_int, _dp]),
+    "dcora_rbcd_agent_set_X": (C.c_int, [_vp, C.c_int, _dp]),
+    "dcora_rbcd_agent_info": (C.c_int, [_vp, C.c_int, _PI, _PI, _PI]),
     "dcora_rbcd_last_result": (C.c_int, [_vp, C.POINTER(ROptResult)]),
     "dcora_rbcd_X_device_ptr": (C.c_int, [_vp, C.POINTER(_vp)]),
     "dcora_rbcd_public_count": (C.c_int, [_vp, C.c_int, _PI]),

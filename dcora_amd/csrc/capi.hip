@@ -524,6 +524,27 @@ int dcora_rbcd_evaluate(dcora_rbcd_t s, double *cost2, double *gradnorm, double 
   return s->s.evaluate_central(cost2, gradnorm, block_norms, next_selected);
   DCORA_CATCH
 }
+int dcora_rbcd_agent_iterate(dcora_rbcd_t s, int agent, int do_optimization) {
+  if (!s) return bad("null");
+  DCORA_TRY
+  return s->s.agent_iterate(agent, do_optimization != 0);
+  DCORA_CATCH
+}
+int dcora_rbcd_agent_get_X(dcora_rbcd_t s, int agent, double *X) {
+  return (s && X) ? s->s.agent_get_X(agent, X) : bad("null");
+}
+int dcora_rbcd_agent_set_X(dcora_rbcd_t s, int agent, const double *X) {
+  return (s && X) ? s->s.agent_set_X(agent, X) : bad("null");
+}
+int dcora_rbcd_agent_info(dcora_rbcd_t s, int agent, int *num_poses, int *first_pose, int *iteration_number) {
+  if (!s || agent < 0 || agent >= s->s.R) return bad("bad agent");
+  const AgentDev &a = s->s.agents[agent];
+  if (num_poses) *num_poses = a.n;
+  if (first_pose) *first_pose = a.col0 / (s->s.d + 1);
+  if (iteration_number)
+    *iteration_number = (int)s->s.agent_it.size() == s->s.R ? s->s.agent_it[agent] : s->s.iteration;
+  return DCORA_OK;
+}
 int dcora_rbcd_last_result(dcora_rbcd_t s, dcora_ropt_result *res) {
   if (!s || !res) return bad("null");
   return s->s.last_result(res);

@@ -59,6 +59,12 @@ class RbcdSession {
   int iterate(int selected, double *cost2, double *gradnorm, double *block_norms, int *next_selected);
   // simultaneous Agent::iterate(true) of a set of agents from one snapshot of the neighbour states
   int iterate_set(const int *set, int count, int allow_adjacent);
+  // Agent::iterate(doOptimization) of one agent; the agents of a session advance in lockstep (one call per agent
+  // and round, as the reference driver makes them)
+  int agent_iterate(int agent, bool do_optimization);
+  int agent_get_X(int agent, double *Xh);
+  int agent_set_X(int agent, const double *Xh);
+  std::vector<int> agent_it;  // Agent::iteration_number() of every agent
   // greedy colouring of the agent graph: agents of one colour share no measurement
   int agent_colours(int *colours, int *ncolours) const;
   int pack_public(int agent, double *packed_dev);
@@ -69,6 +75,9 @@ class RbcdSession {
   void advance_sequences();
   bool seq_advanced_ = false;
   bool own_stream_ = true;
+  bool pending_reset_ = false;  // gamma = alpha = 0 after a restart round, applied when the next round begins
+  int update_nonselected_agent(AgentDev &a, bool restart);
+  int update_selected_agent(AgentDev &a, bool restart);
   hipEvent_t fork_ev_ = nullptr;
   int solve_block(AgentDev &a, std::string *err);
 };

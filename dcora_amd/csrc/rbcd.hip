@@ -185,6 +185,8 @@ int RbcdSession::set_X(const double *Xh) {
   gamma = alpha = 0;
   iteration = 0;
   seq_advanced_ = false;
+  pending_reset_ = false;
+  agent_it.assign(R, 0);
   return DCORA_OK;
 }
 // initializeAcceleration / acceleration off for every agent (ref src/Agent.cpp:1178-1187)
@@ -198,6 +200,8 @@ int RbcdSession::set_acceleration(bool on) {
   gamma = alpha = 0;
   iteration = 0;
   seq_advanced_ = false;
+  pending_reset_ = false;
+  agent_it.assign(R, 0);
   return DCORA_OK;
 }
 int RbcdSession::get_X(double *Xh) {
@@ -235,11 +239,17 @@ int RbcdSession::phase_nonselected(int selected) {
   } else {
     for (AgentDev &a : agents) {
       if (!a.hosted || a.id == selected) continue;
-      const size_t off = (size_t)a.col0 * r;
-      nesterov(st, a.prob->m, 0, restart, -1, -1, alpha, gamma, Xg.p + off, Vg.p + off, Yg.p + off, XPrevg.p + off,
-               nullptr, Buf2{{nullptr, nullptr}}, nullptr);
+      const int rc = update_nonselected_agent(a, restart != 0);
+      if (rc) return rc;
     }
   }
+  return DCORA_OK;
+}
+
+int RbcdSession::update_nonselected_agent(AgentDev &a, bool restart) {
+  const size_t off = (size_t)a.col0 * r;
+  nesterov(st, a.prob->m, 0, restart ? 1 : 0, -1, -1, alpha, gamma, Xg.p + off, Vg.p + off, Yg.p + off,
+           XPrevg.p + off, nullptr, Buf2{{nullptr, nullptr}}, nullptr);
   return DCORA_OK;
 }
 
@@ -250,8 +260,17 @@ int RbcdSession::phase_selected(int selected) {
   seq_advanced_ = false;
   const bool restart = restart_now();
   AgentDev &a = agents[selected];
-  int rc = DCORA_OK;
   if (a.hosted) {
+    const int rc = update_selected_agent(a, restart);
+    if (rc) return rc;
+  }
+  if (restart) gamma = alpha = 0;
+  return DCORA_OK;
+}
+
+int RbcdSession::update_selected_agent(AgentDev &a, bool restart) {
+  int rc = DCORA_OK;
+  {
     DeviceProblem &pb = *a.prob;
     const size_t off = (size_t)a.col0 * r;
     const size_t B = sizeof(double) * (size_t)pb.nelem();
@@ -295,7 +314,85 @@ int RbcdSession::phase_selected(int selected) {
       DCORA_HIP(hipMemcpyAsync(Xg.p + off, Xres.p[0], B, hipMemcpyDeviceToDevice, st));
     }
   }
-  if (restart) gamma = alpha = 0;
+  return DCORA_OK;
+}
+
+// Agent::iterate(doOptimization) of one agent (ref src/Agent.cpp:535-596).  The driver calls every agent once per
+// round (examples/MultiRobotExample.cpp:223-262): the first call of a round advances the shared gamma / alpha
+// sequences (identical for all agents, :1189-1200), a restart round zeroes them when the next round begins.
+int RbcdSession::agent_iterate(int agent, bool do_optimization) {
+  if (agent < 0 || agent >= R) {
+    set_last_error("rbcd: agent out of range");
+    return DCORA_ERR_BAD_ARG;
+  }
+  AgentDev &a = agents[agent];
+  if (!a.hosted) {
+    set_last_error("rbcd: agent is hosted by another rank");
+    return DCORA_ERR_BAD_ARG;
+  }
+  DCORA_HIP(hipSetDevice(opt.device));
+  // Agent::iteration_number() of every agent; between rounds they are all equal to the session's round counter
+  // (also after the session-level calls, which advance whole rounds)
+  bool level = (int)agent_it.size() == R;
+  for (int q = 0; level && q < R; ++q) level = !agents[q].hosted || agent_it[q] == agent_it[agent];
+  if ((int)agent_it.size() != R || (level && agent_it[agent] != iteration)) agent_it.assign(R, iteration);
+  if (agent_it[agent] == iteration) {  // this agent opens round iteration + 1: everybody has finished the last one
+    for (int q = 0; q < R; ++q)
+      if (agents[q].hosted && agent_it[q] != iteration) {
+        set_last_error("rbcd: agent " + std::to_string(agent) + " starts a new round before agent " +
+                       std::to_string(q) + " has iterated in the current one (agents advance in lockstep)");
+        return DCORA_ERR_BAD_ARG;
+      }
+    if (pending_reset_) gamma = alpha = 0;
+    pending_reset_ = false;
+    advance_sequences();
+    seq_advanced_ = false;
+    for (int q = 0; q < R; ++q)
+      if (!agents[q].hosted) agent_it[q] = iteration;
+  } else if (agent_it[agent] != iteration - 1) {
+    set_last_error("rbcd: agents advance in lockstep");
+    return DCORA_ERR_BAD_ARG;
+  }
+  agent_it[agent] = iteration;
+  const bool restart = restart_now();
+  int rc;
+  if (do_optimization) {
+    rc = update_selected_agent(a, restart);
+  } else {
+    rc = opt.acceleration ? update_nonselected_agent(a, restart) : DCORA_OK;
+  }
+  if (restart) pending_reset_ = true;
+  return rc;
+}
+
+int RbcdSession::agent_get_X(int agent, double *Xh) {
+  if (agent < 0 || agent >= R) {
+    set_last_error("rbcd: agent out of range");
+    return DCORA_ERR_BAD_ARG;
+  }
+  DCORA_HIP(hipSetDevice(opt.device));
+  const AgentDev &a = agents[agent];
+  const size_t B = sizeof(double) * (size_t)r * (d + 1) * a.n;
+  DCORA_HIP(hipMemcpyAsync(Xh, Xg.p + (size_t)a.col0 * r, B, hipMemcpyDeviceToHost, st));
+  DCORA_HIP(hipStreamSynchronize(st));
+  return DCORA_OK;
+}
+
+// Agent::setX + initializeAcceleration (ref src/Agent.cpp:64-77, 1178-1187)
+int RbcdSession::agent_set_X(int agent, const double *Xh) {
+  if (agent < 0 || agent >= R) {
+    set_last_error("rbcd: agent out of range");
+    return DCORA_ERR_BAD_ARG;
+  }
+  DCORA_HIP(hipSetDevice(opt.device));
+  const AgentDev &a = agents[agent];
+  const size_t off = (size_t)a.col0 * r;
+  const size_t B = sizeof(double) * (size_t)r * (d + 1) * a.n;
+  DCORA_HIP(hipMemcpyAsync(Xg.p + off, Xh, B, hipMemcpyHostToDevice, st));
+  DCORA_HIP(hipMemcpyAsync(Vg.p + off, Xg.p + off, B, hipMemcpyDeviceToDevice, st));
+  DCORA_HIP(hipMemcpyAsync(Yg.p + off, Xg.p + off, B, hipMemcpyDeviceToDevice, st));
+  DCORA_HIP(hipMemcpyAsync(XPrevg.p + off, Xg.p + off, B, hipMemcpyDeviceToDevice, st));
+  DCORA_HIP(hipStreamSynchronize(st));
   return DCORA_OK;
 }
 

@@ -239,6 +239,15 @@ int dcora_rbcd_set_acceleration(dcora_rbcd_t s, int acceleration);
 int dcora_rbcd_agent_colours(dcora_rbcd_t s, int *colours, int *ncolours);
 /* the central evaluation of dcora_rbcd_iterate alone (ref examples/MultiRobotExample.cpp:264-305); world_size 1 */
 int dcora_rbcd_evaluate(dcora_rbcd_t s, double *cost2, double *gradnorm, double *block_norms, int *next_selected);
+/* Agent::iterate(doOptimization) of ONE agent (ref src/Agent.cpp:535-596), for callers that keep the reference's
+ * per-agent loop (examples/MultiRobotExample.cpp:223-262).  The agents of a session advance in lockstep: one call
+ * per hosted agent and round; the first call of a round advances the shared Nesterov sequences. */
+int dcora_rbcd_agent_iterate(dcora_rbcd_t s, int agent, int do_optimization);
+/* Agent::getX / setX: the agent's own block, r x (d+1) num_poses (ref src/Agent.cpp:64-77, 98-105) */
+int dcora_rbcd_agent_get_X(dcora_rbcd_t s, int agent, double *X);
+int dcora_rbcd_agent_set_X(dcora_rbcd_t s, int agent, const double *X);
+/* num_poses, first global pose index and Agent::iteration_number() of an agent (any of the outputs may be NULL) */
+int dcora_rbcd_agent_info(dcora_rbcd_t s, int agent, int *num_poses, int *first_pose, int *iteration_number);
 /* statistics of the last selected agent's local solve */
 int dcora_rbcd_last_result(dcora_rbcd_t s, dcora_ropt_result *res);
 

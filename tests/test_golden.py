@@ -99,3 +99,14 @@ def test_cpp_facade_testprior(built):
     assert os.path.exists(exe), "build() compiles tests/cpp/test_facade.cpp"
     p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, p.stdout + p.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_agent_facade_runs_the_reference_driver_loop(built):
+    """DCORA::Agent / AgentTeam (dcora_amd/include/DCORA/Agent.h): the loop body of examples/MultiRobotExample.cpp:
+    223-307 written with per-agent iterate / getSharedStateDicts / updateNeighborStates / getX on smallGrid3D,
+    against dcora_rbcd_iterate"""
+    exe = os.path.join(common.HERE, "cpp", "_build", "test_agent_facade")
+    assert os.path.exists(exe), "build() compiles tests/cpp/test_agent_facade.cpp"
+    p = subprocess.run([exe, common.plain_path("smallGrid3D")], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
