@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config5", action="store_true", help="skip the 100k-pose side measurement")
     ap.add_argument("--no-config4", action="store_true", help="skip the tiers.pyfg side measurement")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the timed loop (for a kernel trace of exactly that loop): no side measurements")
     ap.add_argument("--cpu-steps", type=int, default=0, help="oracle iterations for cpu_baseline (0 = auto)")
     return ap.parse_args()
 
@@ -289,7 +291,25 @@ def roofline(da, ds, r, robots):
     ach = nbytes / (ms * 1e-3) / 1e9
     main = {"bound": "hbm", "kernel": "k_fused_precond (dense preconditioner application, one agent, k=%d)" % kb,
             "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
-            "bytes_per_launch": nbytes, "avg_launch_us": ms * 1e3}
+            "bytes_per_launch": nbytes, "avg_launch_us": ms * 1e3,
+            "measured": "HIP events on the solver's stream around 300 back-to-back launches of the kernel in its "
+                        "in-loop form (step length, vector updates, |r|^2, inverse slices)"}
+    # the same kernel inside the timed loop, from the committed rocprofv3 summary of `bench.py --headline-only`
+    # (all launches, the gated no-op ones of the solver's lookahead included)
+    try:
+        import csv
+        with open(os.path.join(ROOT, "profiles", "r01_kernel_stats_headline_loop.csv")) as fh:
+            for row in csv.DictReader(fh):
+                if "k_fused_precond" in row["Name"]:
+                    us = float(row["AverageNs"]) / 1e3
+                    main["in_loop"] = {"avg_launch_us_all_launches": us, "launches": int(row["Calls"]),
+                                       "min_us": float(row["MinNs"]) / 1e3,
+                                       "frac_if_every_launch_moved_the_bytes": nbytes / (us * 1e-6) / 1e9 /
+                                       HBM_PEAK_GBPS,
+                                       "source": "profiles/r01_kernel_stats_headline_loop.csv"}
+                    break
+    except Exception:
+        pass
     Pb.close()
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
@@ -630,7 +650,7 @@ def main():
         dist.destroy_process_group()
     else:
         s, dt, c2, gn = run_single(args, da, torch, ds, X0)
-        coloured = coloured_sweeps(SingleDriver(s), X0, sweeps=40)
+        coloured = None if args.headline_only else coloured_sweeps(SingleDriver(s), X0, sweeps=40)
         c5 = None
     if rank != 0:
         return
@@ -653,6 +673,10 @@ def main():
                    "parallelism": "agents in consecutive groups over %d rank(s)" % world,
                    "final_cost_2f": c2, "final_gradnorm": gn},
     }
+    if args.headline_only:
+        real_stdout.write(json.dumps(line) + "\n")
+        real_stdout.flush()
+        return
     line["coloured_rbcd"] = coloured
     if c5 is not None:
         line["config5_lattice100k"] = c5

@@ -27,10 +27,32 @@ __device__ __forceinline__ bool f_gated(const SolverCtl *ctl, int seq, int gate)
 __device__ __forceinline__ double *f_pick(const Buf2 &b, const SolverCtl *ctl, int sel) {
   return b.p[(ctl->cur ^ sel) & 1];
 }
+// Wave-wide sum, same value in every lane.  Data-parallel-primitive moves inside the 16-lane rows (xor 1, xor 2,
+// mirror of 8, mirror of 16: no LDS crossbar round trips as with __shfl_xor / ds_bpermute), then the four row sums
+// are read as scalars.  Fixed order => reproducible.
+template <int CTRL>
+__device__ __forceinline__ double f_dpp(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double f_readlane(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double f_wave_sum(double v) {
+#ifdef DCORA_WAVE_SUM_SHUFFLE  // A/B switch: the butterfly over ds_bpermute
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+#endif
+  v += f_dpp<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += f_dpp<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += f_dpp<0x141>(v);  // row_half_mirror
+  v += f_dpp<0x140>(v);  // row_mirror
+  return (f_readlane(v, 0) + f_readlane(v, 16)) + (f_readlane(v, 32) + f_readlane(v, 48));
 }
 __device__ __forceinline__ double f_block_sum(double v, double *sm) {
   v = f_wave_sum(v);
@@ -339,7 +361,7 @@ __global__ __launch_bounds__(kBlock) void k_fused_hess(ManiDesc m, CsrDev Q, con
 constexpr int kJChunk = 128;  // output columns per block
 constexpr int kRowChunk = 256;  // residual rows staged per pass
 
-template <int RM>
+template <int RM, bool HAS_M>
 __global__ __launch_bounds__(kBlock) void k_fused_precond(int r, int k, int ldm, int nsplit,
                                                           const double *__restrict__ Minv, Buf2 gradb,
                                                           const double *__restrict__ delta,
@@ -369,19 +391,6 @@ __global__ __launch_bounds__(kBlock) void k_fused_precond(int r, int k, int ldm,
   const int cn0 = min(kRowChunk, c_hi - c_lo);
   const int per_wave0 = (cn0 + 3) / 4;
   const int w_lo0 = min(cn0, wave * per_wave0), w_hi0 = min(cn0, w_lo0 + per_wave0);
-  double2 pre[kPre];
-  {
-    const double *__restrict__ mp0 = Minv + (size_t)(c_lo + w_lo0) * ldm + col;
-#pragma unroll
-    for (int q = 0; q < kPre; ++q) {
-      if (w_lo0 + q < w_hi0 && Minv != nullptr) {
-        pre[q] = *reinterpret_cast<const double2 *>(mp0 + (size_t)q * ldm);
-      } else {
-        pre[q].x = 0.0;
-        pre[q].y = 0.0;
-      }
-    }
-  }
   const double *__restrict__ rsrc = first ? gradb.p[cur] : res_old;
   // own element of the vector updates and own entries of the residual slice: loaded before alpha is known
   const long i0 = (long)blockIdx.x * kBlock + threadIdx.x;
@@ -406,9 +415,26 @@ __global__ __launch_bounds__(kBlock) void k_fused_precond(int r, int k, int ldm,
     st_r[u] = ok ? rsrc[idx] : 0.0;
     st_h[u] = (ok && !first) ? Hd[idx] : 0.0;
   }
-  double myp = 0;
+  // <d, H d> partials: one predicated load per thread (a loop would wait for its loads inside the loop)
+  double myp = (!first && (int)threadIdx.x < np1) ? p1[threadIdx.x] : 0.0;
+  // The rows of the inverse are requested AFTER the few words the step length needs: vector loads retire in issue
+  // order, so the scalar prologue below (two block reductions, the vector updates) waits for those words only and
+  // runs while the 64 KB of the slice are still in flight, instead of behind them.
+  asm volatile("" ::: "memory");
+  // Straight-line loads (row index clamped, value masked afterwards) so that the compiler can count them: behind
+  // per-row branches it falls back to s_waitcnt vmcnt(0) at the first use of ANY loaded value.
+  double2 pre[kPre];
+  if (HAS_M) {
+    const int col_c = min(col, ldm - 2);
+#pragma unroll
+    for (int q = 0; q < kPre; ++q) {
+      const int row = min(c_lo + w_lo0 + q, k - 1);
+      pre[q] = *reinterpret_cast<const double2 *>(Minv + (size_t)row * ldm + col_c);
+    }
+  }
+  asm volatile("" ::: "memory");
   if (!first)
-    for (int i = threadIdx.x; i < np1; i += kBlock) myp += p1[i];
+    for (int i = threadIdx.x + kBlock; i < np1; i += kBlock) myp += p1[i];  // only blocks of > 8192 poses get here
   if (seq > st_o || (!first && seq > st_t)) return;  // finished: no-op (uniform over the grid)
   double alpha = 0, step = 0;
   bool boundary = false;
@@ -475,7 +501,7 @@ __global__ __launch_bounds__(kBlock) void k_fused_precond(int r, int k, int ldm,
     const double tot = f_block_sum(acc2, s_red);
     if (threadIdx.x == 0) p2[blockIdx.x] = tot;
   }
-  if (boundary || Minv == nullptr) return;
+  if (boundary || !HAS_M) return;
   // ---- dense product slice: Z_s(:, j) = sum_{c in slice} r(:, c) Minv(c, j) ----
   double a0[RM], a1[RM];
 #pragma unroll
@@ -501,10 +527,11 @@ __global__ __launch_bounds__(kBlock) void k_fused_precond(int r, int k, int ldm,
     const int w_lo = min(cn, wave * per_wave), w_hi = min(cn, w_lo + per_wave);
     int c = w_lo;
     if (c0 == c_lo) {
-      // rows preloaded before the prologue
+      // rows preloaded before the prologue (those past the wave's range were clamped: masked here)
 #pragma unroll
       for (int q = 0; q < kPre; ++q) {
         const bool ok = (w_lo + q < w_hi);
+        if (!ok) pre[q].x = pre[q].y = 0.0;
 #pragma unroll
         for (int t = 0; t < RM; ++t)
           if (t < r) {
@@ -1051,12 +1078,15 @@ void launch_fused_precond(hipStream_t st, const ManiDesc &m, int ldm, const doub
                           HostFlags *hf, int seq, int iter, int first) {
   const int grid = Minv ? fused_precond_grid(m) : fused_update_grid(m);
   const int ns = Minv ? fused_nsplit(m) : 1;
-  if (m.r <= 4)
-    hipLaunchKernelGGL(k_fused_precond<4>, dim3(grid), dim3(kBlock), 0, st, m.r, m.k, ldm, ns, Minv, grad, delta, Hd,
-                       eta, Heta, res_old, res_new, Zpart, p1, np1, p2, ctl, hf, seq, iter, first);
-  else
-    hipLaunchKernelGGL(k_fused_precond<8>, dim3(grid), dim3(kBlock), 0, st, m.r, m.k, ldm, ns, Minv, grad, delta, Hd,
-                       eta, Heta, res_old, res_new, Zpart, p1, np1, p2, ctl, hf, seq, iter, first);
+#define DCORA_LAUNCH_PRECOND(RM, HM)                                                                               \
+  hipLaunchKernelGGL((k_fused_precond<RM, HM>), dim3(grid), dim3(kBlock), 0, st, m.r, m.k, ldm, ns, Minv, grad,     \
+                     delta, Hd, eta, Heta, res_old, res_new, Zpart, p1, np1, p2, ctl, hf, seq, iter, first)
+  if (m.r <= 4) {
+    if (Minv) DCORA_LAUNCH_PRECOND(4, true); else DCORA_LAUNCH_PRECOND(4, false);
+  } else {
+    if (Minv) DCORA_LAUNCH_PRECOND(8, true); else DCORA_LAUNCH_PRECOND(8, false);
+  }
+#undef DCORA_LAUNCH_PRECOND
 }
 void launch_fused_finish(hipStream_t st, const ManiDesc &m, Buf2 X, const double *Zpart, const double *res,
                          double *z, const double *p2, int np2, double *p3, SolverCtl *ctl, HostFlags *hf, int seq,
