@@ -118,7 +118,8 @@ int DeviceProblem::init(const dcora_dims &dims, const HostCsr &Qh, const double 
   DCORA_HIP(hipMemset(G.p, 0, N * sizeof(double)));
   for (DevBuf<double> *b : {&X0, &X1, &EG0, &EG1, &RG0, &RG1, &delta, &eta, &Heta, &res, &z, &Hd, &W, &Zt})
     DCORA_HIP(b->alloc(N));
-  fused = fused_supported(m) && (std::getenv("DCORA_SOLVER_V1") == nullptr);
+  // (the fused Hessian kernel stages the first matrix tile with clamped, unconditional loads: it needs nnz > 0)
+  fused = fused_supported(m) && Qh.nnz() > 0 && (std::getenv("DCORA_SOLVER_V1") == nullptr);
   group = group_supported(m) && (std::getenv("DCORA_SOLVER_V1") == nullptr);
   if (fused) {
     DCORA_HIP(delta2.alloc(N));

@@ -240,11 +240,29 @@ __global__ __launch_bounds__(kBlock) void k_fused_hess(ManiDesc m, CsrDev Q, con
   const int j = j0 + lc;
   const int pbeg = Q.rp[j0], pend = Q.rp[j0 + ncol];
   const int myb = act ? Q.rp[j] : 0, mye = act ? Q.rp[j + 1] : 0;
+  // <z, r> partials first (one predicated load; the loop below only runs for > 256 partials)
+  double myp = ((int)threadIdx.x < np3) ? p3[threadIdx.x] : 0.0;
   {
+    // first tile of the matrix: all trips' loads are issued before any is stored to LDS (clamped index, straight
+    // line), one memory round trip instead of one per 256 entries
     const int cnt = min(kHessTile, pend - pbeg);
-    for (int i = threadIdx.x; i < cnt; i += kBlock) {
-      s_ci[i] = Q.ci[pbeg + i];
-      s_v[i] = Q.v[pbeg + i];
+    constexpr int SU = kHessTile / kBlock;
+    int ci_r[SU];
+    double v_r[SU];
+    const int last = max(pend - 1, 0);
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int i = min(pbeg + (int)threadIdx.x + u * kBlock, last);
+      ci_r[u] = Q.ci[i];
+      v_r[u] = Q.v[i];
+    }
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int i = threadIdx.x + u * kBlock;
+      if (i < cnt) {
+        s_ci[i] = ci_r[u];
+        s_v[i] = v_r[u];
+      }
     }
   }
   const size_t oown = (size_t)j * r + t;
@@ -262,8 +280,7 @@ __global__ __launch_bounds__(kBlock) void k_fused_hess(ManiDesc m, CsrDev Q, con
   for (int a = 0; a < D; ++a)
 #pragma unroll
     for (int b = 0; b < D; ++b) S[a][b] = (g < npose) ? Sblk[(size_t)(pose0 + g) * D * D + a + b * D] : 0.0;
-  double myp = 0;  // this thread's share of the <z, r> partials (loads in flight with everything above)
-  for (int i = threadIdx.x; i < np3; i += kBlock) myp += p3[i];
+  for (int i = threadIdx.x + kBlock; i < np3; i += kBlock) myp += p3[i];
   if (seq > st_o || seq > st_t) return;  // solve or tCG already finished: no-op (uniform over the grid)
   __syncthreads();  // first tile staged
   // first batch of gathers: addresses do not depend on beta, so the loads are issued before the reduction
@@ -612,30 +629,37 @@ __global__ __launch_bounds__(kBlock) void k_fused_finish(ManiDesc m, int nsplit,
   const int npose = min(PB, m.n - pose0);
   const int nout = npose * DH * r;
   const size_t base = (size_t)pose0 * DH * r;
-  // ---- phase 1 first (independent of the stopping rule): slice sum, residual entry ----
-  {
-    const int e = threadIdx.x;
-    if (e < nout) {
-      double zs = 0;
-      double q[32];
-#pragma unroll
-      for (int u = 0; u < 32; ++u) q[u] = (u < nsplit) ? Zpart[(size_t)u * N + base + e] : 0.0;
-#pragma unroll
-      for (int u = 0; u < 32; ++u) zs += q[u];
-      for (int s = 32; s < nsplit; ++s) zs += Zpart[(size_t)s * N + base + e];
-      s_Z[e] = zs;
-      s_R[e] = res[base + e];
-    }
-  }
+  // Every load of the kernel is issued before the first value is consumed: the |r|^2 partials the stopping rule
+  // needs (two predicated loads per thread; a loop would wait for each trip's load inside the loop), the pose rows,
+  // the residual entry and the split-K slices.  One memory round trip instead of three dependent ones.
   const double *__restrict__ X = Xb.p[cur];
   const int g = threadIdx.x >> 3, tt = threadIdx.x & (GW - 1);
   const bool pact = (g < npose) && (tt < r);
   const size_t o = base + (size_t)g * DH * r;
+  const int e = threadIdx.x;
+  double myp = 0, myp2 = 0;
+  if (!first) {
+    myp = (e < np2) ? p2[e] : 0.0;
+    myp2 = (e + kBlock < np2) ? p2[e + kBlock] : 0.0;
+  }
   Row<D> Y, Zr, Rr;
   ld_row<D>(X + o, r, tt, pact, Y);
-  double myp = 0;
+  // ---- phase 1 (independent of the stopping rule): slice sum, residual entry ----
+  if (e < nout) {
+    const double rres = res[base + e];
+    double zs = 0;
+    double q[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) q[u] = (u < nsplit) ? Zpart[(size_t)u * N + base + e] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 32; ++u) zs += q[u];
+    for (int s = 32; s < nsplit; ++s) zs += Zpart[(size_t)s * N + base + e];
+    s_Z[e] = zs;
+    s_R[e] = rres;
+  }
+  myp += myp2;
   if (!first)
-    for (int i = threadIdx.x; i < np2; i += kBlock) myp += p2[i];
+    for (int i = e + 2 * kBlock; i < np2; i += kBlock) myp += p2[i];
   if (seq > st_o || (!first && seq > st_t)) return;  // finished: no-op (uniform over the grid)
   if (!first) {
     const double nr = sqrt(f_block_sum(myp, s_red));
