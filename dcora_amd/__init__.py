@@ -605,3 +605,31 @@ def project_solution_raslam(X, r, d, n, l, b, device=0):
 def log_trajectory(path, T, d, n):
     """Logger::logTrajectory (ref src/Logger.cpp:107-145): T is d x (d+1) n"""
     check(capi.lib().dcora_log_trajectory(str(path).encode(), d, n, F(np.asarray(T, dtype=np.float64))))
+
+
+def _agent_iterate(self, agent, do_optimization=True):
+    """Agent::iterate(doOptimization) of one agent (agents advance in lockstep)"""
+    check(capi.lib().dcora_rbcd_agent_iterate(self.h, agent, int(bool(do_optimization))))
+
+
+def _agent_info(self, agent):
+    npz, first, it = C.c_int(), C.c_int(), C.c_int()
+    check(capi.lib().dcora_rbcd_agent_info(self.h, agent, C.byref(npz), C.byref(first), C.byref(it)))
+    return dict(num_poses=npz.value, first_pose=first.value, iteration_number=it.value)
+
+
+def _agent_get_X(self, agent):
+    cols = (self.ds.d + 1) * _agent_info(self, agent)["num_poses"]
+    out = np.zeros(self.r * cols)
+    check(capi.lib().dcora_rbcd_agent_get_X(self.h, agent, out))
+    return unF(out, self.r, cols)
+
+
+def _agent_set_X(self, agent, X):
+    check(capi.lib().dcora_rbcd_agent_set_X(self.h, agent, F(X)))
+
+
+RbcdSession.agent_iterate = _agent_iterate
+RbcdSession.agent_get_X = _agent_get_X
+RbcdSession.agent_set_X = _agent_set_X
+RbcdSession.agent_info = _agent_info

@@ -129,3 +129,39 @@ def test_projection_to_the_manifold_is_feasible(env):
         assert abs(np.linalg.norm(X[:, d * n + i]) - 1.0) <= 1e-5
     assert np.array_equal(X[:, d * n + l:], M[:, d * n + l:])
     assert common.rel(X, orc.project_to_manifold(r, d, n, M, l=l, b=b)) < 1e-13
+
+
+@pytest.mark.parametrize("accel", [True, False])
+def test_per_agent_iterate_reproduces_the_session_loop(env, accel):
+    """dcora_rbcd_agent_iterate / _agent_get_X / _agent_set_X: the reference's per-agent calls (non-selected agents
+    iterate(false), the selected one iterate(true), ref examples/MultiRobotExample.cpp:223-262) give the iterates of
+    dcora_rbcd_iterate, across a restart; agents out of step are refused"""
+    da, orc = env
+    ds = common.product_dataset("smallGrid3D")
+    R, r, iters = 5, 5, 34
+    X0 = common.random_point(r, ds.d, ds.n, 6, orc.project_to_manifold)
+    a = da.RbcdSession(ds, num_robots=R, r=r, acceleration=accel)
+    b = da.RbcdSession(ds, num_robots=R, r=r, acceleration=accel)
+    per, dh = ds.n // R, ds.d + 1
+    for q in range(R):  # Agent::setX block by block
+        lo, hi = q * per * dh, (ds.n if q == R - 1 else (q + 1) * per) * dh
+        a.agent_set_X(q, X0[:, lo:hi])
+        assert a.agent_info(q) == dict(num_poses=(hi - lo) // dh, first_pose=q * per, iteration_number=0)
+    b.set_X(X0)
+    sel = 0
+    for it in range(iters):
+        order = [q for q in range(R) if q != sel] + [sel]
+        if it % 2:  # the order in which the non-selected agents are called does not matter
+            order = order[:-1][::-1] + [sel]
+        for q in order:
+            a.agent_iterate(q, q == sel)
+        c2b, gnb, bnb, nxt = b.iterate(sel)
+        c2a, gna, bna, _ = a.evaluate()
+        assert abs(c2a - c2b) <= 1e-12 * abs(c2b)
+        assert all(a.agent_info(q)["iteration_number"] == it + 1 for q in range(R))
+        sel = nxt
+    assert np.abs(a.get_X() - b.get_X()).max() < 1e-11
+    assert np.abs(np.hstack([a.agent_get_X(q) for q in range(R)]) - a.get_X()).max() == 0
+    a.agent_iterate(0, True)
+    with pytest.raises(da.DcoraError, match="lockstep"):
+        a.agent_iterate(0, True)
