@@ -64,6 +64,13 @@ __device__ __forceinline__ double f_block_sum(double v, double *sm) {
   for (int i = 0; i < nw; ++i) t += sm[i];
   return t;
 }
+// Up to 64 partials: every wave loads them itself (lane l takes partial l) and sums them with f_wave_sum, so the
+// total is known in every wave without a barrier or an LDS exchange; more partials go through the block reduction.
+// f_partial_index is the index a thread loads, f_partial_total the matching reduction.
+__device__ __forceinline__ int f_partial_index(int np) { return np <= 64 ? (int)(threadIdx.x & 63u) : (int)threadIdx.x; }
+__device__ __forceinline__ double f_partial_total(double v, int np, double *sm) {
+  return np <= 64 ? f_wave_sum(v) : f_block_sum(v, sm);
+}
 __device__ __forceinline__ double f_sum_partials(const double *p, int np, int stride, int off, double *sm) {
   double v = 0;
   for (int i = threadIdx.x; i < np; i += blockDim.x) v += p[(size_t)i * stride + off];
@@ -241,7 +248,8 @@ __global__ __launch_bounds__(kBlock) void k_fused_hess(ManiDesc m, CsrDev Q, con
   const int pbeg = Q.rp[j0], pend = Q.rp[j0 + ncol];
   const int myb = act ? Q.rp[j] : 0, mye = act ? Q.rp[j + 1] : 0;
   // <z, r> partials first (one predicated load; the loop below only runs for > 256 partials)
-  double myp = ((int)threadIdx.x < np3) ? p3[threadIdx.x] : 0.0;
+  const int pi3 = f_partial_index(np3);
+  double myp = (pi3 < np3) ? p3[pi3] : 0.0;
   {
     // first tile of the matrix: all trips' loads are issued before any is stored to LDS (clamped index, straight
     // line), one memory round trip instead of one per 256 entries
@@ -297,7 +305,7 @@ __global__ __launch_bounds__(kBlock) void k_fused_hess(ManiDesc m, CsrDev Q, con
     ga[q] = (iter > 0) ? d_old[oo] : 0.0;
   }
   // ---- scalar recurrence (ROPTLIB tCG_TR): beta, e_Pd, d_Pd ----
-  const double z_r_new = f_block_sum(myp, s_red);
+  const double z_r_new = f_partial_total(myp, np3, s_red);
   double beta = 0;
   if (iter > 0) beta = z_r_new / c_zr;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -433,7 +441,8 @@ __global__ __launch_bounds__(kBlock) void k_fused_precond(int r, int k, int ldm,
     st_h[u] = (ok && !first) ? Hd[idx] : 0.0;
   }
   // <d, H d> partials: one predicated load per thread (a loop would wait for its loads inside the loop)
-  double myp = (!first && (int)threadIdx.x < np1) ? p1[threadIdx.x] : 0.0;
+  const int pi1 = f_partial_index(np1);
+  double myp = (!first && pi1 < np1) ? p1[pi1] : 0.0;
   // The rows of the inverse are requested AFTER the few words the step length needs: vector loads retire in issue
   // order, so the scalar prologue below (two block reductions, the vector updates) waits for those words only and
   // runs while the 64 KB of the slice are still in flight, instead of behind them.
@@ -456,7 +465,7 @@ __global__ __launch_bounds__(kBlock) void k_fused_precond(int r, int k, int ldm,
   double alpha = 0, step = 0;
   bool boundary = false;
   if (!first) {
-    const double d_Hd = f_block_sum(myp, s_red);
+    const double d_Hd = f_partial_total(myp, np1, s_red);
     const double z_r = c_zr, d_Pd = c_dPd, e_Pe = c_ePe, e_Pd = c_ePd;
     const double Delta = c_Delta;
     alpha = z_r / d_Hd;
