@@ -95,7 +95,9 @@ __global__ __launch_bounds__(kBlock) void k_sp_permute_out_hub(int r, int k, con
 //  * all levels in one launch, a level's blocks polling an arrival counter of the level before (task records
 //    prefetched before the wait, agent-scope release / acquire): 1.4-1.7 ms -- thousands of resident blocks polling
 //    one word starve the producers' atomics, also with padded counters and a slow-poll / fast-poll split;
-//  * larger dissection leaves (fewer levels): 192 / 384 / 768 unknowns per leaf -> 196 / 249 / 285 us.
+//  * larger dissection leaves (fewer levels): 192 / 384 / 768 unknowns per leaf -> 196 / 249 / 285 us;
+//  * batches of 6 entries per lane with all loads issued straight-line before the first use (what paid off in the
+//    fused tCG kernels): 184.6 us against 181.5 us on the same box.
 // One level: LANES lanes per tile of up to kSpTile output rows (LANES = 256: one block per tile).
 // The r values of JP = LANES / r consecutive vector entries are one contiguous run of JP r doubles, so lane
 // l = j r + t loads exactly one of them (fully coalesced), multiplies it with the nrows weights of entry j (the
