@@ -97,7 +97,8 @@ __global__ __launch_bounds__(kBlock) void k_sp_permute_out_hub(int r, int k, con
 //    one word starve the producers' atomics, also with padded counters and a slow-poll / fast-poll split;
 //  * larger dissection leaves (fewer levels): 192 / 384 / 768 unknowns per leaf -> 196 / 249 / 285 us;
 //  * batches of 6 entries per lane with all loads issued straight-line before the first use (what paid off in the
-//    fused tCG kernels): 184.6 us against 181.5 us on the same box.
+//    fused tCG kernels): 184.6 us against 181.5 us on the same box;
+//  * occupancy targets (amdgpu_waves_per_eu 4 / 6 / 8 instead of the 5 the 92 VGPRs give): 190 / 242 / 238 us.
 // One level: LANES lanes per tile of up to kSpTile output rows (LANES = 256: one block per tile).
 // The r values of JP = LANES / r consecutive vector entries are one contiguous run of JP r doubles, so lane
 // l = j r + t loads exactly one of them (fully coalesced), multiplies it with the nrows weights of entry j (the
