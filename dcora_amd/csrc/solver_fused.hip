@@ -82,11 +82,24 @@ __device__ __forceinline__ void f_host_store(volatile int *p, int v) {
 // sum over the 8 lanes of a pose group (every lane of the wave must take part).  The result is re-broadcast from
 // the group's first lane: with FMA contraction the butterfly partial sums can differ in the last bit between
 // lanes, and the Jacobi / Gram-Schmidt decisions taken from them must be identical across the group.
+// DPP row operations (xor 1, xor 2 inside the quads, mirror of the 8 lanes) instead of __shfl / ds_bpermute: the
+// Jacobi sweeps of row_polar take dozens of these sums per pose.  The argument is pinned as an already-rounded value
+// first, so every add below combines two rounded numbers and, addition being commutative, the eight lanes end with
+// bitwise the same sum (same tree as the xor butterfly it replaces).
 __device__ __forceinline__ double grp_sum(double v) {
+#ifdef DCORA_GRP_SUM_SHUFFLE  // A/B switch
   v += __shfl_xor(v, 1, 64);
   v += __shfl_xor(v, 2, 64);
   v += __shfl_xor(v, 4, 64);
   return __shfl(v, (int)(threadIdx.x & 63u & ~7u), 64);
+#endif
+  asm volatile("" : "+v"(v));
+  v += f_dpp<0xB1>(v);   // quad_perm [1,0,3,2]
+  asm volatile("" : "+v"(v));
+  v += f_dpp<0x4E>(v);   // quad_perm [2,3,0,1]
+  asm volatile("" : "+v"(v));
+  v += f_dpp<0x141>(v);  // row_half_mirror: lane i <- lane 7 - i of its group of eight
+  return v;
 }
 
 template <int D>
