@@ -207,4 +207,30 @@ void launch_g_nesterov(hipStream_t st, const ManiDesc &m, int mode, int restart,
                        double alpha, double gamma, double *X, double *V, double *Y, double *XPrev, double *Yloc,
                        Buf2 Xloc, const SolverCtl *ctl);
 
+#if defined(__HIPCC__)
+// ---- wave-level sums on DPP row operations (device code only) ----
+// Moves inside the 16-lane rows (xor 1, xor 2, mirror of 8, mirror of 16) instead of __shfl_xor / ds_bpermute, which
+// goes through the LDS crossbar; the four row sums are then read as scalars.  Fixed order => reproducible.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+// sum over the 64 lanes, same value in every lane
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+  v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_move<0x141>(v);  // row_half_mirror
+  v += dpp_move<0x140>(v);  // row_mirror
+  return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+#endif
+
 }  // namespace dcora

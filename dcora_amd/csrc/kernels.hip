@@ -24,11 +24,7 @@ __device__ __forceinline__ bool gated(const SolverCtl *ctl, int seq, int gate) {
 __device__ __forceinline__ double *pick(const Buf2 &b, const SolverCtl *ctl, int sel) {
   return b.p[ctl ? ((ctl->cur ^ sel) & 1) : 0];
 }
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
+__device__ __forceinline__ double wave_sum(double v) { return wave_sum_dpp(v); }
 // sum over the block, result broadcast to every thread; sm must hold >= 16 doubles
 __device__ __forceinline__ double block_sum(double v, double *sm) {
   v = wave_sum(v);

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(kBlock) void k_gram(int r, int k, const double *__r
   const int a = blockIdx.x / r, b = blockIdx.x - a * r;
   double s = 0;
   for (int c = threadIdx.x; c < k; c += kBlock) s += X[(size_t)c * r + a] * X[(size_t)c * r + b];
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  s = wave_sum_dpp(s);
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) {

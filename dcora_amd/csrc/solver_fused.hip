@@ -31,28 +31,14 @@ __device__ __forceinline__ double *f_pick(const Buf2 &b, const SolverCtl *ctl, i
 // mirror of 8, mirror of 16: no LDS crossbar round trips as with __shfl_xor / ds_bpermute), then the four row sums
 // are read as scalars.  Fixed order => reproducible.
 template <int CTRL>
-__device__ __forceinline__ double f_dpp(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double f_readlane(double v, int lane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-  return __hiloint2double(hi, lo);
-}
+__device__ __forceinline__ double f_dpp(double v) { return dpp_move<CTRL>(v); }
 __device__ __forceinline__ double f_wave_sum(double v) {
 #ifdef DCORA_WAVE_SUM_SHUFFLE  // A/B switch: the butterfly over ds_bpermute
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 #endif
-  v += f_dpp<0xB1>(v);   // quad_perm [1,0,3,2]
-  v += f_dpp<0x4E>(v);   // quad_perm [2,3,0,1]
-  v += f_dpp<0x141>(v);  // row_half_mirror
-  v += f_dpp<0x140>(v);  // row_mirror
-  return (f_readlane(v, 0) + f_readlane(v, 16)) + (f_readlane(v, 32) + f_readlane(v, 48));
+  return wave_sum_dpp(v);  // kernels.h
 }
 __device__ __forceinline__ double f_block_sum(double v, double *sm) {
   v = f_wave_sum(v);
