@@ -127,22 +127,43 @@ __global__ __launch_bounds__(kBlock) void k_spmm(int r, CsrDev A, Buf2 Xb, int s
     for (int base = pbeg; base < pend; base += kSpmmTile) {
       const int cnt = min(kSpmmTile, pend - base);
       __syncthreads();
-      for (int i = threadIdx.x; i < cnt; i += kBlock) {
-        s_ci[i] = A.ci[base + i];
-        s_v[i] = A.v[base + i];
+      {
+        // all trips' loads of the tile are issued (clamped index, straight line) before any is stored to LDS:
+        // one memory round trip per tile instead of one per 256 entries
+        constexpr int SU = kSpmmTile / kBlock;
+        int ci_r[SU];
+        double v_r[SU];
+        const int last = base + cnt - 1;
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+          const int i = min(base + (int)threadIdx.x + u * kBlock, last);
+          ci_r[u] = A.ci[i];
+          v_r[u] = A.v[i];
+        }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+          const int i = threadIdx.x + u * kBlock;
+          if (i < cnt) {
+            s_ci[i] = ci_r[u];
+            s_v[i] = v_r[u];
+          }
+        }
       }
       __syncthreads();
       const int lo = max(myb, base) - base, hi = min(mye, base + cnt) - base;
-      int p = lo;
-      for (; p + 4 <= hi; p += 4) {
-        const double x0 = X[(size_t)s_ci[p] * r + t], x1 = X[(size_t)s_ci[p + 1] * r + t];
-        const double x2 = X[(size_t)s_ci[p + 2] * r + t], x3 = X[(size_t)s_ci[p + 3] * r + t];
-        acc += s_v[p] * x0;
-        acc += s_v[p + 1] * x1;
-        acc += s_v[p + 2] * x2;
-        acc += s_v[p + 3] * x3;
+      // gathers in batches of 8 with every load issued before the first use (index clamped, weight masked)
+      for (int p = lo; p < hi; p += 8) {
+        double x8[8], w8[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const bool ok = p + q < hi;
+          const int pp = ok ? p + q : lo;
+          w8[q] = ok ? s_v[pp] : 0.0;
+          x8[q] = X[(size_t)s_ci[pp] * r + t];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc += w8[q] * x8[q];
       }
-      for (; p < hi; ++p) acc += s_v[p] * X[(size_t)s_ci[p] * r + t];
     }
     if (active && !is_long) {
       const size_t o = (size_t)j * r + t;
