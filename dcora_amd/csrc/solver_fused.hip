@@ -907,29 +907,52 @@ __global__ __launch_bounds__(kBlock) void k_spmm_bsr(int r, BsrDev A, Buf2 Xb, i
     for (int base = bbeg; base < bend; base += kBsrTile) {
       const int cnt = min(kBsrTile, bend - base);
       __syncthreads();
-      for (int i = threadIdx.x; i < cnt * BS; i += kBlock) s_bv[i] = A.bv[(size_t)base * BS + i];
-      for (int i = threadIdx.x; i < cnt; i += kBlock) s_bc[i] = A.bc[base + i];
+      {
+        // the whole tile is requested before any of it is stored to LDS (clamped index, straight-line 16-byte
+        // loads): one memory round trip per tile instead of one per 256 doubles
+        constexpr int SU = (kBsrTile * BS / 2 + kBlock - 1) / kBlock;  // double2 loads per thread
+        const double2 *__restrict__ src = reinterpret_cast<const double2 *>(A.bv + (size_t)base * BS);
+        const int n2 = cnt * BS / 2;  // BS is even ((d+1)^2 = 9 only for d = 2: handled below)
+        double2 v_r[SU];
+        const int bc_r = A.bc[base + min((int)threadIdx.x, cnt - 1)];
+        if ((BS & 1) == 0) {
+#pragma unroll
+          for (int u = 0; u < SU; ++u) v_r[u] = src[min((int)threadIdx.x + u * kBlock, n2 - 1)];
+#pragma unroll
+          for (int u = 0; u < SU; ++u) {
+            const int i = threadIdx.x + u * kBlock;
+            if (i < n2) reinterpret_cast<double2 *>(s_bv)[i] = v_r[u];
+          }
+        } else {
+          for (int i = threadIdx.x; i < cnt * BS; i += kBlock) s_bv[i] = A.bv[(size_t)base * BS + i];
+        }
+        if ((int)threadIdx.x < cnt) s_bc[threadIdx.x] = bc_r;
+        for (int i = threadIdx.x + kBlock; i < cnt; i += kBlock) s_bc[i] = A.bc[base + i];
+      }
       __syncthreads();
       const int lo = max(myb, base) - base, hi = min(mye, base + cnt) - base;
-      for (int b = lo; b < hi; b += 2) {
-        // two matrix blocks per step: 2 (d+1) independent gathers in flight
-        const bool two = b + 1 < hi;
-        const size_t o0 = (size_t)s_bc[b] * DH * r + t;
-        const size_t o1 = two ? (size_t)s_bc[b + 1] * DH * r + t : o0;
-        double x0[DH], x1[DH];
+      for (int b = lo; b < hi; b += 4) {
+        // four matrix blocks per step: 4 (d+1) independent gathers in flight (index clamped, operand masked)
+        double x[4][DH];
+        int bb[4];
 #pragma unroll
-        for (int c = 0; c < DH; ++c) {
-          x0[c] = active ? X[o0 + c * r] : 0.0;
-          x1[c] = (active && two) ? X[o1 + c * r] : 0.0;
+        for (int q = 0; q < 4; ++q) {
+          const bool ok = active && (b + q < hi);
+          bb[q] = (b + q < hi) ? b + q : b;
+          const size_t o = (size_t)s_bc[bb[q]] * DH * r + t;
+#pragma unroll
+          for (int c = 0; c < DH; ++c) x[q][c] = ok ? X[o + c * r] : 0.0;
         }
-        const double *__restrict__ B0 = s_bv + b * BS;
-        const double *__restrict__ B1 = s_bv + (two ? b + 1 : b) * BS;
 #pragma unroll
-        for (int a = 0; a < DH; ++a) {
-          double s = 0;
+        for (int q = 0; q < 4; ++q) {
+          const double *__restrict__ Bq = s_bv + bb[q] * BS;
 #pragma unroll
-          for (int c = 0; c < DH; ++c) s += B0[a * DH + c] * x0[c] + B1[a * DH + c] * x1[c];
-          acc[a] += s;
+          for (int a = 0; a < DH; ++a) {
+            double s = 0;
+#pragma unroll
+            for (int c = 0; c < DH; ++c) s += Bq[a * DH + c] * x[q][c];
+            acc[a] += s;
+          }
         }
       }
     }
