@@ -41,6 +41,33 @@ __device__ __forceinline__ double sum_partials(const double *p, int np, int stri
   for (int i = threadIdx.x; i < np; i += blockDim.x) v += p[(size_t)i * stride + off];
   return block_sum(v, sm);
 }
+// N sums of partial arrays at once for the single-block bookkeeping kernels: every load is issued before the first
+// reduction (one memory round trip instead of one per sum) and the N wave sums share one LDS exchange (two barriers
+// instead of 2 N).  p[q] has np[q] entries of stride st[q] at offset off[q]; sm must hold >= 4 N doubles.
+template <int N>
+__device__ __forceinline__ void sum_partials_n(const double *const (&p)[N], const int (&np)[N], const int (&st)[N],
+                                               const int (&off)[N], double *sm, double (&out)[N]) {
+  double v[N];
+#pragma unroll
+  for (int q = 0; q < N; ++q) v[q] = ((int)threadIdx.x < np[q]) ? p[q][(size_t)threadIdx.x * st[q] + off[q]] : 0.0;
+#pragma unroll
+  for (int q = 0; q < N; ++q)
+    for (int i = threadIdx.x + blockDim.x; i < np[q]; i += blockDim.x) v[q] += p[q][(size_t)i * st[q] + off[q]];
+#pragma unroll
+  for (int q = 0; q < N; ++q) v[q] = wave_sum(v[q]);
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int q = 0; q < N; ++q) sm[q * 4 + w] = v[q];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < N; ++q) {
+    double t = 0;
+    for (int i = 0; i < nw; ++i) t += sm[q * 4 + i];
+    out[q] = t;
+  }
+}
 __device__ __forceinline__ void host_store(volatile int *p, int v) {
   __hip_atomic_store(const_cast<int *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -936,9 +963,11 @@ void launch_dense_apply(hipStream_t st, int r, int k, int ldm, const double *Min
 __global__ __launch_bounds__(kBlock) void k_rtr_init(const double *pA, int npA, const double *pB, int npB,
                                                      SolverCtl *ctl, HostFlags *hf, int seq) {
   __shared__ double s_red[16];
-  const double fq = sum_partials(pA, npA, 2, 0, s_red);
-  const double fg = sum_partials(pA, npA, 2, 1, s_red);
-  const double g2 = sum_partials(pB, npB, 1, 0, s_red);
+  const double *const ps[3] = {pA, pA, pB};
+  const int nps[3] = {npA, npA, npB}, sts[3] = {2, 2, 1}, offs[3] = {0, 1, 0};
+  double sums[3];
+  sum_partials_n<3>(ps, nps, sts, offs, s_red, sums);
+  const double fq = sums[0], fg = sums[1], g2 = sums[2];
   if (threadIdx.x == 0) {
     ctl->f1 = 0.5 * fq + fg;
     ctl->ngf = sqrt(g2);
@@ -1063,12 +1092,12 @@ __global__ __launch_bounds__(kBlock) void k_rtr_decide(const double *pA, int npA
                                                        const double *pC, int npC, SolverCtl *ctl, HostFlags *hf,
                                                        int seq) {
   if (gated(ctl, seq, 1)) return;
-  __shared__ double s_red[16];
-  const double fq = sum_partials(pA, npA, 2, 0, s_red);
-  const double fg = sum_partials(pA, npA, 2, 1, s_red);
-  const double g2 = sum_partials(pB, npB, 1, 0, s_red);
-  const double eg = sum_partials(pC, npC, 2, 0, s_red);
-  const double eh = sum_partials(pC, npC, 2, 1, s_red);
+  __shared__ double s_red[20];
+  const double *const ps[5] = {pA, pA, pB, pC, pC};
+  const int nps[5] = {npA, npA, npB, npC, npC}, sts[5] = {2, 2, 1, 2, 2}, offs[5] = {0, 1, 0, 0, 1};
+  double sums[5];
+  sum_partials_n<5>(ps, nps, sts, offs, s_red, sums);
+  const double fq = sums[0], fg = sums[1], g2 = sums[2], eg = sums[3], eh = sums[4];
   if (threadIdx.x == 0) {
     const double f2 = 0.5 * fq + fg;
     const double rho = (ctl->f1 - f2) / (-(eg + 0.5 * eh));
