@@ -1027,18 +1027,31 @@ __global__ __launch_bounds__(kBlock) void k_eval_finish(int R, const int *__rest
                                                         int seq) {
   __shared__ double s_red[16];
   __shared__ double s_bn[kMaxAgents];
-  for (int b = 0; b < R; ++b) {
-    double v = 0;
-    for (int i = pose_start[b] + threadIdx.x; i < pose_start[b + 1]; i += kBlock) v += posenorm[i];
-    const double tot = f_block_sum(v, s_red);
-    if (threadIdx.x == 0) s_bn[b] = tot;
+  // the cost partials first (loads in flight under the per-agent sums below)
+  double q0 = ((int)threadIdx.x < npA) ? pA[2 * threadIdx.x] : 0.0;
+  double q1 = ((int)threadIdx.x < npA) ? pA[2 * threadIdx.x + 1] : 0.0;
+  // one wave per agent (waves stride over the agents): eight loads in flight per lane, a wave-level sum, no barrier
+  {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = kBlock / 64;
+    for (int b = w; b < R; b += nw) {
+      const int lo = pose_start[b], hi = pose_start[b + 1];
+      double v = 0;
+      for (int i0 = lo + lane; i0 < hi; i0 += 64 * 8) {
+        double t8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t8[u] = posenorm[min(i0 + 64 * u, hi - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += (i0 + 64 * u < hi) ? t8[u] : 0.0;
+      }
+      v = f_wave_sum(v);
+      if (lane == 0) s_bn[b] = v;
+    }
   }
-  double q0 = 0, q1 = 0;
-  for (int i = threadIdx.x; i < npA; i += kBlock) {
+  for (int i = threadIdx.x + kBlock; i < npA; i += kBlock) {
     q0 += pA[2 * i];
     q1 += pA[2 * i + 1];
   }
-  const double fq = f_block_sum(q0, s_red);
+  const double fq = f_block_sum(q0, s_red);  // (its barriers also publish s_bn)
   const double fg = f_block_sum(q1, s_red);
   if (threadIdx.x == 0) {
     double g2 = 0, best = -1;
