@@ -585,8 +585,14 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
   }
   int &seq = seq_;
   SolverCtl *c = ctl.p;
-  launch_ctl_init(st, c, prm.gradnorm_tol, prm.RTR_initial_radius,
-                  single ? prm.RTR_initial_radius : 5 * prm.RTR_initial_radius, max_outer, single ? 1 : 0, max_inner);
+  CtlInit ci;  // written by k_rtr_init, the third kernel of the solve: the first two run with a null gate
+  ci.enable = 1;
+  ci.tol = prm.gradnorm_tol;
+  ci.Delta = prm.RTR_initial_radius;
+  ci.maxDelta = single ? prm.RTR_initial_radius : 5 * prm.RTR_initial_radius;
+  ci.max_outer = max_outer;
+  ci.stop_on_accept = single ? 1 : 0;
+  ci.max_inner = max_inner;
   const int solve_first = seq + 1;
   const CsrDev Qv = Q.view();
   const double *Gp = has_G ? G.p : nullptr;
@@ -601,9 +607,12 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
     return DCORA_ERR_HIP;
   };
   auto outer_done = [&]() { return hf->outer_done_seq >= solve_first; };
-  enq_qapply(Xb(), 0, Gp, EGb(), 0, pA.p, Gate{c, ++seq, 0});
-  int nG = enq_rgrad(Xb(), EGb(), RGb(), Sb(), 0, pB.p, Gate{c, ++seq, 0});
-  launch_rtr_init(st, pA.p, nA, pB.p, nG, c, hf_dev, ++seq);
+  // f(x0), grad(x0) from buffer 0 (null gate: the control block of this solve does not exist yet)
+  ++seq;
+  enq_qapply(Xb(), 0, Gp, EGb(), 0, pA.p, Gate{});
+  ++seq;
+  int nG = enq_rgrad(Xb(), EGb(), RGb(), Sb(), 0, pB.p, Gate{});
+  launch_rtr_init(st, pA.p, nA, pB.p, nG, c, hf_dev, ++seq, ci);
   int last_pace_seq = seq;
   std::vector<int> fin_seq((size_t)std::max(1, max_inner));
   for (int outer = 0; outer < max_outer; ++outer) {

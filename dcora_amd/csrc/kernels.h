@@ -140,8 +140,15 @@ void launch_dense_apply(hipStream_t st, int r, int k, int ldm, const double *Min
 
 // ---- tCG / RTR scalar+vector kernels --------------------------------------------------------------------
 int vec_grid(long nelem);
+// start-of-solve values of the control block, written by k_rtr_init itself when enable != 0 (the two kernels before
+// it then run with a null Gate: they read the start point from buffer 0 and no stamps)
+struct CtlInit {
+  int enable = 0;
+  double tol = 0, Delta = 0, maxDelta = 0;
+  int max_outer = 0, stop_on_accept = 0, max_inner = 0;
+};
 void launch_rtr_init(hipStream_t st, const double *pA, int npA, const double *pB, int npB, SolverCtl *ctl,
-                     HostFlags *hf, int seq);
+                     HostFlags *hf, int seq, CtlInit ci = CtlInit());
 void launch_tcg_begin(hipStream_t st, long nelem, Buf2 grad, double *eta, double *Heta, double *res,
                       SolverCtl *ctl, int seq);
 void launch_tcg_init(hipStream_t st, long nelem, const double *z, const double *p3, int np3, double *delta,

@@ -961,8 +961,28 @@ void launch_dense_apply(hipStream_t st, int r, int k, int ldm, const double *Min
 // Every block recomputes the same scalars from the same partials; block 0 publishes them.
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_rtr_init(const double *pA, int npA, const double *pB, int npB,
-                                                     SolverCtl *ctl, HostFlags *hf, int seq) {
+                                                     SolverCtl *ctl, HostFlags *hf, int seq, CtlInit ci) {
   __shared__ double s_red[16];
+  if (ci.enable && threadIdx.x == 0) {  // start-of-solve control block (saves the separate k_ctl_init launch)
+    SolverCtl *c = ctl;
+    c->f2 = c->rho = 0;
+    c->Delta = ci.Delta;
+    c->maxDelta = ci.maxDelta;
+    c->tol = ci.tol;
+    c->cur = 0;
+    c->outer_it = 0;
+    c->max_outer = ci.max_outer;
+    c->accepted = 0;
+    c->last_accepted = 0;
+    c->stop_on_accept = ci.stop_on_accept;
+    c->outer_done_stamp = INT_MAX;
+    c->alpha = c->e_Pe_n = c->norm_r0 = 0;
+    c->tcg_done_stamp = INT_MAX;
+    c->tcg_status = 4;
+    c->tcg_iters = 0;
+    c->inner_total = 0;
+    c->max_inner = ci.max_inner;
+  }
   const double *const ps[3] = {pA, pA, pB};
   const int nps[3] = {npA, npA, npB}, sts[3] = {2, 2, 1}, offs[3] = {0, 1, 0};
   double sums[3];
@@ -1128,8 +1148,8 @@ __global__ __launch_bounds__(kBlock) void k_rtr_decide(const double *pA, int npA
 }
 
 void launch_rtr_init(hipStream_t st, const double *pA, int npA, const double *pB, int npB, SolverCtl *ctl,
-                     HostFlags *hf, int seq) {
-  hipLaunchKernelGGL(k_rtr_init, dim3(1), dim3(kBlock), 0, st, pA, npA, pB, npB, ctl, hf, seq);
+                     HostFlags *hf, int seq, CtlInit ci) {
+  hipLaunchKernelGGL(k_rtr_init, dim3(1), dim3(kBlock), 0, st, pA, npA, pB, npB, ctl, hf, seq, ci);
 }
 void launch_tcg_begin(hipStream_t st, long nelem, Buf2 grad, double *eta, double *Heta, double *res,
                       SolverCtl *ctl, int seq) {
