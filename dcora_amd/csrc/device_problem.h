@@ -112,10 +112,16 @@ class SparsePrecond {
   long hub_nnz = 0;
   DevBuf<int> hub_idx, hub_ap, hub_apos;
   DevBuf<double> hub_aval, hub_U, hub_Sinv, hub_w;
+  // original unknown -> position in image 0 of the replay vector / position of its final value (no hubs only):
+  // lets the caller's kernels write the right-hand side into y and read the result from it (SpFold, kernels.h)
+  DevBuf<int> in_pos, out_pos;
+  bool foldable() const { return nhub == 0 && in_pos.p != nullptr; }
+  SpFold fold() const { return foldable() ? SpFold{y.p, in_pos.p, out_pos.p} : SpFold{}; }
   int upload(const PartInvHost &P, int rcap);
   int launches() const { return (int)levels.size() + 2 + (nhub > 0 ? 1 : 0); }
-  // Z = R A^-1 for r <= rcap right-hand sides (r x k column-major); R is picked by ctl->cur when g.ctl is set
-  void apply(hipStream_t st, int r, Buf2 R, double *Z, Gate g) const;
+  // Z = R A^-1 for r <= rcap right-hand sides (r x k column-major); R is picked by ctl->cur when g.ctl is set.
+  // levels_only: the right-hand side is already in y and the result is read from y (fold())
+  void apply(hipStream_t st, int r, Buf2 R, double *Z, Gate g, bool levels_only = false) const;
   double bytes_per_apply(int r) const;
 };
 

@@ -599,6 +599,10 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
   const int nA = npA(), nPB = fused_pose_blocks(m);
   const int nPG = sparse_precond ? fused_update_grid(m) : fused_precond_grid(m);
   const double *Mi = sparse_precond ? nullptr : Minv.p;  // null: B only updates, the sparse levels follow
+  // without hubs the sparse preconditioner's two permutations ride in B (scatter of the residual) and C (gather of z)
+  static const bool no_fold = std::getenv("DCORA_SP_NOFOLD") != nullptr;
+  const bool folded = sparse_precond && sp.foldable() && !no_fold;
+  const SpFold sf = folded ? sp.fold() : SpFold{};
   const int nsl = sparse_precond ? 1 : -1;
   double *dbuf[2] = {delta.p, delta2.p};
   double *rbuf[2] = {res.p, res2.p};
@@ -621,10 +625,10 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
     if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0) break;  // TimeBound :252
     // z0 = P(grad): B in "first" mode streams the preconditioner over grad, C projects and forms <z0, r0>
     launch_fused_precond(st, m, ldm, Mi, RGb(), nullptr, nullptr, eta.p, Heta.p, nullptr, rbuf[0], Zpart.p,
-                         nullptr, 0, p2.p, c, hf_dev, ++seq, 0, 1);
+                         nullptr, 0, p2.p, c, hf_dev, ++seq, 0, 1, sf);
     const int tcg_first_seq = seq;
-    if (sparse_precond) sp.apply(st, m.r, buf1(rbuf[0]), Zpart.p, Gate{c, ++seq, 1});
-    launch_fused_finish(st, m, Xb(), Zpart.p, rbuf[0], z.p, nullptr, 0, p3.p, c, hf_dev, ++seq, 0, 1, nsl);
+    if (sparse_precond) sp.apply(st, m.r, buf1(rbuf[0]), Zpart.p, Gate{c, ++seq, 1}, folded);
+    launch_fused_finish(st, m, Xb(), Zpart.p, rbuf[0], z.p, nullptr, 0, p3.p, c, hf_dev, ++seq, 0, 1, nsl, sf);
     for (int j = 0; j < max_inner; ++j) {
       if (j >= kLookahead) {
         const int need = fin_seq[j - kLookahead];
@@ -636,9 +640,9 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
       const int par = j & 1;
       launch_fused_hess(st, m, Qv, z.p, dbuf[par ^ 1], dbuf[par], Xb(), Sb(), Hd.p, p3.p, nPB, p1.p, c, ++seq, j);
       launch_fused_precond(st, m, ldm, Mi, RGb(), dbuf[par], Hd.p, eta.p, Heta.p, rbuf[par], rbuf[par ^ 1],
-                           Zpart.p, p1.p, nPB, p2.p, c, hf_dev, ++seq, j, 0);
-      if (sparse_precond) sp.apply(st, m.r, buf1(rbuf[par ^ 1]), Zpart.p, Gate{c, ++seq, 2});
-      launch_fused_finish(st, m, Xb(), Zpart.p, rbuf[par ^ 1], z.p, p2.p, nPG, p3.p, c, hf_dev, ++seq, j, 0, nsl);
+                           Zpart.p, p1.p, nPB, p2.p, c, hf_dev, ++seq, j, 0, sf);
+      if (sparse_precond) sp.apply(st, m.r, buf1(rbuf[par ^ 1]), Zpart.p, Gate{c, ++seq, 2}, folded);
+      launch_fused_finish(st, m, Xb(), Zpart.p, rbuf[par ^ 1], z.p, p2.p, nPG, p3.p, c, hf_dev, ++seq, j, 0, nsl, sf);
       fin_seq[j] = seq;
     }
     const int nR = enq_retract(Xb(), eta.p, 1.0, Xb(), 1, RGb(), Heta.p, pC.p, Gate{c, ++seq, 1});

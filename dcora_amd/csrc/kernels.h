@@ -194,13 +194,20 @@ int fused_update_grid(const ManiDesc &m);
 void launch_fused_hess(hipStream_t st, const ManiDesc &m, const CsrDev &Q, const double *z, const double *d_old,
                        double *d_new, Buf2 X, Buf2 S, double *Hd, const double *p3, int np3, double *p1,
                        SolverCtl *ctl, int seq, int iter);
+// The sparse preconditioner's two permutations folded into the kernels around it: B scatters the new residual into
+// image 0 of the replay vector (in_pos: original unknown -> position), C reads z from where the replay leaves it
+// (out_pos: original unknown -> final position).  y == nullptr: not folded.
+struct SpFold {
+  double *y = nullptr;
+  const int *in_pos = nullptr, *out_pos = nullptr;
+};
 void launch_fused_precond(hipStream_t st, const ManiDesc &m, int ldm, const double *Minv, Buf2 grad,
                           const double *delta, const double *Hd, double *eta, double *Heta, const double *res_old,
                           double *res_new, double *Zpart, const double *p1, int np1, double *p2, SolverCtl *ctl,
-                          HostFlags *hf, int seq, int iter, int first);
+                          HostFlags *hf, int seq, int iter, int first, SpFold sf = SpFold());
 void launch_fused_finish(hipStream_t st, const ManiDesc &m, Buf2 X, const double *Zpart, const double *res,
                          double *z, const double *p2, int np2, double *p3, SolverCtl *ctl, HostFlags *hf, int seq,
-                         int iter, int first, int nsplit = -1 /* -1: fused_nsplit(m) */);
+                         int iter, int first, int nsplit = -1 /* -1: fused_nsplit(m) */, SpFold sf = SpFold());
 // group-style (8 lanes per pose) rgrad / retract / Nesterov; return the number of partial slots written
 int launch_g_rgrad(hipStream_t st, const ManiDesc &m, Buf2 X, Buf2 EG, Buf2 RG, Buf2 Sblk, int sel, double *partials,
                    double *posenorm, Gate g);

@@ -395,7 +395,7 @@ __global__ __launch_bounds__(kBlock) void k_fused_precond(int r, int k, int ldm,
                                                           double *__restrict__ res_new,
                                                           double *__restrict__ Zpart, const double *__restrict__ p1,
                                                           int np1, double *__restrict__ p2, SolverCtl *ctl,
-                                                          HostFlags *hf, int seq, int iter, int first) {
+                                                          HostFlags *hf, int seq, int iter, int first, SpFold sf) {
   const int par = iter & 1;
   const int st_o = ctl->outer_done_stamp, st_t = ctl->tcg_done_stamp, cur = ctl->cur & 1;
   const double c_zr = ctl->z_r[par], c_dPd = ctl->d_Pd[par], c_ePe = ctl->e_Pe[par], c_ePd = ctl->e_Pd[par],
@@ -496,12 +496,14 @@ __global__ __launch_bounds__(kBlock) void k_fused_precond(int r, int k, int ldm,
       eta[i0] = 0;
       Heta[i0] = 0;
       res_new[i0] = o_r;
+      if (!HAS_M && sf.y) sf.y[(size_t)sf.in_pos[i0 / r] * r + (i0 % r)] = o_r;
     } else {
       eta[i0] = o_eta + step * o_d;
       Heta[i0] = o_Heta + step * o_h;
       if (!boundary) {
         const double rr = o_r + alpha * o_h;
         res_new[i0] = rr;
+        if (!HAS_M && sf.y) sf.y[(size_t)sf.in_pos[i0 / r] * r + (i0 % r)] = rr;
         acc2 += rr * rr;
       }
     }
@@ -511,6 +513,7 @@ __global__ __launch_bounds__(kBlock) void k_fused_precond(int r, int k, int ldm,
       eta[i] = 0;
       Heta[i] = 0;
       res_new[i] = rsrc[i];
+      if (!HAS_M && sf.y) sf.y[(size_t)sf.in_pos[i / r] * r + (i % r)] = rsrc[i];
     } else {
       const double h = Hd[i];
       eta[i] += step * delta[i];
@@ -518,6 +521,7 @@ __global__ __launch_bounds__(kBlock) void k_fused_precond(int r, int k, int ldm,
       if (!boundary) {
         const double rr = res_old[i] + alpha * h;
         res_new[i] = rr;
+        if (!HAS_M && sf.y) sf.y[(size_t)sf.in_pos[i / r] * r + (i % r)] = rr;
         acc2 += rr * rr;
       }
     }
@@ -623,7 +627,7 @@ __global__ __launch_bounds__(kBlock) void k_fused_finish(ManiDesc m, int nsplit,
                                                          const double *__restrict__ res, double *__restrict__ z,
                                                          const double *__restrict__ p2, int np2,
                                                          double *__restrict__ p3, SolverCtl *ctl, HostFlags *hf,
-                                                         int seq, int iter, int first) {
+                                                         int seq, int iter, int first, SpFold sf) {
   const int st_o = ctl->outer_done_stamp, st_t = ctl->tcg_done_stamp, cur = ctl->cur & 1;
   const double c_n0 = ctl->norm_r0;
   const int c_max_inner = ctl->max_inner;
@@ -656,12 +660,17 @@ __global__ __launch_bounds__(kBlock) void k_fused_finish(ManiDesc m, int nsplit,
   if (e < nout) {
     const double rres = res[base + e];
     double zs = 0;
-    double q[32];
+    if (sf.y) {  // sparse preconditioner folded in: the value sits in the replay vector, at its final position
+      const size_t ge = base + e;
+      zs = sf.y[(size_t)sf.out_pos[ge / r] * r + (ge % r)];
+    } else {
+      double q[32];
 #pragma unroll
-    for (int u = 0; u < 32; ++u) q[u] = (u < nsplit) ? Zpart[(size_t)u * N + base + e] : 0.0;
+      for (int u = 0; u < 32; ++u) q[u] = (u < nsplit) ? Zpart[(size_t)u * N + base + e] : 0.0;
 #pragma unroll
-    for (int u = 0; u < 32; ++u) zs += q[u];
-    for (int s = 32; s < nsplit; ++s) zs += Zpart[(size_t)s * N + base + e];
+      for (int u = 0; u < 32; ++u) zs += q[u];
+      for (int s = 32; s < nsplit; ++s) zs += Zpart[(size_t)s * N + base + e];
+    }
     s_Z[e] = zs;
     s_R[e] = rres;
   }
@@ -1143,12 +1152,12 @@ void launch_fused_hess(hipStream_t st, const ManiDesc &m, const CsrDev &Q, const
 void launch_fused_precond(hipStream_t st, const ManiDesc &m, int ldm, const double *Minv, Buf2 grad,
                           const double *delta, const double *Hd, double *eta, double *Heta, const double *res_old,
                           double *res_new, double *Zpart, const double *p1, int np1, double *p2, SolverCtl *ctl,
-                          HostFlags *hf, int seq, int iter, int first) {
+                          HostFlags *hf, int seq, int iter, int first, SpFold sf) {
   const int grid = Minv ? fused_precond_grid(m) : fused_update_grid(m);
   const int ns = Minv ? fused_nsplit(m) : 1;
 #define DCORA_LAUNCH_PRECOND(RM, HM)                                                                               \
   hipLaunchKernelGGL((k_fused_precond<RM, HM>), dim3(grid), dim3(kBlock), 0, st, m.r, m.k, ldm, ns, Minv, grad,     \
-                     delta, Hd, eta, Heta, res_old, res_new, Zpart, p1, np1, p2, ctl, hf, seq, iter, first)
+                     delta, Hd, eta, Heta, res_old, res_new, Zpart, p1, np1, p2, ctl, hf, seq, iter, first, sf)
   if (m.r <= 4) {
     if (Minv) DCORA_LAUNCH_PRECOND(4, true); else DCORA_LAUNCH_PRECOND(4, false);
   } else {
@@ -1158,15 +1167,15 @@ void launch_fused_precond(hipStream_t st, const ManiDesc &m, int ldm, const doub
 }
 void launch_fused_finish(hipStream_t st, const ManiDesc &m, Buf2 X, const double *Zpart, const double *res,
                          double *z, const double *p2, int np2, double *p3, SolverCtl *ctl, HostFlags *hf, int seq,
-                         int iter, int first, int nsplit) {
+                         int iter, int first, int nsplit, SpFold sf) {
   const int grid = fused_pose_blocks(m);
   const int ns = nsplit > 0 ? nsplit : fused_nsplit(m);
   if (m.d == 3)
     hipLaunchKernelGGL(k_fused_finish<3>, dim3(grid), dim3(kBlock), 0, st, m, ns, X, Zpart, res, z, p2, np2, p3, ctl,
-                       hf, seq, iter, first);
+                       hf, seq, iter, first, sf);
   else
     hipLaunchKernelGGL(k_fused_finish<2>, dim3(grid), dim3(kBlock), 0, st, m, ns, X, Zpart, res, z, p2, np2, p3, ctl,
-                       hf, seq, iter, first);
+                       hf, seq, iter, first, sf);
 }
 
 int launch_g_rgrad(hipStream_t st, const ManiDesc &m, Buf2 X, Buf2 EG, Buf2 RG, Buf2 Sblk, int sel, double *partials,

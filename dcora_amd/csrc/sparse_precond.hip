@@ -262,6 +262,17 @@ int SparsePrecond::upload(const PartInvHost &P, int rcap_) {
   nsegs_total = (long)P.segs.size();
   nhub = P.hub.h;
   hub_nnz = (long)P.hub.aval.size();
+  if (nhub == 0) {
+    std::vector<int> ip((size_t)k), op((size_t)k);
+    for (int j = 0; j < k; ++j) {
+      ip[(size_t)P.perm[j]] = j;
+      op[(size_t)P.perm[j]] = P.out_off[j];
+    }
+    DCORA_HIP(in_pos.alloc(ip.size()));
+    DCORA_HIP(hipMemcpy(in_pos.p, ip.data(), ip.size() * sizeof(int), hipMemcpyHostToDevice));
+    DCORA_HIP(out_pos.alloc(op.size()));
+    DCORA_HIP(hipMemcpy(out_pos.p, op.data(), op.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
   if (nhub > 0) {
     const PartInvHub &H = P.hub;
     DCORA_HIP(hub_idx.alloc(H.idx.size()));
@@ -284,11 +295,13 @@ int SparsePrecond::upload(const PartInvHost &P, int rcap_) {
   return DCORA_OK;
 }
 
-void SparsePrecond::apply(hipStream_t st, int r, Buf2 R, double *Z, Gate g) const {
+void SparsePrecond::apply(hipStream_t st, int r, Buf2 R, double *Z, Gate g, bool levels_only) const {
   const long n = (long)r * k;
   const int grid = (int)std::min<long>((n + kBlock - 1) / kBlock, 2048);
-  hipLaunchKernelGGL(k_sp_permute_in, dim3(grid), dim3(kBlock), 0, st, r, k, perm.p, R, y.p, g);
+  levels_only = levels_only && foldable();
+  if (!levels_only) hipLaunchKernelGGL(k_sp_permute_in, dim3(grid), dim3(kBlock), 0, st, r, k, perm.p, R, y.p, g);
   for (const SpLevel &lv : levels) launch_level(st, r, lv, tasks.p, segs.p, vals.p, idxs.p, y.p, g);
+  if (levels_only) return;
   if (nhub > 0) {
     HubDev H{nhub, hub_idx.p, hub_ap.p, hub_apos.p, hub_aval.p, hub_U.p, hub_Sinv.p, hub_w.p};
     hipLaunchKernelGGL(k_sp_hub_dot, dim3(nhub), dim3(kBlock), 0, st, r, H, R, y.p, g);

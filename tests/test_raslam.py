@@ -237,10 +237,11 @@ def test_hip_ra_noiseless_fixed_point_and_solve(built, name):
     opt = da.QuadraticOptimizer(Pr, da.ROptParameters(RTR_iterations=200, RTR_tCG_iterations=200, gradnorm_tol=1e-4))
     X = opt.optimize(X0)
     res = opt.getOptResult()
-    assert res["fOpt"] < 1e-8 and res["gradNormOpt"] < 1e-4
+    # the solve stops at |rgrad| < 1e-4: the cost left at that point is O(1e-8), not exactly reproducible to rounding
+    assert res["fOpt"] < 1e-7 and res["gradNormOpt"] < 1e-4
     Po = orc.Problem(r, d, n, orc.CSR.from_scipy(ds.Q.to_scipy()), reg=reg, l=l, b=b)
     Xo, reso = Po.optimize(X0, RTR_iterations=200, RTR_tCG_iterations=200, gradnorm_tol=1e-4)
-    assert abs(res["fOpt"] - reso["fOpt"]) < 1e-8
+    assert abs(res["fOpt"] - reso["fOpt"]) < 1e-7
     S = da.dual_certificate(r, d, n, X, ds.Q, l=l, b=b)
     psd, theta, v, lmin = da.fast_verification(S, 1e-4, block=1)
     assert psd
