@@ -595,6 +595,7 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
   ci.max_inner = max_inner;
   const int solve_first = seq + 1;
   const CsrDev Qv = Q.view();
+  const BsrDev Qbv = has_bsr ? Qb.view() : BsrDev{};
   const double *Gp = has_G ? G.p : nullptr;
   const int nA = npA(), nPB = fused_pose_blocks(m);
   const int nPG = sparse_precond ? fused_update_grid(m) : fused_precond_grid(m);
@@ -638,9 +639,10 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
       }
       if (hf->tcg_done_seq >= tcg_first_seq) break;
       const int par = j & 1;
-      launch_fused_hess(st, m, Qv, z.p, dbuf[par ^ 1], dbuf[par], Xb(), Sb(), Hd.p, p3.p, nPB, p1.p, c, ++seq, j);
+      const int nP1 = launch_fused_hess(st, m, Qv, z.p, dbuf[par ^ 1], dbuf[par], Xb(), Sb(), Hd.p, p3.p, nPB, p1.p,
+                                        c, ++seq, j, has_bsr ? &Qbv : nullptr);
       launch_fused_precond(st, m, ldm, Mi, RGb(), dbuf[par], Hd.p, eta.p, Heta.p, rbuf[par], rbuf[par ^ 1],
-                           Zpart.p, p1.p, nPB, p2.p, c, hf_dev, ++seq, j, 0, sf);
+                           Zpart.p, p1.p, nP1, p2.p, c, hf_dev, ++seq, j, 0, sf);
       if (sparse_precond) sp.apply(st, m.r, buf1(rbuf[par ^ 1]), Zpart.p, Gate{c, ++seq, 2}, folded);
       launch_fused_finish(st, m, Xb(), Zpart.p, rbuf[par ^ 1], z.p, p2.p, nPG, p3.p, c, hf_dev, ++seq, j, 0, nsl, sf);
       fin_seq[j] = seq;

@@ -191,9 +191,11 @@ int fused_precond_grid(const ManiDesc &m);  // partial slots written by precond
 // Minv == nullptr: the kernel does the step / vector updates only (the sparse preconditioner follows as its own
 // launches); it then writes fused_update_grid(m) partial slots, and finish is called with nsplit = 1
 int fused_update_grid(const ManiDesc &m);
-void launch_fused_hess(hipStream_t st, const ManiDesc &m, const CsrDev &Q, const double *z, const double *d_old,
+// returns the number of <d, H d> partials written (p1)
+int launch_fused_hess(hipStream_t st, const ManiDesc &m, const CsrDev &Q, const double *z, const double *d_old,
                        double *d_new, Buf2 X, Buf2 S, double *Hd, const double *p3, int np3, double *p1,
-                       SolverCtl *ctl, int seq, int iter);
+                       SolverCtl *ctl, int seq, int iter,
+                      const BsrDev *Ab = nullptr /* block-CSR copy of Q: 8-lanes-per-pose kernel */);
 // The sparse preconditioner's two permutations folded into the kernels around it: B scatters the new residual into
 // image 0 of the replay vector (in_pos: original unknown -> position), C reads z from where the replay leaves it
 // (out_pos: original unknown -> final position).  y == nullptr: not folded.

@@ -201,6 +201,7 @@ __device__ __forceinline__ void row_polar(Row<D> &A, bool live) {
 }
 
 constexpr int kPosesPerBlock = kBlock / GW;  // 32 (pure per-pose kernels)
+constexpr int kBsrTile = 160;                // matrix blocks staged per pass (20 KiB at (d+1)^2 = 16)
 constexpr int kHessTile = 1536;              // nnz staged per pass (18 KiB of LDS)
 
 // poses per block of the two-phase kernels: phase 1 runs one thread per output element (pose, column, row),
@@ -371,6 +372,142 @@ __global__ __launch_bounds__(kBlock) void k_fused_hess(ManiDesc m, CsrDev Q, con
   double dacc = 0;
 #pragma unroll
   for (int a = 0; a < DH; ++a) dacc += V.e[a] * W.e[a];
+  const double tot = f_block_sum(dacc, s_red);
+  if (threadIdx.x == 0) p1[blockIdx.x] = tot;
+}
+
+// A on the block structure of Q (pose graphs large enough to carry the block-CSR copy): 8 lanes per pose from the
+// start, so phase 1 leaves W in the lane layout phase 2 works in (no LDS hand-over), one gather of the neighbour's
+// (d+1) r values per matrix block instead of (d+1)^2 scalar entries.  32 poses per workgroup.
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_fused_hess_bsr(ManiDesc m, BsrDev A, const double *__restrict__ z,
+                                                           const double *__restrict__ d_old,
+                                                           double *__restrict__ d_new, Buf2 Xb, Buf2 Sb,
+                                                           double *__restrict__ Hd, const double *__restrict__ p3,
+                                                           int np3, double *__restrict__ p1, SolverCtl *ctl, int seq,
+                                                           int iter) {
+  const int par = iter & 1;
+  const int st_o = ctl->outer_done_stamp, st_t = ctl->tcg_done_stamp, cur = ctl->cur & 1;
+  const double c_zr = ctl->z_r[par ^ 1], c_alpha = ctl->alpha, c_dPd = ctl->d_Pd[par ^ 1], c_ePd = ctl->e_Pd[par ^ 1],
+               c_ePen = ctl->e_Pe_n;
+  constexpr int DH = D + 1, BS = DH * DH;
+  __shared__ double s_bv[kBsrTile * BS];
+  __shared__ int s_bc[kBsrTile];
+  __shared__ double s_red[16];
+  const int r = m.r;
+  const int pose0 = blockIdx.x * kPosesPerBlock;
+  const int g = threadIdx.x >> 3, tt = threadIdx.x & (GW - 1);
+  const int pose = pose0 + g;
+  const bool inr = pose < m.n;
+  const bool pact = inr && (tt < r);
+  const size_t o = (size_t)pose * DH * r;
+  const int pi3 = f_partial_index(np3);
+  double myp = (pi3 < np3) ? p3[pi3] : 0.0;
+  const int pend_pose = min(m.n, pose0 + kPosesPerBlock);
+  const int bbeg = A.bp[pose0], bend = A.bp[pend_pose];
+  const int myb = inr ? A.bp[pose] : 0, mye = inr ? A.bp[pose + 1] : 0;
+  // own rows of z / d_old, pose operands
+  Row<D> Zo, Do, Y;
+  ld_row<D>(z + o, r, tt, pact, Zo);
+  if (iter > 0) {
+    ld_row<D>(d_old + o, r, tt, pact, Do);
+  } else {
+#pragma unroll
+    for (int a = 0; a < DH; ++a) Do.e[a] = 0.0;
+  }
+  const double *__restrict__ X = Xb.p[cur];
+  const double *__restrict__ Sblk = Sb.p[cur];
+  ld_row<D>(X + o, r, tt, pact, Y);
+  double S[D][D];
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int b = 0; b < D; ++b) S[a][b] = inr ? Sblk[(size_t)pose * D * D + a + b * D] : 0.0;
+  for (int i = threadIdx.x + kBlock; i < np3; i += kBlock) myp += p3[i];
+  if (seq > st_o || seq > st_t) return;  // solve or tCG already finished: no-op (uniform over the grid)
+  const double z_r_new = f_partial_total(myp, np3, s_red);
+  double beta = 0;
+  if (iter > 0) beta = z_r_new / c_zr;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (iter == 0) {
+      ctl->z_r[0] = z_r_new;
+      ctl->d_Pd[0] = z_r_new;
+      ctl->e_Pe[0] = 0;
+      ctl->e_Pd[0] = 0;
+    } else {
+      ctl->z_r[par] = z_r_new;
+      ctl->e_Pd[par] = beta * (c_ePd + c_alpha * c_dPd);
+      ctl->d_Pd[par] = z_r_new + beta * beta * c_dPd;
+      ctl->e_Pe[par] = c_ePen;
+    }
+  }
+  // ---- phase 1: W = d_new Q over the pose's block row, d_new = beta d_old - z formed in the gather ----
+  Row<D> W, V;
+#pragma unroll
+  for (int a = 0; a < DH; ++a) W.e[a] = 0.0;
+  for (int base = bbeg; base < bend; base += kBsrTile) {
+    const int cnt = min(kBsrTile, bend - base);
+    __syncthreads();
+    {
+      constexpr int SU = (kBsrTile * BS / 2 + kBlock - 1) / kBlock;
+      const double2 *__restrict__ src = reinterpret_cast<const double2 *>(A.bv + (size_t)base * BS);
+      const int n2 = cnt * BS / 2;
+      double2 v_r[SU];
+      const int bc_r = A.bc[base + min((int)threadIdx.x, cnt - 1)];
+      if ((BS & 1) == 0) {
+#pragma unroll
+        for (int u = 0; u < SU; ++u) v_r[u] = src[min((int)threadIdx.x + u * kBlock, n2 - 1)];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+          const int i = threadIdx.x + u * kBlock;
+          if (i < n2) reinterpret_cast<double2 *>(s_bv)[i] = v_r[u];
+        }
+      } else {
+        for (int i = threadIdx.x; i < cnt * BS; i += kBlock) s_bv[i] = A.bv[(size_t)base * BS + i];
+      }
+      if ((int)threadIdx.x < cnt) s_bc[threadIdx.x] = bc_r;
+      for (int i = threadIdx.x + kBlock; i < cnt; i += kBlock) s_bc[i] = A.bc[base + i];
+    }
+    __syncthreads();
+    const int lo = max(myb, base) - base, hi = min(mye, base + cnt) - base;
+    for (int b = lo; b < hi; b += 4) {
+      double xz[4][DH], xd[4][DH];
+      int bb[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool ok = pact && (b + q < hi);
+        bb[q] = (b + q < hi) ? b + q : b;
+        const size_t oo = (size_t)s_bc[bb[q]] * DH * r + tt;
+#pragma unroll
+        for (int c = 0; c < DH; ++c) {
+          xz[q][c] = ok ? z[oo + c * r] : 0.0;
+          xd[q][c] = (ok && iter > 0) ? d_old[oo + c * r] : 0.0;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double *__restrict__ Bq = s_bv + bb[q] * BS;
+#pragma unroll
+        for (int a = 0; a < DH; ++a) {
+          double s = 0;
+#pragma unroll
+          for (int c = 0; c < DH; ++c) s += Bq[a * DH + c] * (beta * xd[q][c] - xz[q][c]);
+          W.e[a] += s;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < DH; ++a) V.e[a] = (iter > 0) ? beta * Do.e[a] - Zo.e[a] : -Zo.e[a];
+  st_row<D>(d_new + o, r, tt, pact, V);
+  // ---- phase 2 ----
+  row_sub_AS<D>(W, V, S);
+  row_tangent<D>(Y, W);
+  st_row<D>(Hd + o, r, tt, pact, W);
+  double dacc = 0;
+#pragma unroll
+  for (int a = 0; a < DH; ++a) dacc += V.e[a] * W.e[a];
+  if (!pact) dacc = 0;
   const double tot = f_block_sum(dacc, s_red);
   if (threadIdx.x == 0) p1[blockIdx.x] = tot;
 }
@@ -885,7 +1022,6 @@ __global__ __launch_bounds__(kBlock) void k_g_nesterov(ManiDesc m, GNesterovArgs
 // values and column indices of the workgroup's 32 block rows are staged in LDS with coalesced loads and read back
 // as broadcasts.  Four times fewer gather instructions and ~25 % fewer bytes than the scalar-CSR kernel.
 // ------------------------------------------------------------------------------------------------------
-constexpr int kBsrTile = 160;  // matrix blocks staged per pass (20 KiB at (d+1)^2 = 16)
 
 template <int D, bool DOTS>
 __global__ __launch_bounds__(kBlock) void k_spmm_bsr(int r, BsrDev A, Buf2 Xb, int selX,
@@ -1138,9 +1274,19 @@ int fused_update_grid(const ManiDesc &m) {
   return (int)(blocks < 1024 ? blocks : 1024);
 }
 
-void launch_fused_hess(hipStream_t st, const ManiDesc &m, const CsrDev &Q, const double *z, const double *d_old,
-                       double *d_new, Buf2 X, Buf2 S, double *Hd, const double *p3, int np3, double *p1,
-                       SolverCtl *ctl, int seq, int iter) {
+int launch_fused_hess(hipStream_t st, const ManiDesc &m, const CsrDev &Q, const double *z, const double *d_old,
+                      double *d_new, Buf2 X, Buf2 S, double *Hd, const double *p3, int np3, double *p1,
+                      SolverCtl *ctl, int seq, int iter, const BsrDev *Ab) {
+  if (Ab) {  // block structure available: 32 poses per workgroup
+    const int gridb = (m.n + kPosesPerBlock - 1) / kPosesPerBlock;
+    if (m.d == 3)
+      hipLaunchKernelGGL(k_fused_hess_bsr<3>, dim3(gridb), dim3(kBlock), 0, st, m, *Ab, z, d_old, d_new, X, S, Hd, p3,
+                         np3, p1, ctl, seq, iter);
+    else
+      hipLaunchKernelGGL(k_fused_hess_bsr<2>, dim3(gridb), dim3(kBlock), 0, st, m, *Ab, z, d_old, d_new, X, S, Hd, p3,
+                         np3, p1, ctl, seq, iter);
+    return gridb;
+  }
   const int grid = fused_pose_blocks(m);
   if (m.d == 3)
     hipLaunchKernelGGL(k_fused_hess<3>, dim3(grid), dim3(kBlock), 0, st, m, Q, z, d_old, d_new, X, S, Hd, p3, np3,
@@ -1148,6 +1294,7 @@ void launch_fused_hess(hipStream_t st, const ManiDesc &m, const CsrDev &Q, const
   else
     hipLaunchKernelGGL(k_fused_hess<2>, dim3(grid), dim3(kBlock), 0, st, m, Q, z, d_old, d_new, X, S, Hd, p3, np3,
                        p1, ctl, seq, iter);
+  return grid;
 }
 void launch_fused_precond(hipStream_t st, const ManiDesc &m, int ldm, const double *Minv, Buf2 grad,
                           const double *delta, const double *Hd, double *eta, double *Heta, const double *res_old,
