@@ -23,7 +23,7 @@ static void nesterov(hipStream_t st, const ManiDesc &m, int mode, int restart, i
   if (group_kernels(m))
     launch_g_nesterov(st, m, mode, restart, skip_lo, skip_hi, alpha, gamma, X, V, Y, XPrev, Yloc, Xloc, ctl);
   else  // thread-per-pose kernels: the caller resolved the result pointer (ctl == nullptr)
-    launch_nesterov(st, m, mode, restart, skip_lo, skip_hi, alpha, gamma, X, V, Y, XPrev, Yloc, Xloc.p[0]);
+    launch_nesterov(st, m, mode, restart & 1, skip_lo, skip_hi, alpha, gamma, X, V, Y, XPrev, Yloc, Xloc.p[0]);
 }
 
 // The thread-per-pose Nesterov kernels take one result pointer: when the solver left its choice of buffer on the
@@ -231,7 +231,8 @@ int RbcdSession::phase_nonselected(int selected) {
   DCORA_HIP(hipSetDevice(opt.device));
   advance_sequences();
   if (!opt.acceleration) return DCORA_OK;
-  const int restart = restart_now() ? 1 : 0;
+  // bit 1: after the first round every V is the output of a projection (or a copy of X): skip its re-projection
+  const int restart = (restart_now() ? 1 : 0) | (iteration > 1 ? 2 : 0);
   if (opt.world_size == 1) {
     // one launch over the whole graph, skipping the selected agent's poses
     nesterov(st, mg, 0, restart, P.start(selected), P.end(selected), alpha, gamma, Xg.p, Vg.p, Yg.p, XPrevg.p, nullptr,
@@ -239,7 +240,7 @@ int RbcdSession::phase_nonselected(int selected) {
   } else {
     for (AgentDev &a : agents) {
       if (!a.hosted || a.id == selected) continue;
-      const int rc = update_nonselected_agent(a, restart != 0);
+      const int rc = update_nonselected_agent(a, (restart & 1) != 0);
       if (rc) return rc;
     }
   }
@@ -248,8 +249,8 @@ int RbcdSession::phase_nonselected(int selected) {
 
 int RbcdSession::update_nonselected_agent(AgentDev &a, bool restart) {
   const size_t off = (size_t)a.col0 * r;
-  nesterov(st, a.prob->m, 0, restart ? 1 : 0, -1, -1, alpha, gamma, Xg.p + off, Vg.p + off, Yg.p + off,
-           XPrevg.p + off, nullptr, Buf2{{nullptr, nullptr}}, nullptr);
+  nesterov(st, a.prob->m, 0, (restart ? 1 : 0) | (iteration > 1 ? 2 : 0), -1, -1, alpha, gamma, Xg.p + off,
+           Vg.p + off, Yg.p + off, XPrevg.p + off, nullptr, Buf2{{nullptr, nullptr}}, nullptr);
   return DCORA_OK;
 }
 

@@ -983,17 +983,21 @@ __global__ __launch_bounds__(kBlock) void k_g_nesterov(ManiDesc m, GNesterovArgs
       if (a.mode == 1) {
         st_row<D>(a.Y + o, r, t, active, y);
         st_row<D>(a.Yloc + o, r, t, active, y);
-      } else if (a.restart) {
+      } else if (a.restart & 1) {
         st_row<D>(a.V + o, r, t, active, x);
         st_row<D>(a.Y + o, r, t, active, x);
         // uniform control flow for the second polar below is not needed: restart is a kernel argument
       } else {
-        const double vt = v.e[D];
-        row_polar<D>(v, inrange);  // V + g (X - Y) with X == Y
-        v.e[D] = vt;
         st_row<D>(a.Y + o, r, t, active, y);
         st_row<D>(a.X + o, r, t, active, y);
-        st_row<D>(a.V + o, r, t, active, v);
+        // V <- proj(V + gamma (X - Y)) with X == Y.  Bit 1 of `restart`: V is known to be feasible (it is the output
+        // of a projection or a copy of a feasible X since the last set_X), its re-projection is the identity.
+        if (!(a.restart & 2)) {
+          const double vt = v.e[D];
+          row_polar<D>(v, inrange);
+          v.e[D] = vt;
+          st_row<D>(a.V + o, r, t, active, v);
+        }
       }
     } else {
       ld_row<D>(Xloc + o, r, t, active, x);
