@@ -323,6 +323,25 @@ def _precond_info(self):
 QuadraticProblem.precond_info = _precond_info
 
 
+def _qapply_info(self):
+    info = np.zeros(4)
+    check(capi.lib().dcora_problem_qapply_info(self.h, info))
+    return {"kernel": "k_spmm_bsr" if info[0] else "k_spmm", "nnz": int(info[1]), "blocks": int(info[2]),
+            "stored_matrix_bytes": float(info[3])}
+
+
+QuadraticProblem.qapply_info = _qapply_info
+
+
+def time_qapply_rotating(problems, reps=60):
+    """average launch time of the Q-apply over several problems in turn on one stream (HBM-cold when their bytes
+    exceed the Infinity Cache)"""
+    arr = (C.c_void_p * len(problems))(*[getattr(p.h, 'value', p.h) for p in problems])
+    ms = C.c_double()
+    check(capi.lib().dcora_problem_time_qapply_rotating(arr, len(problems), reps, C.byref(ms)))
+    return ms.value
+
+
 class QuadraticOptimizer:
     """ref include/DCORA/QuadraticOptimizer.h: optimize(Y), getOptResult()"""
 
@@ -498,6 +517,70 @@ class RbcdSession:
 
     def synchronize(self):
         check(capi.lib().dcora_rbcd_synchronize(self.h))
+
+
+class Exchange:
+    """neighbour exchange of public poses between the ranks of one node (dcora_exchange_*): the session must have been
+    created with rank / world_size; every rank creates the exchange under the same job name"""
+    IPC, STAGED = 1, 2
+
+    def __init__(self, session, job_name):
+        self.s = session
+        self.h = C.c_void_p()
+        check(capi.lib().dcora_exchange_create(session.h, job_name.encode(), C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            capi.lib().dcora_exchange_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        v = np.zeros(8)
+        check(capi.lib().dcora_exchange_info(self.h, v))
+        return dict(transport={1: "ipc peer stores", 2: "shared host segment"}.get(int(v[0]), "?"), mode=int(v[0]),
+                    peers=int(v[1]), posts=int(v[2]), waits=int(v[3]), bytes_posted=float(v[4]), post_s=float(v[5]),
+                    wait_s=float(v[6]), eval_wait_s=float(v[7]))
+
+    def post(self, agents):
+        a = np.ascontiguousarray(agents, dtype=np.int32)
+        check(capi.lib().dcora_exchange_post(self.h, a, a.size))
+
+    def wait(self, agents):
+        a = np.ascontiguousarray(agents, dtype=np.int32)
+        check(capi.lib().dcora_exchange_wait(self.h, a, a.size))
+
+    def _eval(self, fn, *first):
+        c2, gn, nxt = C.c_double(), C.c_double(), C.c_int()
+        bn = np.zeros(self.s.R)
+        check(fn(self.h, *first, C.byref(c2), C.byref(gn), bn.ctypes.data_as(C.c_void_p), C.byref(nxt)))
+        return c2.value, gn.value, bn, nxt.value
+
+    def evaluate(self):
+        return self._eval(capi.lib().dcora_exchange_evaluate)
+
+    def iterate(self, selected):
+        return self._eval(capi.lib().dcora_exchange_rbcd_iterate, int(selected))
+
+    def tick(self, agents, allow_adjacent=False):
+        a = np.ascontiguousarray(agents, dtype=np.int32)
+        check(capi.lib().dcora_exchange_rbcd_tick(self.h, a, a.size, int(allow_adjacent)))
+
+    def set_X(self, X):
+        check(capi.lib().dcora_exchange_set_X(self.h, F(X)))
+
+    def gather_X(self):
+        out = np.zeros(self.s.r * self.s.k)
+        check(capi.lib().dcora_exchange_gather_X(self.h, out))
+        return unF(out, self.s.r, self.s.k)
+
+    def barrier(self):
+        check(capi.lib().dcora_exchange_barrier(self.h))
 
 
 class RaRbcdSession:

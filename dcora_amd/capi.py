@@ -135,6 +135,17 @@ SIGNATURES = {
     "dcora_rbcd_phase_selected": (C.c_int, [_vp, C.c_int]),
     "dcora_rbcd_phase_evaluate_dev": (C.c_int, [_vp, _vp]),
     "dcora_rbcd_synchronize": (C.c_int, [_vp]),
+    "dcora_exchange_create": (C.c_int, [_vp, C.c_char_p, C.POINTER(_vp)]),
+    "dcora_exchange_destroy": (C.c_int, [_vp]),
+    "dcora_exchange_info": (C.c_int, [_vp, _dp]),
+    "dcora_exchange_post": (C.c_int, [_vp, _ip, C.c_int]),
+    "dcora_exchange_wait": (C.c_int, [_vp, _ip, C.c_int]),
+    "dcora_exchange_evaluate": (C.c_int, [_vp, _PD, _PD, _vp, _PI]),
+    "dcora_exchange_rbcd_iterate": (C.c_int, [_vp, C.c_int, _PD, _PD, _vp, _PI]),
+    "dcora_exchange_rbcd_tick": (C.c_int, [_vp, _ip, C.c_int, C.c_int]),
+    "dcora_exchange_set_X": (C.c_int, [_vp, _dp]),
+    "dcora_exchange_gather_X": (C.c_int, [_vp, _dp]),
+    "dcora_exchange_barrier": (C.c_int, [_vp]),
     "dcora_ra_rbcd_create": (C.c_int, [_vp, C.POINTER(RbcdOptions), C.POINTER(_vp)]),
     "dcora_ra_rbcd_destroy": (C.c_int, [_vp]),
     "dcora_ra_rbcd_info": (C.c_int, [_vp, _PI, _vp]),
@@ -145,6 +156,8 @@ SIGNATURES = {
     "dcora_ra_rbcd_run": (C.c_int, [_vp, C.c_int, C.c_double, _PI, _vp, _vp, _vp]),
     "dcora_ra_rbcd_last_result": (C.c_int, [_vp, C.POINTER(ROptResult)]),
     "dcora_problem_time_qapply": (C.c_int, [_vp, C.c_int, _PD, _PD]),
+    "dcora_problem_time_qapply_rotating": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, _PD]),
+    "dcora_problem_qapply_info": (C.c_int, [_vp, _dp]),
     "dcora_problem_time_precond": (C.c_int, [_vp, C.c_int, _PD, _PD]),
     "dcora_problem_precond_info": (C.c_int, [_vp, _dp]),
     "dcora_robust_params_default": (None, [C.POINTER(RobustParams)]),

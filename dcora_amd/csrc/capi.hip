@@ -9,6 +9,7 @@
 #include "host_graph.h"
 #include "ra_rbcd.h"
 #include "rbcd.h"
+#include "exchange.h"
 #include "host_robust.h"
 #include "robust.h"
 #include "round.h"
@@ -30,6 +31,9 @@ struct dcora_dataset_s {
 struct dcora_rbcd_s {
   RbcdSession s;
   std::vector<int> sel_trace;
+};
+struct dcora_exchange_s {
+  Exchange e;
 };
 
 namespace {
@@ -187,6 +191,53 @@ int dcora_optimizer_optimize(dcora_problem_t p, const dcora_ropt_params *params,
 }
 int dcora_problem_time_qapply(dcora_problem_t p, int reps, double *avg_ms, double *bytes) {
   return p ? p->p.time_qapply(reps, avg_ms, bytes) : bad("null");
+}
+
+// the Q-apply of `count` problems in turn on one stream: with distinct (Q, X, Y) sets whose bytes add up to more than
+// the 256 MiB Infinity Cache every launch streams from HBM
+int dcora_problem_time_qapply_rotating(const dcora_problem_t *ps, int count, int reps, double *avg_ms) {
+  if (!ps || count < 1 || !avg_ms) return bad("null");
+  for (int i = 0; i < count; ++i)
+    if (!ps[i]) return bad("null problem");
+  DCORA_TRY
+  DeviceProblem &P0 = ps[0]->p;
+  DCORA_HIP(hipSetDevice(P0.device));
+  std::vector<hipStream_t> keep(count);
+  for (int i = 0; i < count; ++i) {
+    DCORA_HIP(hipStreamSynchronize(ps[i]->p.st));
+    keep[i] = ps[i]->p.st;
+    ps[i]->p.st = P0.st;
+  }
+  hipEvent_t e0, e1;
+  DCORA_HIP(hipEventCreate(&e0));
+  DCORA_HIP(hipEventCreate(&e1));
+  for (int i = 0; i < count; ++i) ps[i]->p.enqueue_egrad(ps[i]->p.X0.p, ps[i]->p.EG0.p, nullptr);
+  DCORA_HIP(hipEventRecord(e0, P0.st));
+  for (int i = 0; i < reps; ++i) {
+    DeviceProblem &P = ps[i % count]->p;
+    P.enqueue_egrad(P.X0.p, P.EG0.p, nullptr);
+  }
+  DCORA_HIP(hipEventRecord(e1, P0.st));
+  DCORA_HIP(hipEventSynchronize(e1));
+  float ms = 0;
+  DCORA_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  for (int i = 0; i < count; ++i) ps[i]->p.st = keep[i];
+  *avg_ms = (double)ms / reps;
+  return DCORA_OK;
+  DCORA_CATCH
+}
+int dcora_problem_qapply_info(dcora_problem_t p, double *info) {
+  if (!p || !info) return bad("null");
+  const DeviceProblem &P = p->p;
+  info[0] = P.has_bsr ? 1 : 0;
+  info[1] = (double)P.Q.nnz;
+  info[2] = P.has_bsr ? (double)P.Qb.nblocks : 0.0;
+  // bytes of the matrix in the form the kernel reads
+  info[3] = P.has_bsr ? P.Qb.nblocks * (8.0 * (P.m.d + 1) * (P.m.d + 1) + 4.0) + 4.0 * (P.m.n + 1)
+                      : 12.0 * P.Q.nnz + 4.0 * (P.m.k + 1);
+  return DCORA_OK;
 }
 
 int dcora_problem_time_precond(dcora_problem_t p, int reps, double *avg_ms, double *bytes) {
@@ -585,6 +636,86 @@ int dcora_rbcd_synchronize(dcora_rbcd_t s) {
   if (!s) return bad("null");
   DCORA_HIP(hipStreamSynchronize(s->s.st));
   return DCORA_OK;
+}
+
+// ---- neighbour exchange between ranks ------------------------------------------------------------------------------
+int dcora_exchange_create(dcora_rbcd_t s, const char *job_name, dcora_exchange_t *out) {
+  if (!s || !job_name || !out) return bad("null argument");
+  DCORA_TRY
+  dcora_exchange_s *h = new dcora_exchange_s;
+  const int rc = h->e.init(&s->s, job_name);
+  if (rc) {
+    delete h;
+    return rc;
+  }
+  *out = h;
+  return DCORA_OK;
+  DCORA_CATCH
+}
+int dcora_exchange_destroy(dcora_exchange_t ex) {
+  delete ex;
+  return DCORA_OK;
+}
+int dcora_exchange_info(dcora_exchange_t ex, double *info) {
+  if (!ex || !info) return bad("null");
+  const Exchange &e = ex->e;
+  info[0] = e.mode;
+  info[1] = e.num_peers();
+  info[2] = (double)e.posts;
+  info[3] = (double)e.waits;
+  info[4] = e.bytes_posted;
+  info[5] = e.post_s;
+  info[6] = e.wait_s;
+  info[7] = e.eval_wait_s;
+  return DCORA_OK;
+}
+int dcora_exchange_post(dcora_exchange_t ex, const int *agents, int count) {
+  if (!ex || (!agents && count > 0)) return bad("null");
+  DCORA_TRY
+  return ex->e.post(agents, count);
+  DCORA_CATCH
+}
+int dcora_exchange_wait(dcora_exchange_t ex, const int *agents, int count) {
+  if (!ex || (!agents && count > 0)) return bad("null");
+  DCORA_TRY
+  return ex->e.wait(agents, count);
+  DCORA_CATCH
+}
+int dcora_exchange_evaluate(dcora_exchange_t ex, double *cost2, double *gradnorm, double *block_norms,
+                            int *next_selected) {
+  if (!ex) return bad("null");
+  DCORA_TRY
+  return ex->e.evaluate(cost2, gradnorm, block_norms, next_selected);
+  DCORA_CATCH
+}
+int dcora_exchange_rbcd_iterate(dcora_exchange_t ex, int selected, double *cost2, double *gradnorm,
+                                double *block_norms, int *next_selected) {
+  if (!ex) return bad("null");
+  DCORA_TRY
+  return ex->e.rbcd_iterate(selected, cost2, gradnorm, block_norms, next_selected);
+  DCORA_CATCH
+}
+int dcora_exchange_rbcd_tick(dcora_exchange_t ex, const int *set, int count, int allow_adjacent) {
+  if (!ex || !set) return bad("null");
+  DCORA_TRY
+  return ex->e.rbcd_tick(set, count, allow_adjacent);
+  DCORA_CATCH
+}
+int dcora_exchange_set_X(dcora_exchange_t ex, const double *X) {
+  if (!ex || !X) return bad("null");
+  DCORA_TRY
+  return ex->e.set_X(X);
+  DCORA_CATCH
+}
+int dcora_exchange_gather_X(dcora_exchange_t ex, double *X) {
+  if (!ex || !X) return bad("null");
+  DCORA_TRY
+  return ex->e.gather_X(X);
+  DCORA_CATCH
+}
+int dcora_exchange_barrier(dcora_exchange_t ex) {
+  if (!ex) return bad("null");
+  return ex->e.barrier();
 }
 
 // ---- RBCD session, range-aided SLAM ----------------------------------------------------------------------------

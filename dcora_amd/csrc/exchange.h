@@ -1,0 +1,108 @@
+// Neighbour exchange of public poses between the ranks of ONE node (one process per GPU), inside the library
+// (replaces the transport the reference leaves to its host: Agent::getSharedStateDicts -> updateNeighborStates,
+// ref src/Agent.cpp:113-152, 844-906, driven by examples/MultiRobotExample.cpp:236-258).
+//
+// Transport: every rank owns a halo buffer in its HBM with one slot per agent; the peers map
+// it through HIP IPC.  A post is ONE kernel per hosted agent: it gathers the agent's public poses from the mirror of
+// X and stores them straight into the halo slot of every rank that hosts a neighbour of that agent (peer stores over
+// xGMI), fences at system scope and lets its last workgroup store the agent's sequence number into a flag word.  Flag
+// words and the 2R evaluation scalars live in a POSIX shared-memory segment that every rank registers with HIP
+// (device-writable, host-readable): a device store there IS the all-gather.  The receiving host spins on the flag
+// word and enqueues the scatter into its mirror.  No collective, no ring, no host copy of pose data.
+// When IPC mapping (or its self-test) fails on any rank, all ranks fall back to staging the packed poses in the same
+// shared host segment (device store over PCIe, device load over PCIe on the consumer).
+#pragma once
+#include <atomic>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "rbcd.h"
+
+namespace dcora {
+
+constexpr int kMaxRanks = 64;
+constexpr uint32_t kShmMagic = 0x44434f52u;  // "DCOR"
+
+struct alignas(64) ShmFlag {
+  volatile uint64_t seq;
+  uint64_t pad[7];
+};
+struct alignas(64) ShmEval {
+  volatile double g2, xeg;  // |Proj(X_b Q_bb + G_b)|^2, <X_b, X_b Q_bb + G_b>
+  volatile uint64_t seq;
+  uint64_t pad[5];
+};
+struct alignas(64) ShmRank {
+  hipIpcMemHandle_t halo;  // 64 bytes
+  std::atomic<int> device, pid, ipc_ok, published;
+  uint64_t pad[6];
+};
+struct ShmHeader {
+  std::atomic<uint32_t> magic;
+  uint32_t world, R;
+  uint64_t slot_doubles, total_bytes, x_doubles;
+  std::atomic<uint32_t> bar_count, bar_gen;
+  std::atomic<uint32_t> failed;  // a rank gave up: everybody waiting returns an error instead of spinning on
+  uint32_t pad;
+};
+
+enum ExchangeMode { kExchangeIpc = 1, kExchangeStaged = 2 };
+
+class Exchange {
+ public:
+  ~Exchange();
+  int init(RbcdSession *s, const char *job_name);
+  int post(const int *agents, int count);
+  int wait(const int *agents, int count);
+  int evaluate(double *cost2, double *gradnorm, double *block_norms, int *next_selected);
+  int rbcd_iterate(int selected, double *cost2, double *gradnorm, double *block_norms, int *next_selected);
+  int rbcd_tick(const int *set, int count, int allow_adjacent);
+  int barrier(double timeout_s = 120.0);
+  int gather_X(double *Xh);
+  // Agent::setX of every agent on every rank: sequence numbers restart with the Nesterov sequences
+  int set_X(const double *Xh);
+
+  int mode = 0;
+  int rank = 0, world = 1;
+  // statistics since creation (host wall time spent in post / wait / the evaluation all-gather, bytes posted)
+  double post_s = 0, wait_s = 0, eval_wait_s = 0;
+  long posts = 0, waits = 0, evals = 0;
+  double bytes_posted = 0;
+  int num_peers() const;
+
+ private:
+  RbcdSession *s_ = nullptr;
+  std::string name_;
+  void *map_ = nullptr;
+  size_t map_bytes_ = 0;
+  bool registered_ = false;
+  char *dev_map_ = nullptr;  // device view of the segment
+  ShmHeader *hdr_ = nullptr;
+  ShmRank *ranks_ = nullptr;
+  ShmFlag *flags_ = nullptr;  // [parity][agent]
+  ShmEval *evals_ = nullptr;  // [parity][agent]
+  double *staged_ = nullptr;  // [parity][agent][slot]
+  double *xarea_ = nullptr;   // r x (d+1) n
+  size_t off_flags_ = 0, off_evals_ = 0, off_staged_ = 0, off_x_ = 0;
+  size_t slot_ = 0;                // doubles per agent slot
+  DevBuf<double> halo_;            // [parity][agent][slot] + self-test area
+  double *peer_halo_[kMaxRanks]{};  // IPC mappings (null for myself and for ranks I never write to)
+  bool opened_[kMaxRanks]{};
+  DevBuf<unsigned> arrive_;        // one last-workgroup counter per agent
+  DevBuf<double> evalbuf_;         // 2R
+  DevBuf<int> hosted_list_;
+  int n_hosted_ = 0;
+  std::vector<int> owner_;               // rank hosting agent a
+  std::vector<std::vector<int>> dests_;  // for a hosted agent: the other ranks hosting one of its neighbours
+  std::vector<char> needed_;             // agent a (hosted elsewhere) is a neighbour of an agent hosted here
+  std::vector<uint64_t> seq_;            // posts of agent a so far (identical on every rank)
+  uint64_t eval_seq_ = 0;
+
+  size_t halo_off(int parity, int agent) const { return ((size_t)parity * s_->R + agent) * slot_; }
+  int open_segment(const char *job_name, size_t bytes);
+  int setup_ipc(bool attempt);
+  int fail(const std::string &msg, int code);
+};
+
+}  // namespace dcora

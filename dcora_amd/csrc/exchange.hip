@@ -1,0 +1,509 @@
+// Neighbour exchange of public poses between the ranks of one node (see exchange.h).
+#include "exchange.h"
+
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <set>
+
+namespace dcora {
+
+namespace {
+
+using Clock = std::chrono::steady_clock;
+inline double since(Clock::time_point t0) { return std::chrono::duration<double>(Clock::now() - t0).count(); }
+
+constexpr int kMaxDst = 8;
+struct PostDst {
+  double *base[kMaxDst];
+  int n;
+};
+
+// getSharedStateDicts of one agent, written where its neighbours read it: element i of the packed r x (d+1)count
+// block goes to every destination slot (the peers' halo buffers over xGMI, or the shared host segment); the
+// workgroup that finishes last publishes the sequence number.  Every storing wave drains its stores and the
+// workgroup's lane 0 releases at system scope before it arrives (MI355X_MICROARCH.md, valid producer forms).
+__global__ __launch_bounds__(kBlock) void k_post_public(int r, int ncols, const int *__restrict__ src,
+                                                        const double *__restrict__ X, PostDst dst,
+                                                        unsigned *arrive, volatile uint64_t *flag, uint64_t seq) {
+  const long N = (long)ncols * r;
+  for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < N; i += (long)gridDim.x * kBlock) {
+    const int c = (int)(i / r), t = (int)(i - (long)c * r);
+    const double v = X[(size_t)src[c] * r + t];
+    for (int q = 0; q < dst.n; ++q) dst.base[q][i] = v;
+  }
+  __threadfence_system();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned prev = atomicAdd(arrive, 1u);
+    if (prev == gridDim.x - 1) {
+      __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence_system();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store((uint64_t *)flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// the hosted agents' two evaluation scalars into the shared segment: the device store is the all-gather
+__global__ void k_eval_publish(int nh, const int *__restrict__ hosted, const double *__restrict__ ev, ShmEval *slots,
+                               uint64_t seq) {
+  const int i = threadIdx.x;
+  if (i < nh) {
+    const int a = hosted[i];
+    ShmEval *e = slots + a;
+    __hip_atomic_store((double *)&e->g2, ev[2 * a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store((double *)&e->xeg, ev[2 * a + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store((uint64_t *)&e->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+__global__ void k_selftest_write(double *dst, int count, double base) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) dst[i] = base + i;
+  __threadfence_system();
+}
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace
+
+int Exchange::fail(const std::string &msg, int code) {
+  set_last_error("exchange (rank " + std::to_string(rank) + "): " + msg);
+  if (hdr_) hdr_->failed.store(1);
+  return code;
+}
+
+int Exchange::num_peers() const {
+  std::set<int> p;
+  for (const auto &v : dests_) p.insert(v.begin(), v.end());
+  return (int)p.size();
+}
+
+Exchange::~Exchange() {
+  if (s_) (void)hipSetDevice(s_->opt.device);
+  for (int q = 0; q < kMaxRanks; ++q)
+    if (opened_[q] && peer_halo_[q]) (void)hipIpcCloseMemHandle(peer_halo_[q]);
+  if (registered_ && map_) (void)hipHostUnregister(map_);
+  if (map_) munmap(map_, map_bytes_);
+  if (rank == 0 && !name_.empty()) shm_unlink(name_.c_str());
+}
+
+// Rank 0 creates the segment and publishes the magic word last; the others attach once it is there.  The job name
+// must be unique per job on the node (a stale segment of a crashed job under the same name is removed by rank 0).
+int Exchange::open_segment(const char *job_name, size_t bytes) {
+  name_ = std::string("/dcora_") + job_name;
+  int fd = -1;
+  const auto t0 = Clock::now();
+  if (rank == 0) {
+    shm_unlink(name_.c_str());
+    fd = shm_open(name_.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0) return fail("shm_open(create " + name_ + ") failed: " + std::strerror(errno), DCORA_ERR_IO);
+    if (ftruncate(fd, (off_t)bytes) != 0) {
+      close(fd);
+      return fail("ftruncate failed: " + std::string(std::strerror(errno)), DCORA_ERR_IO);
+    }
+  } else {
+    for (;;) {
+      fd = shm_open(name_.c_str(), O_RDWR, 0600);
+      if (fd >= 0) {
+        struct stat sb;
+        if (fstat(fd, &sb) == 0 && (size_t)sb.st_size >= bytes) break;
+        close(fd);
+        fd = -1;
+      }
+      if (since(t0) > 120.0) return fail("segment " + name_ + " did not appear", DCORA_ERR_IO);
+      usleep(2000);
+    }
+  }
+  map_ = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (map_ == MAP_FAILED) {
+    map_ = nullptr;
+    return fail("mmap failed: " + std::string(std::strerror(errno)), DCORA_ERR_IO);
+  }
+  map_bytes_ = bytes;
+  hdr_ = (ShmHeader *)map_;
+  if (rank == 0) {
+    std::memset(map_, 0, bytes);
+    hdr_->world = (uint32_t)world;
+    hdr_->R = (uint32_t)s_->R;
+    hdr_->slot_doubles = slot_;
+    hdr_->total_bytes = bytes;
+    hdr_->magic.store(kShmMagic, std::memory_order_release);
+  } else {
+    while (hdr_->magic.load(std::memory_order_acquire) != kShmMagic) {
+      if (since(t0) > 120.0) return fail("segment " + name_ + " was never initialised", DCORA_ERR_IO);
+      usleep(1000);
+    }
+    if (hdr_->world != (uint32_t)world || hdr_->R != (uint32_t)s_->R || hdr_->slot_doubles != slot_ ||
+        hdr_->total_bytes != bytes)
+      return fail("segment " + name_ + " belongs to a job of another shape (stale name?)", DCORA_ERR_BAD_ARG);
+  }
+  return DCORA_OK;
+}
+
+int Exchange::barrier(double timeout_s) {
+  if (world == 1) return DCORA_OK;
+  const auto t0 = Clock::now();
+  const uint32_t gen = hdr_->bar_gen.load(std::memory_order_acquire);
+  if (hdr_->bar_count.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)world) {
+    hdr_->bar_count.store(0, std::memory_order_relaxed);
+    hdr_->bar_gen.fetch_add(1, std::memory_order_release);
+    return DCORA_OK;
+  }
+  unsigned spins = 0;
+  while (hdr_->bar_gen.load(std::memory_order_acquire) == gen) {
+    if ((++spins & 1023u) == 0) {
+      if (hdr_->failed.load()) return fail("another rank failed", DCORA_ERR_HIP);
+      if (since(t0) > timeout_s) return fail("barrier timed out", DCORA_ERR_HIP);
+      sched_yield();
+    }
+  }
+  return DCORA_OK;
+}
+
+int Exchange::init(RbcdSession *s, const char *job_name) {
+  s_ = s;
+  rank = s->opt.rank;
+  world = s->opt.world_size;
+  const int R = s->R, dh = s->d + 1;
+  if (world > kMaxRanks) return fail("too many ranks", DCORA_ERR_UNSUPPORTED);
+  if (!job_name || !*job_name) return fail("empty job name", DCORA_ERR_BAD_ARG);
+  DCORA_HIP(hipSetDevice(s->opt.device));
+  const int per = (R + world - 1) / world;
+  owner_.resize(R);
+  size_t maxpub = 1;
+  std::vector<int> hosted;
+  for (int a = 0; a < R; ++a) {
+    owner_[a] = a / per;
+    maxpub = std::max(maxpub, s->agents[a].public_poses.size());
+    if (s->agents[a].hosted) hosted.push_back(a);
+    if (s->agents[a].hosted != (owner_[a] == rank)) return fail("agent-to-rank map out of step with the session", DCORA_ERR_BAD_ARG);
+  }
+  n_hosted_ = (int)hosted.size();
+  slot_ = align_up(maxpub * dh * (size_t)s->r, 16);
+  dests_.assign(R, {});
+  needed_.assign(R, 0);
+  for (int a = 0; a < R; ++a)
+    for (int q : s->agents[a].neighbors) {
+      if (s->agents[a].hosted && owner_[q] != rank &&
+          std::find(dests_[a].begin(), dests_[a].end(), owner_[q]) == dests_[a].end())
+        dests_[a].push_back(owner_[q]);
+      if (!s->agents[a].hosted && s->agents[q].hosted) needed_[a] = 1;
+    }
+  for (int a = 0; a < R; ++a)
+    if ((int)dests_[a].size() > kMaxDst) return fail("an agent has neighbours on more than 8 other ranks", DCORA_ERR_UNSUPPORTED);
+  seq_.assign(R, 0);
+
+  // shared segment: header | per-rank records | flags [2][R] | evaluation slots [2][R] | staged poses [2][R][slot] | X
+  const size_t xd = (size_t)s->r * dh * s->n;
+  size_t off = align_up(sizeof(ShmHeader), 64);
+  const size_t off_ranks = off;
+  off += sizeof(ShmRank) * world;
+  off_flags_ = off;
+  off += sizeof(ShmFlag) * 2 * R;
+  off_evals_ = off;
+  off += sizeof(ShmEval) * 2 * R;
+  off = align_up(off, 4096);
+  off_staged_ = off;
+  off += sizeof(double) * 2 * R * slot_;
+  off = align_up(off, 4096);
+  off_x_ = off;
+  off += sizeof(double) * xd;
+  const size_t total = align_up(off, 4096);
+  int rc = open_segment(job_name, total);
+  if (rc) return rc;
+  ranks_ = (ShmRank *)((char *)map_ + off_ranks);
+  flags_ = (ShmFlag *)((char *)map_ + off_flags_);
+  evals_ = (ShmEval *)((char *)map_ + off_evals_);
+  staged_ = (double *)((char *)map_ + off_staged_);
+  xarea_ = (double *)((char *)map_ + off_x_);
+  {
+    const hipError_t e = hipHostRegister(map_, map_bytes_, hipHostRegisterMapped | hipHostRegisterPortable);
+    if (e != hipSuccess) return fail(std::string("hipHostRegister of the shared segment failed: ") + hipGetErrorString(e), DCORA_ERR_HIP);
+    registered_ = true;
+    DCORA_HIP(hipHostGetDevicePointer((void **)&dev_map_, map_, 0));
+  }
+  DCORA_HIP(arrive_.alloc(R));
+  DCORA_HIP(hipMemset(arrive_.p, 0, sizeof(unsigned) * R));
+  DCORA_HIP(evalbuf_.alloc(2 * R));
+  DCORA_HIP(hipMemset(evalbuf_.p, 0, sizeof(double) * 2 * R));
+  DCORA_HIP(hosted_list_.alloc(std::max(1, n_hosted_)));
+  if (n_hosted_)
+    DCORA_HIP(hipMemcpy(hosted_list_.p, hosted.data(), sizeof(int) * n_hosted_, hipMemcpyHostToDevice));
+
+  const char *force = std::getenv("DCORA_EXCHANGE");
+  const bool want_ipc = !(force && std::strcmp(force, "staged") == 0);
+  int ok = 1;
+  if (world > 1) {
+    rc = setup_ipc(want_ipc);
+    if (rc != DCORA_OK && rc != DCORA_ERR_UNSUPPORTED) return rc;
+    ok = rc == DCORA_OK;
+  }
+  ranks_[rank].ipc_ok.store(ok ? 1 : -1, std::memory_order_release);
+  rc = barrier();
+  if (rc) return rc;
+  bool all = true;
+  for (int q = 0; q < world; ++q) all = all && ranks_[q].ipc_ok.load(std::memory_order_acquire) == 1;
+  mode = all ? kExchangeIpc : kExchangeStaged;
+  if (force && std::strcmp(force, "ipc") == 0 && !all) return fail("DCORA_EXCHANGE=ipc but the IPC transport is not usable", DCORA_ERR_HIP);
+  rc = barrier();
+  if (rc) return rc;
+  if (rank == 0) shm_unlink(name_.c_str());  // every rank has it mapped: nothing is left in /dev/shm after the job
+  return DCORA_OK;
+}
+
+// Halo buffers mapped into every rank that writes to them, then one round of test stores checked by the owner.
+// Every rank passes the same two barriers whatever fails locally; the result is this rank's vote.
+int Exchange::setup_ipc(bool attempt) {
+  const int R = s_->R;
+  const size_t test_off = 2 * (size_t)R * slot_;
+  const int ntest = 64;
+  bool ok = attempt;
+  std::string why;
+  auto no = [&](const std::string &m) {
+    if (ok) why = m;
+    ok = false;
+  };
+  if (ok && halo_.alloc(test_off + (size_t)ntest * world) != hipSuccess) no("hipMalloc of the halo buffer");
+  if (ok && hipMemset(halo_.p, 0, sizeof(double) * (test_off + (size_t)ntest * world)) != hipSuccess) no("hipMemset");
+  if (ok && hipIpcGetMemHandle(&ranks_[rank].halo, halo_.p) != hipSuccess) no("hipIpcGetMemHandle");
+  (void)hipGetLastError();
+  ranks_[rank].device.store(s_->opt.device);
+  ranks_[rank].pid.store((int)getpid());
+  ranks_[rank].published.store(ok ? 1 : -1, std::memory_order_release);
+  int rc = barrier();
+  if (rc) return rc;
+  // whom do I write to: the owners of my hosted agents' neighbours
+  std::set<int> peers;
+  for (int a = 0; a < R; ++a) peers.insert(dests_[a].begin(), dests_[a].end());
+  for (int q : peers) {
+    if (!ok) break;
+    if (ranks_[q].published.load(std::memory_order_acquire) != 1) {
+      no("rank " + std::to_string(q) + " has no halo handle");
+      break;
+    }
+    const int pd = ranks_[q].device.load();
+    if (pd != s_->opt.device) {
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, s_->opt.device, pd) == hipSuccess && can) {
+        const hipError_t e = hipDeviceEnablePeerAccess(pd, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) no("hipDeviceEnablePeerAccess");
+      }
+      (void)hipGetLastError();
+    }
+    void *p = nullptr;
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, &ranks_[q].halo, sizeof(h));
+    if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+      (void)hipGetLastError();
+      no("hipIpcOpenMemHandle of rank " + std::to_string(q));
+      break;
+    }
+    peer_halo_[q] = (double *)p;
+    opened_[q] = true;
+  }
+  // self-test: a pattern into my strip of every peer's test area, checked by the owner after the barrier
+  if (ok) {
+    for (int q : peers)
+      hipLaunchKernelGGL(k_selftest_write, dim3(1), dim3(64), 0, s_->st,
+                         peer_halo_[q] + test_off + (size_t)ntest * rank, ntest, 1000.0 * (rank + 1));
+    if (hipStreamSynchronize(s_->st) != hipSuccess) no("self-test stores");
+    (void)hipGetLastError();
+  }
+  rc = barrier();
+  if (rc) return rc;
+  if (ok) {
+    std::vector<double> h((size_t)ntest * world);
+    if (hipMemcpy(h.data(), halo_.p + test_off, sizeof(double) * h.size(), hipMemcpyDeviceToHost) != hipSuccess)
+      no("reading the self-test area");
+    std::set<int> writers;  // ranks hosting an agent whose public poses I need
+    for (int a = 0; a < R; ++a)
+      if (needed_[a]) writers.insert(owner_[a]);
+    for (int q : writers)
+      for (int i = 0; i < ntest && ok; ++i)
+        if (h[(size_t)ntest * q + i] != 1000.0 * (q + 1) + i) no("self-test pattern of rank " + std::to_string(q) + " did not arrive");
+  }
+  if (!ok && attempt)
+    set_last_error("exchange: IPC transport unavailable (" + why + "), the ranks use the shared host segment");
+  return ok ? DCORA_OK : DCORA_ERR_UNSUPPORTED;
+}
+
+int Exchange::post(const int *agents, int count) {
+  const auto t0 = Clock::now();
+  DCORA_HIP(hipSetDevice(s_->opt.device));
+  const int R = s_->R, r = s_->r, dh = s_->d + 1;
+  for (int i = 0; i < count; ++i) {
+    const int a = agents[i];
+    if (a < 0 || a >= R) return fail("post: agent out of range", DCORA_ERR_BAD_ARG);
+    const uint64_t q = ++seq_[a];
+    AgentDev &ag = s_->agents[a];
+    if (!ag.hosted || dests_[a].empty() || ag.public_poses.empty()) continue;
+    const int parity = (int)(q & 1);
+    PostDst dst{};
+    if (mode == kExchangeIpc) {
+      for (int p : dests_[a]) dst.base[dst.n++] = peer_halo_[p] + halo_off(parity, a);
+    } else {
+      dst.base[dst.n++] = (double *)(dev_map_ + off_staged_) + halo_off(parity, a);
+    }
+    const int ncols = (int)ag.public_poses.size() * dh;
+    const long N = (long)ncols * r;
+    const int grid = (int)std::min<long>((N + kBlock - 1) / kBlock, 64);
+    volatile uint64_t *flag = (volatile uint64_t *)(dev_map_ + off_flags_ + sizeof(ShmFlag) * ((size_t)parity * R + a));
+    hipLaunchKernelGGL(k_post_public, dim3(grid), dim3(kBlock), 0, s_->st, r, ncols, ag.public_cols.p, s_->Xg.p, dst,
+                       arrive_.p + a, flag, q);
+    bytes_posted += 8.0 * N * dst.n;
+    ++posts;
+  }
+  DCORA_HIP(hipGetLastError());
+  post_s += since(t0);
+  return DCORA_OK;
+}
+
+int Exchange::wait(const int *agents, int count) {
+  const auto t0 = Clock::now();
+  DCORA_HIP(hipSetDevice(s_->opt.device));
+  const int R = s_->R, r = s_->r, dh = s_->d + 1;
+  for (int i = 0; i < count; ++i) {
+    const int a = agents[i];
+    if (a < 0 || a >= R) return fail("wait: agent out of range", DCORA_ERR_BAD_ARG);
+    if (!needed_[a] || s_->agents[a].public_poses.empty()) continue;
+    const uint64_t want = seq_[a];
+    const int parity = (int)(want & 1);
+    const ShmFlag *f = flags_ + (size_t)parity * R + a;
+    unsigned spins = 0;
+    const auto w0 = Clock::now();
+    while (f->seq < want) {
+      if ((++spins & 4095u) == 0) {
+        if (hdr_->failed.load()) return fail("another rank failed", DCORA_ERR_HIP);
+        if (since(w0) > 120.0) return fail("public poses of agent " + std::to_string(a) + " never arrived", DCORA_ERR_HIP);
+      }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    const double *src = (mode == kExchangeIpc) ? halo_.p + halo_off(parity, a)
+                                               : (const double *)(dev_map_ + off_staged_) + halo_off(parity, a);
+    // updateNeighborStates: into the local mirror of X
+    launch_scatter_cols(s_->st, r, (int)s_->agents[a].public_poses.size() * dh, s_->agents[a].public_cols.p, src,
+                        s_->Xg.p);
+    ++waits;
+  }
+  wait_s += since(t0);
+  return DCORA_OK;
+}
+
+// distributed form of the central evaluation (ref examples/MultiRobotExample.cpp:264-305): every rank evaluates the
+// agents it hosts against the neighbours' public poses it holds, publishes two scalars per agent, reads everybody's
+int Exchange::evaluate(double *cost2, double *gradnorm, double *block_norms, int *next_selected) {
+  const int R = s_->R;
+  int rc = s_->phase_evaluate_dev(evalbuf_.p);
+  if (rc) return rc;
+  const uint64_t want = ++eval_seq_;
+  const int parity = (int)(want & 1);
+  ShmEval *slots_dev = (ShmEval *)(dev_map_ + off_evals_) + (size_t)parity * R;
+  if (n_hosted_)
+    hipLaunchKernelGGL(k_eval_publish, dim3(1), dim3(64), 0, s_->st, n_hosted_, hosted_list_.p, evalbuf_.p, slots_dev,
+                       want);
+  DCORA_HIP(hipGetLastError());
+  const auto t0 = Clock::now();
+  const ShmEval *sl = evals_ + (size_t)parity * R;
+  double g2 = 0, c2 = 0, best = -1;
+  int arg = 0;
+  for (int a = 0; a < R; ++a) {
+    unsigned spins = 0;
+    while (sl[a].seq < want) {
+      if ((++spins & 4095u) == 0) {
+        if (hdr_->failed.load()) return fail("another rank failed", DCORA_ERR_HIP);
+        if (since(t0) > 120.0) return fail("evaluation of agent " + std::to_string(a) + " never arrived", DCORA_ERR_HIP);
+      }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    const double ga = sl[a].g2, xa = sl[a].xeg;
+    const double nb = std::sqrt(ga);
+    if (block_norms) block_norms[a] = nb;
+    g2 += ga;
+    c2 += xa;  // 2 f = sum_b <X_b, X_b Q_bb + G_b>
+    if (nb > best) {
+      best = nb;
+      arg = a;
+    }
+  }
+  eval_wait_s += since(t0);
+  ++evals;
+  if (cost2) *cost2 = c2;
+  if (gradnorm) *gradnorm = std::sqrt(g2);
+  if (next_selected) *next_selected = arg;
+  return DCORA_OK;
+}
+
+// one pass of the reference driver's loop body (examples/MultiRobotExample.cpp:223-307) across the ranks
+int Exchange::rbcd_iterate(int selected, double *cost2, double *gradnorm, double *block_norms, int *next_selected) {
+  const int R = s_->R;
+  if (selected < 0 || selected >= R) return fail("selected agent out of range", DCORA_ERR_BAD_ARG);
+  std::vector<int> others;
+  for (int a = 0; a < R; ++a)
+    if (a != selected) others.push_back(a);
+  int rc = s_->phase_nonselected(selected);  // Agent::iterate(false) of the hosted non-selected agents
+  if (rc) return rc;
+  rc = post(others.data(), (int)others.size());
+  if (rc) return rc;
+  rc = wait(others.data(), (int)others.size());  // the selected agent's pull (and everybody's for the evaluation)
+  if (rc) return rc;
+  rc = s_->phase_selected(selected);  // Agent::iterate(true) where the selected agent lives
+  if (rc) return rc;
+  rc = post(&selected, 1);
+  if (rc) return rc;
+  rc = wait(&selected, 1);
+  if (rc) return rc;
+  int nxt = selected;
+  rc = evaluate(cost2, gradnorm, block_norms, &nxt);
+  if (rc) return rc;
+  if (next_selected) *next_selected = s_->agents[selected].neighbors.empty() ? selected : nxt;
+  return DCORA_OK;
+}
+
+int Exchange::rbcd_tick(const int *set, int count, int allow_adjacent) {
+  int rc = s_->iterate_set(set, count, allow_adjacent);
+  if (rc) return rc;
+  rc = post(set, count);
+  if (rc) return rc;
+  return wait(set, count);
+}
+
+int Exchange::set_X(const double *Xh) {
+  int rc = barrier();
+  if (rc) return rc;
+  rc = s_->set_X(Xh);
+  if (rc) return rc;
+  return barrier();
+}
+
+// every rank's hosted blocks -> the shared segment -> every rank's copy of the whole X
+int Exchange::gather_X(double *Xh) {
+  DCORA_HIP(hipSetDevice(s_->opt.device));
+  const int r = s_->r, dh = s_->d + 1;
+  for (const AgentDev &a : s_->agents) {
+    if (!a.hosted) continue;
+    const size_t off = (size_t)a.col0 * r;
+    DCORA_HIP(hipMemcpyAsync(xarea_ + off, s_->Xg.p + off, sizeof(double) * (size_t)r * dh * a.n, hipMemcpyDeviceToHost,
+                             s_->st));
+  }
+  DCORA_HIP(hipStreamSynchronize(s_->st));
+  int rc = barrier();
+  if (rc) return rc;
+  std::memcpy(Xh, xarea_, sizeof(double) * (size_t)r * dh * s_->n);
+  return barrier();
+}
+
+}  // namespace dcora

@@ -157,6 +157,10 @@ __device__ __forceinline__ void row_polar(Row<D> &A, bool live) {
   for (int a = 0; a < D; ++a)
 #pragma unroll
     for (int b = 0; b < D; ++b) Vm[a][b] = (a == b) ? 1.0 : 0.0;
+  // The sweep loop is wave-uniform (the group sums are cross-lane operations), but a pose stops rotating once ITS
+  // sweep has converged: the result of a pose must not depend on which poses share its wave (a launch over one
+  // agent's poses and a launch over the whole graph place a pose next to different neighbours).
+  bool settled = !live;
   for (int sweep = 0; sweep < 40; ++sweep) {
     double off = 0;
 #pragma unroll
@@ -167,7 +171,7 @@ __device__ __forceinline__ void row_polar(Row<D> &A, bool live) {
         const double aqq = grp_sum(A.e[q] * A.e[q]);
         const double apq = grp_sum(A.e[p] * A.e[q]);
         const double sc = sqrt(app * aqq);
-        if (fabs(apq) > 1e-16 * sc && fabs(apq) > 1e-300) {
+        if (!settled && fabs(apq) > 1e-16 * sc && fabs(apq) > 1e-300) {
           off = fmax(off, fabs(apq) / sc);
           const double zeta = (aqq - app) / (2.0 * apq);
           const double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
@@ -183,7 +187,8 @@ __device__ __forceinline__ void row_polar(Row<D> &A, bool live) {
           }
         }
       }
-    if (__all(!live || off < 1e-15)) break;
+    settled = settled || off < 1e-15;
+    if (__all(settled)) break;
   }
   double u[D];
 #pragma unroll

@@ -270,6 +270,47 @@ int dcora_rbcd_phase_evaluate_dev(dcora_rbcd_t s, double *out_dev);
 int dcora_rbcd_synchronize(dcora_rbcd_t s);
 
 /* ------------------------------------------------------------------------- *
+ * Neighbour exchange between the ranks of one node (one process per GPU): the transport the reference leaves to its
+ * host -- Agent::getSharedStateDicts on the sender, Agent::updateNeighborStates on the receiver (ref src/Agent.cpp:
+ * 113-152, 844-906), moved by the driver (ref examples/MultiRobotExample.cpp:236-258).  An exchange belongs to a
+ * session created with rank / world_size; every rank of the job creates one under the same job name (unique per job
+ * on the node: it names a POSIX shared-memory segment that carries the bootstrap, the flag words and the evaluation
+ * scalars).  Pose data moves by direct stores into the halo buffer of each rank that hosts a NEIGHBOUR of the posting
+ * agent (peer memory mapped through HIP IPC, xGMI between GPUs); there is no collective on the data path.  If the IPC
+ * transport is not usable on some rank, all ranks stage the packed poses in the shared host segment instead
+ * (dcora_exchange_info reports which).  All calls are SPMD: every rank makes the same calls with the same agent lists.
+ * ------------------------------------------------------------------------- */
+typedef struct dcora_exchange_s *dcora_exchange_t;
+int dcora_exchange_create(dcora_rbcd_t s, const char *job_name, dcora_exchange_t *out);
+int dcora_exchange_destroy(dcora_exchange_t ex);
+/* info[8] = {transport (1 = IPC peer stores, 2 = shared host segment), ranks this rank stores to, posts, waits,
+ * bytes posted so far, host seconds in post, host seconds in wait, host seconds waiting for the evaluation scalars} */
+int dcora_exchange_info(dcora_exchange_t ex, double *info8);
+/* getSharedStateDicts of `agents`: each hosted one is written to its neighbours' ranks and flagged (one kernel per
+ * agent on the session's stream; returns without synchronising) */
+int dcora_exchange_post(dcora_exchange_t ex, const int *agents, int count);
+/* updateNeighborStates: waits until the posts of those of `agents` that neighbour an agent hosted here have
+ * arrived and scatters them into the session's mirror of X (enqueued on the session's stream) */
+int dcora_exchange_wait(dcora_exchange_t ex, const int *agents, int count);
+/* the driver's evaluation (ref examples/MultiRobotExample.cpp:264-305) without a central copy of X: every rank
+ * evaluates |Proj(X_b Q_bb + G_b)| and <X_b, X_b Q_bb + G_b> of its agents, 2 R scalars are all-gathered through
+ * the shared segment; same outputs as dcora_rbcd_evaluate, identical on every rank */
+int dcora_exchange_evaluate(dcora_exchange_t ex, double *cost2, double *gradnorm, double *block_norms,
+                            int *next_selected);
+/* dcora_rbcd_iterate across the ranks: non-selected updates, post + wait, the selected agent's solve on its rank,
+ * post + wait of its new public poses, evaluation */
+int dcora_exchange_rbcd_iterate(dcora_exchange_t ex, int selected, double *cost2, double *gradnorm,
+                                double *block_norms, int *next_selected);
+/* dcora_rbcd_iterate_set across the ranks, followed by post + wait of the updated agents */
+int dcora_exchange_rbcd_tick(dcora_exchange_t ex, const int *set, int count, int allow_adjacent);
+/* dcora_rbcd_set_X on every rank between two barriers; dcora_rbcd_get_X of the whole X assembled from the ranks that
+ * host each block (collective; X is valid on every rank) */
+int dcora_exchange_set_X(dcora_exchange_t ex, const double *X);
+int dcora_exchange_gather_X(dcora_exchange_t ex, double *X);
+/* host barrier over the ranks of the job (does not synchronise the device) */
+int dcora_exchange_barrier(dcora_exchange_t ex);
+
+/* ------------------------------------------------------------------------- *
  * RBCD session for multi-robot range-aided SLAM (replaces the Agents on a RangeAidedSLAMGraph and the loop body of
  * examples/MultiRobotExample_RASLAM.cpp; ref src/Agent.cpp:535-596, 1158-1278, src/Graph.cpp:824-1772).
  * Agents = the robots of the pyfg file that own poses, in id order; variables are owned as the reference assigns
@@ -381,6 +422,12 @@ int dcora_round_project_solution_raslam(const dcora_dims *dims, const double *X,
 /* times `reps` launches of the Q-apply kernel Y = X Q + G of a problem with HIP events on the handle's
  * stream; returns average milliseconds per launch and the algorithmic bytes of one launch */
 int dcora_problem_time_qapply(dcora_problem_t p, int reps, double *avg_ms, double *algorithmic_bytes);
+/* the same kernel over `count` problems in turn on one stream: distinct (Q, X, Y) sets, so that with more than 256 MiB
+ * between two uses of a set every launch streams from HBM instead of the Infinity Cache */
+int dcora_problem_time_qapply_rotating(const dcora_problem_t *problems, int count, int reps, double *avg_ms);
+/* which Q-apply kernel the problem runs: info[0] = 0 k_spmm (CSR), 1 k_spmm_bsr (block-CSR, pose graphs with
+ * n >= 8192); info[1] = nnz(Q); info[2] = matrix blocks (block-CSR); info[3] = bytes of the stored matrix form */
+int dcora_problem_qapply_info(dcora_problem_t p, double *info4);
 /* same for the preconditioner application kernel z = Proj_X(r (Q + reg I)^-1) (dense-inverse streaming part) */
 int dcora_problem_time_precond(dcora_problem_t p, int reps, double *avg_ms, double *algorithmic_bytes);
 /* how the preconditioner (Q + reg I)^-1 of ref src/Graph.cpp:1901-1917 is held on the device:

@@ -264,6 +264,7 @@ struct RBCDOptions {
 struct RBCDTrace {
   std::vector<double> cost, gradnorm;  // per iteration (2f and |rgrad|, as printed :278-281)
   std::vector<int> selected, rank;
+  std::vector<double> seconds;  // loop time (this run's clock, staircase set-up excluded) at the end of each iteration
   int total_iters = 0;
   int final_rank = 0;
   int certified = 0;

@@ -405,6 +405,10 @@ void orc_trace_copy(void *h, double *cost, double *gradnorm, int *selected, int 
   std::copy(t->rank.begin(), t->rank.end(), rank);
   if (Xfinal) std::copy(t->Xfinal.a.begin(), t->Xfinal.a.end(), Xfinal);
 }
+void orc_trace_seconds(void *h, double *seconds) {
+  RBCDTrace *t = (RBCDTrace *)h;
+  std::copy(t->seconds.begin(), t->seconds.end(), seconds);
+}
 void orc_trace_free(void *h) { delete (RBCDTrace *)h; }
 
 // ---- robust estimation ------------------------------------------------------------------------------------------------

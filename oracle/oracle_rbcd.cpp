@@ -209,6 +209,7 @@ RBCDTrace run_rbcd(const Dataset &ds, const RBCDOptions &o, const Mat &X0) {
       tr.gradnorm.push_back(gn);
       tr.selected.push_back(selected);
       tr.rank.push_back(r);
+      tr.seconds.push_back(tr.rbcd_seconds + secs(tl0, clk::now()));
       if (o.verbose) std::printf("Iter = %d | robot = %d | cost = %.6f | gradnorm = %.6f\n", totalIter, selected, cost2, gn);
       if (gn < o.rgrad_tol) break;
       // greedy selection (:289-305); every agent here has neighbours

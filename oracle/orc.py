@@ -96,6 +96,7 @@ def lib():
         L.orc_trace_info.argtypes = [C.c_void_p, _dp]
         L.orc_trace_copy.argtypes = [C.c_void_p, _dp, _dp, _ip, _ip, C.c_void_p]
         L.orc_trace_free.argtypes = [C.c_void_p]
+        L.orc_trace_seconds.argtypes = [C.c_void_p, _dp]
         _lib = L
     return _lib
 
@@ -332,11 +333,13 @@ def run_rbcd(ds, X0, num_robots=5, r_min=5, r_max=100, max_iters=1000, min_eig_t
     k = (ds.d + 1) * ds.n
     Xf = np.zeros(rfin * k)
     L.orc_trace_copy(t, cost, gn, sel, rk, Xf.ctypes.data_as(C.c_void_p))
+    secs = np.zeros(it)
+    L.orc_trace_seconds(t, secs)
     L.orc_trace_free(t)
     L.orc_ds_free(h)
     return dict(total_iters=it, final_rank=rfin, certified=int(info[2]), theta=info[3], lambda_min=info[4],
                 rbcd_seconds=info[5], cert_seconds=info[6], setup_seconds=info[7], cost=cost, gradnorm=gn,
-                selected=sel, rank=rk, X=unF(Xf, rfin, k))
+                selected=sel, rank=rk, X=unF(Xf, rfin, k), seconds=secs)
 
 
 class RADataset:

@@ -1,0 +1,55 @@
+"""one rank of a multi-process RBCD run through the library's neighbour exchange (dcora_exchange_*); started by
+tests/test_exchange_gpu.py and by nothing else.  argv: rank world job dataset R r iters out_dir mode"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+
+
+def main():
+    rank, world = int(sys.argv[1]), int(sys.argv[2])
+    job, name = sys.argv[3], sys.argv[4]
+    R, r, iters = int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7])
+    out_dir, mode = sys.argv[8], sys.argv[9]
+    import common
+    import dcora_amd as da
+    ds = common.product_dataset(name)
+    X0 = np.load(os.path.join(out_dir, "X0.npy"))
+    accel = mode == "greedy"
+    s = da.RbcdSession(ds, num_robots=R, r=r, acceleration=accel, rank=rank, world_size=world, device=0)
+    ex = da.Exchange(s, job)
+    ex.set_X(X0)
+    cost, gn, sel = [], [], []
+    if mode == "greedy":
+        selected = 0
+        for _ in range(iters):
+            c2, g, bn, nxt = ex.iterate(selected)
+            cost.append(c2)
+            gn.append(g)
+            sel.append(selected)
+            selected = nxt
+    else:  # coloured ticks, one evaluation per sweep
+        col, nc = s.colours()
+        for _ in range(iters):
+            for c in range(nc):
+                ex.tick(np.flatnonzero(col == c).astype(np.int32))
+            c2, g, bn, nxt = ex.evaluate()
+            cost.append(c2)
+            gn.append(g)
+            sel.append(nxt)
+    X = ex.gather_X()
+    info = ex.info()
+    ex.barrier()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), cost=np.array(cost), gradnorm=np.array(gn),
+             selected=np.array(sel), X=X, mode=info["mode"], posts=info["posts"], waits=info["waits"],
+             bytes_posted=info["bytes_posted"], peers=info["peers"])
+    ex.close()
+    s.close()
+
+
+if __name__ == "__main__":
+    main()

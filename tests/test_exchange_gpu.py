@@ -1,0 +1,189 @@
+"""The multi-rank product path on ONE GPU: several processes (one per rank, all on device 0) run the RBCD loop through
+the library's neighbour exchange (dcora_exchange_*: IPC peer stores or the shared host segment, flag words, the
+evaluation all-gather) and must reproduce the single-session run -- the iterates bit for bit, the costs to rounding
+(the evaluation sums per agent instead of centrally).  ref examples/MultiRobotExample.cpp:223-307,
+src/Agent.cpp:113-152, 844-906."""
+import os
+import subprocess
+import sys
+import uuid
+
+import numpy as np
+import pytest
+
+import common
+
+pytestmark = pytest.mark.gpu
+
+WORKER = os.path.join(common.HERE, "exchange_worker.py")
+
+
+def run_ranks(tmp_path, world, name, R, r, iters, mode, X0, transport=None):
+    np.save(os.path.join(tmp_path, "X0.npy"), X0)
+    job = "t%s" % uuid.uuid4().hex[:12]
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    if transport:
+        env["DCORA_EXCHANGE"] = transport
+    else:
+        env.pop("DCORA_EXCHANGE", None)
+    procs = [subprocess.Popen([sys.executable, WORKER, str(k), str(world), job, name, str(R), str(r), str(iters),
+                               str(tmp_path), mode], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for k in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o.decode(errors="replace"))
+    for k, p in enumerate(procs):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (k, outs[k][-3000:])
+    return [np.load(os.path.join(tmp_path, "rank%d.npz" % k)) for k in range(world)]
+
+
+def single(da, ds, R, r, iters, mode, X0):
+    s = da.RbcdSession(ds, num_robots=R, r=r, acceleration=(mode == "greedy"))
+    s.set_X(X0)
+    if mode == "greedy":
+        out = s.run(max_iters=iters, rgrad_tol=0.0)
+        cost, gn, sel = out["cost"], out["gradnorm"], out["selected"]
+    else:
+        col, nc = s.colours()
+        cost, gn, sel = [], [], []
+        for _ in range(iters):
+            for c in range(nc):
+                s.iterate_set(np.flatnonzero(col == c).astype(np.int32))
+            c2, g, bn, nxt = s.evaluate()
+            cost.append(c2)
+            gn.append(g)
+            sel.append(nxt)
+    X = s.get_X()
+    s.close()
+    return np.asarray(cost), np.asarray(gn), np.asarray(sel), X
+
+
+CASES = [
+    # dataset, agents, ranks, iterations, mode, transport
+    ("sphere2500", 5, 2, 40, "greedy", None),        # restart round (30) inside
+    ("sphere2500", 5, 4, 12, "greedy", "staged"),    # rank 3 hosts no agent; shared-host-segment transport
+    ("torus3D", 8, 4, 10, "greedy", None),           # BASELINE config 3's split, two agents per rank
+    ("torus3D", 8, 2, 4, "coloured", None),          # simultaneous updates of one colour, then post + wait
+]
+
+
+@pytest.mark.parametrize("name,R,world,iters,mode,transport", CASES)
+def test_ranks_reproduce_single_session(tmp_path, name, R, world, iters, mode, transport):
+    import dcora_amd as da
+    ds = common.product_dataset(name)
+    r = 5
+    X0 = common.random_point(r, ds.d, ds.n, 11, lambda r_, d_, n_, M: da.manifold_project(r_, d_, n_, M))
+    cost, gn, sel, X = single(da, ds, R, r, iters, mode, X0)
+    res = run_ranks(str(tmp_path), world, name, R, r, iters, mode, X0, transport)
+    want_mode = 2 if transport == "staged" else 1
+    for k, o in enumerate(res):
+        assert int(o["mode"]) == want_mode, "rank %d used transport %d" % (k, int(o["mode"]))
+        assert np.array_equal(o["selected"], sel), (k, o["selected"], sel)
+        assert np.allclose(o["cost"], cost, rtol=1e-11, atol=0), (k, np.max(np.abs(o["cost"] - cost) / np.abs(cost)))
+        assert np.allclose(o["gradnorm"], gn, rtol=1e-9, atol=0)
+        assert np.array_equal(o["X"], X), "rank %d: iterates differ from the single session (max %g)" % (
+            k, np.max(np.abs(o["X"] - X)))
+        # every rank reads the same evaluation scalars: identical traces on all of them
+        assert np.array_equal(o["cost"], res[0]["cost"]) and np.array_equal(o["gradnorm"], res[0]["gradnorm"])
+    # neighbour-only traffic: ranks that host agents post, and only to ranks hosting their neighbours
+    assert sum(int(o["posts"]) for o in res) > 0
+    assert all(int(o["peers"]) <= world - 1 for o in res)
+
+
+class Hip:
+    """the few HIP runtime calls the in-process transport below needs, from the runtime the library already loaded"""
+
+    def __init__(self):
+        import ctypes as C
+        self.C = C
+        self.rt = C.CDLL("libamdhip64.so")
+        self.rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self.rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.rt.hipFree.argtypes = [C.c_void_p]
+
+    def malloc(self, nbytes):
+        p = self.C.c_void_p()
+        assert self.rt.hipMalloc(self.C.byref(p), nbytes) == 0
+        return p.value
+
+    def d2d(self, dst, src, nbytes):
+        assert self.rt.hipMemcpy(dst, src, nbytes, 3) == 0
+
+    def d2h(self, dst_np, src, nbytes):
+        assert self.rt.hipMemcpy(dst_np.ctypes.data, src, nbytes, 2) == 0
+
+    def free(self, p):
+        self.rt.hipFree(p)
+
+
+def test_two_sessions_pack_unpack_one_process():
+    """rank 0 / rank 1 sessions of world_size 2 in ONE process: pack_public_dev -> device-to-device copy ->
+    unpack_public_dev between the phases reproduces the single session bit for bit (the pieces a host with its own
+    transport would use)"""
+    import dcora_amd as da
+    name, R, r, iters = "sphere2500", 5, 5, 35
+    ds = common.product_dataset(name)
+    X0 = common.random_point(r, ds.d, ds.n, 5, lambda r_, d_, n_, M: da.manifold_project(r_, d_, n_, M))
+    cost, gn, sel, X = single(da, ds, R, r, iters, "greedy", X0)
+    world = 2
+    ss = [da.RbcdSession(ds, num_robots=R, r=r, rank=k, world_size=world) for k in range(world)]
+    per = (R + world - 1) // world
+    owner = [a // per for a in range(R)]
+    dh = ds.d + 1
+    slot = 8 * r * dh * max(ss[0].public_count(a) for a in range(R))
+    hip = Hip()
+    send, recv = hip.malloc(slot), hip.malloc(slot)
+    evs = [hip.malloc(16 * R) for _ in range(world)]
+    for s in ss:
+        s.set_X(X0)
+
+    def move(a):
+        src = ss[owner[a]]
+        src.pack_public_dev(a, send)
+        src.synchronize()
+        hip.d2d(recv, send, slot)  # the device-to-device copy a transport would make
+        for k, s in enumerate(ss):
+            if k != owner[a]:
+                s.unpack_public_dev(a, recv)
+                s.synchronize()
+
+    selected = 0
+    tr_cost, tr_sel = [], []
+    for _ in range(iters):
+        for s in ss:
+            s.phase_nonselected(selected)
+        for a in range(R):
+            if a != selected:
+                move(a)
+        for s in ss:
+            s.phase_selected(selected)
+        move(selected)
+        tot = np.zeros(2 * R)
+        for k, s in enumerate(ss):
+            s.phase_evaluate_dev(evs[k])
+            s.synchronize()
+            h = np.zeros(2 * R)
+            hip.d2h(h, evs[k], 16 * R)
+            tot += h
+        tr_cost.append(float(tot[1::2].sum()))
+        tr_sel.append(selected)
+        selected = int(np.argmax(np.sqrt(tot[0::2])))
+    assert np.array_equal(tr_sel, sel)
+    assert np.allclose(tr_cost, cost, rtol=1e-11, atol=0)
+    Xs = [s.get_X() for s in ss]
+    for a in range(R):
+        n_a = ds.n // R if a < R - 1 else ds.n - (R - 1) * (ds.n // R)
+        c0 = a * (ds.n // R) * dh
+        blk = slice(c0, c0 + n_a * dh)
+        assert np.array_equal(Xs[owner[a]][:, blk], X[:, blk]), "agent %d differs" % a
+    for s in ss:
+        s.close()
+    for p in [send, recv] + evs:
+        hip.free(p)
