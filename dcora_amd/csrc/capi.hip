@@ -713,6 +713,14 @@ int dcora_exchange_gather_X(dcora_exchange_t ex, double *X) {
   return ex->e.gather_X(X);
   DCORA_CATCH
 }
+int dcora_exchange_host_selftest(const char *job_name, int rank, int world_size, int num_agents, int rounds,
+                                 double *checksum) {
+  if (!job_name) return bad("null");
+  DCORA_TRY
+  Exchange e;
+  return e.host_selftest(job_name, rank, world_size, num_agents, rounds, checksum);
+  DCORA_CATCH
+}
 int dcora_exchange_barrier(dcora_exchange_t ex) {
   if (!ex) return bad("null");
   return ex->e.barrier();

@@ -213,6 +213,7 @@ class DeviceProblem {
  private:
   int rtr_dev(const dcora_ropt_params &prm, dcora_ropt_result *res, double **Xres);
   int rtr_dev_fused(const dcora_ropt_params &prm);
+  bool use_pc() const;
   int rgd_dev(const dcora_ropt_params &prm, dcora_ropt_result *res, double **Xres);
   int seq_ = 0;            // launch sequence number, monotonic across solves (HostFlags words are never reset)
   bool pending_ = false;   // a fused solve has been enqueued and its statistics not yet fetched

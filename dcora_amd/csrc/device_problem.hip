@@ -569,6 +569,17 @@ int DeviceProblem::rtr_dev(const dcora_ropt_params &prm, dcora_ropt_result *res_
 //   A (direction update + Q-apply + Riemannian Hessian correction + <d,Hd>)
 //   B (step length + vector updates + |r|^2 + dense preconditioner slices)
 //   C (stopping rule + slice sum + tangent projection + <z,r>)
+// B + C as one launch (k_fused_pc) where that form wins; DCORA_SOLVER_BC = pc / split forces one or the other
+bool DeviceProblem::use_pc() const {
+  static const int forced = [] {
+    const char *e = std::getenv("DCORA_SOLVER_BC");
+    return !e ? 0 : (std::strcmp(e, "split") == 0 ? -1 : (std::strcmp(e, "pc") == 0 ? 1 : 0));
+  }();
+  if (sparse_precond || !has_precond) return false;
+  if (forced) return forced > 0;
+  return fused_pc_preferred(m, ldm);
+}
+
 int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
   static const int kLookahead = std::getenv("DCORA_LOOKAHEAD") ? std::max(1, atoi(std::getenv("DCORA_LOOKAHEAD"))) : 2;
   const auto t0 = std::chrono::steady_clock::now();
@@ -605,6 +616,9 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
   const bool folded = sparse_precond && sp.foldable() && !no_fold;
   const SpFold sf = folded ? sp.fold() : SpFold{};
   const int nsl = sparse_precond ? 1 : -1;
+  // dense preconditioner: B and C are ONE launch (k_fused_pc); DCORA_SOLVER_BC=split keeps the three-launch form
+  const bool pc = use_pc();
+  const int nZ = pc ? fused_pc_blocks(m) : nPB;  // <z, r> partial slots A sums in its prologue
   double *dbuf[2] = {delta.p, delta2.p};
   double *rbuf[2] = {res.p, res2.p};
   auto timed_out = [&]() {
@@ -625,11 +639,18 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
     if (outer_done()) break;
     if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0) break;  // TimeBound :252
     // z0 = P(grad): B in "first" mode streams the preconditioner over grad, C projects and forms <z0, r0>
-    launch_fused_precond(st, m, ldm, Mi, RGb(), nullptr, nullptr, eta.p, Heta.p, nullptr, rbuf[0], Zpart.p,
-                         nullptr, 0, p2.p, c, hf_dev, ++seq, 0, 1, sf);
-    const int tcg_first_seq = seq;
-    if (sparse_precond) sp.apply(st, m.r, buf1(rbuf[0]), Zpart.p, Gate{c, ++seq, 1}, folded);
-    launch_fused_finish(st, m, Xb(), Zpart.p, rbuf[0], z.p, nullptr, 0, p3.p, c, hf_dev, ++seq, 0, 1, nsl, sf);
+    int tcg_first_seq;
+    if (pc) {
+      launch_fused_pc(st, m, ldm, Mi, RGb(), Xb(), nullptr, nullptr, eta.p, Heta.p, nullptr, rbuf[0], z.p, nullptr, 0,
+                      p3.p, c, hf_dev, ++seq, 0, 1);
+      tcg_first_seq = seq;
+    } else {
+      launch_fused_precond(st, m, ldm, Mi, RGb(), nullptr, nullptr, eta.p, Heta.p, nullptr, rbuf[0], Zpart.p,
+                           nullptr, 0, p2.p, c, hf_dev, ++seq, 0, 1, sf);
+      tcg_first_seq = seq;
+      if (sparse_precond) sp.apply(st, m.r, buf1(rbuf[0]), Zpart.p, Gate{c, ++seq, 1}, folded);
+      launch_fused_finish(st, m, Xb(), Zpart.p, rbuf[0], z.p, nullptr, 0, p3.p, c, hf_dev, ++seq, 0, 1, nsl, sf);
+    }
     for (int j = 0; j < max_inner; ++j) {
       if (j >= kLookahead) {
         const int need = fin_seq[j - kLookahead];
@@ -639,12 +660,18 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
       }
       if (hf->tcg_done_seq >= tcg_first_seq) break;
       const int par = j & 1;
-      const int nP1 = launch_fused_hess(st, m, Qv, z.p, dbuf[par ^ 1], dbuf[par], Xb(), Sb(), Hd.p, p3.p, nPB, p1.p,
+      const int nP1 = launch_fused_hess(st, m, Qv, z.p, dbuf[par ^ 1], dbuf[par], Xb(), Sb(), Hd.p, p3.p, nZ, p1.p,
                                         c, ++seq, j, has_bsr ? &Qbv : nullptr);
-      launch_fused_precond(st, m, ldm, Mi, RGb(), dbuf[par], Hd.p, eta.p, Heta.p, rbuf[par], rbuf[par ^ 1],
-                           Zpart.p, p1.p, nP1, p2.p, c, hf_dev, ++seq, j, 0, sf);
-      if (sparse_precond) sp.apply(st, m.r, buf1(rbuf[par ^ 1]), Zpart.p, Gate{c, ++seq, 2}, folded);
-      launch_fused_finish(st, m, Xb(), Zpart.p, rbuf[par ^ 1], z.p, p2.p, nPG, p3.p, c, hf_dev, ++seq, j, 0, nsl, sf);
+      if (pc) {
+        launch_fused_pc(st, m, ldm, Mi, RGb(), Xb(), dbuf[par], Hd.p, eta.p, Heta.p, rbuf[par], rbuf[par ^ 1], z.p,
+                        p1.p, nP1, p3.p, c, hf_dev, ++seq, j, 0);
+      } else {
+        launch_fused_precond(st, m, ldm, Mi, RGb(), dbuf[par], Hd.p, eta.p, Heta.p, rbuf[par], rbuf[par ^ 1],
+                             Zpart.p, p1.p, nP1, p2.p, c, hf_dev, ++seq, j, 0, sf);
+        if (sparse_precond) sp.apply(st, m.r, buf1(rbuf[par ^ 1]), Zpart.p, Gate{c, ++seq, 2}, folded);
+        launch_fused_finish(st, m, Xb(), Zpart.p, rbuf[par ^ 1], z.p, p2.p, nPG, p3.p, c, hf_dev, ++seq, j, 0, nsl,
+                            sf);
+      }
       fin_seq[j] = seq;
     }
     const int nR = enq_retract(Xb(), eta.p, 1.0, Xb(), 1, RGb(), Heta.p, pC.p, Gate{c, ++seq, 1});
@@ -754,13 +781,20 @@ int DeviceProblem::time_precond(int reps, double *avg_ms, double *bytes) {
   static const bool step_form = std::getenv("DCORA_TIME_PRECOND_FIRST") == nullptr;
   const int nPB = fused_pose_blocks(m);
   if (step_form && !sparse_precond) {
-    std::vector<double> ones((size_t)nPB, 1.0);
+    std::vector<double> ones(std::max((size_t)nPB, (size_t)nelem()), 1.0);
     DCORA_HIP(hipMemcpyAsync(p1.p, ones.data(), sizeof(double) * nPB, hipMemcpyHostToDevice, st));
+    // a non-zero residual, so that the one-launch form does not leave through its stopping rule
+    DCORA_HIP(hipMemcpyAsync(res.p, ones.data(), sizeof(double) * nelem(), hipMemcpyHostToDevice, st));
+    DCORA_HIP(hipMemsetAsync(Hd.p, 0, sizeof(double) * nelem(), st));
     DCORA_HIP(hipStreamSynchronize(st));
   }
+  const bool bc_split = !use_pc();
   auto run = [&]() {
     if (sparse_precond)
       sp.apply(st, m.r, buf1(RG0.p), Zt.p, Gate{});
+    else if (!bc_split)  // the one-launch B + C of the dense path, in its in-loop form
+      launch_fused_pc(st, m, ldm, Minv.p, RGb(), Xb(), delta.p, Hd.p, eta.p, Heta.p, res.p, res2.p, z.p, p1.p, nPB, p3.p,
+                      ctl.p, hf_dev, 1, 1, 0);
     else if (step_form)
       launch_fused_precond(st, m, ldm, Minv.p, RGb(), delta.p, Hd.p, eta.p, Heta.p, res.p, res2.p, Zpart.p, p1.p, nPB,
                            p2.p, ctl.p, hf_dev, 1, 1, 0);
@@ -779,7 +813,10 @@ int DeviceProblem::time_precond(int reps, double *avg_ms, double *bytes) {
   (void)hipEventDestroy(e1);
   *avg_ms = (double)ms / reps;
   // algorithmic bytes: the k x k inverse once, the residual in, the split-K slices out
+  // algorithmic bytes, dense form: the k x k inverse once; split form: + the residual in and the split-K slices out;
+  // one-launch form: + r_old, H delta in and eta, H eta, r, z through once (7 r k doubles)
   *bytes = sparse_precond ? sp.bytes_per_apply(m.r)
+           : !bc_split    ? 8.0 * m.k * (double)m.k + 7.0 * 8.0 * m.r * m.k
                           : 8.0 * m.k * (double)m.k + 8.0 * m.r * m.k + 8.0 * m.r * m.k * fused_nsplit(m);
   return DCORA_OK;
 }

@@ -62,6 +62,9 @@ class Exchange {
   int gather_X(double *Xh);
   // Agent::setX of every agent on every rank: sequence numbers restart with the Nesterov sequences
   int set_X(const double *Xh);
+  // host half of the protocol alone (bootstrap, barriers, flags, evaluation slots; host stores stand in for the
+  // device's): runs without a GPU, for the world-size-2 CPU test
+  int host_selftest(const char *job_name, int rank, int world, int R, int rounds, double *checksum);
 
   int mode = 0;
   int rank = 0, world = 1;
@@ -85,6 +88,7 @@ class Exchange {
   double *staged_ = nullptr;  // [parity][agent][slot]
   double *xarea_ = nullptr;   // r x (d+1) n
   size_t off_flags_ = 0, off_evals_ = 0, off_staged_ = 0, off_x_ = 0;
+  int R_ = 0;
   size_t slot_ = 0;                // doubles per agent slot
   DevBuf<double> halo_;            // [parity][agent][slot] + self-test area
   double *peer_halo_[kMaxRanks]{};  // IPC mappings (null for myself and for ranks I never write to)
@@ -99,8 +103,9 @@ class Exchange {
   std::vector<uint64_t> seq_;            // posts of agent a so far (identical on every rank)
   uint64_t eval_seq_ = 0;
 
-  size_t halo_off(int parity, int agent) const { return ((size_t)parity * s_->R + agent) * slot_; }
+  size_t halo_off(int parity, int agent) const { return ((size_t)parity * R_ + agent) * slot_; }
   int open_segment(const char *job_name, size_t bytes);
+  int map_segment(const char *job_name, size_t x_doubles);
   int setup_ipc(bool attempt);
   int fail(const std::string &msg, int code);
 };

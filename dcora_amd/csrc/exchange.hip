@@ -138,7 +138,7 @@ int Exchange::open_segment(const char *job_name, size_t bytes) {
   if (rank == 0) {
     std::memset(map_, 0, bytes);
     hdr_->world = (uint32_t)world;
-    hdr_->R = (uint32_t)s_->R;
+    hdr_->R = (uint32_t)R_;
     hdr_->slot_doubles = slot_;
     hdr_->total_bytes = bytes;
     hdr_->magic.store(kShmMagic, std::memory_order_release);
@@ -147,10 +147,37 @@ int Exchange::open_segment(const char *job_name, size_t bytes) {
       if (since(t0) > 120.0) return fail("segment " + name_ + " was never initialised", DCORA_ERR_IO);
       usleep(1000);
     }
-    if (hdr_->world != (uint32_t)world || hdr_->R != (uint32_t)s_->R || hdr_->slot_doubles != slot_ ||
+    if (hdr_->world != (uint32_t)world || hdr_->R != (uint32_t)R_ || hdr_->slot_doubles != slot_ ||
         hdr_->total_bytes != bytes)
       return fail("segment " + name_ + " belongs to a job of another shape (stale name?)", DCORA_ERR_BAD_ARG);
   }
+  return DCORA_OK;
+}
+
+// shared segment: header | per-rank records | flags [2][R] | evaluation slots [2][R] | staged poses [2][R][slot] | X
+int Exchange::map_segment(const char *job_name, size_t x_doubles) {
+  const int R = R_;
+  size_t off = align_up(sizeof(ShmHeader), 64);
+  const size_t off_ranks = off;
+  off += sizeof(ShmRank) * world;
+  off_flags_ = off;
+  off += sizeof(ShmFlag) * 2 * R;
+  off_evals_ = off;
+  off += sizeof(ShmEval) * 2 * R;
+  off = align_up(off, 4096);
+  off_staged_ = off;
+  off += sizeof(double) * 2 * R * slot_;
+  off = align_up(off, 4096);
+  off_x_ = off;
+  off += sizeof(double) * x_doubles;
+  const size_t total = align_up(off, 4096);
+  const int rc = open_segment(job_name, total);
+  if (rc) return rc;
+  ranks_ = (ShmRank *)((char *)map_ + off_ranks);
+  flags_ = (ShmFlag *)((char *)map_ + off_flags_);
+  evals_ = (ShmEval *)((char *)map_ + off_evals_);
+  staged_ = (double *)((char *)map_ + off_staged_);
+  xarea_ = (double *)((char *)map_ + off_x_);
   return DCORA_OK;
 }
 
@@ -178,6 +205,7 @@ int Exchange::init(RbcdSession *s, const char *job_name) {
   s_ = s;
   rank = s->opt.rank;
   world = s->opt.world_size;
+  R_ = s->R;
   const int R = s->R, dh = s->d + 1;
   if (world > kMaxRanks) return fail("too many ranks", DCORA_ERR_UNSUPPORTED);
   if (!job_name || !*job_name) return fail("empty job name", DCORA_ERR_BAD_ARG);
@@ -207,29 +235,8 @@ int Exchange::init(RbcdSession *s, const char *job_name) {
     if ((int)dests_[a].size() > kMaxDst) return fail("an agent has neighbours on more than 8 other ranks", DCORA_ERR_UNSUPPORTED);
   seq_.assign(R, 0);
 
-  // shared segment: header | per-rank records | flags [2][R] | evaluation slots [2][R] | staged poses [2][R][slot] | X
-  const size_t xd = (size_t)s->r * dh * s->n;
-  size_t off = align_up(sizeof(ShmHeader), 64);
-  const size_t off_ranks = off;
-  off += sizeof(ShmRank) * world;
-  off_flags_ = off;
-  off += sizeof(ShmFlag) * 2 * R;
-  off_evals_ = off;
-  off += sizeof(ShmEval) * 2 * R;
-  off = align_up(off, 4096);
-  off_staged_ = off;
-  off += sizeof(double) * 2 * R * slot_;
-  off = align_up(off, 4096);
-  off_x_ = off;
-  off += sizeof(double) * xd;
-  const size_t total = align_up(off, 4096);
-  int rc = open_segment(job_name, total);
+  int rc = map_segment(job_name, (size_t)s->r * dh * s->n);
   if (rc) return rc;
-  ranks_ = (ShmRank *)((char *)map_ + off_ranks);
-  flags_ = (ShmFlag *)((char *)map_ + off_flags_);
-  evals_ = (ShmEval *)((char *)map_ + off_evals_);
-  staged_ = (double *)((char *)map_ + off_staged_);
-  xarea_ = (double *)((char *)map_ + off_x_);
   {
     const hipError_t e = hipHostRegister(map_, map_bytes_, hipHostRegisterMapped | hipHostRegisterPortable);
     if (e != hipSuccess) return fail(std::string("hipHostRegister of the shared segment failed: ") + hipGetErrorString(e), DCORA_ERR_HIP);
@@ -253,8 +260,8 @@ int Exchange::init(RbcdSession *s, const char *job_name) {
     ok = rc == DCORA_OK;
   }
   ranks_[rank].ipc_ok.store(ok ? 1 : -1, std::memory_order_release);
-  rc = barrier();
-  if (rc) return rc;
+  int rc2 = barrier();
+  if (rc2) return rc2;
   bool all = true;
   for (int q = 0; q < world; ++q) all = all && ranks_[q].ipc_ok.load(std::memory_order_acquire) == 1;
   mode = all ? kExchangeIpc : kExchangeStaged;
@@ -503,6 +510,74 @@ int Exchange::gather_X(double *Xh) {
   int rc = barrier();
   if (rc) return rc;
   std::memcpy(Xh, xarea_, sizeof(double) * (size_t)r * dh * s_->n);
+  return barrier();
+}
+
+// The host half of the protocol on its own (no device): bootstrap through the segment, barriers, and `rounds` rounds
+// of post -> wait -> evaluation all-gather in which host stores stand in for the device's (same slots, same parity
+// double-buffering, same sequence numbers).  checksum is identical on every rank.
+int Exchange::host_selftest(const char *job_name, int rank_, int world_, int R, int rounds, double *checksum) {
+  rank = rank_;
+  world = world_;
+  R_ = R;
+  if (world < 1 || rank < 0 || rank >= world || world > kMaxRanks || R < 1 || R > kMaxAgents || rounds < 1)
+    return fail("host selftest: bad arguments", DCORA_ERR_BAD_ARG);
+  slot_ = 16;
+  int rc = map_segment(job_name, 16);
+  if (rc) return rc;
+  rc = barrier();
+  if (rc) return rc;
+  if (rank == 0) shm_unlink(name_.c_str());
+  const int per = (R + world - 1) / world;
+  double sum = 0;
+  for (int q = 1; q <= rounds; ++q) {
+    const int parity = q & 1;
+    for (int a = 0; a < R; ++a) {
+      if (a / per != rank) continue;
+      double *dst = staged_ + ((size_t)parity * R + a) * slot_;
+      for (size_t i = 0; i < slot_; ++i) dst[i] = 1000.0 * q + 16.0 * a + (double)i;
+      std::atomic_thread_fence(std::memory_order_release);
+      flags_[(size_t)parity * R + a].seq = (uint64_t)q;
+    }
+    const auto t0 = Clock::now();
+    for (int a = 0; a < R; ++a) {
+      const ShmFlag *f = flags_ + (size_t)parity * R + a;
+      unsigned spins = 0;
+      while (f->seq < (uint64_t)q) {
+        if ((++spins & 1023u) == 0) {
+          if (hdr_->failed.load()) return fail("another rank failed", DCORA_ERR_HIP);
+          if (since(t0) > 60.0) return fail("host selftest: a post never arrived", DCORA_ERR_HIP);
+          sched_yield();
+        }
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+      const double *src = staged_ + ((size_t)parity * R + a) * slot_;
+      for (size_t i = 0; i < slot_; ++i)
+        if (src[i] != 1000.0 * q + 16.0 * a + (double)i) return fail("host selftest: payload mismatch", DCORA_ERR_HIP);
+    }
+    for (int a = 0; a < R; ++a) {
+      if (a / per != rank) continue;
+      ShmEval *e = evals_ + (size_t)parity * R + a;
+      e->g2 = q + 0.5 * a;
+      e->xeg = q * 0.25 - a;
+      std::atomic_thread_fence(std::memory_order_release);
+      e->seq = (uint64_t)q;
+    }
+    for (int a = 0; a < R; ++a) {
+      const ShmEval *e = evals_ + (size_t)parity * R + a;
+      unsigned spins = 0;
+      while (e->seq < (uint64_t)q) {
+        if ((++spins & 1023u) == 0) {
+          if (hdr_->failed.load()) return fail("another rank failed", DCORA_ERR_HIP);
+          if (since(t0) > 60.0) return fail("host selftest: an evaluation never arrived", DCORA_ERR_HIP);
+          sched_yield();
+        }
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+      sum += e->g2 * (a + 1) + e->xeg;
+    }
+  }
+  if (checksum) *checksum = sum;
   return barrier();
 }
 

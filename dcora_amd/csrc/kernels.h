@@ -207,6 +207,13 @@ void launch_fused_precond(hipStream_t st, const ManiDesc &m, int ldm, const doub
                           const double *delta, const double *Hd, double *eta, double *Heta, const double *res_old,
                           double *res_new, double *Zpart, const double *p1, int np1, double *p2, SolverCtl *ctl,
                           HostFlags *hf, int seq, int iter, int first, SpFold sf = SpFold());
+// B + C in one launch (dense preconditioner): returns the number of <z, r> partial slots written to p3
+int fused_pc_blocks(const ManiDesc &m);
+bool fused_pc_preferred(const ManiDesc &m, int ldm);  // sizes at which it beats B + C
+int launch_fused_pc(hipStream_t st, const ManiDesc &m, int ldm, const double *Minv, Buf2 grad, Buf2 X,
+                    const double *delta, const double *Hd, double *eta, double *Heta, const double *res_old,
+                    double *res_new, double *z, const double *p1, int np1, double *p3, SolverCtl *ctl, HostFlags *hf,
+                    int seq, int iter, int first);
 void launch_fused_finish(hipStream_t st, const ManiDesc &m, Buf2 X, const double *Zpart, const double *res,
                          double *z, const double *p2, int np2, double *p3, SolverCtl *ctl, HostFlags *hf, int seq,
                          int iter, int first, int nsplit = -1 /* -1: fused_nsplit(m) */, SpFold sf = SpFold());

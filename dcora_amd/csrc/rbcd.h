@@ -14,6 +14,7 @@ namespace dcora {
 struct AgentDev {
   int id = 0, n = 0, col0 = 0;  // poses, first global column
   bool hosted = false;
+  bool v_feasible = false;  // V is the output of a projection since the agent's last setX
   std::unique_ptr<DeviceProblem> prob;  // Q_bb, (Q_bb + 0.1 I)^-1, solver workspace (hosted agents only)
   DevCsr coupling;                      // rows: local columns, cols: global columns (hosted agents only)
   std::vector<int> public_poses;        // global pose indices of my public poses (all agents)
@@ -76,6 +77,7 @@ class RbcdSession {
   bool seq_advanced_ = false;
   bool own_stream_ = true;
   bool pending_reset_ = false;  // gamma = alpha = 0 after a restart round, applied when the next round begins
+  std::vector<char> set_marks_;  // agents that received Agent::setX since the last round
   int update_nonselected_agent(AgentDev &a, bool restart);
   int update_selected_agent(AgentDev &a, bool restart);
   hipEvent_t fork_ev_ = nullptr;

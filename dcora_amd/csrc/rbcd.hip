@@ -63,6 +63,14 @@ int RbcdSession::init(const HostDataset &ds, const dcora_rbcd_options &o) {
     set_last_error("rbcd: bad num_robots / rank / world_size");
     return DCORA_ERR_BAD_ARG;
   }
+  if (o.acceleration && o.restart_interval < 1) {
+    set_last_error("rbcd: acceleration needs restart_interval >= 1 (AgentParameters::restartInterval)");
+    return DCORA_ERR_BAD_ARG;
+  }
+  if (r < d || r > 16) {
+    set_last_error("rbcd: relaxation rank must satisfy d <= r <= 16");
+    return DCORA_ERR_BAD_ARG;
+  }
   P.R = R;
   P.n = n;
   P.per = n / R;
@@ -187,6 +195,8 @@ int RbcdSession::set_X(const double *Xh) {
   seq_advanced_ = false;
   pending_reset_ = false;
   agent_it.assign(R, 0);
+  set_marks_.assign(R, 0);
+  for (AgentDev &a : agents) a.v_feasible = false;  // V = X as handed over: projected in the next round
   return DCORA_OK;
 }
 // initializeAcceleration / acceleration off for every agent (ref src/Agent.cpp:1178-1187)
@@ -202,6 +212,8 @@ int RbcdSession::set_acceleration(bool on) {
   seq_advanced_ = false;
   pending_reset_ = false;
   agent_it.assign(R, 0);
+  set_marks_.assign(R, 0);
+  for (AgentDev &a : agents) a.v_feasible = false;
   return DCORA_OK;
 }
 int RbcdSession::get_X(double *Xh) {
@@ -228,15 +240,27 @@ void RbcdSession::advance_sequences() {
 
 // Agent::iterate(false) for every hosted agent except `selected`
 int RbcdSession::phase_nonselected(int selected) {
+  if (selected < 0 || selected >= R) {
+    set_last_error("rbcd: selected agent out of range");
+    return DCORA_ERR_BAD_ARG;
+  }
   DCORA_HIP(hipSetDevice(opt.device));
   advance_sequences();
+  set_marks_.assign(R, 0);
   if (!opt.acceleration) return DCORA_OK;
-  // bit 1: after the first round every V is the output of a projection (or a copy of X): skip its re-projection
-  const int restart = (restart_now() ? 1 : 0) | (iteration > 1 ? 2 : 0);
+  // bit 1: after the first round every V is the output of a projection (or a copy of X): skip its re-projection.
+  // An Agent::setX of a single agent (which may hand over an X that is not exactly feasible) clears the flag until
+  // the next round has projected every V again.
+  bool all_feasible = true;
+  for (const AgentDev &a : agents)
+    if (a.id != selected) all_feasible = all_feasible && a.v_feasible;
+  const int restart = (restart_now() ? 1 : 0) | (all_feasible ? 2 : 0);
   if (opt.world_size == 1) {
     // one launch over the whole graph, skipping the selected agent's poses
     nesterov(st, mg, 0, restart, P.start(selected), P.end(selected), alpha, gamma, Xg.p, Vg.p, Yg.p, XPrevg.p, nullptr,
              Buf2{{nullptr, nullptr}}, nullptr);
+    for (AgentDev &a : agents)
+      if (a.id != selected) a.v_feasible = true;
   } else {
     for (AgentDev &a : agents) {
       if (!a.hosted || a.id == selected) continue;
@@ -249,13 +273,19 @@ int RbcdSession::phase_nonselected(int selected) {
 
 int RbcdSession::update_nonselected_agent(AgentDev &a, bool restart) {
   const size_t off = (size_t)a.col0 * r;
-  nesterov(st, a.prob->m, 0, (restart ? 1 : 0) | (iteration > 1 ? 2 : 0), -1, -1, alpha, gamma, Xg.p + off,
-           Vg.p + off, Yg.p + off, XPrevg.p + off, nullptr, Buf2{{nullptr, nullptr}}, nullptr);
+  // bit 1: V is known to be feasible (output of a projection since the agent's last setX): skip its re-projection
+  nesterov(st, a.prob->m, 0, (restart ? 1 : 0) | (a.v_feasible ? 2 : 0), -1, -1, alpha, gamma, Xg.p + off, Vg.p + off,
+           Yg.p + off, XPrevg.p + off, nullptr, Buf2{{nullptr, nullptr}}, nullptr);
+  a.v_feasible = true;
   return DCORA_OK;
 }
 
 // Agent::iterate(true) for `selected` when hosted here (ref src/Agent.cpp:535-551, 1158-1176, 1216-1278)
 int RbcdSession::phase_selected(int selected) {
+  if (selected < 0 || selected >= R) {
+    set_last_error("rbcd: selected agent out of range");
+    return DCORA_ERR_BAD_ARG;
+  }
   DCORA_HIP(hipSetDevice(opt.device));
   if (!seq_advanced_) advance_sequences();
   seq_advanced_ = false;
@@ -291,6 +321,7 @@ int RbcdSession::update_selected_agent(AgentDev &a, bool restart) {
       if (rc) return rc;
       nesterov(st, pb.m, 2, 0, -1, -1, alpha, gamma, Xg.p + off, Vg.p + off, Yg.p + off, XPrevg.p + off, nullptr, Xres,
                cs);
+      a.v_feasible = true;  // V = proj(V + gamma (X - Y))
       if (restart) {
         // restartNesterovAcceleration: X = XPrev; updateX(true, false); V = X; Y = X
         DCORA_HIP(hipMemcpyAsync(pb.X0.p, XPrevg.p + off, B, hipMemcpyDeviceToDevice, st));
@@ -332,6 +363,7 @@ int RbcdSession::agent_iterate(int agent, bool do_optimization) {
     return DCORA_ERR_BAD_ARG;
   }
   DCORA_HIP(hipSetDevice(opt.device));
+  set_marks_.assign(R, 0);
   // Agent::iteration_number() of every agent; between rounds they are all equal to the session's round counter
   // (also after the session-level calls, which advance whole rounds)
   bool level = (int)agent_it.size() == R;
@@ -394,6 +426,21 @@ int RbcdSession::agent_set_X(int agent, const double *Xh) {
   DCORA_HIP(hipMemcpyAsync(Yg.p + off, Xg.p + off, B, hipMemcpyDeviceToDevice, st));
   DCORA_HIP(hipMemcpyAsync(XPrevg.p + off, Xg.p + off, B, hipMemcpyDeviceToDevice, st));
   DCORA_HIP(hipStreamSynchronize(st));
+  // initializeAcceleration of this agent: its V is the X it was handed (not necessarily feasible) until the next
+  // projection; once EVERY agent has been set since the last round, the shared sequences restart as after set_X
+  agents[agent].v_feasible = false;
+  if ((int)set_marks_.size() != R) set_marks_.assign(R, 0);
+  set_marks_[agent] = 1;
+  bool all = true;
+  for (int q = 0; q < R; ++q) all = all && (set_marks_[q] || !agents[q].hosted);
+  if (all) {
+    gamma = alpha = 0;
+    iteration = 0;
+    seq_advanced_ = false;
+    pending_reset_ = false;
+    agent_it.assign(R, 0);
+    set_marks_.assign(R, 0);
+  }
   return DCORA_OK;
 }
 
@@ -578,6 +625,7 @@ int RbcdSession::iterate_set(const int *set, int count, int allow_adjacent) {
   DCORA_HIP(hipSetDevice(opt.device));
   iteration++;
   seq_advanced_ = false;
+  set_marks_.assign(R, 0);
   std::vector<AgentDev *> work;
   for (int i = 0; i < count; ++i)
     if (agents[set[i]].hosted) work.push_back(&agents[set[i]]);

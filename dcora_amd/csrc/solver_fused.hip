@@ -9,6 +9,8 @@
 // Every global reduction of the CG recurrence sits exactly on a kernel boundary, so an iteration costs three
 // dependent launches instead of six.  Per-pose arithmetic uses 8 lanes per pose: lane t
 // of a group owns row t of the pose's r x (d+1) block, d x d Gram matrices are reduced with 3 xor-shuffles.
+#include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 
 #include "kernels.h"
@@ -863,6 +865,319 @@ __global__ __launch_bounds__(kBlock) void k_fused_finish(ManiDesc m, int nsplit,
 // ------------------------------------------------------------------------------------------------------
 // group-style versions of the per-outer-iteration kernels (SE layout)
 // ------------------------------------------------------------------------------------------------------
+// B + C in ONE launch for the dense preconditioner (k <= 8000): no split-K, so no slice sum and no boundary between
+// the product and its projection.  A workgroup owns PB whole poses = PB (d+1) output columns of z.  By symmetry of
+// the inverse, column j of (Q + reg I)^-1 is row j: the workgroup streams its PB (d+1) rows (contiguous, 16-byte
+// loads, wave w takes rows w, w + 4, ...) against the WHOLE updated residual, which every workgroup rebuilds for
+// itself in LDS from r_old and H delta (2 r k doubles from L2 -- a quarter more bytes than the inverse itself, but
+// from the cache level with four times the bandwidth).  Because every workgroup holds the whole residual it also
+// knows |r|^2 (same summation order everywhere, bitwise the same value), so the stopping rule needs no kernel
+// boundary either.  Per tCG iteration: A, then this kernel -- two dependent launches instead of three.
+// ------------------------------------------------------------------------------------------------------
+// 16-byte buffer load: one descriptor (SGPRs) per array, per-lane byte offset in ONE VGPR, the uniform part of the
+// address in an SGPR -- instead of a 64-bit VGPR address per load in flight; out-of-range dwords read as zero
+typedef unsigned pc_v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double2 pc_ld16(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+  const pc_v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+  return __builtin_bit_cast(double2, v);
+}
+// sum over each 16-lane row, same value in the row's lanes (the DPP half of wave_sum_dpp)
+__device__ __forceinline__ double row16_sum_dpp(double v) {
+  v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_move<0x141>(v);  // row_half_mirror
+  v += dpp_move<0x140>(v);  // row_mirror
+  return v;
+}
+constexpr int kPcBlock = 256;  // 4 waves: wave w takes the 128-column steps w, w + 4, ... of ALL the workgroup's rows
+constexpr int kPcNW = kPcBlock / 64;
+constexpr int kPcSB = 25;      // 16-byte loads of each staged operand in flight per thread and batch
+constexpr int kPcLoads = 32;   // 16-byte loads of the inverse's rows in flight per lane and batch
+
+// R: the relaxation rank when it is known at compile time (no predication in the inner loops), 0 = run-time r <= 8.
+// MULTI: the residual does not fit one LDS chunk (k > chk): the loop over further chunks is compiled in.
+template <int D, int PB, int R, bool MULTI>
+__global__ __launch_bounds__(kPcBlock) void k_fused_pc(ManiDesc m, int ldm, int chk, const double *__restrict__ Minv,
+                                                       Buf2 gradb, Buf2 Xb, const double *__restrict__ delta,
+                                                       const double *__restrict__ Hd, double *__restrict__ eta,
+                                                       double *__restrict__ Heta, const double *__restrict__ res_old,
+                                                       double *__restrict__ res_new, double *__restrict__ z,
+                                                       const double *__restrict__ p1, int np1,
+                                                       double *__restrict__ p3, SolverCtl *ctl, HostFlags *hf, int seq,
+                                                       int iter, int first) {
+  constexpr int DH = D + 1, NR = PB * DH, RM = R ? R : 8;
+  constexpr int MB = kPcLoads / NR;  // steps of a wave per batch: MB * NR 16-byte loads of the inverse in flight
+  extern __shared__ double s_res[];  // the residual chunk, column-major as in memory: cpad * r doubles
+  __shared__ double s_P[NR * RM + 1][4 * kPcNW];  // row sums (16 lanes each) of the product columns and of |r|^2
+  __shared__ double s_Z[NR * RM + 1], s_R[NR * RM];
+  __shared__ double s_red[16];
+  const int par = iter & 1;
+  const int st_o = ctl->outer_done_stamp, st_t = ctl->tcg_done_stamp, cur = ctl->cur & 1;
+  const double c_zr = ctl->z_r[par], c_dPd = ctl->d_Pd[par], c_ePe = ctl->e_Pe[par], c_ePd = ctl->e_Pd[par],
+               c_Delta = ctl->Delta, c_ngf = ctl->ngf, c_n0 = ctl->norm_r0;
+  const int c_max_inner = ctl->max_inner;
+  const int r = R ? R : m.r, k = m.k;
+  const int pose0 = blockIdx.x * PB;
+  const int npose = min(PB, m.n - pose0);
+  const int j0 = pose0 * DH, nrow = npose * DH;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const double *__restrict__ rsrc = first ? gradb.p[cur] : res_old;
+  // ---- loads first, in the order their values are needed: the <d, H d> partials and the workgroup's own elements,
+  //      the first batch of the residual operands, the first batch of the inverse's rows.  None depends on the step
+  //      length: their latency overlaps the scalar prologue.
+  const int e = threadIdx.x;
+  const bool own = e < nrow * r;
+  const size_t oown = (size_t)j0 * r + e;
+  const int pi1 = (np1 <= 64) ? lane : (int)threadIdx.x;
+  double myp = (!first && pi1 < np1) ? p1[pi1] : 0.0;
+  double o_r = 0, o_h = 0, o_d = 0, o_eta = 0, o_Heta = 0;
+  if (own) {
+    o_r = rsrc[oown];
+    if (!first) {
+      o_h = Hd[oown];
+      o_d = delta[oown];
+      o_eta = eta[oown];
+      o_Heta = Heta[oown];
+    }
+  }
+  const int g = threadIdx.x >> 3, tt = threadIdx.x & (GW - 1);
+  const bool pact = (g < npose) && (tt < r);
+  const size_t o = (size_t)(pose0 + min(g, npose - 1)) * DH * r;
+  Row<D> Y;
+  ld_row<D>(Xb.p[cur] + o, r, tt, pact, Y);
+  const unsigned vec_bytes = (unsigned)((size_t)r * k * sizeof(double));
+  const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(rsrc), 0, vec_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_h =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(first ? rsrc : Hd), 0, vec_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<double *>(Minv), 0, (unsigned)((size_t)k * ldm * sizeof(double)), 0x00020000);
+  const unsigned voff_t = threadIdx.x * 16u, voff_l = (unsigned)lane * 16u;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  double2 xr0[kPcSB], xh0[kPcSB];
+#pragma unroll
+  for (int u = 0; u < kPcSB; ++u) {
+    xr0[u] = pc_ld16(rs_r, voff_t, (unsigned)u * kPcBlock * 16u);
+    if (!first) xh0[u] = pc_ld16(rs_h, voff_t, (unsigned)u * kPcBlock * 16u);
+  }
+  // row q of the workgroup, columns 2 lane, 2 lane + 1 of step (wave + kPcNW * u); rows past the last pose read the
+  // rows that follow (or zeros past the end of the matrix) and are never used
+  double2 pre[MB][NR];
+#pragma unroll
+  for (int u = 0; u < MB; ++u) {
+#pragma unroll
+    for (int q = 0; q < NR; ++q)
+      pre[u][q] = pc_ld16(rs_m, voff_l, (unsigned)(((size_t)(j0 + q) * ldm + (size_t)(wave_u + kPcNW * u) * 128) * 8));
+  }
+  asm volatile("" ::: "memory");
+  if (!first)
+    for (int i = threadIdx.x + kPcBlock; i < np1; i += kPcBlock) myp += p1[i];
+  if (seq > st_o || (!first && seq > st_t)) return;  // finished: no-op (uniform over the grid)
+  // ---- step length / trust-region boundary (ROPTLIB tCG_TR), as in B ----
+  double alpha = 0, step = 0;
+  bool boundary = false;
+  if (!first) {
+    const double d_Hd = (np1 <= 64) ? f_wave_sum(myp) : f_block_sum(myp, s_red);
+    alpha = c_zr / d_Hd;
+    const double e_Pe_new = c_ePe + 2.0 * alpha * c_ePd + alpha * alpha * c_dPd;
+    boundary = (d_Hd <= 0) || (e_Pe_new >= c_Delta * c_Delta);
+    step = boundary ? (-c_ePd + sqrt(c_ePd * c_ePd + c_dPd * (c_Delta * c_Delta - c_ePe))) / c_dPd : alpha;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      ctl->alpha = alpha;
+      ctl->e_Pe_n = e_Pe_new;
+      if (boundary) {
+        ctl->tcg_status = (d_Hd <= 0) ? 0 : 1;
+        ctl->tcg_iters = iter + 1;
+        ctl->inner_total += iter + 1;
+        ctl->tcg_done_stamp = seq;
+        f_host_store(&hf->tcg_done_seq, seq);
+      }
+    }
+  }
+  if (first && blockIdx.x == 0 && threadIdx.x == 0) {
+    ctl->norm_r0 = c_ngf;
+    ctl->tcg_status = 4;
+    ctl->tcg_iters = 0;
+    ctl->tcg_done_stamp = INT_MAX;
+  }
+  if (own) {
+    const int lc = e / r, t = e - lc * r;
+    if (first) {
+      eta[oown] = 0;
+      Heta[oown] = 0;
+      res_new[oown] = o_r;
+      s_R[lc * RM + t] = o_r;
+    } else {
+      eta[oown] = o_eta + step * o_d;
+      Heta[oown] = o_Heta + step * o_h;
+      if (!boundary) {
+        const double rr = o_r + alpha * o_h;
+        res_new[oown] = rr;
+        s_R[lc * RM + t] = rr;
+      }
+    }
+  }
+  if (boundary) return;
+  // ---- the whole updated residual through LDS, chunk by chunk; product with the workgroup's rows ----
+  double acc[NR][RM];
+#pragma unroll
+  for (int q = 0; q < NR; ++q)
+#pragma unroll
+    for (int t = 0; t < RM; ++t) acc[q][t] = 0;
+  double nrm2 = 0;
+  // one batch of staged operands into the LDS image: a straight copy of r_old + alpha H delta
+  auto stage = [&](const double2 (&xr)[kPcSB], const double2 (&xh)[kPcSB], int b0, int npair) {
+#pragma unroll
+    for (int u = 0; u < kPcSB; ++u) {
+      const int i = b0 + u * kPcBlock + (int)threadIdx.x;
+      if (i < npair) {
+        double2 x = xr[u];
+        if (!first) {
+          x.x = fma(alpha, xh[u].x, x.x);
+          x.y = fma(alpha, xh[u].y, x.y);
+        }
+        nrm2 = fma(x.x, x.x, nrm2);
+        nrm2 = fma(x.y, x.y, nrm2);
+        reinterpret_cast<double2 *>(s_res)[i] = x;
+      }
+    }
+  };
+  // the wave's steps of one batch: a lane's two columns of a step are 2 r contiguous doubles of the image
+  auto rows = [&](const double2 (&mm)[MB][NR], int u0, int nstep) {
+#pragma unroll
+    for (int u = 0; u < MB; ++u) {
+      const int sidx = wave_u + kPcNW * (u0 + u);
+      if (sidx < nstep) {
+        const double *__restrict__ xs = s_res + (size_t)(sidx * 128 + 2 * lane) * r;
+        double x0[RM], x1[RM];
+#pragma unroll
+        for (int t = 0; t < RM; ++t) {
+          x0[t] = (R || t < r) ? xs[t] : 0.0;
+          x1[t] = (R || t < r) ? xs[r + t] : 0.0;
+        }
+#pragma unroll
+        for (int t = 0; t < RM; ++t)
+#pragma unroll
+          for (int q = 0; q < NR; ++q) acc[q][t] = fma(x0[t], mm[u][q].x, fma(x1[t], mm[u][q].y, acc[q][t]));
+      }
+    }
+  };
+  // One chunk of the residual.  The first chunk consumes the loads requested before the prologue; it is written out
+  // as its own instance (FIRST = true) so that those registers are dead in the loop over the remaining chunks.
+  auto chunk = [&](int c0, auto first_chunk) {
+    constexpr bool FIRST = decltype(first_chunk)::value;
+    const int cn = min(chk, k - c0);
+    const int cpad = ((cn + 127) / 128) * 128;  // zero-filled up to whole 128-column steps
+    const long Nc = (long)cn * r;               // flat (column-major) length of the chunk: contiguous in memory
+    const int npair = (int)((Nc + 1) >> 1);     // an odd tail reads its missing half as zero (buffer bounds)
+    const unsigned cbase = (unsigned)((size_t)c0 * r * sizeof(double));
+    int b0 = 0;
+    if constexpr (FIRST) {
+      stage(xr0, xh0, 0, npair);
+      b0 = kPcSB * kPcBlock;
+    } else {
+      __syncthreads();
+    }
+#pragma unroll 1
+    for (; b0 < npair; b0 += kPcSB * kPcBlock) {
+      double2 xr[kPcSB], xh[kPcSB];
+#pragma unroll
+      for (int u = 0; u < kPcSB; ++u) {
+        xr[u] = pc_ld16(rs_r, voff_t, cbase + (unsigned)(b0 + u * kPcBlock) * 16u);
+        if (!first) xh[u] = pc_ld16(rs_h, voff_t, cbase + (unsigned)(b0 + u * kPcBlock) * 16u);
+      }
+      stage(xr, xh, b0, npair);
+    }
+    for (long i = 2L * npair + threadIdx.x; i < (long)cpad * r; i += kPcBlock) s_res[i] = 0.0;
+    __syncthreads();
+    const int nstep = cpad / 128;
+    const int nu = (nstep + kPcNW - 1) / kPcNW;  // steps per wave (at most)
+    int u0 = 0;
+    if constexpr (FIRST) {
+      rows(pre, 0, nstep);
+      u0 = MB;
+    }
+#pragma unroll 1
+    for (; u0 < nu; u0 += MB) {
+      double2 mm[MB][NR];
+#pragma unroll
+      for (int u = 0; u < MB; ++u) {
+#pragma unroll
+        for (int q = 0; q < NR; ++q)
+          mm[u][q] = pc_ld16(rs_m, voff_l,
+                             (unsigned)(((size_t)(j0 + q) * ldm + c0 + (size_t)(wave_u + kPcNW * (u0 + u)) * 128) * 8));
+      }
+      rows(mm, u0, nstep);
+    }
+  };
+  chunk(0, std::true_type{});
+  if constexpr (MULTI) {
+#pragma unroll 1
+    for (int c0 = chk; c0 < k; c0 += chk) chunk(c0, std::false_type{});
+  }
+  // ---- sums over the workgroup: every product column and |r|^2.  Four DPP steps give each 16-lane row its sum
+  //      (no lane reads, no LDS), one lane per row stores it, NR * RM + 1 threads add the 16 row sums in a fixed order
+#pragma unroll
+  for (int q = 0; q < NR; ++q)
+#pragma unroll
+    for (int t = 0; t < RM; ++t) {
+      const double v = row16_sum_dpp(acc[q][t]);
+      if ((lane & 15) == 0) s_P[q * RM + t][wave * 4 + (lane >> 4)] = v;
+    }
+  {
+    const double v = row16_sum_dpp(nrm2);
+    if ((lane & 15) == 0) s_P[NR * RM][wave * 4 + (lane >> 4)] = v;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x <= NR * RM) {
+    double v = 0;
+#pragma unroll
+    for (int w = 0; w < 4 * kPcNW; ++w) v += s_P[threadIdx.x][w];
+    s_Z[threadIdx.x] = v;
+  }
+  __syncthreads();
+  // ---- residual stopping rule: every workgroup holds |r|^2 itself (same summation order everywhere) ----
+  if (!first) {
+    const double nr = sqrt(s_Z[NR * RM]);
+    const double kappa = 0.1, tempnum = c_n0;  // theta = 1
+    if (nr <= c_n0 * fmin(tempnum, kappa)) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ctl->tcg_status = (kappa < tempnum) ? 2 : 3;
+        ctl->tcg_iters = iter + 1;
+        ctl->inner_total += iter + 1;
+        ctl->tcg_done_stamp = seq;
+        f_host_store(&hf->tcg_done_seq, seq);
+      }
+      return;
+    }
+  }
+  // ---- z = Proj_X(columns), partial <z, r>: the per-pose lanes all sit in wave 0 (PB <= 4 poses of 8 lanes) ----
+  if (wave == 0) {
+    Row<D> Zr, Rr;
+#pragma unroll
+    for (int a = 0; a < DH; ++a) {
+      Zr.e[a] = pact ? s_Z[(g * DH + a) * RM + tt] : 0.0;
+      Rr.e[a] = pact ? s_R[(g * DH + a) * RM + tt] : 0.0;
+    }
+    row_tangent<D>(Y, Zr);
+    st_row<D>(z + o, r, tt, pact, Zr);
+    double zacc = 0;
+#pragma unroll
+    for (int a = 0; a < DH; ++a) zacc += Zr.e[a] * Rr.e[a];
+    const double tot = f_wave_sum(zacc);
+    if (lane == 0) p3[blockIdx.x] = tot;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (!first && iter + 1 >= c_max_inner) {  // inner loop exhausted: status stays TR_MAXITER
+      ctl->tcg_iters = iter + 1;
+      ctl->inner_total += iter + 1;
+      ctl->tcg_done_stamp = seq;
+      f_host_store(&hf->tcg_done_seq, seq);
+    }
+    f_host_store(&hf->last_seq_done, seq);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // RG = Proj_X(EG), S_i = sym(Y_i^T EG_i), partial |RG|^2
 template <int D>
 __global__ __launch_bounds__(kBlock) void k_g_rgrad(ManiDesc m, Buf2 Xb, Buf2 EGb, Buf2 RGb, Buf2 Sb, int sel,
@@ -1320,6 +1635,66 @@ void launch_fused_precond(hipStream_t st, const ManiDesc &m, int ldm, const doub
     if (Minv) DCORA_LAUNCH_PRECOND(8, true); else DCORA_LAUNCH_PRECOND(8, false);
   }
 #undef DCORA_LAUNCH_PRECOND
+}
+// poses per workgroup of the one-launch B + C: about one workgroup per CU at the headline size
+int fused_pc_pb(const ManiDesc &m) { return m.n <= 768 ? 2 : 4; }
+int fused_pc_blocks(const ManiDesc &m) {
+  const int pb = fused_pc_pb(m);
+  return (m.n + pb - 1) / pb;
+}
+constexpr int kPcLdsCap = 128 * 1024;  // residual chunk in LDS: as many 128-column steps as fit (all of it at k = 2000)
+static int pc_chunk(const ManiDesc &m, int ldm) { return std::min((kPcLdsCap / (8 * m.r)) / 128 * 128, ldm); }
+// where the one-launch form wins (measured on MI355X, sphere2500 blocks): the whole residual in one LDS chunk and one
+// staging batch, r <= 7 -- k = 2000: 11.0 us against 11.3 + 5.1 us for B + C at r = 5, 13.4 / 17.6 at r = 6, 18.0 /
+// 18.6 at r = 7; beyond (k = 3332: 29.2 / 29.2, k = 5000: 76 / 48, r = 8: 21.0 / 20.0) the split form stays
+bool fused_pc_preferred(const ManiDesc &m, int ldm) {
+  return m.k <= pc_chunk(m, ldm) && (long)m.r * m.k <= 2L * kPcSB * kPcBlock && m.r <= 7;
+}
+template <int D, int PB, int R, bool MULTI>
+static int pc_launch(hipStream_t st, const ManiDesc &m, int ldm, const double *Minv, Buf2 grad, Buf2 X,
+                     const double *delta, const double *Hd, double *eta, double *Heta, const double *res_old,
+                     double *res_new, double *z, const double *p1, int np1, double *p3, SolverCtl *ctl, HostFlags *hf,
+                     int seq, int iter, int first) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    attr_set = true;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused_pc<D, PB, R, MULTI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kPcLdsCap) != hipSuccess)
+      (void)hipGetLastError();  // the launch below then fails loudly when the chunk needs more than the default
+  }
+  const int chk = pc_chunk(m, ldm);
+  const int grid = (m.n + PB - 1) / PB;
+  hipLaunchKernelGGL((k_fused_pc<D, PB, R, MULTI>), dim3(grid), dim3(kPcBlock), (size_t)chk * m.r * sizeof(double), st,
+                     m, ldm, chk, Minv, grad, X, delta, Hd, eta, Heta, res_old, res_new, z, p1, np1, p3, ctl, hf, seq,
+                     iter, first);
+  return grid;
+}
+int launch_fused_pc(hipStream_t st, const ManiDesc &m, int ldm, const double *Minv, Buf2 grad, Buf2 X,
+                    const double *delta, const double *Hd, double *eta, double *Heta, const double *res_old,
+                    double *res_new, double *z, const double *p1, int np1, double *p3, SolverCtl *ctl, HostFlags *hf,
+                    int seq, int iter, int first) {
+#define DCORA_PC(D_, PB_, R_, MULTI_)                                                                                \
+  return pc_launch<D_, PB_, R_, MULTI_>(st, m, ldm, Minv, grad, X, delta, Hd, eta, Heta, res_old, res_new, z, p1, np1, \
+                                        p3, ctl, hf, seq, iter, first)
+#define DCORA_PC_R(D_, PB_, MULTI_)             \
+  do {                                          \
+    if (D_ == 3 && m.r == 5) DCORA_PC(D_, PB_, 5, MULTI_); \
+    if (D_ == 3 && m.r == 6) DCORA_PC(D_, PB_, 6, MULTI_); \
+    if (D_ == 3 && m.r == 7) DCORA_PC(D_, PB_, 7, MULTI_); \
+    DCORA_PC(D_, PB_, 0, MULTI_);               \
+  } while (0)
+  const int pb = fused_pc_pb(m);
+  const bool multi = m.k > pc_chunk(m, ldm);
+  if (m.d == 3) {
+    if (pb == 2 && !multi) DCORA_PC_R(3, 2, false);
+    if (pb == 2) DCORA_PC_R(3, 2, true);
+    DCORA_PC_R(3, 4, true);
+  }
+  if (pb == 2 && !multi) DCORA_PC(2, 2, 0, false);
+  if (pb == 2) DCORA_PC(2, 2, 0, true);
+  DCORA_PC(2, 4, 0, true);
+#undef DCORA_PC_R
+#undef DCORA_PC
 }
 void launch_fused_finish(hipStream_t st, const ManiDesc &m, Buf2 X, const double *Zpart, const double *res,
                          double *z, const double *p2, int np2, double *p3, SolverCtl *ctl, HostFlags *hf, int seq,

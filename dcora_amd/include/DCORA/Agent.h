@@ -126,14 +126,32 @@ class Agent {
     }
     return true;
   }
-  // ref src/Agent.cpp:844-906.  The neighbour lives in the same session: its poses are already where the selected
-  // agent's linear term reads them, so this only validates the hand-over.
+  // ref src/Agent.cpp:844-906.  Restriction of this facade: the agents of a team share ONE device-resident mirror of
+  // X, and the selected agent's linear term is built from that mirror -- not from a per-agent copy of what it was
+  // handed.  The hand-over is therefore CHECKED against the mirror: poses that are stale, altered or belong to
+  // another robot are refused (std::runtime_error) instead of being silently ignored; frames that are left out are
+  // still read from the mirror.  (Ranks in different processes exchange through dcora_exchange_* instead.)
   void updateNeighborStates(unsigned neighborID, const PoseDict &poseDict, bool areNeighborStatesAux = false) {
-    (void)areNeighborStatesAux;
+    (void)areNeighborStatesAux;  // the reference driver hands over X in both calls (examples/MultiRobotExample.cpp:252)
+    if (poseDict.empty()) return;
+    int np = 0;
+    check_status(dcora_rbcd_agent_info(team()->session(), (int)neighborID, &np, nullptr, nullptr),
+                 "updateNeighborStates");
+    const unsigned r = relaxation_rank(), dh = dimension() + 1;
+    Matrix Xn(r, dh * (unsigned)np);
+    check_status(dcora_rbcd_agent_get_X(team()->session(), (int)neighborID, Xn.data()), "updateNeighborStates");
     for (const auto &kv : poseDict) {
       if (kv.first.first != neighborID) throw std::invalid_argument("updateNeighborStates: pose of another robot");
-      if (kv.second.rows() != relaxation_rank() || kv.second.cols() != dimension() + 1)
+      if (kv.second.rows() != r || kv.second.cols() != dh)
         throw std::invalid_argument("updateNeighborStates: expected r x (d+1) poses");
+      const unsigned frame = kv.first.second;
+      if (frame >= (unsigned)np) throw std::invalid_argument("updateNeighborStates: frame out of range");
+      for (unsigned c = 0; c < dh; ++c)
+        for (unsigned i = 0; i < r; ++i)
+          if (kv.second(i, c) != Xn(i, frame * dh + c))
+            throw std::runtime_error(
+                "updateNeighborStates: the poses handed over differ from the neighbour's current state; agents of one "
+                "AgentTeam optimise against the shared device mirror and cannot be given stale or altered poses");
     }
   }
   // ref src/Agent.cpp:535 getSharedPose(index): pose `index` of this agent, r x (d+1)

@@ -309,6 +309,11 @@ int dcora_exchange_set_X(dcora_exchange_t ex, const double *X);
 int dcora_exchange_gather_X(dcora_exchange_t ex, double *X);
 /* host barrier over the ranks of the job (does not synchronise the device) */
 int dcora_exchange_barrier(dcora_exchange_t ex);
+/* the host half of the protocol alone, without a device: bootstrap through the shared segment, barriers, and
+ * `rounds` rounds of post -> wait -> evaluation all-gather with host stores in the device's place; every rank of the
+ * job calls it, *checksum comes out identical on all of them.  For multi-process tests on machines without a GPU. */
+int dcora_exchange_host_selftest(const char *job_name, int rank, int world_size, int num_agents, int rounds,
+                                 double *checksum);
 
 /* ------------------------------------------------------------------------- *
  * RBCD session for multi-robot range-aided SLAM (replaces the Agents on a RangeAidedSLAMGraph and the loop body of

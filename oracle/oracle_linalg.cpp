@@ -3,6 +3,7 @@
 // (ref: src/Graph.cpp:1901-1917 preconditioner; src/DCORA_utils.cpp:1737-1747
 // PSD test).  Fill-reducing ordering: minimum degree on the block-compressed
 // graph; numeric phase: up-looking LL^T driven by the elimination tree.
+#include <vector>
 #include <algorithm>
 #include <numeric>
 #include <queue>
@@ -30,8 +31,10 @@ void axpy(double a, const Mat &X, Mat &Y) {
 void spmm_right(const Mat &X, const CSR &Q, Mat &Y) {
   const int r = X.rows;
   if (Y.rows != X.rows || Y.cols != X.cols) Y = Mat(X.rows, X.cols);
+  std::vector<double> accv((size_t)std::max(r, 1));
+  double *acc = accv.data();
   for (int j = 0; j < Q.n; ++j) {
-    double acc[16] = {0};
+    for (int i = 0; i < r; ++i) acc[i] = 0;
     for (int p = Q.rp[j]; p < Q.rp[j + 1]; ++p) {
       const double q = Q.v[p];
       const double *xc = X.col(Q.ci[p]);

@@ -151,5 +151,20 @@ int main(int argc, char **argv) {
     refused = true;
   }
   ok = ok && refused;
+  // poses that are not the neighbour's current state are refused, not silently ignored (ref src/Agent.cpp:844-906:
+  // the reference optimises against what it was handed; this facade optimises against the shared mirror)
+  {
+    DCORA::PoseDict shared;
+    agents[1]->getSharedStateDicts(&shared);
+    agents[0]->updateNeighborStates(1, shared);  // the current state: accepted
+    shared.begin()->second(0, 0) += 1e-3;
+    bool stale_refused = false;
+    try {
+      agents[0]->updateNeighborStates(1, shared);
+    } catch (const std::runtime_error &e) {
+      stale_refused = true;
+    }
+    ok = ok && stale_refused;
+  }
   return ok ? 0 : 1;
 }

@@ -222,3 +222,51 @@ def test_two_rank_coloured_ticks_match_one_after_the_other(built, tmp_path):
                 X[:, own] = P.optimize(X[:, own])[0]
         costs.append(float(np.sum((X @ Qg) * X)))
     assert np.allclose(tr[:, 1], costs, rtol=1e-10) and costs[1] < costs[0]
+
+
+# ---- the library's own exchange: host half of the protocol, real processes, no GPU -----------------------------------
+def _selftest_rank(rank, world, job, R, rounds, tmpdir):
+    import ctypes as C
+    sys.path.insert(0, os.path.dirname(common.HERE))
+    from dcora_amd import capi
+    cs = C.c_double()
+    rc = capi.lib().dcora_exchange_host_selftest(job.encode(), rank, world, R, rounds, C.byref(cs))
+    msg = capi.lib().dcora_last_error().decode()
+    np.save(os.path.join(tmpdir, "cs%d.npy" % rank), np.array([rc, cs.value]))
+    if rc:
+        raise RuntimeError("rank %d: status %d: %s" % (rank, rc, msg))
+
+
+@pytest.mark.parametrize("world,R", [(2, 5), (3, 8), (4, 5)])
+def test_exchange_host_protocol_between_processes(built, tmp_path, world, R):
+    """dcora_exchange_host_selftest in `world` processes: the bootstrap through the POSIX shared segment, the barriers,
+    the per-agent flag words with their parity double-buffering and the evaluation all-gather are the code the GPU
+    ranks run (dcora_amd/csrc/exchange.hip); host stores stand in for the device's.  (4 ranks / 5 agents: a rank
+    without agents takes part in every barrier and wait.)"""
+    import uuid
+    import torch.multiprocessing as mp
+    rounds = 50
+    job = "cpu%s" % uuid.uuid4().hex[:10]
+    mp.spawn(_selftest_rank, args=(world, job, R, rounds, str(tmp_path)), nprocs=world, join=True)
+    want = sum((q + 0.5 * a) * (a + 1) + (0.25 * q - a) for q in range(1, rounds + 1) for a in range(R))
+    for k in range(world):
+        rc, cs = np.load(tmp_path / ("cs%d.npy" % k))
+        assert rc == 0 and abs(cs - want) <= 1e-9 * abs(want), (k, rc, cs, want)
+    assert not os.path.exists("/dev/shm/dcora_" + job)  # rank 0 unlinks the name once everybody is attached
+
+
+def test_exchange_host_protocol_refuses_a_mismatched_job(built, tmp_path):
+    """a rank that attaches with another shape (number of agents) is told so instead of reading foreign slots"""
+    import ctypes as C
+    import multiprocessing as mp
+    import uuid
+    from dcora_amd import capi
+    job = "cpu%s" % uuid.uuid4().hex[:10]
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_selftest_rank, args=(0, 2, job, 5, 3, str(tmp_path)))
+    p.start()
+    cs = C.c_double()
+    rc = capi.lib().dcora_exchange_host_selftest(job.encode(), 1, 2, 6, 3, C.byref(cs))
+    assert rc != 0 and b"another shape" in capi.lib().dcora_last_error()
+    p.join(90)
+    assert p.exitcode is not None and p.exitcode != 0  # rank 0 sees the failure flag and gives up as well
