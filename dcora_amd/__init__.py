@@ -342,6 +342,16 @@ def time_qapply_rotating(problems, reps=60):
     return ms.value
 
 
+def precond_cache_info():
+    v = np.zeros(4)
+    check(capi.lib().dcora_precond_cache_info(v))
+    return {"hits": int(v[0]), "misses": int(v[1]), "entries": int(v[2]), "device_bytes": float(v[3])}
+
+
+def precond_cache_clear():
+    check(capi.lib().dcora_precond_cache_clear())
+
+
 class QuadraticOptimizer:
     """ref include/DCORA/QuadraticOptimizer.h: optimize(Y), getOptResult()"""
 
@@ -401,6 +411,25 @@ def fast_verification(S, eta, block=1, device=0):
     if st not in (0, 5):
         check(st)
     return bool(psd.value), th.value, v, lm.value
+
+
+def lambda_min_certified(S, eta, block=1, max_iterations=120):
+    """estimate (from above, converging) of lambda_min(S) after the certificate S + eta I >= 0 was accepted"""
+    lam, it = C.c_double(), C.c_int()
+    check(capi.lib().dcora_cert_lambda_min_certified(S.n, S.rp, S.ci, S.v, eta, block, max_iterations, C.byref(lam),
+                                                     C.byref(it)))
+    return lam.value, it.value
+
+
+def suboptimality_gap(r, d, n, X, psd, eta, lambda_min=None, l=0, b=0, lambda_bound=None):
+    """bound on f(X) - f* that goes with a certificate (dcora_cert_suboptimality_gap, an addition of this library): after
+    fast_verification(S, eta) returned psd (S + eta I >= 0) or, otherwise, its lambda_min output (of S + eta I);
+    lambda_bound overrides (e.g. min(lambda_min_certified(S, eta), 0))"""
+    lam = lambda_bound if lambda_bound is not None else (-eta if psd else float(lambda_min) - eta)
+    gap, neff = C.c_double(), C.c_double()
+    dims = Dims(r, d, n, l, b)
+    check(capi.lib().dcora_cert_suboptimality_gap(C.byref(dims), F(X), lam, C.byref(gap), C.byref(neff)))
+    return gap.value, neff.value
 
 
 class RbcdSession:

@@ -92,6 +92,8 @@ SIGNATURES = {
                                      _PD, _dp, C.POINTER(C.c_long)]),
     "dcora_cert_fast_verification": (C.c_int, [C.c_int, _ip, _ip, _dp, C.c_double, C.c_int, C.c_int, _PI, _PD, _dp,
                                                _PD]),
+    "dcora_cert_lambda_min_certified": (C.c_int, [C.c_int, _ip, _ip, _dp, C.c_double, C.c_int, C.c_int, _PD, _PI]),
+    "dcora_cert_suboptimality_gap": (C.c_int, [C.POINTER(Dims), _dp, C.c_double, _PD, _PD]),
     "dcora_dataset_load_g2o": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
     "dcora_dataset_create": (C.c_int, [C.c_int, C.c_int, C.c_int, _ip, _dp, C.POINTER(_vp)]),
     "dcora_dataset_info": (C.c_int, [_vp, _PI, _PI, _PI]),
@@ -161,6 +163,8 @@ SIGNATURES = {
     "dcora_problem_qapply_info": (C.c_int, [_vp, _dp]),
     "dcora_problem_time_precond": (C.c_int, [_vp, C.c_int, _PD, _PD]),
     "dcora_problem_precond_info": (C.c_int, [_vp, _dp]),
+    "dcora_precond_cache_info": (C.c_int, [_dp]),
+    "dcora_precond_cache_clear": (C.c_int, []),
     "dcora_robust_params_default": (None, [C.POINTER(RobustParams)]),
     "dcora_robust_weights": (C.c_int, [C.POINTER(RobustParams), C.c_int, C.c_int, _dp, _dp]),
     "dcora_chi2inv": (C.c_int, [C.c_double, C.c_int, _PD]),

@@ -9,6 +9,7 @@
 #include "host_graph.h"
 #include "ra_rbcd.h"
 #include "rbcd.h"
+#include "precond_cache.h"
 #include "exchange.h"
 #include "host_robust.h"
 #include "robust.h"
@@ -251,6 +252,138 @@ int dcora_problem_precond_info(dcora_problem_t p, double *info) {
   info[2] = (double)P.precond_nnzL;
   info[3] = P.precond_setup_ms;
   info[4] = !P.has_precond ? 0 : (P.sparse_precond ? P.sp.weights_per_apply : (double)P.m.k * P.m.k);
+  return DCORA_OK;
+}
+
+// smallest eigenvalue of a matrix the PSD test has accepted: Lanczos (full re-orthogonalisation) on M^-1, M = S + eta I,
+// through the sparse Cholesky factor the test computes (host); lambda_min(S) = 1 / theta_max(M^-1) - eta
+namespace {
+// largest eigenvalue of the symmetric tridiagonal (a, b) of order m by bisection on the Sturm count
+double tridiag_largest(const std::vector<double> &a, const std::vector<double> &b, int m) {
+  double lo = a[0], hi = a[0];
+  for (int i = 0; i < m; ++i) {
+    const double rad = (i > 0 ? std::fabs(b[i - 1]) : 0.0) + (i + 1 < m ? std::fabs(b[i]) : 0.0);
+    lo = std::min(lo, a[i] - rad);
+    hi = std::max(hi, a[i] + rad);
+  }
+  auto count_below = [&](double x) {  // eigenvalues < x
+    int c = 0;
+    double d = a[0] - x;
+    if (d < 0) ++c;
+    for (int i = 1; i < m; ++i) {
+      if (d == 0) d = 1e-300;
+      d = a[i] - x - b[i - 1] * b[i - 1] / d;
+      if (d < 0) ++c;
+    }
+    return c;
+  };
+  for (int it = 0; it < 200 && hi - lo > 1e-15 * std::max(std::fabs(hi), std::fabs(lo)); ++it) {
+    const double mid = 0.5 * (lo + hi);
+    if (count_below(mid) >= m) hi = mid; else lo = mid;
+  }
+  return 0.5 * (lo + hi);
+}
+}  // namespace
+int dcora_cert_lambda_min_certified(int k, const int *rp, const int *ci, const double *v, double eta, int block,
+                                    int max_iterations, double *lambda_min, int *iterations) {
+  if (!rp || !ci || !v || !lambda_min) return bad("null argument");
+  DCORA_TRY
+  const HostCsr S = view_csr(k, rp, ci, v);
+  SparseChol chol;
+  if (!chol.factor(csr_shift_diag(S, eta), block)) {
+    set_last_error("lambda_min_certified: S + eta I is not positive definite (the certificate was not accepted)");
+    return DCORA_ERR_NOT_PD;
+  }
+  const int mmax = std::max(2, std::min(max_iterations, k));
+  std::vector<std::vector<double>> V;
+  std::vector<double> alpha, beta, w((size_t)k);
+  std::vector<double> q((size_t)k);
+  uint64_t sdd = 0x9E3779B97F4A7C15ull;
+  double n2 = 0;
+  for (int i = 0; i < k; ++i) {
+    sdd = sdd * 6364136223846793005ull + 1442695040888963407ull;
+    q[i] = (double)(sdd >> 11) / 9007199254740992.0 - 0.5;
+    n2 += q[i] * q[i];
+  }
+  for (double &t : q) t /= std::sqrt(n2);
+  double lam = 0, prev = 1e300;
+  int j = 0;
+  for (; j < mmax; ++j) {
+    V.push_back(q);
+    chol.solve_vec(q.data(), w.data());  // w = M^-1 q
+    double a = 0;
+    for (int i = 0; i < k; ++i) a += q[i] * w[i];
+    alpha.push_back(a);
+    for (int pass = 0; pass < 2; ++pass)  // full re-orthogonalisation, twice
+      for (const std::vector<double> &u : V) {
+        double c = 0;
+        for (int i = 0; i < k; ++i) c += u[i] * w[i];
+        for (int i = 0; i < k; ++i) w[i] -= c * u[i];
+      }
+    double bn = 0;
+    for (int i = 0; i < k; ++i) bn += w[i] * w[i];
+    bn = std::sqrt(bn);
+    const int m = (int)alpha.size();
+    const bool check = (m % 5 == 0) || bn < 1e-14 * std::fabs(a) || j + 1 == mmax;
+    if (check) {
+      const double th = tridiag_largest(alpha, beta, m);
+      lam = 1.0 / th - eta;
+      if (std::fabs(prev - lam) <= 1e-3 * std::fabs(lam) + 1e-15 || bn < 1e-14 * std::fabs(a)) {
+        ++j;
+        break;
+      }
+      prev = lam;
+    }
+    beta.push_back(bn);
+    for (int i = 0; i < k; ++i) q[i] = w[i] / bn;
+  }
+  *lambda_min = lam;
+  if (iterations) *iterations = j;
+  return DCORA_OK;
+  DCORA_CATCH
+}
+
+int dcora_cert_suboptimality_gap(const dcora_dims *dims, const double *X, double lambda_lower_bound, double *gap,
+                                 double *n_eff) {
+  if (!dims || !X || !gap) return bad("null argument");
+  const ManiDesc m = make_mani(dims->r, dims->d, dims->n, dims->l, dims->b);
+  const int r = m.r;
+  double rot = 0;
+  for (int i = 0; i < m.n; ++i)
+    for (int c = 0; c < m.d; ++c)
+      for (int t = 0; t < r; ++t) {
+        const double x = X[(size_t)(m.rot_col(i) + c) * r + t];
+        rot += x * x;
+      }
+  for (int i = 0; i < m.l; ++i)
+    for (int t = 0; t < r; ++t) {
+      const double x = X[(size_t)m.sphere_col(i) * r + t];
+      rot += x * x;
+    }
+  const int ne = m.num_euc();
+  std::vector<double> mean((size_t)r, 0.0);
+  for (int e = 0; e < ne; ++e)
+    for (int t = 0; t < r; ++t) mean[t] += X[(size_t)m.euc_col(e) * r + t];
+  for (int t = 0; t < r; ++t) mean[t] /= std::max(ne, 1);
+  double euc = 0;
+  for (int e = 0; e < ne; ++e)
+    for (int t = 0; t < r; ++t) {
+      const double x = X[(size_t)m.euc_col(e) * r + t] - mean[t];
+      euc += x * x;
+    }
+  const double tr = rot + euc;
+  if (n_eff) *n_eff = tr;
+  *gap = 0.5 * std::max(0.0, -lambda_lower_bound) * tr;
+  return DCORA_OK;
+}
+
+int dcora_precond_cache_info(double *info4) {
+  if (!info4) return bad("null");
+  precond_cache_stats(info4);
+  return DCORA_OK;
+}
+int dcora_precond_cache_clear(void) {
+  precond_cache_clear();
   return DCORA_OK;
 }
 

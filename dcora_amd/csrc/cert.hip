@@ -261,7 +261,10 @@ int device_min_eig(const HostCsr &S, int maxit, double min_eig_tol, int ncv, uin
       PartInvHost P;
       if (build_partitioned_inverse(csr_shift_diag(S, -sigma), 1, nthreads, &P)) {
         SparsePrecond inv;
-        rc = inv.upload(P, 1);
+        auto img = std::make_shared<SpImage>();
+        rc = img->upload(P);
+        if (rc) return rc;
+        rc = inv.attach(img, 1);
         if (rc) return rc;
         L.inverse_op = &inv;
         LanczosResult si;

@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -29,25 +30,36 @@ struct DevBuf {
   DevBuf() = default;
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
-  DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) {
+  DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n), borrowed(o.borrowed) {
     o.p = nullptr;
     o.n = 0;
+    o.borrowed = false;
   }
   DevBuf &operator=(DevBuf &&o) noexcept {
     if (this != &o) {
       release();
       p = o.p;
       n = o.n;
+      borrowed = o.borrowed;
       o.p = nullptr;
       o.n = 0;
+      o.borrowed = false;
     }
     return *this;
   }
   ~DevBuf() { release(); }
+  bool borrowed = false;  // p belongs to somebody else (a cached image kept alive by a shared_ptr next to this)
   void release() {
-    if (p) (void)hipFree(p);
+    if (p && !borrowed) (void)hipFree(p);
     p = nullptr;
     n = 0;
+    borrowed = false;
+  }
+  void borrow(T *q, size_t count) {
+    release();
+    p = q;
+    n = count;
+    borrowed = true;
   }
   hipError_t alloc(size_t count) {
     release();
@@ -97,13 +109,14 @@ struct DevCsr {
 // 42 us vs sparse 75 us at k = 5000, dense 158 us vs sparse 97 us at k = 10000)
 constexpr int kDensePrecondMaxK = 8000;
 
-class SparsePrecond {
- public:
-  int k = 0, rcap = 0, npieces = 0;
+// immutable device image of a partitioned inverse: shared between the problems that precondition with the same
+// Q + reg I (the staircase levels, problems re-created per update) through the cache of precond_cache.h
+struct SpImage {
+  int k = 0, npieces = 0;
   long nnzL = 0, ntasks_total = 0, nsegs_total = 0;
   double weights_per_apply = 0, rows_total = 0;
   std::vector<SpLevel> levels;
-  DevBuf<double> vals, y;
+  DevBuf<double> vals;
   DevBuf<int> idxs, perm, out_off;
   DevBuf<PTask> tasks;
   DevBuf<PSeg> segs;
@@ -111,14 +124,24 @@ class SparsePrecond {
   int nhub = 0;
   long hub_nnz = 0;
   DevBuf<int> hub_idx, hub_ap, hub_apos;
-  DevBuf<double> hub_aval, hub_U, hub_Sinv, hub_w;
+  DevBuf<double> hub_aval, hub_U, hub_Sinv;
   // original unknown -> position in image 0 of the replay vector / position of its final value (no hubs only):
   // lets the caller's kernels write the right-hand side into y and read the result from it (SpFold, kernels.h)
   DevBuf<int> in_pos, out_pos;
-  bool foldable() const { return nhub == 0 && in_pos.p != nullptr; }
-  SpFold fold() const { return foldable() ? SpFold{y.p, in_pos.p, out_pos.p} : SpFold{}; }
-  int upload(const PartInvHost &P, int rcap);
-  int launches() const { return (int)levels.size() + 2 + (nhub > 0 ? 1 : 0); }
+  int upload(const PartInvHost &P);
+  size_t device_bytes() const;
+};
+
+class SparsePrecond {
+ public:
+  std::shared_ptr<const SpImage> im;  // the stored inverse (read-only)
+  int rcap = 0;
+  DevBuf<double> y, hub_w;            // this problem's replay vector (two ping-pong images) and hub scratch
+  double weights_per_apply = 0;
+  bool foldable() const { return im && im->nhub == 0 && im->in_pos.p != nullptr; }
+  SpFold fold() const { return foldable() ? SpFold{y.p, im->in_pos.p, im->out_pos.p} : SpFold{}; }
+  int attach(std::shared_ptr<const SpImage> image, int rcap);
+  int launches() const { return (int)im->levels.size() + 2 + (im->nhub > 0 ? 1 : 0); }
   // Z = R A^-1 for r <= rcap right-hand sides (r x k column-major); R is picked by ctl->cur when g.ctl is set.
   // levels_only: the right-hand side is already in y and the result is read from y (fold())
   void apply(hipStream_t st, int r, Buf2 R, double *Z, Gate g, bool levels_only = false) const;
@@ -141,6 +164,8 @@ class DeviceProblem {
   DevBuf<double> Minv;  // k x ldm dense inverse of Q + reg I (small blocks)
   int ldm = 0;
   SparsePrecond sp;     // partitioned sparse inverse (large blocks)
+  std::shared_ptr<const DevBuf<double>> Minv_shared;
+  bool precond_cache_hit = false;  // owner of the dense inverse Minv.p points to (cache)
   bool sparse_precond = false;
   bool has_precond = false;
   double precond_setup_ms = 0;

@@ -1,5 +1,6 @@
 // DeviceProblem: QuadraticProblem / QuadraticOptimizer on the MI355X (see device_problem.h).
 #include "device_problem.h"
+#include "precond_cache.h"
 
 #include <algorithm>
 #include <chrono>
@@ -167,48 +168,70 @@ int DeviceProblem::set_G_host(const double *Gh) {
 int DeviceProblem::build_preconditioner(const HostCsr &Qh, double reg) {
   const auto t0 = std::chrono::steady_clock::now();
   const int k = m.k;
-  HostCsr M = csr_shift_diag(Qh, reg);
   unsigned hw = std::thread::hardware_concurrency();
   const int nthreads = (int)std::max(1u, std::min(hw, 32u));
   // Large blocks: partitioned sparse inverse replayed level by level (sparse_precond.h).  Small blocks: the dense
   // inverse streams faster than 2 * depth + 2 dependent launches.  DCORA_PRECOND=dense|sparse overrides.
   const char *pc = std::getenv("DCORA_PRECOND");
   const bool want_sparse = pc ? (std::string(pc) == "sparse") : (k > kDensePrecondMaxK);
-  if (want_sparse) {
-    if (m.r > 16) {
-      set_last_error("sparse preconditioner supports r <= 16");
-      return DCORA_ERR_UNSUPPORTED;
-    }
-    PartInvHost P;
-    if (!build_partitioned_inverse(M, m.se ? m.d + 1 : 1, nthreads, &P)) {
-      set_last_error("preconditioner: Q + reg I is not positive definite");
-      return DCORA_ERR_NOT_PD;
-    }
-    DCORA_HIP(hipSetDevice(device));
-    int rc = sp.upload(P, m.r);
-    if (rc) return rc;
-    precond_nnzL = P.nnzL;
-    sparse_precond = true;
-    has_precond = true;
-    precond_setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    return DCORA_OK;
+  const int block = m.se ? m.d + 1 : 1;
+  if (want_sparse && m.r > 16) {
+    set_last_error("sparse preconditioner supports r <= 16");
+    return DCORA_ERR_UNSUPPORTED;
   }
-  if ((size_t)k > 60000) {
+  if (!want_sparse && (size_t)k > 60000) {
     set_last_error("dense preconditioner limited to k <= 60000");
     return DCORA_ERR_UNSUPPORTED;
   }
-  SparseChol chol;
-  if (!chol.factor(M, m.se ? m.d + 1 : 1)) {
-    set_last_error("preconditioner: Q + reg I is not positive definite");
-    return DCORA_ERR_NOT_PD;
-  }
-  precond_nnzL = chol.nnzL();
-  ldm = ((k + 127) / 128) * 128;  // rows padded so every 16-byte column-pair load of a 128-column chunk is in bounds
-  std::vector<double> inv((size_t)k * ldm, 0.0);
-  chol.dense_inverse(inv.data(), (size_t)ldm, nthreads);
+  // the inverse depends on Q + reg I only (not on r, not on G): built once per distinct matrix, shared afterwards
+  const PrecondKey key = make_precond_key(Qh, reg, block, device, want_sparse);
+  PrecondEntry ent;
+  precond_cache_hit = precond_cache_find(key, &ent);
   DCORA_HIP(hipSetDevice(device));
-  DCORA_HIP(Minv.alloc((size_t)k * ldm + 16));
-  DCORA_HIP(hipMemcpy(Minv.p, inv.data(), (size_t)k * ldm * sizeof(double), hipMemcpyHostToDevice));
+  if (!precond_cache_hit) {
+    HostCsr M = csr_shift_diag(Qh, reg);
+    if (want_sparse) {
+      PartInvHost P;
+      if (!build_partitioned_inverse(M, block, nthreads, &P)) {
+        set_last_error("preconditioner: Q + reg I is not positive definite");
+        return DCORA_ERR_NOT_PD;
+      }
+      auto img = std::make_shared<SpImage>();
+      const int rc = img->upload(P);
+      if (rc) return rc;
+      ent.sparse = img;
+      ent.nnzL = P.nnzL;
+      ent.bytes = img->device_bytes();
+    } else {
+      SparseChol chol;
+      if (!chol.factor(M, block)) {
+        set_last_error("preconditioner: Q + reg I is not positive definite");
+        return DCORA_ERR_NOT_PD;
+      }
+      ent.nnzL = chol.nnzL();
+      // rows padded so every 16-byte column-pair load of a 128-column chunk is in bounds
+      ent.ldm = ((k + 127) / 128) * 128;
+      std::vector<double> inv((size_t)k * ent.ldm, 0.0);
+      chol.dense_inverse(inv.data(), (size_t)ent.ldm, nthreads);
+      auto buf = std::make_shared<DevBuf<double>>();
+      DCORA_HIP(buf->alloc((size_t)k * ent.ldm + 16));
+      DCORA_HIP(hipMemcpy(buf->p, inv.data(), (size_t)k * ent.ldm * sizeof(double), hipMemcpyHostToDevice));
+      ent.dense = buf;
+      ent.bytes = buf->n * sizeof(double);
+    }
+    ent.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    precond_cache_insert(key, ent);
+  }
+  precond_nnzL = ent.nnzL;
+  if (want_sparse) {
+    const int rc = sp.attach(ent.sparse, m.r);
+    if (rc) return rc;
+    sparse_precond = true;
+  } else {
+    ldm = ent.ldm;
+    Minv_shared = ent.dense;
+    Minv.borrow(ent.dense->p, ent.dense->n);
+  }
   has_precond = true;
   precond_setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return DCORA_OK;

@@ -234,9 +234,8 @@ void launch_level(hipStream_t st, int r, const SpLevel &lv, const PTask *tasks, 
 
 }  // namespace
 
-int SparsePrecond::upload(const PartInvHost &P, int rcap_) {
+int SpImage::upload(const PartInvHost &P) {
   k = P.k;
-  rcap = rcap_;
   levels = P.levels;
   nnzL = P.nnzL;
   npieces = P.npieces;
@@ -253,9 +252,6 @@ int SparsePrecond::upload(const PartInvHost &P, int rcap_) {
   DCORA_HIP(hipMemcpy(perm.p, P.perm.data(), P.perm.size() * sizeof(int), hipMemcpyHostToDevice));
   DCORA_HIP(out_off.alloc(P.out_off.size()));
   DCORA_HIP(hipMemcpy(out_off.p, P.out_off.data(), P.out_off.size() * sizeof(int), hipMemcpyHostToDevice));
-  // two ping-pong images of the vector; padded pairs may touch one unknown past the end
-  DCORA_HIP(y.alloc((size_t)(2 * k + 2) * rcap));
-  DCORA_HIP(hipMemset(y.p, 0, (size_t)(2 * k + 2) * rcap * sizeof(double)));
   ntasks_total = (long)P.tasks.size();
   rows_total = 0;
   for (const PTask &t : P.tasks) rows_total += t.nrows;
@@ -289,13 +285,40 @@ int SparsePrecond::upload(const PartInvHost &P, int rcap_) {
     DCORA_HIP(hipMemcpy(hub_U.p, H.U.data(), H.U.size() * sizeof(double), hipMemcpyHostToDevice));
     DCORA_HIP(hub_Sinv.alloc(H.Sinv.size()));
     DCORA_HIP(hipMemcpy(hub_Sinv.p, H.Sinv.data(), H.Sinv.size() * sizeof(double), hipMemcpyHostToDevice));
-    DCORA_HIP(hub_w.alloc((size_t)nhub * rcap));
-    DCORA_HIP(hipMemset(hub_w.p, 0, (size_t)nhub * rcap * sizeof(double)));
+  }
+  return DCORA_OK;
+}
+
+size_t SpImage::device_bytes() const {
+  return vals.n * sizeof(double) + (idxs.n + perm.n + out_off.n + in_pos.n + out_pos.n) * sizeof(int) +
+         tasks.n * sizeof(PTask) + segs.n * sizeof(PSeg) + (hub_aval.n + hub_U.n + hub_Sinv.n) * sizeof(double) +
+         (hub_idx.n + hub_ap.n + hub_apos.n) * sizeof(int);
+}
+
+int SparsePrecond::attach(std::shared_ptr<const SpImage> image, int rcap_) {
+  im = std::move(image);
+  rcap = rcap_;
+  weights_per_apply = im->weights_per_apply;
+  const int k = im->k;
+  // two ping-pong images of the vector; padded pairs may touch one unknown past the end
+  DCORA_HIP(y.alloc((size_t)(2 * k + 2) * rcap));
+  DCORA_HIP(hipMemset(y.p, 0, (size_t)(2 * k + 2) * rcap * sizeof(double)));
+  if (im->nhub > 0) {
+    DCORA_HIP(hub_w.alloc((size_t)im->nhub * rcap));
+    DCORA_HIP(hipMemset(hub_w.p, 0, (size_t)im->nhub * rcap * sizeof(double)));
   }
   return DCORA_OK;
 }
 
 void SparsePrecond::apply(hipStream_t st, int r, Buf2 R, double *Z, Gate g, bool levels_only) const {
+  const SpImage &I = *im;
+  const int k = I.k, nhub = I.nhub;
+  const DevBuf<int> &perm = I.perm, &out_off = I.out_off, &hub_idx = I.hub_idx, &hub_ap = I.hub_ap, &hub_apos = I.hub_apos,
+                    &idxs = I.idxs;
+  const DevBuf<double> &vals = I.vals, &hub_aval = I.hub_aval, &hub_U = I.hub_U, &hub_Sinv = I.hub_Sinv;
+  const DevBuf<PTask> &tasks = I.tasks;
+  const DevBuf<PSeg> &segs = I.segs;
+  const std::vector<SpLevel> &levels = I.levels;
   const long n = (long)r * k;
   const int grid = (int)std::min<long>((n + kBlock - 1) / kBlock, 2048);
   levels_only = levels_only && foldable();
@@ -313,8 +336,9 @@ void SparsePrecond::apply(hipStream_t st, int r, Buf2 R, double *Z, Gate g, bool
 
 double SparsePrecond::bytes_per_apply(int r) const {
   // stored weights once, the task / segment tables, the vector in and out of every row tile, permutes, hub terms
-  return 8.0 * weights_per_apply + 48.0 * ntasks_total + 24.0 * nsegs_total + 16.0 * r * rows_total +
-         32.0 * r * (double)k + 12.0 * hub_nnz + 8.0 * (double)nhub * k;
+  const SpImage &I = *im;
+  return 8.0 * I.weights_per_apply + 48.0 * I.ntasks_total + 24.0 * I.nsegs_total + 16.0 * r * I.rows_total +
+         32.0 * r * (double)I.k + 12.0 * I.hub_nnz + 8.0 * (double)I.nhub * I.k;
 }
 
 }  // namespace dcora

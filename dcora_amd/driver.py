@@ -11,12 +11,13 @@ import time
 
 import numpy as np
 
-from . import QuadraticProblem, RbcdSession, build_Q_pgo, dual_certificate, fast_verification
+from . import (QuadraticProblem, RbcdSession, build_Q_pgo, dual_certificate, fast_verification,
+               lambda_min_certified, suboptimality_gap)
 
 
 def multi_robot_example(ds, X0, num_robots=5, r_min=5, r_max=100, max_iters=1000, rgrad_tol=0.1, min_eig_tol=1e-3,
                         gradient_tolerance=1e-6, preconditioned_gradient_tolerance=1e-6, acceleration=True,
-                        params=None, device=0):
+                        params=None, device=0, refine_gap=False):
     """X0: r_min x (d+1) n start point.  Returns a dict: X (final rank x k), rank, certified, theta, per-level
     records (rank, iterations, cost 2f, gradnorm, seconds of RBCD / certification / escape) and the traces."""
     d, n = ds.d, ds.n
@@ -49,6 +50,15 @@ def multi_robot_example(ds, X0, num_robots=5, r_min=5, r_max=100, max_iters=1000
                "gradnorm": float(out["gradnorm"][-1]), "setup_s": t0 - ts, "rbcd_s": t1 - t0,
                "certification_s": t2 - t1,
                "certified": bool(psd), "theta": float(theta)}
+        # bound on f(X) - f* implied by the certificate (this library's addition, include/dcora_hip.h)
+        lev["suboptimality_gap_f"], lev["n_eff"] = suboptimality_gap(r, d, n, Xopt, psd, min_eig_tol, lmin)
+        if psd and refine_gap:  # the eigenvalue of the accepted certificate instead of the -eta the test guarantees
+            tg = time.perf_counter()
+            lam, _ = lambda_min_certified(S, min_eig_tol, block=d + 1)
+            lev["lambda_min_S"] = lam
+            lev["suboptimality_gap_f_refined"] = suboptimality_gap(r, d, n, Xopt, psd, min_eig_tol,
+                                                                   lambda_bound=min(lam, 0.0))[0]
+            lev["gap_refinement_s"] = time.perf_counter() - tg
         levels.append(lev)
         X = Xopt
         if psd:
@@ -68,7 +78,7 @@ def multi_robot_example(ds, X0, num_robots=5, r_min=5, r_max=100, max_iters=1000
         r += 1
     cat = lambda parts, dt: np.concatenate(parts) if parts else np.zeros(0, dt)
     return {"X": X, "rank": X.shape[0], "certified": certified, "theta": float(theta), "total_iters": int(total),
-            "levels": levels, "cost": cat(cost, float), "gradnorm": cat(gradnorm, float),
+            "suboptimality_gap_f": levels[-1]["suboptimality_gap_f"] if levels else None, "levels": levels, "cost": cat(cost, float), "gradnorm": cat(gradnorm, float),
             "selected": cat(selected, np.int32), "rank_trace": cat(rank, np.int32)}
 
 
@@ -143,6 +153,7 @@ def multi_robot_raslam_example(ra, X0, r_min=None, r_max=100, max_iters=1000, rg
     levels, certified, theta, total = [], False, 0.0, 0
     r = r_min
     while r < r_max:
+        ts = time.perf_counter()
         s = RaRbcdSession(ra, r, acceleration=acceleration, params=params, device=device)
         s.set_X(X)
         t0 = time.perf_counter()

@@ -138,6 +138,26 @@ int dcora_cert_min_eig(int k, const int *rowptr, const int *colidx, const double
 int dcora_cert_fast_verification(int k, const int *rowptr, const int *colidx, const double *vals, double eta,
                                  int block, int device, int *is_psd, double *theta, double *x, double *lambda_min);
 
+/* Suboptimality bound that goes with the certificate -- an ADDITION of this library: the reference reports the
+ * boolean and theta only (ref examples/MultiRobotExample.cpp:321-352).  SE-Sync form: at a first-order critical point
+ * X with certificate matrix S = Q - Lambda(X), every feasible Z = X'^T X' satisfies f(X) - f(X') = -1/2 <S, Z>
+ * <= -1/2 lambda tr(Z) for any lower bound lambda <= min(lambda_min(S), 0).  tr(Z) is evaluated at X itself with the
+ * translation / landmark columns centred (the cost does not see a common shift of them): n_eff = |rotation and
+ * sphere columns|_F^2 + sum_i |p_i - mean p|^2, so gap = -1/2 lambda n_eff is exact for the rotation part and an
+ * estimate for comparison points whose translations spread more than X's.  Pass lambda = -eta after a positive
+ * dcora_cert_fast_verification(S, eta) (then S + eta I >= 0), or lambda_min - eta from its lambda_min output otherwise.
+ * gap is in units of f (half of the "cost" the reference driver prints); n_eff may be NULL. */
+int dcora_cert_suboptimality_gap(const dcora_dims *dims, const double *X, double lambda_lower_bound, double *gap,
+                                 double *n_eff);
+/* The eta-test only says lambda_min(S) >= -eta, and eta n_eff can exceed the cost itself when the trajectory is large
+ * (n_eff grows with the spread of the translations).  After an accepted certificate this returns an upper estimate
+ * of lambda_min(S) that converges to it from above: Lanczos with full re-orthogonalisation on (S + eta I)^-1 (the
+ * matrix the PSD test factorised; sparse Cholesky on the host) until the estimate changes by less than 0.1 % (at
+ * most max_iterations solves).  DCORA_ERR_NOT_PD when S + eta I is not positive definite.  Also an addition of this
+ * library.  lambda_lower_bound = min(lambda_min, 0) in dcora_cert_suboptimality_gap gives the estimate of the gap. */
+int dcora_cert_lambda_min_certified(int k, const int *rowptr, const int *colidx, const double *vals, double eta,
+                                    int block, int max_iterations, double *lambda_min, int *iterations);
+
 /* ------------------------------------------------------------------------- *
  * Data feed  (replaces the parts of src/Graph.cpp / src/DCORA_utils.cpp that
  * produce Q, G and the measurement list)
@@ -440,6 +460,14 @@ int dcora_problem_time_precond(dcora_problem_t p, int reps, double *avg_ms, doub
  * info[1] = kernel launches per application; info[2] = nnz of the Cholesky factor; info[3] = host setup ms;
  * info[4] = doubles of stored inverse one application streams */
 int dcora_problem_precond_info(dcora_problem_t p, double *info5);
+/* The preconditioner image (dense inverse or partitioned sparse inverse of Q + reg I) is cached inside the library,
+ * keyed on the content of the matrix (rowptr, colidx, vals, reg, device): the reference re-creates its QuadraticProblem
+ * on every Agent::updateX (ref src/Agent.cpp:1252) while its Graph keeps Q and the factor (ref src/Graph.cpp:523-533,
+ * 1901-1917).  A second dcora_problem_create / dcora_rbcd_create on the same matrix -- the next staircase level, a
+ * problem re-created per update -- attaches to the resident image instead of factorising again.
+ * info[4] = {hits, misses, entries, device bytes held}.  Budget: DCORA_PRECOND_CACHE_MB (default 8192, 0 = off). */
+int dcora_precond_cache_info(double *info4);
+int dcora_precond_cache_clear(void);
 
 #ifdef __cplusplus
 }

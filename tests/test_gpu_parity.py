@@ -206,6 +206,22 @@ def test_chordal_start_to_certified_optimum_of_sphere2500(env):
     S = da.dual_certificate(r, ds.d, ds.n, X, Q)
     psd, theta, x, lmin = da.fast_verification(S, 1e-3, block=ds.d + 1)
     assert psd
+    # the bound that goes with the certificate: 2 (f - f*) <= eta n_eff, n_eff = tr(X^T X) with centred translations
+    gap, neff = da.suboptimality_gap(r, ds.d, ds.n, X, psd, 1e-3)
+    P = X[:, 3::4]
+    want = 3 * ds.n + np.sum((P - P.mean(axis=1, keepdims=True)) ** 2)
+    assert abs(neff - want) < 1e-9 * want and abs(gap - 0.5e-3 * want) < 1e-12 * want
+    # the eta-test alone is a loose statement on a trajectory of this extent (eta n_eff exceeds the cost itself) ...
+    assert 2 * gap > out["cost"][-1]
+    # ... the eigenvalue of the accepted certificate gives the usable number: lambda_min(S) sits at rounding level of
+    # the scale of S, and the gap estimate -lambda_min n_eff covers the distance to the fully converged optimum
+    # (2 f = 1687.0058, tests/test_configs_gpu.py) within the first-order term the non-zero gradient adds
+    lam, its = da.lambda_min_certified(S, 1e-3, block=ds.d + 1)
+    import scipy.sparse.linalg as sla
+    w = sla.eigsh(S.to_scipy().tocsc(), k=1, sigma=-1e-3, which="LM", return_eigenvectors=False)[0]
+    assert lam >= w - 1e-9 and lam - w < 1e-2 * max(abs(w), 1e-6), (lam, w)
+    gap2, _ = da.suboptimality_gap(r, ds.d, ds.n, X, psd, 1e-3, lambda_bound=min(lam, 0.0))
+    assert gap2 < gap and 2 * gap2 < 0.05 * out["cost"][-1]
     # the oracle agrees on cost and certificate at the device's solution
     dso = common.oracle_dataset("sphere2500")
     Qo = orc.build_Q_pgo(dso)
