@@ -429,7 +429,7 @@ def committed_profile(nbytes):
         try:
             with open(path) as fh:
                 for row in csv.DictReader(fh):
-                    if "k_fused_precond" in row["Name"]:
+                    if "k_fused_pc" in row["Name"] or "k_fused_precond" in row["Name"]:
                         us = float(row["AverageNs"]) / 1e3
                         out["in_loop"] = {"avg_launch_us_all_launches": us, "launches": int(row["Calls"]),
                                           "min_us": float(row["MinNs"]) / 1e3,
@@ -445,7 +445,8 @@ def committed_profile(nbytes):
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
-                out["traffic_bytes_per_launch"] = j.get("k_fused_precond_bytes_per_launch")
+                out["traffic_bytes_per_launch"] = j.get("k_fused_pc_bytes_per_launch",
+                                                         j.get("k_fused_precond_bytes_per_launch"))
                 out["traffic_source"] = "profiles/" + name
             except Exception:
                 pass
@@ -481,13 +482,17 @@ def roofline(da, ds, r, robots):
     pinfo = Pb.precond_info()
     ach = nbytes / (ms * 1e-3) / 1e9
     sec8d = 2.0 * pinfo["nnzL"] * 12 + 2.0 * r * kb * 8
-    main = {"bound": "hbm", "kernel": "k_fused_precond (dense preconditioner application, one agent, k=%d)" % kb,
+    one_launch = os.environ.get("DCORA_SOLVER_BC") != "split" and r <= 7 and r * kb <= 12800
+    kname = "k_fused_pc (step length + vector updates + dense preconditioner product + projection + stopping rule, " \
+            "one launch)" if one_launch else "k_fused_precond (step length + vector updates + dense preconditioner slices)"
+    main = {"bound": "hbm", "kernel": "%s, one agent, k=%d" % (kname, kb),
             "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
             "bytes_per_launch": nbytes, "avg_launch_us": ms * 1e3,
             "peak_note": "spec peak of HBM3E; a streaming kernel reaches about 6.3 TB/s on this part, and at this size "
                          "the operands sit in the 256 MiB Infinity Cache",
-            "bytes_counted": "what the kernel's data structure streams: the dense symmetric inverse (8 k ldm), the "
-                             "residual and the split-K slices",
+            "bytes_counted": "what the kernel's data structure streams once: the dense symmetric inverse (8 k^2) and 7 "
+                             "passes over r x k vectors (r_old, H delta in; eta, H eta, r, z through); not counted: "
+                             "every workgroup re-reading r_old and H delta from L2 to rebuild the residual",
             "survey_8d": {"formula": "bytes_precond = 2 nnz(L) 12 + 2 r k 8 (a sparse-factor solve)",
                           "nnz_L": pinfo["nnzL"], "bytes_precond": sec8d,
                           "achieved_GBps": sec8d / (ms * 1e-3) / 1e9,
@@ -497,7 +502,7 @@ def roofline(da, ds, r, robots):
                                   "a chain of dependent sparse levels); by the sparse-factor byte count the kernel "
                                   "sits at a few percent of the roofline, and the loop is latency-bound"},
             "measured": "HIP events on the solver's stream around 300 back-to-back launches of the kernel in its "
-                        "in-loop form (step length, vector updates, |r|^2, inverse slices), in this run"}
+                        "in-loop form, in this run"}
     main["from_committed_profile"] = committed_profile(nbytes)
     Pb.close()
     try:  # the same kernel on a block 2.5 x larger (sphere2500 split in two, k = 5000): a longer launch

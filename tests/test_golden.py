@@ -110,3 +110,35 @@ def test_cpp_agent_facade_runs_the_reference_driver_loop(built):
     assert os.path.exists(exe), "build() compiles tests/cpp/test_agent_facade.cpp"
     p = subprocess.run([exe, common.plain_path("smallGrid3D")], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, p.stdout + p.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,rank", [("smallGrid3D", 3), ("sphere2500", 5)])
+def test_cpp_staircase_driver_matches_the_python_driver(built, tmp_path, name, rank):
+    """dcora_amd/examples/MultiRobotExample.cpp -- the reference's driver with the Riemannian staircase, as a C++
+    program over the facade classes and the C ABI -- against dcora_amd/driver.py (same control flow through ctypes):
+    same levels, same iteration count, same certified cost; the trajectory it writes is a set of rigid poses"""
+    import json
+    import subprocess
+    import dcora_amd as da
+    from dcora_amd import driver
+    exe = os.path.join(os.path.dirname(common.HERE), "dcora_amd", "examples", "_build", "multi-robot-example")
+    traj = str(tmp_path / "traj.txt")
+    out = subprocess.run([exe, "5", common.plain_path(name), "--rank", str(rank), "--quiet", "--out", traj],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    ds = common.product_dataset(name)
+    T = da.chordal_initialization(ds)
+    X0 = np.zeros((rank, (ds.d + 1) * ds.n))
+    X0[:ds.d] = T
+    ref = driver.multi_robot_example(ds, X0, num_robots=5, r_min=rank, max_iters=1000, rgrad_tol=0.1, min_eig_tol=1e-3)
+    assert res["certified"] and ref["certified"]
+    assert res["rank"] == ref["rank"] and res["levels"] == len(ref["levels"])
+    assert res["iterations"] == ref["total_iters"]
+    assert abs(res["cost_2f"] - ref["cost"][-1]) <= 1e-9 * abs(ref["cost"][-1])
+    assert abs(res["suboptimality_gap_f"] - ref["suboptimality_gap_f"]) <= 1e-5 * ref["suboptimality_gap_f"]  # printed with 6 digits
+    rows = np.loadtxt(traj, comments="#")
+    assert rows.shape == (ds.n, 8)
+    assert np.allclose(np.linalg.norm(rows[:, 4:8], axis=1), 1.0, atol=1e-8)   # unit quaternions
+    assert np.allclose(rows[0, 1:4], 0.0, atol=1e-9)                            # the frame of the first pose
