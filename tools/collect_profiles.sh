@@ -1,0 +1,20 @@
+#!/bin/bash
+# collects the round's rocprofv3 summaries into gpurun_out/r02 (run on the GPU box; copy what is quoted into profiles/)
+export TMPDIR=/tmp
+o=gpurun_out/r02
+rm -rf $o; mkdir -p $o
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/headline -o t -- python3 bench.py --headline-only > $o/headline.log 2>&1
+python3 tools/kstats.py $o/headline 20 > $o/headline_top.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/default -o t -- python3 bench.py --no-cpu-baseline > $o/default.log 2>&1
+python3 tools/kstats.py $o/default 30 > $o/default_top.txt
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $o/pmc_fetch -o t -- python3 tools/pmc_run.py > $o/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $o/pmc_write -o t -- python3 tools/pmc_run.py > $o/pmc_write.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  d=$([ $c = FETCH_SIZE ] && echo pmc_fetch || echo pmc_write)
+  f=$(find $o/$d -name "*counter_collection.csv" | head -1)
+  python3 tools/pmc_summarize.py $f $c > $o/pmc_${c}_summary.csv
+done
+python3 bench.py > $o/bench.json 2> $o/bench.err
+# keep the merged output small
+find $o -name "*kernel_trace.csv" -delete; find $o -name "*counter_collection.csv" -delete
+ls -la $o
