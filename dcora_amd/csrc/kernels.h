@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <climits>
+#include <vector>
 
 namespace dcora {
 

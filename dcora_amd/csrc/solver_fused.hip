@@ -11,6 +11,7 @@
 // of a group owns row t of the pose's r x (d+1) block, d x d Gram matrices are reduced with 3 xor-shuffles.
 #include <algorithm>
 #include <type_traits>
+#include <vector>
 #include <cstdlib>
 
 #include "kernels.h"
@@ -54,6 +55,16 @@ __device__ __forceinline__ double f_block_sum(double v, double *sm) {
 }
 // Up to 64 partials: every wave loads them itself (lane l takes partial l) and sums them with f_wave_sum, so the
 // total is known in every wave without a barrier or an LDS exchange; more partials go through the block reduction.
+// Up to 256 partials without a barrier: every wave loads all of them (lane l takes partials l, l + 64, l + 128, l + 192:
+// four predicated loads requested together) and sums them with f_wave_sum -- __syncthreads() drains vmcnt, i.e. it
+// would wait for every gather the kernel has in flight behind the partials (measured in k_fused_hess with the 250
+// partials of k_fused_pc: 1.7 us at the reduction).  f_partial4_load / f_partial4_total; beyond 256 the block path.
+__device__ __forceinline__ double f_partial4_load(const double *__restrict__ p, int np) {
+  const int l = (int)(threadIdx.x & 63u);
+  const double a = (l < np) ? p[l] : 0.0, b = (l + 64 < np) ? p[l + 64] : 0.0;
+  const double c = (l + 128 < np) ? p[l + 128] : 0.0, d = (l + 192 < np) ? p[l + 192] : 0.0;
+  return (a + b) + (c + d);
+}
 // f_partial_index is the index a thread loads, f_partial_total the matching reduction.
 __device__ __forceinline__ int f_partial_index(int np) { return np <= 64 ? (int)(threadIdx.x & 63u) : (int)threadIdx.x; }
 __device__ __forceinline__ double f_partial_total(double v, int np, double *sm) {
@@ -207,9 +218,9 @@ __device__ __forceinline__ void row_polar(Row<D> &A, bool live) {
   }
 }
 
+constexpr int kHessTile = 1536;              // nnz staged per pass (18 KiB of LDS)
 constexpr int kPosesPerBlock = kBlock / GW;  // 32 (pure per-pose kernels)
 constexpr int kBsrTile = 160;                // matrix blocks staged per pass (20 KiB at (d+1)^2 = 16)
-constexpr int kHessTile = 1536;              // nnz staged per pass (18 KiB of LDS)
 
 // poses per block of the two-phase kernels: phase 1 runs one thread per output element (pose, column, row),
 // phase 2 eight lanes per pose
@@ -254,9 +265,10 @@ __global__ __launch_bounds__(kBlock) void k_fused_hess(ManiDesc m, CsrDev Q, con
   const int j = j0 + lc;
   const int pbeg = Q.rp[j0], pend = Q.rp[j0 + ncol];
   const int myb = act ? Q.rp[j] : 0, mye = act ? Q.rp[j + 1] : 0;
-  // <z, r> partials first (one predicated load; the loop below only runs for > 256 partials)
+  // <z, r> partials first (predicated loads; the loop below only runs for > 256 partials)
+  const bool p3_wave = np3 <= 256;
   const int pi3 = f_partial_index(np3);
-  double myp = (pi3 < np3) ? p3[pi3] : 0.0;
+  double myp = p3_wave ? f_partial4_load(p3, np3) : ((pi3 < np3) ? p3[pi3] : 0.0);
   {
     // first tile of the matrix: all trips' loads are issued before any is stored to LDS (clamped index, straight
     // line), one memory round trip instead of one per 256 entries
@@ -312,7 +324,7 @@ __global__ __launch_bounds__(kBlock) void k_fused_hess(ManiDesc m, CsrDev Q, con
     ga[q] = (iter > 0) ? d_old[oo] : 0.0;
   }
   // ---- scalar recurrence (ROPTLIB tCG_TR): beta, e_Pd, d_Pd ----
-  const double z_r_new = f_partial_total(myp, np3, s_red);
+  const double z_r_new = p3_wave ? f_wave_sum(myp) : f_partial_total(myp, np3, s_red);
   double beta = 0;
   if (iter > 0) beta = z_r_new / c_zr;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1363,11 +1375,18 @@ __global__ __launch_bounds__(kBlock) void k_spmm_bsr(int r, BsrDev A, Buf2 Xb, i
   double d0 = 0, d1 = 0;
   // (an XCD-aware walk -- one contiguous eighth of the pose chunks per XCD -- was measured on the 100k lattice:
   // 36.0 vs 34.9 us, no gain over the plain interleaved walk, so the simple mapping stays)
-  for (int pose0 = blockIdx.x * kPosesPerBlock; pose0 < A.nbrows; pose0 += gridDim.x * kPosesPerBlock) {
+  // Balanced ranges instead of one 32-pose chunk per workgroup: at most 8 workgroups of 256 threads are resident per
+  // CU (2048 on the chip), so a grid of 3125 chunks ran as one full round plus a half-empty one.  Workgroup b takes
+  // the poses [n b / grid, n (b + 1) / grid) in passes of at most 32 (equal-sized passes).
+  const int range_lo = (int)((long)A.nbrows * blockIdx.x / gridDim.x);
+  const int range_hi = (int)((long)A.nbrows * (blockIdx.x + 1) / gridDim.x);
+  const int npass = max(1, (range_hi - range_lo + kPosesPerBlock - 1) / kPosesPerBlock);
+  const int per_pass = (range_hi - range_lo + npass - 1) / npass;
+  for (int pose0 = range_lo; pose0 < range_hi; pose0 += per_pass) {
+    const int pend_pose = min(range_hi, pose0 + per_pass);
     const int pose = pose0 + (threadIdx.x >> 3);
-    const bool inr = pose < A.nbrows;
+    const bool inr = pose < pend_pose;
     const bool active = inr && (t < r);
-    const int pend_pose = min(A.nbrows, pose0 + kPosesPerBlock);
     const int bbeg = A.bp[pose0], bend = A.bp[pend_pose];
     const int myb = inr ? A.bp[pose] : 0, mye = inr ? A.bp[pose + 1] : 0;
     double acc[DH];
@@ -1549,9 +1568,19 @@ void launch_eval_finish(hipStream_t st, int R, const int *pose_start, const doub
 // one chunk of 32 poses per workgroup up to kBsrMaxGrid workgroups (the Q-apply partial buffer holds that many
 // slots): at 100k poses more resident workgroups mean more gathers in flight (34.9 us at 1024, 30.1 us at 2048)
 int spmm_bsr_grid(int nbrows) {
-  long g = ((long)nbrows + kPosesPerBlock - 1) / kPosesPerBlock;
+  // one resident round: 8 workgroups of 256 threads per CU on 256 CUs (DCORA_BSR_GRID overrides, for measurements)
+  static const int cap = [] {
+    const char *e = std::getenv("DCORA_BSR_GRID");
+    const int v = e ? atoi(e) : kBsrMaxGrid;
+    return std::max(1, std::min(v, kBsrMaxGrid));
+  }();
+  static const int per = [] {
+    const char *e = std::getenv("DCORA_BSR_POSES");
+    return e ? std::max(1, atoi(e)) : kPosesPerBlock;
+  }();
+  long g = ((long)nbrows + per - 1) / per;
   if (g < 1) g = 1;
-  if (g > kBsrMaxGrid) g = kBsrMaxGrid;
+  if (g > cap) g = cap;
   return (int)g;
 }
 void launch_spmm_bsr(hipStream_t st, int r, int d, const BsrDev &A, Buf2 X, int selX, const double *G, Buf2 Y,
