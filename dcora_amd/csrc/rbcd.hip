@@ -131,6 +131,7 @@ int RbcdSession::init(const HostDataset &ds, const dcora_rbcd_options &o) {
 
   agents.resize(R);
   std::vector<int> cs(R + 1);
+  std::vector<int> hosted_ids;
   for (int b = 0; b < R; ++b) {
     AgentDev &a = agents[b];
     a.id = b;
@@ -146,17 +147,54 @@ int RbcdSession::init(const HostDataset &ds, const dcora_rbcd_options &o) {
     DCORA_HIP(a.public_cols.alloc(std::max<size_t>(cols.size(), 1)));
     if (!cols.empty())
       DCORA_HIP(hipMemcpy(a.public_cols.p, cols.data(), sizeof(int) * cols.size(), hipMemcpyHostToDevice));
-    if (!a.hosted) continue;
+    if (a.hosted) hosted_ids.push_back(b);
+  }
+  // The hosted agents' problems (Q_bb, its preconditioner: host factorisation + inverse image, coupling block) are
+  // built side by side on host threads: the factorisation of one block is partly serial (the separators above the
+  // sub-trees), so eight blocks of the 100k lattice take 9 s one after the other and 2-3 s together.
+  auto build_agent = [&](int b, std::string *err) -> int {
+    AgentDev &a = agents[b];
+    if (hipSetDevice(o.device) != hipSuccess) return DCORA_ERR_HIP;
     HostCsr Qb = build_Q_pgo(d, a.n, b, touching[b]);
     a.prob.reset(new DeviceProblem);
     dcora_dims dims{r, d, a.n, 0, 0};
     int rc = a.prob->init(dims, Qb, nullptr, 0.1, o.device, st);  // reg = 1e-1, ref src/Graph.cpp:1906
-    if (rc) return rc;
-    HostCsr C = build_coupling_pgo(d, P, b, global);
-    rc = a.coupling.upload(C);
-    if (rc) return rc;
-    DCORA_HIP(hipStreamCreateWithFlags(&a.own, hipStreamNonBlocking));
-    DCORA_HIP(hipEventCreateWithFlags(&a.done, hipEventDisableTiming));
+    if (!rc) {
+      HostCsr C = build_coupling_pgo(d, P, b, global);
+      rc = a.coupling.upload(C);
+    }
+    if (!rc && hipStreamCreateWithFlags(&a.own, hipStreamNonBlocking) != hipSuccess) rc = DCORA_ERR_HIP;
+    if (!rc && hipEventCreateWithFlags(&a.done, hipEventDisableTiming) != hipSuccess) rc = DCORA_ERR_HIP;
+    if (rc && err) *err = dcora_last_error();
+    return rc;
+  };
+  {
+    const size_t nh = hosted_ids.size();
+    std::vector<int> rcs(nh, DCORA_OK);
+    std::vector<std::string> errs(nh);
+    static const bool serial = std::getenv("DCORA_SERIAL_SETUP") != nullptr;
+    // small blocks build in well under a millisecond of host work each: threads only pay off for large ones
+    if (nh > 1 && !serial && (long)(n / R) * dh >= 8192) {
+      std::atomic<size_t> next(0);
+      auto worker = [&] {
+        for (;;) {
+          const size_t i = next.fetch_add(1);
+          if (i >= nh) break;
+          rcs[i] = build_agent(hosted_ids[i], &errs[i]);
+        }
+      };
+      std::vector<std::thread> th;
+      for (size_t t = 1; t < std::min<size_t>(nh, 8); ++t) th.emplace_back(worker);
+      worker();
+      for (std::thread &t : th) t.join();
+    } else {
+      for (size_t i = 0; i < nh; ++i) rcs[i] = build_agent(hosted_ids[i], &errs[i]);
+    }
+    for (size_t i = 0; i < nh; ++i)
+      if (rcs[i]) {
+        set_last_error(errs[i]);
+        return rcs[i];
+      }
   }
   DCORA_HIP(hipEventCreateWithFlags(&fork_ev_, hipEventDisableTiming));
   cs[R] = dh * n;
