@@ -33,7 +33,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md; about 6.3 TB/s is achievable by a stream)
 SUSTAINED_STEPS = 300
@@ -575,7 +574,6 @@ def certified_run(args, da, torch, ds, with_cpu):
     to rank r (the reference driver's InitializationMethod::Chordal, examples/MultiRobotExample.cpp:150-153); clock
     runs from the first RBCD iteration until fastVerification accepts the certificate (examples/...:223-348), file
     parsing and the initialisation excluded.  The same flow is timed on the CPU oracle."""
-    import common
     r = args.rank_r
     t0 = time.perf_counter()
     T = da.chordal_initialization(ds)
@@ -612,8 +610,8 @@ def certified_run(args, da, torch, ds, with_cpu):
                                          "accepted S + eta I (dcora_cert_lambda_min_certified); outside the "
                                          "certification clock"}}}
     if with_cpu:
-        from oracle import orc
-        dso = common.oracle_dataset(args.dataset)
+        from oracle import flows, orc
+        dso = flows.oracle_dataset(args.dataset)
         tr = orc.run_rbcd(dso, X0, num_robots=args.robots, r_min=r, max_iters=1000, staircase=1)
         res["cpu_port"] = {"rbcd_iterations": int(tr["total_iters"]), "agent_setup_ms": 1e3 * tr["setup_seconds"],
                            "rbcd_ms": 1e3 * tr["rbcd_seconds"], "certification_ms": 1e3 * tr["cert_seconds"],
@@ -721,8 +719,8 @@ def config5_multi(da, torch, dist, rank, world):
 
 
 def config3_multi(da, torch, dist, rank, world):
-    import common
-    ds = common.product_dataset("torus3D")
+    from dcora_amd import datasets
+    ds = datasets.product_dataset("torus3D")
     return side_multi(da, torch, dist, rank, world, ds, 8, 5,
                       "torus3D.g2o, 8 agents, r=5, RBCD++ (accel, restart 30), RTR 3x50 tCG", iters=200, sweeps=20)
 
@@ -731,7 +729,6 @@ def config4_multi_robot(da, ra, with_cpu, r=3, iters=40, cpu_iters=3):
     """tiers.pyfg as the multi-robot driver sees it (examples/MultiRobotExample_RASLAM.cpp): 4 robots, every agent
     resident on the GPU (dcora_ra_rbcd_*), RBCD++ from the lifted odometry start with the agents' default local
     solver (RTR 3 x 50); the CPU figure is the same loop over the oracle's local solver for the first iterations"""
-    import cora_flow
     X0 = np.zeros((r, ra.k))
     X0[:ra.d] = ra.X_odom
     t0 = time.perf_counter()
@@ -748,11 +745,11 @@ def config4_multi_robot(da, ra, with_cpu, r=3, iters=40, cpu_iters=3):
            "iterations": iters, "value": iters / dt, "unit": "RBCD iterations/s", "ms_per_step": 1e3 * dt / iters,
            "setup_s": setup_s, "cost_2f_first": float(out["cost"][0]), "cost_2f_last": float(out["cost"][-1])}
     if with_cpu:
-        from oracle import orc
+        from oracle import flows, orc
         opt = dict(RTR_iterations=3, RTR_tCG_iterations=50, gradnorm_tol=1e-2)
-        cora_flow.oracle_ra_rbcd_loop(da, orc, ra, X0, r, 1, True, 30, opt)  # builds / warms what the loop reuses
+        flows.oracle_ra_rbcd_loop(da, orc, ra, X0, r, 1, True, 30, opt)  # builds / warms what the loop reuses
         t0 = time.perf_counter()
-        Xo, tr = cora_flow.oracle_ra_rbcd_loop(da, orc, ra, X0, r, cpu_iters, True, 30, opt)
+        Xo, tr = flows.oracle_ra_rbcd_loop(da, orc, ra, X0, r, cpu_iters, True, 30, opt)
         dtc = time.perf_counter() - t0
         res["cpu_port"] = {"iterations": cpu_iters, "value": cpu_iters / dtc, "unit": "RBCD iterations/s", "cores": 1,
                            "note": "numpy loop over the oracle's local solver, set-up of the agents included",
@@ -768,9 +765,8 @@ def config4_run(da, with_cpu):
     The range-aided layout runs the unfused solver path with the partitioned sparse preconditioner (the landmark
     is a hub: Schur complement).  Both sides keep the reference's 5 s TimeBound of one RTR run
     (ref src/QuadraticOptimizer.cpp:252): the CPU oracle stops on it, the GPU finishes its 200 outer iterations."""
-    import common
-    import cora_flow
-    path = os.path.join(common.DATA, "tiers.pyfg.gz")
+    from dcora_amd import cora_flow, datasets
+    path = os.path.join(datasets.DATA, "tiers.pyfg.gz")
     ra = da.RADataset(path)
     hip = cora_flow.ProductBackend(ra)
     t0 = time.perf_counter()
@@ -795,7 +791,8 @@ def config4_run(da, with_cpu):
             shutil.copyfileobj(src, out)
         ro = orc.RADataset(tmp)
         os.unlink(tmp)
-        cpu = cora_flow.OracleBackend(ro, hip.reg)
+        from oracle import flows
+        cpu = flows.OracleBackend(ro, hip.reg)
         Po = cpu.problem(ro.d)
         t0 = time.perf_counter()
         Xo, fo, gno, oo, io = cpu.optimize(Po, ro.X_odom)
@@ -827,9 +824,8 @@ def cpu_baseline(args, ds_name, X0):
     """the CPU oracle (1 thread) on the same trajectory from the same start point; rates are taken over the SAME
     iteration windows as the GPU figures (the oracle stamps its loop clock after every iteration): the driver's window
     (iterations warmup+2 .. warmup+1+steps) and the sustained window that follows it"""
-    import common
-    from oracle import orc
-    dso = common.oracle_dataset(ds_name)
+    from oracle import flows, orc
+    dso = flows.oracle_dataset(ds_name)
     first = args.warmup + 1
     need = first + args.steps + SUSTAINED_STEPS
     n_it = max(need, args.cpu_steps or 1000)  # about 10 ms / iteration on one core: a 10-30 s sample
@@ -865,13 +861,13 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(env_world or 1)
     import torch
-    import common
     import dcora_amd as da
+    from dcora_amd import datasets
     if da.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: libdcora_hip has no CPU fallback")
     local = int(os.environ.get("LOCAL_RANK", 0)) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
-    ds = common.product_dataset(args.dataset)
+    ds = datasets.product_dataset(args.dataset)
     X0 = initial_point(da, ds, args.rank_r)
     multi = world > 1 or bool(os.environ.get("DCORA_FORCE_MULTI"))  # the latter: 1-rank rehearsal of the N>1 path
     sustained = exch = c3 = c5 = group = None

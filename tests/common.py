@@ -1,40 +1,12 @@
 """shared test helpers: dataset fixtures for the product (dcora_amd) and for the oracle (oracle.orc)"""
-import gzip
 import os
-import shutil
-import tempfile
 
 import numpy as np
 
+from dcora_amd.datasets import DATA, data_path, plain_path, product_dataset  # noqa: F401
+from oracle.flows import oracle_dataset  # noqa: F401
+
 HERE = os.path.dirname(os.path.abspath(__file__))
-DATA = os.path.join(HERE, "golden", "data")
-
-
-def data_path(name):
-    return os.path.join(DATA, name + ".g2o.gz")
-
-
-_tmp = {}
-
-
-def plain_path(name):
-    """decompressed copy (the oracle's reader takes plain files)"""
-    if name not in _tmp:
-        fd, p = tempfile.mkstemp(suffix="_%s.g2o" % name)
-        with os.fdopen(fd, "wb") as out, gzip.open(data_path(name), "rb") as src:
-            shutil.copyfileobj(src, out)
-        _tmp[name] = p
-    return _tmp[name]
-
-
-def oracle_dataset(name):
-    from oracle import orc
-    return orc.read_g2o(plain_path(name))
-
-
-def product_dataset(name):
-    import dcora_amd as da
-    return da.Dataset.load_g2o(data_path(name))
 
 
 def random_point(r, d, n, seed, project):

@@ -1,193 +1,4 @@
-"""The centralised CORA driver of the reference (examples/SingleRobotExample_RASLAM.cpp:48-283) written once over a
-small backend adapter, so the same flow runs on the product (dcora_amd, GPU) and on the CPU oracle:
-
-    X0 = odometry start at rank d
-    for r = d, d+1, ...:  RTR(200 x 200, tol 1e-4) at rank r  ->  S = Q - Lambda(X)  ->  fastVerification(S, 1e-4)
-        certified:  projectSolutionRASLAM -> refine at rank d -> done
-        else:       escapeSaddle (second-order step) into rank r + 1
-
-Used by tests/test_cora.py and by bench.py's config-4 side measurement."""
-import time
-
-import numpy as np
-import scipy.sparse as sp
-
-PARAMS = dict(RTR_iterations=200, RTR_tCG_iterations=200, gradnorm_tol=1e-4)
-MIN_EIG_TOL = 1e-4
-
-
-class ProductBackend:
-    name = "hip"
-
-    def __init__(self, ra):
-        import dcora_amd as da
-        self.da, self.ra, self.Q = da, ra, ra.Q
-        self.reg = da.precond_regularization(ra.Q)
-
-    def problem(self, r):
-        ra = self.ra
-        return self.da.QuadraticProblem(r, ra.d, ra.n, self.Q, reg=self.reg, l=ra.l, b=ra.b)
-
-    def optimize(self, P, X):
-        opt = self.da.QuadraticOptimizer(P, self.da.ROptParameters(**PARAMS))
-        Xo = opt.optimize(X)
-        res = opt.getOptResult()
-        return Xo, res["fOpt"], res["gradNormOpt"], res["outer_iterations"], res["inner_iterations"]
-
-    def certificate(self, r, X):
-        ra = self.ra
-        S = self.da.dual_certificate(r, ra.d, ra.n, X, self.Q, l=ra.l, b=ra.b)
-        psd, theta, v, lmin = self.da.fast_verification(S, MIN_EIG_TOL, block=1)
-        return psd, theta, v
-
-    def escape(self, Pnext, X, theta, v):
-        return Pnext.escapeSaddle(X, theta, v, 1e-4, 1e-4, isSecondOrder=True)
-
-    def project(self, X, r):
-        ra = self.ra
-        return self.da.project_solution_raslam(X, r, ra.d, ra.n, ra.l, ra.b)
-
-    def close(self, P):
-        P.close()
-
-
-class OracleBackend:
-    name = "cpu"
-
-    def __init__(self, ra_oracle, reg):
-        from oracle import orc
-        self.orc, self.ra, self.Q, self.reg = orc, ra_oracle, ra_oracle.Q, reg
-
-    def problem(self, r):
-        ra = self.ra
-        return self.orc.Problem(r, ra.d, ra.n, self.Q, reg=self.reg, l=ra.l, b=ra.b)
-
-    def optimize(self, P, X):
-        Xo, res = P.optimize(X, **PARAMS)
-        return Xo, res["fOpt"], res["gradNormOpt"], int(res["outer_iters"]), int(res["inner_iters"])
-
-    def certificate(self, r, X):
-        ra = self.ra
-        S = self.orc.dual_certificate(r, ra.d, ra.n, X, self.Q, l=ra.l, b=ra.b)
-        psd, theta, v, lmin = self.orc.fast_verification(S, MIN_EIG_TOL, block=1)
-        return psd, theta, v
-
-    def escape(self, Pnext, X, theta, v):
-        return Pnext.escape_saddle(X, theta, v, 1e-4, 1e-4, second_order=True)
-
-    def project(self, X, r):
-        ra = self.ra
-        return self.orc.project_solution_raslam(X, r, ra.d, ra.n, ra.l, ra.b)
-
-    def close(self, P):
-        pass
-
-
-def cora(backend, X0, d, r_max=20, log=None):
-    """returns dict(levels=[{r, f, gradnorm, outer, inner, psd, theta, ms}], certified, r_final, X, X_rounded,
-    f_rounded, ms_total) -- the clock covers the loop of the driver (problem construction included, as in the
-    reference, where every level builds its Graph / QuadraticProblem afresh)"""
-    t_start = time.perf_counter()
-    X = np.array(X0, dtype=np.float64)
-    levels, certified, Xr, fr = [], False, None, None
-    r = d
-    while r < r_max:
-        t0 = time.perf_counter()
-        P = backend.problem(r)
-        Xopt, f, gn, outer, inner = backend.optimize(P, X)
-        psd, theta, v = backend.certificate(r, Xopt)
-        lv = dict(r=r, f=f, gradnorm=gn, outer=outer, inner=inner, psd=bool(psd), theta=theta)
-        if psd:
-            certified = True
-            Xp = Xopt if r == d else backend.project(Xopt, r)
-            Pd = P if r == d else backend.problem(d)
-            Xr, fr, gr, o2, i2 = backend.optimize(Pd, Xp)
-            lv.update(refine_outer=o2, refine_inner=i2)
-            if Pd is not P:
-                backend.close(Pd)
-            backend.close(P)
-            lv["ms"] = 1e3 * (time.perf_counter() - t0)
-            levels.append(lv)
-            X = Xopt
-            break
-        Pn = backend.problem(r + 1)
-        Xn = backend.escape(Pn, Xopt, theta, v)
-        backend.close(Pn)
-        backend.close(P)
-        lv["ms"] = 1e3 * (time.perf_counter() - t0)
-        levels.append(lv)
-        if log:
-            log(lv)
-        if Xn is None:
-            X = Xopt
-            break
-        X = Xn
-        r += 1
-    return dict(levels=levels, certified=certified, r_final=levels[-1]["r"], X=X, X_rounded=Xr, f_rounded=fr,
-                ms_total=1e3 * (time.perf_counter() - t_start))
-
-
-def oracle_ra_rbcd_loop(da, orc, ra, X0, r, iters, accel, restart_interval, opt):
-    """Agent::iterate for every agent + central evaluation + greedy selection (ref src/Agent.cpp:535-596, 1158-1278,
-    examples/MultiRobotExample_RASLAM.cpp), every numerical step on the oracle"""
-    d, n, l, b, k = ra.d, ra.n, ra.l, ra.b, ra.k
-    robots = ra.robots
-    R = len(robots)
-    Qo = orc.CSR.from_scipy(ra.Q.to_scipy())
-    central = orc.Problem(r, d, n, Qo, reg=-1, l=l, b=b)
-    blk, P, C = {}, {}, {}
-    for rb in robots:
-        dims3, own, Qaa, Cc = ra.agent_blocks(rb)
-        reg = da.precond_regularization(Qaa)  # the session computes the same per-agent regularisation
-        blk[rb] = (dims3, own)
-        C[rb] = Cc.tocsr()
-        P[rb] = lambda G, rb=rb, Qaa=Qaa, dims3=dims3, reg=reg: orc.Problem(
-            r, d, dims3[0], orc.CSR.from_scipy(sp.csr_matrix(Qaa.to_scipy())), G=G, reg=reg, l=dims3[1], b=dims3[2])
-    proj = lambda rb, M: orc.project_to_manifold(r, d, blk[rb][0][0], M, l=blk[rb][0][1], b=blk[rb][0][2])
-    X = X0.copy()
-    Xa = {rb: X[:, blk[rb][1]].copy() for rb in robots}
-    V = {rb: Xa[rb].copy() for rb in robots}
-    Y = {rb: Xa[rb].copy() for rb in robots}
-    gamma = alpha = 0.0
-    sel, trace = 0, []
-    for it in range(1, iters + 1):
-        if accel:
-            gamma = (1 + np.sqrt(1 + 4.0 * R * R * gamma * gamma)) / (2.0 * R)
-            alpha = 1.0 / (gamma * R)
-        restart = accel and ((it + 1) % restart_interval == 0)
-        XPrev = {rb: Xa[rb].copy() for rb in robots}
-        for i, rb in enumerate(robots):
-            if i == sel or not accel:
-                continue
-            if restart:
-                V[rb], Y[rb] = Xa[rb].copy(), Xa[rb].copy()
-            else:
-                Y[rb] = proj(rb, (1 - alpha) * Xa[rb] + alpha * V[rb])
-                Xa[rb] = Y[rb].copy()
-                V[rb] = proj(rb, V[rb])
-                X[:, blk[rb][1]] = Xa[rb]
-        rb = robots[sel]
-
-        def solve(start):
-            G = (C[rb] @ X.T).T
-            return P[rb](G).optimize(start, **opt)[0]
-
-        if accel:
-            Y[rb] = proj(rb, (1 - alpha) * Xa[rb] + alpha * V[rb])
-            Xn = solve(Y[rb])
-            V[rb] = proj(rb, V[rb] + gamma * Xn - gamma * Y[rb])
-            Xa[rb] = Xn
-            if restart:
-                Xa[rb] = solve(XPrev[rb])
-                V[rb], Y[rb] = Xa[rb].copy(), Xa[rb].copy()
-        else:
-            Xa[rb] = solve(Xa[rb])
-        X[:, blk[rb][1]] = Xa[rb]
-        if restart:
-            gamma = alpha = 0.0
-        RG = central.rgrad(X)
-        bn = np.array([np.linalg.norm(RG[:, blk[q][1]]) for q in robots])
-        trace.append((sel, 2 * central.f(X), np.linalg.norm(RG)))
-        nxt = int(np.argmax(bn))
-        sel = nxt if C[rb].nnz > 0 else sel
-    return X, np.array(trace)
+"""kept for the tests' imports: the CORA flow lives in dcora_amd/cora_flow.py (product control flow), its oracle backend
+and the oracle RA-SLAM loop in oracle/flows.py (test infrastructure)"""
+from dcora_amd.cora_flow import MIN_EIG_TOL, PARAMS, ProductBackend, cora  # noqa: F401
+from oracle.flows import OracleBackend, oracle_ra_rbcd_loop  # noqa: F401
