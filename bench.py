@@ -145,7 +145,8 @@ class RankDriver:
         now, was = self.ex.info(), self._mark
         self._mark = now
         it = max(1, iterations)
-        return {"transport": now["transport"], "ranks_this_rank_stores_to": now["peers"],
+        return {"transport": now["transport"], "halo_finegrained": now["halo_finegrained"],
+                "ranks_this_rank_stores_to": now["peers"],
                 "post_us_per_iteration": 1e6 * (now["post_s"] - was["post_s"]) / it,
                 "wait_us_per_iteration": 1e6 * (now["wait_s"] - was["wait_s"]) / it,
                 "evaluation_allgather_wait_us_per_iteration": 1e6 * (now["eval_wait_s"] - was["eval_wait_s"]) / it,

@@ -570,9 +570,10 @@ class Exchange:
             pass
 
     def info(self):
-        v = np.zeros(8)
+        v = np.zeros(10)
         check(capi.lib().dcora_exchange_info(self.h, v))
         return dict(transport={1: "ipc peer stores", 2: "shared host segment"}.get(int(v[0]), "?"), mode=int(v[0]),
+                    halo_finegrained=bool(v[8]),
                     peers=int(v[1]), posts=int(v[2]), waits=int(v[3]), bytes_posted=float(v[4]), post_s=float(v[5]),
                     wait_s=float(v[6]), eval_wait_s=float(v[7]))
 

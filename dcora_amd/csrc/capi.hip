@@ -800,6 +800,8 @@ int dcora_exchange_info(dcora_exchange_t ex, double *info) {
   info[5] = e.post_s;
   info[6] = e.wait_s;
   info[7] = e.eval_wait_s;
+  info[8] = e.halo_is_finegrained() ? 1 : 0;
+  info[9] = 0;
   return DCORA_OK;
 }
 int dcora_exchange_post(dcora_exchange_t ex, const int *agents, int count) {

@@ -68,6 +68,7 @@ class Exchange {
 
   int mode = 0;
   int rank = 0, world = 1;
+  bool halo_is_finegrained() const { return halo_finegrained_; }
   // statistics since creation (host wall time spent in post / wait / the evaluation all-gather, bytes posted)
   double post_s = 0, wait_s = 0, eval_wait_s = 0;
   long posts = 0, waits = 0, evals = 0;
@@ -90,7 +91,8 @@ class Exchange {
   size_t off_flags_ = 0, off_evals_ = 0, off_staged_ = 0, off_x_ = 0;
   int R_ = 0;
   size_t slot_ = 0;                // doubles per agent slot
-  DevBuf<double> halo_;            // [parity][agent][slot] + self-test area
+  DevBuf<double> halo_;            // [parity][agent][slot] + self-test area (fine-grained device memory)
+  bool halo_finegrained_ = false;
   double *peer_halo_[kMaxRanks]{};  // IPC mappings (null for myself and for ranks I never write to)
   bool opened_[kMaxRanks]{};
   DevBuf<unsigned> arrive_;        // one last-workgroup counter per agent

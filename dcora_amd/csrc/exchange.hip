@@ -284,7 +284,22 @@ int Exchange::setup_ipc(bool attempt) {
     if (ok) why = m;
     ok = false;
   };
-  if (ok && halo_.alloc(test_off + (size_t)ntest * world) != hipSuccess) no("hipMalloc of the halo buffer");
+  // The halo buffer is written by OTHER GPUs while this GPU's kernels read it launch after launch: fine-grained device
+  // memory (not cached incoherently in this GPU's L2), so that a slot re-used two posts later is never served stale;
+  // plain hipMalloc if the runtime refuses (the self-test below still has to pass).
+  if (ok) {
+    const size_t bytes = sizeof(double) * (test_off + (size_t)ntest * world);
+    void *hp = nullptr;
+    static const bool coarse = std::getenv("DCORA_EXCHANGE_COARSE") != nullptr;
+    if (!coarse && hipExtMallocWithFlags(&hp, bytes, hipDeviceMallocFinegrained) == hipSuccess && hp) {
+      halo_.p = (double *)hp;  // released with hipFree like any DevBuf
+      halo_.n = test_off + (size_t)ntest * world;
+      halo_finegrained_ = true;
+    } else {
+      (void)hipGetLastError();
+      if (halo_.alloc(test_off + (size_t)ntest * world) != hipSuccess) no("hipMalloc of the halo buffer");
+    }
+  }
   if (ok && hipMemset(halo_.p, 0, sizeof(double) * (test_off + (size_t)ntest * world)) != hipSuccess) no("hipMemset");
   if (ok && hipIpcGetMemHandle(&ranks_[rank].halo, halo_.p) != hipSuccess) no("hipIpcGetMemHandle");
   (void)hipGetLastError();

@@ -303,9 +303,10 @@ int dcora_rbcd_synchronize(dcora_rbcd_t s);
 typedef struct dcora_exchange_s *dcora_exchange_t;
 int dcora_exchange_create(dcora_rbcd_t s, const char *job_name, dcora_exchange_t *out);
 int dcora_exchange_destroy(dcora_exchange_t ex);
-/* info[8] = {transport (1 = IPC peer stores, 2 = shared host segment), ranks this rank stores to, posts, waits,
- * bytes posted so far, host seconds in post, host seconds in wait, host seconds waiting for the evaluation scalars} */
-int dcora_exchange_info(dcora_exchange_t ex, double *info8);
+/* info[10] = {transport (1 = IPC peer stores, 2 = shared host segment), ranks this rank stores to, posts, waits,
+ * bytes posted so far, host seconds in post, host seconds in wait, host seconds waiting for the evaluation scalars,
+ * 1 when this rank's halo buffer is fine-grained device memory (remote stores never served stale from the local L2), 0} */
+int dcora_exchange_info(dcora_exchange_t ex, double *info10);
 /* getSharedStateDicts of `agents`: each hosted one is written to its neighbours' ranks and flagged (one kernel per
  * agent on the session's stream; returns without synchronising) */
 int dcora_exchange_post(dcora_exchange_t ex, const int *agents, int count);

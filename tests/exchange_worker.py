@@ -46,7 +46,7 @@ def main():
     ex.barrier()
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), cost=np.array(cost), gradnorm=np.array(gn),
              selected=np.array(sel), X=X, mode=info["mode"], posts=info["posts"], waits=info["waits"],
-             bytes_posted=info["bytes_posted"], peers=info["peers"])
+             bytes_posted=info["bytes_posted"], peers=info["peers"], finegrained=info["halo_finegrained"])
     ex.close()
     s.close()
 

@@ -85,6 +85,8 @@ def test_ranks_reproduce_single_session(tmp_path, name, R, world, iters, mode, t
     want_mode = 2 if transport == "staged" else 1
     for k, o in enumerate(res):
         assert int(o["mode"]) == want_mode, "rank %d used transport %d" % (k, int(o["mode"]))
+        if want_mode == 1:  # the halo buffers other ranks store into are fine-grained device memory
+            assert bool(o["finegrained"]), "rank %d fell back to a coarse-grained halo buffer" % k
         assert np.array_equal(o["selected"], sel), (k, o["selected"], sel)
         assert np.allclose(o["cost"], cost, rtol=1e-11, atol=0), (k, np.max(np.abs(o["cost"] - cost) / np.abs(cost)))
         assert np.allclose(o["gradnorm"], gn, rtol=1e-9, atol=0)
