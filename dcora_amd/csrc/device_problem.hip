@@ -650,11 +650,20 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
   };
   auto outer_done = [&]() { return hf->outer_done_seq >= solve_first; };
   // f(x0), grad(x0) from buffer 0 (null gate: the control block of this solve does not exist yet)
+  // cost + gradient of an evaluation in one launch where the kernel exists (small CSR blocks), else Q-apply + rgrad
+  static const bool grad_split = std::getenv("DCORA_GRAD_SPLIT") != nullptr;
+  const bool gf = !has_bsr && Q.n_long == 0 && !grad_split;
+  const int nAe = gf ? nPB : nA;  // {<XQ,X>, <X,G>} partial slots of an evaluation
+  int nG;
   ++seq;
-  enq_qapply(Xb(), 0, Gp, EGb(), 0, pA.p, Gate{});
-  ++seq;
-  int nG = enq_rgrad(Xb(), EGb(), RGb(), Sb(), 0, pB.p, Gate{});
-  launch_rtr_init(st, pA.p, nA, pB.p, nG, c, hf_dev, ++seq, ci);
+  if (gf) {
+    nG = launch_fused_grad(st, m, Qv, Xb(), Gp, EGb(), RGb(), Sb(), 0, pA.p, pB.p, nullptr, Gate{});
+  } else {
+    enq_qapply(Xb(), 0, Gp, EGb(), 0, pA.p, Gate{});
+    ++seq;
+    nG = enq_rgrad(Xb(), EGb(), RGb(), Sb(), 0, pB.p, Gate{});
+  }
+  launch_rtr_init(st, pA.p, nAe, pB.p, nG, c, hf_dev, ++seq, ci);
   int last_pace_seq = seq;
   std::vector<int> fin_seq((size_t)std::max(1, max_inner));
   for (int outer = 0; outer < max_outer; ++outer) {
@@ -698,9 +707,13 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
       fin_seq[j] = seq;
     }
     const int nR = enq_retract(Xb(), eta.p, 1.0, Xb(), 1, RGb(), Heta.p, pC.p, Gate{c, ++seq, 1});
-    enq_qapply(Xb(), 1, Gp, EGb(), 1, pA.p, Gate{c, ++seq, 1});
-    nG = enq_rgrad(Xb(), EGb(), RGb(), Sb(), 1, pB.p, Gate{c, ++seq, 1});
-    launch_rtr_decide(st, pA.p, nA, pB.p, nG, pC.p, nR, c, hf_dev, ++seq);
+    if (gf) {
+      nG = launch_fused_grad(st, m, Qv, Xb(), Gp, EGb(), RGb(), Sb(), 1, pA.p, pB.p, nullptr, Gate{c, ++seq, 1});
+    } else {
+      enq_qapply(Xb(), 1, Gp, EGb(), 1, pA.p, Gate{c, ++seq, 1});
+      nG = enq_rgrad(Xb(), EGb(), RGb(), Sb(), 1, pB.p, Gate{c, ++seq, 1});
+    }
+    launch_rtr_decide(st, pA.p, nAe, pB.p, nG, pC.p, nR, c, hf_dev, ++seq);
     last_pace_seq = seq;
   }
   return DCORA_OK;

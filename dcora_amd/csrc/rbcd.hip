@@ -489,11 +489,18 @@ int RbcdSession::evaluate_central(double *cost2, double *gradnorm, double *block
     return DCORA_ERR_UNSUPPORTED;
   }
   DeviceProblem &c = *central;
-  c.enqueue_egrad(Xg.p, c.EG0.p, c.pA.p);
+  static const bool grad_split = std::getenv("DCORA_GRAD_SPLIT") != nullptr;
+  const bool gf = c.group && c.fused && !c.has_bsr && c.Q.n_long == 0 && !grad_split;
+  if (!gf) c.enqueue_egrad(Xg.p, c.EG0.p, c.pA.p);
   if (c.group) {
-    c.enq_rgrad(buf1(Xg.p), buf1(c.EG0.p), buf1(c.RG0.p), Buf2{{nullptr, nullptr}}, 0, c.pB.p, Gate{}, posenorm.p);
+    int nA = c.npA();
+    if (gf)  // X Q, the cost dots, the Riemannian gradient and the per-pose norms in one launch
+      nA = launch_fused_grad(st, c.m, c.Q.view(), buf1(Xg.p), nullptr, buf1(c.EG0.p), buf1(c.RG0.p),
+                             Buf2{{nullptr, nullptr}}, 0, c.pA.p, c.pB.p, posenorm.p, Gate{});
+    else
+      c.enq_rgrad(buf1(Xg.p), buf1(c.EG0.p), buf1(c.RG0.p), Buf2{{nullptr, nullptr}}, 0, c.pB.p, Gate{}, posenorm.p);
     const int want = ++eval_seq;
-    launch_eval_finish(st, R, pose_start.p, posenorm.p, c.pA.p, c.npA(), eval_dev, want);
+    launch_eval_finish(st, R, pose_start.p, posenorm.p, c.pA.p, nA, eval_dev, want);
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
     while (eval_host->seq != want) {

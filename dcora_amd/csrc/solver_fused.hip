@@ -395,6 +395,130 @@ __global__ __launch_bounds__(kBlock) void k_fused_hess(ManiDesc m, CsrDev Q, con
   if (threadIdx.x == 0) p1[blockIdx.x] = tot;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Cost and gradient of an RTR evaluation in ONE launch (small pose-graph blocks, CSR): EG = X Q + G with the partial
+// dots {<X Q, X>, <X, G>} (what k_spmm<true> does), then RG = Proj_X(EG), S_i = sym(Y_i^T EG_i) and the partial |RG|^2
+// (what k_g_rgrad does) -- phase 1 one thread per output element with the block's CSR rows staged in LDS, phase 2
+// eight lanes per pose, operands handed over through LDS, exactly as k_fused_hess.  Saves one dependent launch per
+// evaluation (4 per local solve, 1 per central evaluation).
+// ------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_fused_grad(ManiDesc m, CsrDev Q, Buf2 Xb, const double *__restrict__ G,
+                                                       Buf2 EGb, Buf2 RGb, Buf2 Sb, int sel,
+                                                       double *__restrict__ pA, double *__restrict__ pB,
+                                                       double *__restrict__ posenorm, Gate g) {
+  if (g.ctl && g.gate && f_gated(g.ctl, g.seq, g.gate)) return;
+  __shared__ int s_ci[kHessTile];
+  __shared__ double s_v[kHessTile];
+  __shared__ double s_W[kBlock], s_X[kBlock];
+  __shared__ double s_red[16];
+  constexpr int DH = D + 1;
+  const int idx = g.ctl ? ((g.ctl->cur ^ sel) & 1) : 0;
+  const double *__restrict__ X = Xb.p[idx];
+  double *__restrict__ EG = EGb.p[idx];
+  double *__restrict__ RG = RGb.p[idx];
+  double *__restrict__ Sblk = Sb.p[idx];
+  const int r = m.r;
+  const int PB = fused_pb(r, DH);
+  const int pose0 = blockIdx.x * PB;
+  const int npose = min(PB, m.n - pose0);
+  const int j0 = pose0 * DH, ncol = npose * DH, nout = ncol * r;
+  const int e = threadIdx.x;
+  const bool act = e < nout;
+  const int lc = e / r, t = e - lc * r;
+  const int j = j0 + lc;
+  const int pbeg = Q.rp[j0], pend = Q.rp[j0 + ncol];
+  const int myb = act ? Q.rp[j] : 0, mye = act ? Q.rp[j + 1] : 0;
+  const size_t oown = (size_t)j * r + t;
+  const double x_own = act ? X[oown] : 0.0;
+  const double g_own = (act && G) ? G[oown] : 0.0;
+  // ---- phase 1: EG = X Q + G ----
+  double acc = 0;
+  for (int base = pbeg; base < pend; base += kHessTile) {
+    const int cnt = min(kHessTile, pend - base);
+    if (base != pbeg) __syncthreads();
+    {
+      constexpr int SU = kHessTile / kBlock;
+      int ci_r[SU];
+      double v_r[SU];
+      const int last = max(pend - 1, 0);
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int i = min(base + (int)threadIdx.x + u * kBlock, last);
+        ci_r[u] = Q.ci[i];
+        v_r[u] = Q.v[i];
+      }
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int i = threadIdx.x + u * kBlock;
+        if (i < cnt) {
+          s_ci[i] = ci_r[u];
+          s_v[i] = v_r[u];
+        }
+      }
+    }
+    __syncthreads();
+    const int lo = max(myb, base) - base, hi = min(mye, base + cnt) - base;
+    for (int p = lo; p < hi; p += 8) {
+      double b8[8], w8[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const bool ok = p + q < hi;
+        const size_t oo = ok ? (size_t)s_ci[p + q] * r + t : 0;
+        w8[q] = ok ? s_v[p + q] : 0.0;
+        b8[q] = X[oo];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc += w8[q] * b8[q];
+    }
+  }
+  double d0 = 0, d1 = 0;
+  if (act) {
+    const double eg = acc + g_own;
+    EG[oown] = eg;
+    s_W[e] = eg;
+    s_X[e] = x_own;
+    d0 = acc * x_own;
+    d1 = x_own * g_own;
+  }
+  __syncthreads();
+  // ---- phase 2: RG = Proj_X(EG), S_i = sym(Y_i^T EG_i) ----
+  const int gp = threadIdx.x >> 3, tt = threadIdx.x & (GW - 1);
+  const bool pact = (gp < npose) && (tt < r);
+  const int pose = pose0 + gp;
+  const size_t o = (size_t)pose * DH * r;
+  Row<D> Y, E;
+#pragma unroll
+  for (int a = 0; a < DH; ++a) {
+    E.e[a] = pact ? s_W[(gp * DH + a) * r + tt] : 0.0;
+    Y.e[a] = pact ? s_X[(gp * DH + a) * r + tt] : 0.0;
+  }
+  double S[D][D];
+  grp_sym_gram<D>(Y, E, S);
+  if (Sblk && gp < npose && tt == 0)
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int b = 0; b < D; ++b) Sblk[(size_t)pose * D * D + a + b * D] = S[a][b];
+  row_sub_AS<D>(E, Y, S);
+  double pa = 0;
+#pragma unroll
+  for (int a = 0; a < DH; ++a) pa += E.e[a] * E.e[a];
+  if (posenorm) {
+    const double ps = grp_sum(pa);
+    if (gp < npose && tt == 0) posenorm[pose] = ps;
+  }
+  st_row<D>(RG + o, r, tt, pact, E);
+  const double t0 = f_block_sum(d0, s_red);
+  const double t1 = f_block_sum(d1, s_red);
+  const double t2 = f_block_sum(pact ? pa : 0.0, s_red);
+  if (threadIdx.x == 0) {
+    pA[2 * blockIdx.x] = t0;
+    pA[2 * blockIdx.x + 1] = t1;
+    pB[blockIdx.x] = t2;
+  }
+}
+
 // A on the block structure of Q (pose graphs large enough to carry the block-CSR copy): 8 lanes per pose from the
 // start, so phase 1 leaves W in the lane layout phase 2 works in (no LDS hand-over), one gather of the neighbour's
 // (d+1) r values per matrix block instead of (d+1)^2 scalar entries.  32 poses per workgroup.
@@ -1745,6 +1869,19 @@ int launch_g_rgrad(hipStream_t st, const ManiDesc &m, Buf2 X, Buf2 EG, Buf2 RG, 
     hipLaunchKernelGGL(k_g_rgrad<3>, dim3(grid), dim3(kBlock), 0, st, m, X, EG, RG, Sblk, sel, partials, posenorm, g);
   else
     hipLaunchKernelGGL(k_g_rgrad<2>, dim3(grid), dim3(kBlock), 0, st, m, X, EG, RG, Sblk, sel, partials, posenorm, g);
+  return grid;
+}
+// EG = X Q + G, RG = Proj_X(EG), S blocks, partials {<XQ,X>, <X,G>} in pA (2 per block) and |RG|^2 in pB (1 per
+// block); returns the number of blocks.  Small SE blocks without long rows only (the caller checks).
+int launch_fused_grad(hipStream_t st, const ManiDesc &m, const CsrDev &Q, Buf2 X, const double *G, Buf2 EG, Buf2 RG,
+                      Buf2 Sblk, int sel, double *pA, double *pB, double *posenorm, Gate g) {
+  const int grid = fused_pose_blocks(m);
+  if (m.d == 3)
+    hipLaunchKernelGGL(k_fused_grad<3>, dim3(grid), dim3(kBlock), 0, st, m, Q, X, G, EG, RG, Sblk, sel, pA, pB, posenorm,
+                       g);
+  else
+    hipLaunchKernelGGL(k_fused_grad<2>, dim3(grid), dim3(kBlock), 0, st, m, Q, X, G, EG, RG, Sblk, sel, pA, pB, posenorm,
+                       g);
   return grid;
 }
 int launch_g_retract(hipStream_t st, const ManiDesc &m, Buf2 X, const double *V, double alpha, Buf2 out, int selOut,
