@@ -649,7 +649,29 @@ def config5_run(da, with_cpu, iters=60, cpu_iters=4):
         res["coloured_rbcd"] = coloured_sweeps(SingleDriver(s), X0, sweeps=8, warm=1)
     except Exception as e:
         res["coloured_rbcd"] = {"error": str(e)}
+    Xend = s.get_X()
     s.close()
+    # the next levels of the Riemannian staircase (BASELINE: r = 5..7): the same loop at r = 6 and 7 from the r = 5
+    # iterate embedded in the higher rank (zero rows appended, as escapeSaddle's lift does before its step); the
+    # agents' preconditioners come from the cache (they do not depend on r)
+    res["staircase_ranks"] = {"5": {"value": res["value"], "ms_per_step": res["ms_per_step"], "setup_s": setup_s}}
+    for rr in (6, 7):
+        try:
+            t0 = time.perf_counter()
+            sr = da.RbcdSession(ds, num_robots=R, r=rr)
+            st_s = time.perf_counter() - t0
+            Xr = np.vstack([Xend, np.zeros((rr - r, Xend.shape[1]))])
+            sr.set_X(Xr)
+            sr.run(max_iters=3, rgrad_tol=0.0)
+            sr.set_X(Xr)
+            t0 = time.perf_counter()
+            o2 = sr.run(max_iters=30, rgrad_tol=0.0)
+            d2 = time.perf_counter() - t0
+            sr.close()
+            res["staircase_ranks"][str(rr)] = {"value": 30 / d2, "ms_per_step": 1e3 * d2 / 30, "setup_s": st_s,
+                                               "cost_2f_last": float(o2["cost"][-1])}
+        except Exception as e:
+            res["staircase_ranks"][str(rr)] = {"error": str(e)}
     try:  # 16 agents: two per GPU of an 8-GPU node, one of each colour, so that every tick keeps every GPU busy
         s16 = da.RbcdSession(ds, num_robots=16, r=r, acceleration=False)
         res["coloured_rbcd_16_agents"] = coloured_sweeps(SingleDriver(s16), X0, sweeps=6, warm=1)
@@ -669,7 +691,7 @@ def config5_run(da, with_cpu, iters=60, cpu_iters=4):
     return res
 
 
-def side_multi(da, torch, dist, rank, world, ds, R, r, workload, iters=60, sweeps=8, with16=False):
+def side_multi(da, torch, dist, rank, world, ds, R, r, workload, iters=60, sweeps=8, with16=False, more_ranks=()):
     """a BASELINE.json multi-agent config with one process per GPU (consecutive agents share a rank): same loop, the
     library's neighbour exchange between the ranks; a side measurement, never `value`"""
     rng = np.random.default_rng(20250310)
@@ -696,11 +718,29 @@ def side_multi(da, torch, dist, rank, world, ds, R, r, workload, iters=60, sweep
            "iterations": iters, "value": iters / dt, "unit": "RBCD iterations/s", "ms_per_step": 1e3 * dt / iters,
            "setup_s": drv.setup_s, "cost_2f_first": float(costs[0]), "cost_2f_last": float(costs[-1]),
            "exchange": drv.exchange_stats(iters)}
+    Xend = drv.ex.gather_X() if hasattr(drv, "ex") else None
     try:
         res["coloured_rbcd"] = coloured_sweeps(drv, X0, sweeps=sweeps, warm=1)
     except Exception as e:
         res["coloured_rbcd"] = {"error": str(e)}
     drv.close()
+    if more_ranks and Xend is not None:  # the next staircase levels, from the r iterate embedded in the higher rank
+        res["staircase_ranks"] = {str(r): {"value": res["value"], "ms_per_step": res["ms_per_step"]}}
+        for rr in more_ranks:
+            try:
+                d2 = make_driver(da, torch, dist, ds, R, rr, rank, world)
+                Xr = np.vstack([Xend, np.zeros((rr - r, Xend.shape[1]))])
+                d2.set_X(Xr)
+                st2 = (0.0, 0.0, 0)
+                for _ in range(3):
+                    st2 = d2.step(st2[2])
+                d2.set_X(Xr)
+                first2 = (0.0, 0.0, 0)
+                dt2, _o = d2.timed(lambda prev: d2.step((prev or first2)[2]), 30)
+                res["staircase_ranks"][str(rr)] = {"value": 30 / dt2, "ms_per_step": 1e3 * dt2 / 30, "setup_s": d2.setup_s}
+                d2.close()
+            except Exception as e:
+                res["staircase_ranks"][str(rr)] = {"error": str(e)}
     if with16:
         try:  # 16 agents on the chain: at 8 ranks agents 2g and 2g+1 (one of each colour) share rank g
             drv16 = make_driver(da, torch, dist, ds, 16, r, rank, world, acceleration=False)
@@ -716,7 +756,7 @@ def config5_multi(da, torch, dist, rank, world):
     ds = synth.lattice_se3()
     return side_multi(da, torch, dist, rank, world, ds, 8, 5,
                       "synthetic 50x50x40 SE(3) lattice (100000 poses, %d edges, seed 20250310), 8 agents, r=5" % ds.m,
-                      iters=60, sweeps=8, with16=True)
+                      iters=60, sweeps=8, with16=True, more_ranks=(6, 7))
 
 
 def config3_multi(da, torch, dist, rank, world):
