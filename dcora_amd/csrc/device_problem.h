@@ -148,6 +148,11 @@ class SparsePrecond {
   double bytes_per_apply(int r) const;
 };
 
+int stream_acquire(int device, hipStream_t *out);  // recycled non-blocking streams (creation costs milliseconds)
+void stream_release(int device, hipStream_t st);
+int host_flags_acquire(HostFlags **host, HostFlags **dev, int *slot);
+void host_flags_release(HostFlags *host, int slot);
+
 class DeviceProblem {
  public:
   ManiDesc m{};
@@ -179,6 +184,8 @@ class DeviceProblem {
   bool group = false;                  // SE layout, r <= 8: 8-lanes-per-pose rgrad / retract kernels (any n)
   DevBuf<double> pA, pB, pC, p1, p2, p3, scal;
   DevBuf<SolverCtl> ctl;
+  DevBuf<double> arena;         // one allocation behind every workspace buffer above (they borrow slices)
+  int hf_slot = -1;             // slot of hf in the process-wide host-mapped page (-1: a page of its own)
   HostFlags *hf = nullptr;      // host-mapped
   HostFlags *hf_dev = nullptr;  // device view of the same words
   std::vector<double> stage;    // pageable staging for host <-> device copies

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <thread>
 
 namespace dcora {
@@ -61,9 +62,82 @@ int DevBsr::upload(const HostBsr &B) {
 }
 int DevCsr::upload(const HostCsr &A) { return upload(A.n, A.ncols, A.rp.data(), A.ci.data(), A.v.data()); }
 
+// HostFlags words live in one host-mapped page per process, handed out slot by slot: hipHostMalloc per problem cost
+// more than the rest of a cached creation
+namespace {
+constexpr int kFlagSlots = 1024;
+constexpr size_t kFlagStride = 64;  // one line per problem: the words are written over PCIe by different streams
+static_assert(sizeof(HostFlags) <= kFlagStride, "HostFlags slot");
+std::mutex g_flag_mu;
+HostFlags *g_flag_host = nullptr, *g_flag_dev = nullptr;
+std::vector<int> g_flag_free;
+}  // namespace
+// HIP streams are recycled too: hipStreamCreateWithFlags took 1.7-8.5 ms of a 2-9 ms cached problem creation
+// (DCORA_INIT_TIMING), hipStreamDestroy another 1-2 ms.  Idle non-blocking streams are kept per device.
+namespace {
+std::mutex g_stream_mu;
+std::vector<std::pair<int, hipStream_t>> g_idle_streams;
+}  // namespace
+int stream_acquire(int device, hipStream_t *out) {
+  {
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    for (size_t i = 0; i < g_idle_streams.size(); ++i)
+      if (g_idle_streams[i].first == device) {
+        *out = g_idle_streams[i].second;
+        g_idle_streams.erase(g_idle_streams.begin() + (long)i);
+        return DCORA_OK;
+      }
+  }
+  DCORA_HIP(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+  return DCORA_OK;
+}
+void stream_release(int device, hipStream_t st) {
+  if (!st) return;
+  (void)hipStreamSynchronize(st);
+  std::lock_guard<std::mutex> lk(g_stream_mu);
+  if (g_idle_streams.size() < 256) {
+    g_idle_streams.emplace_back(device, st);
+    return;
+  }
+  (void)hipStreamDestroy(st);
+}
+
+int host_flags_acquire(HostFlags **host, HostFlags **dev, int *slot) {
+  std::lock_guard<std::mutex> lk(g_flag_mu);
+  if (!g_flag_host) {
+    DCORA_HIP(hipHostMalloc((void **)&g_flag_host, kFlagStride * kFlagSlots, hipHostMallocMapped | hipHostMallocPortable));
+    std::memset((void *)g_flag_host, 0, kFlagStride * kFlagSlots);
+    DCORA_HIP(hipHostGetDevicePointer((void **)&g_flag_dev, (void *)g_flag_host, 0));
+    for (int i = kFlagSlots - 1; i >= 0; --i) g_flag_free.push_back(i);
+  }
+  if (g_flag_free.empty()) {  // more live problems than slots: a page of its own
+    DCORA_HIP(hipHostMalloc((void **)host, sizeof(HostFlags), hipHostMallocMapped | hipHostMallocPortable));
+    std::memset((void *)*host, 0, sizeof(HostFlags));
+    DCORA_HIP(hipHostGetDevicePointer((void **)dev, (void *)*host, 0));
+    *slot = -1;
+    return DCORA_OK;
+  }
+  *slot = g_flag_free.back();
+  g_flag_free.pop_back();
+  *host = (HostFlags *)((char *)g_flag_host + kFlagStride * (size_t)*slot);
+  *dev = (HostFlags *)((char *)g_flag_dev + kFlagStride * (size_t)*slot);
+  std::memset((void *)*host, 0, sizeof(HostFlags));
+  return DCORA_OK;
+}
+void host_flags_release(HostFlags *host, int slot) {
+  if (!host) return;
+  if (slot < 0) {
+    (void)hipHostFree((void *)host);
+    return;
+  }
+  std::lock_guard<std::mutex> lk(g_flag_mu);
+  g_flag_free.push_back(slot);
+}
+
 DeviceProblem::~DeviceProblem() {
-  if (hf) (void)hipHostFree((void *)hf);
-  if (own_stream && st) (void)hipStreamDestroy(st);
+  if (st) (void)hipStreamSynchronize(st);  // nothing of this problem is in flight when its flag words are recycled
+  host_flags_release(hf, hf_slot);
+  if (own_stream && st) stream_release(device, st);
 }
 
 int DeviceProblem::upload(const double *h, double *d, size_t n) {
@@ -82,6 +156,13 @@ int DeviceProblem::init(const dcora_dims &dims, const HostCsr &Qh, const double 
     set_last_error("bad dims (need 1 <= r <= 16, d in {2,3})");
     return DCORA_ERR_BAD_ARG;
   }
+  const bool init_timing = std::getenv("DCORA_INIT_TIMING") != nullptr;
+  const auto ti0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (init_timing)
+      std::fprintf(stderr, "[init] %-12s %.3f ms\n", what,
+                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ti0).count());
+  };
   m = make_mani(dims.r, dims.d, dims.n, dims.l, dims.b);
   if (Qh.n != m.k) {
     set_last_error("Q dimension does not match (d+1) n + l + b");
@@ -99,11 +180,14 @@ int DeviceProblem::init(const dcora_dims &dims, const HostCsr &Qh, const double 
     st = shared;
     own_stream = false;
   } else {
-    DCORA_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    const int rcs = stream_acquire(device, &st);
+    if (rcs) return rcs;
     own_stream = true;
   }
+  lap("stream");
   int rc = Q.upload(Qh);
   if (rc) return rc;
+  lap("Q upload");
   // block form of Q for graphs large enough to be bandwidth-bound (the scalar-CSR kernel exposes more parallelism
   // and wins while the launch is latency-bound); DCORA_QAPPLY=bsr|csr overrides
   const char *qa = std::getenv("DCORA_QAPPLY");
@@ -115,31 +199,49 @@ int DeviceProblem::init(const dcora_dims &dims, const HostCsr &Qh, const double 
   }
   const size_t N = (size_t)nelem();
   const size_t NS = (size_t)m.n * m.d * m.d + m.l + 1;
-  DCORA_HIP(G.alloc(N));
-  DCORA_HIP(hipMemset(G.p, 0, N * sizeof(double)));
-  for (DevBuf<double> *b : {&X0, &X1, &EG0, &EG1, &RG0, &RG1, &delta, &eta, &Heta, &res, &z, &Hd, &W, &Zt})
-    DCORA_HIP(b->alloc(N));
   // (the fused Hessian kernel stages the first matrix tile with clamped, unconditional loads: it needs nnz > 0)
   fused = fused_supported(m) && Qh.nnz() > 0 && (std::getenv("DCORA_SOLVER_V1") == nullptr);
   group = group_supported(m) && (std::getenv("DCORA_SOLVER_V1") == nullptr);
-  if (fused) {
-    DCORA_HIP(delta2.alloc(N));
-    DCORA_HIP(res2.alloc(N));
-    DCORA_HIP(Zpart.alloc((size_t)fused_nsplit(m) * N));  // slice 0 doubles as Z of the sparse preconditioner
-    DCORA_HIP(hipMemset(delta2.p, 0, N * sizeof(double)));
+  // One allocation for the whole solver workspace, zeroed by one memset: the reference re-creates its problem on
+  // every Agent::updateX (ref src/Agent.cpp:1252), so creation must cost a fraction of a solve -- thirty hipMalloc
+  // and ten synchronous hipMemset calls took 4-8 ms.
+  {
+    struct Slot {
+      DevBuf<double> *b;
+      size_t n;
+    };
+    std::vector<Slot> slots;
+    for (DevBuf<double> *b : {&G, &X0, &X1, &EG0, &EG1, &RG0, &RG1, &delta, &eta, &Heta, &res, &z, &Hd, &W, &Zt})
+      slots.push_back({b, N});
+    if (fused) {
+      slots.push_back({&delta2, N});
+      slots.push_back({&res2, N});
+      slots.push_back({&Zpart, (size_t)fused_nsplit(m) * N});  // slice 0 doubles as Z of the sparse preconditioner
+    }
+    slots.push_back({&S0, NS});
+    slots.push_back({&S1, NS});
+    // 2 doubles per slot; the Q-apply may add up to kMaxPartials / 2 long-row blocks to its kMaxPartials row blocks
+    for (DevBuf<double> *b : {&pB, &pC, &p1, &p2, &p3}) slots.push_back({b, (size_t)4 * kMaxPartials});
+    slots.push_back({&pA, 2 * (size_t)kBsrMaxGrid});  // the block-CSR Q-apply runs up to kBsrMaxGrid workgroups
+    slots.push_back({&scal, 64});
+    auto pad = [](size_t n) { return (n + 31) & ~(size_t)31; };  // 256-byte aligned slices
+    size_t total = 0;
+    for (const Slot &sl : slots) total += pad(sl.n);
+    DCORA_HIP(arena.alloc(total));
+    DCORA_HIP(hipMemsetAsync(arena.p, 0, total * sizeof(double), st));
+    size_t off = 0;
+    for (const Slot &sl : slots) {
+      sl.b->borrow(arena.p + off, sl.n);
+      off += pad(sl.n);
+    }
   }
-  for (DevBuf<double> *b : {&delta, &eta, &Heta, &res, &z, &Hd, &W, &Zt})
-    DCORA_HIP(hipMemset(b->p, 0, N * sizeof(double)));
-  DCORA_HIP(S0.alloc(NS));
-  DCORA_HIP(S1.alloc(NS));
-  // 2 doubles per slot; the Q-apply may add up to kMaxPartials / 2 long-row blocks to its kMaxPartials row blocks
-  for (DevBuf<double> *b : {&pB, &pC, &p1, &p2, &p3}) DCORA_HIP(b->alloc(4 * kMaxPartials));
-  DCORA_HIP(pA.alloc(2 * (size_t)kBsrMaxGrid));  // the block-CSR Q-apply runs up to kBsrMaxGrid workgroups
-  DCORA_HIP(scal.alloc(64));
   DCORA_HIP(ctl.alloc(1));
-  DCORA_HIP(hipHostMalloc((void **)&hf, sizeof(HostFlags), hipHostMallocMapped));
-  std::memset((void *)hf, 0, sizeof(HostFlags));
-  DCORA_HIP(hipHostGetDevicePointer((void **)&hf_dev, (void *)hf, 0));
+  {
+    const int rc2 = host_flags_acquire(&hf, &hf_dev, &hf_slot);
+    if (rc2) return rc2;
+  }
+  DCORA_HIP(hipStreamSynchronize(st));  // the zeroed workspace is visible to every stream before the first upload
+  lap("workspace");
   if (Gh) {
     rc = set_G_host(Gh);
     if (rc) return rc;
@@ -148,6 +250,7 @@ int DeviceProblem::init(const dcora_dims &dims, const HostCsr &Qh, const double 
     rc = build_preconditioner(Qh, reg);
     if (rc) return rc;
   }
+  lap("precond");
   return DCORA_OK;
 }
 

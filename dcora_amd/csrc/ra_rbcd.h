@@ -31,6 +31,7 @@ class RaRbcdSession {
   int d = 0, r = 0, n = 0, l = 0, b = 0, k = 0, R = 0;
   dcora_rbcd_options opt{};
   hipStream_t st = nullptr;
+  int device_of_stream_ = 0;
   std::vector<RaAgentDev> agents;
   std::unique_ptr<DeviceProblem> central;  // global Q: cost and Riemannian gradient of the merged problem
   DevBuf<double> Xg;                       // r x k global mirror (RA ordering)

@@ -25,7 +25,7 @@ int device_precond_regularization(const HostCsr &Q, int device, double *reg) {
 RaRbcdSession::~RaRbcdSession() {
   agents.clear();
   central.reset();
-  if (st) (void)hipStreamDestroy(st);
+  if (st) stream_release(device_of_stream_, st);
 }
 
 int RaRbcdSession::init(const HostRADataset &ds, const dcora_rbcd_options &o) {
@@ -69,7 +69,11 @@ int RaRbcdSession::init(const HostRADataset &ds, const dcora_rbcd_options &o) {
     set_last_error("ra_rbcd: bad number of robots");
     return DCORA_ERR_UNSUPPORTED;
   }
-  DCORA_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  {
+    const int rcs = stream_acquire(o.device, &st);
+    if (rcs) return rcs;
+    device_of_stream_ = o.device;
+  }
   const HostCsr Q = build_Q_ra(ds);
   const size_t N = (size_t)r * k;
   DCORA_HIP(Xg.alloc(N));

@@ -43,13 +43,13 @@ RbcdSession::~RbcdSession() {
   if (eval_host) (void)hipHostFree((void *)eval_host);
   if (x_stage) (void)hipHostFree((void *)x_stage);
   for (AgentDev &a : agents) {
-    if (a.own) (void)hipStreamDestroy(a.own);
+    if (a.own) stream_release(opt.device, a.own);
     if (a.done) (void)hipEventDestroy(a.done);
   }
   if (fork_ev_) (void)hipEventDestroy(fork_ev_);
   agents.clear();
   central.reset();
-  if (st && own_stream_) (void)hipStreamDestroy(st);
+  if (st && own_stream_) stream_release(opt.device, st);
 }
 
 int RbcdSession::init(const HostDataset &ds, const dcora_rbcd_options &o) {
@@ -85,7 +85,8 @@ int RbcdSession::init(const HostDataset &ds, const dcora_rbcd_options &o) {
     st = (hipStream_t)o.stream;
     own_stream_ = false;
   } else {
-    DCORA_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    const int rcs = stream_acquire(o.device, &st);
+    if (rcs) return rcs;
   }
   mg = make_mani(r, d, n, 0, 0);
   const size_t N = (size_t)r * dh * n;
@@ -163,7 +164,7 @@ int RbcdSession::init(const HostDataset &ds, const dcora_rbcd_options &o) {
       HostCsr C = build_coupling_pgo(d, P, b, global);
       rc = a.coupling.upload(C);
     }
-    if (!rc && hipStreamCreateWithFlags(&a.own, hipStreamNonBlocking) != hipSuccess) rc = DCORA_ERR_HIP;
+    if (!rc) rc = stream_acquire(o.device, &a.own);
     if (!rc && hipEventCreateWithFlags(&a.done, hipEventDisableTiming) != hipSuccess) rc = DCORA_ERR_HIP;
     if (rc && err) *err = dcora_last_error();
     return rc;
