@@ -277,7 +277,7 @@ bool load_pyfg(const std::string &path, HostRADataset &ds, std::string &err) {
   while (std::getline(in, line)) {
     std::istringstream ss(line);
     if (!(ss >> tok)) continue;
-    SymH a, b;
+    SymH a;
     if (tok == "VERTEX_SE2" || tok == "VERTEX_SE3:QUAT") {
       const int d = tok == "VERTEX_SE2" ? 2 : 3;
       ds.d = d;

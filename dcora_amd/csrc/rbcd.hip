@@ -175,7 +175,7 @@ int RbcdSession::init(const HostDataset &ds, const dcora_rbcd_options &o) {
     std::vector<std::string> errs(nh);
     static const bool serial = std::getenv("DCORA_SERIAL_SETUP") != nullptr;
     // small blocks build in well under a millisecond of host work each: threads only pay off for large ones
-    if (nh > 1 && !serial && (long)(n / R) * dh >= 8192) {
+    if (nh > 1 && !serial && (long)(n / R) * dh >= 1024) {
       std::atomic<size_t> next(0);
       auto worker = [&] {
         for (;;) {

@@ -27,9 +27,6 @@ __device__ __forceinline__ bool f_gated(const SolverCtl *ctl, int seq, int gate)
   if (gate == 2 && seq > ctl->tcg_done_stamp) return true;
   return false;
 }
-__device__ __forceinline__ double *f_pick(const Buf2 &b, const SolverCtl *ctl, int sel) {
-  return b.p[(ctl->cur ^ sel) & 1];
-}
 // Wave-wide sum, same value in every lane.  Data-parallel-primitive moves inside the 16-lane rows (xor 1, xor 2,
 // mirror of 8, mirror of 16: no LDS crossbar round trips as with __shfl_xor / ds_bpermute), then the four row sums
 // are read as scalars.  Fixed order => reproducible.
@@ -69,11 +66,6 @@ __device__ __forceinline__ double f_partial4_load(const double *__restrict__ p, 
 __device__ __forceinline__ int f_partial_index(int np) { return np <= 64 ? (int)(threadIdx.x & 63u) : (int)threadIdx.x; }
 __device__ __forceinline__ double f_partial_total(double v, int np, double *sm) {
   return np <= 64 ? f_wave_sum(v) : f_block_sum(v, sm);
-}
-__device__ __forceinline__ double f_sum_partials(const double *p, int np, int stride, int off, double *sm) {
-  double v = 0;
-  for (int i = threadIdx.x; i < np; i += blockDim.x) v += p[(size_t)i * stride + off];
-  return f_block_sum(v, sm);
 }
 __device__ __forceinline__ void f_host_store(volatile int *p, int v) {
   __hip_atomic_store(const_cast<int *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -694,7 +686,7 @@ __global__ __launch_bounds__(kBlock) void k_fused_precond(int r, int k, int ldm,
   const int col = jc * kJChunk + 2 * lane;
   const int cn0 = min(kRowChunk, c_hi - c_lo);
   const int per_wave0 = (cn0 + 3) / 4;
-  const int w_lo0 = min(cn0, wave * per_wave0), w_hi0 = min(cn0, w_lo0 + per_wave0);
+  const int w_lo0 = min(cn0, wave * per_wave0);
   const double *__restrict__ rsrc = first ? gradb.p[cur] : res_old;
   // own element of the vector updates and own entries of the residual slice: loaded before alpha is known
   const long i0 = (long)blockIdx.x * kBlock + threadIdx.x;
