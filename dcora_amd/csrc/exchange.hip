@@ -163,7 +163,7 @@ int Exchange::map_segment(const char *job_name, size_t x_doubles) {
   off_flags_ = off;
   off += sizeof(ShmFlag) * 2 * R;
   off_evals_ = off;
-  off += sizeof(ShmEval) * 2 * R;
+  off += sizeof(ShmEval) * 2 * (R + world);  // R agent slots + one heartbeat slot per rank, double-buffered
   off = align_up(off, 4096);
   off_staged_ = off;
   off += sizeof(double) * 2 * R * slot_;
@@ -433,13 +433,29 @@ int Exchange::evaluate(double *cost2, double *gradnorm, double *block_norms, int
   if (rc) return rc;
   const uint64_t want = ++eval_seq_;
   const int parity = (int)(want & 1);
-  ShmEval *slots_dev = (ShmEval *)(dev_map_ + off_evals_) + (size_t)parity * R;
+  const size_t per_parity = (size_t)R + world;
+  ShmEval *slots_dev = (ShmEval *)(dev_map_ + off_evals_) + (size_t)parity * per_parity;
   if (n_hosted_)
     hipLaunchKernelGGL(k_eval_publish, dim3(1), dim3(64), 0, s_->st, n_hosted_, hosted_list_.p, evalbuf_.p, slots_dev,
                        want);
   DCORA_HIP(hipGetLastError());
   const auto t0 = Clock::now();
-  const ShmEval *sl = evals_ + (size_t)parity * R;
+  ShmEval *sl = evals_ + (size_t)parity * per_parity;
+  // Heartbeat of this rank: every rank -- also one that hosts no agent and therefore publishes nothing -- says that
+  // it has entered evaluation `want`, and nobody leaves it before all have.  A rank can then never be lapped: the
+  // slot of parity `want` is overwritten at evaluation want + 2, which every writer enters only after all ranks have
+  // entered want + 1, i.e. after they have finished reading `want`.
+  std::atomic_thread_fence(std::memory_order_release);
+  sl[R + rank].seq = want;
+  for (int q = 0; q < world; ++q) {
+    unsigned spins = 0;
+    while (sl[R + q].seq < want) {
+      if ((++spins & 4095u) == 0) {
+        if (hdr_->failed.load()) return fail("another rank failed", DCORA_ERR_HIP);
+        if (since(t0) > 120.0) return fail("rank " + std::to_string(q) + " never entered the evaluation", DCORA_ERR_HIP);
+      }
+    }
+  }
   double g2 = 0, c2 = 0, best = -1;
   int arg = 0;
   for (int a = 0; a < R; ++a) {
@@ -570,16 +586,32 @@ int Exchange::host_selftest(const char *job_name, int rank_, int world_, int R, 
       for (size_t i = 0; i < slot_; ++i)
         if (src[i] != 1000.0 * q + 16.0 * a + (double)i) return fail("host selftest: payload mismatch", DCORA_ERR_HIP);
     }
+    const size_t per_parity = (size_t)R + world;
     for (int a = 0; a < R; ++a) {
       if (a / per != rank) continue;
-      ShmEval *e = evals_ + (size_t)parity * R + a;
+      ShmEval *e = evals_ + (size_t)parity * per_parity + a;
       e->g2 = q + 0.5 * a;
       e->xeg = q * 0.25 - a;
       std::atomic_thread_fence(std::memory_order_release);
       e->seq = (uint64_t)q;
     }
+    {  // the rank's heartbeat (see Exchange::evaluate): a rank without agents must not be lapped either
+      ShmEval *hb = evals_ + (size_t)parity * per_parity + R;
+      std::atomic_thread_fence(std::memory_order_release);
+      hb[rank].seq = (uint64_t)q;
+      for (int p2 = 0; p2 < world; ++p2) {
+        unsigned spins = 0;
+        while (hb[p2].seq < (uint64_t)q) {
+          if ((++spins & 1023u) == 0) {
+            if (hdr_->failed.load()) return fail("another rank failed", DCORA_ERR_HIP);
+            if (since(t0) > 60.0) return fail("host selftest: a heartbeat never arrived", DCORA_ERR_HIP);
+            sched_yield();
+          }
+        }
+      }
+    }
     for (int a = 0; a < R; ++a) {
-      const ShmEval *e = evals_ + (size_t)parity * R + a;
+      const ShmEval *e = evals_ + (size_t)parity * per_parity + a;
       unsigned spins = 0;
       while (e->seq < (uint64_t)q) {
         if ((++spins & 1023u) == 0) {
