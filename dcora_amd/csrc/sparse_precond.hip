@@ -46,38 +46,51 @@ struct HubDev {
   const double *aval, *U, *Sinv;
   double *w;  // h x r scratch: b2 - a^T y1
 };
-// w(q, :) = R(hub_q, :) - sum_p a_q[p] y1(pos_p, :)   -- one block per hub unknown
-__global__ __launch_bounds__(kBlock) void k_sp_hub_dot(int r, HubDev H, Buf2 Rb, const double *__restrict__ y,
-                                                       Gate g) {
+// w(q, :) = R(hub_q, :) - sum_p a_q[p] y1(pos_p, :).  The sum over the hub's column (thousands of entries: a landmark
+// ranged from every pose) is split over kHubSplit workgroups per hub; each writes its partial to wpart[q][slice][t]
+// and k_sp_permute_out_hub adds the slices in a fixed order (one workgroup per hub took 27 us on tiers.pyfg).
+constexpr int kHubSplit = 32;
+__global__ __launch_bounds__(kBlock) void k_sp_hub_dot(int r, HubDev H, const double *__restrict__ y, Gate g) {
   if (sp_gated(g.ctl, g.seq, g.gate)) return;
   __shared__ double s_part[kBlock];
-  const double *__restrict__ R = Rb.p[g.ctl ? (g.ctl->cur & 1) : 0];
-  const int q = blockIdx.x;
+  const int q = blockIdx.x / kHubSplit, sl = blockIdx.x - q * kHubSplit;
   const int RB = kBlock / r;
   const int lj = threadIdx.x / r, t = threadIdx.x - lj * r;
+  const int beg = H.ap[q], end = H.ap[q + 1];
+  const int per = (end - beg + kHubSplit - 1) / kHubSplit;
+  const int lo = beg + sl * per, hi = min(end, lo + per);
   double acc = 0;
   if (lj < RB)
-    for (int p = H.ap[q] + lj; p < H.ap[q + 1]; p += RB) acc += H.aval[p] * y[(size_t)H.apos[p] * r + t];
+    for (int p = lo + lj; p < hi; p += RB) acc += H.aval[p] * y[(size_t)H.apos[p] * r + t];
   s_part[threadIdx.x] = (lj < RB) ? acc : 0.0;
   __syncthreads();
   if ((int)threadIdx.x < r) {
     double s = 0;
     for (int u = 0; u < RB; ++u) s += s_part[u * r + threadIdx.x];
-    H.w[(size_t)q * r + threadIdx.x] = R[(size_t)H.idx[q] * r + threadIdx.x] - s;
+    H.w[((size_t)q * kHubSplit + sl) * r + threadIdx.x] = s;
   }
 }
 // x2 = Sinv w (recomputed by every block: h r values);  Z[perm[j]] = y1[j] - U(j, :) x2;  Z[hub_q] = x2(q, :)
 __global__ __launch_bounds__(kBlock) void k_sp_permute_out_hub(int r, int k, const int *__restrict__ perm,
                                                                const int *__restrict__ out_off,
                                                                const double *__restrict__ y,
-                                                               double *__restrict__ Z, HubDev H, Gate g) {
+                                                               double *__restrict__ Z, HubDev H, Buf2 Rb, Gate g) {
   if (sp_gated(g.ctl, g.seq, g.gate)) return;
   __shared__ double s_x2[64 * 16];
+  __shared__ double s_w[64 * 16];
+  const double *__restrict__ R = Rb.p[g.ctl ? (g.ctl->cur & 1) : 0];
   const int h = H.h;
+  for (int e = threadIdx.x; e < h * r; e += kBlock) {  // w = b2 - a^T y1: the slices of k_sp_hub_dot in order
+    const int q = e / r, t = e - q * r;
+    double s = 0;
+    for (int sl = 0; sl < kHubSplit; ++sl) s += H.w[((size_t)q * kHubSplit + sl) * r + t];
+    s_w[e] = R[(size_t)H.idx[q] * r + t] - s;
+  }
+  __syncthreads();
   for (int e = threadIdx.x; e < h * r; e += kBlock) {
     const int q = e / r, t = e - q * r;
     double s = 0;
-    for (int q2 = 0; q2 < h; ++q2) s += H.Sinv[(size_t)q * h + q2] * H.w[(size_t)q2 * r + t];
+    for (int q2 = 0; q2 < h; ++q2) s += H.Sinv[(size_t)q * h + q2] * s_w[q2 * r + t];
     s_x2[e] = s;
     if (blockIdx.x == 0) Z[(size_t)H.idx[q] * r + t] = s;
   }
@@ -304,8 +317,8 @@ int SparsePrecond::attach(std::shared_ptr<const SpImage> image, int rcap_) {
   DCORA_HIP(y.alloc((size_t)(2 * k + 2) * rcap));
   DCORA_HIP(hipMemset(y.p, 0, (size_t)(2 * k + 2) * rcap * sizeof(double)));
   if (im->nhub > 0) {
-    DCORA_HIP(hub_w.alloc((size_t)im->nhub * rcap));
-    DCORA_HIP(hipMemset(hub_w.p, 0, (size_t)im->nhub * rcap * sizeof(double)));
+    DCORA_HIP(hub_w.alloc((size_t)im->nhub * kHubSplit * rcap));
+    DCORA_HIP(hipMemset(hub_w.p, 0, (size_t)im->nhub * kHubSplit * rcap * sizeof(double)));
   }
   return DCORA_OK;
 }
@@ -327,8 +340,8 @@ void SparsePrecond::apply(hipStream_t st, int r, Buf2 R, double *Z, Gate g, bool
   if (levels_only) return;
   if (nhub > 0) {
     HubDev H{nhub, hub_idx.p, hub_ap.p, hub_apos.p, hub_aval.p, hub_U.p, hub_Sinv.p, hub_w.p};
-    hipLaunchKernelGGL(k_sp_hub_dot, dim3(nhub), dim3(kBlock), 0, st, r, H, R, y.p, g);
-    hipLaunchKernelGGL(k_sp_permute_out_hub, dim3(grid), dim3(kBlock), 0, st, r, k, perm.p, out_off.p, y.p, Z, H, g);
+    hipLaunchKernelGGL(k_sp_hub_dot, dim3(nhub * kHubSplit), dim3(kBlock), 0, st, r, H, y.p, g);
+    hipLaunchKernelGGL(k_sp_permute_out_hub, dim3(grid), dim3(kBlock), 0, st, r, k, perm.p, out_off.p, y.p, Z, H, R, g);
   } else {
     hipLaunchKernelGGL(k_sp_permute_out, dim3(grid), dim3(kBlock), 0, st, r, k, perm.p, out_off.p, y.p, Z, g);
   }
