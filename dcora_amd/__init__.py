@@ -393,6 +393,31 @@ def is_psd(S, block=1):
     return bool(out.value)
 
 
+def is_psd_device(S, block=1, device=0, info=False):
+    """the PSD test with the numeric factorisation on the device (dcora_cert_is_psd_device)"""
+    out = C.c_int()
+    i6 = np.zeros(8)
+    check(capi.lib().dcora_cert_is_psd_device(S.n, S.rp, S.ci, S.v, block, device, C.byref(out), i6))
+    if info:
+        return bool(out.value), {"symbolic_ms": i6[0], "numeric_ms": i6[1], "arena_bytes": i6[2], "flops": i6[3],
+                                 "levels": int(i6[4]), "launches": int(i6[5]), "logdet": i6[6],
+                                 "lookup_ms": i6[7]}
+    return bool(out.value)
+
+
+def chol_host_selftest(S, block=1):
+    """(is_pd, max |P A P^T - L L^T|, info) of the multifrontal schedule executed on the host (validation only)"""
+    out, res = C.c_int(), C.c_double()
+    i4 = np.zeros(4)
+    check(capi.lib().dcora_chol_host_selftest(S.n, S.rp, S.ci, S.v, block, C.byref(out), C.byref(res), i4))
+    return bool(out.value), res.value, {"pieces": int(i4[0]), "levels": int(i4[1]), "arena": int(i4[2]),
+                                        "flops": i4[3]}
+
+
+def chol_cache_clear():
+    check(capi.lib().dcora_chol_cache_clear())
+
+
 def min_eig(S, max_iterations=1000, tol=1e-3, ncv=20, seed=12345, device=0):
     lam, mv = C.c_double(), C.c_long()
     v = np.zeros(S.n)

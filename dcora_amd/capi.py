@@ -88,6 +88,9 @@ SIGNATURES = {
     "dcora_csr_destroy": (C.c_int, [_vp]),
     "dcora_cert_dual_matrix": (C.c_int, [C.POINTER(Dims), _dp, _ip, _ip, _dp, C.c_int, C.POINTER(_vp)]),
     "dcora_cert_is_psd": (C.c_int, [C.c_int, _ip, _ip, _dp, C.c_int, _PI]),
+    "dcora_cert_is_psd_device": (C.c_int, [C.c_int, _ip, _ip, _dp, C.c_int, C.c_int, _PI, _dp]),
+    "dcora_chol_host_selftest": (C.c_int, [C.c_int, _ip, _ip, _dp, C.c_int, _PI, _PD, _dp]),
+    "dcora_chol_cache_clear": (C.c_int, []),
     "dcora_cert_min_eig": (C.c_int, [C.c_int, _ip, _ip, _dp, C.c_int, C.c_double, C.c_int, C.c_ulonglong, C.c_int,
                                      _PD, _dp, C.POINTER(C.c_long)]),
     "dcora_cert_fast_verification": (C.c_int, [C.c_int, _ip, _ip, _dp, C.c_double, C.c_int, C.c_int, _PI, _PD, _dp,

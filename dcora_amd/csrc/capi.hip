@@ -5,6 +5,7 @@
 
 #include "../../include/dcora_hip.h"
 #include "cert.h"
+#include "device_chol.h"
 #include "device_problem.h"
 #include "host_graph.h"
 #include "ra_rbcd.h"
@@ -429,6 +430,62 @@ int dcora_cert_is_psd(int k, const int *rp, const int *ci, const double *v, int 
   *is_psd = psd ? 1 : 0;
   return rc;
   DCORA_CATCH
+}
+int dcora_cert_is_psd_device(int k, const int *rp, const int *ci, const double *v, int block, int device, int *is_psd,
+                             double *info8) {
+  DCORA_TRY
+  bool pd = false;
+  const int rc = device_chol_is_pd(view_csr(k, rp, ci, v), block, device, &pd, info8);
+  *is_psd = pd ? 1 : 0;
+  return rc;
+  DCORA_CATCH
+}
+int dcora_chol_host_selftest(int k, const int *rp, const int *ci, const double *v, int block, int *is_pd,
+                             double *resid, double *info4) {
+  DCORA_TRY
+  if (k > 4096) {
+    set_last_error("dcora_chol_host_selftest: dense check, k <= 4096");
+    return DCORA_ERR_BAD_ARG;
+  }
+  const HostCsr A = view_csr(k, rp, ci, v);
+  CholSymbolic S;
+  chol_symbolic(A, block, &S);
+  std::vector<double> F;
+  const bool ok = chol_numeric_host(S, v, &F);
+  *is_pd = ok ? 1 : 0;
+  if (info4) {
+    info4[0] = (double)S.pieces.size();
+    info4[1] = (double)S.nlev;
+    info4[2] = (double)S.arena;
+    info4[3] = S.flops;
+  }
+  if (resid) *resid = 0;
+  if (!ok || !resid) return DCORA_OK;
+  std::vector<double> L((size_t)k * k, 0.0), M((size_t)k * k, 0.0);
+  for (const CholPiece &P : S.pieces) {
+    const long long f = (long long)P.c + P.m;
+    for (int j = 0; j < P.c; ++j) {
+      for (int i = j; i < P.c; ++i) L[(size_t)(P.c0 + i) * k + P.c0 + j] = F[(size_t)(P.off + i * f + j)];
+      for (int a = 0; a < P.m; ++a)
+        L[(size_t)S.rows[(size_t)P.rows_off + a] * k + P.c0 + j] = F[(size_t)(P.off + (P.c + a) * f + j)];
+    }
+  }
+  for (int io = 0; io < k; ++io)
+    for (int p = rp[io]; p < rp[io + 1]; ++p) M[(size_t)S.iperm[io] * k + S.iperm[ci[p]]] = v[p];
+  double worst = 0;
+  for (int i = 0; i < k; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double s = 0;
+      for (int l = 0; l <= j; ++l) s += L[(size_t)i * k + l] * L[(size_t)j * k + l];
+      worst = std::max(worst, std::fabs(s - M[(size_t)i * k + j]));
+    }
+  *resid = worst;
+  return DCORA_OK;
+  DCORA_CATCH
+}
+int dcora_chol_cache_clear(void) {
+  chol_cache_clear();
+  return DCORA_OK;
 }
 int dcora_cert_min_eig(int k, const int *rp, const int *ci, const double *v, int max_iterations, double tol, int ncv,
                        unsigned long long seed, int device, double *lambda_min, double *vec, long *num_matvecs) {

@@ -11,6 +11,7 @@
 #include <thread>
 
 #include "cert.h"
+#include "device_chol.h"
 #include "device_problem.h"
 
 namespace dcora {
@@ -390,7 +391,13 @@ int host_is_psd(const HostCsr &S, int block, bool *psd) {
 int device_fast_verification(const HostCsr &S, double eta, int block, int device, bool *psd, double *theta,
                              std::vector<double> *x, double *lambda_min, long *matvecs) {
   HostCsr M = csr_shift_diag(S, eta);
-  int rc = host_is_psd(M, block, psd);
+  // the PSD test: LL^T of S + eta I succeeds <=> PSD up to eta (ref src/DCORA_utils.cpp:1737-1747), factorised on the
+  // device (device_chol.h); DCORA_PSD_HOST=1 keeps the host factorisation for A/B measurements
+  static const bool on_host = [] {
+    const char *e = std::getenv("DCORA_PSD_HOST");
+    return e && atoi(e) != 0;
+  }();
+  int rc = on_host ? host_is_psd(M, block, psd) : device_chol_is_pd(M, block, device, psd);
   if (rc) return rc;
   if (*psd) return DCORA_OK;
   LanczosResult e;

@@ -1,0 +1,62 @@
+// Sparse Cholesky factorisation on the device: the numeric half of the positive-semidefiniteness test of the dual
+// certificate (ref src/DCORA_utils.cpp:1737-1747, isSparseSymmetricMatrixPSD: CHOLMOD LL^T of S + eta I, PSD <=> the
+// factorisation succeeds) and of every other complete factorisation the path needs.
+//
+// Method: multifrontal LL^T over the pieces of the nested dissection of host_sparse.cpp (leaf sub-domains and
+// separators, each a contiguous column range of the permuted matrix).  A piece s with c columns and m rows below
+// them owns a dense front of (c + m)^2 doubles; the fronts of ALL pieces live in one arena (sized for 288 GB of HBM:
+// no stack, no reuse, so every front of a tree level can be worked on at once).  A level of the piece tree is
+//   extend-add of the children's Schur complements (one launch per child slot: fixed order, no atomics),
+//   then a blocked right-looking partial factorisation of the level's fronts, 64 columns at a time:
+//   diagonal block (one workgroup per front: LL^T in LDS, its inverse for the panel), panel = rows * L^-T and the
+//   trailing update as 64 x 64 register-tiled fp64 products.
+// A pivot that is not positive sets a flag that turns every later launch into a no-op (CHOLMOD's
+// quick_return_if_not_posdef).  The host does the symbolic analysis once per sparsity pattern (ordering, piece
+// structures closed under the piece tree, scatter map of the matrix entries); it is cached on the pattern.
+#pragma once
+#include <cstddef>
+#include <memory>
+#include <vector>
+
+#include "host_sparse.h"
+
+namespace dcora {
+
+constexpr int kCholNb = 64;  // panel width of the dense partial factorisations
+
+struct CholPiece {
+  long long off = 0;  // front, row-major (c + m) x (c + m), lower triangle meaningful
+  int c0 = 0, c = 0, m = 0;
+  int parent = -1, level = 0;
+  int rows_off = 0;   // into rows / rel: the m rows below the piece (permuted numbering, ascending)
+};
+
+struct CholSymbolic {
+  int n = 0, nlev = 0;
+  std::vector<int> perm, iperm;
+  std::vector<CholPiece> pieces;
+  std::vector<int> rows;          // concatenated row lists
+  std::vector<int> rel;           // same layout: index of the row inside the PARENT's front
+  std::vector<long long> a_dest;  // per stored entry of the input CSR: where it goes in the arena, -1 = upper triangle
+  long long arena = 0;            // doubles
+  std::vector<int> level_ptr, level_pieces;  // pieces of a level, widest (largest c) first
+  std::vector<int> slot_ptr, slot_children;  // child lists; slots of level t: slot_level_ptr[t] .. slot_level_ptr[t+1]
+  std::vector<int> slot_level_ptr;
+  double flops = 0;
+  int nhub = 0;
+};
+
+// pattern of A only (both triangles stored, diagonal present); block = unknowns ordered together
+void chol_symbolic(const HostCsr &A, int block, CholSymbolic *out);
+
+// the same schedule executed by plain host loops (validation of the symbolic analysis without a GPU; tests only).
+// fronts receives the arena; returns false at the first non-positive pivot
+bool chol_numeric_host(const CholSymbolic &S, const double *vals, std::vector<double> *fronts);
+
+// device numeric factorisation of the matrix whose values (CSR order of the analysed pattern) are vals (host).
+// *pd = every pivot positive.  Symbolic analyses are cached on the pattern; DCORA_CHOL_CACHE=0 disables the cache.
+int device_chol_is_pd(const HostCsr &A, int block, int device, bool *pd, double *info8 = nullptr);
+
+void chol_cache_clear();
+
+}  // namespace dcora

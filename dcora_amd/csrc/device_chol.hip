@@ -1,0 +1,483 @@
+// see device_chol.h
+#include "device_chol.h"
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <list>
+#include <mutex>
+
+#include "device_problem.h"
+
+namespace dcora {
+
+namespace {
+
+constexpr int NB = kCholNb;
+constexpr int kEaRows = 8;  // rows of a child's Schur complement per workgroup of the extend-add
+
+struct PieceDev {
+  long long off;
+  int c, m;
+  int parent, rel_off;
+};
+
+// F[dest[p]] = v[p] for the entries of the lower triangle
+__global__ __launch_bounds__(256) void k_chol_scatter(long long nnz, const long long *__restrict__ dest,
+                                                      const double *__restrict__ v, double *__restrict__ F) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= nnz) return;
+  const long long q = dest[p];
+  if (q >= 0) F[q] = v[p];
+}
+
+// parent front += Schur complement of one child (children of one slot have distinct parents: no two workgroups of a
+// launch touch the same front entry)
+__global__ __launch_bounds__(256) void k_chol_extend_add(const PieceDev *__restrict__ pieces,
+                                                         const int *__restrict__ children,
+                                                         const int *__restrict__ rel, double *__restrict__ F,
+                                                         const int *__restrict__ fail) {
+  if (*fail) return;
+  const PieceDev D = pieces[children[blockIdx.y]];
+  const int a0 = blockIdx.x * kEaRows;
+  if (a0 >= D.m) return;
+  const PieceDev P = pieces[D.parent];
+  const long long fd = (long long)D.c + D.m, fp = (long long)P.c + P.m;
+  const int *__restrict__ rl = rel + D.rel_off;
+  const double *__restrict__ U = F + D.off + (long long)D.c * fd + D.c;
+  double *__restrict__ T = F + P.off;
+  const int a1 = min(D.m, a0 + kEaRows);
+  for (int a = a0; a < a1; ++a) {
+    const long long ra = rl[a];
+    for (int b = threadIdx.x; b <= a; b += 256) T[ra * fp + rl[b]] += U[(long long)a * fd + b];
+  }
+}
+
+// diagonal block of the current panel: LL^T of up to 64 columns in LDS, written back in place, and L^-1 for the
+// panel below.  A pivot that is not positive raises *fail.
+__global__ __launch_bounds__(256) void k_chol_potrf(const PieceDev *__restrict__ pieces, const int *__restrict__ list,
+                                                    int j0, double *__restrict__ F, double *__restrict__ Linv,
+                                                    int *__restrict__ fail, double *__restrict__ logdet) {
+  if (*fail) return;
+  const PieceDev P = pieces[list[blockIdx.x]];
+  const int jb = min(NB, P.c - j0);
+  const long long f = (long long)P.c + P.m;
+  double *__restrict__ M = F + P.off + (long long)j0 * f + j0;
+  __shared__ double L[NB][NB + 1];
+  __shared__ double Li[NB][NB + 1];
+  __shared__ double dg[NB];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int i = e >> 6, j = e & 63;
+    L[i][j] = (i < jb && j <= i) ? M[(long long)i * f + j] : (i == j ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  const int i = tid >> 2, kq = tid & 3;
+  bool bad = false;
+  for (int j = 0; j < jb; ++j) {
+    const double d = L[j][j];  // the same word for every lane: the branch below is uniform
+    if (!(d > 0.0)) {
+      bad = true;
+      break;
+    }
+    if (i > j) {
+      const double lij = L[i][j] * (1.0 / d);
+      for (int k = j + 1 + kq; k <= i; k += 4) L[i][k] -= lij * L[k][j];
+    }
+    __syncthreads();
+  }
+  if (bad) {
+    if (tid == 0) *fail = 1;
+    return;
+  }
+  if (tid < NB) {
+    dg[tid] = sqrt(L[tid][tid]);
+    // log det of the factored matrix (a cross-check of the whole factorisation for the tests; order of the sum free)
+    double lg = tid < jb ? log(L[tid][tid]) : 0.0;
+    for (int o = 32; o > 0; o >>= 1) lg += __shfl_xor(lg, o);
+    if (tid == 0) atomicAdd(logdet, lg);
+  }
+  __syncthreads();
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int r = e >> 6, j = e & 63;
+    if (j < r)
+      L[r][j] = L[r][j] / dg[j];
+    else if (j == r)
+      L[r][j] = dg[j];
+  }
+  __syncthreads();
+  for (int e = tid; e < jb * jb; e += 256) {
+    const int r = e / jb, j = e - r * jb;
+    if (j <= r) M[(long long)r * f + j] = L[r][j];
+  }
+  if (P.m == 0 && j0 + jb >= P.c) return;  // nothing below the last panel of a root
+  // inverse of the triangular block, column k by lane group k (4 lanes share the sum over l)
+  {
+    const int k = tid >> 2;
+    for (int r = kq; r < k; r += 4) Li[r][k] = 0.0;
+    if (kq == 0) Li[k][k] = 1.0 / L[k][k];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int r = k + 1; r < NB; ++r) {
+      double s = 0;
+      for (int l = k + kq; l < r; l += 4) s += L[r][l] * Li[l][k];
+      s += __shfl_xor(s, 1);
+      s += __shfl_xor(s, 2);
+      if (kq == 0) Li[r][k] = -s / L[r][r];
+      // the other lanes of the group read Li[r][k] in the next round: same wave, LDS operations stay in order
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();
+  double *__restrict__ O = Linv + (size_t)blockIdx.x * NB * NB;
+  for (int e = tid; e < NB * NB; e += 256) O[e] = Li[e >> 6][e & 63];
+}
+
+// acc[u][v] = sum_k A[(ty + 16 u)][k] B[(tx + 16 v)][k]; A and B are row-major with k contiguous; rows beyond
+// arows / brows and k beyond K read as zero
+__device__ __forceinline__ void chol_tile_product(const double *__restrict__ Ag, long long lda, int arows,
+                                                  const double *__restrict__ Bg, long long ldb, int brows, int K,
+                                                  double (*As)[NB + 1], double (*Bs)[NB + 1], double acc[4][4]) {
+  const int tid = threadIdx.x;
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int i = e >> 6, k = e & 63;
+    As[k][i] = (i < arows && k < K) ? Ag[(long long)i * lda + k] : 0.0;
+    Bs[k][i] = (i < brows && k < K) ? Bg[(long long)i * ldb + k] : 0.0;
+  }
+  __syncthreads();
+  const int ty = tid >> 4, tx = tid & 15;
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[u][v] = 0;
+#pragma unroll 8
+  for (int k = 0; k < NB; ++k) {
+    double a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] = As[k][ty + 16 * u];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) b[v] = Bs[k][tx + 16 * v];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) acc[u][v] = fma(a[u], b[v], acc[u][v]);
+  }
+}
+
+// panel below the diagonal block:  X = B L^-T, 64 rows per workgroup, in place
+__global__ __launch_bounds__(256) void k_chol_trsm(const PieceDev *__restrict__ pieces, const int *__restrict__ list,
+                                                   int j0, double *__restrict__ F, const double *__restrict__ Linv,
+                                                   const int *__restrict__ fail) {
+  if (*fail) return;
+  const PieceDev P = pieces[list[blockIdx.y]];
+  const int jb = min(NB, P.c - j0);
+  const int f = P.c + P.m;
+  const int r0 = j0 + jb + NB * blockIdx.x;
+  if (r0 >= f) return;
+  __shared__ double As[NB][NB + 1];
+  __shared__ double Bs[NB][NB + 1];
+  double *__restrict__ A = F + P.off + (long long)r0 * f + j0;
+  double acc[4][4];
+  chol_tile_product(A, f, min(NB, f - r0), Linv + (size_t)blockIdx.y * NB * NB, NB, jb, jb, As, Bs, acc);
+  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = ty + 16 * u;
+    if (r0 + i >= f) continue;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int j = tx + 16 * v;
+      if (j < jb) A[(long long)i * f + j] = acc[u][v];
+    }
+  }
+}
+
+// trailing update: C(ti, tj) -= X(ti) X(tj)^T over the 64 x 64 tiles of the lower triangle
+__global__ __launch_bounds__(256) void k_chol_syrk(const PieceDev *__restrict__ pieces, const int *__restrict__ list,
+                                                   int j0, double *__restrict__ F, const int *__restrict__ fail) {
+  if (*fail) return;
+  const PieceDev P = pieces[list[blockIdx.y]];
+  const int jb = min(NB, P.c - j0);
+  const int f = P.c + P.m;
+  const int base = j0 + jb;
+  int ti = (int)((sqrtf(8.0f * (float)blockIdx.x + 1.0f) - 1.0f) * 0.5f);
+  while ((ti + 1) * (ti + 2) / 2 <= (int)blockIdx.x) ++ti;
+  while (ti * (ti + 1) / 2 > (int)blockIdx.x) --ti;
+  const int tj = blockIdx.x - ti * (ti + 1) / 2;
+  const int ri0 = base + NB * ti, cj0 = base + NB * tj;
+  if (ri0 >= f) return;
+  __shared__ double As[NB][NB + 1];
+  __shared__ double Bs[NB][NB + 1];
+  double *__restrict__ M = F + P.off;
+  double acc[4][4];
+  chol_tile_product(M + (long long)ri0 * f + j0, f, min(NB, f - ri0), M + (long long)cj0 * f + j0, f,
+                    min(NB, f - cj0), jb, As, Bs, acc);
+  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int r = ri0 + ty + 16 * u;
+    if (r >= f) continue;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int c = cj0 + tx + 16 * v;
+      if (c <= r) M[(long long)r * f + c] -= acc[u][v];
+    }
+  }
+}
+
+inline uint64_t mix64(uint64_t h, uint64_t w) {
+  h ^= w;
+  h *= 0x9E3779B97F4A7C15ull;
+  h ^= h >> 29;
+  return h;
+}
+void hash_ints(const int *p, size_t n, uint64_t *h0, uint64_t *h1) {
+  size_t i = 0;
+  for (; i + 2 <= n; i += 2) {
+    uint64_t w;
+    std::memcpy(&w, p + i, 8);
+    *h0 = mix64(*h0, w);
+    *h1 = mix64(*h1 + 0xD1B54A32D192ED03ull, w ^ (*h0 >> 7));
+  }
+  uint64_t w = (i < n) ? (uint64_t)(unsigned)p[i] : 0x5bd1e995ull;
+  *h0 = mix64(*h0, w ^ n);
+  *h1 = mix64(*h1, w + n);
+}
+
+struct Launch {
+  int kind;  // 0 extend-add, 1 potrf, 2 trsm, 3 syrk
+  int list;  // offset into the device list (children or level pieces)
+  int gx, gy, j0;
+};
+
+struct CholImage {
+  std::mutex mu;  // one factorisation at a time per image (arena, values and flags are the image's)
+  int device = 0;
+  CholSymbolic sym;
+  DevBuf<PieceDev> pieces;
+  DevBuf<int> rel, lists;  // lists = level_pieces followed by slot_children
+  DevBuf<long long> dest;
+  DevBuf<double> linv, arena, vals;
+  DevBuf<int> fail;
+  DevBuf<double> logdet;
+  std::vector<Launch> plan;
+  double symbolic_ms = 0;
+  size_t table_bytes = 0;
+};
+
+struct CacheSlot {
+  uint64_t h0, h1;
+  int n, nnz, block, device;
+  std::shared_ptr<CholImage> img;
+};
+std::mutex g_mu;
+std::list<CacheSlot> g_cache;
+
+int build_image(const HostCsr &A, int block, int device, std::shared_ptr<CholImage> *out) {
+  auto img = std::make_shared<CholImage>();
+  img->device = device;
+  const auto t0 = std::chrono::steady_clock::now();
+  chol_symbolic(A, block, &img->sym);
+  const CholSymbolic &S = img->sym;
+  const int np = (int)S.pieces.size();
+  std::vector<PieceDev> pd((size_t)np);
+  for (int s = 0; s < np; ++s) {
+    pd[s].off = S.pieces[s].off;
+    pd[s].c = S.pieces[s].c;
+    pd[s].m = S.pieces[s].m;
+    pd[s].parent = S.pieces[s].parent;
+    pd[s].rel_off = S.pieces[s].rows_off;
+  }
+  std::vector<int> lists(S.level_pieces);
+  const int child_base = (int)lists.size();
+  lists.insert(lists.end(), S.slot_children.begin(), S.slot_children.end());
+  int max_level_count = 1;
+  for (int t = 0; t < S.nlev; ++t) {
+    max_level_count = std::max(max_level_count, S.level_ptr[t + 1] - S.level_ptr[t]);
+    for (int sl = S.slot_level_ptr[t]; sl < S.slot_level_ptr[t + 1]; ++sl) {
+      const int first = S.slot_ptr[sl], count = S.slot_ptr[sl + 1] - first;
+      int maxm = 0;
+      for (int q = 0; q < count; ++q) maxm = std::max(maxm, S.pieces[S.slot_children[first + q]].m);
+      if (count > 0 && maxm > 0)
+        img->plan.push_back(Launch{0, child_base + first, (maxm + kEaRows - 1) / kEaRows, count, 0});
+    }
+    const int lp = S.level_ptr[t], ln = S.level_ptr[t + 1] - lp;
+    const int cmax = S.pieces[S.level_pieces[lp]].c;
+    for (int j0 = 0; j0 < cmax; j0 += NB) {
+      int active = 0, maxrows = 0;
+      while (active < ln && S.pieces[S.level_pieces[lp + active]].c > j0) {
+        const CholPiece &P = S.pieces[S.level_pieces[lp + active]];
+        maxrows = std::max(maxrows, P.c + P.m - j0 - std::min(NB, P.c - j0));
+        ++active;
+      }
+      img->plan.push_back(Launch{1, lp, active, 1, j0});
+      if (maxrows > 0) {
+        const int T = (maxrows + NB - 1) / NB;
+        img->plan.push_back(Launch{2, lp, T, active, j0});
+        img->plan.push_back(Launch{3, lp, T * (T + 1) / 2, active, j0});
+      }
+    }
+  }
+  img->symbolic_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  DCORA_HIP(img->pieces.alloc(pd.size()));
+  DCORA_HIP(hipMemcpy(img->pieces.p, pd.data(), pd.size() * sizeof(PieceDev), hipMemcpyHostToDevice));
+  DCORA_HIP(img->rel.alloc(std::max<size_t>(1, S.rel.size())));
+  if (!S.rel.empty()) DCORA_HIP(hipMemcpy(img->rel.p, S.rel.data(), S.rel.size() * sizeof(int), hipMemcpyHostToDevice));
+  DCORA_HIP(img->lists.alloc(lists.size()));
+  DCORA_HIP(hipMemcpy(img->lists.p, lists.data(), lists.size() * sizeof(int), hipMemcpyHostToDevice));
+  DCORA_HIP(img->dest.alloc(S.a_dest.size()));
+  DCORA_HIP(hipMemcpy(img->dest.p, S.a_dest.data(), S.a_dest.size() * sizeof(long long), hipMemcpyHostToDevice));
+  DCORA_HIP(img->linv.alloc((size_t)max_level_count * NB * NB));
+  DCORA_HIP(img->vals.alloc(S.a_dest.size()));
+  DCORA_HIP(img->fail.alloc(1));
+  DCORA_HIP(img->logdet.alloc(1));
+  img->table_bytes = pd.size() * sizeof(PieceDev) + (S.rel.size() + lists.size()) * sizeof(int) +
+                     S.a_dest.size() * (sizeof(long long) + sizeof(double)) + (size_t)max_level_count * NB * NB * 8;
+  *out = img;
+  return DCORA_OK;
+}
+
+// arenas up to this many bytes stay with the cached image (allocating and freeing tens of GB per factorisation costs
+// more than the factorisation); larger ones are allocated per call.  Default: a quarter of the device's memory.
+size_t arena_keep_bytes() {
+  static const size_t b = [] {
+    if (const char *e = std::getenv("DCORA_CHOL_ARENA_KEEP_MB")) return (size_t)(std::atof(e) * 1024.0 * 1024.0);
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) return (size_t)2048 << 20;
+    return tot / 4;
+  }();
+  return b;
+}
+
+}  // namespace
+
+void chol_cache_clear() {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_cache.clear();
+}
+
+int device_chol_is_pd(const HostCsr &A, int block, int device, bool *pd, double *info8) {
+  double *info6 = info8;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_last_error("no HIP device available: libdcora_hip has no CPU fallback");
+    return DCORA_ERR_NO_DEVICE;
+  }
+  DCORA_HIP(hipSetDevice(device));
+  const auto t0 = std::chrono::steady_clock::now();
+  static const bool use_cache = [] {
+    const char *e = std::getenv("DCORA_CHOL_CACHE");
+    return !(e && atoi(e) == 0);
+  }();
+  uint64_t h0 = 0x243F6A8885A308D3ull, h1 = 0x13198A2E03707344ull;
+  hash_ints(A.rp.data(), A.rp.size(), &h0, &h1);
+  hash_ints(A.ci.data(), A.ci.size(), &h0, &h1);
+  std::shared_ptr<CholImage> img;
+  bool hit = false;
+  if (use_cache) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto it = g_cache.begin(); it != g_cache.end(); ++it)
+      if (it->h0 == h0 && it->h1 == h1 && it->n == A.n && it->nnz == A.nnz() && it->block == block &&
+          it->device == device) {
+        g_cache.splice(g_cache.begin(), g_cache, it);
+        img = g_cache.front().img;
+        hit = true;
+        break;
+      }
+  }
+  if (!img) {
+    const int rc = build_image(A, block, device, &img);
+    if (rc) return rc;
+    if (use_cache) {
+      std::lock_guard<std::mutex> lk(g_mu);
+      g_cache.push_front(CacheSlot{h0, h1, A.n, A.nnz(), block, device, img});
+      while (g_cache.size() > 8) g_cache.pop_back();
+    }
+  }
+  const CholSymbolic &S = img->sym;
+  std::lock_guard<std::mutex> image_lock(img->mu);
+  const auto t1 = std::chrono::steady_clock::now();
+  hipStream_t st = nullptr;
+  int rc = stream_acquire(device, &st);
+  if (rc) return rc;
+  struct Rel {
+    int device;
+    hipStream_t st;
+    ~Rel() { stream_release(device, st); }
+  } rel_guard{device, st};
+  DevBuf<double> local_arena;
+  double *F = nullptr;
+  const size_t arena_bytes = (size_t)S.arena * sizeof(double);
+  if (arena_bytes <= arena_keep_bytes()) {
+    if (!img->arena.p) {
+      // the arenas kept by all cached images together stay within the same bound: idle images give theirs up
+      std::lock_guard<std::mutex> lk(g_mu);
+      size_t held = arena_bytes;
+      for (CacheSlot &c : g_cache)
+        if (c.img != img && c.img->arena.p) {
+          held += c.img->arena.n * sizeof(double);
+          if (held > arena_keep_bytes() && c.img->mu.try_lock()) {
+            held -= c.img->arena.n * sizeof(double);
+            c.img->arena.release();
+            c.img->mu.unlock();
+          }
+        }
+    }
+    if (!img->arena.p) DCORA_HIP(img->arena.alloc((size_t)S.arena));
+    F = img->arena.p;
+  } else {
+    DCORA_HIP(local_arena.alloc((size_t)S.arena));
+    F = local_arena.p;
+  }
+  const long long nnz = (long long)S.a_dest.size();
+  DCORA_HIP(hipMemcpyAsync(img->vals.p, A.v.data(), (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, st));
+  DCORA_HIP(hipMemsetAsync(F, 0, arena_bytes, st));
+  DCORA_HIP(hipMemsetAsync(img->fail.p, 0, sizeof(int), st));
+  DCORA_HIP(hipMemsetAsync(img->logdet.p, 0, sizeof(double), st));
+  hipLaunchKernelGGL(k_chol_scatter, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, nnz, img->dest.p,
+                     img->vals.p, F);
+  for (const Launch &L : img->plan) {
+    const int *list = img->lists.p + L.list;
+    switch (L.kind) {
+      case 0:
+        hipLaunchKernelGGL(k_chol_extend_add, dim3(L.gx, L.gy), dim3(256), 0, st, img->pieces.p, list, img->rel.p, F,
+                           img->fail.p);
+        break;
+      case 1:
+        hipLaunchKernelGGL(k_chol_potrf, dim3(L.gx), dim3(256), 0, st, img->pieces.p, list, L.j0, F, img->linv.p,
+                           img->fail.p, img->logdet.p);
+        break;
+      case 2:
+        hipLaunchKernelGGL(k_chol_trsm, dim3(L.gx, L.gy), dim3(256), 0, st, img->pieces.p, list, L.j0, F, img->linv.p,
+                           img->fail.p);
+        break;
+      default:
+        hipLaunchKernelGGL(k_chol_syrk, dim3(L.gx, L.gy), dim3(256), 0, st, img->pieces.p, list, L.j0, F,
+                           img->fail.p);
+        break;
+    }
+  }
+  DCORA_HIP(hipGetLastError());
+  int failed = 0;
+  double logdet = 0;
+  DCORA_HIP(hipMemcpyAsync(&failed, img->fail.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  DCORA_HIP(hipMemcpyAsync(&logdet, img->logdet.p, sizeof(double), hipMemcpyDeviceToHost, st));
+  DCORA_HIP(hipStreamSynchronize(st));
+  *pd = failed == 0;
+  if (info6) {
+    const auto t2 = std::chrono::steady_clock::now();
+    info6[0] = hit ? 0.0 : img->symbolic_ms;
+    info6[1] = std::chrono::duration<double, std::milli>(t2 - t1).count();
+    info6[2] = (double)arena_bytes;
+    info6[3] = S.flops;
+    info6[4] = (double)S.nlev;
+    info6[5] = (double)img->plan.size();
+    info6[6] = logdet;
+    info6[7] = std::chrono::duration<double, std::milli>(t1 - t0).count();  // pattern hash + cache look-up / analysis
+  }
+  return DCORA_OK;
+}
+
+}  // namespace dcora

@@ -130,6 +130,18 @@ int dcora_cert_dual_matrix(const dcora_dims *dims, const double *X, const int *r
                            const double *vals, int device, dcora_csr_t *S);
 /* isSparseSymmetricMatrixPSD (ref :1737-1747) */
 int dcora_cert_is_psd(int k, const int *rowptr, const int *colidx, const double *vals, int block, int *is_psd);
+/* the same test with the numeric factorisation on the device (multifrontal LL^T over the nested-dissection pieces,
+ * dcora_amd/csrc/device_chol.h; the symbolic analysis is cached on the sparsity pattern).  This is what
+ * dcora_cert_fast_verification runs.  info8 (optional): symbolic ms (0 on a cache hit), numeric ms, bytes of the
+ * front arena, factorisation flops, tree levels, kernel launches, log det of the matrix (when PD), ms of the pattern
+ * hash + cache look-up. */
+int dcora_cert_is_psd_device(int k, const int *rowptr, const int *colidx, const double *vals, int block, int device,
+                             int *is_psd, double *info8);
+/* validation of the symbolic analysis without a GPU: the schedule of dcora_cert_is_psd_device executed by plain host
+ * loops; *resid = max |P A P^T - L L^T| (dense check, k <= 4096).  Test utility, not a product path. */
+int dcora_chol_host_selftest(int k, const int *rowptr, const int *colidx, const double *vals, int block, int *is_pd,
+                             double *resid, double *info4);
+int dcora_chol_cache_clear(void);
 /* computeMinimumEigenPair(S, max_iterations, min_eig_num_tol, num_Lanczos_vectors) (ref :1809-1896) */
 int dcora_cert_min_eig(int k, const int *rowptr, const int *colidx, const double *vals, int max_iterations,
                        double min_eig_num_tol, int num_lanczos_vectors, unsigned long long seed, int device,
