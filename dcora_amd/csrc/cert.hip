@@ -260,7 +260,9 @@ int device_min_eig(const HostCsr &S, int maxit, double min_eig_tol, int ncv, uin
     const int nthreads = (int)std::max(1u, std::min(hw, 32u));
     for (int i = 0; i < 10; ++i) {
       PartInvHost P;
-      if (build_partitioned_inverse(csr_shift_diag(S, -sigma), 1, nthreads, &P)) {
+      const int brc = build_partitioned_inverse_auto(csr_shift_diag(S, -sigma), 1, nthreads, device, &P);
+      if (brc && brc != DCORA_ERR_NOT_PD) return brc;
+      if (brc == DCORA_OK) {
         SparsePrecond inv;
         auto img = std::make_shared<SpImage>();
         rc = img->upload(P);

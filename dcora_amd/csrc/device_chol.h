@@ -46,8 +46,9 @@ struct CholSymbolic {
   int nhub = 0;
 };
 
-// pattern of A only (both triangles stored, diagonal present); block = unknowns ordered together
-void chol_symbolic(const HostCsr &A, int block, CholSymbolic *out);
+// pattern of A only (both triangles stored, diagonal present); block = unknowns ordered together; top_unknowns: see
+// amd_like_order (0 = plain dissection tree, what a factorisation for its own sake wants)
+void chol_symbolic(const HostCsr &A, int block, CholSymbolic *out, int top_unknowns = 0);
 
 // the same schedule executed by plain host loops (validation of the symbolic analysis without a GPU; tests only).
 // fronts receives the arena; returns false at the first non-positive pivot
@@ -56,6 +57,18 @@ bool chol_numeric_host(const CholSymbolic &S, const double *vals, std::vector<do
 // device numeric factorisation of the matrix whose values (CSR order of the analysed pattern) are vals (host).
 // *pd = every pivot positive.  Symbolic analyses are cached on the pattern; DCORA_CHOL_CACHE=0 disables the cache.
 int device_chol_is_pd(const HostCsr &A, int block, int device, bool *pd, double *info8 = nullptr);
+
+// the factor itself, by pieces (sparse_precond.h), for the builder of the partitioned inverse: ordered with
+// top_unknowns (nd_top_default() for the replay).  DCORA_ERR_NOT_PD when a pivot is not positive.
+struct PiecewiseFactor;
+int device_chol_piecewise_factor(const HostCsr &A, int block, int top_unknowns, int device, PiecewiseFactor *out,
+                                 double *info8 = nullptr);
+
+// partitioned inverse of A (sparse_precond.h) with the numeric factorisation on the device and the piece inverses and
+// the replay schedule on the host; DCORA_FACTOR=host keeps the host factorisation (A/B measurements).
+// DCORA_OK, DCORA_ERR_NOT_PD, or a HIP error.
+struct PartInvHost;
+int build_partitioned_inverse_auto(const HostCsr &A, int block, int nthreads, int device, PartInvHost *out);
 
 void chol_cache_clear();
 

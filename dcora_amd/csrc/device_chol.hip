@@ -10,6 +10,7 @@
 #include <mutex>
 
 #include "device_problem.h"
+#include "sparse_precond.h"
 
 namespace dcora {
 
@@ -227,6 +228,21 @@ __global__ __launch_bounds__(256) void k_chol_syrk(const PieceDev *__restrict__ 
   }
 }
 
+// the first c columns of every front (diagonal block over the rows below), packed piece after piece
+__global__ __launch_bounds__(256) void k_chol_pack(const PieceDev *__restrict__ pieces,
+                                                   const long long *__restrict__ panel_off,
+                                                   const double *__restrict__ F, double *__restrict__ out) {
+  const PieceDev P = pieces[blockIdx.y];
+  const int f = P.c + P.m, c = P.c;
+  const long long n = (long long)f * c;
+  const double *__restrict__ M = F + P.off;
+  double *__restrict__ O = out + panel_off[blockIdx.y];
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+    const int i = (int)(e / c), j = (int)(e - (long long)i * c);
+    O[e] = (i >= c || j <= i) ? M[(long long)i * f + j] : 0.0;
+  }
+}
+
 inline uint64_t mix64(uint64_t h, uint64_t w) {
   h ^= w;
   h *= 0x9E3779B97F4A7C15ull;
@@ -269,17 +285,17 @@ struct CholImage {
 
 struct CacheSlot {
   uint64_t h0, h1;
-  int n, nnz, block, device;
+  int n, nnz, block, device, top;
   std::shared_ptr<CholImage> img;
 };
 std::mutex g_mu;
 std::list<CacheSlot> g_cache;
 
-int build_image(const HostCsr &A, int block, int device, std::shared_ptr<CholImage> *out) {
+int build_image(const HostCsr &A, int block, int top, int device, std::shared_ptr<CholImage> *out) {
   auto img = std::make_shared<CholImage>();
   img->device = device;
   const auto t0 = std::chrono::steady_clock::now();
-  chol_symbolic(A, block, &img->sym);
+  chol_symbolic(A, block, &img->sym, top);
   const CholSymbolic &S = img->sym;
   const int np = (int)S.pieces.size();
   std::vector<PieceDev> pd((size_t)np);
@@ -358,7 +374,8 @@ void chol_cache_clear() {
   g_cache.clear();
 }
 
-int device_chol_is_pd(const HostCsr &A, int block, int device, bool *pd, double *info8) {
+namespace {
+int factor_on_device(const HostCsr &A, int block, int top, int device, bool *pd, double *info8, PiecewiseFactor *panels) {
   double *info6 = info8;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -380,7 +397,7 @@ int device_chol_is_pd(const HostCsr &A, int block, int device, bool *pd, double 
     std::lock_guard<std::mutex> lk(g_mu);
     for (auto it = g_cache.begin(); it != g_cache.end(); ++it)
       if (it->h0 == h0 && it->h1 == h1 && it->n == A.n && it->nnz == A.nnz() && it->block == block &&
-          it->device == device) {
+          it->device == device && it->top == top) {
         g_cache.splice(g_cache.begin(), g_cache, it);
         img = g_cache.front().img;
         hit = true;
@@ -388,11 +405,11 @@ int device_chol_is_pd(const HostCsr &A, int block, int device, bool *pd, double 
       }
   }
   if (!img) {
-    const int rc = build_image(A, block, device, &img);
+    const int rc = build_image(A, block, top, device, &img);
     if (rc) return rc;
     if (use_cache) {
       std::lock_guard<std::mutex> lk(g_mu);
-      g_cache.push_front(CacheSlot{h0, h1, A.n, A.nnz(), block, device, img});
+      g_cache.push_front(CacheSlot{h0, h1, A.n, A.nnz(), block, device, top, img});
       while (g_cache.size() > 8) g_cache.pop_back();
     }
   }
@@ -466,6 +483,45 @@ int device_chol_is_pd(const HostCsr &A, int block, int device, bool *pd, double 
   DCORA_HIP(hipMemcpyAsync(&logdet, img->logdet.p, sizeof(double), hipMemcpyDeviceToHost, st));
   DCORA_HIP(hipStreamSynchronize(st));
   *pd = failed == 0;
+  if (panels && failed == 0) {
+    // hand the factor over by pieces: pack the panels on the device, one copy to the host
+    const int np = (int)S.pieces.size();
+    std::vector<long long> poff((size_t)np + 1, 0);
+    int fmax = 1;
+    for (int s2 = 0; s2 < np; ++s2) {
+      const CholPiece &P = S.pieces[s2];
+      poff[s2 + 1] = poff[s2] + (long long)(P.c + P.m) * P.c;
+      fmax = std::max(fmax, P.c + P.m);
+    }
+    DevBuf<long long> dpoff;
+    DevBuf<double> packed;
+    DCORA_HIP(dpoff.alloc(poff.size()));
+    DCORA_HIP(packed.alloc((size_t)std::max<long long>(1, poff[np])));
+    DCORA_HIP(hipMemcpyAsync(dpoff.p, poff.data(), poff.size() * sizeof(long long), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_chol_pack, dim3(std::min(64, (fmax + 7) / 8), np), dim3(256), 0, st, img->pieces.p, dpoff.p, F,
+                       packed.p);
+    std::vector<double> host((size_t)poff[np]);
+    DCORA_HIP(hipMemcpyAsync(host.data(), packed.p, host.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    DCORA_HIP(hipStreamSynchronize(st));
+    PiecewiseFactor &W = *panels;
+    W = PiecewiseFactor();
+    W.n = S.n;
+    W.nhub = S.nhub;
+    W.perm = S.perm;
+    W.iperm = S.iperm;
+    W.pieces.assign((size_t)np, PieceFactor());
+    long nz = 0;
+    for (int s2 = 0; s2 < np; ++s2) {
+      const CholPiece &P = S.pieces[s2];
+      PieceFactor &pf = W.pieces[s2];
+      pf.c0 = P.c0;
+      pf.c = P.c;
+      pf.rows.assign(S.rows.begin() + P.rows_off, S.rows.begin() + P.rows_off + P.m);
+      pf.panel.assign(host.begin() + poff[s2], host.begin() + poff[s2 + 1]);
+      for (double v : pf.panel) nz += v != 0.0;
+    }
+    W.nnzL = nz;
+  }
   if (info6) {
     const auto t2 = std::chrono::steady_clock::now();
     info6[0] = hit ? 0.0 : img->symbolic_ms;
@@ -478,6 +534,35 @@ int device_chol_is_pd(const HostCsr &A, int block, int device, bool *pd, double 
     info6[7] = std::chrono::duration<double, std::milli>(t1 - t0).count();  // pattern hash + cache look-up / analysis
   }
   return DCORA_OK;
+}
+}  // namespace
+
+int device_chol_is_pd(const HostCsr &A, int block, int device, bool *pd, double *info8) {
+  return factor_on_device(A, block, 0, device, pd, info8, nullptr);
+}
+
+int device_chol_piecewise_factor(const HostCsr &A, int block, int top_unknowns, int device, PiecewiseFactor *out,
+                                 double *info8) {
+  bool pd = false;
+  const int rc = factor_on_device(A, block, top_unknowns, device, &pd, info8, out);
+  if (rc) return rc;
+  if (!pd) {
+    set_last_error("matrix is not positive definite");
+    return DCORA_ERR_NOT_PD;
+  }
+  return DCORA_OK;
+}
+
+int build_partitioned_inverse_auto(const HostCsr &A, int block, int nthreads, int device, PartInvHost *out) {
+  static const bool host_factor = [] {
+    const char *e = std::getenv("DCORA_FACTOR");
+    return e && std::strcmp(e, "host") == 0;
+  }();
+  if (host_factor) return build_partitioned_inverse(A, block, nthreads, out) ? DCORA_OK : DCORA_ERR_NOT_PD;
+  PiecewiseFactor F;
+  const int rc = device_chol_piecewise_factor(A, block, nd_top_default(), device, &F);
+  if (rc) return rc;
+  return build_partitioned_inverse_from(A, F, nthreads, out) ? DCORA_OK : DCORA_ERR_NOT_PD;
 }
 
 }  // namespace dcora

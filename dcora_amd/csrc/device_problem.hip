@@ -1,5 +1,6 @@
 // DeviceProblem: QuadraticProblem / QuadraticOptimizer on the MI355X (see device_problem.h).
 #include "device_problem.h"
+#include "device_chol.h"
 #include "precond_cache.h"
 
 #include <algorithm>
@@ -295,7 +296,10 @@ int DeviceProblem::build_preconditioner(const HostCsr &Qh, double reg) {
     HostCsr M = csr_shift_diag(Qh, reg);
     if (want_sparse) {
       PartInvHost P;
-      if (!build_partitioned_inverse(M, block, nthreads, &P)) {
+      const int brc = build_partitioned_inverse_auto(M, block, nthreads, device, &P);
+      if (brc && brc != DCORA_ERR_NOT_PD) return brc;
+      const bool ok = brc == DCORA_OK;
+      if (!ok) {
         set_last_error("preconditioner: Q + reg I is not positive definite");
         return DCORA_ERR_NOT_PD;
       }

@@ -7,14 +7,14 @@
 
 namespace dcora {
 
-void chol_symbolic(const HostCsr &A, int block, CholSymbolic *out) {
+void chol_symbolic(const HostCsr &A, int block, CholSymbolic *out, int top_unknowns) {
   CholSymbolic &S = *out;
   S = CholSymbolic();
   const int n = A.n;
   S.n = n;
   std::vector<int> cuts;
   int nhub = 0;
-  S.perm = amd_like_order(A, block, &cuts, &nhub);
+  S.perm = amd_like_order(A, block, &cuts, &nhub, nullptr, 0, nullptr, top_unknowns);
   S.nhub = nhub;
   S.iperm.assign((size_t)n, 0);
   for (int i = 0; i < n; ++i) S.iperm[S.perm[i]] = i;

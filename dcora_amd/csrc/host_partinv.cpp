@@ -3,6 +3,9 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <thread>
@@ -16,6 +19,7 @@ namespace {
 struct Piece {
   int c0 = 0, c = 0;          // columns [c0, c0 + c) in permuted numbering
   std::vector<int> rows;      // rows of L below the piece, ascending
+  std::vector<int> src;       // where each of them sits in the factor's panel (row c + src)
   int level = 0;
   std::vector<double> Dinv;   // D^-1, c x c row-major (lower triangular)
   std::vector<double> W;      // -B D^-1, m x c row-major
@@ -41,6 +45,27 @@ inline void inline_first_segment(PTask &T, const std::vector<PSeg> &segs) {
 // lanes per row tile, from the average number of vector entries a tile gathers: a step covers lanes / r of them;
 // aim for a handful of steps per lane so that the loads of a tile are all in flight together (the upper levels
 // have few tiles and are latency-bound otherwise)
+// body(i) for i in [0, n) on up to nthreads threads, dynamic chunks (setup-time helper)
+template <class F>
+void parallel_for(int n, int nthreads, int chunk, F body) {
+  nthreads = std::max(1, std::min(nthreads, (n + chunk - 1) / chunk));
+  std::atomic<int> next(0);
+  auto work = [&]() {
+    for (;;) {
+      const int i0 = next.fetch_add(chunk);
+      if (i0 >= n) break;
+      const int i1 = std::min(n, i0 + chunk);
+      for (int i = i0; i < i1; ++i) body(i);
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < nthreads; ++t) th.emplace_back(work);
+  work();
+  for (auto &t : th) t.join();
+}
+
+constexpr int kBigPiece = 384;  // pieces this wide are inverted by all threads together (the merged top of the tree)
+
 int pick_lanes(double avg_entries_per_tile) {
   if (avg_entries_per_tile >= 160) return 256;
   if (avg_entries_per_tile >= 20) return 64;
@@ -50,85 +75,222 @@ int pick_lanes(double avg_entries_per_tile) {
 
 }  // namespace
 
-bool build_partitioned_inverse(const HostCsr &A, int block, int nthreads, PartInvHost *out) {
-  SparseChol chol;
-  if (!chol.factor(A, block)) return false;
-  const int kfull = A.n;
-  // hubs are the trailing columns of the order and the last piece: they stay out of the replay (Schur complement,
-  // see PartInvHub); the leading k x k block of L is the factor of A11
-  const int h = (chol.nhub() > 0 && chol.nhub() <= 64 && chol.nhub() < kfull) ? chol.nhub() : 0;
-  const int k = kfull - h;
+void piecewise_from_chol(const SparseChol &chol, PiecewiseFactor *out) {
+  PiecewiseFactor &F = *out;
+  F = PiecewiseFactor();
+  F.n = chol.n();
+  F.nhub = chol.nhub();
+  F.nnzL = chol.nnzL();
+  F.perm = chol.perm();
+  F.iperm = chol.iperm();
   const std::vector<int> &Lp = chol.Lp(), &Li = chol.Li();
   const std::vector<double> &Lx = chol.Lx();
   const std::vector<int> &cuts = chol.pieces();
+  const int np = (int)cuts.size() - 1;
+  F.pieces.assign((size_t)np, PieceFactor());
+  std::vector<int> mark((size_t)F.n, -1), where((size_t)F.n, -1);
+  for (int s = 0; s < np; ++s) {
+    PieceFactor &p = F.pieces[s];
+    p.c0 = cuts[s];
+    p.c = cuts[s + 1] - cuts[s];
+    const int hi = p.c0 + p.c, c = p.c;
+    for (int j = p.c0; j < hi; ++j)
+      for (int q = Lp[j] + 1; q < Lp[j + 1]; ++q) {
+        const int i = Li[q];
+        if (i >= hi && mark[i] != s) {
+          mark[i] = s;
+          p.rows.push_back(i);
+        }
+      }
+    std::sort(p.rows.begin(), p.rows.end());
+    const int m = (int)p.rows.size();
+    for (int a2 = 0; a2 < m; ++a2) where[p.rows[a2]] = a2;
+    p.panel.assign((size_t)(c + m) * c, 0.0);
+    for (int j = 0; j < c; ++j)
+      for (int q = Lp[p.c0 + j]; q < Lp[p.c0 + j + 1]; ++q) {
+        const int i = Li[q];
+        const int row = i < hi ? i - p.c0 : c + where[i];
+        p.panel[(size_t)row * c + j] = Lx[q];
+      }
+  }
+}
+
+namespace {
+// u <- A11^-1 u with the pieces [0, np) of the factor (the leading k x k block of L): block forward and backward
+// substitution on the panels (hubs only: h right-hand sides, set-up time)
+void piecewise_solve(const PiecewiseFactor &F, int np, int k, std::vector<double> &u) {
+  for (int s = 0; s < np; ++s) {
+    const PieceFactor &p = F.pieces[s];
+    const int c = p.c, m = (int)p.rows.size();
+    double *us = &u[(size_t)p.c0];
+    for (int i = 0; i < c; ++i) {
+      const double *di = &p.panel[(size_t)i * c];
+      double sum = us[i];
+      for (int l = 0; l < i; ++l) sum -= di[l] * us[l];
+      us[i] = sum / di[i];
+    }
+    for (int a2 = 0; a2 < m; ++a2) {
+      const int row = p.rows[a2];
+      if (row >= k) continue;
+      const double *ba = &p.panel[(size_t)(c + a2) * c];
+      double sum = 0;
+      for (int j = 0; j < c; ++j) sum += ba[j] * us[j];
+      u[(size_t)row] -= sum;
+    }
+  }
+  for (int s = np - 1; s >= 0; --s) {
+    const PieceFactor &p = F.pieces[s];
+    const int c = p.c, m = (int)p.rows.size();
+    double *us = &u[(size_t)p.c0];
+    for (int a2 = 0; a2 < m; ++a2) {
+      const int row = p.rows[a2];
+      if (row >= k) continue;
+      const double ur = u[(size_t)row];
+      if (ur == 0.0) continue;
+      const double *ba = &p.panel[(size_t)(c + a2) * c];
+      for (int j = 0; j < c; ++j) us[j] -= ba[j] * ur;
+    }
+    for (int i = c - 1; i >= 0; --i) {
+      const double xi = us[i] / p.panel[(size_t)i * c + i];
+      us[i] = xi;
+      const double *di = &p.panel[(size_t)i * c];
+      for (int l = 0; l < i; ++l) us[l] -= di[l] * xi;
+    }
+  }
+}
+}  // namespace
+
+bool build_partitioned_inverse(const HostCsr &A, int block, int nthreads, PartInvHost *out) {
+  const bool timing = std::getenv("DCORA_INIT_TIMING") != nullptr;
+  const auto T0 = std::chrono::steady_clock::now();
+  SparseChol chol;
+  if (!chol.factor(A, block, nd_top_default())) return false;
+  PiecewiseFactor F;
+  piecewise_from_chol(chol, &F);
+  if (timing)
+    std::fprintf(stderr, "[partinv] host factorisation + panels %.1f ms\n",
+                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count());
+  return build_partitioned_inverse_from(A, F, nthreads, out);
+}
+
+bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, int nthreads, PartInvHost *out) {
+  const bool timing = std::getenv("DCORA_INIT_TIMING") != nullptr;
+  auto tnow = [] { return std::chrono::steady_clock::now(); };
+  auto tms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  const auto T1 = tnow();
+  const int kfull = A.n;
+  // hubs are the trailing columns of the order and the last piece: they stay out of the replay (Schur complement,
+  // see PartInvHub); the leading k x k block of L is the factor of A11
+  const int h = (F.nhub > 0 && F.nhub <= 64 && F.nhub < kfull) ? F.nhub : 0;
+  const int k = kfull - h;
   PartInvHost &P = *out;
   P = PartInvHost();
   P.k = k;
   P.kfull = kfull;
-  P.perm.assign(chol.perm().begin(), chol.perm().begin() + k);
-  P.nnzL = chol.nnzL();
-  const int np = (int)cuts.size() - 1 - (h > 0 ? 1 : 0);
+  P.perm.assign(F.perm.begin(), F.perm.begin() + k);
+  P.nnzL = F.nnzL;
+  const int np = (int)F.pieces.size() - (h > 0 ? 1 : 0);
   P.npieces = np;
   std::vector<Piece> pc((size_t)np);
   std::vector<int> piece_of((size_t)k);
   for (int s = 0; s < np; ++s) {
-    pc[s].c0 = cuts[s];
-    pc[s].c = cuts[s + 1] - cuts[s];
-    for (int j = cuts[s]; j < cuts[s + 1]; ++j) piece_of[j] = s;
+    pc[s].c0 = F.pieces[s].c0;
+    pc[s].c = F.pieces[s].c;
+    for (int j = pc[s].c0; j < pc[s].c0 + pc[s].c; ++j) piece_of[j] = s;
   }
-  // rows below each piece (union over its columns) and dependency levels (longest path from the leaves)
-  {
-    std::vector<int> mark((size_t)k, -1);
-    for (int s = 0; s < np; ++s) {
-      const int hi = pc[s].c0 + pc[s].c;
-      std::vector<int> &rows = pc[s].rows;
-      for (int j = pc[s].c0; j < hi; ++j)
-        for (int p = Lp[j] + 1; p < Lp[j + 1]; ++p) {
-          const int i = Li[p];
-          if (i >= hi && i < k && mark[i] != s) {
-            mark[i] = s;
-            rows.push_back(i);
-          }
-        }
-      std::sort(rows.begin(), rows.end());
-      for (int i : rows) {
-        Piece &q = pc[piece_of[i]];
-        q.level = std::max(q.level, pc[s].level + 1);
-      }
+  // rows below each piece and dependency levels (longest path from the leaves).  Rows of the hubs are left to the
+  // Schur complement; rows that a closed piece structure carries as explicit zeros (device_chol.h) are dropped.
+  for (int s = 0; s < np; ++s) {
+    const PieceFactor &f = F.pieces[s];
+    const int c = f.c;
+    for (int a2 = 0; a2 < (int)f.rows.size(); ++a2) {
+      const int i = f.rows[a2];
+      if (i >= k) continue;
+      const double *ba = &f.panel[(size_t)(c + a2) * c];
+      bool any = false;
+      for (int j = 0; j < c && !any; ++j) any = ba[j] != 0.0;
+      if (!any) continue;
+      pc[s].rows.push_back(i);
+      pc[s].src.push_back(a2);
+    }
+    for (int i : pc[s].rows) {
+      Piece &q = pc[piece_of[i]];
+      q.level = std::max(q.level, pc[s].level + 1);
     }
   }
   int nlev = 0;
   for (const Piece &p : pc) nlev = std::max(nlev, p.level + 1);
-  // ---- numeric part: D^-1 and W = -B D^-1 of every piece, pieces in parallel, most expensive first ----
+  // ---- numeric part: D^-1 and W = -B D^-1 of every piece.  Wide pieces first, one at a time with all threads on the
+  //      columns of the inverse (column k of D^-1 is an independent forward substitution); then the many small
+  //      pieces in parallel, most expensive first ----
+  nthreads = std::max(1, nthreads);
+  auto extract = [&](int s, std::vector<double> &D, std::vector<double> &B) {
+    const PieceFactor &f = F.pieces[s];
+    const Piece &p = pc[s];
+    const int c = p.c, m = (int)p.rows.size();
+    D.assign(f.panel.begin(), f.panel.begin() + (size_t)c * c);
+    B.resize((size_t)m * c);
+    for (int a2 = 0; a2 < m; ++a2)
+      std::copy(&f.panel[(size_t)(c + p.src[a2]) * c], &f.panel[(size_t)(c + p.src[a2]) * c] + c, &B[(size_t)a2 * c]);
+  };
+  auto w_row = [](const double *ba, const std::vector<double> &Dinv, int c, double *wa) {
+    for (int l = 0; l < c; ++l) {
+      const double b = ba[l];
+      if (b == 0.0) continue;
+      const double *dl = &Dinv[(size_t)l * c];
+      for (int j = 0; j <= l; ++j) wa[j] -= b * dl[j];
+    }
+  };
   {
-    std::vector<int> order((size_t)np);
-    std::iota(order.begin(), order.end(), 0);
+    std::vector<double> D, B;
+    for (int s = 0; s < np; ++s) {
+      Piece &p = pc[s];
+      if (p.c < kBigPiece || nthreads < 2) continue;
+      const int c = p.c, m = (int)p.rows.size();
+      extract(s, D, B);
+      std::vector<double> &Dinv = p.Dinv;
+      Dinv.assign((size_t)c * c, 0.0);
+      // column kc of D^-1 by forward substitution in axpy form over the rows of D^T (contiguous, vectorisable:
+      // a dot-product form would be a serial chain of dependent additions)
+      std::vector<double> DT((size_t)c * c);
+      parallel_for(c, nthreads, 16, [&](int i) {
+        for (int l = 0; l <= i; ++l) DT[(size_t)l * c + i] = D[(size_t)i * c + l];
+      });
+      parallel_for(c, nthreads, 4, [&](int kc) {
+        std::vector<double> x((size_t)c, 0.0);
+        x[kc] = 1.0;
+        for (int l = kc; l < c; ++l) {
+          const double *dl = &DT[(size_t)l * c];
+          const double xl = x[l] / dl[l];
+          x[l] = xl;
+          if (xl == 0.0) continue;
+          for (int i = l + 1; i < c; ++i) x[i] -= dl[i] * xl;
+        }
+        for (int i = kc; i < c; ++i) Dinv[(size_t)i * c + kc] = x[i];
+      });
+      p.W.assign((size_t)m * c, 0.0);
+      parallel_for(m, nthreads, 8, [&](int a) { w_row(&B[(size_t)a * c], Dinv, c, &p.W[(size_t)a * c]); });
+    }
+  }
+  {
+    std::vector<int> order;
+    for (int s = 0; s < np; ++s)
+      if (pc[s].Dinv.empty()) order.push_back(s);
     std::sort(order.begin(), order.end(), [&](int a, int b) {
       const double wa = (double)pc[a].c * pc[a].c * (pc[a].c + 3.0 * pc[a].rows.size());
       const double wb = (double)pc[b].c * pc[b].c * (pc[b].c + 3.0 * pc[b].rows.size());
       return wa > wb;
     });
+    const int nord = (int)order.size();
     std::atomic<int> next(0);
     auto work = [&]() {
       std::vector<double> D, B;
-      std::vector<int> where((size_t)k, -1);
       for (;;) {
         const int t = next.fetch_add(1);
-        if (t >= np) break;
+        if (t >= nord) break;
         Piece &p = pc[order[t]];
-        const int c = p.c, c0 = p.c0, m = (int)p.rows.size();
-        D.assign((size_t)c * c, 0.0);
-        B.assign((size_t)m * c, 0.0);
-        for (int a = 0; a < m; ++a) where[p.rows[a]] = a;
-        for (int j = 0; j < c; ++j)
-          for (int q = Lp[c0 + j]; q < Lp[c0 + j + 1]; ++q) {
-            const int i = Li[q];
-            if (i < c0 + c)
-              D[(size_t)(i - c0) * c + j] = Lx[q];
-            else if (i < k)
-              B[(size_t)where[i] * c + j] = Lx[q];
-          }
-        for (int a = 0; a < m; ++a) where[p.rows[a]] = -1;
+        const int c = p.c, m = (int)p.rows.size();
+        extract(order[t], D, B);
         // Dinv = D^-1 (lower triangular), built row by row: row_i = (e_i - sum_{l<i} D_il row_l) / D_ii
         std::vector<double> &Dinv = p.Dinv;
         Dinv.assign((size_t)c * c, 0.0);
@@ -146,24 +308,16 @@ bool build_partitioned_inverse(const HostCsr &A, int block, int nthreads, PartIn
           ri[i] = inv;
         }
         p.W.assign((size_t)m * c, 0.0);
-        for (int a = 0; a < m; ++a) {
-          const double *ba = &B[(size_t)a * c];
-          double *wa = &p.W[(size_t)a * c];
-          for (int l = 0; l < c; ++l) {
-            const double b = ba[l];
-            if (b == 0.0) continue;
-            const double *dl = &Dinv[(size_t)l * c];
-            for (int j = 0; j <= l; ++j) wa[j] -= b * dl[j];
-          }
-        }
+        for (int a = 0; a < m; ++a) w_row(&B[(size_t)a * c], Dinv, c, &p.W[(size_t)a * c]);
       }
     };
-    nthreads = std::max(1, std::min(nthreads, np));
+    const int nt = std::max(1, std::min(nthreads, nord));
     std::vector<std::thread> th;
-    for (int t = 1; t < nthreads; ++t) th.emplace_back(work);
+    for (int t = 1; t < nt; ++t) th.emplace_back(work);
     work();
     for (auto &t : th) t.join();
   }
+  const auto T2 = tnow();
   // ---- schedule.  Which buffer holds a piece's current value is static; start: everything in buffer 0.
   // A task is a tile of up to kSpTile consecutive output rows that gather from the same sources; the weights of
   // a segment are stored entry-major over the tile's rows:  [entry j][row q]. ----
@@ -294,13 +448,28 @@ bool build_partitioned_inverse(const HostCsr &A, int block, int nthreads, PartIn
       std::vector<double> M;  // top level only: D^-T D^-1 (c x c, symmetric)
       if (t == nlev - 1) {
         M.assign((size_t)c * c, 0.0);
-        for (int i = 0; i < c; ++i) {
-          const double *di = &p.Dinv[(size_t)i * c];
-          for (int a = 0; a <= i; ++a) {
-            const double v = di[a];
-            if (v == 0.0) continue;
+        if (c >= kBigPiece && nthreads > 1) {
+          // row a of the lower triangle by one thread: M(a, j) = sum_{i >= a} Dinv(i, a) Dinv(i, j), j <= a
+          parallel_for(c, nthreads, 4, [&](int a) {
             double *ma = &M[(size_t)a * c];
-            for (int j = 0; j <= i; ++j) ma[j] += v * di[j];
+            for (int i = a; i < c; ++i) {
+              const double *di = &p.Dinv[(size_t)i * c];
+              const double v = di[a];
+              if (v == 0.0) continue;
+              for (int j = 0; j <= a; ++j) ma[j] += v * di[j];
+            }
+          });
+          for (int a = 0; a < c; ++a)
+            for (int j = a + 1; j < c; ++j) M[(size_t)a * c + j] = M[(size_t)j * c + a];
+        } else {
+          for (int i = 0; i < c; ++i) {
+            const double *di = &p.Dinv[(size_t)i * c];
+            for (int a = 0; a <= i; ++a) {
+              const double v = di[a];
+              if (v == 0.0) continue;
+              double *ma = &M[(size_t)a * c];
+              for (int j = 0; j <= i; ++j) ma[j] += v * di[j];
+            }
           }
         }
       }
@@ -353,11 +522,17 @@ bool build_partitioned_inverse(const HostCsr &A, int block, int nthreads, PartIn
   P.out_off.resize((size_t)k);
   for (int j = 0; j < k; ++j) P.out_off[j] = pos(bit[piece_of[j]], j);
   P.weights_read_per_apply = weights;
+  if (timing) {
+    int cmax = 0;
+    for (const Piece &p : pc) cmax = std::max(cmax, p.c);
+    std::fprintf(stderr, "[partinv] k %d pieces %d levels %d widest piece %d: piece inverses %.1f, schedule %.1f ms\n",
+                 k, np, nlev, cmax, tms(T1, T2), tms(T2, tnow()));
+  }
   // ---- hubs: U = A11^-1 a with the leading block of L, Sc = alpha - a^T U ----
   if (h > 0) {
     PartInvHub &H = P.hub;
     H.h = h;
-    const std::vector<int> &perm = chol.perm(), &iperm = chol.iperm();
+    const std::vector<int> &perm = F.perm, &iperm = F.iperm;
     H.idx.assign(perm.begin() + k, perm.end());
     H.ap.assign(1, 0);
     H.U.assign((size_t)k * h, 0.0);
@@ -377,19 +552,7 @@ bool build_partitioned_inverse(const HostCsr &A, int block, int nthreads, PartIn
       }
       H.ap.push_back((int)H.apos.size());
       u = acol;
-      for (int j = 0; j < k; ++j) {
-        u[j] /= Lx[Lp[j]];
-        const double uj = u[j];
-        if (uj == 0.0) continue;
-        for (int p = Lp[j] + 1; p < Lp[j + 1]; ++p)
-          if (Li[p] < k) u[Li[p]] -= Lx[p] * uj;
-      }
-      for (int j = k - 1; j >= 0; --j) {
-        double s = u[j];
-        for (int p = Lp[j] + 1; p < Lp[j + 1]; ++p)
-          if (Li[p] < k) s -= Lx[p] * u[Li[p]];
-        u[j] = s / Lx[Lp[j]];
-      }
+      piecewise_solve(F, np, k, u);
       for (int j = 0; j < k; ++j) H.U[(size_t)j * h + q] = u[j];
     }
     // Sc = alpha - a^T U (symmetric positive definite), inverted by Gauss-Jordan (h is tiny)

@@ -152,7 +152,11 @@ void leaf_order(const NDGraph &G, const std::vector<int> &nodes, std::vector<int
 void nd_recurse(const NDGraph &G, std::vector<int> nodes, std::vector<int> &comp_id, int &next_cid,
                 std::vector<int> &level, std::vector<int> &out, std::vector<int> &cuts, int leaf_nodes,
                 int task_nodes, std::vector<std::pair<int, int>> &tasks,
-                std::vector<std::vector<std::pair<int, int>>> &sep_waves) {
+                std::vector<std::vector<std::pair<int, int>>> &sep_waves, int top_depth,
+                std::vector<long> *sep_nodes_by_depth) {
+  // top_depth > 0: the separators of the first top_depth dissection depths are not placed between their sub-trees
+  // but collected and eliminated last, as ONE piece (see amd_like_order).  sep_nodes_by_depth (optional) receives the
+  // number of separator nodes per depth.
   // iterative worklist: (nodes) ; output order is built back-to-front: separators last.
   // A component and everything dissected out of it occupy one contiguous run of the order; maximal components of
   // at most task_nodes nodes are reported as independent tasks (their columns depend on nothing outside the run).
@@ -162,6 +166,7 @@ void nd_recurse(const NDGraph &G, std::vector<int> nodes, std::vector<int> &comp
   std::vector<char> stack_in_task;
   std::vector<int> stack_depth;
   std::vector<int> rev;  // reversed elimination order
+  std::vector<int> top;  // separators of depth < top_depth, in the order they were found (root first)
   stack.push_back(std::move(nodes));
   stack_in_task.push_back(0);
   stack_depth.push_back(0);
@@ -179,7 +184,7 @@ void nd_recurse(const NDGraph &G, std::vector<int> nodes, std::vector<int> &comp
     stack_in_task.pop_back();
     stack_depth.pop_back();
     if (cur.empty()) continue;
-    if (!in_task && (int)cur.size() <= task_nodes) {
+    if (!in_task && (int)cur.size() <= task_nodes && dep >= top_depth) {
       tasks.emplace_back((int)rev.size(), (int)cur.size());
       in_task = 1;
     }
@@ -233,17 +238,25 @@ void nd_recurse(const NDGraph &G, std::vector<int> nodes, std::vector<int> &comp
     const int mid = level[order[order.size() / 2]];
     const int sep_level = std::min(std::max(mid, 1), depth - 1);
     std::vector<int> left, right;
-    const int sep_start = (int)rev.size();
+    const bool to_top = dep < top_depth;
+    std::vector<int> &sep_dst = to_top ? top : rev;
+    const int sep_start = (int)sep_dst.size();
     for (int u : order) {
       if (level[u] == sep_level)
-        rev.push_back(u);  // separators are eliminated last
+        sep_dst.push_back(u);  // separators are eliminated last
       else if (level[u] < sep_level)
         left.push_back(u);
       else
         right.push_back(u);
     }
-    cuts.push_back((int)rev.size());
-    if (!in_task) note_sep(dep, sep_start, (int)rev.size() - sep_start);
+    if (sep_nodes_by_depth) {
+      if ((int)sep_nodes_by_depth->size() <= dep) sep_nodes_by_depth->resize(dep + 1, 0);
+      (*sep_nodes_by_depth)[dep] += (long)sep_dst.size() - sep_start;
+    }
+    if (!to_top) {
+      cuts.push_back((int)rev.size());
+      if (!in_task) note_sep(dep, sep_start, (int)rev.size() - sep_start);
+    }
     for (int u : cur) comp_id[u] = -1;
     stack.push_back(std::move(left));
     stack.push_back(std::move(right));
@@ -261,14 +274,27 @@ void nd_recurse(const NDGraph &G, std::vector<int> nodes, std::vector<int> &comp
   for (int &c : cuts) c = total - c;
   cuts.push_back(0);
   cuts.push_back(total);
+  if (!top.empty()) {  // the merged top piece: deeper separators first, the root separator last
+    for (auto it = top.rbegin(); it != top.rend(); ++it) out.push_back(*it);
+    cuts.push_back(total + (int)top.size());
+  }
   std::sort(cuts.begin(), cuts.end());
   cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
 }
 }  // namespace
 
+int nd_top_default() {
+  // measured on sphere2500 / torus3D / tiers.pyfg / a 100k-lattice agent: best of 1536 / 2048 / 3072 / 4096
+  static const int v = [] {
+    const char *e = std::getenv("DCORA_ND_TOP");
+    return e ? atoi(e) : 3072;
+  }();
+  return v;
+}
+
 std::vector<int> amd_like_order(const HostCsr &A, int block, std::vector<int> *pieces, int *nhub_cols,
                                 std::vector<std::pair<int, int>> *col_tasks, int want_tasks,
-                                std::vector<std::vector<std::pair<int, int>>> *col_waves) {
+                                std::vector<std::vector<std::pair<int, int>>> *col_waves, int top_unknowns) {
   const int n = A.n;
   if (block < 1) block = 1;
   const int nb = (n + block - 1) / block;
@@ -306,7 +332,30 @@ std::vector<int> amd_like_order(const HostCsr &A, int block, std::vector<int> *p
   std::vector<std::pair<int, int>> tasks;
   const int task_nodes = (col_tasks && want_tasks > 1) ? std::max(4 * leaf_nodes, (int)all.size() / want_tasks) : 0;
   std::vector<std::vector<std::pair<int, int>>> waves;
-  nd_recurse(G, all, comp_id, next_cid, level, border, cuts, leaf_nodes, task_nodes, tasks, waves);
+  // Dense top of the tree.  On surface-like graphs (sphere2500, tiers.pyfg) the upper separators are small; every
+  // dissection depth costs the device replay two dependent launches (sparse_precond.h), while ONE piece holding the
+  // separators of the first L depths is applied by a single symmetric dense product.  L = as many depths as fit
+  // top_unknowns unknowns (nd_top_default() for the replay; 0 for a plain factorisation, whose dense fronts would
+  // only get more expensive); volume-like graphs, whose root separator alone is larger, keep the plain tree.
+  int top_depth = 0;
+  {
+    if (top_unknowns > 0 && (int)all.size() >= 16 * leaf_nodes) {
+      std::vector<long> by_depth;
+      std::vector<int> comp0(nb, -1), level0(nb, -1), border0, cuts0;
+      std::vector<std::pair<int, int>> tasks0;
+      std::vector<std::vector<std::pair<int, int>>> waves0;
+      int cid0 = 0;
+      nd_recurse(G, all, comp0, cid0, level0, border0, cuts0, leaf_nodes, 0, tasks0, waves0, 0, &by_depth);
+      long sum = 0;
+      for (size_t dpt = 0; dpt < by_depth.size(); ++dpt) {
+        sum += by_depth[dpt] * block;
+        if (sum > top_unknowns) break;
+        top_depth = (int)dpt + 1;
+      }
+      if (top_depth < 2) top_depth = 0;  // one depth alone is the plain tree
+    }
+  }
+  nd_recurse(G, all, comp_id, next_cid, level, border, cuts, leaf_nodes, task_nodes, tasks, waves, top_depth, nullptr);
   if (col_tasks) {
     col_tasks->clear();
     for (const auto &t : tasks)
@@ -347,7 +396,7 @@ std::vector<int> amd_like_order(const HostCsr &A, int block, std::vector<int> *p
 // ---------------------------------------------------------------------------------------------------
 // Numeric factorisation: up-looking LL^T over the elimination tree
 // ---------------------------------------------------------------------------------------------------
-bool SparseChol::factor(const HostCsr &A, int block) {
+bool SparseChol::factor(const HostCsr &A, int block, int top_unknowns) {
   n_ = A.n;
   ok_ = false;
   const int n = n_;
@@ -357,7 +406,7 @@ bool SparseChol::factor(const HostCsr &A, int block) {
   if (const char *e = std::getenv("DCORA_FACTOR_THREADS")) nthreads = std::max(1, atoi(e));
   std::vector<std::pair<int, int>> tasks;
   std::vector<std::vector<std::pair<int, int>>> waves;  // separators above the tasks, by dissection depth
-  perm_ = amd_like_order(A, block, &pieces_, &nhub_, &tasks, 4 * nthreads, &waves);
+  perm_ = amd_like_order(A, block, &pieces_, &nhub_, &tasks, 4 * nthreads, &waves, top_unknowns);
   const bool timing = std::getenv("DCORA_FACTOR_TIMING") != nullptr;
   auto tnow = [] { return std::chrono::steady_clock::now(); };
   auto tms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };

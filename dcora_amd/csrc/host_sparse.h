@@ -36,7 +36,9 @@ class SparseChol {
   // A symmetric (both triangles); block = size of the index groups that are ordered together (d+1 for pose graphs).
   // Returns false when a pivot is not positive (matrix not PD): quick return, like CHOLMOD's
   // quick_return_if_not_posdef.
-  bool factor(const HostCsr &A, int block);
+  // top_unknowns > 0: the upper separators of the dissection, as many depths as fit that many unknowns, are
+  // ordered last as ONE piece (the dense top the device replay of sparse_precond.h wants)
+  bool factor(const HostCsr &A, int block, int top_unknowns = 0);
   bool ok() const { return ok_; }
   long nnzL() const { return (long)Li_.size(); }
   int n() const { return n_; }
@@ -71,6 +73,8 @@ class SparseChol {
 std::vector<int> amd_like_order(const HostCsr &A, int block, std::vector<int> *pieces = nullptr,
                                 int *nhub_cols = nullptr, std::vector<std::pair<int, int>> *col_tasks = nullptr,
                                 int want_tasks = 0,
-                                std::vector<std::vector<std::pair<int, int>>> *col_waves = nullptr);
+                                std::vector<std::vector<std::pair<int, int>>> *col_waves = nullptr,
+                                int top_unknowns = 0);
+int nd_top_default();  // DCORA_ND_TOP, default 3072
 
 }  // namespace dcora

@@ -75,8 +75,27 @@ struct PartInvHost {
   double weights_read_per_apply = 0;  // doubles of stored weights one solve streams
 };
 
+// A Cholesky factor P A P^T = L L^T handed over by dissection pieces: piece s holds the columns [c0, c0 + c) of L as
+// a dense (c + m) x c panel (row-major): the lower-triangular diagonal block over the m rows listed in rows
+// (permuted numbering, ascending; rows that are entirely zero are allowed).  Produced by the host factorisation
+// (piecewise_from_chol) or by the device factorisation (device_chol.h).
+struct PieceFactor {
+  int c0 = 0, c = 0;
+  std::vector<int> rows;
+  std::vector<double> panel;
+};
+struct PiecewiseFactor {
+  int n = 0, nhub = 0;
+  long nnzL = 0;
+  std::vector<int> perm, iperm;
+  std::vector<PieceFactor> pieces;
+};
+void piecewise_from_chol(const SparseChol &chol, PiecewiseFactor *out);
+
 // A symmetric positive definite (both triangles); block = unknowns ordered together.  false => not PD.
+// The first form factorises on the host; the second takes a factor of A in the order nd_top_default() asks for.
 bool build_partitioned_inverse(const HostCsr &A, int block, int nthreads, PartInvHost *out);
+bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, int nthreads, PartInvHost *out);
 
 // host reference of the device schedule (tests of the builder without a GPU): Z = R A^-1, R and Z are r x k
 // column-major

@@ -105,7 +105,8 @@ def test_c4_tiers_certificate_and_min_eig(env):
     # theta returned by fastVerification is a negative-curvature direction usable by escapeSaddle
     assert theta < -cora_flow.MIN_EIG_TOL / 2 and v @ (A @ v) < 0
     oko, lamo, veco, mvo = orc.min_eig(So, tol=1e-4)
-    assert oko and abs(lamo - want) < 1e-6 * max(1.0, abs(want))
+    # (the oracle's Lanczos stops at its tolerance, 1e-4 relative: how far below that it lands depends on X)
+    assert oko and abs(lamo - want) < 1e-4 * max(1.0, abs(want))
 
 
 # ---- C5 ------------------------------------------------------------------------------------------------------------
