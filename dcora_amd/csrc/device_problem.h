@@ -87,8 +87,8 @@ struct DevBsr {
 
 struct DevCsr {
   int nrows = 0, ncols = 0, nnz = 0, n_long = 0;
-  DevBuf<int> rp, ci, long_rows;
-  DevBuf<double> v;
+  DevBuf<int> rp, ci, long_rows, long_cnt;
+  DevBuf<double> v, long_part;
   int upload(const HostCsr &A);
   int upload(int nrows, int ncols, const int *rp, const int *ci, const double *v);
   CsrDev view() const {
@@ -100,6 +100,8 @@ struct DevCsr {
     c.v = v.p;
     c.n_long = n_long;
     c.long_rows = long_rows.p;
+    c.long_part = long_part.p;
+    c.long_cnt = long_cnt.p;
     return c;
   }
 };
@@ -125,7 +127,7 @@ struct SpImage {
   long hub_nnz = 0;
   DevBuf<int> hub_idx, hub_ap, hub_apos;
   DevBuf<double> hub_aval, hub_U, hub_Sinv;
-  // original unknown -> position in image 0 of the replay vector / position of its final value (no hubs only):
+  // original unknown -> position in image 0 of the replay vector / position of its final value (-1 on a hub):
   // lets the caller's kernels write the right-hand side into y and read the result from it (SpFold, kernels.h)
   DevBuf<int> in_pos, out_pos;
   int upload(const PartInvHost &P);
@@ -139,7 +141,17 @@ class SparsePrecond {
   DevBuf<double> y, hub_w;            // this problem's replay vector (two ping-pong images) and hub scratch
   double weights_per_apply = 0;
   bool foldable() const { return im && im->nhub == 0 && im->in_pos.p != nullptr; }
-  SpFold fold() const { return foldable() ? SpFold{y.p, im->in_pos.p, im->out_pos.p} : SpFold{}; }
+  SpFold fold() const {
+    SpFold f;
+    if (foldable()) {
+      f.y = y.p;
+      f.in_pos = im->in_pos.p;
+      f.out_pos = im->out_pos.p;
+    }
+    return f;
+  }
+  // the same for the generic-layout kernels (k_tcg_update1 / k_tangent), which also apply the hub correction
+  SpFold fold_generic() const;
   int attach(std::shared_ptr<const SpImage> image, int rcap);
   int launches() const { return (int)im->levels.size() + 2 + (im->nhub > 0 ? 1 : 0); }
   // Z = R A^-1 for r <= rcap right-hand sides (r x k column-major); R is picked by ctl->cur when g.ctl is set.

@@ -46,6 +46,9 @@ int DevCsr::upload(int nr, int nc, const int *rph, const int *cih, const double 
   }
   DCORA_HIP(long_rows.alloc(std::max(n_long, 1)));
   if (n_long) DCORA_HIP(hipMemcpy(long_rows.p, lr.data(), sizeof(int) * n_long, hipMemcpyHostToDevice));
+  DCORA_HIP(long_part.alloc((size_t)std::max(n_long, 1) * kLongSplit * 16));
+  DCORA_HIP(long_cnt.alloc(std::max(n_long, 1)));
+  DCORA_HIP(hipMemset(long_cnt.p, 0, sizeof(int) * std::max(n_long, 1)));
   return DCORA_OK;
 }
 int DevBsr::upload(const HostBsr &B) {
@@ -637,6 +640,8 @@ int DeviceProblem::rtr_dev(const dcora_ropt_params &prm, dcora_ropt_result *res_
   int last_pace_seq = seq;
 
   std::vector<int> upd2_seq((size_t)std::max(1, h.max_inner));
+  static const bool no_fold = std::getenv("DCORA_RA_NOFOLD") != nullptr;
+  const SpFold sfg = (sparse_precond && !no_fold) ? sp.fold_generic() : SpFold();
   for (int outer = 0; outer < h.max_outer; ++outer) {
     // wait for the previous decision (rtr_init / rtr_decide) before committing to another outer iteration
     if (!spin_until([&] { return hf->last_seq_done >= last_pace_seq || hf->outer_done_seq != 0; }, 20.0))
@@ -663,9 +668,14 @@ int DeviceProblem::rtr_dev(const dcora_ropt_params &prm, dcora_ropt_result *res_
       if (hf->tcg_done_seq >= tcg_first_seq) break;
       launch_spmm(st, m.r, Qv, buf1(delta.p), 0, nullptr, buf1(W.p), 0, nullptr, Gate{c, ++seq, 2});
       launch_hessfix(st, m, Xb(), Sb(), delta.p, W.p, Hd.p, p1.p, Gate{c, ++seq, 2});
-      launch_tcg_update1(st, N, delta.p, Hd.p, eta.p, Heta.p, res.p, p1.p, nP, p2.p, c, hf_dev, ++seq, j);
-      enq_minv(buf1(res.p), Zt.p, p2.p, nV, Gate{c, ++seq, 2});
-      launch_tangent(st, m, Xb(), Zt.p, z.p, res.p, p3.p, p2.p, nV, c, hf_dev, ++seq, 2, j);
+      // sparse preconditioner: its two permutations (and the hub correction) ride in the kernels either side of the
+      // level replay -- two launches fewer per tCG iteration
+      launch_tcg_update1(st, N, delta.p, Hd.p, eta.p, Heta.p, res.p, p1.p, nP, p2.p, c, hf_dev, ++seq, j, m.r, sfg);
+      if (sfg.y)
+        sp.apply(st, m.r, buf1(res.p), Zt.p, Gate{c, ++seq, 2}, true);
+      else
+        enq_minv(buf1(res.p), Zt.p, p2.p, nV, Gate{c, ++seq, 2});
+      launch_tangent(st, m, Xb(), Zt.p, z.p, res.p, p3.p, p2.p, nV, c, hf_dev, ++seq, 2, j, sfg);
       launch_tcg_update2(st, N, z.p, delta.p, p3.p, nP, c, hf_dev, ++seq, j);
       upd2_seq[j] = seq;
     }

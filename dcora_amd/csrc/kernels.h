@@ -35,6 +35,7 @@ inline ManiDesc make_mani(int r, int d, int n, int l, int b) {
   return m;
 }
 
+constexpr int kLongSplit = 8;  // workgroups per long row; the last one to arrive adds the slices in order
 constexpr int kLongRow = 512;  // rows with more entries (a landmark ranged from every pose) get a block of their own
 struct CsrDev {
   int nrows = 0;
@@ -44,6 +45,8 @@ struct CsrDev {
   const double *v = nullptr;
   int n_long = 0;                  // rows with more than kLongRow entries ...
   const int *long_rows = nullptr;  // ... and their indices
+  double *long_part = nullptr;     // n_long x kLongSplit x 16 partial sums of the workgroups sharing a long row
+  int *long_cnt = nullptr;         // n_long arrival counters (zero between launches)
 };
 
 // block-CSR view of a pose-graph matrix: (d+1) x (d+1) dense blocks, row-major inside a block
@@ -115,11 +118,23 @@ int pose_grid(const ManiDesc &m);
 // RG = Proj_X(EG); Sblk_i = sym(Y_i^T EG_i) (spheres: y^T eg); partial |RG|^2 (1 per block)
 void launch_rgrad(hipStream_t st, const ManiDesc &m, Buf2 X, Buf2 EG, Buf2 RG, Buf2 Sblk, int sel,
                   double *partials, Gate g);
+// The sparse preconditioner's two permutations folded into the kernels around it: B scatters the new residual into
+// image 0 of the replay vector (in_pos: original unknown -> position), C reads z from where the replay leaves it
+// (out_pos: original unknown -> final position).  y == nullptr: not folded.
+struct SpFold {
+  double *y = nullptr;
+  const int *in_pos = nullptr, *out_pos = nullptr;
+  // hubs (sparse_precond.h, PartInvHub; the generic-layout kernels only): in_pos / out_pos are -1 on a hub unknown,
+  // z = y1 - U x2 with x2 = Sinv (r(hub) - slices of k_sp_hub_dot), z(hub) = x2
+  int h = 0, hub_split = 0;
+  const int *hub_idx = nullptr;
+  const double *hub_U = nullptr, *hub_Sinv = nullptr, *hub_w = nullptr;
+};
 // out = Proj_X(V); partial <out, R> when R != null.  When p2 != null the prologue evaluates the tCG
 // residual stopping rule |r| <= |r0| min(|r0|^theta, kappa) from the np2 partials of |r|^2.
 void launch_tangent(hipStream_t st, const ManiDesc &m, Buf2 X, const double *V, double *out, const double *R,
                     double *partials, const double *p2, int np2, SolverCtl *ctl, HostFlags *hf, int seq,
-                    int gate, int iter);
+                    int gate, int iter, SpFold sf = SpFold());
 // HV = Proj_X(W - V S); partial <V, HV>
 void launch_hessfix(hipStream_t st, const ManiDesc &m, Buf2 X, Buf2 Sblk, const double *V, const double *W,
                     double *HV, double *partials, Gate g);
@@ -156,7 +171,7 @@ void launch_tcg_init(hipStream_t st, long nelem, const double *z, const double *
                      SolverCtl *ctl, int seq);
 void launch_tcg_update1(hipStream_t st, long nelem, const double *delta, const double *Hd, double *eta,
                         double *Heta, double *res, const double *p1, int np1, double *p2, SolverCtl *ctl,
-                        HostFlags *hf, int seq, int iter);
+                        HostFlags *hf, int seq, int iter, int r = 1, SpFold sf = SpFold());
 void launch_tcg_update2(hipStream_t st, long nelem, const double *z, double *delta, const double *p3, int np3,
                         SolverCtl *ctl, HostFlags *hf, int seq, int iter);
 void launch_rtr_decide(hipStream_t st, const double *pA, int npA, const double *pB, int npB, const double *pC,
@@ -197,13 +212,6 @@ int launch_fused_hess(hipStream_t st, const ManiDesc &m, const CsrDev &Q, const 
                        double *d_new, Buf2 X, Buf2 S, double *Hd, const double *p3, int np3, double *p1,
                        SolverCtl *ctl, int seq, int iter,
                       const BsrDev *Ab = nullptr /* block-CSR copy of Q: 8-lanes-per-pose kernel */);
-// The sparse preconditioner's two permutations folded into the kernels around it: B scatters the new residual into
-// image 0 of the replay vector (in_pos: original unknown -> position), C reads z from where the replay leaves it
-// (out_pos: original unknown -> final position).  y == nullptr: not folded.
-struct SpFold {
-  double *y = nullptr;
-  const int *in_pos = nullptr, *out_pos = nullptr;
-};
 void launch_fused_precond(hipStream_t st, const ManiDesc &m, int ldm, const double *Minv, Buf2 grad,
                           const double *delta, const double *Hd, double *eta, double *Heta, const double *res_old,
                           double *res_new, double *Zpart, const double *p1, int np1, double *p2, SolverCtl *ctl,

@@ -109,19 +109,57 @@ __global__ __launch_bounds__(kBlock) void k_spmm(int r, CsrDev A, Buf2 Xb, int s
   const int lj = threadIdx.x / r, t = threadIdx.x - lj * r;
   double d0 = 0, d1 = 0;
   if ((int)blockIdx.x >= main_grid) {
-    // one block for one long row: the RB entry groups stride over the row, partial sums meet in LDS
-    const int j = A.long_rows[blockIdx.x - main_grid];
-    const int pb = A.rp[j], pe = A.rp[j + 1];
+    // kLongSplit workgroups per long row (a landmark ranged from 7789 poses on tiers.pyfg: one workgroup was the
+    // longest of the launch): each takes a slice, the RB entry groups stride over it, partial sums meet in LDS and
+    // go to a scratch row; the last workgroup to arrive adds the slices in slice order (reproducible) and finishes
+    const int li = ((int)blockIdx.x - main_grid) / kLongSplit, sl = ((int)blockIdx.x - main_grid) % kLongSplit;
+    const int j = A.long_rows[li];
+    const int rb0 = A.rp[j], re0 = A.rp[j + 1];
+    const int per = (re0 - rb0 + kLongSplit - 1) / kLongSplit;
+    const int pb = rb0 + sl * per, pe = min(re0, pb + per);
     double acc = 0;
-    if (lj < RB)
-      for (int p = pb + lj; p < pe; p += RB) acc += A.v[p] * X[(size_t)A.ci[p] * r + t];
+    if (lj < RB) {
+      // eight entries per step with every load in flight before the first use (index clamped, weight masked)
+      for (int p = pb + lj; p < pe; p += 8 * RB) {
+        int c8[8];
+        double w8[8], x8[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int pp = p + q * RB;
+          const bool ok = pp < pe;
+          c8[q] = A.ci[ok ? pp : rb0];
+          w8[q] = ok ? A.v[pp] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x8[q] = X[(size_t)c8[q] * r + t];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc += w8[q] * x8[q];
+      }
+    }
     double *s_part = s_v;  // kBlock doubles
+    __shared__ int s_last;
     __syncthreads();
     s_part[threadIdx.x] = (lj < RB) ? acc : 0.0;
     __syncthreads();
-    if (threadIdx.x < r) {
+    if ((int)threadIdx.x < r) {
       double y = 0;
       for (int q = 0; q < RB; ++q) y += s_part[q * r + threadIdx.x];
+      __hip_atomic_store(A.long_part + ((size_t)li * kLongSplit + sl) * 16 + threadIdx.x, y, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0)
+      s_last = (__hip_atomic_fetch_add(A.long_cnt + li, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) ==
+                kLongSplit - 1);
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) __hip_atomic_store(A.long_cnt + li, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((int)threadIdx.x < r) {
+      double y = 0;
+      for (int q = 0; q < kLongSplit; ++q)
+        y += __hip_atomic_load(A.long_part + ((size_t)li * kLongSplit + q) * 16 + threadIdx.x, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
       const size_t o = (size_t)j * r + threadIdx.x;
       if (DOTS) {
         const double x = X[o];
@@ -135,8 +173,8 @@ __global__ __launch_bounds__(kBlock) void k_spmm(int r, CsrDev A, Buf2 Xb, int s
       const double a = block_sum(d0, s_red);
       const double b = block_sum(d1, s_red);
       if (threadIdx.x == 0) {
-        partials[2 * blockIdx.x] = a;
-        partials[2 * blockIdx.x + 1] = b;
+        partials[2 * (main_grid + li)] = a;
+        partials[2 * (main_grid + li) + 1] = b;
       }
     }
     return;
@@ -217,7 +255,7 @@ __global__ __launch_bounds__(kBlock) void k_spmm(int r, CsrDev A, Buf2 Xb, int s
 void launch_spmm(hipStream_t st, int r, const CsrDev &A, Buf2 X, int selX, const double *G, Buf2 Y, int selY,
                  double *partials, Gate g) {
   const int main_grid = spmm_grid(A.nrows, r);
-  const int grid = main_grid + A.n_long;
+  const int grid = main_grid + A.n_long * kLongSplit;
   if (partials)
     hipLaunchKernelGGL(k_spmm<true>, dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials, g,
                        main_grid);
@@ -445,9 +483,10 @@ __global__ __launch_bounds__(kBlock) void k_tangent(ManiDesc m, Buf2 Xb, const d
                                                     double *__restrict__ out, const double *__restrict__ R,
                                                     double *__restrict__ partials, const double *__restrict__ p2,
                                                     int np2, SolverCtl *ctl, HostFlags *hf, int seq, int gate,
-                                                    int iter) {
+                                                    int iter, SpFold sf) {
   if (gated(ctl, seq, gate)) return;
   __shared__ double s_red[16];
+  __shared__ double s_x2[64 * 16];
   if (p2) {
     // ROPTLIB tCG_TR stopping rule (theta = 1, kappa = 0.1): |r| <= |r0| min(|r0|^theta, kappa)
     const double nr = sqrt(sum_partials(p2, np2, 1, 0, s_red));
@@ -468,13 +507,47 @@ __global__ __launch_bounds__(kBlock) void k_tangent(ManiDesc m, Buf2 Xb, const d
   const double *X = pick(Xb, ctl, 0);
   const int r = m.r;
   const long items = (long)m.n + m.l + m.num_euc();
+  // sparse preconditioner folded in (generic layout): V(col, t) is read from where the level replay left it, with the
+  // hub correction of k_sp_permute_out_hub; x2 = Sinv (R(hub) - a^T y1) is rebuilt by every workgroup
+  const bool folded = sf.y != nullptr;
+  if (folded && sf.h > 0) {
+    for (int e = threadIdx.x; e < sf.h * r; e += kBlock) {
+      const int q = e / r, t = e - q * r;
+      double s = 0;
+      for (int q2 = 0; q2 < sf.h; ++q2) {
+        double w = R[(size_t)sf.hub_idx[q2] * r + t];
+        for (int sl = 0; sl < sf.hub_split; ++sl) w -= sf.hub_w[((size_t)q2 * sf.hub_split + sl) * r + t];
+        s += sf.hub_Sinv[(size_t)q * sf.h + q2] * w;
+      }
+      s_x2[e] = s;
+    }
+    __syncthreads();
+  }
+  auto vfold = [&](size_t col, int t) -> double {
+    const int jp = sf.in_pos[col];
+    if (jp < 0) {  // a hub unknown
+      for (int q = 0; q < sf.h; ++q)
+        if ((size_t)sf.hub_idx[q] == col) return s_x2[q * r + t];
+      return 0.0;
+    }
+    double v = sf.y[(size_t)sf.out_pos[col] * r + t];
+    for (int q = 0; q < sf.h; ++q) v -= sf.hub_U[(size_t)jp * sf.h + q] * s_x2[q * r + t];
+    return v;
+  };
   double acc = 0;
   for (long it = (long)blockIdx.x * kBlock + threadIdx.x; it < items; it += (long)gridDim.x * kBlock) {
     if (it < m.n) {
       const size_t o = (size_t)m.rot_col((int)it) * r;
       Blk<D, RM> Y, W;
       ld_blk<D, RM>(X + o, r, Y);
-      ld_blk<D, RM>(V + o, r, W);
+      if (folded) {
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+          for (int t = 0; t < RM; ++t) W.a[a][t] = (t < r) ? vfold((size_t)m.rot_col((int)it) + a, t) : 0.0;
+      } else {
+        ld_blk<D, RM>(V + o, r, W);
+      }
       double S[D][D];
       sym_gram<D, RM>(Y, W, S);
       sub_AS<D, RM>(W, Y, S);
@@ -485,18 +558,27 @@ __global__ __launch_bounds__(kBlock) void k_tangent(ManiDesc m, Buf2 Xb, const d
       }
       st_blk<D, RM>(out + o, r, W);
     } else if (it < m.n + m.l) {
-      const size_t o = (size_t)m.sphere_col((int)(it - m.n)) * r;
+      const size_t col = (size_t)m.sphere_col((int)(it - m.n));
+      const size_t o = col * r;
+      double vv[RM];
+#pragma unroll
+      for (int t = 0; t < RM; ++t) vv[t] = (t < r) ? (folded ? vfold(col, t) : V[o + t]) : 0.0;
       double s = 0;
-      for (int t = 0; t < r; ++t) s += X[o + t] * V[o + t];
-      for (int t = 0; t < r; ++t) {
-        const double v = V[o + t] - X[o + t] * s;
-        if (R) acc += v * R[o + t];
-        out[o + t] = v;
-      }
+#pragma unroll
+      for (int t = 0; t < RM; ++t)
+        if (t < r) s += X[o + t] * vv[t];
+#pragma unroll
+      for (int t = 0; t < RM; ++t)
+        if (t < r) {
+          const double v = vv[t] - X[o + t] * s;
+          if (R) acc += v * R[o + t];
+          out[o + t] = v;
+        }
     } else {
-      const size_t o = (size_t)m.euc_col((int)(it - m.n - m.l)) * r;
+      const size_t col = (size_t)m.euc_col((int)(it - m.n - m.l));
+      const size_t o = col * r;
       for (int t = 0; t < r; ++t) {
-        const double v = V[o + t];
+        const double v = folded ? vfold(col, t) : V[o + t];
         if (R) acc += v * R[o + t];
         out[o + t] = v;
       }
@@ -855,9 +937,9 @@ void launch_rgrad(hipStream_t st, const ManiDesc &m, Buf2 X, Buf2 EG, Buf2 RG, B
 }
 void launch_tangent(hipStream_t st, const ManiDesc &m, Buf2 X, const double *V, double *out, const double *R,
                     double *partials, const double *p2, int np2, SolverCtl *ctl, HostFlags *hf, int seq,
-                    int gate, int iter) {
+                    int gate, int iter, SpFold sf) {
   const int grid = pose_grid(m);
-  DCORA_DISPATCH_POSE(k_tangent, m, grid, st, m, X, V, out, R, partials, p2, np2, ctl, hf, seq, gate, iter);
+  DCORA_DISPATCH_POSE(k_tangent, m, grid, st, m, X, V, out, R, partials, p2, np2, ctl, hf, seq, gate, iter, sf);
 }
 void launch_hessfix(hipStream_t st, const ManiDesc &m, Buf2 X, Buf2 Sblk, const double *V, const double *W,
                     double *HV, double *partials, Gate g) {
@@ -1041,7 +1123,7 @@ __global__ __launch_bounds__(kBlock) void k_tcg_update1(long nelem, const double
                                                         double *__restrict__ Heta, double *__restrict__ res,
                                                         const double *__restrict__ p1, int np1,
                                                         double *__restrict__ p2, SolverCtl *ctl, HostFlags *hf,
-                                                        int seq, int iter) {
+                                                        int seq, int iter, int r, SpFold sf) {
   if (gated(ctl, seq, 2)) return;
   __shared__ double s_red[16];
   const int par = iter & 1;
@@ -1062,6 +1144,11 @@ __global__ __launch_bounds__(kBlock) void k_tcg_update1(long nelem, const double
       const double rr = res[i] + alpha * h;
       res[i] = rr;
       acc += rr * rr;
+      if (sf.y) {  // the replay's permute-in folded in: the new residual goes straight to its place in image 0
+        const long col = i / r;
+        const int jp = sf.in_pos[col];
+        if (jp >= 0) sf.y[(size_t)jp * r + (i - col * r)] = rr;
+      }
     }
   }
   const double tot = block_sum(acc, s_red);
@@ -1162,9 +1249,9 @@ void launch_tcg_init(hipStream_t st, long nelem, const double *z, const double *
 }
 void launch_tcg_update1(hipStream_t st, long nelem, const double *delta, const double *Hd, double *eta,
                         double *Heta, double *res, const double *p1, int np1, double *p2, SolverCtl *ctl,
-                        HostFlags *hf, int seq, int iter) {
+                        HostFlags *hf, int seq, int iter, int r, SpFold sf) {
   hipLaunchKernelGGL(k_tcg_update1, dim3(vec_grid(nelem)), dim3(kBlock), 0, st, nelem, delta, Hd, eta, Heta, res,
-                     p1, np1, p2, ctl, hf, seq, iter);
+                     p1, np1, p2, ctl, hf, seq, iter, r, sf);
 }
 void launch_tcg_update2(hipStream_t st, long nelem, const double *z, double *delta, const double *p3, int np3,
                         SolverCtl *ctl, HostFlags *hf, int seq, int iter) {

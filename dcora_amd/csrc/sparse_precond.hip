@@ -271,8 +271,9 @@ int SpImage::upload(const PartInvHost &P) {
   nsegs_total = (long)P.segs.size();
   nhub = P.hub.h;
   hub_nnz = (long)P.hub.aval.size();
-  if (nhub == 0) {
-    std::vector<int> ip((size_t)k), op((size_t)k);
+  {
+    // original unknown -> position in image 0 / position of the final value; -1 on a hub unknown
+    std::vector<int> ip((size_t)P.kfull, -1), op((size_t)P.kfull, -1);
     for (int j = 0; j < k; ++j) {
       ip[(size_t)P.perm[j]] = j;
       op[(size_t)P.perm[j]] = P.out_off[j];
@@ -334,17 +335,33 @@ void SparsePrecond::apply(hipStream_t st, int r, Buf2 R, double *Z, Gate g, bool
   const std::vector<SpLevel> &levels = I.levels;
   const long n = (long)r * k;
   const int grid = (int)std::min<long>((n + kBlock - 1) / kBlock, 2048);
-  levels_only = levels_only && foldable();
+  levels_only = levels_only && im->in_pos.p != nullptr;
   if (!levels_only) hipLaunchKernelGGL(k_sp_permute_in, dim3(grid), dim3(kBlock), 0, st, r, k, perm.p, R, y.p, g);
   for (const SpLevel &lv : levels) launch_level(st, r, lv, tasks.p, segs.p, vals.p, idxs.p, y.p, g);
-  if (levels_only) return;
+  if (levels_only && nhub == 0) return;
   if (nhub > 0) {
     HubDev H{nhub, hub_idx.p, hub_ap.p, hub_apos.p, hub_aval.p, hub_U.p, hub_Sinv.p, hub_w.p};
     hipLaunchKernelGGL(k_sp_hub_dot, dim3(nhub * kHubSplit), dim3(kBlock), 0, st, r, H, y.p, g);
+    if (levels_only) return;  // the caller's kernel applies the hub correction while it reads y (fold_generic())
     hipLaunchKernelGGL(k_sp_permute_out_hub, dim3(grid), dim3(kBlock), 0, st, r, k, perm.p, out_off.p, y.p, Z, H, R, g);
   } else {
     hipLaunchKernelGGL(k_sp_permute_out, dim3(grid), dim3(kBlock), 0, st, r, k, perm.p, out_off.p, y.p, Z, g);
   }
+}
+
+SpFold SparsePrecond::fold_generic() const {
+  SpFold f;
+  if (!im || !im->in_pos.p) return f;
+  f.y = y.p;
+  f.in_pos = im->in_pos.p;
+  f.out_pos = im->out_pos.p;
+  f.h = im->nhub;
+  f.hub_split = kHubSplit;
+  f.hub_idx = im->hub_idx.p;
+  f.hub_U = im->hub_U.p;
+  f.hub_Sinv = im->hub_Sinv.p;
+  f.hub_w = hub_w.p;
+  return f;
 }
 
 double SparsePrecond::bytes_per_apply(int r) const {
