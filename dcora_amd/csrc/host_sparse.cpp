@@ -328,7 +328,11 @@ std::vector<int> amd_like_order(const HostCsr &A, int block, std::vector<int> *p
   int next_cid = 0;
   std::vector<int> cuts;
   // leaf sub-domains of ~96 unknowns: 24 pose blocks, or 96 scalar unknowns when the graph is not block-compressed
-  const int leaf_nodes = std::max(24, 96 / block);
+  static const int leaf_unknowns = [] {
+    const char *e = std::getenv("DCORA_ND_LEAF");
+    return e ? std::max(8, atoi(e)) : 96;
+  }();
+  int leaf_nodes = std::max(leaf_unknowns / 4, leaf_unknowns / block);
   std::vector<std::pair<int, int>> tasks;
   const int task_nodes = (col_tasks && want_tasks > 1) ? std::max(4 * leaf_nodes, (int)all.size() / want_tasks) : 0;
   std::vector<std::vector<std::pair<int, int>>> waves;
@@ -353,6 +357,11 @@ std::vector<int> amd_like_order(const HostCsr &A, int block, std::vector<int> *p
         top_depth = (int)dpt + 1;
       }
       if (top_depth < 2) top_depth = 0;  // one depth alone is the plain tree
+      // Surface-like graphs (many depths fit the dense top) also want leaves twice as large: one depth less, and
+      // their leaf level is small next to the launch it saves.  Measured per application of the replay, leaves of
+      // 96 / 192 / 384 unknowns: sphere2500 49 / 41 / 39 us, torus3D 89 / 75 / 74, tiers.pyfg 72 / 65 / 82,
+      // an agent of the 100k lattice (two depths in the top) 169 / 190 / 235.
+      if (top_depth >= 4 && std::getenv("DCORA_ND_LEAF") == nullptr) leaf_nodes *= 2;
     }
   }
   nd_recurse(G, all, comp_id, next_cid, level, border, cuts, leaf_nodes, task_nodes, tasks, waves, top_depth, nullptr);

@@ -523,16 +523,41 @@ __global__ __launch_bounds__(kBlock) void k_tangent(ManiDesc m, Buf2 Xb, const d
     }
     __syncthreads();
   }
-  auto vfold = [&](size_t col, int t) -> double {
-    const int jp = sf.in_pos[col];
-    if (jp < 0) {  // a hub unknown
-      for (int q = 0; q < sf.h; ++q)
-        if ((size_t)sf.hub_idx[q] == col) return s_x2[q * r + t];
-      return 0.0;
+  // NC consecutive columns starting at col0: positions first, then every value, straight line (a hub column -- rare --
+  // is patched afterwards)
+  auto vcols = [&](size_t col0, auto nc_tag, double (*vv)[RM]) {
+    constexpr int NC = decltype(nc_tag)::value;
+    int jp[NC], op[NC];
+#pragma unroll
+    for (int a = 0; a < NC; ++a) {
+      jp[a] = sf.in_pos[col0 + a];
+      op[a] = sf.out_pos[col0 + a];
     }
-    double v = sf.y[(size_t)sf.out_pos[col] * r + t];
-    for (int q = 0; q < sf.h; ++q) v -= sf.hub_U[(size_t)jp * sf.h + q] * s_x2[q * r + t];
-    return v;
+#pragma unroll
+    for (int a = 0; a < NC; ++a)
+#pragma unroll
+      for (int t = 0; t < RM; ++t) vv[a][t] = (t < r) ? sf.y[(size_t)max(op[a], 0) * r + t] : 0.0;
+    for (int q = 0; q < sf.h; ++q) {
+      double u[NC];
+#pragma unroll
+      for (int a = 0; a < NC; ++a) u[a] = sf.hub_U[(size_t)max(jp[a], 0) * sf.h + q];
+#pragma unroll
+      for (int a = 0; a < NC; ++a)
+#pragma unroll
+        for (int t = 0; t < RM; ++t)
+          if (t < r) vv[a][t] -= u[a] * s_x2[q * r + t];
+    }
+#pragma unroll
+    for (int a = 0; a < NC; ++a)
+      if (jp[a] < 0) {
+#pragma unroll
+        for (int t = 0; t < RM; ++t) vv[a][t] = 0.0;
+        for (int q = 0; q < sf.h; ++q)
+          if ((size_t)sf.hub_idx[q] == col0 + a)
+#pragma unroll
+            for (int t = 0; t < RM; ++t)
+              if (t < r) vv[a][t] = s_x2[q * r + t];
+      }
   };
   double acc = 0;
   for (long it = (long)blockIdx.x * kBlock + threadIdx.x; it < items; it += (long)gridDim.x * kBlock) {
@@ -541,10 +566,7 @@ __global__ __launch_bounds__(kBlock) void k_tangent(ManiDesc m, Buf2 Xb, const d
       Blk<D, RM> Y, W;
       ld_blk<D, RM>(X + o, r, Y);
       if (folded) {
-#pragma unroll
-        for (int a = 0; a < D; ++a)
-#pragma unroll
-          for (int t = 0; t < RM; ++t) W.a[a][t] = (t < r) ? vfold((size_t)m.rot_col((int)it) + a, t) : 0.0;
+        vcols((size_t)m.rot_col((int)it), std::integral_constant<int, D>{}, W.a);
       } else {
         ld_blk<D, RM>(V + o, r, W);
       }
@@ -560,9 +582,14 @@ __global__ __launch_bounds__(kBlock) void k_tangent(ManiDesc m, Buf2 Xb, const d
     } else if (it < m.n + m.l) {
       const size_t col = (size_t)m.sphere_col((int)(it - m.n));
       const size_t o = col * r;
-      double vv[RM];
+      double vv1[1][RM];
+      if (folded) {
+        vcols(col, std::integral_constant<int, 1>{}, vv1);
+      } else {
 #pragma unroll
-      for (int t = 0; t < RM; ++t) vv[t] = (t < r) ? (folded ? vfold(col, t) : V[o + t]) : 0.0;
+        for (int t = 0; t < RM; ++t) vv1[0][t] = (t < r) ? V[o + t] : 0.0;
+      }
+      const double *vv = vv1[0];
       double s = 0;
 #pragma unroll
       for (int t = 0; t < RM; ++t)
@@ -577,11 +604,20 @@ __global__ __launch_bounds__(kBlock) void k_tangent(ManiDesc m, Buf2 Xb, const d
     } else {
       const size_t col = (size_t)m.euc_col((int)(it - m.n - m.l));
       const size_t o = col * r;
-      for (int t = 0; t < r; ++t) {
-        const double v = folded ? vfold(col, t) : V[o + t];
-        if (R) acc += v * R[o + t];
-        out[o + t] = v;
+      double ve[1][RM];
+      if (folded) {
+        vcols(col, std::integral_constant<int, 1>{}, ve);
+      } else {
+#pragma unroll
+        for (int t = 0; t < RM; ++t) ve[0][t] = (t < r) ? V[o + t] : 0.0;
       }
+#pragma unroll
+      for (int t = 0; t < RM; ++t)
+        if (t < r) {
+          const double v = ve[0][t];
+          if (R) acc += v * R[o + t];
+          out[o + t] = v;
+        }
     }
   }
   if (partials) {
