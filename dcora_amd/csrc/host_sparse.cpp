@@ -176,6 +176,61 @@ void nd_recurse(const NDGraph &G, std::vector<int> nodes, std::vector<int> &comp
     if ((int)sep_waves.size() <= dep) sep_waves.resize(dep + 1);
     sep_waves[dep].emplace_back(start, count);
   };
+  // one dissection step of a labelled component (comp_id == cid, level == -1 on its nodes):
+  // 0 = split into sep / left / right, 1 = disconnected (reached / rest returned in left / right), 2 = too shallow
+  auto try_split = [&](const std::vector<int> &cur, int cid, std::vector<int> &sep, std::vector<int> &left,
+                       std::vector<int> &right) -> int {
+    sep.clear();
+    left.clear();
+    right.clear();
+    int root = cur[0];
+    bfs_levels(G, comp_id, cid, root, level, order);  // pseudo-peripheral root: two more sweeps below
+    if (order.size() < cur.size()) {
+      for (int u : cur)
+        if (level[u] < 0) right.push_back(u);
+      left = order;
+      return 1;
+    }
+    for (int sweep = 0; sweep < 2; ++sweep) {
+      root = order.back();
+      for (int u : cur) level[u] = -1;
+      bfs_levels(G, comp_id, cid, root, level, order);
+    }
+    const int depth = level[order.back()];
+    if (depth < 2) return 2;
+    // separator = level closest to the median node
+    const int mid = level[order[order.size() / 2]];
+    const int sep_level = std::min(std::max(mid, 1), depth - 1);
+    for (int u : order) {
+      if (level[u] == sep_level)
+        sep.push_back(u);  // separators are eliminated last
+      else if (level[u] < sep_level)
+        left.push_back(u);
+      else
+        right.push_back(u);
+    }
+    return 0;
+  };
+  auto label = [&](const std::vector<int> &nodes_, int cid) {
+    for (int u : nodes_) {
+      comp_id[u] = cid;
+      level[u] = -1;
+    }
+  };
+  auto unlabel = [&](const std::vector<int> &nodes_) {
+    for (int u : nodes_) comp_id[u] = -1;
+  };
+  auto push = [&](std::vector<int> &&nodes_, char in_task, int dep) {
+    stack.push_back(std::move(nodes_));
+    stack_in_task.push_back(in_task);
+    stack_depth.push_back(dep);
+  };
+  auto count_sep = [&](int dep, size_t count) {
+    if (!sep_nodes_by_depth) return;
+    if ((int)sep_nodes_by_depth->size() <= dep) sep_nodes_by_depth->resize(dep + 1, 0);
+    (*sep_nodes_by_depth)[dep] += (long)count;
+  };
+  std::vector<int> sep, left, right;
   while (!stack.empty()) {
     std::vector<int> cur = std::move(stack.back());
     char in_task = stack_in_task.back();
@@ -189,81 +244,49 @@ void nd_recurse(const NDGraph &G, std::vector<int> nodes, std::vector<int> &comp
       in_task = 1;
     }
     const int cid = next_cid++;
-    for (int u : cur) {
-      comp_id[u] = cid;
-      level[u] = -1;
-    }
+    label(cur, cid);
     if ((int)cur.size() <= leaf_nodes) {
       std::vector<int> lo;
       leaf_order(G, cur, comp_id, cid, lo);
       for (auto it = lo.rbegin(); it != lo.rend(); ++it) rev.push_back(*it);
       cuts.push_back((int)rev.size());
-      for (int u : cur) comp_id[u] = -1;
+      unlabel(cur);
       continue;
     }
-    // pseudo-peripheral root: two BFS sweeps
-    int root = cur[0];
-    bfs_levels(G, comp_id, cid, root, level, order);
-    if (order.size() < cur.size()) {
-      // disconnected: split off the reached component
-      std::vector<int> rest;
-      for (int u : cur)
-        if (level[u] < 0) rest.push_back(u);
-      std::vector<int> reached = order;
-      for (int u : cur) comp_id[u] = -1;
-      stack.push_back(std::move(rest));
-      stack.push_back(std::move(reached));
-      stack_in_task.push_back(in_task);
-      stack_in_task.push_back(in_task);
-      stack_depth.push_back(dep);
-      stack_depth.push_back(dep);
+    const int how = try_split(cur, cid, sep, left, right);
+    if (how == 1) {  // disconnected: split off the reached component
+      unlabel(cur);
+      push(std::move(right), in_task, dep);
+      push(std::move(left), in_task, dep);
       continue;
     }
-    for (int sweep = 0; sweep < 2; ++sweep) {
-      root = order.back();
-      for (int u : cur) level[u] = -1;
-      bfs_levels(G, comp_id, cid, root, level, order);
-    }
-    const int depth = level[order.back()];
-    if (depth < 2) {
+    if (how == 2) {
       std::vector<int> lo;
       leaf_order(G, cur, comp_id, cid, lo);
       if (!in_task) note_sep(dep, (int)rev.size(), (int)lo.size());
       for (auto it = lo.rbegin(); it != lo.rend(); ++it) rev.push_back(*it);
       cuts.push_back((int)rev.size());
-      for (int u : cur) comp_id[u] = -1;
+      unlabel(cur);
       continue;
     }
-    // separator = level closest to the median node
-    const int mid = level[order[order.size() / 2]];
-    const int sep_level = std::min(std::max(mid, 1), depth - 1);
-    std::vector<int> left, right;
-    const bool to_top = dep < top_depth;
-    std::vector<int> &sep_dst = to_top ? top : rev;
-    const int sep_start = (int)sep_dst.size();
-    for (int u : order) {
-      if (level[u] == sep_level)
-        sep_dst.push_back(u);  // separators are eliminated last
-      else if (level[u] < sep_level)
-        left.push_back(u);
-      else
-        right.push_back(u);
+    unlabel(cur);
+    count_sep(dep, sep.size());
+    if (dep < top_depth) {
+      top.insert(top.end(), sep.begin(), sep.end());
+      push(std::move(left), in_task, dep + 1);
+      push(std::move(right), in_task, dep + 1);
+      continue;
     }
-    if (sep_nodes_by_depth) {
-      if ((int)sep_nodes_by_depth->size() <= dep) sep_nodes_by_depth->resize(dep + 1, 0);
-      (*sep_nodes_by_depth)[dep] += (long)sep_dst.size() - sep_start;
-    }
-    if (!to_top) {
-      cuts.push_back((int)rev.size());
-      if (!in_task) note_sep(dep, sep_start, (int)rev.size() - sep_start);
-    }
-    for (int u : cur) comp_id[u] = -1;
-    stack.push_back(std::move(left));
-    stack.push_back(std::move(right));
-    stack_in_task.push_back(in_task);
-    stack_in_task.push_back(in_task);
-    stack_depth.push_back(dep + 1);
-    stack_depth.push_back(dep + 1);
+    // (Measured and dropped: the separators of the two children joined to this one as ONE piece -- a four-way
+    // dissection step, to halve the dependent levels of the device replay below the dense top.  BFS-level separators
+    // leave many children disconnected, so only one depth pair merged on the critical path of a 100k-lattice agent:
+    // 19 -> 17 launches, +32 MB of weights, 170 -> 190 us per application.)
+    const int sep_start = (int)rev.size();
+    rev.insert(rev.end(), sep.begin(), sep.end());
+    cuts.push_back((int)rev.size());
+    if (!in_task) note_sep(dep, sep_start, (int)rev.size() - sep_start);
+    push(std::move(left), in_task, dep + 1);
+    push(std::move(right), in_task, dep + 1);
   }
   for (auto it = rev.rbegin(); it != rev.rend(); ++it) out.push_back(*it);
   // cuts were taken in the reversed order: position p there is position total - p in the final order
@@ -361,7 +384,10 @@ std::vector<int> amd_like_order(const HostCsr &A, int block, std::vector<int> *p
       // their leaf level is small next to the launch it saves.  Measured per application of the replay, leaves of
       // 96 / 192 / 384 unknowns: sphere2500 49 / 41 / 39 us, torus3D 89 / 75 / 74, tiers.pyfg 72 / 65 / 82,
       // an agent of the 100k lattice (two depths in the top) 169 / 190 / 235.
-      if (top_depth >= 4 && std::getenv("DCORA_ND_LEAF") == nullptr) leaf_nodes *= 2;
+      if (top_depth >= 3 && std::getenv("DCORA_ND_LEAF") == nullptr) leaf_nodes *= 2;
+      if (std::getenv("DCORA_FACTOR_TIMING"))
+        std::fprintf(stderr, "[order] %d nodes: dense top of %d depths, leaves of %d nodes\n", (int)all.size(), top_depth,
+                     leaf_nodes);
     }
   }
   nd_recurse(G, all, comp_id, next_cid, level, border, cuts, leaf_nodes, task_nodes, tasks, waves, top_depth, nullptr);
