@@ -70,6 +70,10 @@ int device_chol_piecewise_factor(const HostCsr &A, int block, int top_unknowns, 
 struct PartInvHost;
 int build_partitioned_inverse_auto(const HostCsr &A, int block, int nthreads, int device, PartInvHost *out);
 
+// dense inverse of a small SPD matrix, entirely on the device: Minv (device, k rows of ldm >= k doubles, row-major,
+// both triangles) <- A^-1.  *pd = false (and Minv undefined) when A is not positive definite.
+int device_dense_spd_inverse(const HostCsr &A, int device, double *Minv, int ldm, bool *pd);
+
 void chol_cache_clear();
 
 }  // namespace dcora

@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) void k_chol_extend_add(const PieceDev *__restr
 // panel below.  A pivot that is not positive raises *fail.
 __global__ __launch_bounds__(256) void k_chol_potrf(const PieceDev *__restrict__ pieces, const int *__restrict__ list,
                                                     int j0, double *__restrict__ F, double *__restrict__ Linv,
-                                                    int *__restrict__ fail, double *__restrict__ logdet) {
+                                                    int *__restrict__ fail, double *__restrict__ logdet,
+                                                    int always_inv) {
   if (*fail) return;
   const PieceDev P = pieces[list[blockIdx.x]];
   const int jb = min(NB, P.c - j0);
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256) void k_chol_potrf(const PieceDev *__restrict__
     const int r = e / jb, j = e - r * jb;
     if (j <= r) M[(long long)r * f + j] = L[r][j];
   }
-  if (P.m == 0 && j0 + jb >= P.c) return;  // nothing below the last panel of a root
+  if (!always_inv && P.m == 0 && j0 + jb >= P.c) return;  // nothing below the last panel of a root
   // inverse of the triangular block, column k by lane group k (4 lanes share the sum over l)
   {
     const int k = tid >> 2;
@@ -241,6 +242,140 @@ __global__ __launch_bounds__(256) void k_chol_pack(const PieceDev *__restrict__ 
     const int i = (int)(e / c), j = (int)(e - (long long)i * c);
     O[e] = (i >= c || j <= i) ? M[(long long)i * f + j] : 0.0;
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Dense inverse of a small SPD matrix on the device (the dense preconditioner of blocks up to 8000 unknowns,
+// ref src/QuadraticProblem.cpp:70-84 applied as an explicit inverse): A = L L^T by the panel kernels above (the whole
+// matrix is one front), Y = L^-1 block row by block row, A^-1 = Y^T Y.  Y is kept transposed (YT, upper block
+// triangular) so that every product below runs over contiguous rows of both operands.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dense_scatter(int k, const int *__restrict__ rp, const int *__restrict__ ci,
+                                                       const double *__restrict__ v, double *__restrict__ A) {
+  const int i = blockIdx.x;
+  for (int p = rp[i] + threadIdx.x; p < rp[i + 1]; p += 256) {
+    const int j = ci[p];
+    if (j <= i) A[(size_t)i * k + j] = v[p];
+  }
+}
+
+// acc += A-rows x B-rows^T over K chunks of 64: A(ia, l) and B(ib, l), l in [l0, l1)
+__device__ __forceinline__ void tile_product_range(const double *__restrict__ Arow, const double *__restrict__ Brow,
+                                                   long long ld, int arows, int brows, int l0, int l1,
+                                                   double (*As)[NB + 1], double (*Bs)[NB + 1], double acc[4][4]) {
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  for (int l = l0; l < l1; l += NB) {
+    const int K = min(NB, l1 - l);
+    __syncthreads();
+    for (int e = tid; e < NB * NB; e += 256) {
+      const int i = e >> 6, kk = e & 63;
+      As[kk][i] = (i < arows && kk < K) ? Arow[(long long)i * ld + l + kk] : 0.0;
+      Bs[kk][i] = (i < brows && kk < K) ? Brow[(long long)i * ld + l + kk] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int kk = 0; kk < NB; ++kk) {
+      double a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] = As[kk][ty + 16 * u];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) b[v] = Bs[kk][tx + 16 * v];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] = fma(a[u], b[v], acc[u][v]);
+    }
+  }
+}
+
+// block row ib of Y = L^-1, written as block column ib of YT:  YT(j, ib) = -(YT(j, j..ib) L(ib, j..ib)^T) Linv_ib^T
+// for the block rows j < ib (one workgroup each), YT(ib, ib) = Linv_ib^T
+__global__ __launch_bounds__(256) void k_dense_trtri_row(int k, int ib, const double *__restrict__ L,
+                                                         double *__restrict__ YT, const double *__restrict__ Linv) {
+  __shared__ double As[NB][NB + 1];
+  __shared__ double Bs[NB][NB + 1];
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const int i0 = ib * NB, ni = min(NB, k - i0);
+  const double *__restrict__ Li = Linv + (size_t)ib * NB * NB;
+  if ((int)blockIdx.x == ib) {  // diagonal block: the transpose of the inverse of the diagonal block of L
+    for (int e = tid; e < NB * NB; e += 256) {
+      const int a = e >> 6, b = e & 63;
+      if (a < ni && b < ni) YT[(size_t)(i0 + a) * k + i0 + b] = Li[b * NB + a];
+    }
+    return;
+  }
+  const int j = blockIdx.x, j0 = j * NB;
+  double acc[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[u][v] = 0;
+  // TT(a, m) = sum_l YT(j0 + a, l) L(i0 + m, l), l over the block columns j .. ib - 1
+  tile_product_range(YT + (size_t)j0 * k, L + (size_t)i0 * k, k, NB, ni, j0, i0, As, Bs, acc);
+  __syncthreads();
+  // second product from LDS: YT(j0 + a, i0 + b) = -sum_m TT(a, m) Linv(b, m)
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) As[tx + 16 * v][ty + 16 * u] = acc[u][v];  // As[m][a]
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int b = e >> 6, mm = e & 63;
+    Bs[mm][b] = Li[b * NB + mm];  // Bs[m][b]
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[u][v] = 0;
+#pragma unroll 8
+  for (int mm = 0; mm < NB; ++mm) {
+    double a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] = As[mm][ty + 16 * u];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) b[v] = Bs[mm][tx + 16 * v];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) acc[u][v] = fma(a[u], b[v], acc[u][v]);
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int b = tx + 16 * v;
+      if (b < ni) YT[(size_t)(j0 + ty + 16 * u) * k + i0 + b] = -acc[u][v];
+    }
+}
+
+// M = Y^T Y = YT YT^T: tile (ta, tb), tb <= ta, sums over the columns l >= block ta; both triangles are written
+__global__ __launch_bounds__(256) void k_dense_lauum(int k, const double *__restrict__ YT, double *__restrict__ M,
+                                                     int ldm) {
+  __shared__ double As[NB][NB + 1];
+  __shared__ double Bs[NB][NB + 1];
+  int ta = (int)((sqrtf(8.0f * (float)blockIdx.x + 1.0f) - 1.0f) * 0.5f);
+  while ((ta + 1) * (ta + 2) / 2 <= (int)blockIdx.x) ++ta;
+  while (ta * (ta + 1) / 2 > (int)blockIdx.x) --ta;
+  const int tb = blockIdx.x - ta * (ta + 1) / 2;
+  const int a0 = ta * NB, b0 = tb * NB;
+  const int na = min(NB, k - a0), nb = min(NB, k - b0);
+  double acc[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[u][v] = 0;
+  tile_product_range(YT + (size_t)a0 * k, YT + (size_t)b0 * k, k, na, nb, a0, k, As, Bs, acc);
+  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int a = a0 + ty + 16 * u, b = b0 + tx + 16 * v;
+      if (a < k && b < k) {
+        M[(size_t)a * ldm + b] = acc[u][v];
+        M[(size_t)b * ldm + a] = acc[u][v];
+      }
+    }
 }
 
 inline uint64_t mix64(uint64_t h, uint64_t w) {
@@ -464,7 +599,7 @@ int factor_on_device(const HostCsr &A, int block, int top, int device, bool *pd,
         break;
       case 1:
         hipLaunchKernelGGL(k_chol_potrf, dim3(L.gx), dim3(256), 0, st, img->pieces.p, list, L.j0, F, img->linv.p,
-                           img->fail.p, img->logdet.p);
+                           img->fail.p, img->logdet.p, 0);
         break;
       case 2:
         hipLaunchKernelGGL(k_chol_trsm, dim3(L.gx, L.gy), dim3(256), 0, st, img->pieces.p, list, L.j0, F, img->linv.p,
@@ -550,6 +685,73 @@ int device_chol_piecewise_factor(const HostCsr &A, int block, int top_unknowns, 
     set_last_error("matrix is not positive definite");
     return DCORA_ERR_NOT_PD;
   }
+  return DCORA_OK;
+}
+
+int device_dense_spd_inverse(const HostCsr &A, int device, double *Minv, int ldm, bool *pd) {
+  const int k = A.n;
+  DCORA_HIP(hipSetDevice(device));
+  hipStream_t st = nullptr;
+  int rc = stream_acquire(device, &st);
+  if (rc) return rc;
+  struct Rel {
+    int device;
+    hipStream_t st;
+    ~Rel() { stream_release(device, st); }
+  } rel_guard{device, st};
+  const int nb = (k + NB - 1) / NB;
+  // one allocation for everything (hipMalloc / hipFree synchronise the device: agents are set up concurrently)
+  const size_t nnz = A.ci.size();
+  auto up16 = [](size_t bytes) { return (bytes + 15) & ~(size_t)15; };
+  const size_t o_L = 0, o_YT = o_L + up16((size_t)k * k * 8), o_linv = o_YT + up16((size_t)k * k * 8),
+               o_v = o_linv + up16((size_t)nb * NB * NB * 8), o_logdet = o_v + up16(std::max<size_t>(1, nnz) * 8),
+               o_piece = o_logdet + 16, o_rp = o_piece + up16(sizeof(PieceDev)), o_ci = o_rp + up16(((size_t)k + 1) * 4),
+               o_fail = o_ci + up16(std::max<size_t>(1, nnz) * 4), o_list = o_fail + 16, total = o_list + 16;
+  DevBuf<char> arena;
+  DCORA_HIP(arena.alloc(total));
+  struct {
+    double *p;
+  } L{(double *)(arena.p + o_L)}, YT{(double *)(arena.p + o_YT)}, linv{(double *)(arena.p + o_linv)},
+      v{(double *)(arena.p + o_v)}, logdet{(double *)(arena.p + o_logdet)};
+  struct {
+    int *p;
+  } rp{(int *)(arena.p + o_rp)}, ci{(int *)(arena.p + o_ci)}, fail{(int *)(arena.p + o_fail)},
+      list{(int *)(arena.p + o_list)};
+  struct {
+    PieceDev *p;
+  } piece{(PieceDev *)(arena.p + o_piece)};
+  const PieceDev one{0, k, 0, -1, 0};
+  const int zero_list = 0;
+  DCORA_HIP(hipMemcpyAsync(rp.p, A.rp.data(), ((size_t)k + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+  DCORA_HIP(hipMemcpyAsync(ci.p, A.ci.data(), nnz * sizeof(int), hipMemcpyHostToDevice, st));
+  DCORA_HIP(hipMemcpyAsync(v.p, A.v.data(), nnz * sizeof(double), hipMemcpyHostToDevice, st));
+  DCORA_HIP(hipMemcpyAsync(piece.p, &one, sizeof one, hipMemcpyHostToDevice, st));
+  DCORA_HIP(hipMemcpyAsync(list.p, &zero_list, sizeof(int), hipMemcpyHostToDevice, st));
+  DCORA_HIP(hipMemsetAsync(L.p, 0, o_linv, st));  // L and YT
+  DCORA_HIP(hipMemsetAsync(fail.p, 0, sizeof(int), st));
+  DCORA_HIP(hipMemsetAsync(logdet.p, 0, sizeof(double), st));
+  DCORA_HIP(hipMemsetAsync(Minv, 0, (size_t)k * ldm * sizeof(double), st));
+  hipLaunchKernelGGL(k_dense_scatter, dim3(k), dim3(256), 0, st, k, rp.p, ci.p, v.p, L.p);
+  for (int p = 0; p < nb; ++p) {
+    const int j0 = p * NB, jb = std::min(NB, k - j0), rows = k - j0 - jb;
+    hipLaunchKernelGGL(k_chol_potrf, dim3(1), dim3(256), 0, st, piece.p, list.p, j0, L.p, linv.p + (size_t)p * NB * NB,
+                       fail.p, logdet.p, 1);
+    if (rows > 0) {
+      const int T = (rows + NB - 1) / NB;
+      hipLaunchKernelGGL(k_chol_trsm, dim3(T, 1), dim3(256), 0, st, piece.p, list.p, j0, L.p,
+                         linv.p + (size_t)p * NB * NB, fail.p);
+      hipLaunchKernelGGL(k_chol_syrk, dim3(T * (T + 1) / 2, 1), dim3(256), 0, st, piece.p, list.p, j0, L.p, fail.p);
+    }
+  }
+  // (a failed factorisation leaves garbage behind the flag: the products below are harmless, the caller drops Minv)
+  for (int ib = 0; ib < nb; ++ib)
+    hipLaunchKernelGGL(k_dense_trtri_row, dim3(ib + 1), dim3(256), 0, st, k, ib, L.p, YT.p, linv.p);
+  hipLaunchKernelGGL(k_dense_lauum, dim3(nb * (nb + 1) / 2), dim3(256), 0, st, k, YT.p, Minv, ldm);
+  DCORA_HIP(hipGetLastError());
+  int failed = 0;
+  DCORA_HIP(hipMemcpyAsync(&failed, fail.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  DCORA_HIP(hipStreamSynchronize(st));
+  *pd = failed == 0;
   return DCORA_OK;
 }
 

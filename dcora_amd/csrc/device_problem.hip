@@ -313,19 +313,34 @@ int DeviceProblem::build_preconditioner(const HostCsr &Qh, double reg) {
       ent.nnzL = P.nnzL;
       ent.bytes = img->device_bytes();
     } else {
-      SparseChol chol;
-      if (!chol.factor(M, block)) {
-        set_last_error("preconditioner: Q + reg I is not positive definite");
-        return DCORA_ERR_NOT_PD;
-      }
-      ent.nnzL = chol.nnzL();
       // rows padded so every 16-byte column-pair load of a 128-column chunk is in bounds
       ent.ldm = ((k + 127) / 128) * 128;
-      std::vector<double> inv((size_t)k * ent.ldm, 0.0);
-      chol.dense_inverse(inv.data(), (size_t)ent.ldm, nthreads);
       auto buf = std::make_shared<DevBuf<double>>();
       DCORA_HIP(buf->alloc((size_t)k * ent.ldm + 16));
-      DCORA_HIP(hipMemcpy(buf->p, inv.data(), (size_t)k * ent.ldm * sizeof(double), hipMemcpyHostToDevice));
+      static const bool host_factor = [] {
+        const char *e = std::getenv("DCORA_FACTOR");
+        return e && std::string(e) == "host";
+      }();
+      if (host_factor) {  // A/B measurements: sparse Cholesky and k solves on host threads, one upload
+        SparseChol chol;
+        if (!chol.factor(M, block)) {
+          set_last_error("preconditioner: Q + reg I is not positive definite");
+          return DCORA_ERR_NOT_PD;
+        }
+        ent.nnzL = chol.nnzL();
+        std::vector<double> inv((size_t)k * ent.ldm, 0.0);
+        chol.dense_inverse(inv.data(), (size_t)ent.ldm, nthreads);
+        DCORA_HIP(hipMemcpy(buf->p, inv.data(), (size_t)k * ent.ldm * sizeof(double), hipMemcpyHostToDevice));
+      } else {  // dense LL^T, L^-1 and L^-T L^-1 on the device (device_chol.h)
+        bool pd = false;
+        const int rc = device_dense_spd_inverse(M, device, buf->p, ent.ldm, &pd);
+        if (rc) return rc;
+        if (!pd) {
+          set_last_error("preconditioner: Q + reg I is not positive definite");
+          return DCORA_ERR_NOT_PD;
+        }
+        ent.nnzL = (long)k * (k + 1) / 2;  // the dense factor that was formed
+      }
       ent.dense = buf;
       ent.bytes = buf->n * sizeof(double);
     }
