@@ -691,6 +691,80 @@ def config5_run(da, with_cpu, iters=60, cpu_iters=4):
     return res
 
 
+def config2_run(da, ds, with_cpu, r=5):
+    """BASELINE.json config 2 as a side measurement: sphere2500 as ONE problem (k = 10 000, sparse preconditioner),
+    QuadraticOptimizer from the chordal start to |rgrad| < 1e-4 (RTR 40 x 100 tCG, what tests/test_configs_gpu.py
+    checks against the oracle), then the certificate."""
+    Q = da.build_Q_pgo(ds)
+    t0 = time.perf_counter()
+    P = da.QuadraticProblem(r, ds.d, ds.n, Q)
+    setup_s = time.perf_counter() - t0
+    T = da.chordal_initialization(ds)
+    Xc = np.zeros((r, (ds.d + 1) * ds.n))
+    Xc[:ds.d] = T
+    prm = dict(RTR_iterations=40, RTR_tCG_iterations=100, gradnorm_tol=1e-4)
+    opt = da.QuadraticOptimizer(P, da.ROptParameters(**prm))
+    opt.optimize(Xc)  # warm-up
+    t0 = time.perf_counter()
+    X = opt.optimize(Xc)
+    dt = time.perf_counter() - t0
+    res = opt.getOptResult()
+    t0 = time.perf_counter()
+    S = da.dual_certificate(r, ds.d, ds.n, X, Q)
+    psd, theta, x, lmin = da.fast_verification(S, 1e-3, block=ds.d + 1)
+    cert_s = time.perf_counter() - t0
+    out = {"workload": "sphere2500.g2o, one problem of k = 10000, r = 5: RTR 40 x 100 tCG from the chordal start",
+           "preconditioner": P.precond_info(), "problem_setup_s": setup_s, "seconds": dt,
+           "outer_iterations": int(res["outer_iterations"]), "tcg_iterations": int(res["inner_iterations"]),
+           "tcg_iterations_per_s": res["inner_iterations"] / dt, "cost_2f": 2.0 * res["fOpt"],
+           "gradnorm": res["gradNormOpt"], "certified": bool(psd), "certification_ms": 1e3 * cert_s}
+    P.close()
+    if with_cpu:
+        from oracle import flows, orc
+        dso = flows.oracle_dataset("sphere2500")
+        Po = orc.Problem(r, dso.d, dso.n, orc.build_Q_pgo(dso))
+        t0 = time.perf_counter()
+        Xo, reso = Po.optimize(Xc, **prm)
+        dto = time.perf_counter() - t0
+        out["cpu_port"] = {"seconds": dto, "outer_iterations": int(reso["outer_iters"]),
+                           "tcg_iterations": int(reso["inner_iters"]), "cost_2f": 2.0 * reso["fOpt"], "cores": 1}
+        out["speedup_vs_cpu_port"] = dto / dt
+    return out
+
+
+def psd_test_block(da, ds):
+    """the PSD test of the certificate (isSparseSymmetricMatrixPSD, ref src/DCORA_utils.cpp:1737-1747) with the
+    numeric factorisation on the device (dcora_cert_is_psd_device): sphere2500 (k = 10 000) and the whole 100k
+    lattice (k = 400 000), positive verdicts, i.e. complete factorisations"""
+    import scipy.sparse as sp
+    from dcora_amd import synth
+    out = {}
+    for name, d_, blk, host in (("sphere2500", ds, ds.d + 1, True), ("lattice100k", synth.lattice_se3(), 4, False)):
+        Q = da.build_Q_pgo(d_).to_scipy()
+        A = da.Csr.from_scipy((Q + 1e-3 * sp.identity(Q.shape[0])).tocsr())
+        da.chol_cache_clear()
+        t0 = time.perf_counter()
+        ok, cold = da.is_psd_device(A, blk, info=True)
+        cold_ms = 1e3 * (time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        ok2, warm = da.is_psd_device(A, blk, info=True)
+        warm_ms = 1e3 * (time.perf_counter() - t0)
+        e = {"k": A.n, "nnz": A.nnz, "positive_definite": bool(ok and ok2), "first_call_ms": cold_ms,
+             "symbolic_ms": cold["symbolic_ms"], "repeat_call_ms": warm_ms, "numeric_ms": warm["numeric_ms"],
+             "factorisation_gflop": warm["flops"] / 1e9, "achieved_tflops": warm["flops"] / warm["numeric_ms"] / 1e9,
+             "front_arena_mb": warm["arena_bytes"] / 1e6, "tree_levels": warm["levels"], "launches": warm["launches"]}
+        if host:
+            t0 = time.perf_counter()
+            okh = da.is_psd(A, blk)
+            e["host_factorisation_ms"] = 1e3 * (time.perf_counter() - t0)
+            e["host_agrees"] = bool(okh == ok)
+        else:
+            e["host_factorisation_ms"] = None
+            e["host_note"] = "the host factorisation of this matrix did not finish in 7 minutes (DESIGN.md section 8)"
+        out[name] = e
+    return out
+
+
 def side_multi(da, torch, dist, rank, world, ds, R, r, workload, iters=60, sweeps=8, with16=False, more_ranks=()):
     """a BASELINE.json multi-agent config with one process per GPU (consecutive agents share a rank): same loop, the
     library's neighbour exchange between the ranks; a side measurement, never `value`"""
@@ -973,6 +1047,16 @@ def main():
             line["ms_to_certified_optimum"] = certified_run(args, da, torch, ds, not args.no_cpu_baseline)
         except Exception as e:  # never lose the headline line to the second measurement
             line["ms_to_certified_optimum"] = {"error": str(e)}
+        if not args.no_config4:
+            try:
+                line["config2_sphere2500_single"] = config2_run(da, ds, not args.no_cpu_baseline)
+            except Exception as e:
+                line["config2_sphere2500_single"] = {"error": str(e)}
+        if not args.no_config5:
+            try:
+                line["psd_test"] = psd_test_block(da, ds)
+            except Exception as e:
+                line["psd_test"] = {"error": str(e)}
         if not args.no_config5:
             try:
                 line["config5_lattice100k"] = config5_run(da, not args.no_cpu_baseline)

@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void k_chol_pack(const PieceDev *__restrict__ 
 // ---------------------------------------------------------------------------------------------------------
 // Dense inverse of a small SPD matrix on the device (the dense preconditioner of blocks up to 8000 unknowns,
 // ref src/QuadraticProblem.cpp:70-84 applied as an explicit inverse): A = L L^T by the panel kernels above (the whole
-// matrix is one front), Y = L^-1 block row by block row, A^-1 = Y^T Y.  Y is kept transposed (YT, upper block
+// matrix is one front), Y = L^-1 right-looking by block rows, A^-1 = Y^T Y.  Y is kept transposed (YT, upper block
 // triangular) so that every product below runs over contiguous rows of both operands.
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_dense_scatter(int k, const int *__restrict__ rp, const int *__restrict__ ci,
@@ -288,10 +288,11 @@ __device__ __forceinline__ void tile_product_range(const double *__restrict__ Ar
   }
 }
 
-// block row ib of Y = L^-1, written as block column ib of YT:  YT(j, ib) = -(YT(j, j..ib) L(ib, j..ib)^T) Linv_ib^T
-// for the block rows j < ib (one workgroup each), YT(ib, ib) = Linv_ib^T
-__global__ __launch_bounds__(256) void k_dense_trtri_row(int k, int ib, const double *__restrict__ L,
-                                                         double *__restrict__ YT, const double *__restrict__ Linv) {
+// Y = L^-1 right-looking, one block row of L at a time; Y is kept transposed (YT(j, i) = Y(i, j)^T).  Step ib:
+//   finish:  YT(j, ib) = -TT(j, ib) Linv_ib^T for the block rows j < ib (TT accumulated in place), YT(ib, ib) = Linv_ib^T
+//   update:  TT(j, i) += YT(j, ib) L(i, ib)^T for every block row i > ib and j <= ib  -- (nb - ib - 1)(ib + 1) tiles
+__global__ __launch_bounds__(256) void k_dense_trtri_finish(int k, int ib, double *__restrict__ YT,
+                                                            const double *__restrict__ Linv) {
   __shared__ double As[NB][NB + 1];
   __shared__ double Bs[NB][NB + 1];
   const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
@@ -304,25 +305,14 @@ __global__ __launch_bounds__(256) void k_dense_trtri_row(int k, int ib, const do
     }
     return;
   }
-  const int j = blockIdx.x, j0 = j * NB;
-  double acc[4][4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u)
-#pragma unroll
-    for (int v = 0; v < 4; ++v) acc[u][v] = 0;
-  // TT(a, m) = sum_l YT(j0 + a, l) L(i0 + m, l), l over the block columns j .. ib - 1
-  tile_product_range(YT + (size_t)j0 * k, L + (size_t)i0 * k, k, NB, ni, j0, i0, As, Bs, acc);
-  __syncthreads();
-  // second product from LDS: YT(j0 + a, i0 + b) = -sum_m TT(a, m) Linv(b, m)
-#pragma unroll
-  for (int u = 0; u < 4; ++u)
-#pragma unroll
-    for (int v = 0; v < 4; ++v) As[tx + 16 * v][ty + 16 * u] = acc[u][v];  // As[m][a]
+  const int j0 = blockIdx.x * NB;
   for (int e = tid; e < NB * NB; e += 256) {
-    const int b = e >> 6, mm = e & 63;
-    Bs[mm][b] = Li[b * NB + mm];  // Bs[m][b]
+    const int a = e >> 6, mm = e & 63;
+    As[mm][a] = (mm < ni) ? YT[(size_t)(j0 + a) * k + i0 + mm] : 0.0;  // TT(a, m)
+    Bs[mm][a] = Li[a * NB + mm];                                       // Linv(b = a, m)
   }
   __syncthreads();
+  double acc[4][4];
 #pragma unroll
   for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -345,6 +335,27 @@ __global__ __launch_bounds__(256) void k_dense_trtri_row(int k, int ib, const do
     for (int v = 0; v < 4; ++v) {
       const int b = tx + 16 * v;
       if (b < ni) YT[(size_t)(j0 + ty + 16 * u) * k + i0 + b] = -acc[u][v];
+    }
+}
+__global__ __launch_bounds__(256) void k_dense_trtri_update(int k, int ib, const double *__restrict__ L,
+                                                            double *__restrict__ YT) {
+  __shared__ double As[NB][NB + 1];
+  __shared__ double Bs[NB][NB + 1];
+  const int i0 = (ib + 1 + blockIdx.x) * NB, j0 = blockIdx.y * NB, l0 = ib * NB;
+  const int ni = min(NB, k - i0);
+  double acc[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[u][v] = 0;
+  tile_product_range(YT + (size_t)j0 * k, L + (size_t)i0 * k, k, NB, ni, l0, l0 + NB, As, Bs, acc);
+  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int mm = tx + 16 * v;
+      if (mm < ni) YT[(size_t)(j0 + ty + 16 * u) * k + i0 + mm] += acc[u][v];
     }
 }
 
@@ -744,8 +755,11 @@ int device_dense_spd_inverse(const HostCsr &A, int device, double *Minv, int ldm
     }
   }
   // (a failed factorisation leaves garbage behind the flag: the products below are harmless, the caller drops Minv)
-  for (int ib = 0; ib < nb; ++ib)
-    hipLaunchKernelGGL(k_dense_trtri_row, dim3(ib + 1), dim3(256), 0, st, k, ib, L.p, YT.p, linv.p);
+  for (int ib = 0; ib < nb; ++ib) {
+    hipLaunchKernelGGL(k_dense_trtri_finish, dim3(ib + 1), dim3(256), 0, st, k, ib, YT.p, linv.p);
+    if (ib + 1 < nb)
+      hipLaunchKernelGGL(k_dense_trtri_update, dim3(nb - ib - 1, ib + 1), dim3(256), 0, st, k, ib, L.p, YT.p);
+  }
   hipLaunchKernelGGL(k_dense_lauum, dim3(nb * (nb + 1) / 2), dim3(256), 0, st, k, YT.p, Minv, ldm);
   DCORA_HIP(hipGetLastError());
   int failed = 0;
