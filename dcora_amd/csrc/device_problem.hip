@@ -339,7 +339,13 @@ int DeviceProblem::build_preconditioner(const HostCsr &Qh, double reg) {
           set_last_error("preconditioner: Q + reg I is not positive definite");
           return DCORA_ERR_NOT_PD;
         }
-        ent.nnzL = (long)k * (k + 1) / 2;  // the dense factor that was formed
+        // nnz(L) of the SPARSE factor of this matrix (what a triangular solve would stream: the quantity SURVEY 8(d)
+        // prices the preconditioner by), from the pattern alone -- the dense factor that was formed has k (k + 1) / 2
+        CholSymbolic sym;
+        chol_symbolic(M, block, &sym);
+        long nz = 0;
+        for (const CholPiece &pc : sym.pieces) nz += (long)pc.c * (pc.c + 1) / 2 + (long)pc.m * pc.c;
+        ent.nnzL = nz;
       }
       ent.dense = buf;
       ent.bytes = buf->n * sizeof(double);
