@@ -57,7 +57,9 @@ __global__ __launch_bounds__(256) void k_chol_extend_add(const PieceDev *__restr
 }
 
 // diagonal block of the current panel: LL^T of up to 64 columns in LDS, written back in place, and L^-1 for the
-// panel below.  A pivot that is not positive raises *fail.
+// panel below.  A pivot that is not positive raises *fail.  (Measured and dropped: ONE wave with the block in registers,
+// lane i owning row i and v_readlane broadcasts instead of LDS and barriers -- 308 VGPRs, 11 800 readlanes, and slower:
+// sphere2500 PSD test 1.84 -> 2.35 ms, the VALU -> SGPR -> VALU hazard of every broadcast costs more than the barrier.)
 __global__ __launch_bounds__(256) void k_chol_potrf(const PieceDev *__restrict__ pieces, const int *__restrict__ list,
                                                     int j0, double *__restrict__ F, double *__restrict__ Linv,
                                                     int *__restrict__ fail, double *__restrict__ logdet,
