@@ -51,6 +51,57 @@ def test_symbolic_with_hub_and_disconnected_parts(built):
     assert ok and resid <= 1e-12 * abs(B).max()
 
 
+def _chain(n, diag=4.0):
+    A = sp.diags([np.full(n, diag)], [0]).tolil()
+    for i in range(n - 1):
+        A[i, i + 1] = A[i + 1, i] = -1.0
+    return A.tocsr()
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 63, 64, 65, 130])
+def test_symbolic_tiny_matrices(built, n):
+    import dcora_amd as da
+    for block in (1, 4):
+        ok, resid, info = da.chol_host_selftest(da.Csr.from_scipy(_chain(n)), block)
+        assert ok and resid <= 1e-14
+    assert not da.chol_host_selftest(da.Csr.from_scipy(_chain(n, diag=-1.0)), 1)[0]
+
+
+@pytest.mark.gpu
+def test_device_tiny_matrices(built):
+    """one column, less than / exactly / just over one 64-column panel, two leaves and a separator"""
+    import dcora_amd as da
+    for n in (1, 2, 5, 63, 64, 65, 130, 200):
+        A = _chain(n)
+        pd, info = da.is_psd_device(da.Csr.from_scipy(A), 1, info=True)
+        ld = np.linalg.slogdet(A.toarray())[1]
+        assert pd and abs(info["logdet"] - ld) <= 1e-12 * max(1.0, abs(ld))
+        assert not da.is_psd_device(da.Csr.from_scipy(_chain(n, diag=1.0 if n > 2 else -1.0)), 1)
+
+
+@pytest.mark.gpu
+def test_dense_inverse_built_on_the_device(built):
+    """the dense preconditioner (k <= 8000) is formed by the device (LL^T, L^-1, L^-T L^-1): against a direct solve"""
+    import dcora_amd as da
+    ds, Q = _Q(da, "sphere2500")
+    nb = 330                                    # k = 1320: 20 full panels and one of 40 columns
+    Qb = Q[:4 * nb, :4 * nb].tocsr()
+    da.precond_cache_clear()
+    P = da.QuadraticProblem(5, 3, nb, da.Csr.from_scipy(Qb), reg=0.1)
+    assert P.precond_info()["kind"] == "dense"
+    rng = np.random.default_rng(3)
+    X = da.manifold_project(5, 3, nb, rng.uniform(-1, 1, (5, 4 * nb)))
+    V = rng.standard_normal((5, 4 * nb))
+    Z = P.PreCondition(X, V)
+    M = (Qb + 0.1 * sp.identity(4 * nb)).tocsc()
+    want = spl.splu(M).solve(V.T).T
+    # PreCondition projects the solve onto the tangent space at X: compare through the projection of the reference
+    from oracle import orc
+    want = orc.tangent_project(5, 3, nb, X, want)
+    assert np.linalg.norm(Z - want) <= 1e-10 * np.linalg.norm(want)
+    P.close()
+
+
 @pytest.mark.gpu
 def test_device_verdict_and_logdet_vs_scipy_and_oracle(built):
     import dcora_amd as da
