@@ -301,7 +301,19 @@ int Exchange::setup_ipc(bool attempt) {
     }
   }
   if (ok && hipMemset(halo_.p, 0, sizeof(double) * (test_off + (size_t)ntest * world)) != hipSuccess) no("hipMemset");
-  if (ok && hipIpcGetMemHandle(&ranks_[rank].halo, halo_.p) != hipSuccess) no("hipIpcGetMemHandle");
+  if (ok && hipIpcGetMemHandle(&ranks_[rank].halo, halo_.p) != hipSuccess) {
+    (void)hipGetLastError();
+    if (halo_finegrained_) {  // a runtime that exports no handle for fine-grained memory: once more with plain hipMalloc
+      halo_.release();
+      halo_finegrained_ = false;
+      if (halo_.alloc(test_off + (size_t)ntest * world) != hipSuccess ||
+          hipMemset(halo_.p, 0, sizeof(double) * (test_off + (size_t)ntest * world)) != hipSuccess ||
+          hipIpcGetMemHandle(&ranks_[rank].halo, halo_.p) != hipSuccess)
+        no("hipIpcGetMemHandle");
+    } else {
+      no("hipIpcGetMemHandle");
+    }
+  }
   (void)hipGetLastError();
   ranks_[rank].device.store(s_->opt.device);
   ranks_[rank].pid.store((int)getpid());

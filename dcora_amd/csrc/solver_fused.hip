@@ -1475,6 +1475,10 @@ __global__ __launch_bounds__(kBlock) void k_g_nesterov(ManiDesc m, GNesterovArgs
 // as broadcasts.  Four times fewer gather instructions and ~25 % fewer bytes than the scalar-CSR kernel.
 // ------------------------------------------------------------------------------------------------------
 
+// matrix blocks whose neighbour rows are gathered together.  Measured on the 100k lattice, warm / cold us: 1: 28.2 / 35.7,
+// 2: 27.2 / 34.0, 3: 27.8 / 35.0, 4: 29.5 / 36.2, 6: 32.0 / 39.2, 8: 32.1 / 39.6 -- the registers of a deeper batch cost more
+// resident waves (94 VGPRs at 4, 74 at 2) than its loads in flight give back; forcing 7 or 8 waves per SIMD changes nothing
+constexpr int kBsrGather = 2;
 template <int D, bool DOTS>
 __global__ __launch_bounds__(kBlock) void k_spmm_bsr(int r, BsrDev A, Buf2 Xb, int selX,
                                                      const double *__restrict__ G, Buf2 Yb, int selY,
@@ -1535,12 +1539,13 @@ __global__ __launch_bounds__(kBlock) void k_spmm_bsr(int r, BsrDev A, Buf2 Xb, i
       }
       __syncthreads();
       const int lo = max(myb, base) - base, hi = min(mye, base + cnt) - base;
-      for (int b = lo; b < hi; b += 4) {
-        // four matrix blocks per step: 4 (d+1) independent gathers in flight (index clamped, operand masked)
-        double x[4][DH];
-        int bb[4];
+      for (int b = lo; b < hi; b += kBsrGather) {
+        // kBsrGather matrix blocks per step: their (d+1) gathers each are in flight together (index clamped, operand
+        // masked)
+        double x[kBsrGather][DH];
+        int bb[kBsrGather];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < kBsrGather; ++q) {
           const bool ok = active && (b + q < hi);
           bb[q] = (b + q < hi) ? b + q : b;
           const size_t o = (size_t)s_bc[bb[q]] * DH * r + t;
@@ -1548,7 +1553,7 @@ __global__ __launch_bounds__(kBlock) void k_spmm_bsr(int r, BsrDev A, Buf2 Xb, i
           for (int c = 0; c < DH; ++c) x[q][c] = ok ? X[o + c * r] : 0.0;
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < kBsrGather; ++q) {
           const double *__restrict__ Bq = s_bv + bb[q] * BS;
 #pragma unroll
           for (int a = 0; a < DH; ++a) {
