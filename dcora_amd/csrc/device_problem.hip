@@ -217,8 +217,8 @@ int DeviceProblem::init(const dcora_dims &dims, const HostCsr &Qh, const double 
     std::vector<Slot> slots;
     for (DevBuf<double> *b : {&G, &X0, &X1, &EG0, &EG1, &RG0, &RG1, &delta, &eta, &Heta, &res, &z, &Hd, &W, &Zt})
       slots.push_back({b, N});
+    slots.push_back({&delta2, N});
     if (fused) {
-      slots.push_back({&delta2, N});
       slots.push_back({&res2, N});
       slots.push_back({&Zpart, (size_t)fused_nsplit(m) * N});  // slice 0 doubles as Z of the sparse preconditioner
     }
@@ -675,7 +675,9 @@ int DeviceProblem::rtr_dev(const dcora_ropt_params &prm, dcora_ropt_result *res_
     const int tcg_first_seq = seq;
     enq_minv(buf1(res.p), Zt.p, nullptr, 0, Gate{c, ++seq, 1});
     launch_tangent(st, m, Xb(), Zt.p, z.p, res.p, p3.p, nullptr, 0, c, hf_dev, ++seq, 1, 0);
-    launch_tcg_init(st, N, z.p, p3.p, nP, delta.p, c, ++seq);
+    // the direction update (k_tcg_init, then k_tcg_update2 of the previous iteration) rides in the Hessian SpMM of
+    // the next one (k_spmm_dir); the direction ping-pongs between two buffers
+    double *const db[2] = {delta.p, delta2.p};
     for (int j = 0; j < h.max_inner; ++j) {
       if (j >= kLookahead) {
         const int need = upd2_seq[j - kLookahead];
@@ -687,17 +689,19 @@ int DeviceProblem::rtr_dev(const dcora_ropt_params &prm, dcora_ropt_result *res_
           return timed_out();
       }
       if (hf->tcg_done_seq >= tcg_first_seq) break;
-      launch_spmm(st, m.r, Qv, buf1(delta.p), 0, nullptr, buf1(W.p), 0, nullptr, Gate{c, ++seq, 2});
-      launch_hessfix(st, m, Xb(), Sb(), delta.p, W.p, Hd.p, p1.p, Gate{c, ++seq, 2});
+      double *const dcur = db[j & 1];
+      launch_spmm_dir(st, m.r, Qv, z.p, db[(j + 1) & 1], dcur, W.p, p3.p, nP, c, ++seq, j);
+      launch_hessfix(st, m, Xb(), Sb(), dcur, W.p, Hd.p, p1.p, Gate{c, ++seq, 2});
       // sparse preconditioner: its two permutations (and the hub correction) ride in the kernels either side of the
       // level replay -- two launches fewer per tCG iteration
-      launch_tcg_update1(st, N, delta.p, Hd.p, eta.p, Heta.p, res.p, p1.p, nP, p2.p, c, hf_dev, ++seq, j, m.r, sfg);
+      launch_tcg_update1(st, N, dcur, Hd.p, eta.p, Heta.p, res.p, p1.p, nP, p2.p, c, hf_dev, ++seq, j, m.r, sfg);
       if (sfg.y)
         sp.apply(st, m.r, buf1(res.p), Zt.p, Gate{c, ++seq, 2}, true);
       else
         enq_minv(buf1(res.p), Zt.p, p2.p, nV, Gate{c, ++seq, 2});
       launch_tangent(st, m, Xb(), Zt.p, z.p, res.p, p3.p, p2.p, nV, c, hf_dev, ++seq, 2, j, sfg);
-      launch_tcg_update2(st, N, z.p, delta.p, p3.p, nP, c, hf_dev, ++seq, j);
+      // the inner loop exhausted: the bookkeeping of the last direction update (status TR_MAXITER) has no next SpMM
+      if (j == h.max_inner - 1) launch_tcg_update2(st, N, z.p, dcur, p3.p, nP, c, hf_dev, ++seq, j);
       upd2_seq[j] = seq;
     }
     // ---- trial point, model ratio, acceptance ----

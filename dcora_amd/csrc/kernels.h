@@ -103,6 +103,10 @@ struct Gate {
 
 // ---- SpMM: Y = X * A (+ G); optional partial dots {sum (X*A) o X, sum X o G}, 2 per block ---------------
 int spmm_grid(int nrows, int r);
+// W = (-z + beta d_old) Q with the direction written to d_new and the tCG scalar recurrence of iteration `iter`
+// (k_tcg_init for iter 0, k_tcg_update2 of iteration iter - 1 otherwise) folded in
+void launch_spmm_dir(hipStream_t st, int r, const CsrDev &A, const double *z, const double *d_old, double *d_new,
+                     double *W, const double *p3, int np3, SolverCtl *ctl, int seq, int iter);
 inline int spmm_slots(const CsrDev &A, int r) { return spmm_grid(A.nrows, r) + A.n_long; }  // partial slots written
 void launch_spmm(hipStream_t st, int r, const CsrDev &A, Buf2 X, int selX, const double *G, Buf2 Y, int selY,
                  double *partials, Gate g);

@@ -252,6 +252,168 @@ __global__ __launch_bounds__(kBlock) void k_spmm(int r, CsrDev A, Buf2 Xb, int s
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Generic-layout tCG, iteration `iter`: the direction update of the previous iteration folded into the Hessian SpMM.
+//   delta_new = -z + beta delta_old   (beta = <z, r>_new / <z, r>_old from the partials p3; iter 0: delta_new = -z)
+//   W = delta_new Q                   (delta_new formed in the gather, written for the block's own columns)
+// and the scalar recurrence of ROPTLIB's tCG_TR that k_tcg_init / k_tcg_update2 keep (block 0).  delta_old and
+// delta_new are different buffers: other workgroups still gather the old direction.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_spmm_dir(int r, CsrDev A, const double *__restrict__ z,
+                                                     const double *__restrict__ d_old, double *__restrict__ d_new,
+                                                     double *__restrict__ W, const double *__restrict__ p3, int np3,
+                                                     SolverCtl *ctl, int seq, int iter, int main_grid) {
+  if (gated(ctl, seq, 2)) return;
+  __shared__ int s_ci[kSpmmTile];
+  __shared__ double s_v[kSpmmTile];
+  __shared__ double s_red[16];
+  __shared__ int s_last;
+  const int par = (iter - 1) & 1;
+  const double z_r_new = sum_partials(p3, np3, 1, 0, s_red);
+  const double beta = iter > 0 ? z_r_new / ctl->z_r[par] : 0.0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (iter == 0) {
+      ctl->z_r[0] = z_r_new;
+      ctl->d_Pd[0] = z_r_new;
+      ctl->e_Pe[0] = 0;
+      ctl->e_Pd[0] = 0;
+    } else {
+      const double alpha = ctl->alpha;
+      const double d_Pd = ctl->d_Pd[par], e_Pd = ctl->e_Pd[par];
+      ctl->z_r[par ^ 1] = z_r_new;
+      ctl->e_Pd[par ^ 1] = beta * (e_Pd + alpha * d_Pd);
+      ctl->d_Pd[par ^ 1] = z_r_new + beta * beta * d_Pd;
+      ctl->e_Pe[par ^ 1] = ctl->e_Pe_n;
+    }
+  }
+  const int RB = kBlock / r;
+  const int nrb = (A.nrows + RB - 1) / RB;
+  const int lj = threadIdx.x / r, t = threadIdx.x - lj * r;
+  auto dir = [&](size_t o) -> double { return iter > 0 ? fma(beta, d_old[o], -z[o]) : -z[o]; };
+  if ((int)blockIdx.x >= main_grid) {  // a slice of a long row (see k_spmm)
+    const int li = ((int)blockIdx.x - main_grid) / kLongSplit, sl = ((int)blockIdx.x - main_grid) % kLongSplit;
+    const int j = A.long_rows[li];
+    const int rb0 = A.rp[j], re0 = A.rp[j + 1];
+    const int per = (re0 - rb0 + kLongSplit - 1) / kLongSplit;
+    const int pb = rb0 + sl * per, pe = min(re0, pb + per);
+    double acc = 0;
+    if (lj < RB) {
+      for (int p = pb + lj; p < pe; p += 8 * RB) {
+        int c8[8];
+        double w8[8], x8[8], y8[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int pp = p + q * RB;
+          const bool ok = pp < pe;
+          c8[q] = A.ci[ok ? pp : rb0];
+          w8[q] = ok ? A.v[pp] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const size_t o = (size_t)c8[q] * r + t;
+          x8[q] = z[o];
+          y8[q] = iter > 0 ? d_old[o] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc += w8[q] * fma(beta, y8[q], -x8[q]);
+      }
+    }
+    double *s_part = s_v;
+    __syncthreads();
+    s_part[threadIdx.x] = (lj < RB) ? acc : 0.0;
+    __syncthreads();
+    if ((int)threadIdx.x < r) {
+      double y = 0;
+      for (int q = 0; q < RB; ++q) y += s_part[q * r + threadIdx.x];
+      __hip_atomic_store(A.long_part + ((size_t)li * kLongSplit + sl) * 16 + threadIdx.x, y, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0)
+      s_last = (__hip_atomic_fetch_add(A.long_cnt + li, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) ==
+                kLongSplit - 1);
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) __hip_atomic_store(A.long_cnt + li, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((int)threadIdx.x < r) {
+      double y = 0;
+      for (int q = 0; q < kLongSplit; ++q)
+        y += __hip_atomic_load(A.long_part + ((size_t)li * kLongSplit + q) * 16 + threadIdx.x, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+      const size_t o = (size_t)j * r + threadIdx.x;
+      W[o] = y;
+      d_new[o] = dir(o);
+    }
+    return;
+  }
+  for (int rb = blockIdx.x; rb < nrb; rb += main_grid) {
+    const int j0 = rb * RB;
+    const int j1 = min(A.nrows, j0 + RB);
+    const int j = j0 + lj;
+    const bool active = (lj < RB) && (j < j1);
+    const int pbeg = A.rp[j0], pend = A.rp[j1];
+    int myb = active ? A.rp[j] : 0, mye = active ? A.rp[j + 1] : 0;
+    const bool is_long = A.n_long > 0 && (mye - myb > kLongRow);  // served by its own workgroups
+    if (is_long) mye = myb;
+    const double own = (active && !is_long) ? dir((size_t)j * r + t) : 0.0;
+    double acc = 0;
+    for (int base = pbeg; base < pend; base += kSpmmTile) {
+      const int cnt = min(kSpmmTile, pend - base);
+      __syncthreads();
+      {
+        constexpr int SU = kSpmmTile / kBlock;
+        int ci_r[SU];
+        double v_r[SU];
+        const int last = base + cnt - 1;
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+          const int i = min(base + (int)threadIdx.x + u * kBlock, last);
+          ci_r[u] = A.ci[i];
+          v_r[u] = A.v[i];
+        }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+          const int i = threadIdx.x + u * kBlock;
+          if (i < cnt) {
+            s_ci[i] = ci_r[u];
+            s_v[i] = v_r[u];
+          }
+        }
+      }
+      __syncthreads();
+      const int lo = max(myb, base) - base, hi = min(mye, base + cnt) - base;
+      for (int p = lo; p < hi; p += 8) {
+        double x8[8], y8[8], w8[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const bool ok = p + q < hi;
+          const int pp = ok ? p + q : lo;
+          w8[q] = ok ? s_v[pp] : 0.0;
+          const size_t o = (size_t)s_ci[pp] * r + t;
+          x8[q] = z[o];
+          y8[q] = iter > 0 ? d_old[o] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc += w8[q] * fma(beta, y8[q], -x8[q]);
+      }
+    }
+    if (active && !is_long) {
+      const size_t o = (size_t)j * r + t;
+      W[o] = acc;
+      d_new[o] = own;
+    }
+  }
+}
+
+void launch_spmm_dir(hipStream_t st, int r, const CsrDev &A, const double *z, const double *d_old, double *d_new,
+                     double *W, const double *p3, int np3, SolverCtl *ctl, int seq, int iter) {
+  const int main_grid = spmm_grid(A.nrows, r);
+  const int grid = main_grid + A.n_long * kLongSplit;
+  hipLaunchKernelGGL(k_spmm_dir, dim3(grid), dim3(kBlock), 0, st, r, A, z, d_old, d_new, W, p3, np3, ctl, seq, iter,
+                     main_grid);
+}
+
 void launch_spmm(hipStream_t st, int r, const CsrDev &A, Buf2 X, int selX, const double *G, Buf2 Y, int selY,
                  double *partials, Gate g) {
   const int main_grid = spmm_grid(A.nrows, r);
@@ -624,6 +786,8 @@ __global__ __launch_bounds__(kBlock) void k_tangent(ManiDesc m, Buf2 Xb, const d
     const double tot = block_sum(acc, s_red);
     if (threadIdx.x == 0) partials[blockIdx.x] = tot;
   }
+  // the last kernel of a tCG iteration when the direction update is folded into the next SpMM: paces the host
+  if (hf && gate == 2 && blockIdx.x == 0 && threadIdx.x == 0) host_store(&hf->last_seq_done, seq);
 }
 
 // ---- HV = Proj_X(W - V S), partial <V, HV>  (ROPTLIB EucHvToHv for the Euclidean metric) -----------------
