@@ -488,8 +488,9 @@ def roofline(da, ds, r, robots):
     main = {"bound": "hbm", "kernel": "%s, one agent, k=%d" % (kname, kb),
             "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
             "bytes_per_launch": nbytes, "avg_launch_us": ms * 1e3,
-            "peak_note": "spec peak of HBM3E; a streaming kernel reaches about 6.3 TB/s on this part, and at this size "
-                         "the operands sit in the 256 MiB Infinity Cache",
+            "peak_note": "spec peak of HBM3E; measured_stream_triad is what a = b + s c over 6.4 GB reaches on this box in "
+                         "this run, and at this kernel's size the operands sit in the 256 MiB Infinity Cache",
+            "measured_stream_triad_GBps": da.stream_triad_gbps(),
             "bytes_counted": "what the kernel's data structure streams once: the dense symmetric inverse (8 k^2) and 7 "
                              "passes over r x k vectors (r_old, H delta in; eta, H eta, r, z through); not counted: "
                              "every workgroup re-reading r_old and H delta from L2 to rebuild the residual",
@@ -950,7 +951,7 @@ def cpu_baseline(args, ds_name, X0):
     same = args.steps / (t[first + args.steps - 1] - t[first - 1])
     lo, hi = first + args.steps, first + args.steps + SUSTAINED_STEPS
     sus = SUSTAINED_STEPS / (t[hi - 1] - t[lo - 1])
-    return {"value": sus, "unit": "RBCD iterations/s", "cores": 1, "kind": "port",
+    return {"value": sus, "unit": "RBCD iterations/s", "cores": 1, "host_cores_of_the_box": os.cpu_count(), "kind": "port",
             "sample": "iterations %d..%d of the same workload and start point (the window of `sustained`); the oracle "
                       "ran %d iterations, %.1f s of loop time" % (lo + 1, hi, tr["total_iters"], t[-1]),
             "ms_per_step": 1e3 / sus,

@@ -414,6 +414,17 @@ def chol_host_selftest(S, block=1):
                                         "flops": i4[3]}
 
 
+def stream_triad_gbps(n=1 << 28, reps=20, device=0):
+    """measured HBM stream figure of the box: a = b + s c over three arrays of n doubles (6.4 GB by default, far
+    beyond the 256 MiB Infinity Cache)"""
+    L = capi.lib()
+    L.dcora_debug_stream_triad.restype = C.c_int
+    L.dcora_debug_stream_triad.argtypes = [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
+    out = C.c_double()
+    check(L.dcora_debug_stream_triad(device, n, reps, C.byref(out)))
+    return out.value
+
+
 def chol_cache_clear():
     check(capi.lib().dcora_chol_cache_clear())
 

@@ -1224,6 +1224,69 @@ extern "C" int dcora_debug_partinv_selftest(int n, const int *rp, const int *ci,
   return DCORA_OK;
 }
 
+// measurement hook (bench.py, SURVEY 8(d): "verify with a stream-triad on the box"): a[i] = b[i] + s c[i] over three
+// arrays of n doubles, `reps` launches back to back between two HIP events; GB/s counts 24 n bytes per launch
+namespace {
+__global__ __launch_bounds__(256) void k_stream_triad(size_t n2, const double2 *__restrict__ b,
+                                                      const double2 *__restrict__ c, double2 *__restrict__ a,
+                                                      double s) {
+  // four 16-byte loads per array in flight per lane
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n2; i += 4 * stride) {
+    double2 x[4], y[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      x[u] = b[i + u * stride];
+      y[u] = c[i + u * stride];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      a[i + u * stride] = make_double2(x[u].x + s * y[u].x, x[u].y + s * y[u].y);
+  }
+  for (; i < n2; i += stride) {
+    const double2 x = b[i], y = c[i];
+    a[i] = make_double2(x.x + s * y.x, x.y + s * y.y);
+  }
+}
+}  // namespace
+extern "C" int dcora_debug_stream_triad(int device, size_t n, int reps, double *gbps) {
+  DCORA_TRY
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_last_error("no HIP device available: libdcora_hip has no CPU fallback");
+    return DCORA_ERR_NO_DEVICE;
+  }
+  DCORA_HIP(hipSetDevice(device));
+  n &= ~(size_t)1;
+  DevBuf<double> A, B, Cc;
+  DCORA_HIP(A.alloc(n));
+  DCORA_HIP(B.alloc(n));
+  DCORA_HIP(Cc.alloc(n));
+  DCORA_HIP(hipMemset(B.p, 0, n * sizeof(double)));
+  DCORA_HIP(hipMemset(Cc.p, 0, n * sizeof(double)));
+  hipEvent_t e0, e1;
+  DCORA_HIP(hipEventCreate(&e0));
+  DCORA_HIP(hipEventCreate(&e1));
+  const int grid = getenv("DCORA_TRIAD_GRID") ? atoi(getenv("DCORA_TRIAD_GRID")) : 1024;  // 1024 / 2048 / 8192 workgroups: 5.01 / 4.85 / 4.48 TB/s
+  for (int w = 0; w < 3; ++w)
+    hipLaunchKernelGGL(k_stream_triad, dim3(grid), dim3(256), 0, nullptr, n / 2, (const double2 *)B.p,
+                       (const double2 *)Cc.p, (double2 *)A.p, 0.5);
+  DCORA_HIP(hipEventRecord(e0, nullptr));
+  for (int w = 0; w < reps; ++w)
+    hipLaunchKernelGGL(k_stream_triad, dim3(grid), dim3(256), 0, nullptr, n / 2, (const double2 *)B.p,
+                       (const double2 *)Cc.p, (double2 *)A.p, 0.5);
+  DCORA_HIP(hipEventRecord(e1, nullptr));
+  DCORA_HIP(hipEventSynchronize(e1));
+  float ms = 0;
+  DCORA_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *gbps = 24.0 * (double)n * reps / (ms * 1e-3) / 1e9;
+  return DCORA_OK;
+  DCORA_CATCH
+}
+
 // debug / test hook: per-level shape of the partitioned-inverse schedule: out[4 * lev + {0,1,2,3}] =
 // {row tasks, segments, stored weights streamed, lanes per task}; returns the number of levels in *nlev
 extern "C" int dcora_debug_partinv_levels(int n, const int *rp, const int *ci, const double *v, int block, int max_levels,
