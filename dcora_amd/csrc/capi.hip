@@ -1287,6 +1287,109 @@ extern "C" int dcora_debug_stream_triad(int device, size_t n, int reps, double *
   DCORA_CATCH
 }
 
+// measurement hook: cost of a grid-wide barrier among `blocks` co-resident workgroups (monotonic arrival counter in
+// device memory, agent-scope release / acquire, one polling lane per workgroup with s_sleep) -- the price a persistent
+// one-launch tCG iteration would pay per dependency.  Every wait is bounded: a workgroup that does
+// not see its peers within `spin_limit` polls gives up and raises *timeouts, the kernel always drains.
+namespace {
+__global__ __launch_bounds__(256) void k_grid_barrier_probe(unsigned *counter, int iters, int spin_limit,
+                                                            int *timeouts, double *sink, int mode) {
+  // mode 0: one arrival counter polled by every workgroup.  mode 1: two levels -- groups of 32 workgroups (words 64
+  // apart) arrive on their group's counter, the last of a group arrives on the top counter, the last of all bumps one
+  // release word per group; a workgroup polls only its group's release word.
+  extern __shared__ double s_dyn[];
+  const unsigned nb = gridDim.x;
+  constexpr unsigned GS = 32;
+  const unsigned ng = (nb + GS - 1) / GS, g = blockIdx.x / GS;
+  const unsigned gsize = min(GS, nb - g * GS);
+  unsigned *grp = counter + 64 * (1 + g), *rel = counter + 64 * (1 + ng + g);
+  unsigned target = 0, epoch = 0;
+  double acc = 0;
+  bool dead = false;
+  for (int it = 0; it < iters && !dead; ++it) {
+    acc += s_dyn[threadIdx.x & 7];  // keep the LDS allocation alive
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int spins = 0;
+      if (mode == 0) {
+        target += nb;
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+          if (++spins > spin_limit) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+      } else {
+        ++epoch;
+        const unsigned a = __hip_atomic_fetch_add(grp, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (a + 1 == epoch * gsize) {  // last of the group
+          const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+          if (t + 1 == epoch * ng)     // last of all: release every group
+            for (unsigned q = 0; q < ng; ++q)
+              __hip_atomic_store(counter + 64 * (1 + ng + q), epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        while (__hip_atomic_load(rel, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+          if (++spins > spin_limit) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      if (spins > spin_limit) atomicAdd(timeouts, 1);
+      s_dyn[8] = (spins > spin_limit) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    dead = s_dyn[8] != 0.0;
+  }
+  if (acc == 12345.678) sink[0] = acc;
+}
+}  // namespace
+extern "C" int dcora_debug_grid_barrier(int device, int blocks, int iters, int lds_bytes, int mode,
+                                        double *us_per_barrier, int *timeouts_out) {
+  DCORA_TRY
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_last_error("no HIP device available: libdcora_hip has no CPU fallback");
+    return DCORA_ERR_NO_DEVICE;
+  }
+  DCORA_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  DCORA_HIP(hipGetDeviceProperties(&prop, device));
+  if (blocks < 1 || blocks > prop.multiProcessorCount || lds_bytes < 128 || lds_bytes > 160 * 1024) {
+    set_last_error("grid barrier probe: one workgroup per compute unit at most, 128 B .. 160 KB of LDS");
+    return DCORA_ERR_BAD_ARG;
+  }
+  DevBuf<unsigned> counter;
+  DevBuf<int> touts;
+  DevBuf<double> sink;
+  const size_t nwords = 64 * (1 + 2 * ((size_t)blocks / 32 + 1));
+  DCORA_HIP(counter.alloc(nwords));
+  DCORA_HIP(touts.alloc(1));
+  DCORA_HIP(sink.alloc(1));
+  DCORA_HIP(hipFuncSetAttribute((const void *)k_grid_barrier_probe, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                lds_bytes));
+  hipEvent_t e0, e1;
+  DCORA_HIP(hipEventCreate(&e0));
+  DCORA_HIP(hipEventCreate(&e1));
+  float ms[2] = {0, 0};
+  const int its[2] = {1, iters};
+  for (int pass = 0; pass < 2; ++pass) {
+    DCORA_HIP(hipMemset(counter.p, 0, nwords * sizeof(unsigned)));
+    DCORA_HIP(hipMemset(touts.p, 0, sizeof(int)));
+    DCORA_HIP(hipEventRecord(e0, nullptr));
+    hipLaunchKernelGGL(k_grid_barrier_probe, dim3(blocks), dim3(256), lds_bytes, nullptr, counter.p, its[pass], 200000,
+                       touts.p, sink.p, mode);
+    DCORA_HIP(hipEventRecord(e1, nullptr));
+    DCORA_HIP(hipEventSynchronize(e1));
+    DCORA_HIP(hipEventElapsedTime(&ms[pass], e0, e1));
+  }
+  int t = 0;
+  DCORA_HIP(hipMemcpy(&t, touts.p, sizeof(int), hipMemcpyDeviceToHost));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *timeouts_out = t;
+  *us_per_barrier = 1e3 * (ms[1] - ms[0]) / std::max(1, iters - 1);
+  return DCORA_OK;
+  DCORA_CATCH
+}
+
 // debug / test hook: per-level shape of the partitioned-inverse schedule: out[4 * lev + {0,1,2,3}] =
 // {row tasks, segments, stored weights streamed, lanes per task}; returns the number of levels in *nlev
 extern "C" int dcora_debug_partinv_levels(int n, const int *rp, const int *ci, const double *v, int block, int max_levels,
