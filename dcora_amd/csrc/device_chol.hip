@@ -525,6 +525,10 @@ void chol_cache_clear() {
 namespace {
 int factor_on_device(const HostCsr &A, int block, int top, int device, bool *pd, double *info8, PiecewiseFactor *panels) {
   double *info6 = info8;
+  if (A.n <= 0 || (int)A.rp.size() != A.n + 1) {
+    set_last_error("sparse Cholesky: empty or malformed matrix");
+    return DCORA_ERR_BAD_ARG;
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     set_last_error("no HIP device available: libdcora_hip has no CPU fallback");
