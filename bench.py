@@ -766,6 +766,55 @@ def psd_test_block(da, ds):
     return out
 
 
+def config5_central(da, r=5):
+    """BASELINE config 5 to its certified optimum on ONE GPU with the centralised solver (the single-robot flow of the
+    reference, examples/SingleRobotExample.cpp, at k = 400 000): problem creation with the central preconditioner
+    (partitioned inverse from the device factorisation), RTR rounds of 50 x 200 tCG from the seeded random start to
+    |rgrad| < 1e-2, dual certificate + fastVerification.  The agents' RBCD++ converges sublinearly on this graph
+    (config5_lattice100k); this block is what makes its optimum and its certificate known."""
+    from dcora_amd import synth
+    ds = synth.lattice_se3()
+    k = (ds.d + 1) * ds.n
+    Q = da.build_Q_pgo(ds)
+    t0 = time.perf_counter()
+    P = da.QuadraticProblem(r, ds.d, ds.n, Q)
+    setup_s = time.perf_counter() - t0
+    info = P.precond_info()
+    pms, pbytes = P.time_precond(reps=10)
+    rng = np.random.default_rng(20250310)
+    X = da.manifold_project(r, ds.d, ds.n, rng.uniform(-1, 1, (r, k)))
+    solve_s, outer, inner, rounds = 0.0, 0, 0, 0
+    res = None
+    for rounds in range(1, 41):
+        opt = da.QuadraticOptimizer(P, da.ROptParameters(RTR_iterations=50, RTR_tCG_iterations=200, gradnorm_tol=1e-2))
+        t0 = time.perf_counter()
+        X = opt.optimize(X)
+        solve_s += time.perf_counter() - t0
+        res = opt.getOptResult()
+        outer += int(res["outer_iterations"])
+        inner += int(res["inner_iterations"])
+        if res["gradNormOpt"] < 1e-2:
+            break
+    P.close()
+    t0 = time.perf_counter()
+    S = da.dual_certificate(r, ds.d, ds.n, X, Q)
+    psd, theta, v, lmin = da.fast_verification(S, 1e-3, block=ds.d + 1)
+    cert_s = time.perf_counter() - t0
+    gap, n_eff = da.suboptimality_gap(r, ds.d, ds.n, X, psd, 1e-3, lmin)
+    return {"workload": "synthetic 50x50x40 SE(3) lattice as ONE problem (k = 400000), r = 5, RTR rounds of 50 x 200 tCG "
+                        "from the seeded random start to |rgrad| < 1e-2",
+            "problem_setup_s": setup_s, "preconditioner": {"kind": info["kind"], "launches": info["launches"],
+                                                           "nnz_L": info["nnzL"], "application_us": 1e3 * pms,
+                                                           "bytes_per_application": pbytes},
+            "solve_s": solve_s, "rtr_rounds": rounds, "outer_iterations": outer, "tcg_iterations": inner,
+            "tcg_iterations_per_s": inner / solve_s, "cost_2f": 2.0 * res["fOpt"], "gradnorm": res["gradNormOpt"],
+            "certification_s": cert_s, "certified": bool(psd), "rank": r,
+            "seconds_to_certified_optimum": setup_s + solve_s + cert_s,
+            "certified_suboptimality_gap_2f": 2.0 * gap, "n_eff": n_eff,
+            "cpu_port": None, "cpu_note": "no CPU leg: the oracle's sparse Cholesky of this matrix does not finish in "
+                                          "minutes (DESIGN.md section 8)"}
+
+
 def side_multi(da, torch, dist, rank, world, ds, R, r, workload, iters=60, sweeps=8, with16=False, more_ranks=()):
     """a BASELINE.json multi-agent config with one process per GPU (consecutive agents share a rank): same loop, the
     library's neighbour exchange between the ranks; a side measurement, never `value`"""
@@ -1058,6 +1107,11 @@ def main():
                 line["psd_test"] = psd_test_block(da, ds)
             except Exception as e:
                 line["psd_test"] = {"error": str(e)}
+        if not args.no_config5:
+            try:
+                line["config5_central_certified"] = config5_central(da)
+            except Exception as e:
+                line["config5_central_certified"] = {"error": str(e)}
         if not args.no_config5:
             try:
                 line["config5_lattice100k"] = config5_run(da, not args.no_cpu_baseline)

@@ -179,12 +179,58 @@ def test_c5_lattice_certificate_at_full_size(env, lattice):
     # the matrix IS positive definite -- takes minutes on the host and is not part of the test suite: DESIGN.md section 8)
 
 
+def test_c5_certified_optimum_at_full_size(env, lattice):
+    """BASELINE config 5 to its CERTIFIED optimum: the whole 100k-pose lattice as one problem (k = 400 000) -- central
+    preconditioner = partitioned inverse built from the device factorisation --, QuadraticOptimizer from the seeded
+    random start to |rgrad| < 1e-2, dual certificate, fastVerification: rank 5 certifies (the staircase ends at its
+    first level).  No CPU implementation can follow at this size (the oracle's factorisation alone takes minutes), so
+    the checks are the ones that hold at any size: cost and gradient recomputed from Q with scipy / the oracle's
+    projection, S against the oracle's assembly, S X^T = 0, and the distributed loop started from the optimum
+    terminates at once with the same cost."""
+    da, orc = env
+    ds = lattice
+    r, k = 5, 4 * ds.n
+    Q = da.build_Q_pgo(ds)
+    P = da.QuadraticProblem(r, ds.d, ds.n, Q)
+    assert P.precond_info()["kind"] == "sparse"
+    rng = np.random.default_rng(20250310)
+    X = da.manifold_project(r, ds.d, ds.n, rng.uniform(-1, 1, (r, k)))
+    for _ in range(40):
+        opt = da.QuadraticOptimizer(P, da.ROptParameters(RTR_iterations=50, RTR_tCG_iterations=200, gradnorm_tol=1e-2))
+        X = opt.optimize(X)
+        res = opt.getOptResult()
+        if res["gradNormOpt"] < 1e-2:
+            break
+    assert res["gradNormOpt"] < 1e-2
+    P.close()
+    A = Q.to_scipy()
+    XQ = (A @ X.T).T                      # Q symmetric
+    f = 0.5 * float(np.sum(XQ * X))
+    assert abs(f - res["fOpt"]) <= 1e-10 * abs(f)
+    assert abs(2 * f - 457289.94) <= 1e-6 * 457289.94   # the optimum of this seeded graph
+    rg = orc.tangent_project(r, ds.d, ds.n, X, XQ)
+    assert np.linalg.norm(rg) < 2e-2
+    S = da.dual_certificate(r, ds.d, ds.n, X, Q)
+    So = orc.dual_certificate(r, ds.d, ds.n, X, orc.CSR(Q.n, Q.rp, Q.ci, Q.v))
+    As = S.to_scipy()
+    assert abs(As - So.to_scipy()).max() <= 1e-9 * abs(As).max()
+    assert np.linalg.norm(As @ X.T) < 1e-1
+    psd, theta, v, lmin = da.fast_verification(S, 1e-3, block=ds.d + 1)
+    assert psd
+    # the agents' loop from the optimum: nothing left to do, same cost
+    s = da.RbcdSession(ds, num_robots=8, r=r)
+    s.set_X(X)
+    out = s.run(max_iters=3, rgrad_tol=0.1)
+    s.close()
+    assert out["gradnorm"][-1] < 0.1 and abs(out["cost"][-1] - 2 * f) <= 1e-9 * abs(2 * f)
+
+
 def test_c5_staircase_step_on_a_lattice_block(env):
     """one step r = 5 -> 6 of the Riemannian staircase (ref examples/MultiRobotExample.cpp:223-372: RBCD to a
     first-order point, certificate, minimum eigenpair, escapeSaddle) on a 16 x 16 x 12 lattice of the same generator
     (3072 poses, 8 agents), where the oracle can follow: both flows visit the same verdicts and the escape decreases
-    the cost.  (At 100 000 poses the central preconditioner escapeSaddle needs -- a factorisation of the whole
-    400 000-unknown graph -- takes minutes on the host: recorded in DESIGN.md as not yet on the device.)"""
+    the cost.  (At 100 000 poses rank 5 already certifies, test_c5_certified_optimum_at_full_size: there is no saddle
+    to escape from, and the oracle could not follow there.)"""
     da, orc = env
     from dcora_amd import synth
     ds = synth.lattice_se3(16, 16, 12)
