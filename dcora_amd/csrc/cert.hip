@@ -256,8 +256,7 @@ int device_min_eig(const HostCsr &S, int maxit, double min_eig_tol, int ncv, uin
     // on failure with the floor -2 eta.  The solve per step is the partitioned sparse inverse of the SPD matrix
     // S - sigma I replayed on the device (sparse_precond.h), one right-hand side.
     double sigma = -10.0;
-    unsigned hw = std::thread::hardware_concurrency();
-    const int nthreads = (int)std::max(1u, std::min(hw, 32u));
+    const int nthreads = std::max(1, std::min(host_cpus_available(), 32));
     for (int i = 0; i < 10; ++i) {
       PartInvHost P;
       const int brc = build_partitioned_inverse_auto(csr_shift_diag(S, -sigma), 1, nthreads, device, &P);

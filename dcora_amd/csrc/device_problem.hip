@@ -1,4 +1,6 @@
 // DeviceProblem: QuadraticProblem / QuadraticOptimizer on the MI355X (see device_problem.h).
+#include <atomic>
+
 #include "device_problem.h"
 #include "device_chol.h"
 #include "precond_cache.h"
@@ -275,8 +277,16 @@ int DeviceProblem::set_G_host(const double *Gh) {
 int DeviceProblem::build_preconditioner(const HostCsr &Qh, double reg) {
   const auto t0 = std::chrono::steady_clock::now();
   const int k = m.k;
-  unsigned hw = std::thread::hardware_concurrency();
-  const int nthreads = (int)std::max(1u, std::min(hw, 32u));
+  // host threads of the set-up: what the process may really use (host_cpus_available), shared between the problems
+  // that are being set up at the same time (the agents of a session are created side by side)
+  static std::atomic<int> builders{0};
+  struct Builder {
+    std::atomic<int> &c;
+    int active;
+    explicit Builder(std::atomic<int> &c_) : c(c_), active(c_.fetch_add(1) + 1) {}
+    ~Builder() { c.fetch_sub(1); }
+  } builder(builders);
+  const int nthreads = std::max(2, host_cpus_available() / std::max(1, builder.active));
   // Large blocks: partitioned sparse inverse replayed level by level (sparse_precond.h).  Small blocks: the dense
   // inverse streams faster than 2 * depth + 2 dependent launches.  DCORA_PRECOND=dense|sparse overrides.
   const char *pc = std::getenv("DCORA_PRECOND");

@@ -330,15 +330,32 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
   std::vector<std::vector<std::pair<int, int>>> hits((size_t)k);  // per row: (piece, local row) of this level
   double weights = 0;
   std::vector<double> &vals = P.vals;
-  // appends the interleaved weights of one segment: get(q, j) = weight of tile row q at entry j (j < len)
-  auto emit = [&](int nrows, int len, auto get) -> long long {
-    const long long off = (long long)vals.size();
-    vals.resize(vals.size() + (size_t)len * nrows);
-    double *w = vals.data() + off;
-    for (int j = 0; j < len; ++j)
-      for (int q = 0; q < nrows; ++q) w[(size_t)j * nrows + q] = get(q, j);
+  // The weights of a segment ([entry j][tile row q], j < len) are only RESERVED while the schedule is laid out; the
+  // (by far larger) job of writing them -- 0.8 G doubles for the whole 100k lattice -- is done afterwards by all threads
+  struct Fill {
+    long long off;
+    const double *base;  // Dinv / W of a piece, or the symmetric top block
+    int kind, nrows, len, c, a0, m;
+    int loc[kSpTile];
+  };
+  std::vector<Fill> fills;
+  std::vector<std::vector<double>> top_blocks;  // D^-T D^-1 of the top pieces: alive until the fill
+  long long cursor = 0;
+  auto reserve = [&](int kind, int nrows, int len, const double *base, int c, int a0, int m, const int *loc) {
+    Fill f;
+    f.off = cursor;
+    f.base = base;
+    f.kind = kind;
+    f.nrows = nrows;
+    f.len = len;
+    f.c = c;
+    f.a0 = a0;
+    f.m = m;
+    for (int q = 0; q < kSpTile; ++q) f.loc[q] = loc ? loc[q] : 0;
+    fills.push_back(f);
+    cursor += (long long)len * nrows;
     weights += (double)len * nrows;
-    return off;
+    return f.off;
   };
   // forward: y <- L_t^-1 y, leaves first.  The top level is skipped here: its pieces feed nobody (no rows below),
   // so their forward and backward steps are adjacent and are applied together as the symmetric D^-T D^-1 below
@@ -394,9 +411,7 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
           S.idx = 0;
           S.pad = 0;
           const int c = p.c;
-          S.w = emit(nrows, S.len, [&](int r_, int j) {
-            return (j <= a0 + r_ && j < c) ? p.Dinv[(size_t)(a0 + r_) * c + j] : 0.0;
-          });
+          S.w = reserve(0, nrows, S.len, p.Dinv.data(), c, a0, 0, nullptr);
           P.segs.push_back(S);
         } else {
           T.carry = pos(bit[q], p.c0 + a0);
@@ -404,7 +419,7 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
           for (size_t u = 0; u < h0.size(); ++u) {
             const int sid = h0[u].first;
             const Piece &s = pc[sid];
-            int loc[RT];
+            int loc[RT] = {0};
             for (int r_ = 0; r_ < nrows; ++r_) loc[r_] = hits[p.c0 + a0 + r_][u].second;
             PSeg S;
             S.len = pad2(s.c);
@@ -412,7 +427,7 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
             S.idx = 0;
             S.pad = 0;
             const int c = s.c;
-            S.w = emit(nrows, S.len, [&](int r_, int j) { return j < c ? s.W[(size_t)loc[r_] * c + j] : 0.0; });
+            S.w = reserve(1, nrows, S.len, s.W.data(), c, 0, 0, loc);
             P.segs.push_back(S);
           }
         }
@@ -445,9 +460,12 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
       const int idx0 = (int)P.idxs.size();
       for (int i : p.rows) P.idxs.push_back(pos(bit[piece_of[i]], i));
       if (m & 1) P.idxs.push_back(P.idxs.back());  // padded pair: weight 0, any valid position
-      std::vector<double> M;  // top level only: D^-T D^-1 (c x c, symmetric)
+      // top level only: D^-T D^-1 (c x c, symmetric), kept until the weights are written
+      const double *Mtop = nullptr;
       if (t == nlev - 1) {
-        M.assign((size_t)c * c, 0.0);
+        top_blocks.emplace_back((size_t)c * c, 0.0);
+        std::vector<double> &M = top_blocks.back();
+        Mtop = M.data();
         if (c >= kBigPiece && nthreads > 1) {
           // row a of the lower triangle by one thread: M(a, j) = sum_{i >= a} Dinv(i, a) Dinv(i, j), j <= a
           parallel_for(c, nthreads, 4, [&](int a) {
@@ -486,14 +504,12 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
         if (t == nlev - 1) {
           S.len = pad2(c);
           S.src = pos(bit[s], p.c0);
-          S.w = emit(nrows, S.len, [&](int r_, int j) { return j < c ? M[(size_t)(a0 + r_) * c + j] : 0.0; });
+          S.w = reserve(2, nrows, S.len, Mtop, c, a0, 0, nullptr);
         } else {
           S.len = pad2(c - a0);
           S.src = pos(bit[s], p.c0 + a0);
           // (D^-T)(a0 + q, a0 + j) = Dinv(a0 + j, a0 + q), zero below the diagonal of the transpose
-          S.w = emit(nrows, S.len, [&](int r_, int j) {
-            return (j >= r_ && a0 + j < c) ? p.Dinv[(size_t)(a0 + j) * c + (a0 + r_)] : 0.0;
-          });
+          S.w = reserve(3, nrows, S.len, p.Dinv.data(), c, a0, 0, nullptr);
         }
         P.segs.push_back(S);
         seg_len_sum += S.len;
@@ -504,7 +520,7 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
           Wt.src = -1;
           Wt.idx = idx0;
           Wt.pad = 0;
-          Wt.w = emit(nrows, Wt.len, [&](int r_, int j) { return j < m ? p.W[(size_t)j * c + (a0 + r_)] : 0.0; });
+          Wt.w = reserve(4, nrows, Wt.len, p.W.data(), c, a0, m, nullptr);
           P.segs.push_back(Wt);
           seg_len_sum += Wt.len;
           ++seg_cnt;
@@ -519,6 +535,49 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
     lv.lanes = pick_lanes(lv.ntasks ? (double)seg_len_sum / lv.ntasks : 1.0);
     P.levels.push_back(lv);
   }
+  // ---- write the weights ----
+  vals.assign((size_t)cursor, 0.0);
+  parallel_for((int)fills.size(), nthreads, 64, [&](int fi) {
+    const Fill &f = fills[(size_t)fi];
+    double *w = vals.data() + f.off;
+    const int nr = f.nrows, c = f.c, a0 = f.a0;
+    switch (f.kind) {
+      case 0:  // forward, own rows: row a0 + q of D^-1
+        for (int q = 0; q < nr; ++q) {
+          const double *src = f.base + (size_t)(a0 + q) * c;
+          const int hi = std::min(std::min(f.len, c), a0 + q + 1);
+          for (int j = 0; j < hi; ++j) w[(size_t)j * nr + q] = src[j];
+        }
+        break;
+      case 1:  // forward, rows fed by a piece below: rows loc[q] of W
+        for (int q = 0; q < nr; ++q) {
+          const double *src = f.base + (size_t)f.loc[q] * c;
+          const int hi = std::min(f.len, c);
+          for (int j = 0; j < hi; ++j) w[(size_t)j * nr + q] = src[j];
+        }
+        break;
+      case 2:  // top level: rows a0 + q of D^-T D^-1
+        for (int q = 0; q < nr; ++q) {
+          const double *src = f.base + (size_t)(a0 + q) * c;
+          const int hi = std::min(f.len, c);
+          for (int j = 0; j < hi; ++j) w[(size_t)j * nr + q] = src[j];
+        }
+        break;
+      case 3:  // backward, own rows: (D^-T)(a0 + q, a0 + j) = Dinv(a0 + j, a0 + q), j >= q
+        for (int j = 0; j < f.len && a0 + j < c; ++j) {
+          const double *src = f.base + (size_t)(a0 + j) * c + a0;
+          for (int q = 0; q < nr && q <= j; ++q) w[(size_t)j * nr + q] = src[q];
+        }
+        break;
+      default:  // backward, rows below: W(j, a0 + q)
+        for (int j = 0; j < f.len && j < f.m; ++j) {
+          const double *src = f.base + (size_t)j * c + a0;
+          for (int q = 0; q < nr; ++q) w[(size_t)j * nr + q] = src[q];
+        }
+        break;
+    }
+  });
+  top_blocks.clear();
   P.out_off.resize((size_t)k);
   for (int j = 0; j < k; ++j) P.out_off[j] = pos(bit[piece_of[j]], j);
   P.weights_read_per_apply = weights;

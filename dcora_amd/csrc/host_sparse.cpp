@@ -1,6 +1,8 @@
 // Host-side sparse helpers of the product (setup-time only; see host_sparse.h).
 #include "host_sparse.h"
 
+#include <sched.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -306,6 +308,42 @@ void nd_recurse(const NDGraph &G, std::vector<int> nodes, std::vector<int> &comp
 }
 }  // namespace
 
+int host_cpus_available() {
+  static const int n = [] {
+    if (const char *e = std::getenv("DCORA_HOST_THREADS")) return std::max(1, atoi(e));
+    long best = (long)std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) best = std::min<long>(best, CPU_COUNT(&set));
+    auto quota = [&](const char *path) {
+      if (FILE *f = std::fopen(path, "r")) {
+        char a[64] = {0};
+        long period = 0;
+        if (std::fscanf(f, "%63s %ld", a, &period) == 2 && std::strcmp(a, "max") != 0 && period > 0) {
+          const long q = atol(a);
+          if (q > 0) best = std::min(best, (q + period - 1) / period);
+        }
+        std::fclose(f);
+      }
+    };
+    quota("/sys/fs/cgroup/cpu.max");
+    {
+      long q = -1, per = -1;
+      if (FILE *f = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+        if (std::fscanf(f, "%ld", &q) != 1) q = -1;
+        std::fclose(f);
+      }
+      if (FILE *f = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+        if (std::fscanf(f, "%ld", &per) != 1) per = -1;
+        std::fclose(f);
+      }
+      if (q > 0 && per > 0) best = std::min(best, (q + per - 1) / per);
+    }
+    return (int)std::max(1L, best);
+  }();
+  return n;
+}
+
 int nd_top_default() {
   // measured on sphere2500 / torus3D / tiers.pyfg / a 100k-lattice agent: best of 1536 / 2048 / 3072 / 4096
   static const int v = [] {
@@ -436,8 +474,7 @@ bool SparseChol::factor(const HostCsr &A, int block, int top_unknowns) {
   ok_ = false;
   const int n = n_;
   // sub-tree parallel numeric phase for matrices that are worth it
-  unsigned hw = std::thread::hardware_concurrency();
-  int nthreads = (n >= 4096) ? (int)std::max(1u, std::min(hw, 16u)) : 1;
+  int nthreads = (n >= 4096) ? std::max(1, std::min(host_cpus_available(), 16)) : 1;
   if (const char *e = std::getenv("DCORA_FACTOR_THREADS")) nthreads = std::max(1, atoi(e));
   std::vector<std::pair<int, int>> tasks;
   std::vector<std::vector<std::pair<int, int>>> waves;  // separators above the tasks, by dissection depth
