@@ -243,7 +243,7 @@ int launch_g_retract(hipStream_t st, const ManiDesc &m, Buf2 X, const double *V,
                      Buf2 grad, const double *HV, double *partials, Gate g);
 void launch_g_nesterov(hipStream_t st, const ManiDesc &m, int mode, int restart, int skip_lo, int skip_hi,
                        double alpha, double gamma, double *X, double *V, double *Y, double *XPrev, double *Yloc,
-                       Buf2 Xloc, const SolverCtl *ctl);
+                       Buf2 Xloc, const SolverCtl *ctl, double *inner_Yloc = nullptr);
 
 #if defined(__HIPCC__)
 // ---- wave-level sums on DPP row operations (device code only) ----

@@ -75,6 +75,7 @@ class RbcdSession {
   bool restart_now() const { return opt.acceleration && ((iteration + 1) % opt.restart_interval == 0); }
   void advance_sequences();
   bool seq_advanced_ = false;
+  int staged_selected_ = -1;  // agent whose Nesterov step rode in the non-selected agents' launch of this round
   bool own_stream_ = true;
   bool pending_reset_ = false;  // gamma = alpha = 0 after a restart round, applied when the next round begins
   std::vector<char> set_marks_;  // agents that received Agent::setX since the last round

@@ -286,6 +286,7 @@ int RbcdSession::phase_nonselected(int selected) {
   DCORA_HIP(hipSetDevice(opt.device));
   advance_sequences();
   set_marks_.assign(R, 0);
+  staged_selected_ = -1;
   if (!opt.acceleration) return DCORA_OK;
   // bit 1: after the first round every V is the output of a projection (or a copy of X): skip its re-projection.
   // An Agent::setX of a single agent (which may hand over an X that is not exactly feasible) clears the flag until
@@ -295,9 +296,16 @@ int RbcdSession::phase_nonselected(int selected) {
     if (a.id != selected) all_feasible = all_feasible && a.v_feasible;
   const int restart = (restart_now() ? 1 : 0) | (all_feasible ? 2 : 0);
   if (opt.world_size == 1) {
-    // one launch over the whole graph, skipping the selected agent's poses
-    nesterov(st, mg, 0, restart, P.start(selected), P.end(selected), alpha, gamma, Xg.p, Vg.p, Yg.p, XPrevg.p, nullptr,
-             Buf2{{nullptr, nullptr}}, nullptr);
+    // one launch over the whole graph; the selected agent's poses take their own step of the same kernel (Y and the
+    // local solver's start point <- proj((1 - alpha) X + alpha V), what update_selected_agent would launch next)
+    if (group_kernels(mg) && agents[selected].hosted && agents[selected].prob) {
+      launch_g_nesterov(st, mg, 0, restart, P.start(selected), P.end(selected), alpha, gamma, Xg.p, Vg.p, Yg.p, XPrevg.p,
+                        nullptr, Buf2{{nullptr, nullptr}}, nullptr, agents[selected].prob->X0.p);
+      staged_selected_ = selected;
+    } else {
+      nesterov(st, mg, 0, restart, P.start(selected), P.end(selected), alpha, gamma, Xg.p, Vg.p, Yg.p, XPrevg.p, nullptr,
+               Buf2{{nullptr, nullptr}}, nullptr);
+    }
     for (AgentDev &a : agents)
       if (a.id != selected) a.v_feasible = true;
   } else {
@@ -352,8 +360,10 @@ int RbcdSession::update_selected_agent(AgentDev &a, bool restart) {
     const SolverCtl *cs = nullptr;
     last_solver = &pb;
     if (opt.acceleration) {
-      nesterov(st, pb.m, 1, 0, -1, -1, alpha, gamma, Xg.p + off, Vg.p + off, Yg.p + off, XPrevg.p + off, pb.X0.p,
-               Buf2{{nullptr, nullptr}}, nullptr);
+      if (staged_selected_ != a.id)  // (otherwise the non-selected agents' launch has taken this step already)
+        nesterov(st, pb.m, 1, 0, -1, -1, alpha, gamma, Xg.p + off, Vg.p + off, Yg.p + off, XPrevg.p + off, pb.X0.p,
+                 Buf2{{nullptr, nullptr}}, nullptr);
+      staged_selected_ = -1;
       rc = pb.optimize_dev(opt.local, &Xres, &cs);
       if (rc) return rc;
       rc = resolve_pick(pb, &Xres, &cs);

@@ -1404,6 +1404,7 @@ struct GNesterovArgs {
   int mode, restart, skip_lo, skip_hi;
   double alpha, gamma;
   double *X, *V, *Y, *XPrev, *Yloc;
+  double *inner_Yloc;     // mode 0 only: when set, the skipped poses run mode 1 instead (Y and this buffer <- their y)
   Buf2 Xloc;              // result buffers of the local solve
   const SolverCtl *ctl;   // picks Xloc.p[ctl->cur] when non-null
 };
@@ -1415,7 +1416,9 @@ __global__ __launch_bounds__(kBlock) void k_g_nesterov(ManiDesc m, GNesterovArgs
   const int t = threadIdx.x & (GW - 1);
   for (int pose0 = blockIdx.x * kPosesPerBlock; pose0 < m.n; pose0 += gridDim.x * kPosesPerBlock) {
     const int pose = pose0 + (threadIdx.x >> 3);
-    const bool inrange = (pose < m.n) && !(pose >= a.skip_lo && pose < a.skip_hi);
+    const bool skipped = pose >= a.skip_lo && pose < a.skip_hi;
+    const bool inner = skipped && a.inner_Yloc != nullptr && pose < m.n;  // the selected agent's poses, staged here
+    const bool inrange = (pose < m.n) && (!skipped || inner);
     const bool active = inrange && (t < r);
     const size_t o = (size_t)pose * DH * r;
     Row<D> x, v, y;
@@ -1428,9 +1431,10 @@ __global__ __launch_bounds__(kBlock) void k_g_nesterov(ManiDesc m, GNesterovArgs
       row_polar<D>(y, inrange);
       y.e[D] = yt;
       st_row<D>(a.XPrev + o, r, t, active, x);
-      if (a.mode == 1) {
+      if (a.mode == 1 || inner) {
         st_row<D>(a.Y + o, r, t, active, y);
-        st_row<D>(a.Yloc + o, r, t, active, y);
+        double *yl = inner ? a.inner_Yloc + (size_t)(pose - a.skip_lo) * DH * r : a.Yloc + o;
+        st_row<D>(yl, r, t, active, y);
       } else if (a.restart & 1) {
         st_row<D>(a.V + o, r, t, active, x);
         st_row<D>(a.Y + o, r, t, active, x);
@@ -1894,8 +1898,8 @@ int launch_g_retract(hipStream_t st, const ManiDesc &m, Buf2 X, const double *V,
 }
 void launch_g_nesterov(hipStream_t st, const ManiDesc &m, int mode, int restart, int skip_lo, int skip_hi,
                        double alpha, double gamma, double *X, double *V, double *Y, double *XPrev, double *Yloc,
-                       Buf2 Xloc, const SolverCtl *ctl) {
-  GNesterovArgs a{mode, restart, skip_lo, skip_hi, alpha, gamma, X, V, Y, XPrev, Yloc, Xloc, ctl};
+                       Buf2 Xloc, const SolverCtl *ctl, double *inner_Yloc) {
+  GNesterovArgs a{mode, restart, skip_lo, skip_hi, alpha, gamma, X, V, Y, XPrev, Yloc, inner_Yloc, Xloc, ctl};
   const int grid = group_grid(m.n);
   if (m.d == 3)
     hipLaunchKernelGGL(k_g_nesterov<3>, dim3(grid), dim3(kBlock), 0, st, m, a);
