@@ -89,12 +89,16 @@ class Dataset:
         return h
 
 
-def chordal_initialization(ds):
-    """chordalInitialization (ref src/DCORA_solver.cpp:218-268); returns T, d x (d+1) n"""
+def chordal_initialization(ds, device=None):
+    """chordalInitialization (ref src/DCORA_solver.cpp:218-268); returns T, d x (d+1) n.  device: solve the two SPD
+    systems on that GPU (large graphs) instead of on the host"""
     h = ds.handle()
     out = np.zeros(ds.d * (ds.d + 1) * ds.n)
     try:
-        check(capi.lib().dcora_dataset_chordal_init(h, out))
+        if device is None:
+            check(capi.lib().dcora_dataset_chordal_init(h, out))
+        else:
+            check(capi.lib().dcora_dataset_chordal_init_device(h, int(device), out))
     finally:
         capi.lib().dcora_dataset_destroy(h)
     return unF(out, ds.d, (ds.d + 1) * ds.n)

@@ -103,6 +103,7 @@ SIGNATURES = {
     "dcora_dataset_copy": (C.c_int, [_vp, _ip, _dp]),
     "dcora_dataset_destroy": (C.c_int, [_vp]),
     "dcora_dataset_chordal_init": (C.c_int, [_vp, _dp]),
+    "dcora_dataset_chordal_init_device": (C.c_int, [_vp, C.c_int, _dp]),
     "dcora_graph_build_Q_pgo": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _ip, _dp, C.POINTER(_vp)]),
     "dcora_radataset_load_pyfg": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
     "dcora_radataset_info": (C.c_int, [_vp, _ip]),

@@ -582,6 +582,23 @@ int dcora_dataset_chordal_init(dcora_dataset_t ds, double *T) {
   return DCORA_OK;
   DCORA_CATCH
 }
+int dcora_dataset_chordal_init_device(dcora_dataset_t ds, int device, double *T) {
+  if (!ds || !T) return bad("null argument");
+  DCORA_TRY
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_last_error("no HIP device available: libdcora_hip has no CPU fallback");
+    return DCORA_ERR_NO_DEVICE;
+  }
+  std::vector<double> out;
+  if (!chordal_initialization(ds->ds, out, device_spd_solver(device))) {
+    set_last_error("chordal initialisation: reduced Laplacian not positive definite (disconnected graph?)");
+    return DCORA_ERR_NOT_PD;
+  }
+  std::copy(out.begin(), out.end(), T);
+  return DCORA_OK;
+  DCORA_CATCH
+}
 int dcora_graph_build_Q_pgo(int d, int n, int agent_id, int m, const int *ids, const double *vals, dcora_csr_t *Q) {
   DCORA_TRY
   dcora_csr_s *h = new dcora_csr_s;

@@ -15,6 +15,7 @@
 // structures closed under the piece tree, scatter map of the matrix entries); it is cached on the pattern.
 #pragma once
 #include <cstddef>
+#include <functional>
 #include <memory>
 #include <vector>
 
@@ -73,6 +74,11 @@ int build_partitioned_inverse_auto(const HostCsr &A, int block, int nthreads, in
 // dense inverse of a small SPD matrix, entirely on the device: Minv (device, k rows of ldm >= k doubles, row-major,
 // both triangles) <- A^-1.  *pd = false (and Minv undefined) when A is not positive definite.
 int device_dense_spd_inverse(const HostCsr &A, int device, double *Minv, int ldm, bool *pd);
+
+// X = A^-1 B for a sparse SPD matrix and up to 16 right-hand sides (contiguous per unknown) through the partitioned
+// inverse built from the device factorisation and ONE replay on the device: the solver the chordal initialisation
+// takes at sizes where the host factorisation takes minutes (host_graph.h, SpdSolve)
+std::function<bool(const HostCsr &, int, int, const double *, double *)> device_spd_solver(int device);
 
 void chol_cache_clear();
 

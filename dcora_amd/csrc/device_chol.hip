@@ -775,6 +775,28 @@ int device_dense_spd_inverse(const HostCsr &A, int device, double *Minv, int ldm
   return DCORA_OK;
 }
 
+std::function<bool(const HostCsr &, int, int, const double *, double *)> device_spd_solver(int device) {
+  return [device](const HostCsr &A, int block, int nrhs, const double *B, double *X) -> bool {
+    if (nrhs < 1 || nrhs > 16) return false;
+    if (hipSetDevice(device) != hipSuccess) return false;
+    PartInvHost P;
+    const int nthreads = std::max(2, host_cpus_available());
+    if (build_partitioned_inverse_auto(A, block, nthreads, device, &P) != DCORA_OK) return false;
+    auto img = std::make_shared<SpImage>();
+    if (img->upload(P) != DCORA_OK) return false;
+    P = PartInvHost();  // the host image is no longer needed
+    SparsePrecond sp;
+    if (sp.attach(img, nrhs) != DCORA_OK) return false;
+    const size_t N = (size_t)A.n * nrhs;
+    DevBuf<double> dB, dX;
+    if (dB.alloc(N) != hipSuccess || dX.alloc(N) != hipSuccess) return false;
+    if (hipMemcpy(dB.p, B, N * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return false;
+    sp.apply(nullptr, nrhs, buf1(dB.p), dX.p, Gate{});
+    if (hipMemcpy(X, dX.p, N * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return false;
+    return true;
+  };
+}
+
 int build_partitioned_inverse_auto(const HostCsr &A, int block, int nthreads, int device, PartInvHost *out) {
   static const bool host_factor = [] {
     const char *e = std::getenv("DCORA_FACTOR");

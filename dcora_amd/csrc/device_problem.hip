@@ -665,7 +665,9 @@ int DeviceProblem::rtr_dev(const dcora_ropt_params &prm, dcora_ropt_result *res_
   };
 
   // f(x0), grad(x0)
-  launch_spmm(st, m.r, Qv, Xb(), 0, Gp, EGb(), 0, pA.p, Gate{c, ++seq, 0});
+  // (enq_qapply, not the CSR kernel directly: the number of partial slots npA() counts follows the Q-apply kernel that
+  // runs -- block-CSR for large pose graphs)
+  enq_qapply(Xb(), 0, Gp, EGb(), 0, pA.p, Gate{c, ++seq, 0});
   launch_rgrad(st, m, Xb(), EGb(), RGb(), Sb(), 0, pB.p, Gate{c, ++seq, 0});
   launch_rtr_init(st, pA.p, nA, pB.p, nP, c, hf_dev, ++seq);
   int last_pace_seq = seq;
@@ -716,7 +718,7 @@ int DeviceProblem::rtr_dev(const dcora_ropt_params &prm, dcora_ropt_result *res_
     }
     // ---- trial point, model ratio, acceptance ----
     launch_retract(st, m, Xb(), eta.p, 1.0, Xb(), 1, RGb(), Heta.p, pC.p, Gate{c, ++seq, 1});
-    launch_spmm(st, m.r, Qv, Xb(), 1, Gp, EGb(), 1, pA.p, Gate{c, ++seq, 1});
+    enq_qapply(Xb(), 1, Gp, EGb(), 1, pA.p, Gate{c, ++seq, 1});
     launch_rgrad(st, m, Xb(), EGb(), RGb(), Sb(), 1, pB.p, Gate{c, ++seq, 1});
     launch_rtr_decide(st, pA.p, nA, pB.p, nP, pC.p, nP, c, hf_dev, ++seq);
     last_pace_seq = seq;

@@ -4,6 +4,7 @@
 //   C   (ref src/Graph.cpp:685-822)     -- the coupling blocks: G_b = X_global * C_b, i.e. the linear term of
 //                                          agent b as a sparse product with the neighbours' public poses
 #pragma once
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -69,7 +70,11 @@ void ra_agent_columns(const HostRADataset &ds, int robot, int dims3[3], std::vec
 // (the same restriction the reference assembles edge by edge, ref src/Graph.cpp:824-1772)
 void extract_agent_blocks(const HostCsr &Q, const std::vector<int> &own, HostCsr *Qaa, HostCsr *C);
 // chordalInitialization (ref src/DCORA_solver.cpp:218-268): T is d x (d+1) n column-major, pose 0 = identity
-bool chordal_initialization(const HostDataset &ds, std::vector<double> &T);
+// solve(A, block, nrhs, B, X): X = A^-1 B for a sparse SPD A, right-hand sides contiguous per unknown (B[i * nrhs + t]);
+// false when A is not positive definite.  nullptr: sparse Cholesky on the host.  The device variant is
+// device_spd_solver(device) of device_chol.h (the host factorisation of the 100k lattice's systems takes minutes).
+using SpdSolve = std::function<bool(const HostCsr &, int, int, const double *, double *)>;
+bool chordal_initialization(const HostDataset &ds, std::vector<double> &T, const SpdSolve &solve = nullptr);
 bool load_pyfg(const std::string &path, HostRADataset &out, std::string &err);
 // start point of the centralised CORA driver (ref examples/SingleRobotExample_RASLAM.cpp:92-150): odometry chains
 // anchored at their ground-truth first pose, ground-truth unit spheres, seeded uniform(-1, 1) landmarks; d x k

@@ -82,7 +82,25 @@ void project_to_rotation_group_host(int d, const double *M, double *out) { proje
 
 // T (d x (d+1) n, column-major, SE ordering); returns false when a reduced Laplacian is not positive definite
 // (disconnected measurement graph)
-bool chordal_initialization(const HostDataset &ds, std::vector<double> &T) {
+namespace {
+// host solve: nested-dissection Cholesky, right-hand sides in the permuted order
+bool host_spd_solve(const HostCsr &A, int block, int nrhs, const double *B, double *X) {
+  SparseChol ch;
+  if (!ch.factor(A, block)) return false;
+  const int m = A.n;
+  std::vector<double> y((size_t)m * nrhs);
+  const std::vector<int> &perm = ch.perm();
+  for (int q = 0; q < m; ++q)
+    for (int a = 0; a < nrhs; ++a) y[(size_t)q * nrhs + a] = B[(size_t)perm[q] * nrhs + a];
+  ch.solve_inplace(y.data(), nrhs);
+  for (int q = 0; q < m; ++q)
+    for (int a = 0; a < nrhs; ++a) X[(size_t)perm[q] * nrhs + a] = y[(size_t)q * nrhs + a];
+  return true;
+}
+}  // namespace
+
+bool chordal_initialization(const HostDataset &ds, std::vector<double> &T, const SpdSolve &solve_in) {
+  const SpdSolve solve = solve_in ? solve_in : SpdSolve(host_spd_solve);
   const int d = ds.d, n = ds.n, dh = d + 1;
   T.assign((size_t)d * dh * n, 0.0);
   for (int a = 0; a < d; ++a) T[(size_t)a * d + a] = 1.0;
@@ -113,16 +131,8 @@ bool chordal_initialization(const HostDataset &ds, std::vector<double> &T) {
   }
   {
     HostCsr L = csr_from_coo(m, m, I, J, V);
-    SparseChol ch;
-    if (!ch.factor(L, d)) return false;
-    std::vector<double> y((size_t)m * d);
-    const std::vector<int> &perm = ch.perm();
-    for (int q = 0; q < m; ++q)
-      for (int a = 0; a < d; ++a) y[(size_t)q * d + a] = rhs[(size_t)perm[q] * d + a];
-    ch.solve_inplace(y.data(), d);
     std::vector<double> sol((size_t)m * d);
-    for (int q = 0; q < m; ++q)
-      for (int a = 0; a < d; ++a) sol[(size_t)perm[q] * d + a] = y[(size_t)q * d + a];
+    if (!solve(L, d, d, rhs.data(), sol.data())) return false;
     for (int i = 1; i < n; ++i) {
       double blk[9], out[9];
       for (int c = 0; c < d; ++c)
@@ -153,15 +163,10 @@ bool chordal_initialization(const HostDataset &ds, std::vector<double> &T) {
     }
   }
   HostCsr Lt = csr_from_coo(n - 1, n - 1, I, J, V);
-  SparseChol ct;
-  if (!ct.factor(Lt, 1)) return false;
   std::vector<double> y((size_t)(n - 1) * d);
-  const std::vector<int> &perm = ct.perm();
+  if (!solve(Lt, 1, d, b.data(), y.data())) return false;
   for (int q = 0; q < n - 1; ++q)
-    for (int a = 0; a < d; ++a) y[(size_t)q * d + a] = b[(size_t)perm[q] * d + a];
-  ct.solve_inplace(y.data(), d);
-  for (int q = 0; q < n - 1; ++q)
-    for (int a = 0; a < d; ++a) T[(size_t)((perm[q] + 1) * dh + d) * d + a] = y[(size_t)q * d + a];
+    for (int a = 0; a < d; ++a) T[(size_t)((q + 1) * dh + d) * d + a] = y[(size_t)q * d + a];
   return true;
 }
 

@@ -186,6 +186,10 @@ int dcora_dataset_destroy(dcora_dataset_t ds);
 /* chordalInitialization (ref src/DCORA_solver.cpp:218-268): T is d x (d+1) n column-major (SE ordering), the start
  * point of the reference driver's InitializationMethod::Chordal (ref examples/MultiRobotExample.cpp:150-153) */
 int dcora_dataset_chordal_init(dcora_dataset_t ds, double *T);
+/* the same with the two sparse SPD systems solved on the device (partitioned inverse built from the device
+ * factorisation, one replay each): for graphs whose host factorisation takes minutes (the 100k lattice: 237 s on the
+ * host).  Same result up to the rounding of the solves. */
+int dcora_dataset_chordal_init_device(dcora_dataset_t ds, int device, double *T);
 /* Graph::constructQuadraticCostTermPGO (ref src/Graph.cpp:579-683) for agent `agent_id` owning n poses */
 int dcora_graph_build_Q_pgo(int d, int n, int agent_id, int m, const int *ids, const double *vals, dcora_csr_t *Q);
 

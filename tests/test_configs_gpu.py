@@ -225,6 +225,34 @@ def test_c5_certified_optimum_at_full_size(env, lattice):
     assert out["gradnorm"][-1] < 0.1 and abs(out["cost"][-1] - 2 * f) <= 1e-9 * abs(2 * f)
 
 
+def test_large_single_problem_reports_the_cost_of_its_iterates(env):
+    """a single problem of 27 000 poses: block-CSR Q-apply, too many pose blocks for the fused kernels, i.e. the generic
+    RTR path.  Its bookkeeping (fInit, fOpt, and with them the trust-region ratio) must be the cost of the iterates --
+    the partial-sum slots the solver adds up have to be the ones its Q-apply kernel wrote, also right after another
+    evaluation left other partials in the buffer (a regression: the CSR kernel's 1024 slots were summed as 844)."""
+    da, orc = env
+    from dcora_amd import synth
+    ds = synth.lattice_se3(30, 30, 30)
+    r, k = 5, 4 * ds.n
+    rng = np.random.default_rng(1)
+    X = da.manifold_project(r, ds.d, ds.n, rng.uniform(-1, 1, (r, k)))
+    Q = da.build_Q_pgo(ds)
+    A = Q.to_scipy()
+    f = lambda Y: 0.5 * float(np.sum((A @ Y.T).T * Y))
+    P = da.QuadraticProblem(r, ds.d, ds.n, Q)
+    assert P.qapply_info()["kernel"] == "k_spmm_bsr"
+    assert abs(P.f(0.5 * X) - f(0.5 * X)) <= 1e-11 * f(X)     # leaves the partials of another point behind
+    assert abs(P.f(X) - f(X)) <= 1e-11 * f(X)
+    for iters in (1, 3):
+        opt = da.QuadraticOptimizer(P, da.ROptParameters(RTR_iterations=iters, RTR_tCG_iterations=5, gradnorm_tol=1e-2))
+        Xn = opt.optimize(X)
+        res = opt.getOptResult()
+        assert abs(res["fInit"] - f(X)) <= 1e-11 * f(X)
+        assert abs(res["fOpt"] - f(Xn)) <= 1e-11 * f(X)
+        assert res["fOpt"] < res["fInit"]
+    P.close()
+
+
 def test_c5_staircase_step_on_a_lattice_block(env):
     """one step r = 5 -> 6 of the Riemannian staircase (ref examples/MultiRobotExample.cpp:223-372: RBCD to a
     first-order point, certificate, minimum eigenpair, escapeSaddle) on a 16 x 16 x 12 lattice of the same generator

@@ -103,6 +103,21 @@ def test_dense_inverse_built_on_the_device(built):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["smallGrid3D", "sphere2500", "CSAIL"])
+def test_chordal_initialisation_with_device_solves(built, name):
+    """the two SPD systems of the chordal initialisation (ref src/DCORA_solver.cpp:218-268) solved on the device through
+    the partitioned inverse: same start point as with the host factorisation and as the oracle's"""
+    import dcora_amd as da
+    from oracle import orc
+    ds = common.product_dataset(name)
+    Th = da.chordal_initialization(ds)
+    Td = da.chordal_initialization(ds, device=0)
+    assert np.linalg.norm(Td - Th) <= 1e-9 * np.linalg.norm(Th)
+    To = orc.chordal_initialization(common.oracle_dataset(name))
+    assert np.linalg.norm(Td - To) <= 1e-8 * np.linalg.norm(To)
+
+
+@pytest.mark.gpu
 def test_device_verdict_and_logdet_vs_scipy_and_oracle(built):
     import dcora_amd as da
     from oracle import orc
