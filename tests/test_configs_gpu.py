@@ -253,6 +253,45 @@ def test_large_single_problem_reports_the_cost_of_its_iterates(env):
     P.close()
 
 
+@pytest.mark.parametrize("dims,r,expect", [
+    ((10, 10, 20), 5, ("dense", "k_spmm")),       # k = 8000: the largest dense preconditioner
+    ((3, 23, 29), 5, ("sparse", "k_spmm")),       # k = 8004: the first sparse one
+    ((13, 21, 30), 5, ("sparse", "k_spmm")),      # n = 8190: the last CSR Q-apply
+    ((16, 16, 32), 5, ("sparse", "k_spmm_bsr")),  # n = 8192: the first block-CSR one
+    ((32, 32, 24), 5, ("sparse", "k_spmm_bsr")),  # n = 24576: 2048 pose blocks, the last fused solve at r = 5
+    ((30, 41, 20), 5, ("sparse", "k_spmm_bsr")),  # n = 24600: the first one on the generic path
+    ((16, 16, 32), 8, ("sparse", "k_spmm_bsr")),  # r = 8: the widest fused rank
+    ((13, 21, 30), 9, ("sparse", "k_spmm")),      # r = 9: generic kernels
+])
+def test_size_regimes_agree_with_an_independent_cost(env, dims, r, expect):
+    """every switch of kernel family by size (dense / sparse preconditioner, CSR / block-CSR Q-apply, fused / generic
+    solver, r <= 8 / r > 8) on either side of its threshold: cost and gradient norm against scipy / the oracle's
+    projection, and a short solve whose bookkeeping must be the cost of its own iterates"""
+    da, orc = env
+    from dcora_amd import synth
+    ds = synth.lattice_se3(*dims)
+    k = 4 * ds.n
+    rng = np.random.default_rng(5)
+    X = da.manifold_project(r, ds.d, ds.n, rng.uniform(-1, 1, (r, k)))
+    Q = da.build_Q_pgo(ds)
+    A = Q.to_scipy()
+    f = lambda Y: 0.5 * float(np.sum((A @ Y.T).T * Y))
+    P = da.QuadraticProblem(r, ds.d, ds.n, Q)
+    assert (P.precond_info()["kind"], P.qapply_info()["kernel"]) == expect
+    fx = f(X)
+    assert abs(P.f(X) - fx) <= 1e-11 * fx
+    rg = orc.tangent_project(r, ds.d, ds.n, X, (A @ X.T).T)
+    assert abs(P.RieGradNorm(X) - np.linalg.norm(rg)) <= 1e-10 * np.linalg.norm(rg)
+    opt = da.QuadraticOptimizer(P, da.ROptParameters(RTR_iterations=3, RTR_tCG_iterations=10, gradnorm_tol=1e-2))
+    Xn = opt.optimize(X)
+    res = opt.getOptResult()
+    assert abs(res["fInit"] - fx) <= 1e-11 * fx
+    assert abs(res["fOpt"] - f(Xn)) <= 1e-11 * fx
+    assert res["fOpt"] < res["fInit"]
+    assert abs(res["gradNormInit"] - np.linalg.norm(rg)) <= 1e-10 * np.linalg.norm(rg)
+    P.close()
+
+
 def test_c5_staircase_step_on_a_lattice_block(env):
     """one step r = 5 -> 6 of the Riemannian staircase (ref examples/MultiRobotExample.cpp:223-372: RBCD to a
     first-order point, certificate, minimum eigenpair, escapeSaddle) on a 16 x 16 x 12 lattice of the same generator
