@@ -245,6 +245,16 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
     std::vector<double> D, B;
     for (int s = 0; s < np; ++s) {
       Piece &p = pc[s];
+      if (F.pieces[s].inverted) {  // the device delivered L11^-1 over W: nothing to compute
+        const PieceFactor &f = F.pieces[s];
+        const int c = p.c, m = (int)p.rows.size();
+        p.Dinv.assign(f.panel.begin(), f.panel.begin() + (size_t)c * c);
+        p.W.resize((size_t)m * c);
+        for (int a2 = 0; a2 < m; ++a2)
+          std::copy(&f.panel[(size_t)(c + p.src[a2]) * c], &f.panel[(size_t)(c + p.src[a2]) * c] + c,
+                    &p.W[(size_t)a2 * c]);
+        continue;
+      }
       if (p.c < kBigPiece || nthreads < 2) continue;
       const int c = p.c, m = (int)p.rows.size();
       extract(s, D, B);
@@ -463,6 +473,9 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
       // top level only: D^-T D^-1 (c x c, symmetric), kept until the weights are written
       const double *Mtop = nullptr;
       if (t == nlev - 1) {
+        if (!F.pieces[s].Mtop.empty()) {  // formed on the device
+          Mtop = F.pieces[s].Mtop.data();
+        } else {
         top_blocks.emplace_back((size_t)c * c, 0.0);
         std::vector<double> &M = top_blocks.back();
         Mtop = M.data();
@@ -489,6 +502,7 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
               for (int j = 0; j <= i; ++j) ma[j] += v * di[j];
             }
           }
+        }
         }
       }
       for (int a0 = 0; a0 < c; a0 += RT) {

@@ -83,6 +83,10 @@ struct PieceFactor {
   int c0 = 0, c = 0;
   std::vector<int> rows;
   std::vector<double> panel;
+  // wide pieces may arrive already inverted by the device (device_chol.h): the panel then holds L11^-1 over
+  // W = -L21 L11^-1, and for a piece without rows below Mtop = L11^-T L11^-1 (c x c, both triangles)
+  bool inverted = false;
+  std::vector<double> Mtop;
 };
 struct PiecewiseFactor {
   int n = 0, nhub = 0;
