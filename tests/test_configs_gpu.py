@@ -217,6 +217,18 @@ def test_c5_certified_optimum_at_full_size(env, lattice):
     assert np.linalg.norm(As @ X.T) < 1e-1
     psd, theta, v, lmin = da.fast_verification(S, 1e-3, block=ds.d + 1)
     assert psd
+    # recovered poses (the third output north_star names): the certified solution has rank d, so rounding it to
+    # SE(3)^n in the frame of pose 0 loses nothing -- the globally optimal trajectory
+    # (from the random start the components beyond rank d are still decaying at |rgrad| = 1e-2: 3e-4 of the largest
+    # singular value; from the chordal start the solution has rank d exactly and the rounded cost equals f to 1e-13)
+    sv = np.linalg.svd(X, compute_uv=False)
+    assert sv[ds.d] <= 1e-3 * sv[0]
+    T = da.align_lifted_trajectory_to_frame(X, X[:, :4], ds.d, ds.n, True)
+    f_round = 0.5 * float(np.sum((A @ T.T).T * T))
+    assert f * (1 - 1e-9) <= f_round <= f * (1 + 1e-4)
+    for i in (0, 1, 31415, ds.n - 1):
+        Ri = T[:, 4 * i:4 * i + 3]
+        assert np.abs(Ri.T @ Ri - np.eye(3)).max() < 1e-12 and np.linalg.det(Ri) > 0.999
     # the agents' loop from the optimum: nothing left to do, same cost
     s = da.RbcdSession(ds, num_robots=8, r=r)
     s.set_X(X)
