@@ -142,3 +142,36 @@ def test_cpp_staircase_driver_matches_the_python_driver(built, tmp_path, name, r
     assert rows.shape == (ds.n, 8)
     assert np.allclose(np.linalg.norm(rows[:, 4:8], axis=1), 1.0, atol=1e-8)   # unit quaternions
     assert np.allclose(rows[0, 1:4], 0.0, atol=1e-9)                            # the frame of the first pose
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["range_aided_slam_test_2d", "range_aided_slam_test_3d"])
+def test_cpp_raslam_staircase_driver_matches_the_python_driver(built, name):
+    """dcora_amd/examples/MultiRobotExample_RASLAM.cpp -- the reference's multi-robot range-aided SLAM driver (agents per
+    robot of the pyfg file, staircase from rank d, certificate, escapeSaddle) as a C++ program over the C ABI -- against
+    dcora_amd/driver.py: same levels, iteration count and certified cost from the same odometry start"""
+    import gzip
+    import json
+    import shutil
+    import subprocess
+    import tempfile
+    import dcora_amd as da
+    from dcora_amd import driver
+    exe = os.path.join(os.path.dirname(common.HERE), "dcora_amd", "examples", "_build", "multi-robot-example-raslam")
+    gz = os.path.join(common.DATA, name + ".pyfg.gz")
+    with tempfile.NamedTemporaryFile(suffix=".pyfg", delete=False) as tmp, gzip.open(gz, "rb") as src:
+        shutil.copyfileobj(src, tmp)
+        plain = tmp.name
+    try:
+        out = subprocess.run([exe, plain, "--quiet", "--iters", "300", "--rgrad-tol", "1e-3"], capture_output=True,
+                             text=True, timeout=300)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        res = json.loads(out.stdout.strip().splitlines()[-1])
+    finally:
+        os.unlink(plain)
+    ra = da.RADataset(gz)
+    ref = driver.multi_robot_raslam_example(ra, ra.X_odom, max_iters=300, rgrad_tol=1e-3, r_max=ra.d + 12)
+    assert res["certified"] and ref["certified"]
+    assert res["rank"] == ref["rank"] and res["levels"] == len(ref["levels"])
+    assert res["iterations"] == ref["total_iters"]
+    assert abs(res["cost_2f"] - ref["levels"][-1]["cost_2f"]) <= 1e-9 + 1e-6 * abs(ref["levels"][-1]["cost_2f"])
