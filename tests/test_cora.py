@@ -77,3 +77,33 @@ def test_cora_flow_on_single_drone_matches_oracle(built):
         assert np.allclose(R.T @ R, np.eye(d), atol=1e-9)
     print("single_drone CORA: hip %.0f ms, cpu %.0f ms, levels %s" %
           (out["ms_total"], ref["ms_total"], [(lv["r"], round(lv["f"], 6), lv["inner"]) for lv in out["levels"]]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["range_aided_slam_test_2d", "range_aided_slam_test_3d", "single_drone"])
+def test_cpp_cora_driver_matches_the_python_flow(built, name):
+    """dcora_amd/examples/SingleRobotExample_RASLAM.cpp -- the reference's centralised CORA driver as a C++ program over
+    the facade -- against dcora_amd/cora_flow.py from the same odometry start: same certified cost, both rounded costs
+    above it"""
+    import json
+    import subprocess
+    import dcora_amd as da
+    exe = os.path.join(os.path.dirname(common.HERE), "dcora_amd", "examples", "_build", "single-robot-example-raslam")
+    plain = _plain(name)
+    try:
+        run = subprocess.run([exe, plain], capture_output=True, text=True, timeout=600)
+        assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+        res = json.loads(run.stdout.strip().splitlines()[-1])
+    finally:
+        os.unlink(plain)
+    ra = da.RADataset(os.path.join(common.DATA, name + ".pyfg.gz"))
+    ref = cora_flow.cora(cora_flow.ProductBackend(ra), ra.X_odom, ra.d)
+    assert res["certified"] and ref["certified"]
+    f_ref = ref["levels"][-1]["f"]
+    assert abs(res["f"] - f_ref) <= 1e-9 + 1e-6 * abs(f_ref)
+    assert res["gradnorm"] < 1e-4
+    assert res["f"] <= res["f_rounded"] + 1e-9 and f_ref <= ref["f_rounded"] + 1e-9
+    if name != "single_drone":   # deterministic kernels, the same calls in the same order: the same trajectory
+        assert res["rank"] == ref["r_final"] and res["levels"] == len(ref["levels"])
+        assert abs(res["f_rounded"] - ref["f_rounded"]) <= 1e-9 + 1e-6 * abs(ref["f_rounded"])
+    print(name, "C++ CORA driver:", res)
