@@ -1481,7 +1481,11 @@ __global__ __launch_bounds__(kBlock) void k_g_nesterov(ManiDesc m, GNesterovArgs
 
 // matrix blocks whose neighbour rows are gathered together.  Measured on the 100k lattice, warm / cold us: 1: 28.2 / 35.7,
 // 2: 27.2 / 34.0, 3: 27.8 / 35.0, 4: 29.5 / 36.2, 6: 32.0 / 39.2, 8: 32.1 / 39.6 -- the registers of a deeper batch cost more
-// resident waves (94 VGPRs at 4, 74 at 2) than its loads in flight give back; forcing 7 or 8 waves per SIMD changes nothing
+// resident waves (94 VGPRs at 4, 74 at 2) than its loads in flight give back; forcing 7 or 8 waves per SIMD changes nothing.
+// Non-temporal loads of the block stream and of G and non-temporal stores of Y (they bypass the Infinity Cache): warm
+// 27.2 -> 36.8 us, cold 33.7 -> 37.1 us.  Per launch the kernel also moves 717 MB through LDS (every lane reads the
+// (d+1)^2 values of its block: 9 us of LDS time per CU) and issues 350 k gather instructions of 8+ lines each (another
+// 9 us of address-unit time), next to 21 us of HBM time at the measured triad rate: balanced, not HBM-bound alone.
 constexpr int kBsrGather = 2;
 template <int D, bool DOTS>
 __global__ __launch_bounds__(kBlock) void k_spmm_bsr(int r, BsrDev A, Buf2 Xb, int selX,
