@@ -33,12 +33,24 @@ inline void inline_first_segment(PTask &T, const std::vector<PSeg> &segs) {
   T.src0 = 0;
   T.idx0 = 0;
   T.w0 = 0;
+  T.len1 = 0;
+  T.src1 = 0;
+  T.idx1 = 0;
+  T.w1 = 0;
+  T.pad = 0;
   if (T.nseg > 0) {
     const PSeg &S = segs[(size_t)T.seg0];
     T.len0 = S.len;
     T.src0 = S.src;
     T.idx0 = S.idx;
     T.w0 = S.w;
+  }
+  if (T.nseg > 1) {
+    const PSeg &S = segs[(size_t)T.seg0 + 1];
+    T.len1 = S.len;
+    T.src1 = S.src;
+    T.idx1 = S.idx;
+    T.w1 = S.w;
   }
 }
 
@@ -66,8 +78,21 @@ void parallel_for(int n, int nthreads, int chunk, F body) {
 
 constexpr int kBigPiece = 384;  // pieces this wide are inverted by all threads together (the merged top of the tree)
 
-int pick_lanes(double avg_entries_per_tile) {
-  if (avg_entries_per_tile >= 160) return 256;
+int pick_lanes(double avg_entries_per_tile, int ntasks) {
+  // experiment (DCORA_SP_LANES="t256,t128,t64,t32,cap"): lanes per tile from the entries a tile gathers; cap > 0: no more
+  // than cap waves per level as long as a smaller tile exists
+  static const char *e = std::getenv("DCORA_SP_LANES");
+  if (e) {
+    int t256 = 400, t128 = 160, t64 = 20, t32 = 8, cap = 0;
+    std::sscanf(e, "%d,%d,%d,%d,%d", &t256, &t128, &t64, &t32, &cap);
+    int L = avg_entries_per_tile >= t256 ? 256 : avg_entries_per_tile >= t128 ? 128 : avg_entries_per_tile >= t64 ? 64
+            : avg_entries_per_tile >= t32 ? 32 : 16;
+    if (cap > 0)
+      while (L > 64 && (long long)ntasks * L / 64 > cap) L /= 2;
+    return L;
+  }
+  if (avg_entries_per_tile >= 400) return 256;
+  if (avg_entries_per_tile >= 160) return 128;
   if (avg_entries_per_tile >= 20) return 64;
   if (avg_entries_per_tile >= 8) return 32;
   return 16;
@@ -454,7 +479,7 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
     for (int i : hit_rows) hits[i].clear();
     for (int q : affected) bit[q] ^= 1;
     lv.ntasks = (int)P.tasks.size() - lv.task0;
-    lv.lanes = pick_lanes(lv.ntasks ? (double)seg_len_sum / lv.ntasks : 1.0);
+    lv.lanes = pick_lanes(lv.ntasks ? (double)seg_len_sum / lv.ntasks : 1.0, lv.ntasks);
     P.levels.push_back(lv);
   }
   P.nforward = nlev - 1;
@@ -546,7 +571,7 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
     }
     for (int s : by_level[t]) bit[s] ^= 1;
     lv.ntasks = (int)P.tasks.size() - lv.task0;
-    lv.lanes = pick_lanes(lv.ntasks ? (double)seg_len_sum / lv.ntasks : 1.0);
+    lv.lanes = pick_lanes(lv.ntasks ? (double)seg_len_sum / lv.ntasks : 1.0, lv.ntasks);
     P.levels.push_back(lv);
   }
   // ---- write the weights ----
@@ -600,6 +625,18 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
     for (const Piece &p : pc) cmax = std::max(cmax, p.c);
     std::fprintf(stderr, "[partinv] k %d pieces %d levels %d widest piece %d: piece inverses %.1f, schedule %.1f ms\n",
                  k, np, nlev, cmax, tms(T1, T2), tms(T2, tnow()));
+    for (size_t li = 0; li < P.levels.size(); ++li) {
+      const SpLevel &lv = P.levels[li];
+      long long w = 0, sg = 0;
+      for (int t = lv.task0; t < lv.task0 + lv.ntasks; ++t) {
+        const PTask &T = P.tasks[(size_t)t];
+        for (int q = T.seg0; q < T.seg0 + T.nseg; ++q) w += (long long)P.segs[(size_t)q].len * T.nrows;
+        sg += T.nseg;
+      }
+      std::fprintf(stderr, "[partinv]   level %2zu%s tiles %6d lanes %3d waves %6lld segments/tile %.2f weights %.2f MB\n", li,
+                   (int)li < P.nforward ? "f" : "b", lv.ntasks, lv.lanes, (long long)lv.ntasks * lv.lanes / 64,
+                   lv.ntasks ? (double)sg / lv.ntasks : 0.0, 8e-6 * (double)w);
+    }
   }
   // ---- hubs: U = A11^-1 a with the leading block of L, Sc = alpha - a^T U ----
   if (h > 0) {

@@ -28,10 +28,12 @@ struct PTask {  // a tile of nrows <= kSpTile consecutive output rows of one lev
   int carry;    // first old value to keep (same units) or -1
   int seg0, nseg;
   int nrows;
-  int len0, src0, idx0;  // copy of segment seg0 (when nseg > 0): saves the device one dependent load
-  long long w0;
-  long long pad;
+  int len0, src0, idx0;  // copies of the segments seg0 and seg0 + 1 (len = 0 when absent): tiles of up to two
+  long long w0;          // segments -- every tile of the backward sweep, most of the forward one -- need no
+  long long w1;          // dependent load of a segment record on the device
+  int len1, src1, idx1, pad;
 };
+static_assert(sizeof(PTask) == 64, "PTask is read as four 16-byte words");
 struct PSeg {       // row q of the tile:  sum_j w[q][j] * y[src + j]   or   sum_j w[q][j] * y[idx[j]]
   long long w;      // offset into the weight array (even => 16-byte aligned); layout [entry j][row q], len even
   int src;          // >= 0: contiguous run starting here (in unknowns); < 0: indexed through idx

@@ -1,6 +1,8 @@
 // Device side of the sparse preconditioner (sparse_precond.h): uploads the partitioned inverse and replays its
 // level schedule, one gather kernel per level.
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 
 #include "device_problem.h"
 
@@ -222,6 +224,146 @@ __global__ __launch_bounds__(kBlock) void k_sp_level(int r, const PTask *__restr
   }
 }
 
+// Second form of the level kernel: one lane per gathered ENTRY instead of one lane per (entry, value).  A lane reads the
+// RT weights of its entry once (32 distinct bytes per lane -- in the form above the r lanes of an entry read the same 32
+// bytes, and the address unit pays for every lane) and the entry's r vector values, and keeps RT x r running sums; a
+// tile of 1000 entries is 4 steps per lane on 256 lanes (20 above), so every load of a tile is in flight at once.  Sums
+// over the lanes of a tile: four DPP steps inside each 16-lane row, the row sums through LDS, added in a fixed order.
+__device__ __forceinline__ double sp_row16_sum(double v) {
+  v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_move<0x141>(v);  // row_half_mirror
+  v += dpp_move<0x140>(v);  // row_mirror
+  return v;
+}
+template <int LANES, int R>
+__global__ __launch_bounds__(kBlock) void k_sp_level2(const PTask *__restrict__ tasks, int ntasks,
+                                                      const PSeg *__restrict__ segs, const double *__restrict__ vals,
+                                                      const int *__restrict__ idxs, double *__restrict__ y, Gate g) {
+  if (sp_gated(g.ctl, g.seq, g.gate)) return;
+  constexpr int RT = kSpTile, r = R;
+  constexpr int TPB = kBlock / LANES;                 // tiles per workgroup
+  constexpr int NROW = (LANES + 15) / 16;             // 16-lane rows per tile
+  constexpr int NE = (RT * R + LANES - 1) / LANES;    // output elements per lane
+  constexpr int UN = LANES >= 128 ? 4 : 2;            // steps in flight per lane
+  __shared__ double s_part[TPB][RT * R][NROW];
+  const int tid = threadIdx.x;
+  const int lane = tid & (LANES - 1), tile = tid / LANES;
+  const int task = blockIdx.x * TPB + tile;
+  const bool active = task < ntasks;
+  PTask T;
+  T.out = 0; T.carry = -1; T.seg0 = 0; T.nseg = 0; T.nrows = 0;
+  T.len0 = 0; T.src0 = 0; T.idx0 = 0; T.w0 = 0;
+  T.len1 = 0; T.src1 = 0; T.idx1 = 0; T.w1 = 0;
+  if (active) T = tasks[task];
+  const int nrows = T.nrows, ne = nrows * r;
+  double cv[NE];
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int e = lane + i * LANES;
+    cv[i] = (T.carry >= 0 && e < ne) ? y[(size_t)T.carry * r + e] : 0.0;
+  }
+  double acc[RT][R];
+#pragma unroll
+  for (int q = 0; q < RT; ++q)
+#pragma unroll
+    for (int t = 0; t < R; ++t) acc[q][t] = 0;
+  for (int s = T.seg0; s < T.seg0 + T.nseg; ++s) {
+    PSeg S;
+    if (s == T.seg0) {  // the first two segments came with the task record
+      S.w = T.w0;
+      S.src = T.src0;
+      S.idx = T.idx0;
+      S.len = T.len0;
+    } else if (s == T.seg0 + 1) {
+      S.w = T.w1;
+      S.src = T.src1;
+      S.idx = T.idx1;
+      S.len = T.len1;
+    } else {
+      S = segs[s];
+    }
+    const double *__restrict__ w = vals + S.w;
+    const int *__restrict__ ix = idxs + S.idx;
+    const bool direct = S.src >= 0;
+    if (nrows == RT) {
+#pragma unroll UN
+      for (int j = lane; j < S.len; j += LANES) {
+        const size_t pos = direct ? (size_t)(S.src + j) : (size_t)ix[j];
+        const double *__restrict__ ys = y + pos * r;
+        double yv[R];
+#pragma unroll
+        for (int t = 0; t < R; ++t) yv[t] = ys[t];
+        const double2 a0 = *reinterpret_cast<const double2 *>(w + (size_t)j * RT);
+        const double2 a1 = *reinterpret_cast<const double2 *>(w + (size_t)j * RT + 2);
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+          acc[0][t] += a0.x * yv[t];
+          acc[1][t] += a0.y * yv[t];
+          acc[2][t] += a1.x * yv[t];
+          acc[3][t] += a1.y * yv[t];
+        }
+      }
+    } else {
+#pragma unroll 2
+      for (int j = lane; j < S.len; j += LANES) {
+        const size_t pos = direct ? (size_t)(S.src + j) : (size_t)ix[j];
+        const double *__restrict__ ys = y + pos * r;
+        const double *__restrict__ wa = w + (size_t)j * nrows;
+        double yv[R];
+#pragma unroll
+        for (int t = 0; t < R; ++t) yv[t] = ys[t];
+#pragma unroll
+        for (int q = 0; q < RT; ++q)
+          if (q < nrows) {
+            const double a = wa[q];
+#pragma unroll
+            for (int t = 0; t < R; ++t) acc[q][t] += a * yv[t];
+          }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < RT; ++q)
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+      const double v = sp_row16_sum(acc[q][t]);
+      if ((lane & 15) == 0) s_part[tile][q * R + t][lane >> 4] = v;
+    }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int e = lane + i * LANES;
+    if (e < ne) {
+      double v = cv[i];
+#pragma unroll
+      for (int u = 0; u < NROW; ++u) v += s_part[tile][e][u];
+      y[(size_t)T.out * r + e] = v;
+    }
+  }
+}
+
+template <int LANES>
+bool launch_level2(hipStream_t st, int r, int grid, const PTask *tp, int ntasks, const PSeg *segs, const double *vals,
+                   const int *idxs, double *y, Gate g) {
+  switch (r) {
+#define DCORA_SP_CASE(RR)                                                                                              \
+  case RR:                                                                                                             \
+    hipLaunchKernelGGL((k_sp_level2<LANES, RR>), dim3(grid), dim3(kBlock), 0, st, tp, ntasks, segs, vals, idxs, y, g); \
+    return true;
+    DCORA_SP_CASE(2)
+    DCORA_SP_CASE(3)
+    DCORA_SP_CASE(4)
+    DCORA_SP_CASE(5)
+    DCORA_SP_CASE(6)
+    DCORA_SP_CASE(7)
+    DCORA_SP_CASE(8)
+#undef DCORA_SP_CASE
+    default:
+      return false;
+  }
+}
+
 void launch_level(hipStream_t st, int r, const SpLevel &lv, const PTask *tasks, const PSeg *segs, const double *vals,
                   const int *idxs, double *y, Gate g) {
   const int lanes = lv.lanes;
@@ -229,9 +371,27 @@ void launch_level(hipStream_t st, int r, const SpLevel &lv, const PTask *tasks, 
   const int grid = (int)((threads + kBlock - 1) / kBlock);
   if (grid == 0) return;
   const PTask *tp = tasks + lv.task0;
+  static const bool v1 = [] {
+    const char *e = std::getenv("DCORA_SP_KERNEL");
+    return e && std::strcmp(e, "v1") == 0;
+  }();
+  if (!v1) {
+    bool done = false;
+    switch (lanes) {
+      case 256: done = launch_level2<256>(st, r, grid, tp, lv.ntasks, segs, vals, idxs, y, g); break;
+      case 128: done = launch_level2<128>(st, r, grid, tp, lv.ntasks, segs, vals, idxs, y, g); break;
+      case 64: done = launch_level2<64>(st, r, grid, tp, lv.ntasks, segs, vals, idxs, y, g); break;
+      case 32: done = launch_level2<32>(st, r, grid, tp, lv.ntasks, segs, vals, idxs, y, g); break;
+      default: done = launch_level2<16>(st, r, grid, tp, lv.ntasks, segs, vals, idxs, y, g); break;
+    }
+    if (done) return;
+  }
   switch (lanes) {
     case 256:
       hipLaunchKernelGGL((k_sp_level<256>), dim3(grid), dim3(kBlock), 0, st, r, tp, lv.ntasks, segs, vals, idxs, y, g);
+      break;
+    case 128:
+      hipLaunchKernelGGL((k_sp_level<128>), dim3(grid), dim3(kBlock), 0, st, r, tp, lv.ntasks, segs, vals, idxs, y, g);
       break;
     case 64:
       hipLaunchKernelGGL((k_sp_level<64>), dim3(grid), dim3(kBlock), 0, st, r, tp, lv.ntasks, segs, vals, idxs, y, g);
@@ -367,7 +527,7 @@ SpFold SparsePrecond::fold_generic() const {
 double SparsePrecond::bytes_per_apply(int r) const {
   // stored weights once, the task / segment tables, the vector in and out of every row tile, permutes, hub terms
   const SpImage &I = *im;
-  return 8.0 * I.weights_per_apply + 48.0 * I.ntasks_total + 24.0 * I.nsegs_total + 16.0 * r * I.rows_total +
+  return 8.0 * I.weights_per_apply + 64.0 * I.ntasks_total + 24.0 * I.nsegs_total + 16.0 * r * I.rows_total +
          32.0 * r * (double)I.k + 12.0 * I.hub_nnz + 8.0 * (double)I.nhub * I.k;
 }
 
