@@ -79,20 +79,8 @@ void parallel_for(int n, int nthreads, int chunk, F body) {
 constexpr int kBigPiece = 384;  // pieces this wide are inverted by all threads together (the merged top of the tree)
 
 int pick_lanes(double avg_entries_per_tile, int ntasks) {
-  // experiment (DCORA_SP_LANES="t256,t128,t64,t32,cap"): lanes per tile from the entries a tile gathers; cap > 0: no more
-  // than cap waves per level as long as a smaller tile exists
-  static const char *e = std::getenv("DCORA_SP_LANES");
-  if (e) {
-    int t256 = 400, t128 = 160, t64 = 20, t32 = 8, cap = 0;
-    std::sscanf(e, "%d,%d,%d,%d,%d", &t256, &t128, &t64, &t32, &cap);
-    int L = avg_entries_per_tile >= t256 ? 256 : avg_entries_per_tile >= t128 ? 128 : avg_entries_per_tile >= t64 ? 64
-            : avg_entries_per_tile >= t32 ? 32 : 16;
-    if (cap > 0)
-      while (L > 64 && (long long)ntasks * L / 64 > cap) L /= 2;
-    return L;
-  }
-  if (avg_entries_per_tile >= 400) return 256;
-  if (avg_entries_per_tile >= 160) return 128;
+  (void)ntasks;
+  if (avg_entries_per_tile >= 160) return 256;
   if (avg_entries_per_tile >= 20) return 64;
   if (avg_entries_per_tile >= 8) return 32;
   return 16;
@@ -479,7 +467,8 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
     for (int i : hit_rows) hits[i].clear();
     for (int q : affected) bit[q] ^= 1;
     lv.ntasks = (int)P.tasks.size() - lv.task0;
-    lv.lanes = pick_lanes(lv.ntasks ? (double)seg_len_sum / lv.ntasks : 1.0, lv.ntasks);
+    lv.avg_entries = lv.ntasks ? (double)seg_len_sum / lv.ntasks : 1.0;
+    lv.lanes = pick_lanes(lv.avg_entries, lv.ntasks);
     P.levels.push_back(lv);
   }
   P.nforward = nlev - 1;
@@ -571,7 +560,8 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
     }
     for (int s : by_level[t]) bit[s] ^= 1;
     lv.ntasks = (int)P.tasks.size() - lv.task0;
-    lv.lanes = pick_lanes(lv.ntasks ? (double)seg_len_sum / lv.ntasks : 1.0, lv.ntasks);
+    lv.avg_entries = lv.ntasks ? (double)seg_len_sum / lv.ntasks : 1.0;
+    lv.lanes = pick_lanes(lv.avg_entries, lv.ntasks);
     P.levels.push_back(lv);
   }
   // ---- write the weights ----

@@ -42,7 +42,8 @@ struct PSeg {       // row q of the tile:  sum_j w[q][j] * y[src + j]   or   sum
   int pad;
 };
 struct SpLevel {
-  int task0 = 0, ntasks = 0, lanes = 8;  // lanes per task (8, 16, 32 or 64)
+  int task0 = 0, ntasks = 0, lanes = 8;  // lanes per task of the first kernel form (16, 32, 64, 128 or 256)
+  double avg_entries = 0;                // vector entries a tile gathers, on average (the launch picks the lanes from it)
 };
 
 // host image of the partitioned inverse: built by build_partitioned_inverse, uploaded by SparsePrecond

@@ -1,6 +1,7 @@
 // Device side of the sparse preconditioner (sparse_precond.h): uploads the partitioned inverse and replays its
 // level schedule, one gather kernel per level.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -249,7 +250,8 @@ __global__ __launch_bounds__(kBlock) void k_sp_level2(const PTask *__restrict__ 
   __shared__ double s_part[TPB][RT * R][NROW];
   const int tid = threadIdx.x;
   const int lane = tid & (LANES - 1), tile = tid / LANES;
-  const int task = blockIdx.x * TPB + tile;
+  // a tile of 64+ lanes is the same for the whole wave: its record is read through the scalar cache into SGPRs
+  const int task = LANES >= 64 ? __builtin_amdgcn_readfirstlane(blockIdx.x * TPB + tile) : blockIdx.x * TPB + tile;
   const bool active = task < ntasks;
   PTask T;
   T.out = 0; T.carry = -1; T.seg0 = 0; T.nseg = 0; T.nrows = 0;
@@ -364,18 +366,36 @@ bool launch_level2(hipStream_t st, int r, int grid, const PTask *tp, int ntasks,
   }
 }
 
+// lanes per tile of the second kernel form, from the entries a tile gathers and the rank: a lane takes one entry per step
+// and ends with a reduction of RT r sums, so short tiles want narrow tiles (several per wave) the more the larger r is.
+// Measured (us per application, lattice agent r = 5 / sphere2500 r = 5 / tiers r = 2): 64 lanes from 20 entries and 32
+// from 8: 145.4 / 30.8 / 50.3; from 100 and 30: 140.1 / 30.9 / 58.4; from 140 and 40: 139.7 / 32.8 / 61.5.
+// DCORA_SP_LANES = "t256,t128,t64,t32" overrides the thresholds (measurements).
+int sp_pick_lanes(double avg, int r) {
+  static const int *ov = [] {
+    static int t[4];
+    const char *e = std::getenv("DCORA_SP_LANES");
+    if (!e || std::sscanf(e, "%d,%d,%d,%d", &t[0], &t[1], &t[2], &t[3]) != 4) return (const int *)nullptr;
+    return (const int *)t;
+  }();
+  const int t256 = ov ? ov[0] : 400, t128 = ov ? ov[1] : 160, t64 = ov ? ov[2] : (r >= 4 ? 100 : 20),
+            t32 = ov ? ov[3] : (r >= 4 ? 30 : 8);
+  return avg >= t256 ? 256 : avg >= t128 ? 128 : avg >= t64 ? 64 : avg >= t32 ? 32 : 16;
+}
+
 void launch_level(hipStream_t st, int r, const SpLevel &lv, const PTask *tasks, const PSeg *segs, const double *vals,
                   const int *idxs, double *y, Gate g) {
-  const int lanes = lv.lanes;
-  const long threads = (long)lv.ntasks * lanes;
-  const int grid = (int)((threads + kBlock - 1) / kBlock);
-  if (grid == 0) return;
-  const PTask *tp = tasks + lv.task0;
   static const bool v1 = [] {
     const char *e = std::getenv("DCORA_SP_KERNEL");
     return e && std::strcmp(e, "v1") == 0;
   }();
-  if (!v1) {
+  const bool form2 = !v1 && r >= 2 && r <= 8;
+  const int lanes = form2 ? sp_pick_lanes(lv.avg_entries, r) : lv.lanes;
+  const long threads = (long)lv.ntasks * lanes;
+  const int grid = (int)((threads + kBlock - 1) / kBlock);
+  if (grid == 0) return;
+  const PTask *tp = tasks + lv.task0;
+  if (form2) {
     bool done = false;
     switch (lanes) {
       case 256: done = launch_level2<256>(st, r, grid, tp, lv.ntasks, segs, vals, idxs, y, g); break;
