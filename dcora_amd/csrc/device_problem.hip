@@ -993,14 +993,33 @@ int DeviceProblem::time_precond(int reps, double *avg_ms, double *bytes) {
                            nullptr, 0, p2.p, ctl.p, hf_dev, 1, 0, 1);
   };
   for (int i = 0; i < 3; ++i) run();
+  // DCORA_TIME_PRECOND_GRAPH=1: the same launches captured once in a hipGraph and replayed (measurement of what the
+  // stream's per-launch dispatch costs next to the kernels themselves)
+  static const bool as_graph = std::getenv("DCORA_TIME_PRECOND_GRAPH") != nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t gexec = nullptr;
+  if (as_graph) {
+    DCORA_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    run();
+    DCORA_HIP(hipStreamEndCapture(st, &graph));
+    DCORA_HIP(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
+    for (int i = 0; i < 3; ++i) DCORA_HIP(hipGraphLaunch(gexec, st));
+  }
   DCORA_HIP(hipEventRecord(e0, st));
-  for (int i = 0; i < reps; ++i) run();
+  for (int i = 0; i < reps; ++i) {
+    if (as_graph)
+      DCORA_HIP(hipGraphLaunch(gexec, st));
+    else
+      run();
+  }
   DCORA_HIP(hipEventRecord(e1, st));
   DCORA_HIP(hipEventSynchronize(e1));
   float ms = 0;
   DCORA_HIP(hipEventElapsedTime(&ms, e0, e1));
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
+  if (gexec) (void)hipGraphExecDestroy(gexec);
+  if (graph) (void)hipGraphDestroy(graph);
   *avg_ms = (double)ms / reps;
   // algorithmic bytes: the k x k inverse once, the residual in, the split-K slices out
   // algorithmic bytes, dense form: the k x k inverse once; split form: + the residual in and the split-K slices out;
