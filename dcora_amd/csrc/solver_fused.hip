@@ -13,6 +13,7 @@
 #include <type_traits>
 #include <vector>
 #include <cstdlib>
+#include <cstring>
 
 #include "kernels.h"
 
@@ -1598,6 +1599,126 @@ __global__ __launch_bounds__(kBlock) void k_spmm_bsr(int r, BsrDev A, Buf2 Xb, i
   }
 }
 
+// Second form of the block Q-apply: no LDS.  The 8 lanes of a pose read the block themselves -- lane t loads row t & 3
+// of the (d+1)^2 block (32 bytes; the two quads of a pose load the same 128 bytes, which the address unit merges) -- and
+// every lane gets the rows it does not hold by DPP quad broadcasts (VALU, per SIMD) instead of 16 broadcast reads of LDS
+// per block (one LDS pipe per CU: 717 MB per launch on the 100k lattice).  No staging pass, no barrier.  The column
+// indices of up to 8 blocks of a pose come with one load and are handed round with ds_bpermute.  Same summation order
+// as k_spmm_bsr: bitwise the same result (tools/cmp_bsr.py).  Measured on the 100k lattice, warm / cold us:
+// k_spmm_bsr 27.4 / 33.9; this form with 2 / 3 / 4 blocks gathered together 26.6 / 35.6, 24.8 / 33.1, 26.6 / 34.2;
+// with the rows of the next batch and G requested one step ahead (software pipeline, 114 instead of 80 VGPRs)
+// 26.9 / 33.3 (3 blocks), 27.0 / 32.6 (2 blocks): the cold figure does not move with the kernel's structure.
+constexpr int kBsrGather2 = 3;
+template <int A_>
+__device__ __forceinline__ double quad_bcast(double v) {
+  return dpp_move<A_ * 0x55>(v);  // quad_perm [A, A, A, A]
+}
+template <int D, bool DOTS>
+__global__ __launch_bounds__(kBlock) void k_spmm_bsr2(int r, BsrDev A, Buf2 Xb, int selX,
+                                                      const double *__restrict__ G, Buf2 Yb, int selY,
+                                                      double *__restrict__ partials, Gate g) {
+  if (g.ctl && g.gate && f_gated(g.ctl, g.seq, g.gate)) return;
+  constexpr int DH = D + 1, BS = DH * DH;
+  __shared__ double s_red[16];
+  const int cur = g.ctl ? (g.ctl->cur & 1) : 0;
+  const double *__restrict__ X = Xb.p[g.ctl ? ((cur ^ selX) & 1) : 0];
+  double *__restrict__ Y = Yb.p[g.ctl ? ((cur ^ selY) & 1) : 0];
+  const int t = threadIdx.x & (GW - 1);
+  const int rowq = min(t & 3, DH - 1);  // the block row this lane holds
+  double d0 = 0, d1 = 0;
+  const int range_lo = (int)((long)A.nbrows * blockIdx.x / gridDim.x);
+  const int range_hi = (int)((long)A.nbrows * (blockIdx.x + 1) / gridDim.x);
+  const int npass = max(1, (range_hi - range_lo + kPosesPerBlock - 1) / kPosesPerBlock);
+  const int per_pass = (range_hi - range_lo + npass - 1) / npass;
+  for (int pose0 = range_lo; pose0 < range_hi; pose0 += per_pass) {
+    const int pend_pose = min(range_hi, pose0 + per_pass);
+    const int pose = pose0 + (threadIdx.x >> 3);
+    const bool inr = pose < pend_pose;
+    const bool active = inr && (t < r);
+    const int myb = inr ? A.bp[pose] : 0, mye = inr ? A.bp[pose + 1] : 0;
+    double acc[DH];
+#pragma unroll
+    for (int a = 0; a < DH; ++a) acc[a] = 0;
+    for (int b0 = myb; b0 < mye; b0 += GW) {
+      const int nb = min(GW, mye - b0);
+      const int mybc = (t < nb) ? A.bc[b0 + t] : 0;
+      for (int q0 = 0; q0 < nb; q0 += kBsrGather2) {
+        double x[kBsrGather2][DH], brow[kBsrGather2][DH];
+#pragma unroll
+        for (int q = 0; q < kBsrGather2; ++q) {
+          const bool ok = q0 + q < nb;
+          const int qc = ok ? q0 + q : q0;
+          const int col = __shfl(mybc, qc, GW);
+          const size_t o = (size_t)col * DH * r + t;
+#pragma unroll
+          for (int c = 0; c < DH; ++c) x[q][c] = (ok && active) ? X[o + c * r] : 0.0;
+          const double *__restrict__ bp_ = A.bv + (size_t)(b0 + qc) * BS + rowq * DH;
+          if (DH == 4) {
+            const double2 u0 = *reinterpret_cast<const double2 *>(bp_);
+            const double2 u1 = *reinterpret_cast<const double2 *>(bp_ + 2);
+            brow[q][0] = u0.x;
+            brow[q][1] = u0.y;
+            brow[q][2] = u1.x;
+            brow[q][DH - 1] = u1.y;
+          } else {
+#pragma unroll
+            for (int c = 0; c < DH; ++c) brow[q][c] = bp_[c];
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < kBsrGather2; ++q) {
+          {
+            double s = 0;
+#pragma unroll
+            for (int c = 0; c < DH; ++c) s += quad_bcast<0>(brow[q][c]) * x[q][c];
+            acc[0] += s;
+          }
+          {
+            double s = 0;
+#pragma unroll
+            for (int c = 0; c < DH; ++c) s += quad_bcast<1>(brow[q][c]) * x[q][c];
+            acc[1] += s;
+          }
+          {
+            double s = 0;
+#pragma unroll
+            for (int c = 0; c < DH; ++c) s += quad_bcast<2>(brow[q][c]) * x[q][c];
+            acc[2] += s;
+          }
+          if (DH == 4) {
+            double s = 0;
+#pragma unroll
+            for (int c = 0; c < DH; ++c) s += quad_bcast<3>(brow[q][c]) * x[q][c];
+            acc[DH - 1] += s;
+          }
+        }
+      }
+    }
+    if (active) {
+      const size_t o = (size_t)pose * DH * r + t;
+#pragma unroll
+      for (int a = 0; a < DH; ++a) {
+        double y = acc[a];
+        if (DOTS) {
+          const double x = X[o + a * r];
+          d0 += acc[a] * x;
+          if (G) d1 += x * G[o + a * r];
+        }
+        if (G) y += G[o + a * r];
+        Y[o + a * r] = y;
+      }
+    }
+  }
+  if (DOTS) {
+    const double a = f_block_sum(d0, s_red);
+    const double b = f_block_sum(d1, s_red);
+    if (threadIdx.x == 0) {
+      partials[2 * blockIdx.x] = a;
+      partials[2 * blockIdx.x + 1] = b;
+    }
+  }
+}
+
 int group_grid(int n) {
   long g = ((long)n + kPosesPerBlock - 1) / kPosesPerBlock;
   if (g < 1) g = 1;
@@ -1715,6 +1836,21 @@ int spmm_bsr_grid(int nbrows) {
 void launch_spmm_bsr(hipStream_t st, int r, int d, const BsrDev &A, Buf2 X, int selX, const double *G, Buf2 Y,
                      int selY, double *partials, Gate g) {
   const int grid = spmm_bsr_grid(A.nbrows);
+  static const bool v1 = [] {  // DCORA_BSR_KERNEL=v1: the LDS-staged form (A/B measurements, tests of both forms)
+    const char *e = std::getenv("DCORA_BSR_KERNEL");
+    return e && std::strcmp(e, "v1") == 0;
+  }();
+  if (!v1) {
+    if (d == 3 && partials)
+      hipLaunchKernelGGL((k_spmm_bsr2<3, true>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials, g);
+    else if (d == 3)
+      hipLaunchKernelGGL((k_spmm_bsr2<3, false>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials, g);
+    else if (partials)
+      hipLaunchKernelGGL((k_spmm_bsr2<2, true>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials, g);
+    else
+      hipLaunchKernelGGL((k_spmm_bsr2<2, false>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials, g);
+    return;
+  }
   if (d == 3) {
     if (partials)
       hipLaunchKernelGGL((k_spmm_bsr<3, true>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials, g);
