@@ -1608,6 +1608,10 @@ __global__ __launch_bounds__(kBlock) void k_spmm_bsr(int r, BsrDev A, Buf2 Xb, i
 // k_spmm_bsr 27.4 / 33.9; this form with 2 / 3 / 4 blocks gathered together 26.6 / 35.6, 24.8 / 33.1, 26.6 / 34.2;
 // with the rows of the next batch and G requested one step ahead (software pipeline, 114 instead of 80 VGPRs)
 // 26.9 / 33.3 (3 blocks), 27.0 / 32.6 (2 blocks): the cold figure does not move with the kernel's structure.
+// Every off-diagonal block stored once and read across by its mirror (Q is symmetric; 60 -> 37 MB of matrix, transposed
+// reads as four strided 8-byte loads, one more index per block): 29.0 / 36.2 -- and 28.8 / 38.3 with the same load code
+// on the unshared storage: the kernel is bound by the NUMBER of load instructions (each touches 8 poses' lines), about
+// 1.6 us per instruction and block step, not by the bytes; 16-byte loads of the block rows are what the 24.8 us rest on.
 constexpr int kBsrGather2 = 3;
 template <int A_>
 __device__ __forceinline__ double quad_bcast(double v) {
