@@ -1612,6 +1612,9 @@ __global__ __launch_bounds__(kBlock) void k_spmm_bsr(int r, BsrDev A, Buf2 Xb, i
 // reads as four strided 8-byte loads, one more index per block): 29.0 / 36.2 -- and 28.8 / 38.3 with the same load code
 // on the unshared storage: the kernel is bound by the NUMBER of load instructions (each touches 8 poses' lines), about
 // 1.6 us per instruction and block step, not by the bytes; 16-byte loads of the block rows are what the 24.8 us rest on.
+// r lanes per pose instead of 8 (12 poses per wave at r = 5, a third fewer load instructions), the block rows handed
+// round with ds_bpermute because pose groups no longer align with DPP quads: 36 us warm -- 32 ds_bpermute per block cost
+// far more than the 32 DPP moves they replace.
 constexpr int kBsrGather2 = 3;
 template <int A_>
 __device__ __forceinline__ double quad_bcast(double v) {
