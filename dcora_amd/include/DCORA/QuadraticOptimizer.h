@@ -24,6 +24,8 @@ class QuadraticOptimizer {
     result_.tCGStatus = r.tCGStatus;
     return out;
   }
+  // ref include/DCORA/QuadraticOptimizer.h:52: the optimizer outlives the problems it is pointed at (one per update)
+  void setProblem(QuadraticProblem *p) { problem_ = p; }
   void setVerbose(bool v) { params_.verbose = v; }
   void setAlgorithm(ROptParameters::ROptMethod alg) { params_.method = alg; }
   void setRGDStepsize(double s) { params_.RGD_stepsize = s; }

@@ -82,5 +82,15 @@ int main() {
   const bool psd = DCORA::fastVerification(S, 1e-3, &theta, &v, d + 1);
   std::printf("rounding err %.3e, certificate PSD %d\n", std::sqrt(e2), (int)psd);
   ok = ok && std::sqrt(e2) < 1e-6 && psd;
+  // setProblem (ref include/DCORA/QuadraticOptimizer.h:52): the same optimizer pointed at a second problem object on
+  // the same data gives the same answer
+  DCORA::QuadraticProblem problem2(pd);
+  optimizer.setProblem(&problem2);
+  const DCORA::Matrix Topt2 = optimizer.optimize(T);
+  double e3 = 0;
+  for (int c = 0; c < 4 * n; ++c)
+    for (int i = 0; i < r; ++i) e3 += std::pow(Topt2(i, c) - Topt(i, c), 2);
+  std::printf("setProblem: difference %.3e\n", std::sqrt(e3));
+  ok = ok && e3 == 0.0;
   return ok ? 0 : 1;
 }
