@@ -1614,7 +1614,9 @@ __global__ __launch_bounds__(kBlock) void k_spmm_bsr(int r, BsrDev A, Buf2 Xb, i
 // 1.6 us per instruction and block step, not by the bytes; 16-byte loads of the block rows are what the 24.8 us rest on.
 // r lanes per pose instead of 8 (12 poses per wave at r = 5, a third fewer load instructions), the block rows handed
 // round with ds_bpermute because pose groups no longer align with DPP quads: 36 us warm -- 32 ds_bpermute per block cost
-// far more than the 32 DPP moves they replace.
+// far more than the 32 DPP moves they replace.  The neighbour's block gathered by two 16-byte loads per lane (row
+// pairs of one column, redistributed inside the quad by DPP broadcasts and selects) instead of d + 1 loads of 8 bytes:
+// 30.4 us warm -- at odd r the 16-byte loads are not 16-byte aligned, and 32 more DPP moves and 16 selects per block.
 constexpr int kBsrGather2 = 3;
 template <int A_>
 __device__ __forceinline__ double quad_bcast(double v) {
