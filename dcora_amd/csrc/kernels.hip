@@ -673,14 +673,29 @@ __global__ __launch_bounds__(kBlock) void k_tangent(ManiDesc m, Buf2 Xb, const d
   // hub correction of k_sp_permute_out_hub; x2 = Sinv (R(hub) - a^T y1) is rebuilt by every workgroup
   const bool folded = sf.y != nullptr;
   if (folded && sf.h > 0) {
+    // two steps with all slice loads of a step in flight together (same summation order as the one-loop form: every
+    // w(q2, t) is R minus its slices in slice order, every x2(q, t) the sum over q2 in order)
+    __shared__ double s_w[64 * 16];
+    for (int e = threadIdx.x; e < sf.h * r; e += kBlock) {
+      const int q2 = e / r, t = e - q2 * r;
+      double w = R[(size_t)sf.hub_idx[q2] * r + t];
+      const double *__restrict__ hw = sf.hub_w + (size_t)q2 * sf.hub_split * r + t;
+      int sl = 0;
+      for (; sl + 8 <= sf.hub_split; sl += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = hw[(size_t)(sl + u) * r];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w -= v[u];
+      }
+      for (; sl < sf.hub_split; ++sl) w -= hw[(size_t)sl * r];
+      s_w[e] = w;
+    }
+    __syncthreads();
     for (int e = threadIdx.x; e < sf.h * r; e += kBlock) {
       const int q = e / r, t = e - q * r;
       double s = 0;
-      for (int q2 = 0; q2 < sf.h; ++q2) {
-        double w = R[(size_t)sf.hub_idx[q2] * r + t];
-        for (int sl = 0; sl < sf.hub_split; ++sl) w -= sf.hub_w[((size_t)q2 * sf.hub_split + sl) * r + t];
-        s += sf.hub_Sinv[(size_t)q * sf.h + q2] * w;
-      }
+      for (int q2 = 0; q2 < sf.h; ++q2) s += sf.hub_Sinv[(size_t)q * sf.h + q2] * s_w[q2 * r + t];
       s_x2[e] = s;
     }
     __syncthreads();
