@@ -732,10 +732,10 @@ int factor_on_device(const HostCsr &A, int block, int top, int device, bool *pd,
       for (int s2 = 0; s2 < np; ++s2)
         if (S.pieces[s2].c >= kWide) {
           wide.push_back(s2);
-          if (S.pieces[s2].m == 0) {
-            moff[s2] = mtotal;
-            mtotal += (long long)S.pieces[s2].c * S.pieces[s2].c;
-          }
+          // L11^-T L11^-1 of every wide piece: the merged schedule (host_partinv2.cpp) applies the two triangular
+          // products of a piece as this one symmetric product
+          moff[s2] = mtotal;
+          mtotal += (long long)S.pieces[s2].c * S.pieces[s2].c;
         }
     DevBuf<double> yt, wbuf, tinv, mtop;
     if (!wide.empty()) {
@@ -765,8 +765,7 @@ int factor_on_device(const HostCsr &A, int block, int top, int device, bool *pd,
                              yt.p, wbuf.p);
         hipLaunchKernelGGL(k_piece_pack_inverted, dim3(std::min<long long>(4096, ((f * c) + 255) / 256)), dim3(256), 0,
                            st, c, m, yt.p, wbuf.p, packed.p + poff[s2]);
-        if (m == 0)
-          hipLaunchKernelGGL(k_dense_lauum, dim3(nbk * (nbk + 1) / 2), dim3(256), 0, st, c, yt.p, mtop.p + moff[s2], c);
+        hipLaunchKernelGGL(k_dense_lauum, dim3(nbk * (nbk + 1) / 2), dim3(256), 0, st, c, yt.p, mtop.p + moff[s2], c);
       }
       DCORA_HIP(hipGetLastError());
     }

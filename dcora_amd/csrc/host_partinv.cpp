@@ -10,71 +10,14 @@
 #include <numeric>
 #include <thread>
 
+#include "host_partinv_int.h"
 #include "sparse_precond.h"
 
 namespace dcora {
 
+using namespace partinv;
+
 namespace {
-
-struct Piece {
-  int c0 = 0, c = 0;          // columns [c0, c0 + c) in permuted numbering
-  std::vector<int> rows;      // rows of L below the piece, ascending
-  std::vector<int> src;       // where each of them sits in the factor's panel (row c + src)
-  int level = 0;
-  std::vector<double> Dinv;   // D^-1, c x c row-major (lower triangular)
-  std::vector<double> W;      // -B D^-1, m x c row-major
-};
-
-inline int pad2(int x) { return (x + 1) & ~1; }
-
-// the first segment travels inside the task record: one dependent load less on the device
-inline void inline_first_segment(PTask &T, const std::vector<PSeg> &segs) {
-  T.len0 = 0;
-  T.src0 = 0;
-  T.idx0 = 0;
-  T.w0 = 0;
-  T.len1 = 0;
-  T.src1 = 0;
-  T.idx1 = 0;
-  T.w1 = 0;
-  T.pad = 0;
-  if (T.nseg > 0) {
-    const PSeg &S = segs[(size_t)T.seg0];
-    T.len0 = S.len;
-    T.src0 = S.src;
-    T.idx0 = S.idx;
-    T.w0 = S.w;
-  }
-  if (T.nseg > 1) {
-    const PSeg &S = segs[(size_t)T.seg0 + 1];
-    T.len1 = S.len;
-    T.src1 = S.src;
-    T.idx1 = S.idx;
-    T.w1 = S.w;
-  }
-}
-
-// lanes per row tile, from the average number of vector entries a tile gathers: a step covers lanes / r of them;
-// aim for a handful of steps per lane so that the loads of a tile are all in flight together (the upper levels
-// have few tiles and are latency-bound otherwise)
-// body(i) for i in [0, n) on up to nthreads threads, dynamic chunks (setup-time helper)
-template <class F>
-void parallel_for(int n, int nthreads, int chunk, F body) {
-  nthreads = std::max(1, std::min(nthreads, (n + chunk - 1) / chunk));
-  std::atomic<int> next(0);
-  auto work = [&]() {
-    for (;;) {
-      const int i0 = next.fetch_add(chunk);
-      if (i0 >= n) break;
-      const int i1 = std::min(n, i0 + chunk);
-      for (int i = i0; i < i1; ++i) body(i);
-    }
-  };
-  std::vector<std::thread> th;
-  for (int t = 1; t < nthreads; ++t) th.emplace_back(work);
-  work();
-  for (auto &t : th) t.join();
-}
 
 constexpr int kBigPiece = 384;  // pieces this wide are inverted by all threads together (the merged top of the tree)
 
@@ -233,6 +176,16 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
   }
   int nlev = 0;
   for (const Piece &p : pc) nlev = std::max(nlev, p.level + 1);
+  if (const char *dump = std::getenv("DCORA_PARTINV_DUMP")) {  // structure only: c0 c level m rows...
+    if (FILE *fp = std::fopen(dump, "w")) {
+      for (const Piece &p : pc) {
+        std::fprintf(fp, "%d %d %d %d", p.c0, p.c, p.level, (int)p.rows.size());
+        for (int i : p.rows) std::fprintf(fp, " %d", i);
+        std::fprintf(fp, "\n");
+      }
+      std::fclose(fp);
+    }
+  }
   // ---- numeric part: D^-1 and W = -B D^-1 of every piece.  Wide pieces first, one at a time with all threads on the
   //      columns of the inverse (column k of D^-1 is an independent forward substitution); then the many small
   //      pieces in parallel, most expensive first ----
@@ -341,6 +294,21 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
     for (auto &t : th) t.join();
   }
   const auto T2 = tnow();
+  // ---- schedule: merged levels (host_partinv2.cpp) unless DCORA_SP_SCHEDULE=v1 asks for one launch per tree level ----
+  static const bool schedule_v1 = [] {
+    const char *e = std::getenv("DCORA_SP_SCHEDULE");
+    return e && std::strcmp(e, "v1") == 0;
+  }();
+  const bool merged = !schedule_v1;
+  if (merged) {
+    std::vector<const double *> Mgiven((size_t)np, nullptr);
+    for (int s = 0; s < np; ++s)
+      if (!F.pieces[s].Mtop.empty()) Mgiven[s] = F.pieces[s].Mtop.data();
+    layout_merged(pc, Mgiven, piece_of, k, nlev, nthreads, timing, &P);
+    if (timing)
+      std::fprintf(stderr, "[partinv] k %d pieces %d levels %d: piece inverses %.1f, merged schedule %.1f ms\n", k, np, nlev,
+                   tms(T1, T2), tms(T2, tnow()));
+  } else {
   // ---- schedule.  Which buffer holds a piece's current value is static; start: everything in buffer 0.
   // A task is a tile of up to kSpTile consecutive output rows that gather from the same sources; the weights of
   // a segment are stored entry-major over the tile's rows:  [entry j][row q]. ----
@@ -355,12 +323,6 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
   std::vector<double> &vals = P.vals;
   // The weights of a segment ([entry j][tile row q], j < len) are only RESERVED while the schedule is laid out; the
   // (by far larger) job of writing them -- 0.8 G doubles for the whole 100k lattice -- is done afterwards by all threads
-  struct Fill {
-    long long off;
-    const double *base;  // Dinv / W of a piece, or the symmetric top block
-    int kind, nrows, len, c, a0, m;
-    int loc[kSpTile];
-  };
   std::vector<Fill> fills;
   std::vector<std::vector<double>> top_blocks;  // D^-T D^-1 of the top pieces: alive until the fill
   long long cursor = 0;
@@ -565,47 +527,7 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
     P.levels.push_back(lv);
   }
   // ---- write the weights ----
-  vals.assign((size_t)cursor, 0.0);
-  parallel_for((int)fills.size(), nthreads, 64, [&](int fi) {
-    const Fill &f = fills[(size_t)fi];
-    double *w = vals.data() + f.off;
-    const int nr = f.nrows, c = f.c, a0 = f.a0;
-    switch (f.kind) {
-      case 0:  // forward, own rows: row a0 + q of D^-1
-        for (int q = 0; q < nr; ++q) {
-          const double *src = f.base + (size_t)(a0 + q) * c;
-          const int hi = std::min(std::min(f.len, c), a0 + q + 1);
-          for (int j = 0; j < hi; ++j) w[(size_t)j * nr + q] = src[j];
-        }
-        break;
-      case 1:  // forward, rows fed by a piece below: rows loc[q] of W
-        for (int q = 0; q < nr; ++q) {
-          const double *src = f.base + (size_t)f.loc[q] * c;
-          const int hi = std::min(f.len, c);
-          for (int j = 0; j < hi; ++j) w[(size_t)j * nr + q] = src[j];
-        }
-        break;
-      case 2:  // top level: rows a0 + q of D^-T D^-1
-        for (int q = 0; q < nr; ++q) {
-          const double *src = f.base + (size_t)(a0 + q) * c;
-          const int hi = std::min(f.len, c);
-          for (int j = 0; j < hi; ++j) w[(size_t)j * nr + q] = src[j];
-        }
-        break;
-      case 3:  // backward, own rows: (D^-T)(a0 + q, a0 + j) = Dinv(a0 + j, a0 + q), j >= q
-        for (int j = 0; j < f.len && a0 + j < c; ++j) {
-          const double *src = f.base + (size_t)(a0 + j) * c + a0;
-          for (int q = 0; q < nr && q <= j; ++q) w[(size_t)j * nr + q] = src[q];
-        }
-        break;
-      default:  // backward, rows below: W(j, a0 + q)
-        for (int j = 0; j < f.len && j < f.m; ++j) {
-          const double *src = f.base + (size_t)j * c + a0;
-          for (int q = 0; q < nr; ++q) w[(size_t)j * nr + q] = src[q];
-        }
-        break;
-    }
-  });
+  write_weights(fills, cursor, nthreads, &vals);
   top_blocks.clear();
   P.out_off.resize((size_t)k);
   for (int j = 0; j < k; ++j) P.out_off[j] = pos(bit[piece_of[j]], j);
@@ -628,6 +550,7 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
                    lv.ntasks ? (double)sg / lv.ntasks : 0.0, 8e-6 * (double)w);
     }
   }
+  }  // schedule v1
   // ---- hubs: U = A11^-1 a with the leading block of L, Sc = alpha - a^T U ----
   if (h > 0) {
     PartInvHub &H = P.hub;
@@ -689,9 +612,56 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
   }
   if (P.idxs.size() & 1) P.idxs.push_back(0);
   if (P.idxs.empty()) P.idxs.assign(2, 0);
-  if (vals.empty()) vals.assign(2, 0.0);
+  if (P.vals.empty()) P.vals.assign(2, 0.0);
   return true;
 }
+
+namespace partinv {
+void write_weights(const std::vector<Fill> &fills, long long total, int nthreads, std::vector<double> *vals_out) {
+  std::vector<double> &vals = *vals_out;
+  vals.assign((size_t)total, 0.0);
+  parallel_for((int)fills.size(), nthreads, 64, [&](int fi) {
+    const Fill &f = fills[(size_t)fi];
+    double *w = vals.data() + f.off;
+    const int nr = f.nrows, c = f.c, a0 = f.a0;
+    switch (f.kind) {
+      case 0:  // rows a0 + q of a lower-triangular matrix
+        for (int q = 0; q < nr; ++q) {
+          const double *src = f.base + (size_t)(a0 + q) * c;
+          const int hi = std::min(std::min(f.len, c), a0 + q + 1);
+          for (int j = 0; j < hi; ++j) w[(size_t)j * nr + q] = src[j];
+        }
+        break;
+      case 1:  // rows loc[q] of a matrix with c columns
+        for (int q = 0; q < nr; ++q) {
+          const double *src = f.base + (size_t)f.loc[q] * c;
+          const int hi = std::min(f.len, c);
+          for (int j = 0; j < hi; ++j) w[(size_t)j * nr + q] = src[j];
+        }
+        break;
+      case 2:  // rows a0 + q of a full c x c matrix
+        for (int q = 0; q < nr; ++q) {
+          const double *src = f.base + (size_t)(a0 + q) * c;
+          const int hi = std::min(f.len, c);
+          for (int j = 0; j < hi; ++j) w[(size_t)j * nr + q] = src[j];
+        }
+        break;
+      case 3:  // (D^-T)(a0 + q, a0 + j) = Dinv(a0 + j, a0 + q), j >= q
+        for (int j = 0; j < f.len && a0 + j < c; ++j) {
+          const double *src = f.base + (size_t)(a0 + j) * c + a0;
+          for (int q = 0; q < nr && q <= j; ++q) w[(size_t)j * nr + q] = src[q];
+        }
+        break;
+      default:  // transposed block: base(j, a0 + q)
+        for (int j = 0; j < f.len && j < f.m; ++j) {
+          const double *src = f.base + (size_t)j * c + a0;
+          for (int q = 0; q < nr; ++q) w[(size_t)j * nr + q] = src[q];
+        }
+        break;
+    }
+  });
+}
+}  // namespace partinv
 
 void partitioned_inverse_apply_host(const PartInvHost &P, int r, const double *R, double *Z) {
   const int k = P.k;

@@ -1,0 +1,92 @@
+// Shared between the two schedule builders of the partitioned inverse (host_partinv.cpp: one launch per tree level;
+// host_partinv2.cpp: merged levels).  Set-up time code, host only.
+#pragma once
+#include <algorithm>
+#include <atomic>
+#include <thread>
+#include <vector>
+
+#include "sparse_precond.h"
+
+namespace dcora {
+namespace partinv {
+
+struct Piece {
+  int c0 = 0, c = 0;          // columns [c0, c0 + c) in permuted numbering
+  std::vector<int> rows;      // rows of L below the piece, ascending
+  std::vector<int> src;       // where each of them sits in the factor's panel (row c + src)
+  int level = 0;
+  std::vector<double> Dinv;   // D^-1, c x c row-major (lower triangular)
+  std::vector<double> W;      // -B D^-1, m x c row-major
+};
+
+inline int pad2(int x) { return (x + 1) & ~1; }
+
+// the first two segments travel inside the task record: no dependent load of a segment record on the device
+inline void inline_first_segment(PTask &T, const std::vector<PSeg> &segs) {
+  T.len0 = 0;
+  T.src0 = 0;
+  T.idx0 = 0;
+  T.w0 = 0;
+  T.len1 = 0;
+  T.src1 = 0;
+  T.idx1 = 0;
+  T.w1 = 0;
+  T.pad = 0;
+  if (T.nseg > 0) {
+    const PSeg &S = segs[(size_t)T.seg0];
+    T.len0 = S.len;
+    T.src0 = S.src;
+    T.idx0 = S.idx;
+    T.w0 = S.w;
+  }
+  if (T.nseg > 1) {
+    const PSeg &S = segs[(size_t)T.seg0 + 1];
+    T.len1 = S.len;
+    T.src1 = S.src;
+    T.idx1 = S.idx;
+    T.w1 = S.w;
+  }
+}
+
+// body(i) for i in [0, n) on up to nthreads threads, dynamic chunks
+template <class F>
+void parallel_for(int n, int nthreads, int chunk, F body) {
+  nthreads = std::max(1, std::min(nthreads, (n + chunk - 1) / chunk));
+  std::atomic<int> next(0);
+  auto work = [&]() {
+    for (;;) {
+      const int i0 = next.fetch_add(chunk);
+      if (i0 >= n) break;
+      const int i1 = std::min(n, i0 + chunk);
+      for (int i = i0; i < i1; ++i) body(i);
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < nthreads; ++t) th.emplace_back(work);
+  work();
+  for (auto &t : th) t.join();
+}
+
+// The weights of a segment ([entry j][tile row q], j < len) are only RESERVED while a schedule is laid out; writing
+// them -- 0.8 G doubles for the whole 100k lattice -- is done afterwards by all threads.
+//   kind 0: rows a0 + q of a lower-triangular c x c matrix (entries up to the diagonal)
+//   kind 1: rows loc[q] of an (any) x c matrix
+//   kind 2: rows a0 + q of a full c x c matrix
+//   kind 3: transposed lower triangle: w[j][q] = base(a0 + j, a0 + q), j >= q
+//   kind 4: transposed block: w[j][q] = base(j, a0 + q), j < m
+struct Fill {
+  long long off;
+  const double *base;
+  int kind, nrows, len, c, a0, m;
+  int loc[kSpTile];
+};
+void write_weights(const std::vector<Fill> &fills, long long total, int nthreads, std::vector<double> *vals);
+
+// second schedule builder (host_partinv2.cpp).  pc: pieces with Dinv and W; Mgiven[s] (may be null): D^-T D^-1 of piece
+// s where the device delivered it.  Fills P->levels / tasks / segs / idxs / vals / out_off / weights_read_per_apply.
+void layout_merged(const std::vector<Piece> &pc, const std::vector<const double *> &Mgiven,
+                   const std::vector<int> &piece_of, int k, int nlev, int nthreads, bool timing, PartInvHost *P);
+
+}  // namespace partinv
+}  // namespace dcora

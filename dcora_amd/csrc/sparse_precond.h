@@ -44,6 +44,12 @@ struct PSeg {       // row q of the tile:  sum_j w[q][j] * y[src + j]   or   sum
 struct SpLevel {
   int task0 = 0, ntasks = 0, lanes = 8;  // lanes per task of the first kernel form (16, 32, 64, 128 or 256)
   double avg_entries = 0;                // vector entries a tile gathers, on average (the launch picks the lanes from it)
+  // Merged schedule (host_partinv2.cpp): the tasks of a launch gather anything from 8 to thousands of entries, so
+  // they are sorted by entries, longest first, and every tile gets the lanes its own length asks for: tasks
+  // [0, cls[g][0]) run on 256 lanes, [cls[g][0], cls[g][1]) on 128, then 64, 32, and the rest on 16; g = 0 for r >= 4,
+  // g = 1 for r < 4 (sp_pick_lanes' thresholds).
+  int multi = 0;
+  int cls[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 };
 
 // host image of the partitioned inverse: built by build_partitioned_inverse, uploaded by SparsePrecond
