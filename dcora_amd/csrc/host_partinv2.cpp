@@ -54,7 +54,9 @@ struct Source {        // what a piece contributes to the rows above it in one f
 // measured on launches of one tree level each, short bursts bound by their dependent loads; a merged launch streams
 // ~30 MB, and there the RT r sums a tile reduces over its lanes (14 of 129 us on an agent of the 100k lattice) weigh more
 // than the steps a lane walks.  Measured (us per application, agent of the 100k lattice, r = 5 / 7):
-// x1 129.5 / 156.8, x2 114.5 / 143.7, x3 132 / 141, x4 137.7 / 148.7, x8 171 / 180.
+// x1 129.5 / 156.8, x2 114.5 / 143.7, x3 132 / 141, x4 137.7 / 148.7, x8 171 / 180.  Tiles of 8 and 4 lanes for the
+// shortest lists, and lanes chosen as entries / steps for 3 .. 12 steps per lane, were measured as well: no gain
+// (119-186 us) -- fewer lanes mean fewer sums to reduce but longer dependent walks, and the walk costs more.
 int lanes_class(long entries, int regime) {
   static const double scale = [] {
     const char *e = std::getenv("DCORA_SP_CLS_SCALE");
@@ -516,7 +518,7 @@ void layout_merged(const std::vector<Piece> &pc, const std::vector<const double 
       const long e = -order[i].first;
       sum += e;
       for (int g2 = 0; g2 < 2; ++g2) {
-        const int cl = lanes_class(e, g2);
+        const int cl = lanes_class(e, g2);  // 0 .. 4: 256 .. 16 lanes per tile
         for (int cidx = 0; cidx < cl && cidx < 4; ++cidx) lv.cls[g2][cidx] = std::min(lv.cls[g2][cidx], (int)i);
       }
       P.tasks.push_back(Ln.tasks[(size_t)order[i].second]);

@@ -47,7 +47,7 @@ struct SpLevel {
   // Merged schedule (host_partinv2.cpp): the tasks of a launch gather anything from 8 to thousands of entries, so
   // they are sorted by entries, longest first, and every tile gets the lanes its own length asks for: tasks
   // [0, cls[g][0]) run on 256 lanes, [cls[g][0], cls[g][1]) on 128, then 64, 32, and the rest on 16; g = 0 for r >= 4,
-  // g = 1 for r < 4 (sp_pick_lanes' thresholds).
+  // g = 1 for r < 4.
   int multi = 0;
   int cls[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 };

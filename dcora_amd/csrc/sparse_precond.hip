@@ -238,7 +238,7 @@ __device__ __forceinline__ double sp_row16_sum(double v) {
   return v;
 }
 // first_task: the task of the workgroup's first tile; s_part: RT * R * 16 doubles of LDS
-template <int LANES, int R, int EXP = 0>
+template <int LANES, int R>
 __device__ __forceinline__ void sp_tiles(int first_task, const PTask *__restrict__ tasks, int ntasks,
                                          const PSeg *__restrict__ segs, const double *__restrict__ vals,
                                          const int *__restrict__ idxs, double *__restrict__ y,
@@ -246,7 +246,7 @@ __device__ __forceinline__ void sp_tiles(int first_task, const PTask *__restrict
   constexpr int RT = kSpTile, r = R;
   constexpr int NROW = (LANES + 15) / 16;             // 16-lane rows per tile
   constexpr int NE = (RT * R + LANES - 1) / LANES;    // output elements per lane
-  constexpr int UN = (LANES >= 128 || EXP == 8 || EXP == 9) ? 4 : 2;  // steps in flight per lane
+  constexpr int UN = LANES >= 128 ? 4 : 2;            // steps in flight per lane
   double(*s_part)[RT * R][NROW] = reinterpret_cast<double(*)[RT * R][NROW]>(s_part_raw);
   const int tid = threadIdx.x;
   const int lane = tid & (LANES - 1), tile = tid / LANES;
@@ -296,42 +296,10 @@ __device__ __forceinline__ void sp_tiles(int first_task, const PTask *__restrict
         const size_t pos = direct ? (size_t)(S.src + j) : (size_t)ix[j];
         const double *__restrict__ ys = y + pos * r;
         double yv[R];
-        if (EXP == 1 || EXP == 4 || EXP == 5) {  // timing experiments: no vector loads
 #pragma unroll
-          for (int t = 0; t < R; ++t) yv[t] = (double)(t + 1) + (double)pos;
-        } else if (EXP == 3) {  // aligned 16-byte loads covering the entry, values picked by the parity of its start
-          constexpr int NV = (R & 1) ? (R + 2) / 2 : R / 2;
-          const size_t e0 = (pos * r) & ~(size_t)1;
-          const bool odd = ((pos * r) & 1) != 0;
-          double2 v[NV];
-#pragma unroll
-          for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const double2 *>(y + e0 + 2 * i);
-#pragma unroll
-          for (int t = 0; t < R; ++t) {
-            const double lo = (t & 1) ? v[t / 2].y : v[t / 2].x;
-            const double hi = ((t + 1) & 1) ? v[(t + 1) / 2].y : v[(t + 1) / 2].x;
-            yv[t] = ((R & 1) && odd) ? hi : lo;
-          }
-        } else {
-#pragma unroll
-          for (int t = 0; t < R; ++t) yv[t] = ys[t];
-        }
-        double2 a0, a1;
-        if (EXP == 2 || EXP == 4 || EXP == 5) {
-          a0 = make_double2(1.0, 2.0);
-          a1 = make_double2(3.0, (double)j);
-        } else {
-          if (EXP == 7 || EXP == 9) {
-            typedef double d2v __attribute__((ext_vector_type(2)));
-            const d2v b0 = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(w + (size_t)j * RT));
-            const d2v b1 = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(w + (size_t)j * RT + 2));
-            a0 = make_double2(b0.x, b0.y);
-            a1 = make_double2(b1.x, b1.y);
-          } else {
-            a0 = *reinterpret_cast<const double2 *>(w + (size_t)j * RT);
-            a1 = *reinterpret_cast<const double2 *>(w + (size_t)j * RT + 2);
-          }
-        }
+        for (int t = 0; t < R; ++t) yv[t] = ys[t];
+        const double2 a0 = *reinterpret_cast<const double2 *>(w + (size_t)j * RT);
+        const double2 a1 = *reinterpret_cast<const double2 *>(w + (size_t)j * RT + 2);
 #pragma unroll
         for (int t = 0; t < R; ++t) {
           acc[0][t] += a0.x * yv[t];
@@ -363,7 +331,7 @@ __device__ __forceinline__ void sp_tiles(int first_task, const PTask *__restrict
   for (int q = 0; q < RT; ++q)
 #pragma unroll
     for (int t = 0; t < R; ++t) {
-      const double v = (EXP == 5 || EXP == 6) ? acc[q][t] : sp_row16_sum(acc[q][t]);
+      const double v = sp_row16_sum(acc[q][t]);
       if ((lane & 15) == 0) s_part[tile][q * R + t][lane >> 4] = v;
     }
   __syncthreads();
@@ -390,51 +358,34 @@ __global__ __launch_bounds__(kBlock) void k_sp_level2(const PTask *__restrict__ 
 // One launch of the merged schedule (host_partinv2.cpp): the tasks are sorted by the entries they gather and fall into
 // five classes of lanes per tile; the workgroups of a class are consecutive, so a workgroup learns its class from
 // blockIdx and the kernel arguments alone (no load in front of the task record).
+constexpr int kSpClasses = 5;  // 256, 128, 64, 32, 16 lanes per tile
 struct SpClasses {
-  int wg_end[5];    // workgroups [wg_end[c-1], wg_end[c]) run class c (256, 128, 64, 32, 16 lanes per tile)
-  int task_beg[5];  // first task of the class
-  int task_end[5];
+  int wg_end[kSpClasses];    // workgroups [wg_end[c-1], wg_end[c]) run class c
+  int task_beg[kSpClasses];  // first task of the class
+  int task_end[kSpClasses];
 };
-template <int R, int EXP = 0>
+template <int R>
 __global__ __launch_bounds__(kBlock) void k_sp_multi(const PTask *__restrict__ tasks, SpClasses C,
                                                      const PSeg *__restrict__ segs, const double *__restrict__ vals,
                                                      const int *__restrict__ idxs, double *__restrict__ y, Gate g) {
   __shared__ double s_part[kSpTile * R * 16];
   const int b = blockIdx.x;
   if (b < C.wg_end[0]) {
-    sp_tiles<256, R, EXP>(C.task_beg[0] + b, tasks, C.task_end[0], segs, vals, idxs, y, s_part, g);
+    sp_tiles<256, R>(C.task_beg[0] + b, tasks, C.task_end[0], segs, vals, idxs, y, s_part, g);
   } else if (b < C.wg_end[1]) {
-    sp_tiles<128, R, EXP>(C.task_beg[1] + (b - C.wg_end[0]) * 2, tasks, C.task_end[1], segs, vals, idxs, y, s_part, g);
+    sp_tiles<128, R>(C.task_beg[1] + (b - C.wg_end[0]) * 2, tasks, C.task_end[1], segs, vals, idxs, y, s_part, g);
   } else if (b < C.wg_end[2]) {
-    sp_tiles<64, R, EXP>(C.task_beg[2] + (b - C.wg_end[1]) * 4, tasks, C.task_end[2], segs, vals, idxs, y, s_part, g);
+    sp_tiles<64, R>(C.task_beg[2] + (b - C.wg_end[1]) * 4, tasks, C.task_end[2], segs, vals, idxs, y, s_part, g);
   } else if (b < C.wg_end[3]) {
-    sp_tiles<32, R, EXP>(C.task_beg[3] + (b - C.wg_end[2]) * 8, tasks, C.task_end[3], segs, vals, idxs, y, s_part, g);
+    sp_tiles<32, R>(C.task_beg[3] + (b - C.wg_end[2]) * 8, tasks, C.task_end[3], segs, vals, idxs, y, s_part, g);
   } else {
-    sp_tiles<16, R, EXP>(C.task_beg[4] + (b - C.wg_end[3]) * 16, tasks, C.task_end[4], segs, vals, idxs, y, s_part, g);
+    sp_tiles<16, R>(C.task_beg[4] + (b - C.wg_end[3]) * 16, tasks, C.task_end[4], segs, vals, idxs, y, s_part, g);
   }
 }
 
 template <int R>
 void launch_multi_r(hipStream_t st, int grid, const PTask *tp, const SpClasses &C, const PSeg *segs, const double *vals,
                     const int *idxs, double *y, Gate g) {
-  static const int exp = [] {
-    const char *e = std::getenv("DCORA_SP_EXP");
-    return e ? atoi(e) : 0;
-  }();
-  if (R == 5 || R == 7) {  // timing experiments (see sp_tiles)
-    switch (exp) {
-      case 1: hipLaunchKernelGGL((k_sp_multi<R, 1>), dim3(grid), dim3(kBlock), 0, st, tp, C, segs, vals, idxs, y, g); return;
-      case 2: hipLaunchKernelGGL((k_sp_multi<R, 2>), dim3(grid), dim3(kBlock), 0, st, tp, C, segs, vals, idxs, y, g); return;
-      case 3: hipLaunchKernelGGL((k_sp_multi<R, 3>), dim3(grid), dim3(kBlock), 0, st, tp, C, segs, vals, idxs, y, g); return;
-      case 4: hipLaunchKernelGGL((k_sp_multi<R, 4>), dim3(grid), dim3(kBlock), 0, st, tp, C, segs, vals, idxs, y, g); return;
-      case 5: hipLaunchKernelGGL((k_sp_multi<R, 5>), dim3(grid), dim3(kBlock), 0, st, tp, C, segs, vals, idxs, y, g); return;
-      case 6: hipLaunchKernelGGL((k_sp_multi<R, 6>), dim3(grid), dim3(kBlock), 0, st, tp, C, segs, vals, idxs, y, g); return;
-      case 7: hipLaunchKernelGGL((k_sp_multi<R, 7>), dim3(grid), dim3(kBlock), 0, st, tp, C, segs, vals, idxs, y, g); return;
-      case 8: hipLaunchKernelGGL((k_sp_multi<R, 8>), dim3(grid), dim3(kBlock), 0, st, tp, C, segs, vals, idxs, y, g); return;
-      case 9: hipLaunchKernelGGL((k_sp_multi<R, 9>), dim3(grid), dim3(kBlock), 0, st, tp, C, segs, vals, idxs, y, g); return;
-      default: break;
-    }
-  }
   hipLaunchKernelGGL((k_sp_multi<R>), dim3(grid), dim3(kBlock), 0, st, tp, C, segs, vals, idxs, y, g);
 }
 
@@ -444,8 +395,8 @@ bool launch_multi(hipStream_t st, int r, const SpLevel &lv, const PTask *tasks, 
   const int *cls = lv.cls[r >= 4 ? 0 : 1];
   SpClasses C;
   int beg = 0, wg = 0;
-  for (int c = 0; c < 5; ++c) {
-    const int end = c < 4 ? cls[c] : lv.ntasks;
+  for (int c = 0; c < kSpClasses; ++c) {
+    const int end = c < kSpClasses - 1 ? cls[c] : lv.ntasks;
     const int tpb = 1 << c;  // tiles per workgroup: 1, 2, 4, 8, 16
     C.task_beg[c] = beg;
     C.task_end[c] = end;
