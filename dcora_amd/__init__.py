@@ -455,7 +455,8 @@ def fast_verification(S, eta, block=1, device=0):
 
 
 def lambda_min_certified(S, eta, block=1, max_iterations=120):
-    """estimate (from above, converging) of lambda_min(S) after the certificate S + eta I >= 0 was accepted"""
+    """certified lower bound of lambda_min(S) after the certificate S + eta I >= 0 was accepted: the Lanczos estimate on
+    (S + eta I)^-1 minus its Ritz residual, verified by a Cholesky factorisation of S - bound I (-eta if that fails)"""
     lam, it = C.c_double(), C.c_int()
     check(capi.lib().dcora_cert_lambda_min_certified(S.n, S.rp, S.ci, S.v, eta, block, max_iterations, C.byref(lam),
                                                      C.byref(it)))
@@ -614,7 +615,7 @@ class Exchange:
         v = np.zeros(10)
         check(capi.lib().dcora_exchange_info(self.h, v))
         return dict(transport={1: "ipc peer stores", 2: "shared host segment"}.get(int(v[0]), "?"), mode=int(v[0]),
-                    halo_finegrained=bool(v[8]),
+                    halo_finegrained=bool(v[8]), wait="device (the scatter kernel polls the flag)" if v[9] else "host spin",
                     peers=int(v[1]), posts=int(v[2]), waits=int(v[3]), bytes_posted=float(v[4]), post_s=float(v[5]),
                     wait_s=float(v[6]), eval_wait_s=float(v[7]))
 

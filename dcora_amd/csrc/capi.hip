@@ -256,8 +256,12 @@ int dcora_problem_precond_info(dcora_problem_t p, double *info) {
   return DCORA_OK;
 }
 
-// smallest eigenvalue of a matrix the PSD test has accepted: Lanczos (full re-orthogonalisation) on M^-1, M = S + eta I,
-// through the sparse Cholesky factor the test computes (host); lambda_min(S) = 1 / theta_max(M^-1) - eta
+// A CERTIFIED lower bound of the smallest eigenvalue of a matrix the PSD test has accepted.  Lanczos (full
+// re-orthogonalisation) on M^-1, M = S + eta I, through the sparse Cholesky factor the test computes (host), gives a
+// Ritz value theta <= theta_max(M^-1) -- so 1 / theta - eta errs UPWARD and is only an estimate.  The candidate bound
+// 1 / (theta + |beta_m s_m|) - eta (Ritz residual added) is then VERIFIED the way the certificate itself is
+// (ref src/DCORA_utils.cpp:1737-1747): S - lambda I must have a Cholesky factorisation.  What is returned is the
+// verified shift; when the verification fails the only certified figure, -eta, is returned.
 namespace {
 // largest eigenvalue of the symmetric tridiagonal (a, b) of order m by bisection on the Sturm count
 double tridiag_largest(const std::vector<double> &a, const std::vector<double> &b, int m) {
@@ -307,7 +311,7 @@ int dcora_cert_lambda_min_certified(int k, const int *rp, const int *ci, const d
     n2 += q[i] * q[i];
   }
   for (double &t : q) t /= std::sqrt(n2);
-  double lam = 0, prev = 1e300;
+  double lam = 0, prev = 1e300, th_last = 0, bn_last = 0;
   int j = 0;
   for (; j < mmax; ++j) {
     V.push_back(q);
@@ -328,6 +332,8 @@ int dcora_cert_lambda_min_certified(int k, const int *rp, const int *ci, const d
     const bool check = (m % 5 == 0) || bn < 1e-14 * std::fabs(a) || j + 1 == mmax;
     if (check) {
       const double th = tridiag_largest(alpha, beta, m);
+      th_last = th;
+      bn_last = bn;
       lam = 1.0 / th - eta;
       if (std::fabs(prev - lam) <= 1e-3 * std::fabs(lam) + 1e-15 || bn < 1e-14 * std::fabs(a)) {
         ++j;
@@ -338,7 +344,37 @@ int dcora_cert_lambda_min_certified(int k, const int *rp, const int *ci, const d
     beta.push_back(bn);
     for (int i = 0; i < k; ++i) q[i] = w[i] / bn;
   }
-  *lambda_min = lam;
+  // Ritz residual |beta_m s_m|: s = eigenvector of the tridiagonal for th_last, by its three-term recurrence
+  double resid = 0;
+  {
+    const int m = (int)alpha.size();
+    std::vector<double> sv((size_t)m, 0.0);
+    sv[0] = 1.0;
+    double nrm = 1.0;
+    for (int i = 0; i + 1 < m; ++i) {
+      const double b = (i < (int)beta.size() && beta[i] != 0.0) ? beta[i] : 1e-300;
+      double t = (th_last - alpha[i]) * sv[i];
+      if (i > 0) t -= beta[i - 1] * sv[i - 1];
+      sv[i + 1] = t / b;
+      nrm += sv[i + 1] * sv[i + 1];
+      if (nrm > 1e200) {  // rescale
+        for (int u = 0; u <= i + 1; ++u) sv[u] *= 1e-100;
+        nrm *= 1e-200;
+      }
+    }
+    resid = std::fabs(bn_last * sv[m - 1]) / std::sqrt(nrm);
+  }
+  const double cand = 1.0 / (th_last + resid) - eta;
+  // verification: S - shift I factors  <=>  lambda_min(S) > shift (up to the rounding of the factorisation)
+  double shift = cand - 1e-3 * std::fabs(cand) - 1e-13;
+  if (!(shift > -eta)) shift = -eta;
+  double bound = -eta;
+  if (shift > -eta) {
+    SparseChol verify;
+    if (verify.factor(csr_shift_diag(S, -shift), block)) bound = shift;
+  }
+  (void)lam;
+  *lambda_min = bound;
   if (iterations) *iterations = j;
   return DCORA_OK;
   DCORA_CATCH
@@ -875,7 +911,7 @@ int dcora_exchange_info(dcora_exchange_t ex, double *info) {
   info[6] = e.wait_s;
   info[7] = e.eval_wait_s;
   info[8] = e.halo_is_finegrained() ? 1 : 0;
-  info[9] = 0;
+  info[9] = e.waits_on_device() ? 1 : 0;
   return DCORA_OK;
 }
 int dcora_exchange_post(dcora_exchange_t ex, const int *agents, int count) {
@@ -928,6 +964,13 @@ int dcora_exchange_host_selftest(const char *job_name, int rank, int world_size,
   DCORA_TRY
   Exchange e;
   return e.host_selftest(job_name, rank, world_size, num_agents, rounds, checksum);
+  DCORA_CATCH
+}
+int dcora_debug_exchange_leave_stale(const char *job_name, int world_size, int num_agents) {
+  if (!job_name) return bad("null");
+  DCORA_TRY
+  Exchange e;
+  return e.debug_leave_stale(job_name, world_size, num_agents);
   DCORA_CATCH
 }
 int dcora_exchange_barrier(dcora_exchange_t ex) {

@@ -753,8 +753,10 @@ bool DeviceProblem::use_pc() const {
     return !e ? 0 : (std::strcmp(e, "split") == 0 ? -1 : (std::strcmp(e, "pc") == 0 ? 1 : 0));
   }();
   if (sparse_precond || !has_precond) return false;
-  if (forced) return forced > 0;
-  return fused_pc_preferred(m, ldm);
+  if (forced < 0) return false;
+  if (!forced && !fused_pc_preferred(m, ldm)) return false;
+  // the one-launch form needs more dynamic LDS than the default limit; a device that refuses the attribute keeps B + C
+  return fused_pc_ready(m, ldm);
 }
 
 int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
@@ -827,8 +829,12 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
     // z0 = P(grad): B in "first" mode streams the preconditioner over grad, C projects and forms <z0, r0>
     int tcg_first_seq;
     if (pc) {
-      launch_fused_pc(st, m, ldm, Mi, RGb(), Xb(), nullptr, nullptr, eta.p, Heta.p, nullptr, rbuf[0], z.p, nullptr, 0,
-                      p3.p, c, hf_dev, ++seq, 0, 1);
+      if (launch_fused_pc(st, m, ldm, Mi, RGb(), Xb(), nullptr, nullptr, eta.p, Heta.p, nullptr, rbuf[0], z.p, nullptr,
+                          0, p3.p, c, hf_dev, ++seq, 0, 1) < 0) {
+        DCORA_HIP(hipStreamSynchronize(st));
+        set_last_error("k_fused_pc could not be launched on this device");
+        return DCORA_ERR_HIP;
+      }
       tcg_first_seq = seq;
     } else {
       launch_fused_precond(st, m, ldm, Mi, RGb(), nullptr, nullptr, eta.p, Heta.p, nullptr, rbuf[0], Zpart.p,

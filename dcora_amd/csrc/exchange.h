@@ -44,7 +44,7 @@ struct ShmHeader {
   uint64_t slot_doubles, total_bytes, x_doubles;
   std::atomic<uint32_t> bar_count, bar_gen;
   std::atomic<uint32_t> failed;  // a rank gave up: everybody waiting returns an error instead of spinning on
-  uint32_t pad;
+  int32_t creator_pid;           // rank 0's process: a segment whose creator is gone is a stale one (crashed job)
 };
 
 enum ExchangeMode { kExchangeIpc = 1, kExchangeStaged = 2 };
@@ -65,11 +65,14 @@ class Exchange {
   // host half of the protocol alone (bootstrap, barriers, flags, evaluation slots; host stores stand in for the
   // device's): runs without a GPU, for the world-size-2 CPU test
   int host_selftest(const char *job_name, int rank, int world, int R, int rounds, double *checksum);
+  // test hook: what a crashed job of this shape leaves behind under the name (initialised, creator gone)
+  int debug_leave_stale(const char *job_name, int world, int R);
 
   int mode = 0;
   int rank = 0, world = 1;
   bool halo_is_finegrained() const { return halo_finegrained_; }
   // statistics since creation (host wall time spent in post / wait / the evaluation all-gather, bytes posted)
+  bool waits_on_device() const { return device_wait_; }
   double post_s = 0, wait_s = 0, eval_wait_s = 0;
   long posts = 0, waits = 0, evals = 0;
   double bytes_posted = 0;
@@ -88,7 +91,11 @@ class Exchange {
   ShmEval *evals_ = nullptr;  // [parity][agent]
   double *staged_ = nullptr;  // [parity][agent][slot]
   double *xarea_ = nullptr;   // r x (d+1) n
-  size_t off_flags_ = 0, off_evals_ = 0, off_staged_ = 0, off_x_ = 0;
+  ShmFlag *consumed_ = nullptr;  // [consumer rank][agent]: the last post of the agent that rank has scattered
+  size_t off_flags_ = 0, off_evals_ = 0, off_staged_ = 0, off_x_ = 0, off_consumed_ = 0;
+  size_t devflag_off_ = 0;       // in a halo buffer, behind the slots and the self-test area: [parity][agent] x 64 bytes
+  bool device_wait_ = true;      // the scatter kernel polls the flag itself (no host hop between post and scatter)
+  DevBuf<unsigned> arrive2_;     // last-workgroup counters of the scatter kernels
   int R_ = 0;
   size_t slot_ = 0;                // doubles per agent slot
   DevBuf<double> halo_;            // [parity][agent][slot] + self-test area (fine-grained device memory)

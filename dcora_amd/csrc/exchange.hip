@@ -3,6 +3,7 @@
 
 #include <fcntl.h>
 #include <sched.h>
+#include <signal.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -32,7 +33,7 @@ struct PostDst {
 // workgroup that finishes last publishes the sequence number.  Every storing wave drains its stores and the
 // workgroup's lane 0 releases at system scope before it arrives (MI355X_MICROARCH.md, valid producer forms).
 __global__ __launch_bounds__(kBlock) void k_post_public(int r, int ncols, const int *__restrict__ src,
-                                                        const double *__restrict__ X, PostDst dst,
+                                                        const double *__restrict__ X, PostDst dst, PostDst dflag,
                                                         unsigned *arrive, volatile uint64_t *flag, uint64_t seq) {
   const long N = (long)ncols * r;
   for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < N; i += (long)gridDim.x * kBlock) {
@@ -49,7 +50,56 @@ __global__ __launch_bounds__(kBlock) void k_post_public(int r, int ncols, const 
       __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __threadfence_system();
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // the flag word next to each destination's slot (what that rank's scatter kernel polls), then the host-visible one
+      for (int q = 0; q < dflag.n; ++q)
+        __hip_atomic_store((uint64_t *)dflag.base[q], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       __hip_atomic_store((uint64_t *)flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// updateNeighborStates on the consumer's side, with the wait inside: lane 0 of every workgroup polls the flag word
+// (system-scope relaxed loads, s_sleep between polls; bounded -- a producer that never arrives raises `failed` and the
+// kernel ends), one system-scope acquire, then the slot is read with system-scope loads and scattered into the mirror of
+// X.  The workgroup that finishes last tells the producer that the slot has been read (back-pressure of post()).
+constexpr long long kWaitBudgetTicks = 20LL * 100000000LL;  // 20 s of the 100 MHz wall clock
+__global__ __launch_bounds__(kBlock) void k_wait_scatter(int r, int ncols, const int *__restrict__ cols,
+                                                         const double *src, double *__restrict__ X,
+                                                         const uint64_t *flag, uint64_t want, unsigned *arrive,
+                                                         uint64_t *consumed, uint32_t *failed) {
+  __shared__ int s_bad;
+  if (threadIdx.x == 0) {
+    int bad = 0;
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+      __builtin_amdgcn_s_sleep(16);
+      if (wall_clock64() - t0 > kWaitBudgetTicks ||
+          __hip_atomic_load(failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) {
+        bad = 1;
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_bad = bad;
+  }
+  __syncthreads();
+  if (s_bad) {
+    if (threadIdx.x == 0) __hip_atomic_store(failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
+  const long N = (long)ncols * r;
+  for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < N; i += (long)gridDim.x * kBlock) {
+    const int c = (int)(i / r), t = (int)(i - (long)c * r);
+    X[(size_t)cols[c] * r + t] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned prev = atomicAdd(arrive, 1u);
+    if (prev == gridDim.x - 1) {
+      __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(consumed, want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
@@ -77,6 +127,19 @@ __global__ void k_selftest_write(double *dst, int count, double base) {
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// host polling with back-off: a burst of pause instructions, then the core is handed over between polls (a rank per
+// core is not guaranteed: the four-ranks-on-one-GPU rehearsal runs on whatever cores the container has)
+inline void polite_spin(unsigned &spins) {
+  ++spins;
+  if (spins < 2048u) {
+    __builtin_ia32_pause();
+  } else if (spins < 8192u) {
+    sched_yield();
+  } else {
+    usleep(50);
+  }
+}
+
 }  // namespace
 
 int Exchange::fail(const std::string &msg, int code) {
@@ -100,58 +163,85 @@ Exchange::~Exchange() {
   if (rank == 0 && !name_.empty()) shm_unlink(name_.c_str());
 }
 
-// Rank 0 creates the segment and publishes the magic word last; the others attach once it is there.  The job name
-// must be unique per job on the node (a stale segment of a crashed job under the same name is removed by rank 0).
+// Rank 0 removes whatever carries the name, creates the segment and publishes the magic word last; the others attach
+// once it is there.  A rank that opened the name BEFORE rank 0 replaced it holds a stale segment (a crashed job, a reused
+// job name): it recognises that by the creator's process being gone or by the name resolving to another inode by now,
+// drops the mapping and opens the name again.  Two LIVE jobs under one name on one node remain a caller's error.
 int Exchange::open_segment(const char *job_name, size_t bytes) {
   name_ = std::string("/dcora_") + job_name;
-  int fd = -1;
   const auto t0 = Clock::now();
   if (rank == 0) {
     shm_unlink(name_.c_str());
-    fd = shm_open(name_.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+    const int fd = shm_open(name_.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
     if (fd < 0) return fail("shm_open(create " + name_ + ") failed: " + std::strerror(errno), DCORA_ERR_IO);
     if (ftruncate(fd, (off_t)bytes) != 0) {
       close(fd);
       return fail("ftruncate failed: " + std::string(std::strerror(errno)), DCORA_ERR_IO);
     }
-  } else {
-    for (;;) {
-      fd = shm_open(name_.c_str(), O_RDWR, 0600);
-      if (fd >= 0) {
-        struct stat sb;
-        if (fstat(fd, &sb) == 0 && (size_t)sb.st_size >= bytes) break;
-        close(fd);
-        fd = -1;
-      }
-      if (since(t0) > 120.0) return fail("segment " + name_ + " did not appear", DCORA_ERR_IO);
-      usleep(2000);
+    map_ = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (map_ == MAP_FAILED) {
+      map_ = nullptr;
+      return fail("mmap failed: " + std::string(std::strerror(errno)), DCORA_ERR_IO);
     }
-  }
-  map_ = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-  close(fd);
-  if (map_ == MAP_FAILED) {
-    map_ = nullptr;
-    return fail("mmap failed: " + std::string(std::strerror(errno)), DCORA_ERR_IO);
-  }
-  map_bytes_ = bytes;
-  hdr_ = (ShmHeader *)map_;
-  if (rank == 0) {
+    map_bytes_ = bytes;
+    hdr_ = (ShmHeader *)map_;
     std::memset(map_, 0, bytes);
     hdr_->world = (uint32_t)world;
     hdr_->R = (uint32_t)R_;
     hdr_->slot_doubles = slot_;
     hdr_->total_bytes = bytes;
+    hdr_->creator_pid = (int32_t)getpid();
     hdr_->magic.store(kShmMagic, std::memory_order_release);
-  } else {
-    while (hdr_->magic.load(std::memory_order_acquire) != kShmMagic) {
-      if (since(t0) > 120.0) return fail("segment " + name_ + " was never initialised", DCORA_ERR_IO);
-      usleep(1000);
-    }
-    if (hdr_->world != (uint32_t)world || hdr_->R != (uint32_t)R_ || hdr_->slot_doubles != slot_ ||
-        hdr_->total_bytes != bytes)
-      return fail("segment " + name_ + " belongs to a job of another shape (stale name?)", DCORA_ERR_BAD_ARG);
+    return DCORA_OK;
   }
-  return DCORA_OK;
+  for (;;) {
+    if (since(t0) > 120.0) return fail("segment " + name_ + " did not appear", DCORA_ERR_IO);
+    const int fd = shm_open(name_.c_str(), O_RDWR, 0600);
+    struct stat sb;
+    if (fd < 0 || fstat(fd, &sb) != 0 || (size_t)sb.st_size < bytes) {
+      if (fd >= 0) close(fd);
+      usleep(2000);
+      continue;
+    }
+    void *mp = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (mp == MAP_FAILED) return fail("mmap failed: " + std::string(std::strerror(errno)), DCORA_ERR_IO);
+    ShmHeader *h = (ShmHeader *)mp;
+    bool good = false;
+    const auto t1 = Clock::now();
+    while (since(t1) < 0.25) {  // a fresh segment is initialised within microseconds of its creation
+      if (h->magic.load(std::memory_order_acquire) == kShmMagic) {
+        good = true;
+        break;
+      }
+      usleep(500);
+    }
+    if (good) {
+      // still the segment the name stands for, and its creator is alive?
+      struct stat now;
+      const int fd2 = shm_open(name_.c_str(), O_RDONLY, 0600);
+      const bool same = fd2 >= 0 && fstat(fd2, &now) == 0 && now.st_ino == sb.st_ino && now.st_dev == sb.st_dev;
+      if (fd2 >= 0) close(fd2);
+      const bool alive = h->creator_pid > 0 && (kill((pid_t)h->creator_pid, 0) == 0 || errno == EPERM);
+      good = same && alive;
+    }
+    if (!good) {
+      munmap(mp, bytes);
+      usleep(2000);
+      continue;
+    }
+    if (h->world != (uint32_t)world || h->R != (uint32_t)R_ || h->slot_doubles != slot_ || h->total_bytes != bytes) {
+      h->failed.store(1);  // the job's other ranks give up as well instead of waiting for this one
+      munmap(mp, bytes);
+      return fail("segment " + name_ + " belongs to a job of another shape (a live job under the same name?)",
+                  DCORA_ERR_BAD_ARG);
+    }
+    map_ = mp;
+    map_bytes_ = bytes;
+    hdr_ = h;
+    return DCORA_OK;
+  }
 }
 
 // shared segment: header | per-rank records | flags [2][R] | evaluation slots [2][R] | staged poses [2][R][slot] | X
@@ -164,6 +254,8 @@ int Exchange::map_segment(const char *job_name, size_t x_doubles) {
   off += sizeof(ShmFlag) * 2 * R;
   off_evals_ = off;
   off += sizeof(ShmEval) * 2 * (R + world);  // R agent slots + one heartbeat slot per rank, double-buffered
+  off_consumed_ = off;
+  off += sizeof(ShmFlag) * (size_t)world * R;
   off = align_up(off, 4096);
   off_staged_ = off;
   off += sizeof(double) * 2 * R * slot_;
@@ -176,6 +268,7 @@ int Exchange::map_segment(const char *job_name, size_t x_doubles) {
   ranks_ = (ShmRank *)((char *)map_ + off_ranks);
   flags_ = (ShmFlag *)((char *)map_ + off_flags_);
   evals_ = (ShmEval *)((char *)map_ + off_evals_);
+  consumed_ = (ShmFlag *)((char *)map_ + off_consumed_);
   staged_ = (double *)((char *)map_ + off_staged_);
   xarea_ = (double *)((char *)map_ + off_x_);
   return DCORA_OK;
@@ -245,6 +338,12 @@ int Exchange::init(RbcdSession *s, const char *job_name) {
   }
   DCORA_HIP(arrive_.alloc(R));
   DCORA_HIP(hipMemset(arrive_.p, 0, sizeof(unsigned) * R));
+  DCORA_HIP(arrive2_.alloc(R));
+  DCORA_HIP(hipMemset(arrive2_.p, 0, sizeof(unsigned) * R));
+  {
+    const char *wm = std::getenv("DCORA_EXCHANGE_WAIT");  // host: the host spins on the flag, then enqueues the scatter
+    device_wait_ = !(wm && std::strcmp(wm, "host") == 0);
+  }
   DCORA_HIP(evalbuf_.alloc(2 * R));
   DCORA_HIP(hipMemset(evalbuf_.p, 0, sizeof(double) * 2 * R));
   DCORA_HIP(hosted_list_.alloc(std::max(1, n_hosted_)));
@@ -278,6 +377,8 @@ int Exchange::setup_ipc(bool attempt) {
   const int R = s_->R;
   const size_t test_off = 2 * (size_t)R * slot_;
   const int ntest = 64;
+  devflag_off_ = align_up(test_off + (size_t)ntest * world, 8);
+  const size_t halo_doubles = devflag_off_ + 2 * (size_t)R * 8;  // + one 64-byte flag word per (parity, agent)
   bool ok = attempt;
   std::string why;
   auto no = [&](const std::string &m) {
@@ -288,26 +389,26 @@ int Exchange::setup_ipc(bool attempt) {
   // memory (not cached incoherently in this GPU's L2), so that a slot re-used two posts later is never served stale;
   // plain hipMalloc if the runtime refuses (the self-test below still has to pass).
   if (ok) {
-    const size_t bytes = sizeof(double) * (test_off + (size_t)ntest * world);
+    const size_t bytes = sizeof(double) * halo_doubles;
     void *hp = nullptr;
     static const bool coarse = std::getenv("DCORA_EXCHANGE_COARSE") != nullptr;
     if (!coarse && hipExtMallocWithFlags(&hp, bytes, hipDeviceMallocFinegrained) == hipSuccess && hp) {
       halo_.p = (double *)hp;  // released with hipFree like any DevBuf
-      halo_.n = test_off + (size_t)ntest * world;
+      halo_.n = halo_doubles;
       halo_finegrained_ = true;
     } else {
       (void)hipGetLastError();
-      if (halo_.alloc(test_off + (size_t)ntest * world) != hipSuccess) no("hipMalloc of the halo buffer");
+      if (halo_.alloc(halo_doubles) != hipSuccess) no("hipMalloc of the halo buffer");
     }
   }
-  if (ok && hipMemset(halo_.p, 0, sizeof(double) * (test_off + (size_t)ntest * world)) != hipSuccess) no("hipMemset");
+  if (ok && hipMemset(halo_.p, 0, sizeof(double) * halo_doubles) != hipSuccess) no("hipMemset");
   if (ok && hipIpcGetMemHandle(&ranks_[rank].halo, halo_.p) != hipSuccess) {
     (void)hipGetLastError();
     if (halo_finegrained_) {  // a runtime that exports no handle for fine-grained memory: once more with plain hipMalloc
       halo_.release();
       halo_finegrained_ = false;
-      if (halo_.alloc(test_off + (size_t)ntest * world) != hipSuccess ||
-          hipMemset(halo_.p, 0, sizeof(double) * (test_off + (size_t)ntest * world)) != hipSuccess ||
+      if (halo_.alloc(halo_doubles) != hipSuccess ||
+          hipMemset(halo_.p, 0, sizeof(double) * halo_doubles) != hipSuccess ||
           hipIpcGetMemHandle(&ranks_[rank].halo, halo_.p) != hipSuccess)
         no("hipIpcGetMemHandle");
     } else {
@@ -386,9 +487,32 @@ int Exchange::post(const int *agents, int count) {
     AgentDev &ag = s_->agents[a];
     if (!ag.hosted || dests_[a].empty() || ag.public_poses.empty()) continue;
     const int parity = (int)(q & 1);
-    PostDst dst{};
+    // Back-pressure: the slot of this parity was last written by post q - 2; every rank that reads it must have
+    // scattered that post before it is overwritten (the evaluation's heartbeat used to be the only thing between a
+    // producer running ahead and a torn read: ticks of one set posted again and again, the per-phase C ABI).
+    if (q > 2) {
+      const auto b0 = Clock::now();
+      for (int p : dests_[a]) {
+        const ShmFlag *cf = consumed_ + (size_t)p * R + a;
+        unsigned spins = 0;
+        while (cf->seq + 2 < q) {
+          polite_spin(spins);
+          if ((spins & 1023u) == 0) {
+            if (hdr_->failed.load()) return fail("another rank failed", DCORA_ERR_HIP);
+            if (since(b0) > 120.0)
+              return fail("rank " + std::to_string(p) + " never read post " + std::to_string(q - 2) + " of agent " +
+                              std::to_string(a),
+                          DCORA_ERR_HIP);
+          }
+        }
+      }
+    }
+    PostDst dst{}, dflag{};
     if (mode == kExchangeIpc) {
-      for (int p : dests_[a]) dst.base[dst.n++] = peer_halo_[p] + halo_off(parity, a);
+      for (int p : dests_[a]) {
+        dst.base[dst.n++] = peer_halo_[p] + halo_off(parity, a);
+        dflag.base[dflag.n++] = peer_halo_[p] + devflag_off_ + ((size_t)parity * R + a) * 8;
+      }
     } else {
       dst.base[dst.n++] = (double *)(dev_map_ + off_staged_) + halo_off(parity, a);
     }
@@ -397,7 +521,7 @@ int Exchange::post(const int *agents, int count) {
     const int grid = (int)std::min<long>((N + kBlock - 1) / kBlock, 64);
     volatile uint64_t *flag = (volatile uint64_t *)(dev_map_ + off_flags_ + sizeof(ShmFlag) * ((size_t)parity * R + a));
     hipLaunchKernelGGL(k_post_public, dim3(grid), dim3(kBlock), 0, s_->st, r, ncols, ag.public_cols.p, s_->Xg.p, dst,
-                       arrive_.p + a, flag, q);
+                       dflag, arrive_.p + a, flag, q);
     bytes_posted += 8.0 * N * dst.n;
     ++posts;
   }
@@ -417,20 +541,33 @@ int Exchange::wait(const int *agents, int count) {
     const uint64_t want = seq_[a];
     const int parity = (int)(want & 1);
     const ShmFlag *f = flags_ + (size_t)parity * R + a;
-    unsigned spins = 0;
-    const auto w0 = Clock::now();
-    while (f->seq < want) {
-      if ((++spins & 4095u) == 0) {
-        if (hdr_->failed.load()) return fail("another rank failed", DCORA_ERR_HIP);
-        if (since(w0) > 120.0) return fail("public poses of agent " + std::to_string(a) + " never arrived", DCORA_ERR_HIP);
+    if (!device_wait_) {  // DCORA_EXCHANGE_WAIT=host: the host waits for the flag, the kernel below finds it set
+      unsigned spins = 0;
+      const auto w0 = Clock::now();
+      while (f->seq < want) {
+        polite_spin(spins);
+        if ((spins & 1023u) == 0) {
+          if (hdr_->failed.load()) return fail("another rank failed", DCORA_ERR_HIP);
+          if (since(w0) > 120.0)
+            return fail("public poses of agent " + std::to_string(a) + " never arrived", DCORA_ERR_HIP);
+        }
       }
+      std::atomic_thread_fence(std::memory_order_acquire);
     }
-    std::atomic_thread_fence(std::memory_order_acquire);
-    const double *src = (mode == kExchangeIpc) ? halo_.p + halo_off(parity, a)
-                                               : (const double *)(dev_map_ + off_staged_) + halo_off(parity, a);
+    const bool ipc = mode == kExchangeIpc;
+    const double *src = ipc ? halo_.p + halo_off(parity, a) : (const double *)(dev_map_ + off_staged_) + halo_off(parity, a);
+    // the flag the kernel polls: next to the slot in this rank's halo buffer (stored by the producer over xGMI), or the
+    // host-visible word when the poses are staged in the shared segment
+    const uint64_t *dflag = ipc ? (const uint64_t *)(halo_.p + devflag_off_ + ((size_t)parity * R + a) * 8)
+                                : (const uint64_t *)(dev_map_ + off_flags_ + sizeof(ShmFlag) * ((size_t)parity * R + a));
+    const int ncols = (int)s_->agents[a].public_poses.size() * dh;
+    const long N = (long)ncols * r;
+    const int grid = (int)std::min<long>((N + kBlock - 1) / kBlock, 32);
+    uint64_t *cons = (uint64_t *)(dev_map_ + off_consumed_ + sizeof(ShmFlag) * ((size_t)rank * R + a));
+    uint32_t *failed = (uint32_t *)(dev_map_ + offsetof(ShmHeader, failed));
     // updateNeighborStates: into the local mirror of X
-    launch_scatter_cols(s_->st, r, (int)s_->agents[a].public_poses.size() * dh, s_->agents[a].public_cols.p, src,
-                        s_->Xg.p);
+    hipLaunchKernelGGL(k_wait_scatter, dim3(grid), dim3(kBlock), 0, s_->st, r, ncols, s_->agents[a].public_cols.p, src,
+                       s_->Xg.p, dflag, want, arrive2_.p + a, cons, failed);
     ++waits;
   }
   wait_s += since(t0);
@@ -462,7 +599,8 @@ int Exchange::evaluate(double *cost2, double *gradnorm, double *block_norms, int
   for (int q = 0; q < world; ++q) {
     unsigned spins = 0;
     while (sl[R + q].seq < want) {
-      if ((++spins & 4095u) == 0) {
+      polite_spin(spins);
+      if ((spins & 1023u) == 0) {
         if (hdr_->failed.load()) return fail("another rank failed", DCORA_ERR_HIP);
         if (since(t0) > 120.0) return fail("rank " + std::to_string(q) + " never entered the evaluation", DCORA_ERR_HIP);
       }
@@ -473,7 +611,8 @@ int Exchange::evaluate(double *cost2, double *gradnorm, double *block_norms, int
   for (int a = 0; a < R; ++a) {
     unsigned spins = 0;
     while (sl[a].seq < want) {
-      if ((++spins & 4095u) == 0) {
+      polite_spin(spins);
+      if ((spins & 1023u) == 0) {
         if (hdr_->failed.load()) return fail("another rank failed", DCORA_ERR_HIP);
         if (since(t0) > 120.0) return fail("evaluation of agent " + std::to_string(a) + " never arrived", DCORA_ERR_HIP);
       }
@@ -554,6 +693,19 @@ int Exchange::gather_X(double *Xh) {
   if (rc) return rc;
   std::memcpy(Xh, xarea_, sizeof(double) * (size_t)r * dh * s_->n);
   return barrier();
+}
+
+int Exchange::debug_leave_stale(const char *job_name, int world_, int R) {
+  rank = 0;
+  world = world_;
+  R_ = R;
+  slot_ = 16;
+  const int rc = map_segment(job_name, 16);
+  if (rc) return rc;
+  hdr_->creator_pid = 0x7ffffff0;  // beyond any pid_max: nobody answers
+  hdr_->bar_count.store(1);        // and its barrier stands as the crash left it
+  name_.clear();                   // the destructor must not remove it
+  return DCORA_OK;
 }
 
 // The host half of the protocol on its own (no device): bootstrap through the segment, barriers, and `rounds` rounds

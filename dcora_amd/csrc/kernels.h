@@ -223,6 +223,7 @@ void launch_fused_precond(hipStream_t st, const ManiDesc &m, int ldm, const doub
 // B + C in one launch (dense preconditioner): returns the number of <z, r> partial slots written to p3
 int fused_pc_blocks(const ManiDesc &m);
 bool fused_pc_preferred(const ManiDesc &m, int ldm);  // sizes at which it beats B + C
+bool fused_pc_ready(const ManiDesc &m, int ldm);      // the current device grants the kernel its dynamic LDS
 int launch_fused_pc(hipStream_t st, const ManiDesc &m, int ldm, const double *Minv, Buf2 grad, Buf2 X,
                     const double *delta, const double *Hd, double *eta, double *Heta, const double *res_old,
                     double *res_new, double *z, const double *p1, int np1, double *p3, SolverCtl *ctl, HostFlags *hf,

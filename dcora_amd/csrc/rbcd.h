@@ -76,6 +76,7 @@ class RbcdSession {
   void advance_sequences();
   bool seq_advanced_ = false;
   int staged_selected_ = -1;  // agent whose Nesterov step rode in the non-selected agents' launch of this round
+  int staged_iteration_ = -1; // the round it was staged in: honoured by update_selected_agent in that round only
   bool own_stream_ = true;
   bool pending_reset_ = false;  // gamma = alpha = 0 after a restart round, applied when the next round begins
   std::vector<char> set_marks_;  // agents that received Agent::setX since the last round

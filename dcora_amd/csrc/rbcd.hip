@@ -222,6 +222,7 @@ int RbcdSession::init(const HostDataset &ds, const dcora_rbcd_options &o) {
 
 // Agent::setX + initializeAcceleration for every agent (ref src/Agent.cpp:64-77, 1178-1187)
 int RbcdSession::set_X(const double *Xh) {
+  staged_selected_ = -1;  // a step staged by an interrupted round does not survive a new start point
   DCORA_HIP(hipSetDevice(opt.device));
   const size_t B = sizeof(double) * (size_t)r * (d + 1) * n;
   DCORA_HIP(hipMemcpyAsync(Xg.p, Xh, B, hipMemcpyHostToDevice, st));
@@ -240,6 +241,7 @@ int RbcdSession::set_X(const double *Xh) {
 }
 // initializeAcceleration / acceleration off for every agent (ref src/Agent.cpp:1178-1187)
 int RbcdSession::set_acceleration(bool on) {
+  staged_selected_ = -1;
   DCORA_HIP(hipSetDevice(opt.device));
   opt.acceleration = on ? 1 : 0;
   const size_t B = sizeof(double) * (size_t)r * (d + 1) * n;
@@ -302,6 +304,7 @@ int RbcdSession::phase_nonselected(int selected) {
       launch_g_nesterov(st, mg, 0, restart, P.start(selected), P.end(selected), alpha, gamma, Xg.p, Vg.p, Yg.p, XPrevg.p,
                         nullptr, Buf2{{nullptr, nullptr}}, nullptr, agents[selected].prob->X0.p);
       staged_selected_ = selected;
+      staged_iteration_ = iteration;
     } else {
       nesterov(st, mg, 0, restart, P.start(selected), P.end(selected), alpha, gamma, Xg.p, Vg.p, Yg.p, XPrevg.p, nullptr,
                Buf2{{nullptr, nullptr}}, nullptr);
@@ -360,7 +363,8 @@ int RbcdSession::update_selected_agent(AgentDev &a, bool restart) {
     const SolverCtl *cs = nullptr;
     last_solver = &pb;
     if (opt.acceleration) {
-      if (staged_selected_ != a.id)  // (otherwise the non-selected agents' launch has taken this step already)
+      // (skipped only when the non-selected agents' launch of THIS round has taken the step already)
+      if (staged_selected_ != a.id || staged_iteration_ != iteration)
         nesterov(st, pb.m, 1, 0, -1, -1, alpha, gamma, Xg.p + off, Vg.p + off, Yg.p + off, XPrevg.p + off, pb.X0.p,
                  Buf2{{nullptr, nullptr}}, nullptr);
       staged_selected_ = -1;
@@ -402,6 +406,7 @@ int RbcdSession::update_selected_agent(AgentDev &a, bool restart) {
 // round (examples/MultiRobotExample.cpp:223-262): the first call of a round advances the shared gamma / alpha
 // sequences (identical for all agents, :1189-1200), a restart round zeroes them when the next round begins.
 int RbcdSession::agent_iterate(int agent, bool do_optimization) {
+  staged_selected_ = -1;  // the per-agent API never rides in a whole-graph launch
   if (agent < 0 || agent >= R) {
     set_last_error("rbcd: agent out of range");
     return DCORA_ERR_BAD_ARG;
@@ -462,6 +467,7 @@ int RbcdSession::agent_get_X(int agent, double *Xh) {
 
 // Agent::setX + initializeAcceleration (ref src/Agent.cpp:64-77, 1178-1187)
 int RbcdSession::agent_set_X(int agent, const double *Xh) {
+  staged_selected_ = -1;
   if (agent < 0 || agent >= R) {
     set_last_error("rbcd: agent out of range");
     return DCORA_ERR_BAD_ARG;
@@ -654,6 +660,7 @@ int RbcdSession::solve_block(AgentDev &a, std::string *err) {
 // ref src/Agent.cpp:650-678; non-accelerated like that mode, :651-653).  With a set of mutually non-adjacent
 // agents (one colour of agent_colours) the result equals updating them one after the other.
 int RbcdSession::iterate_set(const int *set, int count, int allow_adjacent) {
+  staged_selected_ = -1;
   if (opt.acceleration) {
     set_last_error("rbcd: simultaneous updates need acceleration off (ref src/Agent.cpp:651-653)");
     return DCORA_ERR_UNSUPPORTED;

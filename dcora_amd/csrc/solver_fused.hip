@@ -10,6 +10,7 @@
 // dependent launches instead of six.  Per-pose arithmetic uses 8 lanes per pose: lane t
 // of a group owns row t of the pose's r x (d+1) block, d x d Gram matrices are reduced with 3 xor-shuffles.
 #include <algorithm>
+#include <atomic>
 #include <type_traits>
 #include <vector>
 #include <cstdlib>
@@ -1957,28 +1958,40 @@ template <int D, int PB, int R, bool MULTI>
 static int pc_launch(hipStream_t st, const ManiDesc &m, int ldm, const double *Minv, Buf2 grad, Buf2 X,
                      const double *delta, const double *Hd, double *eta, double *Heta, const double *res_old,
                      double *res_new, double *z, const double *p1, int np1, double *p3, SolverCtl *ctl, HostFlags *hf,
-                     int seq, int iter, int first) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    attr_set = true;
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused_pc<D, PB, R, MULTI>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, kPcLdsCap) != hipSuccess)
-      (void)hipGetLastError();  // the launch below then fails loudly when the chunk needs more than the default
+                     int seq, int iter, int first, bool prepare_only) {
+  // The dynamic-LDS limit is an attribute of (function, DEVICE): it is set once per device the instantiation runs on
+  // (one bit per device; a process drives R GPUs from R host threads, SURVEY 8(b) threading).  -1 = this device refuses
+  // the attribute or the launch; use_pc() asks with st == nullptr before choosing the one-launch form.
+  static std::atomic<unsigned long long> tried{0}, ok{0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+  const unsigned long long bit = 1ull << dev;
+  if (!(tried.load(std::memory_order_acquire) & bit)) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused_pc<D, PB, R, MULTI>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, kPcLdsCap);
+    if (e == hipSuccess)
+      ok.fetch_or(bit, std::memory_order_release);
+    else
+      (void)hipGetLastError();
+    tried.fetch_or(bit, std::memory_order_release);
   }
   const int chk = pc_chunk(m, ldm);
+  const size_t lds = (size_t)chk * m.r * sizeof(double);
+  if (!(ok.load(std::memory_order_acquire) & bit) && lds > 64 * 1024) return -1;
   const int grid = (m.n + PB - 1) / PB;
-  hipLaunchKernelGGL((k_fused_pc<D, PB, R, MULTI>), dim3(grid), dim3(kPcBlock), (size_t)chk * m.r * sizeof(double), st,
-                     m, ldm, chk, Minv, grad, X, delta, Hd, eta, Heta, res_old, res_new, z, p1, np1, p3, ctl, hf, seq,
-                     iter, first);
+  if (prepare_only) return grid;
+  hipLaunchKernelGGL((k_fused_pc<D, PB, R, MULTI>), dim3(grid), dim3(kPcBlock), lds, st, m, ldm, chk, Minv, grad, X,
+                     delta, Hd, eta, Heta, res_old, res_new, z, p1, np1, p3, ctl, hf, seq, iter, first);
+  if (hipGetLastError() != hipSuccess) return -1;
   return grid;
 }
-int launch_fused_pc(hipStream_t st, const ManiDesc &m, int ldm, const double *Minv, Buf2 grad, Buf2 X,
-                    const double *delta, const double *Hd, double *eta, double *Heta, const double *res_old,
-                    double *res_new, double *z, const double *p1, int np1, double *p3, SolverCtl *ctl, HostFlags *hf,
-                    int seq, int iter, int first) {
+static int fused_pc_dispatch(hipStream_t st, const ManiDesc &m, int ldm, const double *Minv, Buf2 grad, Buf2 X,
+                             const double *delta, const double *Hd, double *eta, double *Heta, const double *res_old,
+                             double *res_new, double *z, const double *p1, int np1, double *p3, SolverCtl *ctl,
+                             HostFlags *hf, int seq, int iter, int first, bool prepare_only) {
 #define DCORA_PC(D_, PB_, R_, MULTI_)                                                                                \
   return pc_launch<D_, PB_, R_, MULTI_>(st, m, ldm, Minv, grad, X, delta, Hd, eta, Heta, res_old, res_new, z, p1, np1, \
-                                        p3, ctl, hf, seq, iter, first)
+                                        p3, ctl, hf, seq, iter, first, prepare_only)
 #define DCORA_PC_R(D_, PB_, MULTI_)             \
   do {                                          \
     if (D_ == 3 && m.r == 5) DCORA_PC(D_, PB_, 5, MULTI_); \
@@ -1998,6 +2011,18 @@ int launch_fused_pc(hipStream_t st, const ManiDesc &m, int ldm, const double *Mi
   DCORA_PC(2, 4, 0, true);
 #undef DCORA_PC_R
 #undef DCORA_PC
+}
+int launch_fused_pc(hipStream_t st, const ManiDesc &m, int ldm, const double *Minv, Buf2 grad, Buf2 X,
+                    const double *delta, const double *Hd, double *eta, double *Heta, const double *res_old,
+                    double *res_new, double *z, const double *p1, int np1, double *p3, SolverCtl *ctl, HostFlags *hf,
+                    int seq, int iter, int first) {
+  return fused_pc_dispatch(st, m, ldm, Minv, grad, X, delta, Hd, eta, Heta, res_old, res_new, z, p1, np1, p3, ctl, hf,
+                           seq, iter, first, false);
+}
+bool fused_pc_ready(const ManiDesc &m, int ldm) {
+  Buf2 none{};
+  return fused_pc_dispatch(nullptr, m, ldm, nullptr, none, none, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                           nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, true) >= 0;
 }
 void launch_fused_finish(hipStream_t st, const ManiDesc &m, Buf2 X, const double *Zpart, const double *res,
                          double *z, const double *p2, int np2, double *p3, SolverCtl *ctl, HostFlags *hf, int seq,

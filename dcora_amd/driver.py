@@ -52,7 +52,7 @@ def multi_robot_example(ds, X0, num_robots=5, r_min=5, r_max=100, max_iters=1000
                "certified": bool(psd), "theta": float(theta)}
         # bound on f(X) - f* implied by the certificate (this library's addition, include/dcora_hip.h)
         lev["suboptimality_gap_f"], lev["n_eff"] = suboptimality_gap(r, d, n, Xopt, psd, min_eig_tol, lmin)
-        if psd and refine_gap:  # the eigenvalue of the accepted certificate instead of the -eta the test guarantees
+        if psd and refine_gap:  # a verified lower bound of lambda_min(S) instead of the -eta the test guarantees
             tg = time.perf_counter()
             lam, _ = lambda_min_certified(S, min_eig_tol, block=d + 1)
             lev["lambda_min_S"] = lam

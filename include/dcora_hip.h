@@ -162,11 +162,14 @@ int dcora_cert_fast_verification(int k, const int *rowptr, const int *colidx, co
 int dcora_cert_suboptimality_gap(const dcora_dims *dims, const double *X, double lambda_lower_bound, double *gap,
                                  double *n_eff);
 /* The eta-test only says lambda_min(S) >= -eta, and eta n_eff can exceed the cost itself when the trajectory is large
- * (n_eff grows with the spread of the translations).  After an accepted certificate this returns an upper estimate
- * of lambda_min(S) that converges to it from above: Lanczos with full re-orthogonalisation on (S + eta I)^-1 (the
- * matrix the PSD test factorised; sparse Cholesky on the host) until the estimate changes by less than 0.1 % (at
- * most max_iterations solves).  DCORA_ERR_NOT_PD when S + eta I is not positive definite.  Also an addition of this
- * library.  lambda_lower_bound = min(lambda_min, 0) in dcora_cert_suboptimality_gap gives the estimate of the gap. */
+ * (n_eff grows with the spread of the translations).  After an accepted certificate this returns a CERTIFIED lower
+ * bound of lambda_min(S): Lanczos with full re-orthogonalisation on (S + eta I)^-1 (the matrix the PSD test
+ * factorised; sparse Cholesky on the host) until the Ritz value changes by less than 0.1 % (at most max_iterations
+ * solves) gives the candidate 1 / (theta + Ritz residual) - eta, which is lowered by 0.1 % and then VERIFIED like the
+ * certificate itself: S - lambda I must have a Cholesky factorisation.  The verified shift is returned; when the
+ * verification fails, -eta (what the accepted certificate guarantees by itself).  DCORA_ERR_NOT_PD when S + eta I is
+ * not positive definite.  An addition of this library.  lambda_lower_bound = min(lambda_min, 0) in
+ * dcora_cert_suboptimality_gap gives a certified gap. */
 int dcora_cert_lambda_min_certified(int k, const int *rowptr, const int *colidx, const double *vals, double eta,
                                     int block, int max_iterations, double *lambda_min, int *iterations);
 
@@ -321,10 +324,13 @@ int dcora_exchange_create(dcora_rbcd_t s, const char *job_name, dcora_exchange_t
 int dcora_exchange_destroy(dcora_exchange_t ex);
 /* info[10] = {transport (1 = IPC peer stores, 2 = shared host segment), ranks this rank stores to, posts, waits,
  * bytes posted so far, host seconds in post, host seconds in wait, host seconds waiting for the evaluation scalars,
- * 1 when this rank's halo buffer is fine-grained device memory (remote stores never served stale from the local L2), 0} */
+ * 1 when this rank's halo buffer is fine-grained device memory (remote stores never served stale from the local L2),
+ * 1 when the scatter kernel itself waits for the producer's flag (default; DCORA_EXCHANGE_WAIT=host: the host spins)} */
 int dcora_exchange_info(dcora_exchange_t ex, double *info10);
 /* getSharedStateDicts of `agents`: each hosted one is written to its neighbours' ranks and flagged (one kernel per
- * agent on the session's stream; returns without synchronising) */
+ * agent on the session's stream; returns without synchronising).  A slot is re-used two posts later: the call first
+ * waits until every reading rank has scattered that older post (an error after 120 s, never a torn read), so a post
+ * may run at most two ahead of the dcora_exchange_wait calls of its readers. */
 int dcora_exchange_post(dcora_exchange_t ex, const int *agents, int count);
 /* updateNeighborStates: waits until the posts of those of `agents` that neighbour an agent hosted here have
  * arrived and scatters them into the session's mirror of X (enqueued on the session's stream) */
@@ -351,6 +357,9 @@ int dcora_exchange_barrier(dcora_exchange_t ex);
  * job calls it, *checksum comes out identical on all of them.  For multi-process tests on machines without a GPU. */
 int dcora_exchange_host_selftest(const char *job_name, int rank, int world_size, int num_agents, int rounds,
                                  double *checksum);
+/* test hook: leaves under the job's name what a crashed job of the same shape would (an initialised segment whose
+ * creator is gone); a job started afterwards under that name must not attach to it */
+int dcora_debug_exchange_leave_stale(const char *job_name, int world_size, int num_agents);
 
 /* ------------------------------------------------------------------------- *
  * RBCD session for multi-robot range-aided SLAM (replaces the Agents on a RangeAidedSLAMGraph and the loop body of

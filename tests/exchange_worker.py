@@ -20,7 +20,9 @@ def main():
     ds = common.product_dataset(name)
     X0 = np.load(os.path.join(out_dir, "X0.npy"))
     accel = mode == "greedy"
-    s = da.RbcdSession(ds, num_robots=R, r=r, acceleration=accel, rank=rank, world_size=world, device=0)
+    # one GPU per rank where the box has them (peer access + cross-device IPC over xGMI); all ranks on device 0 otherwise
+    device = rank % max(da.device_count(), 1)
+    s = da.RbcdSession(ds, num_robots=R, r=r, acceleration=accel, rank=rank, world_size=world, device=device)
     ex = da.Exchange(s, job)
     ex.set_X(X0)
     cost, gn, sel = [], [], []
@@ -46,7 +48,8 @@ def main():
     ex.barrier()
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), cost=np.array(cost), gradnorm=np.array(gn),
              selected=np.array(sel), X=X, mode=info["mode"], posts=info["posts"], waits=info["waits"],
-             bytes_posted=info["bytes_posted"], peers=info["peers"], finegrained=info["halo_finegrained"])
+             bytes_posted=info["bytes_posted"], peers=info["peers"], finegrained=info["halo_finegrained"],
+             wait=info["wait"], device=device)
     ex.close()
     s.close()
 

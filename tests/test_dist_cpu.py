@@ -3,6 +3,7 @@ public-pose pack -> all_gather (pull) / broadcast (push) -> unpack, block-wise e
 replaced by a numpy model with the same interface whose local solve is the oracle, so the distributed result must
 equal the single-process oracle run bit-for-bit in its selection sequence."""
 import os
+import time
 import sys
 
 import numpy as np
@@ -270,3 +271,35 @@ def test_exchange_host_protocol_refuses_a_mismatched_job(built, tmp_path):
     assert rc != 0 and b"another shape" in capi.lib().dcora_last_error()
     p.join(90)
     assert p.exitcode is not None and p.exitcode != 0  # rank 0 sees the failure flag and gives up as well
+
+
+def _late_rank0(world, job, R, rounds, tmpdir, delay):
+    time.sleep(delay)
+    _selftest_rank(0, world, job, R, rounds, tmpdir)
+
+
+def test_exchange_bootstrap_does_not_attach_to_a_stale_segment(built, tmp_path):
+    """a crashed job left an initialised segment of the same shape under the name; the other ranks of a new job start
+    BEFORE rank 0 replaces it: they must recognise it as stale (its creator is gone, the name moves on) and attach to
+    the new one -- the round-2 bootstrap mapped the stale inode and every rank sat in the barrier until its time-out"""
+    import multiprocessing as mp
+    import uuid
+    from dcora_amd import capi
+    world, R, rounds = 3, 5, 20
+    job = "cpu%s" % uuid.uuid4().hex[:10]
+    assert capi.lib().dcora_debug_exchange_leave_stale(job.encode(), world, R) == 0
+    assert os.path.exists("/dev/shm/dcora_" + job)
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_selftest_rank, args=(k, world, job, R, rounds, str(tmp_path))) for k in (1, 2)]
+    for p in procs:
+        p.start()
+    late = ctx.Process(target=_late_rank0, args=(world, job, R, rounds, str(tmp_path), 1.0))
+    late.start()
+    for p in procs + [late]:
+        p.join(60)
+        assert p.exitcode == 0
+    want = sum((q + 0.5 * a) * (a + 1) + (0.25 * q - a) for q in range(1, rounds + 1) for a in range(R))
+    for k in range(world):
+        rc, cs = np.load(tmp_path / ("cs%d.npy" % k))
+        assert rc == 0 and abs(cs - want) <= 1e-9 * abs(want)
+    assert not os.path.exists("/dev/shm/dcora_" + job)

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 WORKER = os.path.join(common.HERE, "exchange_worker.py")
 
 
-def run_ranks(tmp_path, world, name, R, r, iters, mode, X0, transport=None):
+def run_ranks(tmp_path, world, name, R, r, iters, mode, X0, transport=None, wait=None):
     np.save(os.path.join(tmp_path, "X0.npy"), X0)
     job = "t%s" % uuid.uuid4().hex[:12]
     env = dict(os.environ)
@@ -27,6 +27,10 @@ def run_ranks(tmp_path, world, name, R, r, iters, mode, X0, transport=None):
         env["DCORA_EXCHANGE"] = transport
     else:
         env.pop("DCORA_EXCHANGE", None)
+    if wait:
+        env["DCORA_EXCHANGE_WAIT"] = wait
+    else:
+        env.pop("DCORA_EXCHANGE_WAIT", None)
     procs = [subprocess.Popen([sys.executable, WORKER, str(k), str(world), job, name, str(R), str(r), str(iters),
                                str(tmp_path), mode], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
              for k in range(world)]
@@ -66,25 +70,28 @@ def single(da, ds, R, r, iters, mode, X0):
 
 
 CASES = [
-    # dataset, agents, ranks, iterations, mode, transport
-    ("sphere2500", 5, 2, 40, "greedy", None),        # restart round (30) inside
-    ("sphere2500", 5, 4, 12, "greedy", "staged"),    # rank 3 hosts no agent; shared-host-segment transport
-    ("torus3D", 8, 4, 10, "greedy", None),           # BASELINE config 3's split, two agents per rank
-    ("torus3D", 8, 2, 4, "coloured", None),          # simultaneous updates of one colour, then post + wait
+    # dataset, agents, ranks, iterations, mode, transport, who waits for the producer's flag (default: the scatter kernel)
+    ("sphere2500", 5, 2, 40, "greedy", None, None),        # restart round (30) inside
+    ("sphere2500", 5, 4, 12, "greedy", "staged", None),    # rank 3 hosts no agent; shared-host-segment transport
+    ("torus3D", 8, 4, 10, "greedy", None, None),           # BASELINE config 3's split, two agents per rank
+    ("torus3D", 8, 2, 4, "coloured", None, None),          # simultaneous updates of one colour, then post + wait
+    ("sphere2500", 5, 2, 12, "greedy", None, "host"),      # DCORA_EXCHANGE_WAIT=host: the round-2 form of the wait
+    ("torus3D", 8, 4, 6, "greedy", "staged", "host"),
 ]
 
 
-@pytest.mark.parametrize("name,R,world,iters,mode,transport", CASES)
-def test_ranks_reproduce_single_session(tmp_path, name, R, world, iters, mode, transport):
+@pytest.mark.parametrize("name,R,world,iters,mode,transport,wait", CASES)
+def test_ranks_reproduce_single_session(tmp_path, name, R, world, iters, mode, transport, wait):
     import dcora_amd as da
     ds = common.product_dataset(name)
     r = 5
     X0 = common.random_point(r, ds.d, ds.n, 11, lambda r_, d_, n_, M: da.manifold_project(r_, d_, n_, M))
     cost, gn, sel, X = single(da, ds, R, r, iters, mode, X0)
-    res = run_ranks(str(tmp_path), world, name, R, r, iters, mode, X0, transport)
+    res = run_ranks(str(tmp_path), world, name, R, r, iters, mode, X0, transport, wait)
     want_mode = 2 if transport == "staged" else 1
     for k, o in enumerate(res):
         assert int(o["mode"]) == want_mode, "rank %d used transport %d" % (k, int(o["mode"]))
+        assert str(o["wait"]).startswith("host" if wait == "host" else "device"), str(o["wait"])
         if want_mode == 1:  # the halo buffers other ranks store into are fine-grained device memory
             assert bool(o["finegrained"]), "rank %d fell back to a coarse-grained halo buffer" % k
         assert np.array_equal(o["selected"], sel), (k, o["selected"], sel)

@@ -219,7 +219,9 @@ def test_chordal_start_to_certified_optimum_of_sphere2500(env):
     lam, its = da.lambda_min_certified(S, 1e-3, block=ds.d + 1)
     import scipy.sparse.linalg as sla
     w = sla.eigsh(S.to_scipy().tocsc(), k=1, sigma=-1e-3, which="LM", return_eigenvectors=False)[0]
-    assert lam >= w - 1e-9 and lam - w < 1e-2 * max(abs(w), 1e-6), (lam, w)
+    # a lower bound (verified by a factorisation of S - lam I), and a tight one
+    assert lam <= w + 1e-12 and w - lam < 2e-2 * max(abs(w), 1e-6), (lam, w)
+    assert lam > -1e-3
     gap2, _ = da.suboptimality_gap(r, ds.d, ds.n, X, psd, 1e-3, lambda_bound=min(lam, 0.0))
     assert gap2 < gap and 2 * gap2 < 0.05 * out["cost"][-1]
     # the oracle agrees on cost and certificate at the device's solution
