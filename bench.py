@@ -17,9 +17,12 @@ stores into IPC-mapped halo buffers over xGMI, flag words and the 2R evaluation 
 torch.distributed (backend nccl = RCCL) only brackets the timed region (barrier, MAX over ranks).
 
 Prints ONE JSON line on rank 0 (see the task contract) with two extra objects:
-  roofline     -- the dominant kernel of the timed loop (k_fused_precond) timed live with HIP events
+  roofline     -- the dominant kernel of the timed loop (k_fused_pc: step + vector updates + the dense preconditioner
+                  product + projection of a tCG iteration in one launch) timed live with HIP events
   cpu_baseline -- the CPU oracle (oracle/, a port of the reference algorithm) on the same iteration window of the
-                  same workload, 1 host thread (the reference ships single-threaded: OpenMP off)
+                  same workload, 1 host thread (the reference ships single-threaded: OpenMP off); r_threads: the same
+                  with one host thread per agent (what the reference's asynchronous mode starts)
+`value` is the MEDIAN of REPLAYS replays of the driver's window (value_samples lists them).
 """
 import argparse
 import json
@@ -53,6 +56,8 @@ def parse():
     ap.add_argument("--headline-only", action="store_true",
                     help="only the timed loop (for a kernel trace of exactly that loop): no side measurements")
     ap.add_argument("--cpu-steps", type=int, default=0, help="oracle iterations for cpu_baseline (0 = auto)")
+    ap.add_argument("--cpu-c4-staircase", action="store_true",
+                    help="also run the CPU port through the whole tiers.pyfg staircase (minutes)")
     return ap.parse_args()
 
 
@@ -79,12 +84,14 @@ def run_single(args, da, torch, ds, X0):
     t0 = time.perf_counter()
     s = da.RbcdSession(ds, num_robots=args.robots, r=args.rank_r)
     setup_s = time.perf_counter() - t0
-    s.set_X(X0)
-    out = s.run(max_iters=args.warmup, rgrad_tol=0.0)
-    # continue the trajectory: dcora_rbcd_run restarts selection at agent 0, so drive iterate() from here
-    selected = int(out["selected"][-1]) if args.warmup > 0 else 0
-    # one untimed pass to recover the greedy choice after warmup
-    c2, gn, bn, selected = s.iterate(selected)
+
+    def warm():
+        s.set_X(X0)
+        out = s.run(max_iters=args.warmup, rgrad_tol=0.0)
+        # continue the trajectory: dcora_rbcd_run restarts selection at agent 0, so drive iterate() from here
+        selected = int(out["selected"][-1]) if args.warmup > 0 else 0
+        # one untimed pass to recover the greedy choice after warmup
+        return s.iterate(selected)[3]
 
     def window(count, selected):
         s.synchronize()
@@ -97,7 +104,15 @@ def run_single(args, da, torch, ds, X0):
         torch.cuda.synchronize()
         return time.perf_counter() - t0, c2, gn, selected
 
-    dt, c2, gn, selected = window(args.steps, selected)
+    # the driver's window is a few milliseconds: it is replayed REPLAYS times from the start point (same warm-up, same
+    # K iterations of the same trajectory) and `value` is the median; every sample is printed
+    samples = []
+    for _ in range(REPLAYS):
+        selected = warm()
+        dt, c2, gn, selected = window(args.steps, selected)
+        samples.append(dt)
+    dt = float(np.median(samples))
+    run_single.samples = samples
     sustained = None
     if not args.headline_only:
         first = args.warmup + 1 + args.steps
@@ -389,6 +404,69 @@ def coloured_sweeps(drv, X0, sweeps, warm=2):
             "gradnorm_last": float(last[1])}
 
 
+STRONG_SWEEPS = 10
+REPLAYS = 5
+
+
+def strong_scaling_entry(drv, X0, R, n_gpus):
+    """one point of the strong-scaling curve: coloured sweeps over the WHOLE 100k lattice split into R agents (a sweep
+    updates every block once; the graph, the start point and the number of sweeps do not depend on n_gpus)"""
+    c = coloured_sweeps(drv, X0, sweeps=STRONG_SWEEPS, warm=1)
+    return {"agents": R, "n_gpus": n_gpus, "sweeps": STRONG_SWEEPS, "sweeps_per_s": 1e3 / c["ms_per_sweep"],
+            "block_updates_per_s": c["block_updates_per_s"], "ms_per_sweep": c["ms_per_sweep"],
+            "cost_2f_after_first_sweep": c["cost_2f_after_first_sweep"],
+            "cost_2f_after_%d_sweeps" % STRONG_SWEEPS: c["cost_2f_last"], "colours": c["colours"]}
+
+
+STRONG_NOTE = ("strong scaling of the mode that CAN scale: coloured simultaneous updates (ref src/Agent.cpp:650-678 as "
+               "ticks) on the 100k-pose lattice with R = 2 N agents, agents 2g and 2g+1 (one of each colour) on rank "
+               "g, so every tick keeps every GPU busy; same graph, start point and number of sweeps at every N.  The "
+               "N = 1 line carries the one-GPU figure for R = 4, 8 and 16, i.e. the denominator of the ratio for "
+               "N = 2, 4, 8: speed-up(N) = sweeps_per_s at N GPUs / sweeps_per_s on one GPU at the same R.  Sequential "
+               "RBCD (`value`) updates one block per iteration and is not expected to rise with N.")
+
+
+def strong_scaling_single(da):
+    from dcora_amd import synth
+    ds = synth.lattice_se3()
+    r = 5
+    rng = np.random.default_rng(20250310)
+    X0 = da.manifold_project(r, ds.d, ds.n, rng.uniform(-1, 1, (r, (ds.d + 1) * ds.n)))
+    out = {"note": STRONG_NOTE, "n_gpus": 1, "one_gpu": {}}
+    for R in (4, 8, 16):
+        try:
+            t0 = time.perf_counter()
+            s = da.RbcdSession(ds, num_robots=R, r=r, acceleration=False)
+            st = time.perf_counter() - t0
+            e = strong_scaling_entry(SingleDriver(s), X0, R, 1)
+            e["setup_s"] = st
+            out["one_gpu"]["R=%d" % R] = e
+            s.close()
+        except Exception as e:  # noqa: BLE001
+            out["one_gpu"]["R=%d" % R] = {"error": str(e)}
+    return out
+
+
+def strong_scaling_multi(da, torch, dist, rank, world):
+    from dcora_amd import synth
+    ds = synth.lattice_se3()
+    r, R = 5, 2 * world
+    rng = np.random.default_rng(20250310)
+    X0 = da.manifold_project(r, ds.d, ds.n, rng.uniform(-1, 1, (r, (ds.d + 1) * ds.n)))
+    out = {"note": STRONG_NOTE, "n_gpus": world}
+    try:
+        drv = make_driver(da, torch, dist, ds, R, r, rank, world, acceleration=False)
+        e = strong_scaling_entry(drv, X0, R, world)
+        e["setup_s"] = drv.setup_s
+        e["transport"] = drv.transport
+        e["exchange"] = drv.exchange_stats(STRONG_SWEEPS)
+        out["R=%d" % R] = e
+        drv.close()
+    except Exception as e:  # noqa: BLE001
+        out["R=%d" % R] = {"error": str(e)}
+    return out
+
+
 class SingleDriver:
     """the same interface on one process without a process group"""
     dist = None
@@ -676,12 +754,6 @@ def config5_run(da, with_cpu, iters=60, cpu_iters=4):
                                                "cost_2f_last": float(o2["cost"][-1])}
         except Exception as e:
             res["staircase_ranks"][str(rr)] = {"error": str(e)}
-    try:  # 16 agents: two per GPU of an 8-GPU node, one of each colour, so that every tick keeps every GPU busy
-        s16 = da.RbcdSession(ds, num_robots=16, r=r, acceleration=False)
-        res["coloured_rbcd_16_agents"] = coloured_sweeps(SingleDriver(s16), X0, sweeps=6, warm=1)
-        s16.close()
-    except Exception as e:
-        res["coloured_rbcd_16_agents"] = {"error": str(e)}
     if with_cpu:
         from oracle import orc
         dso = orc.Dataset(ds.d, ds.n, ds.ids, ds.vals)
@@ -732,11 +804,12 @@ def config2_run(da, ds, with_cpu, r=5):
         dto = time.perf_counter() - t0
         out["cpu_port"] = {"seconds": dto, "outer_iterations": int(reso["outer_iters"]),
                            "tcg_iterations": int(reso["inner_iters"]), "cost_2f": 2.0 * reso["fOpt"], "cores": 1}
-        out["speedup_vs_cpu_port"] = dto / dt
         # the two runs need not take the same number of iterations: close to the optimum the trust-region ratio is a
         # difference of costs at the rounding level, and equally accurate preconditioners (host / device inverses) led
-        # to 6, 18 and 40 outer iterations to the same optimum -- the per-iteration ratio is the like-for-like figure
+        # to 6, 18 and 40 outer iterations to the same optimum -- the per-iteration ratio is the like-for-like figure;
+        # the wall-clock ratio is printed under a name that says what it includes
         out["speedup_per_tcg_iteration"] = (dto / max(1, reso["inner_iters"])) / (dt / max(1, res["inner_iterations"]))
+        out["wall_clock_ratio_including_fewer_iterations"] = dto / dt
     return out
 
 
@@ -879,7 +952,7 @@ def config5_central(da, r=5):
                                           "minutes (DESIGN.md section 8)"}
 
 
-def side_multi(da, torch, dist, rank, world, ds, R, r, workload, iters=60, sweeps=8, with16=False, more_ranks=()):
+def side_multi(da, torch, dist, rank, world, ds, R, r, workload, iters=60, sweeps=8, more_ranks=()):
     """a BASELINE.json multi-agent config with one process per GPU (consecutive agents share a rank): same loop, the
     library's neighbour exchange between the ranks; a side measurement, never `value`"""
     rng = np.random.default_rng(20250310)
@@ -929,13 +1002,6 @@ def side_multi(da, torch, dist, rank, world, ds, R, r, workload, iters=60, sweep
                 d2.close()
             except Exception as e:
                 res["staircase_ranks"][str(rr)] = {"error": str(e)}
-    if with16:
-        try:  # 16 agents on the chain: at 8 ranks agents 2g and 2g+1 (one of each colour) share rank g
-            drv16 = make_driver(da, torch, dist, ds, 16, r, rank, world, acceleration=False)
-            res["coloured_rbcd_16_agents"] = coloured_sweeps(drv16, X0, sweeps=6, warm=1)
-            drv16.close()
-        except Exception as e:
-            res["coloured_rbcd_16_agents"] = {"error": str(e)}
     return res
 
 
@@ -944,7 +1010,7 @@ def config5_multi(da, torch, dist, rank, world):
     ds = synth.lattice_se3()
     return side_multi(da, torch, dist, rank, world, ds, 8, 5,
                       "synthetic 50x50x40 SE(3) lattice (100000 poses, %d edges, seed 20250310), 8 agents, r=5" % ds.m,
-                      iters=60, sweeps=8, with16=True, more_ranks=(6, 7))
+                      iters=60, sweeps=8, more_ranks=(6, 7))
 
 
 def config3_multi(da, torch, dist, rank, world):
@@ -987,7 +1053,7 @@ def config4_multi_robot(da, ra, with_cpu, r=3, iters=40, cpu_iters=3):
     return res
 
 
-def config4_run(da, with_cpu):
+def config4_run(da, with_cpu, cpu_staircase=False):
     """BASELINE.json config 4 as a side measurement (never `value`): tiers.pyfg (d = 2, 9768 poses, 7789 ranges, one
     landmark: k = 37 094), the first level of the centralised CORA flow -- RTR with the driver's parameters
     (200 x 200 tCG, tol 1e-4, ref examples/SingleRobotExample_RASLAM.cpp:59-79) at rank d from the odometry start.
@@ -1046,6 +1112,34 @@ def config4_run(da, with_cpu):
         res["multi_robot"] = config4_multi_robot(da, ra, with_cpu)
     except Exception as e:
         res["multi_robot"] = {"error": str(e)}
+    # the second half of the metric on this configuration: the whole staircase of the reference's driver
+    # (examples/SingleRobotExample_RASLAM.cpp:188-283) from the odometry start to the certified, rounded solution
+    try:
+        out = cora_flow.cora(hip, ra.X_odom, ra.d)
+        lv = out["levels"]
+        res["ms_to_certified_optimum"] = {
+            "value": out["ms_total"], "unit": "ms", "certified": bool(out["certified"]), "certified_at_rank": out["r_final"],
+            "ranks_visited": [a["r"] for a in lv], "f_per_rank": [a["f"] for a in lv],
+            "theta_per_rank": [a["theta"] for a in lv], "tcg_iterations": int(sum(a["inner"] for a in lv)),
+            "f_certified": lv[-1]["f"], "f_rounded": out["f_rounded"],
+            "relative_gap_rounded_vs_certified": (out["f_rounded"] - lv[-1]["f"]) / abs(lv[-1]["f"]),
+            "clock": "the driver's loop: every level creates its problem (preconditioner from the library's cache after "
+                     "the first), RTR 200 x 200, dual certificate + fastVerification, escapeSaddle; then "
+                     "projectSolutionRASLAM and the refinement at rank d"}
+        if cpu_staircase and with_cpu:
+            from oracle import flows as _fl
+            t0 = time.perf_counter()
+            ref = cora_flow.cora(_fl.OracleBackend(ro, hip.reg), ro.X_odom, ro.d)
+            res["ms_to_certified_optimum"]["cpu_port"] = {
+                "value": 1e3 * (time.perf_counter() - t0), "unit": "ms", "cores": 1, "certified": bool(ref["certified"]),
+                "certified_at_rank": ref["r_final"], "f_certified": ref["levels"][-1]["f"], "f_rounded": ref["f_rounded"],
+                "note": "every RTR run of the port stops on the reference's 5 s TimeBound"}
+        else:
+            res["ms_to_certified_optimum"]["cpu_port"] = (
+                "not run by default (minutes: each of its RTR runs stops on the reference's 5 s TimeBound, its "
+                "certificates take tens of seconds each); --cpu-c4-staircase runs it, DESIGN.md section 5 has the figure")
+    except Exception as e:
+        res["ms_to_certified_optimum"] = {"error": str(e)}
     return res
 
 
@@ -1071,7 +1165,36 @@ def cpu_baseline(args, ds_name, X0):
             "same_window_as_value": {"iterations": "%d..%d" % (first + 1, first + args.steps), "value": same,
                                      "ms_per_step": 1e3 / same},
             "whole_sample": {"iterations": int(tr["total_iters"]), "value": tr["total_iters"] / t[-1]},
-            "final_cost_2f_of_sample": float(tr["cost"][-1])}
+            "final_cost_2f_of_sample": float(tr["cost"][-1]),
+            "r_threads": cpu_r_threads(args, dso, X0, orc, tr)}
+
+
+def cpu_r_threads(args, dso, X0, orc, tr1):
+    """the variant with one host thread per agent (ref src/Agent.cpp:660-662 starts one per agent in
+    its asynchronous mode).  (i) the SAME synchronous loop with the non-selected agents' updates of a round on R
+    threads -- one agent solves at a time, so threads buy next to nothing there; (ii) the mode in which they do:
+    agents of one colour updating at the same time, block updates/s with 1 and with R threads (the CPU side of
+    `coloured_rbcd`).  Bounded samples of the same workload and start point."""
+    R = args.robots
+    n_it = 300
+    trR = orc.run_rbcd(dso, X0, num_robots=R, r_min=args.rank_r, max_iters=n_it, staircase=0, rgrad_tol=0.0, threads=R)
+    same_trace = bool(np.array_equal(trR["selected"], tr1["selected"][:n_it]) and
+                      np.allclose(trR["cost"], tr1["cost"][:n_it], rtol=1e-12, atol=0))
+    t1 = tr1["seconds"]
+    out = {"cores": R, "host_cores_of_the_box": os.cpu_count(),
+           "sequential_loop": {"value": n_it / trR["seconds"][-1], "unit": "RBCD iterations/s",
+                               "one_thread_over_the_same_iterations": n_it / t1[n_it - 1],
+                               "same_trace_as_one_thread": same_trace,
+                               "sample": "iterations 1..%d of the same workload" % n_it}}
+    sweeps = 20
+    c1 = orc.run_coloured(dso, X0, num_robots=R, r=args.rank_r, sweeps=sweeps, threads=1)
+    cR = orc.run_coloured(dso, X0, num_robots=R, r=args.rank_r, sweeps=sweeps, threads=R)
+    out["coloured_updates"] = {"unit": "block updates/s", "sweeps": sweeps, "colours": cR["colours"],
+                               "one_thread": sweeps * R / c1["loop_seconds"],
+                               "r_threads": sweeps * R / cR["loop_seconds"],
+                               "same_costs": bool(np.array_equal(c1["cost"], cR["cost"])),
+                               "cost_2f_last": float(cR["cost"][-1])}
+    return out
 
 
 def main():
@@ -1099,7 +1222,7 @@ def main():
     ds = datasets.product_dataset(args.dataset)
     X0 = initial_point(da, ds, args.rank_r)
     multi = world > 1 or bool(os.environ.get("DCORA_FORCE_MULTI"))  # the latter: 1-rank rehearsal of the N>1 path
-    sustained = exch = c3 = c5 = group = None
+    sustained = exch = c3 = c5 = group = strong = None
     if multi:
         import torch.distributed as dist
         dist.init_process_group(os.environ.get("DCORA_DIST_BACKEND", "nccl"))
@@ -1112,6 +1235,7 @@ def main():
         if not args.headline_only:
             c3 = None if args.no_config3 else config3_multi(da, torch, dist, rank, world)
             c5 = None if args.no_config5 else config5_multi(da, torch, dist, rank, world)
+            strong = None if args.no_config5 else strong_scaling_multi(da, torch, dist, rank, world)
         dist.barrier()
         dist.destroy_process_group()
     else:
@@ -1140,6 +1264,10 @@ def main():
                                        (args.warmup + 2, args.warmup + 1 + args.steps),
                    "final_cost_2f": c2, "final_gradnorm": gn},
     }
+    if getattr(run_single, "samples", None):
+        sm = [args.steps / t for t in run_single.samples]
+        line["value_samples"] = {"replays": len(sm), "statistic": "median (each replay: set X0, the same warm-up, the "
+                                 "same K timed iterations)", "min": min(sm), "max": max(sm), "all": sm}
     if group is not None:
         line["process_group"] = group
         line["exchange"] = exch
@@ -1155,6 +1283,8 @@ def main():
         line["config3_torus3D_8agents"] = c3
     if c5 is not None:
         line["config5_lattice100k"] = c5
+    if strong is not None:
+        line["strong_scaling"] = strong
     line["roofline"], line["roofline_qapply"] = roofline(da, ds, args.rank_r, args.robots)
     if world == 1 and not multi:
         try:
@@ -1181,9 +1311,13 @@ def main():
                 line["config5_lattice100k"] = config5_run(da, not args.no_cpu_baseline)
             except Exception as e:
                 line["config5_lattice100k"] = {"error": str(e)}
+            try:
+                line["strong_scaling"] = strong_scaling_single(da)
+            except Exception as e:
+                line["strong_scaling"] = {"error": str(e)}
         if not args.no_config4:
             try:
-                line["config4_tiers"] = config4_run(da, not args.no_cpu_baseline)
+                line["config4_tiers"] = config4_run(da, not args.no_cpu_baseline, args.cpu_c4_staircase)
             except Exception as e:
                 line["config4_tiers"] = {"error": str(e)}
         if not args.no_cpu_baseline:

@@ -260,6 +260,9 @@ struct RBCDOptions {
   int staircase = 1;  // run certification + escape
   int verbose = 0;
   ROptParams opt;
+  // > 1: the non-selected agents' iterate(false) of a round run on this many host threads (one per agent is what the
+  // reference's asynchronous mode starts, ref src/Agent.cpp:660-662); same arithmetic, same trace
+  int threads = 1;
 };
 struct RBCDTrace {
   std::vector<double> cost, gradnorm;  // per iteration (2f and |rgrad|, as printed :278-281)
@@ -273,6 +276,7 @@ struct RBCDTrace {
   Mat Xfinal;
 };
 RBCDTrace run_rbcd(const Dataset &ds, const RBCDOptions &o, const Mat &X0);
+RBCDTrace run_coloured(const Dataset &ds, const RBCDOptions &o, const Mat &X0, int sweeps);
 
 // ---- robust estimation (oracle_robust.cpp) ------------------------------------------------------------------
 // ref: include/DCORA/DCORA_robust.h:25-140, src/DCORA_robust.cpp:51-148

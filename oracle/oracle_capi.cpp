@@ -382,8 +382,26 @@ void *orc_run_rbcd(void *dsh, const double *opts, const double *X0, int x0_rows)
   o.opt.RTR_iterations = (int)opts[13];
   o.opt.RTR_tCG_iterations = (int)opts[14];
   o.opt.RTR_initial_radius = opts[15];
+  o.threads = (int)opts[16];
   Mat X0m = view_mat(x0_rows, (ds->d + 1) * ds->n, X0);
   return new RBCDTrace(run_rbcd(*ds, o, X0m));
+}
+// coloured simultaneous updates: opts as above (r_min = the rank; max_iters = sweeps)
+void *orc_run_coloured(void *dsh, const double *opts, const double *X0, int x0_rows) {
+  Dataset *ds = (Dataset *)dsh;
+  RBCDOptions o;
+  o.num_robots = (int)opts[0];
+  o.r_min = (int)opts[1];
+  o.opt.method = (int)opts[9];
+  o.opt.gradnorm_tol = opts[10];
+  o.opt.RGD_stepsize = opts[11];
+  o.opt.RGD_use_preconditioner = (int)opts[12];
+  o.opt.RTR_iterations = (int)opts[13];
+  o.opt.RTR_tCG_iterations = (int)opts[14];
+  o.opt.RTR_initial_radius = opts[15];
+  o.threads = (int)opts[16];
+  Mat X0m = view_mat(x0_rows, (ds->d + 1) * ds->n, X0);
+  return new RBCDTrace(run_coloured(*ds, o, X0m, (int)opts[3]));
 }
 // info: [total_iters, final_rank, certified, theta, lambda_min, rbcd_seconds, cert_seconds, setup_seconds]
 void orc_trace_info(void *h, double *info) {

@@ -8,6 +8,9 @@
 #include <cstdio>
 #include <set>
 
+#include <atomic>
+#include <thread>
+
 #include "oracle.hpp"
 
 namespace orc {
@@ -182,8 +185,23 @@ RBCDTrace run_rbcd(const Dataset &ds, const RBCDOptions &o, const Mat &X0) {
     Mat Xopt(r, n * dh), RG;
     int selected = 0;
     for (int iter = 0; iter < o.max_iters; ++iter) {
-      for (int rb = 0; rb < Rn; ++rb)
-        if (rb != selected) agents[rb].iterate(false);
+      if (o.threads > 1) {  // the agents are independent here: each touches its own state only
+        std::vector<std::thread> th;
+        std::atomic<int> next(0);
+        auto work = [&]() {
+          for (;;) {
+            const int rb = next.fetch_add(1);
+            if (rb >= Rn) break;
+            if (rb != selected) agents[rb].iterate(false);
+          }
+        };
+        for (int t = 1; t < std::min(o.threads, Rn); ++t) th.emplace_back(work);
+        work();
+        for (auto &t : th) t.join();
+      } else {
+        for (int rb = 0; rb < Rn; ++rb)
+          if (rb != selected) agents[rb].iterate(false);
+      }
       for (int rb = 0; rb < Rn; ++rb) {
         if (rb == selected) continue;
         PoseDict dct;
@@ -271,6 +289,115 @@ RBCDTrace run_rbcd(const Dataset &ds, const RBCDOptions &o, const Mat &X0) {
     for (int j = 0; j < Xn.cols; ++j)
       for (int t = 0; t < r + 1; ++t) Xcurr(t, j) = Xn(t, j);
   }
+  return tr;
+}
+
+
+// Coloured simultaneous updates (a separate mode; the CPU figure that sits beside the product's dcora_rbcd_iterate_set):
+// the agents of one colour -- no two share a measurement -- run Agent::iterate(true) AT THE SAME TIME, one host thread
+// per agent as the reference's asynchronous mode starts them (ref src/Agent.cpp:650-678), non-accelerated as that mode
+// is; every updating agent first pulls its neighbours' public poses.  A sweep = one tick per colour; the central cost
+// is evaluated once per sweep.  Same partition and problem set-up as run_rbcd.
+RBCDTrace run_coloured(const Dataset &ds, const RBCDOptions &o, const Mat &X0, int sweeps) {
+  RBCDTrace tr;
+  const int d = ds.d, n = ds.n, dh = d + 1, Rn = o.num_robots, r = o.r_min;
+  const int per = n / Rn;
+  auto robot_of = [&](int idx) { return std::min(idx / per, Rn - 1); };
+  auto start_of = [&](int rb) { return rb * per; };
+  auto end_of = [&](int rb) { return rb == Rn - 1 ? n : (rb + 1) * per; };
+  const auto t_setup0 = clk::now();
+  std::vector<std::vector<Meas>> touching(Rn);
+  std::vector<std::set<int>> adj(Rn);
+  for (const Meas &mi : ds.meas) {
+    Meas m = mi;
+    m.r1 = robot_of(mi.p1);
+    m.r2 = robot_of(mi.p2);
+    m.p1 = mi.p1 - start_of(m.r1);
+    m.p2 = mi.p2 - start_of(m.r2);
+    touching[m.r1].push_back(m);
+    if (m.r2 != m.r1) {
+      touching[m.r2].push_back(m);
+      adj[m.r1].insert(m.r2);
+      adj[m.r2].insert(m.r1);
+    }
+  }
+  std::vector<int> colour(Rn, -1);
+  int ncol = 0;
+  for (int a = 0; a < Rn; ++a) {  // greedy, in index order
+    std::set<int> used;
+    for (int b : adj[a])
+      if (colour[b] >= 0) used.insert(colour[b]);
+    int c = 0;
+    while (used.count(c)) ++c;
+    colour[a] = c;
+    ncol = std::max(ncol, c + 1);
+  }
+  std::vector<Meas> central = ds.meas;
+  for (Meas &m : central) m.r1 = m.r2 = 0;
+  CSR Qc = build_Q_pgo(d, n, 0, central);
+  std::vector<Agent> agents(Rn);
+  {
+    std::vector<std::thread> th;
+    std::atomic<int> next(0);
+    auto work = [&]() {
+      for (;;) {
+        const int rb = next.fetch_add(1);
+        if (rb >= Rn) break;
+        agents[rb].acceleration = 0;
+        agents[rb].opt = o.opt;
+        agents[rb].setup(rb, Rn, r, d, end_of(rb) - start_of(rb), touching[rb]);
+        Mat Xb(r, (end_of(rb) - start_of(rb)) * dh);
+        for (int j = 0; j < Xb.cols; ++j)
+          for (int t = 0; t < r; ++t) Xb(t, j) = X0(t, start_of(rb) * dh + j);
+        agents[rb].setX(Xb);
+      }
+    };
+    for (int t = 1; t < std::min(std::max(o.threads, 1), Rn); ++t) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+  }
+  Problem Pc;
+  Pc.D = Dims{r, d, n, 0, 0};
+  Pc.Q = &Qc;
+  tr.setup_seconds = secs(t_setup0, clk::now());
+  const auto tl0 = clk::now();
+  Mat Xopt(r, n * dh), RG;
+  for (int sw = 0; sw < sweeps; ++sw) {
+    for (int c = 0; c < ncol; ++c) {
+      std::vector<int> set;
+      for (int a = 0; a < Rn; ++a)
+        if (colour[a] == c) set.push_back(a);
+      // every member pulls the public poses of its neighbours (none of which updates in this tick)
+      for (int a : set)
+        for (int b : adj[a]) {
+          PoseDict dct;
+          agents[b].shared_dict(dct);
+          agents[a].update_neighbor(b, dct, false);
+        }
+      if (o.threads > 1) {
+        std::vector<std::thread> th;
+        for (size_t i = 1; i < set.size(); ++i) th.emplace_back([&, i]() { agents[set[i]].iterate(true); });
+        if (!set.empty()) agents[set[0]].iterate(true);
+        for (auto &t : th) t.join();
+      } else {
+        for (int a : set) agents[a].iterate(true);
+      }
+    }
+    for (int rb = 0; rb < Rn; ++rb) {
+      const Mat &Xr = agents[rb].X;
+      std::copy(Xr.a.begin(), Xr.a.end(), Xopt.col(start_of(rb) * dh));
+    }
+    Pc.rgrad(Xopt, RG);
+    tr.cost.push_back(2 * Pc.f(Xopt));
+    tr.gradnorm.push_back(norm(RG));
+    tr.selected.push_back(ncol);
+    tr.rank.push_back(r);
+    tr.seconds.push_back(secs(tl0, clk::now()));
+  }
+  tr.rbcd_seconds = secs(tl0, clk::now());
+  tr.total_iters = (int)tr.cost.size();
+  tr.final_rank = r;
+  tr.Xfinal = Xopt;
   return tr;
 }
 

@@ -93,6 +93,8 @@ def lib():
         L.orc_ra_free.argtypes = [C.c_void_p]
         L.orc_run_rbcd.restype = C.c_void_p
         L.orc_run_rbcd.argtypes = [C.c_void_p, _dp, _dp, C.c_int]
+        L.orc_run_coloured.restype = C.c_void_p
+        L.orc_run_coloured.argtypes = [C.c_void_p, _dp, _dp, C.c_int]
         L.orc_trace_info.argtypes = [C.c_void_p, _dp]
         L.orc_trace_copy.argtypes = [C.c_void_p, _dp, _dp, _ip, _ip, C.c_void_p]
         L.orc_trace_free.argtypes = [C.c_void_p]
@@ -316,12 +318,12 @@ def fast_verification(S, eta, block=1):
 
 def run_rbcd(ds, X0, num_robots=5, r_min=5, r_max=100, max_iters=1000, min_eig_tol=1e-3, rgrad_tol=0.1,
              acceleration=1, staircase=1, verbose=0, method=0, gradnorm_tol=1e-2, RGD_stepsize=1e-3,
-             RGD_use_precond=1, RTR_iterations=3, RTR_tCG_iterations=50, RTR_initial_radius=100.0):
+             RGD_use_precond=1, RTR_iterations=3, RTR_tCG_iterations=50, RTR_initial_radius=100.0, threads=1):
     L = lib()
     h = L.orc_ds_create(ds.d, ds.n, ds.m, ds.ids, ds.vals)
     opts = np.array([num_robots, r_min, r_max, max_iters, min_eig_tol, rgrad_tol, acceleration, staircase, verbose,
                      method, gradnorm_tol, RGD_stepsize, RGD_use_precond, RTR_iterations, RTR_tCG_iterations,
-                     RTR_initial_radius], dtype=np.float64)
+                     RTR_initial_radius, threads], dtype=np.float64)
     X0 = np.asarray(X0, dtype=np.float64)
     t = L.orc_run_rbcd(h, opts, F(X0), X0.shape[0])
     info = np.zeros(8)
@@ -340,6 +342,30 @@ def run_rbcd(ds, X0, num_robots=5, r_min=5, r_max=100, max_iters=1000, min_eig_t
     return dict(total_iters=it, final_rank=rfin, certified=int(info[2]), theta=info[3], lambda_min=info[4],
                 rbcd_seconds=info[5], cert_seconds=info[6], setup_seconds=info[7], cost=cost, gradnorm=gn,
                 selected=sel, rank=rk, X=unF(Xf, rfin, k), seconds=secs)
+
+
+def run_coloured(ds, X0, num_robots=5, r=5, sweeps=10, threads=1, method=0, gradnorm_tol=1e-2, RGD_stepsize=1e-3,
+                 RGD_use_precond=1, RTR_iterations=3, RTR_tCG_iterations=50, RTR_initial_radius=100.0):
+    """coloured simultaneous updates (agents of one colour at once, non-accelerated; ref src/Agent.cpp:650-678 as ticks)
+    with `threads` host threads: per-sweep central cost, loop seconds, set-up seconds"""
+    L = lib()
+    h = L.orc_ds_create(ds.d, ds.n, ds.m, ds.ids, ds.vals)
+    opts = np.array([num_robots, r, 100, sweeps, 1e-3, 0.0, 0, 0, 0, method, gradnorm_tol, RGD_stepsize,
+                     RGD_use_precond, RTR_iterations, RTR_tCG_iterations, RTR_initial_radius, threads], dtype=np.float64)
+    X0 = np.asarray(X0, dtype=np.float64)
+    t = L.orc_run_coloured(h, opts, F(X0), X0.shape[0])
+    info = np.zeros(8)
+    L.orc_trace_info(t, info)
+    it = int(info[0])
+    cost, gn = np.zeros(it), np.zeros(it)
+    sel, rk = np.zeros(it, np.int32), np.zeros(it, np.int32)
+    k = (ds.d + 1) * ds.n
+    Xf = np.zeros(r * k)
+    L.orc_trace_copy(t, cost, gn, sel, rk, Xf.ctypes.data_as(C.c_void_p))
+    L.orc_trace_free(t)
+    L.orc_ds_free(h)
+    return dict(sweeps=it, colours=int(sel[0]) if it else 0, loop_seconds=info[5], setup_seconds=info[7], cost=cost,
+                gradnorm=gn, X=unF(Xf, r, k))
 
 
 class RADataset:

@@ -111,6 +111,60 @@ def test_c4_tiers_certificate_and_min_eig(env):
     assert oko and abs(lamo - want) < 1e-4 * max(1.0, abs(want))
 
 
+def test_c4_tiers_staircase_to_the_certified_rounded_solution(env):
+    """BASELINE config 4 END TO END: the centralised CORA driver (ref examples/SingleRobotExample_RASLAM.cpp:188-283)
+    on tiers.pyfg from the odometry start -- RTR at rank 2, certificate, escapeSaddle, ... up the Riemannian staircase
+    until fastVerification accepts, then projectSolutionRASLAM and the refinement at rank d.  The CPU port cannot
+    follow within a test (its RTR runs stop on the reference's 5 s TimeBound at every level), so beyond the first
+    level the checks are the properties the flow must have whatever the path: every rejected level is a critical
+    point with negative curvature, the cost falls from level to level, the accepted level's certificate holds
+    (S X^T = 0, S + eta I >= 0 by two independent factorisations) and bounds the rounded solution from below, and
+    the rounded solution is feasible."""
+    da, orc = env
+    import cora_flow
+    ra = da.RADataset(ra_path("tiers"))
+    d, n, l, b = ra.d, ra.n, ra.l, ra.b
+    hip = cora_flow.ProductBackend(ra)
+    out = cora_flow.cora(hip, ra.X_odom, d)
+    lv = out["levels"]
+    assert out["certified"] and lv[-1]["psd"] and out["r_final"] == d + len(lv) - 1
+    assert 4 <= out["r_final"] <= 8                      # rank 6 on the boxes this ran on
+    for a in lv[:-1]:                                    # saddles: escapeSaddle had a direction to leave along
+        assert not a["psd"] and a["theta"] < -cora_flow.MIN_EIG_TOL / 2 and a["gradnorm"] < 5e-3
+    f = [a["f"] for a in lv]
+    assert all(f[i + 1] < f[i] for i in range(len(f) - 1))
+    # first level against the oracle (both stop after the same 18 outer iterations; the oracle on its TimeBound)
+    ro = orc.RADataset(ra_plain("tiers"))
+    cpu = cora_flow.OracleBackend(ro, hip.reg)
+    Xo, fo, gno, oo, io = cpu.optimize(cpu.problem(d), ro.X_odom)
+    assert abs(lv[0]["f"] - fo) <= 1e-6 * abs(fo), (lv[0]["f"], fo)
+    # the accepted certificate, recomputed here from the returned iterate
+    r, X = out["r_final"], out["X"]
+    assert X.shape == (r, ra.k)
+    S = da.dual_certificate(r, d, n, X, ra.Q, l=l, b=b)
+    A = S.to_scipy()
+    assert np.linalg.norm(A @ X.T) < 10 * lv[-1]["gradnorm"] + 1e-6
+    So = orc.dual_certificate(r, d, n, X, ro.Q, l=l, b=b)
+    assert abs(A - So.to_scipy()).max() <= 1e-9 * abs(A).max()
+    assert da.fast_verification(S, cora_flow.MIN_EIG_TOL, block=1)[0]
+    assert orc.is_psd(orc.CSR.from_scipy(So.to_scipy() + cora_flow.MIN_EIG_TOL * sp.identity(ra.k)), block=1)
+    fX = 0.5 * np.sum((X @ ra.Q.to_scipy()) * X)
+    assert abs(fX - lv[-1]["f"]) <= 1e-9 * abs(fX)
+    # the rounded solution: feasible at rank d, and the certified value bounds it from below (to the eta-test's slack)
+    Xr = out["X_rounded"]
+    assert Xr.shape == (d, ra.k)
+    for i in range(n):
+        Ri = Xr[:, i * d:(i + 1) * d]
+        assert np.allclose(Ri.T @ Ri, np.eye(d), atol=1e-9)
+    if l:
+        assert np.allclose(np.linalg.norm(Xr[:, d * n:d * n + l], axis=0), 1.0, atol=1e-9)
+    fr = 0.5 * np.sum((Xr @ ra.Q.to_scipy()) * Xr)
+    assert abs(fr - out["f_rounded"]) <= 1e-9 * abs(fr)
+    neff = np.sum(Xr ** 2)
+    assert fr >= lv[-1]["f"] - 0.5 * cora_flow.MIN_EIG_TOL * neff - 1e-6 * abs(fr)
+    assert fr <= lv[0]["f"] * (1 + 1e-6)                 # the refinement at rank d starts from a better point than odometry
+
+
 # ---- C5 ------------------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def lattice(env):

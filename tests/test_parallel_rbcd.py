@@ -134,3 +134,42 @@ def test_simultaneous_updates_refuse_acceleration_and_bad_sets(built):
     for bad in ([0, 0], [5], [-1]):
         with pytest.raises(da.DcoraError, match="out of range or twice"):
             s.iterate_set(bad)
+
+
+def test_oracle_coloured_ticks_do_not_depend_on_the_thread_count(built):
+    """the CPU side of the coloured mode (oracle run_coloured: one host thread per agent of a colour, ref
+    src/Agent.cpp:660-662) is the same arithmetic on 1 and on R threads, and its cost decreases monotonically"""
+    from oracle import orc
+    dso = common.oracle_dataset("smallGrid3D")
+    X0 = common.random_point(5, dso.d, dso.n, 7, orc.project_to_manifold)
+    a = orc.run_coloured(dso, X0, num_robots=5, r=5, sweeps=6, threads=1)
+    b = orc.run_coloured(dso, X0, num_robots=5, r=5, sweeps=6, threads=5)
+    assert a["colours"] == b["colours"] == 2
+    assert np.array_equal(a["cost"], b["cost"]) and np.array_equal(a["X"], b["X"])
+    assert np.all(np.diff(a["cost"]) <= 1e-9 * a["cost"][:-1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,R", [("sphere2500", 5), ("torus3D", 8)])
+def test_coloured_sweeps_match_the_oracles_threaded_agents(built, name, R):
+    """dcora_rbcd_iterate_set over the colours against the oracle's own Agents updating colour by colour on R host
+    threads: same cost after every sweep"""
+    import dcora_amd as da
+    from oracle import orc
+    ds, dso = common.product_dataset(name), common.oracle_dataset(name)
+    r, sweeps = 5, 4
+    X0 = common.random_point(r, ds.d, ds.n, 5, orc.project_to_manifold)
+    want = orc.run_coloured(dso, X0, num_robots=R, r=r, sweeps=sweeps, threads=R)
+    s = da.RbcdSession(ds, num_robots=R, r=r, acceleration=False)
+    col, nc = s.colours()
+    assert nc == want["colours"]
+    s.set_X(X0)
+    cost = []
+    for _ in range(sweeps):
+        for S in _sets(col, nc):
+            s.iterate_set(S)
+        cost.append(s.evaluate()[0])
+    X = s.get_X()
+    s.close()
+    assert np.allclose(cost, want["cost"], rtol=1e-8, atol=0), (cost, want["cost"])
+    assert common.rel(X, want["X"]) < 1e-6
