@@ -36,7 +36,8 @@ struct alignas(64) ShmEval {
 struct alignas(64) ShmRank {
   hipIpcMemHandle_t halo;  // 64 bytes
   std::atomic<int> device, pid, ipc_ok, published;
-  uint64_t pad[6];
+  std::atomic<uint64_t> bus;  // hash of the device's PCI bus id: two ranks with the same value share a GPU
+  uint64_t pad[5];
 };
 struct ShmHeader {
   std::atomic<uint32_t> magic;

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <set>
@@ -341,8 +342,14 @@ int Exchange::init(RbcdSession *s, const char *job_name) {
   DCORA_HIP(arrive2_.alloc(R));
   DCORA_HIP(hipMemset(arrive2_.p, 0, sizeof(unsigned) * R));
   {
-    const char *wm = std::getenv("DCORA_EXCHANGE_WAIT");  // host: the host spins on the flag, then enqueues the scatter
-    device_wait_ = !(wm && std::strcmp(wm, "host") == 0);
+    char bus[64] = {0};
+    uint64_t h = 1469598103934665603ull;
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), s->opt.device) != hipSuccess) {
+      (void)hipGetLastError();
+      std::snprintf(bus, sizeof(bus), "device-%d", s->opt.device);
+    }
+    for (const char *c = bus; *c; ++c) h = (h ^ (uint64_t)(unsigned char)*c) * 1099511628211ull;
+    ranks_[rank].bus.store(h ? h : 1, std::memory_order_release);
   }
   DCORA_HIP(evalbuf_.alloc(2 * R));
   DCORA_HIP(hipMemset(evalbuf_.p, 0, sizeof(double) * 2 * R));
@@ -364,6 +371,18 @@ int Exchange::init(RbcdSession *s, const char *job_name) {
   bool all = true;
   for (int q = 0; q < world; ++q) all = all && ranks_[q].ipc_ok.load(std::memory_order_acquire) == 1;
   mode = all ? kExchangeIpc : kExchangeStaged;
+  {
+    // Who waits for a producer's flag.  With a GPU of its own the consumer's scatter kernel polls the flag itself: no
+    // host hop between the producer's stores and the scatter.  Ranks SHARING a GPU (the rehearsal on one device) keep
+    // the host's wait: a kernel that polls occupies the queue the producer's kernels of the other process need --
+    // measured with 4 ranks on one MI355X: 875 against 1084 it/s on the headline, 274 against 664 on the 100k lattice.
+    // DCORA_EXCHANGE_WAIT=device / host forces one or the other.
+    bool shared_gpu = false;
+    for (int q = 0; q < world; ++q)
+      if (q != rank && ranks_[q].bus.load(std::memory_order_acquire) == ranks_[rank].bus.load()) shared_gpu = true;
+    const char *wm = std::getenv("DCORA_EXCHANGE_WAIT");
+    device_wait_ = wm ? std::strcmp(wm, "host") != 0 : !shared_gpu;
+  }
   if (force && std::strcmp(force, "ipc") == 0 && !all) return fail("DCORA_EXCHANGE=ipc but the IPC transport is not usable", DCORA_ERR_HIP);
   rc = barrier();
   if (rc) return rc;

@@ -70,13 +70,16 @@ def single(da, ds, R, r, iters, mode, X0):
 
 
 CASES = [
-    # dataset, agents, ranks, iterations, mode, transport, who waits for the producer's flag (default: the scatter kernel)
-    ("sphere2500", 5, 2, 40, "greedy", None, None),        # restart round (30) inside
-    ("sphere2500", 5, 4, 12, "greedy", "staged", None),    # rank 3 hosts no agent; shared-host-segment transport
-    ("torus3D", 8, 4, 10, "greedy", None, None),           # BASELINE config 3's split, two agents per rank
-    ("torus3D", 8, 2, 4, "coloured", None, None),          # simultaneous updates of one colour, then post + wait
-    ("sphere2500", 5, 2, 12, "greedy", None, "host"),      # DCORA_EXCHANGE_WAIT=host: the round-2 form of the wait
+    # dataset, agents, ranks, iterations, mode, transport, who waits for the producer's flag: "device" = the scatter
+    # kernel polls it (the default where every rank has a GPU of its own), "host" = the host spins (the default where
+    # ranks share a GPU), None = that default
+    ("sphere2500", 5, 2, 40, "greedy", None, "device"),        # restart round (30) inside
+    ("sphere2500", 5, 4, 12, "greedy", "staged", "device"),    # rank 3 hosts no agent; shared-host-segment transport
+    ("torus3D", 8, 4, 10, "greedy", None, "device"),           # BASELINE config 3's split, two agents per rank
+    ("torus3D", 8, 2, 4, "coloured", None, "device"),          # simultaneous updates of one colour, then post + wait
+    ("sphere2500", 5, 2, 12, "greedy", None, "host"),          # the round-2 form of the wait
     ("torus3D", 8, 4, 6, "greedy", "staged", "host"),
+    ("torus3D", 8, 2, 6, "greedy", None, None),
 ]
 
 
@@ -91,7 +94,10 @@ def test_ranks_reproduce_single_session(tmp_path, name, R, world, iters, mode, t
     want_mode = 2 if transport == "staged" else 1
     for k, o in enumerate(res):
         assert int(o["mode"]) == want_mode, "rank %d used transport %d" % (k, int(o["mode"]))
-        assert str(o["wait"]).startswith("host" if wait == "host" else "device"), str(o["wait"])
+        own_gpu = da.device_count() >= world  # tests/exchange_worker.py: device = rank % device_count()
+        expect = wait or ("device" if own_gpu else "host")
+        assert str(o["wait"]).startswith(expect), (str(o["wait"]), expect)
+        assert int(o["device"]) == k % max(da.device_count(), 1)
         if want_mode == 1:  # the halo buffers other ranks store into are fine-grained device memory
             assert bool(o["finegrained"]), "rank %d fell back to a coarse-grained halo buffer" % k
         assert np.array_equal(o["selected"], sel), (k, o["selected"], sel)
