@@ -1729,6 +1729,138 @@ __global__ __launch_bounds__(kBlock) void k_spmm_bsr2(int r, BsrDev A, Buf2 Xb, 
   }
 }
 
+// Third form of the block Q-apply (d = 3): HALF the load instructions.  The kernels above are bound by the number of
+// loads they issue (each touches the lines of 8 poses), and a lane there issues six per matrix block: two for its row of
+// the block and d + 1 = 4 gathers of 8 bytes, one per column of the neighbour's r x 4 block.  Here a lane issues three
+// 16-byte loads: the 8 lanes of a pose are (column pair c2, row pair rp); the lane gathers rows (2 rp, 2 rp + 1) of the
+// neighbour's columns 2 c2 and 2 c2 + 1 -- 16 bytes each, 8-byte aligned in the tight r x k layout, which
+// global_load_dwordx4 takes -- and loads the 16 bytes B[rp][2 c2 .. 2 c2 + 1] of the block, whose other rows arrive by
+// DPP quad broadcasts (8 per block instead of 16).  It accumulates the products of ITS two columns for its two rows and
+// all four output columns; the two column pairs of a pose are added once per pose (lane t and t ^ 4), not per block.
+// At odd r the last row pair is loaded one row lower (rows r - 2, r - 1) and its first half ignored: nothing is read
+// beyond a column.  The summation order differs from k_spmm_bsr2 (rounding-level differences, still deterministic).
+// MEASURED AND NOT THE DEFAULT (DCORA_BSR_KERNEL=v3; round 3, 100k lattice, warm / cold us): r = 5: 28.6 / 36.7 against
+// 24.6 / 33.1 for k_spmm_bsr2; r = 7: 31.8 / 38.8 against 27.8 / 37.9; and at EVEN r, where every 16-byte gather is
+// 16-byte aligned -- what an internal padded leading dimension (ld = 6 at r = 5) would buy at +20 % vector bytes --
+// r = 4: 26.9 / 33.9 against 23.4 / 30.7, r = 6: 29.9 / 36.7 against 26.1 / 34.7, r = 8: 31.6 / 40.0 against 28.2 / 35.9.
+// Half the load instructions, 6 of 8 lanes working, and slower everywhere: the Q-apply is not bound by the number of
+// its loads but by the dependent chain (row pointer -> column indices -> gather) at the head of each of its ~3000
+// short-lived workgroups and by what the fabric delivers to scattered 128-byte requests.
+struct __attribute__((packed, aligned(8))) Pair8 {
+  double x, y;
+};
+constexpr int kBsrGather3 = 4;
+template <bool DOTS>
+__global__ __launch_bounds__(kBlock) void k_spmm_bsr3(int r, BsrDev A, Buf2 Xb, int selX,
+                                                      const double *__restrict__ G, Buf2 Yb, int selY,
+                                                      double *__restrict__ partials, Gate g) {
+  if (g.ctl && g.gate && f_gated(g.ctl, g.seq, g.gate)) return;
+  constexpr int DH = 4, BS = 16;
+  __shared__ double s_red[16];
+  const int cur = g.ctl ? (g.ctl->cur & 1) : 0;
+  const double *__restrict__ X = Xb.p[g.ctl ? ((cur ^ selX) & 1) : 0];
+  double *__restrict__ Y = Yb.p[g.ctl ? ((cur ^ selY) & 1) : 0];
+  const int t = threadIdx.x & (GW - 1);
+  const int c2 = t >> 2, rp = t & 3;
+  const int r0 = 2 * rp;
+  const bool have0 = r0 < r, have1 = r0 + 1 < r;
+  const bool tail = have0 && !have1;               // odd r: the last row alone
+  const int lo = have1 ? r0 : (have0 ? r0 - 1 : 0);  // first row of the 16 bytes this lane gathers (r >= 2)
+  double d0 = 0, d1 = 0;
+  const int range_lo = (int)((long)A.nbrows * blockIdx.x / gridDim.x);
+  const int range_hi = (int)((long)A.nbrows * (blockIdx.x + 1) / gridDim.x);
+  const int npass = max(1, (range_hi - range_lo + kPosesPerBlock - 1) / kPosesPerBlock);
+  const int per_pass = (range_hi - range_lo + npass - 1) / npass;
+  for (int pose0 = range_lo; pose0 < range_hi; pose0 += per_pass) {
+    const int pend_pose = min(range_hi, pose0 + per_pass);
+    const int pose = pose0 + (threadIdx.x >> 3);
+    const bool inr = pose < pend_pose;
+    const int myb = inr ? A.bp[pose] : 0, mye = inr ? A.bp[pose + 1] : 0;
+    double acc[DH][2];
+#pragma unroll
+    for (int a = 0; a < DH; ++a) acc[a][0] = acc[a][1] = 0;
+    for (int b0 = myb; b0 < mye; b0 += GW) {
+      const int nb = min(GW, mye - b0);
+      const int mybc = (t < nb) ? A.bc[b0 + t] : 0;
+      for (int q0 = 0; q0 < nb; q0 += kBsrGather3) {
+        Pair8 xa[kBsrGather3], xb[kBsrGather3];
+        double2 w[kBsrGather3];
+#pragma unroll
+        for (int q = 0; q < kBsrGather3; ++q) {
+          const bool ok = q0 + q < nb;
+          const int qc = ok ? q0 + q : q0;
+          const int col = __shfl(mybc, qc, GW);
+          const double *__restrict__ xc = X + ((size_t)col * DH + 2 * c2) * r + lo;
+          xa[q] = *reinterpret_cast<const Pair8 *>(xc);
+          xb[q] = *reinterpret_cast<const Pair8 *>(xc + r);
+          w[q] = *reinterpret_cast<const double2 *>(A.bv + (size_t)(b0 + qc) * BS + rp * DH + 2 * c2);
+          if (!ok) w[q] = make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int q = 0; q < kBsrGather3; ++q) {
+          const double xa0 = tail ? xa[q].y : xa[q].x, xa1 = tail ? 0.0 : xa[q].y;
+          const double xb0 = tail ? xb[q].y : xb[q].x, xb1 = tail ? 0.0 : xb[q].y;
+          {
+            const double b0v = quad_bcast<0>(w[q].x), b1v = quad_bcast<0>(w[q].y);
+            acc[0][0] += b0v * xa0 + b1v * xb0;
+            acc[0][1] += b0v * xa1 + b1v * xb1;
+          }
+          {
+            const double b0v = quad_bcast<1>(w[q].x), b1v = quad_bcast<1>(w[q].y);
+            acc[1][0] += b0v * xa0 + b1v * xb0;
+            acc[1][1] += b0v * xa1 + b1v * xb1;
+          }
+          {
+            const double b0v = quad_bcast<2>(w[q].x), b1v = quad_bcast<2>(w[q].y);
+            acc[2][0] += b0v * xa0 + b1v * xb0;
+            acc[2][1] += b0v * xa1 + b1v * xb1;
+          }
+          {
+            const double b0v = quad_bcast<3>(w[q].x), b1v = quad_bcast<3>(w[q].y);
+            acc[3][0] += b0v * xa0 + b1v * xb0;
+            acc[3][1] += b0v * xa1 + b1v * xb1;
+          }
+        }
+      }
+    }
+    // the two column pairs of the pose meet; lane c2 then owns output columns 2 c2 and 2 c2 + 1 of its two rows
+    double tot[2][2];
+#pragma unroll
+    for (int a = 0; a < DH; ++a)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const double other = __shfl_xor(acc[a][h], 4, GW);
+        const double sum = c2 == 0 ? acc[a][h] + other : other + acc[a][h];  // same order in both lanes
+        if ((a >> 1) == c2) tot[a & 1][h] = sum;
+      }
+    if (inr && have0) {
+#pragma unroll
+      for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (h == 1 && !have1) continue;
+          const size_t o = ((size_t)pose * DH + 2 * c2 + a2) * r + r0 + h;
+          double y = tot[a2][h];
+          if (DOTS) {
+            const double x = X[o];
+            d0 += y * x;
+            if (G) d1 += x * G[o];
+          }
+          if (G) y += G[o];
+          Y[o] = y;
+        }
+    }
+  }
+  if (DOTS) {
+    const double a = f_block_sum(d0, s_red);
+    const double b = f_block_sum(d1, s_red);
+    if (threadIdx.x == 0) {
+      partials[2 * blockIdx.x] = a;
+      partials[2 * blockIdx.x + 1] = b;
+    }
+  }
+}
+
 int group_grid(int n) {
   long g = ((long)n + kPosesPerBlock - 1) / kPosesPerBlock;
   if (g < 1) g = 1;
@@ -1846,10 +1978,19 @@ int spmm_bsr_grid(int nbrows) {
 void launch_spmm_bsr(hipStream_t st, int r, int d, const BsrDev &A, Buf2 X, int selX, const double *G, Buf2 Y,
                      int selY, double *partials, Gate g) {
   const int grid = spmm_bsr_grid(A.nbrows);
-  static const bool v1 = [] {  // DCORA_BSR_KERNEL=v1: the LDS-staged form (A/B measurements, tests of both forms)
+  // DCORA_BSR_KERNEL=v1: the LDS-staged form, v3: 16-byte gathers (A/B measurements, tests); default: k_spmm_bsr2
+  static const int form = [] {
     const char *e = std::getenv("DCORA_BSR_KERNEL");
-    return e && std::strcmp(e, "v1") == 0;
+    return !e ? 2 : std::strcmp(e, "v1") == 0 ? 1 : std::strcmp(e, "v3") == 0 ? 3 : 2;
   }();
+  const bool v1 = form == 1;
+  if (form == 3 && d == 3 && r >= 2 && r <= 8) {
+    if (partials)
+      hipLaunchKernelGGL((k_spmm_bsr3<true>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials, g);
+    else
+      hipLaunchKernelGGL((k_spmm_bsr3<false>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials, g);
+    return;
+  }
   if (!v1) {
     if (d == 3 && partials)
       hipLaunchKernelGGL((k_spmm_bsr2<3, true>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials, g);

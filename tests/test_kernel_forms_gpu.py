@@ -1,5 +1,6 @@
-"""Two forms of two hot kernels live side by side (the choice is read once per process): the block Q-apply without LDS
-(k_spmm_bsr2) against the LDS-staged one (DCORA_BSR_KERNEL=v1), which must agree BITWISE (same summation order), and the
+"""Forms of two hot kernels live side by side (the choice is read once per process): the block Q-apply without LDS
+(k_spmm_bsr2, the default) against the LDS-staged one (DCORA_BSR_KERNEL=v1), which must agree BITWISE (same
+summation order), the form with 16-byte gathers (k_spmm_bsr3, DCORA_BSR_KERNEL=v3) against both to rounding, and the
 entry-per-lane level kernel of the sparse preconditioner (k_sp_level2) against the (entry, value)-per-lane one
 (DCORA_SP_KERNEL=v1), which sum in a different order and must agree to rounding.  One child process per form."""
 import os
@@ -58,11 +59,14 @@ def test_both_forms_of_the_block_qapply_and_of_the_level_kernel_agree(built, tmp
         pytest.skip("DCORA_SOLVER_V1 switches the block Q-apply off")
     new = _run(tmp_path, "new", {})
     old = _run(tmp_path, "old", {"DCORA_BSR_KERNEL": "v1", "DCORA_SP_KERNEL": "v1"})
-    assert set(new.files) == set(old.files)
+    v3 = _run(tmp_path, "v3", {"DCORA_BSR_KERNEL": "v3"})  # 16-byte gathers, column pairs summed per pose (another order)
+    assert set(new.files) == set(old.files) == set(v3.files)
     for key in new.files:
         if key.endswith("_info"):
             assert not new[key][0] and new[key][1], key   # the block Q-apply and the sparse preconditioner ran
         elif key.endswith("_z"):
             assert common.rel(new[key], old[key]) < 1e-12, key
+            assert common.rel(v3[key], old[key]) < 1e-12, key
         else:
             assert np.array_equal(new[key], old[key]), key
+            assert common.rel(v3[key], old[key]) < 1e-13, key
