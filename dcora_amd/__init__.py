@@ -619,6 +619,21 @@ class Exchange:
                     peers=int(v[1]), posts=int(v[2]), waits=int(v[3]), bytes_posted=float(v[4]), post_s=float(v[5]),
                     wait_s=float(v[6]), eval_wait_s=float(v[7]))
 
+    def certify(self, Q, eta, k):
+        """fastVerification of the current iterate across the ranks (dcora_exchange_certify); Q: the global Csr on rank 0,
+        None elsewhere; k = (d + 1) n.  -> (certified, theta, lambda_min of S + eta I, v, matvecs, distributed)"""
+        cert, dist = C.c_int(), C.c_int()
+        th, lm, mv = C.c_double(), C.c_double(), C.c_longlong()
+        v = np.zeros(k)
+        if Q is None:
+            check(capi.lib().dcora_exchange_certify(self.h, k, None, None, None, eta, C.byref(cert), C.byref(th),
+                                                    C.byref(lm), v, C.byref(mv), C.byref(dist)))
+        else:
+            check(capi.lib().dcora_exchange_certify(self.h, k, Q.rp.ctypes.data, Q.ci.ctypes.data, Q.v.ctypes.data, eta,
+                                                    C.byref(cert), C.byref(th), C.byref(lm), v, C.byref(mv),
+                                                    C.byref(dist)))
+        return bool(cert.value), th.value, lm.value, v, mv.value, bool(dist.value)
+
     def post(self, agents):
         a = np.ascontiguousarray(agents, dtype=np.int32)
         check(capi.lib().dcora_exchange_post(self.h, a, a.size))

@@ -152,6 +152,8 @@ SIGNATURES = {
     "dcora_exchange_set_X": (C.c_int, [_vp, _dp]),
     "dcora_exchange_gather_X": (C.c_int, [_vp, _dp]),
     "dcora_exchange_barrier": (C.c_int, [_vp]),
+    "dcora_exchange_certify": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_double, _PI, _PD, _PD, _dp,
+                                         C.POINTER(C.c_longlong), _PI]),
     "dcora_exchange_host_selftest": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, _PD]),
     "dcora_debug_exchange_leave_stale": (C.c_int, [C.c_char_p, C.c_int, C.c_int]),
     "dcora_ra_rbcd_create": (C.c_int, [_vp, C.POINTER(RbcdOptions), C.POINTER(_vp)]),

@@ -966,6 +966,18 @@ int dcora_exchange_host_selftest(const char *job_name, int rank, int world_size,
   return e.host_selftest(job_name, rank, world_size, num_agents, rounds, checksum);
   DCORA_CATCH
 }
+int dcora_exchange_certify(dcora_exchange_t ex, int k, const int *rowptr, const int *colidx, const double *vals,
+                           double eta, int *certified, double *theta, double *lambda_min, double *v, long long *matvecs,
+                           int *distributed) {
+  if (!ex) return bad("null");
+  DCORA_TRY
+  if (rowptr && colidx && vals) {
+    const HostCsr Q = view_csr(k, rowptr, colidx, vals);
+    return ex->e.certify(&Q, eta, certified, theta, lambda_min, v, matvecs, distributed);
+  }
+  return ex->e.certify(nullptr, eta, certified, theta, lambda_min, v, matvecs, distributed);
+  DCORA_CATCH
+}
 int dcora_debug_exchange_leave_stale(const char *job_name, int world_size, int num_agents) {
   if (!job_name) return bad("null");
   DCORA_TRY

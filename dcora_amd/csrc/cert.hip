@@ -92,8 +92,24 @@ int DeviceLanczos::init(const HostCsr &S, int device_) {
   DCORA_HIP(small.alloc(1024));
   return DCORA_OK;
 }
+int DeviceLanczos::init_rows(int n_local, int n_global_, int lo_, int device_, hipStream_t stream) {
+  device = device_;
+  n = n_local;
+  n_global = n_global_;
+  lo = lo_;
+  st = stream;
+  own_stream = false;
+  DCORA_HIP(hipSetDevice(device));
+  const size_t nn = (size_t)std::max(n, 1);
+  DCORA_HIP(V.alloc(nn * (kMaxNcv + 1)));
+  DCORA_HIP(Vtmp.alloc(nn * kMaxNcv));
+  DCORA_HIP(w.alloc(nn));
+  DCORA_HIP(part.alloc((size_t)kMaxPartials * 24));
+  DCORA_HIP(small.alloc(1024));
+  return DCORA_OK;
+}
 DeviceLanczos::~DeviceLanczos() {
-  if (st) (void)hipStreamDestroy(st);
+  if (st && own_stream) (void)hipStreamDestroy(st);
 }
 
 // Thick-restart Lanczos for the largest-magnitude eigenpair of (S - shift I).  Convergence test and the
@@ -105,22 +121,42 @@ int DeviceLanczos::largest_magnitude(double shift, int ncv, int maxit, double to
   out->ok = false;
   out->v.assign(n, 0.0);
   out->matvecs = 0;
-  if (n == 0) return DCORA_OK;
-  const int m = std::min(std::min(ncv, kMaxNcv), n);
+  const bool rows = (bool)allreduce;          // row-block form: sums over the ranks after every local reduction
+  const int ng = rows ? n_global : n;         // order of the whole problem
+  if (ng == 0) return DCORA_OK;
+  const int m = std::min(std::min(ncv, kMaxNcv), ng);
   const int keep = std::max(1, std::min(m - 1, m / 2));
-  std::vector<double> H((size_t)m * m, 0.0), Z, th, host_v(n), hbuf(64);
-  {
-    uint64_t s = seed ? seed : 1;
+  std::vector<double> H((size_t)m * m, 0.0), Z, th, host_v((size_t)std::max(n, 1)), hbuf(64);
+  // a vector of the whole problem from the seeded stream (or x0, given for the whole problem), this rank's slice of it
+  auto whole_vector = [&](uint64_t s, const double *given, double *norm) {
     double nn = 0;
-    for (int i = 0; i < n; ++i) {
-      host_v[i] = x0 ? x0[i] : (u01(s) - 0.5);
-      nn += host_v[i] * host_v[i];
+    for (int i = 0; i < ng; ++i) {
+      const double x = given ? given[i] : (u01(s) - 0.5);
+      if (i >= lo && i < lo + n) host_v[(size_t)(i - lo)] = x;
+      nn += x * x;
     }
-    nn = std::sqrt(nn);
+    *norm = std::sqrt(nn);
+  };
+  if (!rows) lo = 0;
+  {
+    double nn = 0;
+    whole_vector(seed ? seed : 1, x0, &nn);
     for (double &x : host_v) x /= nn;
     DCORA_HIP(hipMemcpyAsync(V.p, host_v.data(), sizeof(double) * n, hipMemcpyHostToDevice, st));
     DCORA_HIP(hipStreamSynchronize(st));
   }
+  // sums over the ranks of `count` doubles that sit on the device at dev (no-op on one rank)
+  auto reduce_dev = [&](double *dev, int count) -> int {
+    if (!rows) return DCORA_OK;
+    std::vector<double> tmp((size_t)count);
+    DCORA_HIP(hipMemcpyAsync(tmp.data(), dev, sizeof(double) * count, hipMemcpyDeviceToHost, st));
+    DCORA_HIP(hipStreamSynchronize(st));
+    const int rc2 = allreduce(tmp.data(), count);
+    if (rc2) return rc2;
+    DCORA_HIP(hipMemcpyAsync(dev, tmp.data(), sizeof(double) * count, hipMemcpyHostToDevice, st));
+    DCORA_HIP(hipStreamSynchronize(st));  // tmp leaves scope
+    return DCORA_OK;
+  };
   const double eps23 = std::pow(2.220446049250313e-16, 2.0 / 3.0);
   const int npart = vec_grid(n);
   const CsrDev Sv = Sd.view();
@@ -130,7 +166,11 @@ int DeviceLanczos::largest_magnitude(double shift, int ncv, int maxit, double to
   for (int it = 0; it <= maxit; ++it) {
     for (int j = k; j < m; ++j) {
       double *vj = V.p + (size_t)j * n;
-      if (inverse_op) {
+      if (op) {
+        const int orc = op(vj, w.p);
+        if (orc) return orc;
+        if (shift != 0) launch_scale_shift(st, n, shift, vj, w.p);
+      } else if (inverse_op) {
         inverse_op->apply(st, 1, buf1(vj), w.p, Gate{});
       } else {
         launch_spmm(st, 1, Sv, buf1(vj), 0, nullptr, buf1(w.p), 0, nullptr, Gate{});
@@ -141,10 +181,16 @@ int DeviceLanczos::largest_magnitude(double shift, int ncv, int maxit, double to
       for (int pass = 0; pass < 2; ++pass) {
         launch_lanczos_proj(st, n, nv, V.p, w.p, part.p);
         launch_sum_partials(st, part.p, npart, 24, nv, small.p + 32 * pass);
+        const int rrc = reduce_dev(small.p + 32 * pass, nv);
+        if (rrc) return rrc;
         launch_lanczos_sub(st, n, nv, V.p, small.p + 32 * pass, w.p);
       }
       launch_dot(st, n, w.p, w.p, part.p);
       launch_sum_partials(st, part.p, npart, 1, 1, small.p + 64);
+      {
+        const int rrc = reduce_dev(small.p + 64, 1);
+        if (rrc) return rrc;
+      }
       DCORA_HIP(hipMemcpyAsync(hbuf.data(), small.p, sizeof(double) * 64, hipMemcpyDeviceToHost, st));
       double b2 = 0;
       DCORA_HIP(hipMemcpyAsync(&b2, small.p + 64, sizeof(double), hipMemcpyDeviceToHost, st));
@@ -157,16 +203,22 @@ int DeviceLanczos::largest_magnitude(double shift, int ncv, int maxit, double to
       beta = std::sqrt(b2);
       if (beta < 1e-300) {
         // invariant subspace: continue with a fresh random direction orthogonalised against the basis
-        uint64_t s = seed + 7919 * (j + 1);
-        for (int i = 0; i < n; ++i) host_v[i] = u01(s) - 0.5;
+        double unused = 0;
+        whole_vector(seed + 7919 * (j + 1), nullptr, &unused);
         DCORA_HIP(hipMemcpyAsync(w.p, host_v.data(), sizeof(double) * n, hipMemcpyHostToDevice, st));
         for (int pass = 0; pass < 2; ++pass) {
           launch_lanczos_proj(st, n, nv, V.p, w.p, part.p);
           launch_sum_partials(st, part.p, npart, 24, nv, small.p);
+          const int rrc = reduce_dev(small.p, nv);
+          if (rrc) return rrc;
           launch_lanczos_sub(st, n, nv, V.p, small.p, w.p);
         }
         launch_dot(st, n, w.p, w.p, part.p);
         launch_sum_partials(st, part.p, npart, 1, 1, small.p + 64);
+        {
+          const int rrc = reduce_dev(small.p + 64, 1);
+          if (rrc) return rrc;
+        }
         launch_scale(st, n, small.p + 64, w.p, V.p + (size_t)(j + 1) * n);
         DCORA_HIP(hipStreamSynchronize(st));
         beta = 0;
@@ -180,8 +232,8 @@ int DeviceLanczos::largest_magnitude(double shift, int ncv, int maxit, double to
     const int b0 = ord[0];
     const double resid = std::fabs(beta * Z[(size_t)(m - 1) * m + b0]);
     const bool conv = resid < tol * std::max(eps23, std::fabs(th[b0]));
-    if (conv || it == maxit || m == n) {
-      out->ok = conv || (m == n);
+    if (conv || it == maxit || m == ng) {
+      out->ok = conv || (m == ng);
       out->lambda = th[b0];
       std::vector<double> zc(m);
       for (int i = 0; i < m; ++i) zc[i] = Z[(size_t)i * m + b0];
@@ -192,6 +244,10 @@ int DeviceLanczos::largest_magnitude(double shift, int ncv, int maxit, double to
       DCORA_HIP(hipStreamSynchronize(st));
       double nn = 0;
       for (double x : out->v) nn += x * x;
+      if (rows) {
+        const int rrc = allreduce(&nn, 1);
+        if (rrc) return rrc;
+      }
       nn = std::sqrt(nn);
       for (double &x : out->v) x /= nn;
       return DCORA_OK;
@@ -212,6 +268,25 @@ int DeviceLanczos::largest_magnitude(double shift, int ncv, int maxit, double to
     k = keep;
   }
   return DCORA_OK;
+}
+
+// start vector of the spectrum-shifted run: the first row of the matrix with a ~3 % random perturbation
+// (ref src/DCORA_utils.cpp:1861-1866)
+std::vector<double> min_eig_second_start(const HostCsr &S, uint64_t seed) {
+  const int k = S.n;
+  std::vector<double> x0((size_t)k, 0.0), pert((size_t)k);
+  for (int p = S.rp[0]; p < S.rp[1]; ++p) x0[S.ci[p]] = S.v[p];
+  uint64_t s = seed + 17;
+  double pn = 0, vn = 0;
+  for (int i = 0; i < k; ++i) {
+    pert[i] = 2 * u01(s) - 1;
+    pn += pert[i] * pert[i];
+    vn += x0[i] * x0[i];
+  }
+  pn = std::sqrt(pn);
+  vn = std::sqrt(vn);
+  for (int i = 0; i < k; ++i) x0[i] += 0.03 * vn * pert[i] / pn;
+  return x0;
 }
 
 // ref src/DCORA_utils.cpp:1809-1896
@@ -235,18 +310,7 @@ int device_min_eig(const HostCsr &S, int maxit, double min_eig_tol, int ncv, uin
     return DCORA_OK;
   }
   const double lambda_lm = lm.lambda;
-  std::vector<double> x0(k, 0.0), pert(k);
-  for (int p = S.rp[0]; p < S.rp[1]; ++p) x0[S.ci[p]] = S.v[p];
-  uint64_t s = seed + 17;
-  double pn = 0, vn = 0;
-  for (int i = 0; i < k; ++i) {
-    pert[i] = 2 * u01(s) - 1;
-    pn += pert[i] * pert[i];
-    vn += x0[i] * x0[i];
-  }
-  pn = std::sqrt(pn);
-  vn = std::sqrt(vn);
-  for (int i = 0; i < k; ++i) x0[i] += 0.03 * vn * pert[i] / pn;  // ~3 % perturbation, :1861-1866
+  const std::vector<double> x0 = min_eig_second_start(S, seed);
   LanczosResult sh;
   rc = L.largest_magnitude(2 * lambda_lm, ncv, maxit, min_eig_tol / lambda_lm, x0.data(), seed, &sh);
   if (rc) return rc;

@@ -39,6 +39,10 @@ struct alignas(64) ShmRank {
   std::atomic<uint64_t> bus;  // hash of the device's PCI bus id: two ranks with the same value share a GPU
   uint64_t pad[5];
 };
+struct alignas(64) ShmRed {  // one rank's contribution to a sum over the ranks
+  volatile uint64_t seq;
+  double vals[31];
+};
 struct ShmHeader {
   std::atomic<uint32_t> magic;
   uint32_t world, R;
@@ -56,6 +60,18 @@ class Exchange {
   int init(RbcdSession *s, const char *job_name);
   int post(const int *agents, int count);
   int wait(const int *agents, int count);
+  int post_arr(const int *agents, int count, int r, const double *arr);
+  int wait_arr(const int *agents, int count, int r, double *arr);
+  // sum of `count` (<= 31) doubles over the ranks, added in rank order: the same bits on every rank
+  int allreduce_sum(double *vals, int count);
+  // Certification across the ranks ("Collective"): fastVerification (ref src/DCORA_utils.cpp:1713-1735)
+  // of the current iterate.  The PSD test runs on rank 0 (it assembles S from the gathered X and the global Q it is
+  // given; Qglobal may be null on the other ranks); when it fails, the minimum eigenpair of S + eta I is computed by
+  // ALL ranks: each applies its row block of S (its agents' Q_bb and coupling blocks, the Lambda blocks of its poses)
+  // to its slice of the Lanczos vectors, the public entries travel like public poses, every inner product is an
+  // allreduce_sum.  v (may be null): the eigenvector, (d+1) n doubles, the same on every rank.
+  int certify(const HostCsr *Qglobal, double eta, int *certified, double *theta, double *lambda_min, double *v,
+              long long *matvecs, int *distributed);
   int evaluate(double *cost2, double *gradnorm, double *block_norms, int *next_selected);
   int rbcd_iterate(int selected, double *cost2, double *gradnorm, double *block_norms, int *next_selected);
   int rbcd_tick(const int *set, int count, int allow_adjacent);
@@ -92,6 +108,9 @@ class Exchange {
   ShmEval *evals_ = nullptr;  // [parity][agent]
   double *staged_ = nullptr;  // [parity][agent][slot]
   double *xarea_ = nullptr;   // r x (d+1) n
+  ShmRed *red_ = nullptr;        // [parity][rank]
+  size_t off_red_ = 0;
+  uint64_t red_seq_ = 0;
   ShmFlag *consumed_ = nullptr;  // [consumer rank][agent]: the last post of the agent that rank has scattered
   size_t off_flags_ = 0, off_evals_ = 0, off_staged_ = 0, off_x_ = 0, off_consumed_ = 0;
   size_t devflag_off_ = 0;       // in a halo buffer, behind the slots and the self-test area: [parity][agent] x 64 bytes

@@ -257,6 +257,8 @@ int Exchange::map_segment(const char *job_name, size_t x_doubles) {
   off += sizeof(ShmEval) * 2 * (R + world);  // R agent slots + one heartbeat slot per rank, double-buffered
   off_consumed_ = off;
   off += sizeof(ShmFlag) * (size_t)world * R;
+  off_red_ = off;
+  off += sizeof(ShmRed) * 2 * (size_t)world;
   off = align_up(off, 4096);
   off_staged_ = off;
   off += sizeof(double) * 2 * R * slot_;
@@ -270,6 +272,7 @@ int Exchange::map_segment(const char *job_name, size_t x_doubles) {
   flags_ = (ShmFlag *)((char *)map_ + off_flags_);
   evals_ = (ShmEval *)((char *)map_ + off_evals_);
   consumed_ = (ShmFlag *)((char *)map_ + off_consumed_);
+  red_ = (ShmRed *)((char *)map_ + off_red_);
   staged_ = (double *)((char *)map_ + off_staged_);
   xarea_ = (double *)((char *)map_ + off_x_);
   return DCORA_OK;
@@ -495,10 +498,14 @@ int Exchange::setup_ipc(bool attempt) {
   return ok ? DCORA_OK : DCORA_ERR_UNSUPPORTED;
 }
 
-int Exchange::post(const int *agents, int count) {
+int Exchange::post(const int *agents, int count) { return post_arr(agents, count, s_->r, s_->Xg.p); }
+int Exchange::wait(const int *agents, int count) { return wait_arr(agents, count, s_->r, s_->Xg.p); }
+
+// the same exchange for any r x (d+1)n array laid out like X (the certificate's vectors: r = 1)
+int Exchange::post_arr(const int *agents, int count, int r, const double *arr) {
   const auto t0 = Clock::now();
   DCORA_HIP(hipSetDevice(s_->opt.device));
-  const int R = s_->R, r = s_->r, dh = s_->d + 1;
+  const int R = s_->R, dh = s_->d + 1;
   for (int i = 0; i < count; ++i) {
     const int a = agents[i];
     if (a < 0 || a >= R) return fail("post: agent out of range", DCORA_ERR_BAD_ARG);
@@ -539,7 +546,7 @@ int Exchange::post(const int *agents, int count) {
     const long N = (long)ncols * r;
     const int grid = (int)std::min<long>((N + kBlock - 1) / kBlock, 64);
     volatile uint64_t *flag = (volatile uint64_t *)(dev_map_ + off_flags_ + sizeof(ShmFlag) * ((size_t)parity * R + a));
-    hipLaunchKernelGGL(k_post_public, dim3(grid), dim3(kBlock), 0, s_->st, r, ncols, ag.public_cols.p, s_->Xg.p, dst,
+    hipLaunchKernelGGL(k_post_public, dim3(grid), dim3(kBlock), 0, s_->st, r, ncols, ag.public_cols.p, arr, dst,
                        dflag, arrive_.p + a, flag, q);
     bytes_posted += 8.0 * N * dst.n;
     ++posts;
@@ -549,10 +556,10 @@ int Exchange::post(const int *agents, int count) {
   return DCORA_OK;
 }
 
-int Exchange::wait(const int *agents, int count) {
+int Exchange::wait_arr(const int *agents, int count, int r, double *arr) {
   const auto t0 = Clock::now();
   DCORA_HIP(hipSetDevice(s_->opt.device));
-  const int R = s_->R, r = s_->r, dh = s_->d + 1;
+  const int R = s_->R, dh = s_->d + 1;
   for (int i = 0; i < count; ++i) {
     const int a = agents[i];
     if (a < 0 || a >= R) return fail("wait: agent out of range", DCORA_ERR_BAD_ARG);
@@ -586,7 +593,7 @@ int Exchange::wait(const int *agents, int count) {
     uint32_t *failed = (uint32_t *)(dev_map_ + offsetof(ShmHeader, failed));
     // updateNeighborStates: into the local mirror of X
     hipLaunchKernelGGL(k_wait_scatter, dim3(grid), dim3(kBlock), 0, s_->st, r, ncols, s_->agents[a].public_cols.p, src,
-                       s_->Xg.p, dflag, want, arrive2_.p + a, cons, failed);
+                       arr, dflag, want, arrive2_.p + a, cons, failed);
     ++waits;
   }
   wait_s += since(t0);

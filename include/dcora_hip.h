@@ -352,6 +352,20 @@ int dcora_exchange_set_X(dcora_exchange_t ex, const double *X);
 int dcora_exchange_gather_X(dcora_exchange_t ex, double *X);
 /* host barrier over the ranks of the job (does not synchronise the device) */
 int dcora_exchange_barrier(dcora_exchange_t ex);
+/* fastVerification of the current iterate across the ranks (ref src/DCORA_utils.cpp:1713-1735 on the global
+ * S = Q - Lambda(X); the driver calls it where examples/MultiRobotExample.cpp:329-330 does).  SPMD.  The global
+ * connection Laplacian Q (k = (d+1) n, CSR) is needed on rank 0 only (NULL elsewhere): rank 0 assembles S from the
+ * gathered X and runs the PSD test (Cholesky of S + eta I on its device).  When that fails the minimum eigenpair of
+ * S + eta I is computed by ALL ranks: each applies the row block of S of the agents it hosts (Q_bb, the coupling
+ * blocks, the Lambda blocks of its poses) to its slice of the Lanczos vectors, the public entries travel between
+ * neighbouring ranks like public poses, and every inner product is summed over the ranks through the shared segment in
+ * rank order (the same bits everywhere).  *certified: 1 = S + eta I >= 0; otherwise *theta = v^T S v (the curvature
+ * escapeSaddle takes), *lambda_min = the eigenvalue of S + eta I, v (NULL or k doubles) its unit eigenvector, the same
+ * on every rank; *distributed: 1 when the eigenpair came from the row-block Lanczos runs, 0 when they did not
+ * converge and rank 0's shift-and-invert fallback (a factorisation of the whole matrix) supplied it. */
+int dcora_exchange_certify(dcora_exchange_t ex, int k, const int *rowptr, const int *colidx, const double *vals,
+                           double eta, int *certified, double *theta, double *lambda_min, double *v, long long *matvecs,
+                           int *distributed);
 /* the host half of the protocol alone, without a device: bootstrap through the shared segment, barriers, and
  * `rounds` rounds of post -> wait -> evaluation all-gather with host stores in the device's place; every rank of the
  * job calls it, *checksum comes out identical on all of them.  For multi-process tests on machines without a GPU. */

@@ -43,13 +43,20 @@ def main():
             cost.append(c2)
             gn.append(g)
             sel.append(nxt)
+    cert = None
+    if os.environ.get("DCORA_TEST_CERTIFY"):
+        eta = float(os.environ["DCORA_TEST_CERTIFY"])
+        Q = da.build_Q_pgo(ds) if rank == 0 else None
+        cert = ex.certify(Q, eta, (ds.d + 1) * ds.n)
     X = ex.gather_X()
     info = ex.info()
     ex.barrier()
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), cost=np.array(cost), gradnorm=np.array(gn),
              selected=np.array(sel), X=X, mode=info["mode"], posts=info["posts"], waits=info["waits"],
              bytes_posted=info["bytes_posted"], peers=info["peers"], finegrained=info["halo_finegrained"],
-             wait=info["wait"], device=device)
+             wait=info["wait"], device=device,
+             **({} if cert is None else dict(cert_ok=cert[0], cert_theta=cert[1], cert_lambda=cert[2], cert_v=cert[3],
+                                             cert_matvecs=cert[4], cert_distributed=cert[5])))
     ex.close()
     s.close()
 

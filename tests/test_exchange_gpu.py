@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 WORKER = os.path.join(common.HERE, "exchange_worker.py")
 
 
-def run_ranks(tmp_path, world, name, R, r, iters, mode, X0, transport=None, wait=None):
+def run_ranks(tmp_path, world, name, R, r, iters, mode, X0, transport=None, wait=None, certify=None):
     np.save(os.path.join(tmp_path, "X0.npy"), X0)
     job = "t%s" % uuid.uuid4().hex[:12]
     env = dict(os.environ)
@@ -31,6 +31,10 @@ def run_ranks(tmp_path, world, name, R, r, iters, mode, X0, transport=None, wait
         env["DCORA_EXCHANGE_WAIT"] = wait
     else:
         env.pop("DCORA_EXCHANGE_WAIT", None)
+    if certify is not None:
+        env["DCORA_TEST_CERTIFY"] = repr(certify)
+    else:
+        env.pop("DCORA_TEST_CERTIFY", None)
     procs = [subprocess.Popen([sys.executable, WORKER, str(k), str(world), job, name, str(R), str(r), str(iters),
                                str(tmp_path), mode], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
              for k in range(world)]
@@ -110,6 +114,38 @@ def test_ranks_reproduce_single_session(tmp_path, name, R, world, iters, mode, t
     # neighbour-only traffic: ranks that host agents post, and only to ranks hosting their neighbours
     assert sum(int(o["posts"]) for o in res) > 0
     assert all(int(o["peers"]) <= world - 1 for o in res)
+
+
+@pytest.mark.parametrize("name,R,world,iters", [("sphere2500", 5, 2, 25), ("torus3D", 8, 4, 12), ("sphere2500", 5, 4, 8)])
+def test_certification_across_ranks_matches_one_gpu(tmp_path, name, R, world, iters):
+    """dcora_exchange_certify (SURVEY 8(e) "Collective": row-block S v with the halo exchange, inner products summed
+    over the ranks) against fastVerification of the same iterate on one GPU: same verdict, lambda_min and theta, and
+    the eigenvector up to its sign.  A few RBCD iterations from a random start leave a saddle direction, so the
+    eigenpair -- the distributed part -- is what gets compared."""
+    import dcora_amd as da
+    ds = common.product_dataset(name)
+    r, eta = 5, 1e-3
+    X0 = common.random_point(r, ds.d, ds.n, 11, lambda r_, d_, n_, M: da.manifold_project(r_, d_, n_, M))
+    res = run_ranks(str(tmp_path), world, name, R, r, iters, "greedy", X0, certify=eta)
+    X = res[0]["X"]
+    Q = da.build_Q_pgo(ds)
+    S = da.dual_certificate(r, ds.d, ds.n, X, Q)
+    psd, theta, v, lmin = da.fast_verification(S, eta, block=ds.d + 1)
+    A = S.to_scipy()
+    for k, o in enumerate(res):
+        assert bool(o["cert_ok"]) == bool(psd) == False
+        assert bool(o["cert_distributed"]), "rank %d: the row-block Lanczos runs did not converge" % k
+        assert int(o["cert_matvecs"]) > 0
+        lam, th, vv = float(o["cert_lambda"]), float(o["cert_theta"]), o["cert_v"]
+        assert abs(lam - lmin) <= 1e-6 * max(1.0, abs(lmin)), (lam, lmin)
+        assert abs(np.linalg.norm(vv) - 1) < 1e-12
+        assert abs(th - vv @ (A @ vv)) <= 1e-9 * max(1.0, abs(th))          # theta is the curvature along v
+        assert abs(th - theta) <= 1e-5 * max(1.0, abs(theta)), (th, theta)
+        assert min(np.linalg.norm(vv - v), np.linalg.norm(vv + v)) < 1e-3
+        # (S + eta I) v = lambda v to the tolerance of the run
+        assert np.linalg.norm(A @ vv + eta * vv - lam * vv) < 1e-3 * max(1.0, abs(lam))
+        # every rank holds the same bits
+        assert np.array_equal(vv, res[0]["cert_v"]) and lam == float(res[0]["cert_lambda"])
 
 
 class Hip:
