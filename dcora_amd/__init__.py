@@ -619,6 +619,12 @@ class Exchange:
                     peers=int(v[1]), posts=int(v[2]), waits=int(v[3]), bytes_posted=float(v[4]), post_s=float(v[5]),
                     wait_s=float(v[6]), eval_wait_s=float(v[7]))
 
+    def all_ready(self, ready):
+        """AND over the ranks of `ready` (Agent::shouldTerminate's team condition, ref src/Agent.cpp:1137-1153)"""
+        out = C.c_int()
+        check(capi.lib().dcora_exchange_all_ready(self.h, int(bool(ready)), C.byref(out)))
+        return bool(out.value)
+
     def certify(self, Q, eta, k):
         """fastVerification of the current iterate across the ranks (dcora_exchange_certify); Q: the global Csr on rank 0,
         None elsewhere; k = (d + 1) n.  -> (certified, theta, lambda_min of S + eta I, v, matvecs, distributed)"""

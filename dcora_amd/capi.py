@@ -130,6 +130,8 @@ SIGNATURES = {
     "dcora_rbcd_agent_iterate": (C.c_int, [_vp, C.c_int, C.c_int]),
     "dcora_rbcd_agent_get_X": (C.c_int, [_vp, C.c_int, _dp]),
     "dcora_rbcd_agent_set_X": (C.c_int, [_vp, C.c_int, _dp]),
+    "dcora_rbcd_agent_update_neighbor": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _ip, _dp, C.c_int]),
+    "dcora_rbcd_agent_last_skipped": (C.c_int, [_vp, C.c_int, _PI]),
     "dcora_rbcd_agent_info": (C.c_int, [_vp, C.c_int, _PI, _PI, _PI]),
     "dcora_rbcd_last_result": (C.c_int, [_vp, C.POINTER(ROptResult)]),
     "dcora_rbcd_X_device_ptr": (C.c_int, [_vp, C.POINTER(_vp)]),
@@ -152,6 +154,7 @@ SIGNATURES = {
     "dcora_exchange_set_X": (C.c_int, [_vp, _dp]),
     "dcora_exchange_gather_X": (C.c_int, [_vp, _dp]),
     "dcora_exchange_barrier": (C.c_int, [_vp]),
+    "dcora_exchange_all_ready": (C.c_int, [_vp, C.c_int, _PI]),
     "dcora_exchange_certify": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, C.c_double, _PI, _PD, _PD, _dp,
                                          C.POINTER(C.c_longlong), _PI]),
     "dcora_exchange_host_selftest": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, _PD]),

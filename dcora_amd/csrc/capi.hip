@@ -824,6 +824,18 @@ int dcora_rbcd_agent_iterate(dcora_rbcd_t s, int agent, int do_optimization) {
   return s->s.agent_iterate(agent, do_optimization != 0);
   DCORA_CATCH
 }
+int dcora_rbcd_agent_update_neighbor(dcora_rbcd_t s, int agent, int neighbor, int count, const int *frames,
+                                     const double *poses, int auxiliary) {
+  if (!s || (count > 0 && (!frames || !poses))) return bad("null");
+  DCORA_TRY
+  return s->s.agent_update_neighbor(agent, neighbor, count, frames, poses, auxiliary != 0);
+  DCORA_CATCH
+}
+int dcora_rbcd_agent_last_skipped(dcora_rbcd_t s, int agent, int *skipped) {
+  if (!s || !skipped || agent < 0 || agent >= s->s.R) return bad("bad agent");
+  *skipped = s->s.agents[agent].last_skipped ? 1 : 0;
+  return DCORA_OK;
+}
 int dcora_rbcd_agent_get_X(dcora_rbcd_t s, int agent, double *X) {
   return (s && X) ? s->s.agent_get_X(agent, X) : bad("null");
 }
@@ -976,6 +988,16 @@ int dcora_exchange_certify(dcora_exchange_t ex, int k, const int *rowptr, const 
     return ex->e.certify(&Q, eta, certified, theta, lambda_min, v, matvecs, distributed);
   }
   return ex->e.certify(nullptr, eta, certified, theta, lambda_min, v, matvecs, distributed);
+  DCORA_CATCH
+}
+int dcora_exchange_all_ready(dcora_exchange_t ex, int ready, int *all_ready) {
+  if (!ex || !all_ready) return bad("null");
+  DCORA_TRY
+  double notready = ready ? 0.0 : 1.0;
+  const int rc = ex->e.allreduce_sum(&notready, 1);
+  if (rc) return rc;
+  *all_ready = notready == 0.0 ? 1 : 0;
+  return DCORA_OK;
   DCORA_CATCH
 }
 int dcora_debug_exchange_leave_stale(const char *job_name, int world_size, int num_agents) {

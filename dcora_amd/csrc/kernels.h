@@ -239,7 +239,8 @@ int launch_g_rgrad(hipStream_t st, const ManiDesc &m, Buf2 X, Buf2 EG, Buf2 RG, 
 void launch_ctl_init(hipStream_t st, SolverCtl *c, double tol, double Delta, double maxDelta, int max_outer,
                      int stop_on_accept, int max_inner);
 void launch_eval_finish(hipStream_t st, int R, const int *pose_start, const double *posenorm, const double *pA,
-                        int npA, EvalOut *out_dev, int seq);
+                        int npA, EvalOut *out_dev, int seq, double *split_scratch = nullptr, int nposes = 0);
+int eval_split_doubles();
 int launch_g_retract(hipStream_t st, const ManiDesc &m, Buf2 X, const double *V, double alpha, Buf2 out, int selOut,
                      Buf2 grad, const double *HV, double *partials, Gate g);
 void launch_g_nesterov(hipStream_t st, const ManiDesc &m, int mode, int restart, int skip_lo, int skip_hi,

@@ -17,9 +17,22 @@ struct PrecondKey {
   uint64_t h0 = 0, h1 = 0;
   int k = 0, nnz = 0, block = 0, device = 0, sparse = 0;
   double reg = 0;
+  // A hit attaches another problem's inverse: two 64-bit hashes are not left to decide that alone.  The guard holds
+  // what a colliding matrix would also have to reproduce exactly: the plain sums of its values and of its column
+  // indices (independent of the hash's mixing) and 24 entries sampled at fixed strides (value, column index, and the
+  // row pointers at those strides).
+  static constexpr int kSamples = 24;
+  double vsum = 0, vabs = 0;
+  long long cisum = 0;
+  double vsample[kSamples] = {0};
+  int cisample[kSamples] = {0}, rpsample[kSamples] = {0};
   bool operator==(const PrecondKey &o) const {
-    return h0 == o.h0 && h1 == o.h1 && k == o.k && nnz == o.nnz && block == o.block && device == o.device &&
-           sparse == o.sparse && reg == o.reg;
+    if (!(h0 == o.h0 && h1 == o.h1 && k == o.k && nnz == o.nnz && block == o.block && device == o.device &&
+          sparse == o.sparse && reg == o.reg && vsum == o.vsum && vabs == o.vabs && cisum == o.cisum))
+      return false;
+    for (int i = 0; i < kSamples; ++i)
+      if (vsample[i] != o.vsample[i] || cisample[i] != o.cisample[i] || rpsample[i] != o.rpsample[i]) return false;
+    return true;
   }
 };
 PrecondKey make_precond_key(const HostCsr &Q, double reg, int block, int device, bool sparse);

@@ -64,6 +64,20 @@ PrecondKey make_precond_key(const HostCsr &Q, double reg, int block, int device,
   hash_bytes(Q.rp.data(), Q.rp.size() * sizeof(int), &k.h0, &k.h1);
   hash_bytes(Q.ci.data(), Q.ci.size() * sizeof(int), &k.h0, &k.h1);
   hash_bytes(Q.v.data(), Q.v.size() * sizeof(double), &k.h0, &k.h1);
+  const size_t nz = Q.ci.size(), nr = Q.rp.size();
+  for (size_t i = 0; i < nz; ++i) {
+    k.vsum += Q.v[i];
+    k.vabs += Q.v[i] < 0 ? -Q.v[i] : Q.v[i];
+    k.cisum += Q.ci[i];
+  }
+  for (int q = 0; q < PrecondKey::kSamples; ++q) {
+    if (nz) {
+      const size_t i = (size_t)((double)q / PrecondKey::kSamples * (double)nz);
+      k.vsample[q] = Q.v[i];
+      k.cisample[q] = Q.ci[i];
+    }
+    if (nr) k.rpsample[q] = Q.rp[(size_t)((double)q / PrecondKey::kSamples * (double)nr)];
+  }
   return k;
 }
 

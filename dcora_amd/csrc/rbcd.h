@@ -22,6 +22,17 @@ struct AgentDev {
   std::vector<int> neighbors;           // agents sharing a measurement with me (all agents)
   hipStream_t own = nullptr;            // stream of my solve when several agents update at once (hosted agents only;
   hipEvent_t done = nullptr;            // both owned by the session)
+  // Agent::updateNeighborStates (ref src/Agent.cpp:844-906): once an agent has been HANDED neighbour poses it
+  // optimises against what it was handed -- its own cache of them (neighborPoseDict / neighborAuxPoseDict), stale or
+  // not -- instead of the session's shared mirror.  required: the global poses of other agents my measurements
+  // reach (Graph::requireNeighborPose); nbr[0 / 1]: my copies (plain / auxiliary), laid out like the mirror; got:
+  // which required poses each cache holds.  An optimisation whose cache misses a required pose is skipped
+  // (constructDataMatrices fails, ref src/Agent.cpp:1243-1249).
+  std::vector<int> required;
+  bool detached = false;
+  DevBuf<double> nbr[2];
+  std::vector<char> got[2];
+  bool last_skipped = false;
 };
 
 class RbcdSession {
@@ -35,7 +46,7 @@ class RbcdSession {
   std::unique_ptr<DeviceProblem> central;  // global Q (evaluation); world_size == 1 only
   DevBuf<double> Xg, Vg, Yg, XPrevg;       // r x (d+1) n global mirrors
   DevBuf<int> col_start;                   // R + 1 global column offsets
-  DevBuf<double> evalbuf, posenorm;
+  DevBuf<double> evalbuf, posenorm, eval_split;
   DevBuf<int> pose_start;          // R + 1 global pose offsets
   EvalOut *eval_host = nullptr;    // host-mapped results of the evaluation epilogue
   double *x_stage = nullptr;       // pinned staging buffer of get_X
@@ -65,6 +76,8 @@ class RbcdSession {
   int agent_iterate(int agent, bool do_optimization);
   int agent_get_X(int agent, double *Xh);
   int agent_set_X(int agent, const double *Xh);
+  // count poses of `neighbor` (frames local to it, each r x (d+1) column-major in `poses`) handed to `agent`
+  int agent_update_neighbor(int agent, int neighbor, int count, const int *frames, const double *poses, bool aux);
   std::vector<int> agent_it;  // Agent::iteration_number() of every agent
   // greedy colouring of the agent graph: agents of one colour share no measurement
   int agent_colours(int *colours, int *ncolours) const;

@@ -99,6 +99,7 @@ int RbcdSession::init(const HostDataset &ds, const dcora_rbcd_options &o) {
     return DCORA_ERR_UNSUPPORTED;
   }
   DCORA_HIP(posenorm.alloc(n));
+  DCORA_HIP(eval_split.alloc((size_t)eval_split_doubles()));
   DCORA_HIP(hipHostMalloc((void **)&eval_host, sizeof(EvalOut), hipHostMallocMapped));
   std::memset((void *)eval_host, 0, sizeof(EvalOut));
   DCORA_HIP(hipHostGetDevicePointer((void **)&eval_dev, (void *)eval_host, 0));
@@ -111,7 +112,7 @@ int RbcdSession::init(const HostDataset &ds, const dcora_rbcd_options &o) {
 
   // partition (ref examples/MultiRobotExample.cpp:56-118)
   std::vector<std::vector<PoseMeas>> touching(R);
-  std::vector<std::set<int>> pub(R), nb(R);
+  std::vector<std::set<int>> pub(R), nb(R), req(R);
   for (const PoseMeas &mi : ds.meas) {
     PoseMeas e = mi;
     e.r1 = P.robot_of(mi.p1);
@@ -123,6 +124,8 @@ int RbcdSession::init(const HostDataset &ds, const dcora_rbcd_options &o) {
       touching[e.r2].push_back(e);
       pub[e.r1].insert(mi.p1);
       pub[e.r2].insert(mi.p2);
+      req[e.r1].insert(mi.p2);
+      req[e.r2].insert(mi.p1);
       nb[e.r1].insert(e.r2);
       nb[e.r2].insert(e.r1);
     }
@@ -142,6 +145,7 @@ int RbcdSession::init(const HostDataset &ds, const dcora_rbcd_options &o) {
     a.hosted = (b / ((R + o.world_size - 1) / o.world_size)) == o.rank;  // consecutive agents share a rank
     a.public_poses.assign(pub[b].begin(), pub[b].end());
     a.neighbors.assign(nb[b].begin(), nb[b].end());
+    a.required.assign(req[b].begin(), req[b].end());
     std::vector<int> cols;
     for (int p : a.public_poses)
       for (int c = 0; c < dh; ++c) cols.push_back(p * dh + c);
@@ -356,8 +360,21 @@ int RbcdSession::update_selected_agent(AgentDev &a, bool restart) {
     const size_t off = (size_t)a.col0 * r;
     const size_t B = sizeof(double) * (size_t)pb.nelem();
     // Graph::constructLinearCostTermPGO: G_b = sum_c X_c Q_cb from the neighbours' public poses
-    // (ref src/Graph.cpp:685-822); the mirror Xg holds them after the pull / unpack
-    launch_spmm(st, r, a.coupling.view(), buf1(Xg.p), 0, nullptr, buf1(pb.G.p), 0, nullptr, Gate{});
+    // (ref src/Graph.cpp:685-822); the mirror Xg holds them after the pull / unpack -- or, for an agent that has been
+    // handed poses through Agent::updateNeighborStates, its own cache of them: the auxiliary one when it optimises
+    // from Y (ref src/Agent.cpp:1234-1240)
+    a.last_skipped = false;
+    auto cache_complete = [&](int which) {
+      for (char c : a.got[which])
+        if (!c) return false;
+      return true;
+    };
+    if (a.detached && !cache_complete(opt.acceleration ? 1 : 0)) {
+      a.last_skipped = true;  // "cannot construct data matrices... Skip optimization" (ref src/Agent.cpp:1243-1249)
+      return DCORA_OK;
+    }
+    const double *nsrc = a.detached ? a.nbr[opt.acceleration ? 1 : 0].p : Xg.p;
+    launch_spmm(st, r, a.coupling.view(), buf1(nsrc), 0, nullptr, buf1(pb.G.p), 0, nullptr, Gate{});
     pb.has_G = true;
     Buf2 Xres{{nullptr, nullptr}};
     const SolverCtl *cs = nullptr;
@@ -377,6 +394,12 @@ int RbcdSession::update_selected_agent(AgentDev &a, bool restart) {
       a.v_feasible = true;  // V = proj(V + gamma (X - Y))
       if (restart) {
         // restartNesterovAcceleration: X = XPrev; updateX(true, false); V = X; Y = X
+        if (a.detached) {  // updateX(.., false) reads the PLAIN cache (ref src/Agent.cpp:1237-1240)
+          if (cache_complete(0))
+            launch_spmm(st, r, a.coupling.view(), buf1(a.nbr[0].p), 0, nullptr, buf1(pb.G.p), 0, nullptr, Gate{});
+          else
+            a.last_skipped = true;
+        }
         DCORA_HIP(hipMemcpyAsync(pb.X0.p, XPrevg.p + off, B, hipMemcpyDeviceToDevice, st));
         rc = pb.optimize_dev(opt.local, &Xres, &cs);
         if (rc) return rc;
@@ -452,6 +475,60 @@ int RbcdSession::agent_iterate(int agent, bool do_optimization) {
   return rc;
 }
 
+// Agent::updateNeighborStates (ref src/Agent.cpp:844-906): poses the agent does not require are ignored
+// (Graph::requireNeighborPose); the others go into its plain or auxiliary cache
+int RbcdSession::agent_update_neighbor(int agent, int neighbor, int count, const int *frames, const double *poses,
+                                       bool aux) {
+  if (agent < 0 || agent >= R || neighbor < 0 || neighbor >= R || neighbor == agent || count < 0) {
+    set_last_error("rbcd: bad agent / neighbour");
+    return DCORA_ERR_BAD_ARG;
+  }
+  AgentDev &a = agents[agent];
+  if (!a.hosted) {
+    set_last_error("rbcd: agent is hosted by another rank");
+    return DCORA_ERR_BAD_ARG;
+  }
+  DCORA_HIP(hipSetDevice(opt.device));
+  const int dh = d + 1;
+  const size_t blk = (size_t)r * dh;
+  if (!a.detached) {
+    const size_t N = (size_t)r * dh * n;
+    for (int w = 0; w < 2; ++w) {
+      DCORA_HIP(a.nbr[w].alloc(N));
+      DCORA_HIP(hipMemsetAsync(a.nbr[w].p, 0, sizeof(double) * N, st));
+      a.got[w].assign(a.required.size(), 0);
+    }
+    a.detached = true;
+  }
+  const int which = aux ? 1 : 0;
+  std::vector<double> packed;
+  std::vector<int> cols;
+  for (int q = 0; q < count; ++q) {
+    const int f = frames[q];
+    if (f < 0 || f >= agents[neighbor].n) {
+      set_last_error("rbcd: frame out of range");
+      return DCORA_ERR_BAD_ARG;
+    }
+    const int gp = P.start(neighbor) + f;
+    const auto it = std::lower_bound(a.required.begin(), a.required.end(), gp);
+    if (it == a.required.end() || *it != gp) continue;  // not required: ignored, as in the reference
+    a.got[which][(size_t)(it - a.required.begin())] = 1;
+    packed.insert(packed.end(), poses + (size_t)q * blk, poses + (size_t)(q + 1) * blk);
+    for (int c = 0; c < dh; ++c) cols.push_back(gp * dh + c);
+  }
+  if (!cols.empty()) {
+    DevBuf<double> dp;
+    DevBuf<int> dc;
+    DCORA_HIP(dp.alloc(packed.size()));
+    DCORA_HIP(dc.alloc(cols.size()));
+    DCORA_HIP(hipMemcpyAsync(dp.p, packed.data(), sizeof(double) * packed.size(), hipMemcpyHostToDevice, st));
+    DCORA_HIP(hipMemcpyAsync(dc.p, cols.data(), sizeof(int) * cols.size(), hipMemcpyHostToDevice, st));
+    launch_scatter_cols(st, r, (int)cols.size(), dc.p, dp.p, a.nbr[which].p);
+    DCORA_HIP(hipStreamSynchronize(st));  // the staging buffers leave scope
+  }
+  return DCORA_OK;
+}
+
 int RbcdSession::agent_get_X(int agent, double *Xh) {
   if (agent < 0 || agent >= R) {
     set_last_error("rbcd: agent out of range");
@@ -517,7 +594,7 @@ int RbcdSession::evaluate_central(double *cost2, double *gradnorm, double *block
     else
       c.enq_rgrad(buf1(Xg.p), buf1(c.EG0.p), buf1(c.RG0.p), Buf2{{nullptr, nullptr}}, 0, c.pB.p, Gate{}, posenorm.p);
     const int want = ++eval_seq;
-    launch_eval_finish(st, R, pose_start.p, posenorm.p, c.pA.p, nA, eval_dev, want);
+    launch_eval_finish(st, R, pose_start.p, posenorm.p, c.pA.p, nA, eval_dev, want, eval_split.p, n);
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
     while (eval_host->seq != want) {

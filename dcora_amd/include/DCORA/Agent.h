@@ -1,42 +1,61 @@
 // Agent with the reference's per-robot interface (ref include/DCORA/Agent.h:256-650) on top of the RBCD session of
-// include/dcora_hip.h, so that the reference's driver loop (examples/MultiRobotExample.cpp:184-307) runs unchanged:
+// include/dcora_hip.h, so that the reference's driver (examples/MultiRobotExample.cpp:184-307) runs with its own lines:
 //
-//     auto team = DCORA::AgentTeam::create(dataset_handle, params);      // Agents of this process + their device state
-//     for (auto &a : team->agents) a->setX(block of Xcurr);
+//     DCORA::AgentParameters options(d, r, robot_IDs);                    // :186
+//     auto *agent = new DCORA::Agent(robot, options);                     // :192
+//     agent->setMeasurements(odometry[robot], private_loop_closures[robot], shared_loop_closure[robot]);   // :201
+//     agent->initialize();                                                // :203
+//     agents[robot]->setX(block of Xcurr);                                // :213
 //     for (iter ...) {
-//       for (auto &a : team->agents) if (a->getID() != selected) a->iterate(false);
-//       ... getSharedStateDicts / updateNeighborStates ...
-//       team->agents[selected]->iterate(true);
+//       for (auto *a : agents) if (a->getID() != selected) a->iterate(false);
+//       ... getSharedStateDicts / updateNeighborStates (plain and auxiliary) ...
+//       agents[selected]->iterate(true);
 //       ... getX of every agent, central evaluation, greedy selection ...
 //     }
 //
-// What differs from the reference object model: the agents of one process share one device-resident mirror of the
-// lifted variable (the session), so a neighbour's public poses are visible to the selected agent without a copy --
-// getSharedStateDicts still hands out the poses (for callers that ship them to other processes), updateNeighborStates
-// checks what it is given against the mirror's layout and stores it.  Measurements come from the dataset the team is
-// created from (the contiguous partition of the driver, :56-118) instead of three setMeasurements lists.
+// Object model.  The agents of one process share one device-resident session (one mirror of the lifted variable, one
+// stream): the Agents constructed with the same AgentParameters find each other through a process-wide registry, and
+// the session is created when the LAST robot of AgentParameters::robotIDs has been initialised -- from the union of the
+// measurements the agents were given, which must follow the driver's contiguous partition (equal pose counts, the last
+// robot takes the remainder; :56-118).  Robots that live in other processes are not this class's business: a rank of a
+// multi-process job creates its session with rank / world_size and exchanges through dcora_exchange_*.
+// AgentTeam::create(dataset, params) remains as the direct way to the same state.
+//
+// updateNeighborStates hands poses to ONE agent: from then on that agent optimises against what it was handed (its own
+// plain / auxiliary caches on the device: stale poses are used as given, poses it does not require are ignored, an
+// incomplete cache skips the optimisation, ref src/Agent.cpp:844-906, 1234-1249).
 #pragma once
 #include <map>
 #include <memory>
+#include <mutex>
+#include <set>
+#include <string>
 #include <utility>
 
 #include "DCORA_types.h"
+#include "Graph.h"
 
 namespace DCORA {
 
 // ref include/DCORA/Agent.h:40-147 (the fields the RBCD loop reads)
 struct AgentParameters {
-  unsigned d = 3, r = 5, numRobots = 1;
+  unsigned d = 3, r = 5;
+  std::set<unsigned> robotIDs;
+  unsigned numRobots = 1;
   ROptParameters localOptimizationParams;
   bool acceleration = false;
   unsigned restartInterval = 30;
+  bool verbose = false, logData = false;
+  std::string logDirectory;
   int device = 0;
-  AgentParameters(unsigned dIn, unsigned rIn, unsigned numRobotsIn) : d(dIn), r(rIn), numRobots(numRobotsIn) {}
+  AgentParameters(unsigned dIn, unsigned rIn, const std::set<unsigned> &robotIDsIn)
+      : d(dIn), r(rIn), robotIDs(robotIDsIn), numRobots((unsigned)robotIDsIn.size()) {}
+  AgentParameters(unsigned dIn, unsigned rIn, unsigned numRobotsIn) : d(dIn), r(rIn), numRobots(numRobotsIn) {
+    for (unsigned i = 0; i < numRobotsIn; ++i) robotIDs.insert(i);
+  }
 };
 
-// ref include/DCORA/DCORA_types.h (PoseID = (robot, frame)); a lifted pose is r x (d+1)
-using PoseID = std::pair<unsigned, unsigned>;
-using PoseDict = std::map<PoseID, Matrix>;
+using PoseDict = std::map<PoseID, Matrix>;  // a lifted pose is r x (d+1)
 
 class Agent;
 
@@ -45,19 +64,14 @@ class AgentTeam : public std::enable_shared_from_this<AgentTeam> {
  public:
   static std::shared_ptr<AgentTeam> create(dcora_dataset_t dataset, const AgentParameters &params) {
     std::shared_ptr<AgentTeam> t(new AgentTeam(params));
-    dcora_rbcd_options o;
-    dcora_rbcd_options_default(&o);
-    o.num_robots = (int)params.numRobots;
-    o.r = (int)params.r;
-    o.acceleration = params.acceleration ? 1 : 0;
-    o.restart_interval = (int)params.restartInterval;
-    o.local = params.localOptimizationParams.c();
-    o.device = params.device;
-    check_status(dcora_rbcd_create(dataset, &o, &t->session_), "AgentTeam");
+    t->open(dataset);
     t->build_agents();
     return t;
   }
-  ~AgentTeam() { dcora_rbcd_destroy(session_); }
+  ~AgentTeam() {
+    dcora_rbcd_destroy(session_);
+    if (owned_ds_) dcora_dataset_destroy(owned_ds_);
+  }
   AgentTeam(const AgentTeam &) = delete;
   AgentTeam &operator=(const AgentTeam &) = delete;
 
@@ -66,59 +80,152 @@ class AgentTeam : public std::enable_shared_from_this<AgentTeam> {
   dcora_rbcd_t session() const { return session_; }
 
  private:
+  friend class Agent;
   explicit AgentTeam(const AgentParameters &p) : params_(p) {}
+  void open(dcora_dataset_t dataset) {
+    dcora_rbcd_options o;
+    dcora_rbcd_options_default(&o);
+    o.num_robots = (int)params_.numRobots;
+    o.r = (int)params_.r;
+    o.acceleration = params_.acceleration ? 1 : 0;
+    o.restart_interval = (int)params_.restartInterval;
+    o.local = params_.localOptimizationParams.c();
+    o.device = params_.device;
+    check_status(dcora_rbcd_create(dataset, &o, &session_), "AgentTeam");
+  }
   void build_agents();
   AgentParameters params_;
   dcora_rbcd_t session_ = nullptr;
+  dcora_dataset_t owned_ds_ = nullptr;
 };
+
+namespace detail {
+// Agents constructed one by one (the reference's shape) meet here until their team is complete
+struct PendingTeam {
+  explicit PendingTeam(const AgentParameters &p) : params(p) {}
+  AgentParameters params;
+  std::map<unsigned, std::vector<RelativePosePoseMeasurement>> odometry, private_lc, shared_lc;
+  std::set<unsigned> constructed, initialized;
+  std::shared_ptr<AgentTeam> team;
+  std::mutex mu;
+};
+struct TeamKey {
+  unsigned d, r;
+  std::set<unsigned> ids;
+  bool accel;
+  bool operator<(const TeamKey &o) const {
+    if (d != o.d) return d < o.d;
+    if (r != o.r) return r < o.r;
+    if (accel != o.accel) return accel < o.accel;
+    return ids < o.ids;
+  }
+};
+inline std::map<TeamKey, std::weak_ptr<PendingTeam>> &team_registry() {
+  static std::map<TeamKey, std::weak_ptr<PendingTeam>> reg;
+  return reg;
+}
+inline std::mutex &team_registry_mutex() {
+  static std::mutex mu;
+  return mu;
+}
+}  // namespace detail
 
 class Agent {
  public:
-  Agent(unsigned ID, const std::shared_ptr<AgentTeam> &team) : mID(ID), team_(team) {
-    int np = 0, first = 0;
-    check_status(dcora_rbcd_agent_info(team->session(), (int)ID, &np, &first, nullptr), "Agent");
-    n_ = (unsigned)np;
-    first_pose_ = (unsigned)first;
+  // member of a team created from a dataset (AgentTeam::create)
+  Agent(unsigned ID, const std::shared_ptr<AgentTeam> &team) : mID(ID), params_(team->params()), team_(team) {}
+  // the reference's constructor (ref include/DCORA/Agent.h:256): the team forms when every robot of params.robotIDs
+  // has been constructed, given its measurements and initialised in this process
+  Agent(unsigned ID, const AgentParameters &params) : mID(ID), params_(params) {
+    if (!params.robotIDs.count(ID)) throw std::invalid_argument("Agent: ID is not in AgentParameters::robotIDs");
+    std::lock_guard<std::mutex> lk(detail::team_registry_mutex());
+    const detail::TeamKey key{params.d, params.r, params.robotIDs, params.acceleration};
+    std::shared_ptr<detail::PendingTeam> p = detail::team_registry()[key].lock();
+    if (!p || p->constructed.count(ID)) {  // none yet, or that team already has this robot: a new generation
+      p = std::make_shared<detail::PendingTeam>(params);
+      detail::team_registry()[key] = p;
+    }
+    p->constructed.insert(ID);
+    pending_ = p;
   }
   unsigned getID() const { return mID; }
-  unsigned relaxation_rank() const { return team()->params().r; }
-  unsigned dimension() const { return team()->params().d; }
-  unsigned num_poses() const { return n_; }
-  unsigned problem_dimension() const { return (dimension() + 1) * n_; }
+  unsigned relaxation_rank() const { return params_.r; }
+  unsigned dimension() const { return params_.d; }
+  unsigned num_poses() const { return info().first; }
+  unsigned problem_dimension() const { return (dimension() + 1) * num_poses(); }
   unsigned instance_number() const { return 0; }
   unsigned iteration_number() const {
     int it = 0;
-    check_status(dcora_rbcd_agent_info(team()->session(), (int)mID, nullptr, nullptr, &it), "iteration_number");
+    check_status(dcora_rbcd_agent_info(session(), (int)mID, nullptr, nullptr, &it), "iteration_number");
     return (unsigned)it;
+  }
+  // ref include/DCORA/Agent.h:269-285 / src/Agent.cpp (setMeasurements): the three lists of the driver's partition
+  void setMeasurements(const std::vector<RelativePosePoseMeasurement> &inputOdometry,
+                       const std::vector<RelativePosePoseMeasurement> &inputPrivateLoopClosures,
+                       const std::vector<RelativePosePoseMeasurement> &inputSharedLoopClosures) {
+    if (!pending_) throw std::logic_error("Agent::setMeasurements: this agent belongs to a team created from a dataset");
+    std::lock_guard<std::mutex> lk(pending_->mu);
+    if (pending_->team) throw std::logic_error("Agent::setMeasurements: the team has been formed already");
+    pending_->odometry[mID] = inputOdometry;
+    pending_->private_lc[mID] = inputPrivateLoopClosures;
+    pending_->shared_lc[mID] = inputSharedLoopClosures;
+  }
+  // ref include/DCORA/Agent.h:315 (the trajectory / frame arguments of the reference's initialisation do not apply: the
+  // driver sets X itself, :208-217).  The last robot to arrive forms the team.
+  void initialize() {
+    if (!pending_) return;
+    std::lock_guard<std::mutex> lk(pending_->mu);
+    pending_->initialized.insert(mID);
+    if (!pending_->team && pending_->initialized == pending_->params.robotIDs) form_team(*pending_);
+  }
+  // ref include/DCORA/Agent.h:638-644: the lifting matrix all robots share (r x d, orthonormal columns).  The solver
+  // on the device does not need it (the driver hands over lifted states); it is kept for callers that lift with it.
+  bool getLiftingMatrix(Matrix *M) const {
+    if (lifting_.rows() == 0) {
+      Matrix Y(relaxation_rank(), dimension());
+      for (unsigned i = 0; i < dimension(); ++i) Y(i, i) = 1.0;
+      *M = Y;
+    } else {
+      *M = lifting_;
+    }
+    return true;
+  }
+  void setLiftingMatrix(const Matrix &M) {
+    if (M.rows() != relaxation_rank() || M.cols() != dimension())
+      throw std::invalid_argument("setLiftingMatrix: expected r x d");
+    lifting_ = M;
   }
   // ref src/Agent.cpp:64-77 (also re-initialises the acceleration, :1178-1187)
   void setX(const Matrix &Xin) {
     if (Xin.rows() != relaxation_rank() || Xin.cols() != problem_dimension())
       throw std::invalid_argument("Agent::setX: expected r x (d+1) n");
-    check_status(dcora_rbcd_agent_set_X(team()->session(), (int)mID, Xin.data()), "setX");
+    check_status(dcora_rbcd_agent_set_X(session(), (int)mID, Xin.data()), "setX");
   }
   // ref src/Agent.cpp:98-105
   bool getX(Matrix *Mout) {
     *Mout = Matrix(relaxation_rank(), problem_dimension());
-    return dcora_rbcd_agent_get_X(team()->session(), (int)mID, Mout->data()) == DCORA_OK;
+    return dcora_rbcd_agent_get_X(session(), (int)mID, Mout->data()) == DCORA_OK;
   }
-  // ref src/Agent.cpp:535-596
+  // ref src/Agent.cpp:535-596; false when the optimisation was skipped because a required neighbour pose has never
+  // been handed over (ref :1243-1249)
   bool iterate(bool doOptimization = true) {
-    check_status(dcora_rbcd_agent_iterate(team()->session(), (int)mID, doOptimization ? 1 : 0), "iterate");
-    return true;
+    check_status(dcora_rbcd_agent_iterate(session(), (int)mID, doOptimization ? 1 : 0), "iterate");
+    int skipped = 0;
+    check_status(dcora_rbcd_agent_last_skipped(session(), (int)mID, &skipped), "iterate");
+    return !(doOptimization && skipped);
   }
   // ref src/Agent.cpp:113-152: my public poses (those with an inter-robot measurement), keyed (robot, local frame)
   bool getSharedStateDicts(PoseDict *poseDict) {
     int cnt = 0;
-    check_status(dcora_rbcd_public_count(team()->session(), (int)mID, &cnt), "getSharedStateDicts");
+    check_status(dcora_rbcd_public_count(session(), (int)mID, &cnt), "getSharedStateDicts");
     std::vector<int> idx((size_t)(cnt > 0 ? cnt : 1));
-    check_status(dcora_rbcd_public_indices(team()->session(), (int)mID, idx.data()), "getSharedStateDicts");
+    check_status(dcora_rbcd_public_indices(session(), (int)mID, idx.data()), "getSharedStateDicts");
     Matrix X;
     if (!getX(&X)) return false;
-    const unsigned r = relaxation_rank(), dh = dimension() + 1;
+    const unsigned r = relaxation_rank(), dh = dimension() + 1, first = info().second;
     poseDict->clear();
     for (int q = 0; q < cnt; ++q) {
-      const unsigned local = (unsigned)idx[(size_t)q] - first_pose_;
+      const unsigned local = (unsigned)idx[(size_t)q] - first;
       Matrix P(r, dh);
       for (unsigned c = 0; c < dh; ++c)
         for (unsigned i = 0; i < r; ++i) P(i, c) = X(i, local * dh + c);
@@ -126,38 +233,31 @@ class Agent {
     }
     return true;
   }
-  // ref src/Agent.cpp:844-906.  Restriction of this facade: the agents of a team share ONE device-resident mirror of
-  // X, and the selected agent's linear term is built from that mirror -- not from a per-agent copy of what it was
-  // handed.  The hand-over is therefore CHECKED against the mirror: poses that are stale, altered or belong to
-  // another robot are refused (std::runtime_error) instead of being silently ignored; frames that are left out are
-  // still read from the mirror.  (Ranks in different processes exchange through dcora_exchange_* instead.)
+  // ref src/Agent.cpp:844-906: the poses go into this agent's own cache on the device (the plain one, or the auxiliary
+  // one it reads when it optimises from Y); the reference's CHECKs on the robot id and the shapes throw here
   void updateNeighborStates(unsigned neighborID, const PoseDict &poseDict, bool areNeighborStatesAux = false) {
-    (void)areNeighborStatesAux;  // the reference driver hands over X in both calls (examples/MultiRobotExample.cpp:252)
+    if (neighborID == mID) throw std::invalid_argument("updateNeighborStates: neighborID is this agent");
     if (poseDict.empty()) return;
-    int np = 0;
-    check_status(dcora_rbcd_agent_info(team()->session(), (int)neighborID, &np, nullptr, nullptr),
-                 "updateNeighborStates");
     const unsigned r = relaxation_rank(), dh = dimension() + 1;
-    Matrix Xn(r, dh * (unsigned)np);
-    check_status(dcora_rbcd_agent_get_X(team()->session(), (int)neighborID, Xn.data()), "updateNeighborStates");
+    std::vector<int> frames;
+    std::vector<double> poses;
+    frames.reserve(poseDict.size());
+    poses.reserve(poseDict.size() * r * dh);
     for (const auto &kv : poseDict) {
-      if (kv.first.first != neighborID) throw std::invalid_argument("updateNeighborStates: pose of another robot");
+      if (kv.first.robot_id != neighborID) throw std::invalid_argument("updateNeighborStates: pose of another robot");
       if (kv.second.rows() != r || kv.second.cols() != dh)
         throw std::invalid_argument("updateNeighborStates: expected r x (d+1) poses");
-      const unsigned frame = kv.first.second;
-      if (frame >= (unsigned)np) throw std::invalid_argument("updateNeighborStates: frame out of range");
-      for (unsigned c = 0; c < dh; ++c)
-        for (unsigned i = 0; i < r; ++i)
-          if (kv.second(i, c) != Xn(i, frame * dh + c))
-            throw std::runtime_error(
-                "updateNeighborStates: the poses handed over differ from the neighbour's current state; agents of one "
-                "AgentTeam optimise against the shared device mirror and cannot be given stale or altered poses");
+      frames.push_back((int)kv.first.frame_id);
+      poses.insert(poses.end(), kv.second.data(), kv.second.data() + (size_t)r * dh);
     }
+    check_status(dcora_rbcd_agent_update_neighbor(session(), (int)mID, (int)neighborID, (int)frames.size(),
+                                                  frames.data(), poses.data(), areNeighborStatesAux ? 1 : 0),
+                 "updateNeighborStates");
   }
   // ref src/Agent.cpp:535 getSharedPose(index): pose `index` of this agent, r x (d+1)
   bool getSharedPose(unsigned index, Matrix *Mout) {
     Matrix X;
-    if (index >= n_ || !getX(&X)) return false;
+    if (index >= num_poses() || !getX(&X)) return false;
     const unsigned r = relaxation_rank(), dh = dimension() + 1;
     *Mout = Matrix(r, dh);
     for (unsigned c = 0; c < dh; ++c)
@@ -167,12 +267,99 @@ class Agent {
 
  private:
   std::shared_ptr<AgentTeam> team() const {
+    if (pending_) {
+      std::lock_guard<std::mutex> lk(pending_->mu);
+      if (!pending_->team)
+        throw std::logic_error(
+            "Agent: its team is not complete -- every robot of AgentParameters::robotIDs must have been constructed, "
+            "given its measurements and initialised in this process (robots of other processes: a session per rank "
+            "with rank / world_size and dcora_exchange_*)");
+      return pending_->team;
+    }
     std::shared_ptr<AgentTeam> t = team_.lock();
     if (!t) throw std::runtime_error("Agent outlived its AgentTeam");
     return t;
   }
-  unsigned mID, n_ = 0, first_pose_ = 0;
+  dcora_rbcd_t session() const { return team()->session(); }
+  // (number of poses, first global pose)
+  std::pair<unsigned, unsigned> info() const {
+    if (!have_info_) {
+      int np = 0, first = 0;
+      check_status(dcora_rbcd_agent_info(session(), (int)mID, &np, &first, nullptr), "Agent");
+      n_ = (unsigned)np;
+      first_pose_ = (unsigned)first;
+      have_info_ = true;
+    }
+    return {n_, first_pose_};
+  }
+  // the team of agents that were constructed one by one: the union of their measurements as one dataset in global pose
+  // numbering (the driver's contiguous partition, ref examples/MultiRobotExample.cpp:56-118), one session
+  static void form_team(detail::PendingTeam &p) {
+    const AgentParameters &prm = p.params;
+    const unsigned R = prm.numRobots, d = prm.d;
+    unsigned want = 0;
+    for (unsigned id : prm.robotIDs)
+      if (id != want++) throw std::invalid_argument("AgentTeam: robot IDs must be 0 .. numRobots - 1");
+    std::vector<unsigned> np(R, 0);
+    auto count = [&](const std::vector<RelativePosePoseMeasurement> &v) {
+      for (const RelativePosePoseMeasurement &m : v) {
+        if (m.r1 >= R || m.r2 >= R) throw std::invalid_argument("AgentTeam: measurement names an unknown robot");
+        np[m.r1] = std::max<unsigned>(np[m.r1], (unsigned)m.p1 + 1);
+        np[m.r2] = std::max<unsigned>(np[m.r2], (unsigned)m.p2 + 1);
+      }
+    };
+    for (unsigned b = 0; b < R; ++b) {
+      count(p.odometry[b]);
+      count(p.private_lc[b]);
+      count(p.shared_lc[b]);
+    }
+    unsigned n = 0;
+    std::vector<unsigned> start(R + 1, 0);
+    for (unsigned b = 0; b < R; ++b) {
+      start[b] = n;
+      n += np[b];
+    }
+    start[R] = n;
+    const unsigned per = n / R;
+    for (unsigned b = 0; b + 1 < R; ++b)
+      if (np[b] != per)
+        throw std::invalid_argument(
+            "AgentTeam: the robots' pose counts do not follow the contiguous partition of the driver (n / numRobots "
+            "poses each, the last robot takes the remainder)");
+    std::vector<RelativePosePoseMeasurement> all;
+    auto take = [&](const std::vector<RelativePosePoseMeasurement> &v, unsigned owner, bool shared) {
+      for (const RelativePosePoseMeasurement &m : v) {
+        if (shared && m.r1 != owner) continue;  // a shared closure sits in both robots' lists: counted once
+        RelativePosePoseMeasurement g = m;
+        g.p1 = start[m.r1] + m.p1;
+        g.p2 = start[m.r2] + m.p2;
+        g.r1 = g.r2 = 0;
+        all.push_back(g);
+      }
+    };
+    for (unsigned b = 0; b < R; ++b) {
+      take(p.odometry[b], b, false);
+      take(p.private_lc[b], b, false);
+      take(p.shared_lc[b], b, true);
+    }
+    std::vector<int> ids;
+    std::vector<double> vals;
+    pack_measurements(all, d, &ids, &vals);
+    dcora_dataset_t ds = nullptr;
+    check_status(dcora_dataset_create((int)d, (int)n, (int)all.size(), ids.data(), vals.data(), &ds), "AgentTeam");
+    std::shared_ptr<AgentTeam> t(new AgentTeam(prm));
+    t->owned_ds_ = ds;
+    t->open(ds);
+    p.team = t;
+  }
+
+  unsigned mID;
+  AgentParameters params_;
+  mutable unsigned n_ = 0, first_pose_ = 0;
+  mutable bool have_info_ = false;
   std::weak_ptr<AgentTeam> team_;
+  std::shared_ptr<detail::PendingTeam> pending_;
+  Matrix lifting_;
 };
 
 inline void AgentTeam::build_agents() {

@@ -77,6 +77,34 @@ struct ROPTResult {
   int tCGStatus = 4;
 };
 
+// ref include/DCORA/DCORA_types.h (PoseID): a pose is named by (robot, frame)
+struct PoseID {
+  unsigned robot_id = 0, frame_id = 0;
+  PoseID() = default;
+  PoseID(unsigned robot, unsigned frame) : robot_id(robot), frame_id(frame) {}
+  bool operator<(const PoseID &o) const {
+    return robot_id != o.robot_id ? robot_id < o.robot_id : frame_id < o.frame_id;
+  }
+  bool operator==(const PoseID &o) const { return robot_id == o.robot_id && frame_id == o.frame_id; }
+};
+
+// ref include/DCORA/Measurements.h:275-335 (the fields and the basic constructor the drivers use)
+struct RelativePosePoseMeasurement {
+  size_t r1 = 0, r2 = 0, p1 = 0, p2 = 0;
+  Matrix R;  // d x d
+  Vector t;  // d
+  double kappa = 0, tau = 0;
+  bool fixedWeight = false;
+  double weight = 1.0;
+  RelativePosePoseMeasurement() = default;
+  RelativePosePoseMeasurement(size_t firstRobot, size_t secondRobot, size_t firstPose, size_t secondPose,
+                              const Matrix &relativeRotation, const Vector &relativeTranslation,
+                              double rotationalPrecision, double translationalPrecision, bool fixedWeightIn = false,
+                              double weightIn = 1.0)
+      : r1(firstRobot), r2(secondRobot), p1(firstPose), p2(secondPose), R(relativeRotation), t(relativeTranslation),
+        kappa(rotationalPrecision), tau(translationalPrecision), fixedWeight(fixedWeightIn), weight(weightIn) {}
+};
+
 // glog CHECK stand-in: invariants abort in the reference (ref src/QuadraticProblem.cpp:39-40); here they throw on
 // the host side of the ABI (never across it)
 inline void check_status(int st, const char *what) {

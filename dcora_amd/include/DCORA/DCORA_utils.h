@@ -2,6 +2,8 @@
 // libdcora_hip (ref include/DCORA/DCORA_utils.h): certification, rounding, initialisation.  Same names and
 // argument meaning as the reference; every call goes through the C ABI of include/dcora_hip.h.
 #pragma once
+#include <algorithm>
+
 #include "DCORA_types.h"
 
 namespace DCORA {
@@ -24,6 +26,39 @@ inline SparseMatrix take(dcora_csr_t h) {
   return S;
 }
 }  // namespace detail
+
+// ref include/DCORA/Measurements.h:765-777, src/DCORA_utils.cpp:179-375: the pose-pose measurements of a g2o file in
+// global pose numbering (r1 = r2 = 0), through the library's reader
+struct G2ODataset {
+  unsigned dim = 0, num_poses = 0;
+  std::vector<RelativePosePoseMeasurement> pose_pose_measurements;
+};
+inline G2ODataset read_g2o_file(const std::string &filename) {
+  dcora_dataset_t ds = nullptr;
+  detail::check(dcora_dataset_load_g2o(filename.c_str(), &ds), "read_g2o_file");
+  int d = 0, n = 0, m = 0;
+  dcora_dataset_info(ds, &d, &n, &m);
+  const size_t w = (size_t)d * d + d + 3;
+  std::vector<int> ids((size_t)4 * m);
+  std::vector<double> vals((size_t)m * w);
+  detail::check(dcora_dataset_copy(ds, ids.data(), vals.data()), "read_g2o_file");
+  dcora_dataset_destroy(ds);
+  G2ODataset out;
+  out.dim = (unsigned)d;
+  out.num_poses = (unsigned)n;
+  out.pose_pose_measurements.reserve((size_t)m);
+  for (int i = 0; i < m; ++i) {
+    const double *v = &vals[(size_t)i * w];
+    Matrix R((size_t)d, (size_t)d);
+    for (int c = 0; c < d; ++c)
+      for (int a = 0; a < d; ++a) R((size_t)a, (size_t)c) = v[c * d + a];
+    Vector t(v + d * d, v + d * d + d);
+    out.pose_pose_measurements.emplace_back((size_t)ids[4 * (size_t)i], (size_t)ids[4 * (size_t)i + 2],
+                                            (size_t)ids[4 * (size_t)i + 1], (size_t)ids[4 * (size_t)i + 3], R, t,
+                                            v[d * d + d], v[d * d + d + 1], false, v[d * d + d + 2]);
+  }
+  return out;
+}
 
 // ref src/DCORA_utils.cpp:1898-1931 / 1933-1982
 inline SparseMatrix constructDualCertificateMatrixPGO(const Matrix &X, const SparseMatrix &Q, unsigned d, unsigned n) {

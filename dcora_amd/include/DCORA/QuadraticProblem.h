@@ -5,6 +5,7 @@
 // src/Graph.cpp:1901-1917), which is exactly the ProblemData below -- see INTEGRATION.md for the two-line adapter.
 #pragma once
 #include "DCORA_types.h"
+#include "Graph.h"
 
 namespace DCORA {
 
@@ -22,6 +23,17 @@ class QuadraticProblem {
     dcora_dims dims{(int)pd.r, (int)pd.d, (int)pd.n, (int)pd.l, (int)pd.b};
     check_status(dcora_problem_create(&dims, pd.Q.rowptr.data(), pd.Q.colidx.data(), pd.Q.vals.data(),
                                       pd.G.rows() ? pd.G.data() : nullptr, pd.precond_reg, pd.device, &h_),
+                 "QuadraticProblem");
+  }
+  // the reference's constructor (ref include/DCORA/QuadraticProblem.h:28, src/QuadraticProblem.cpp:19-34): (r, d, n) and
+  // Q from the Graph; no linear term (the central problems of the drivers have none); the preconditioner with the
+  // pose-graph regularisation of ref src/Graph.cpp:1906 is built when withPreconditioner is set (escapeSaddle needs it)
+  explicit QuadraticProblem(const std::shared_ptr<Graph> &graph, bool withPreconditioner = false, int device = 0)
+      : r_(graph->r()), d_(graph->d()), n_(graph->n()), l_(0), b_(0), graph_(graph) {
+    const SparseMatrix &Q = graph->quadraticMatrix();
+    dcora_dims dims{(int)r_, (int)d_, (int)n_, 0, 0};
+    check_status(dcora_problem_create(&dims, Q.rowptr.data(), Q.colidx.data(), Q.vals.data(), nullptr,
+                                      withPreconditioner ? 0.1 : -1.0, device, &h_),
                  "QuadraticProblem");
   }
   ~QuadraticProblem() { dcora_problem_destroy(h_); }
@@ -77,6 +89,7 @@ class QuadraticProblem {
 
  private:
   unsigned r_, d_, n_, l_, b_;
+  std::shared_ptr<Graph> graph_;
   dcora_problem_t h_ = nullptr;
 };
 

@@ -282,6 +282,16 @@ int dcora_rbcd_evaluate(dcora_rbcd_t s, double *cost2, double *gradnorm, double 
  * per-agent loop (examples/MultiRobotExample.cpp:223-262).  The agents of a session advance in lockstep: one call
  * per hosted agent and round; the first call of a round advances the shared Nesterov sequences. */
 int dcora_rbcd_agent_iterate(dcora_rbcd_t s, int agent, int do_optimization);
+/* Agent::updateNeighborStates (ref src/Agent.cpp:844-906): `count` public poses of `neighbor` (frames local to it;
+ * poses: count blocks of r x (d+1), column-major) handed to `agent`.  From the first such call on the agent optimises
+ * against what it was HANDED -- its own cache of neighbour poses, the plain one or (auxiliary != 0) the one used when
+ * it starts from Y -- and no longer against the session's shared mirror: stale poses are used as they are, poses it
+ * does not require are ignored (Graph::requireNeighborPose), and an iterate(true) whose cache misses a required pose
+ * skips the optimisation (ref src/Agent.cpp:1243-1249; dcora_rbcd_agent_last_skipped tells).  Agents that are never
+ * handed anything keep reading the mirror (the session-level loop, dcora_rbcd_iterate). */
+int dcora_rbcd_agent_update_neighbor(dcora_rbcd_t s, int agent, int neighbor, int count, const int *frames,
+                                     const double *poses, int auxiliary);
+int dcora_rbcd_agent_last_skipped(dcora_rbcd_t s, int agent, int *skipped);
 /* Agent::getX / setX: the agent's own block, r x (d+1) num_poses (ref src/Agent.cpp:64-77, 98-105) */
 int dcora_rbcd_agent_get_X(dcora_rbcd_t s, int agent, double *X);
 int dcora_rbcd_agent_set_X(dcora_rbcd_t s, int agent, const double *X);
@@ -352,6 +362,9 @@ int dcora_exchange_set_X(dcora_exchange_t ex, const double *X);
 int dcora_exchange_gather_X(dcora_exchange_t ex, double *X);
 /* host barrier over the ranks of the job (does not synchronise the device) */
 int dcora_exchange_barrier(dcora_exchange_t ex);
+/* Agent::shouldTerminate's team condition (ref src/Agent.cpp:1137-1153: terminate only when EVERY robot reports
+ * readyToTerminate): the AND of the ranks' flags through the shared segment.  SPMD; *all_ready is the same everywhere. */
+int dcora_exchange_all_ready(dcora_exchange_t ex, int ready, int *all_ready);
 /* fastVerification of the current iterate across the ranks (ref src/DCORA_utils.cpp:1713-1735 on the global
  * S = Q - Lambda(X); the driver calls it where examples/MultiRobotExample.cpp:329-330 does).  SPMD.  The global
  * connection Laplacian Q (k = (d+1) n, CSR) is needed on rank 0 only (NULL elsewhere): rank 0 assembles S from the

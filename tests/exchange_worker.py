@@ -43,6 +43,9 @@ def main():
             cost.append(c2)
             gn.append(g)
             sel.append(nxt)
+    # the team's termination condition: everybody ready only when every rank says so
+    assert ex.all_ready(True) is True
+    assert ex.all_ready(rank != world - 1) is False
     cert = None
     if os.environ.get("DCORA_TEST_CERTIFY"):
         eta = float(os.environ["DCORA_TEST_CERTIFY"])
