@@ -500,7 +500,7 @@ def committed_profile(nbytes):
     passes): NOT measured in this run, reported under their own key with their source"""
     import csv
     out = {"note": "read from committed rocprofv3 summaries, not measured in this run"}
-    for tag in ("r02", "r01"):
+    for tag in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_kernel_stats_headline_loop.csv" % tag)
         if not os.path.exists(path):
             continue
@@ -518,7 +518,7 @@ def committed_profile(nbytes):
         except Exception:
             pass
         break
-    for name in ("r02_pmc_traffic.json", "pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
         pmc = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pmc):
             try:
@@ -546,7 +546,8 @@ def qapply_entry(P, ms, nbytes, extra=None):
 
 def roofline(da, ds, r, robots):
     """HIP-event timing, live in this run, of the kernels that carry the bytes of the loop, each on its own stream:
-    - the dominant kernel of the timed loop: k_fused_precond, the dense (Q_bb + 0.1 I)^-1 application of one agent;
+    - the dominant kernel of the timed loop: k_fused_pc (step, vector updates, the dense (Q_bb + 0.1 I)^-1 product and
+      the projection of one tCG iteration of one agent in one launch);
     - the Q-apply kernel (Y = X Q + G) on the whole sphere2500 graph (k_spmm) and on the synthetic 100k-pose lattice
       of BASELINE.json config 5 (k_spmm_bsr), there both cache-warm (one set re-read back to back) and HBM-cold
       (four distinct (Q, X, Y) sets in turn, 4 x 124 MB > the 256 MiB Infinity Cache)."""
@@ -639,7 +640,8 @@ def roofline(da, ds, r, robots):
         ach = nbytes / (ms * 1e-3) / 1e9
         s8 = 2.0 * info["nnzL"] * 12 + 2.0 * r * ka * 8
         out["precond_sparse_lattice100k_agent"] = {
-            "kernel": "partitioned sparse inverse replay (z = r (Q + 0.1 I)^-1), %d launches" % info["launches"],
+            "kernel": "partitioned sparse inverse replay (z = r (Q + 0.1 I)^-1): k_sp_multi, merged-level schedule, "
+                      "%d launches (two of them the permutations the solver folds into its own kernels)" % info["launches"],
             "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
             "bytes_per_application": nbytes, "avg_application_us": ms * 1e3, "launches": info["launches"], "k": ka,
             "nnz_L": info["nnzL"], "survey_8d_bytes_precond": s8,

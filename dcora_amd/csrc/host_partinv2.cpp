@@ -58,10 +58,12 @@ struct Source {        // what a piece contributes to the rows above it in one f
 // shortest lists, and lanes chosen as entries / steps for 3 .. 12 steps per lane, were measured as well: no gain
 // (119-186 us) -- fewer lanes mean fewer sums to reduce but longer dependent walks, and the walk costs more.
 int lanes_class(long entries, int regime) {
-  static const double scale = [] {
+  static const double scale_env = [] {
     const char *e = std::getenv("DCORA_SP_CLS_SCALE");
-    return e ? atof(e) : 2.0;
+    return e ? atof(e) : 0.0;
   }();
+  // r < 4 (tiers.pyfg, r = 2: RT r = 8 sums per tile) keeps the thresholds: 14 640 tCG it/s at x1 against 14 060 at x2
+  const double scale = scale_env > 0 ? scale_env : (regime == 0 ? 2.0 : 1.0);
   const double t64 = scale * (regime == 0 ? 100 : 20), t32 = scale * (regime == 0 ? 30 : 8);
   return entries >= scale * 400 ? 0 : entries >= scale * 160 ? 1 : entries >= t64 ? 2 : entries >= t32 ? 3 : 4;
 }

@@ -1,7 +1,7 @@
 #!/bin/bash
-# collects the round's rocprofv3 summaries into gpurun_out/r02 (run on the GPU box; copy what is quoted into profiles/)
+# collects the round's rocprofv3 summaries into gpurun_out/r03 (run on the GPU box; copy what is quoted into profiles/)
 export TMPDIR=/tmp
-o=gpurun_out/r02
+o=gpurun_out/r03
 rm -rf $o; mkdir -p $o
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/headline -o t -- python3 bench.py --headline-only > $o/headline.log 2>&1
 python3 tools/kstats.py $o/headline 20 > $o/headline_top.txt
