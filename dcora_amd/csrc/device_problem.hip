@@ -989,8 +989,8 @@ int DeviceProblem::time_precond(int reps, double *avg_ms, double *bytes) {
     if (sparse_precond)
       sp.apply(st, m.r, buf1(RG0.p), Zt.p, Gate{});
     else if (!bc_split)  // the one-launch B + C of the dense path, in its in-loop form
-      launch_fused_pc(st, m, ldm, Minv.p, RGb(), Xb(), delta.p, Hd.p, eta.p, Heta.p, res.p, res2.p, z.p, p1.p, nPB, p3.p,
-                      ctl.p, hf_dev, 1, 1, 0);
+      launch_fused_pc(st, m, ldm, Minv.p, RGb(), Xb(), delta.p, Hd.p, eta.p, Heta.p, res.p, res2.p, z.p, p1.p,
+                      std::getenv("DCORA_PC_EXP") ? -1 : nPB, p3.p, ctl.p, hf_dev, 1, 1, 0);
     else if (step_form)
       launch_fused_precond(st, m, ldm, Minv.p, RGb(), delta.p, Hd.p, eta.p, Heta.p, res.p, res2.p, Zpart.p, p1.p, nPB,
                            p2.p, ctl.p, hf_dev, 1, 1, 0);

@@ -1059,7 +1059,9 @@ __global__ __launch_bounds__(kPcBlock) void k_fused_pc(ManiDesc m, int ldm, int 
   const bool own = e < nrow * r;
   const size_t oown = (size_t)j0 * r + e;
   const int pi1 = (np1 <= 64) ? lane : (int)threadIdx.x;
-  double myp = (!first && pi1 < np1) ? p1[pi1] : 0.0;
+  // np1 < 0: timing experiment (DCORA_PC_EXP=1, time_precond only): <d, H d> is taken from the control block, as it would
+  // be if the PRODUCER's last workgroup had summed its partials and stored the scalar -- what that scheme can save here
+  double myp = (!first && np1 >= 0 && pi1 < np1) ? p1[pi1] : 0.0;
   double o_r = 0, o_h = 0, o_d = 0, o_eta = 0, o_Heta = 0;
   if (own) {
     o_r = rsrc[oown];
@@ -1106,7 +1108,7 @@ __global__ __launch_bounds__(kPcBlock) void k_fused_pc(ManiDesc m, int ldm, int 
   double alpha = 0, step = 0;
   bool boundary = false;
   if (!first) {
-    const double d_Hd = (np1 <= 64) ? f_wave_sum(myp) : f_block_sum(myp, s_red);
+    const double d_Hd = np1 < 0 ? c_dPd + 1.0 : ((np1 <= 64) ? f_wave_sum(myp) : f_block_sum(myp, s_red));
     alpha = c_zr / d_Hd;
     const double e_Pe_new = c_ePe + 2.0 * alpha * c_ePd + alpha * alpha * c_dPd;
     boundary = (d_Hd <= 0) || (e_Pe_new >= c_Delta * c_Delta);
