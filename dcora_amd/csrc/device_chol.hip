@@ -56,14 +56,189 @@ __global__ __launch_bounds__(256) void k_chol_extend_add(const PieceDev *__restr
   }
 }
 
-// diagonal block of the current panel: LL^T of up to 64 columns in LDS, written back in place, and L^-1 for the
-// panel below.  A pivot that is not positive raises *fail.  (Measured and dropped: ONE wave with the block in registers,
-// lane i owning row i and v_readlane broadcasts instead of LDS and barriers -- 308 VGPRs, 11 800 readlanes, and slower:
-// sphere2500 PSD test 1.84 -> 2.35 ms, the VALU -> SGPR -> VALU hazard of every broadcast costs more than the barrier.)
+// ---- 64 x 64 Cholesky and triangular inverse of a workgroup, blocked by 16 (round 3).  The column-by-column forms
+//      below (k_chol_potrf_v1, DCORA_POTRF=v1) pay a workgroup barrier per column and a 64-step dependent walk per
+//      column of the inverse: 83 us per diagonal block, 13 of the 21 ms of the headline's agent set-up and half of
+//      sphere2500's PSD test.  Blocked: the 16 x 16 diagonal block is factored by ONE wave (LDS operations of a wave
+//      stay in order: no workgroup barrier inside its 16 steps), the panel below it is a 16-step substitution per row,
+//      the trailing update a rank-16 product over all threads; the inverse is four 16 x 16 inversions side by side
+//      (one per wave) and three rounds of 16 x 16 block products. ----
+// L: lower triangle in LDS, identity beyond the matrix' order; returns false (uniformly) on a non-positive pivot
+__device__ __forceinline__ bool blocked_potrf64(double (*L)[NB + 1], int *s_bad, double *rd) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (tid == 0) *s_bad = 0;
+  __syncthreads();
+  for (int j0 = 0; j0 < NB; j0 += 16) {
+    if (wave == 0) {
+      // L D L^T elimination of the 16 x 16 block (no square root, one reciprocal and one wave barrier per column; the
+      // columns keep l_ij d_j until the end), then the scaling to L L^T by the whole wave
+      const int i = lane >> 2, kq = lane & 3;
+      bool bad = false;
+      for (int j = 0; j < 16; ++j) {
+        const double d = L[j0 + j][j0 + j];  // the same word for every lane: the branch is uniform
+        if (!(d > 0.0)) {
+          bad = true;
+          break;
+        }
+        if (i > j) {
+          const double lij = L[j0 + i][j0 + j] * (1.0 / d);
+          for (int k = j + 1 + kq; k <= i; k += 4) L[j0 + i][j0 + k] -= lij * L[j0 + k][j0 + j];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (bad) {
+        if (lane == 0) *s_bad = 1;
+      } else {
+        if (lane < 16) rd[j0 + lane] = 1.0 / sqrt(L[j0 + lane][j0 + lane]);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int e = lane; e < 256; e += 64) {
+          const int a = e >> 4, c_ = e & 15;
+          if (c_ < a)
+            L[j0 + a][j0 + c_] *= rd[j0 + c_];
+          else if (c_ == a)
+            L[j0 + a][j0 + a] = sqrt(L[j0 + a][j0 + a]);
+        }
+      }
+    }
+    __syncthreads();
+    if (*s_bad) return false;
+    const int nrem = NB - j0 - 16;
+    if (nrem > 0) {
+      // panel: row i of the rows below times D^-T, forward substitution along the row (reciprocal diagonal in rd)
+      if (tid < nrem) {
+        const int i = j0 + 16 + tid;
+        double x[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          double sacc = L[i][j0 + k];
+#pragma unroll
+          for (int l = 0; l < 16; ++l)
+            if (l < k) sacc -= x[l] * L[j0 + k][j0 + l];
+          x[k] = sacc * rd[j0 + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) L[i][j0 + k] = x[k];
+      }
+      __syncthreads();
+      // trailing update of the lower triangle by the rank-16 product of the panel with itself
+      for (int e = tid; e < nrem * nrem; e += 256) {
+        const int a = e / nrem, b = e - a * nrem;
+        if (b > a) continue;
+        const int i = j0 + 16 + a, k = j0 + 16 + b;
+        double sacc = 0;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) sacc += L[i][j0 + l] * L[k][j0 + l];
+        L[i][k] -= sacc;
+      }
+      __syncthreads();
+    }
+  }
+  return true;
+}
+// Li = L^-1 (both lower triangular in LDS); Ts: 48 x 17 doubles of scratch
+__device__ __forceinline__ void blocked_trtri64(double (*L)[NB + 1], double (*Li)[NB + 1], double (*Ts)[17],
+                                                const double *rd /* 1 / L[k][k] */) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int r_ = e >> 6, c_ = e & 63;
+    if (c_ > r_ || (r_ >> 4) != (c_ >> 4)) Li[r_][c_] = 0.0;  // above the diagonal and the off-diagonal blocks
+  }
+  {
+    // the diagonal block of this wave: column k by a group of 4 lanes (they share the sum over l)
+    const int j0 = 16 * wave, k = lane >> 2, kq = lane & 3;
+    if (kq == 0) Li[j0 + k][j0 + k] = rd[j0 + k];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int r_ = 1; r_ < 16; ++r_) {
+      if (r_ > k) {
+        double sacc = 0;
+        for (int l = k + kq; l < r_; l += 4) sacc += L[j0 + r_][j0 + l] * Li[j0 + l][j0 + k];
+        sacc += __shfl_xor(sacc, 1);
+        sacc += __shfl_xor(sacc, 2);
+        if (kq == 0) Li[j0 + r_][j0 + k] = -sacc * rd[j0 + r_];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();
+  // block (bi, bj), bi - bj = dist:  Li_ij = -Li_ii (sum_{bk = bj}^{bi - 1} L_i,bk Li_bk,j)
+  for (int dist = 1; dist < 4; ++dist) {
+    const int nblk = 4 - dist;
+    for (int e = tid; e < nblk * 256; e += 256) {
+      const int q = e >> 8, a = (e >> 4) & 15, c_ = e & 15;
+      const int bj = q, bi = q + dist;
+      double sacc = 0;
+      for (int bk = bj; bk < bi; ++bk)
+#pragma unroll
+        for (int l = 0; l < 16; ++l) sacc += L[16 * bi + a][16 * bk + l] * Li[16 * bk + l][16 * bj + c_];
+      Ts[16 * q + a][c_] = sacc;
+    }
+    __syncthreads();
+    for (int e = tid; e < nblk * 256; e += 256) {
+      const int q = e >> 8, a = (e >> 4) & 15, c_ = e & 15;
+      const int bj = q, bi = q + dist;
+      double sacc = 0;
+#pragma unroll
+      for (int l = 0; l < 16; ++l)
+        if (l <= a) sacc += Li[16 * bi + a][16 * bi + l] * Ts[16 * q + l][c_];
+      Li[16 * bi + a][16 * bj + c_] = -sacc;
+    }
+    __syncthreads();
+  }
+}
+
+// diagonal block of the current panel, blocked form (see above): LL^T of up to 64 columns, written back in place, and
+// L^-1 for the panel below; a pivot that is not positive raises *fail
 __global__ __launch_bounds__(256) void k_chol_potrf(const PieceDev *__restrict__ pieces, const int *__restrict__ list,
                                                     int j0, double *__restrict__ F, double *__restrict__ Linv,
                                                     int *__restrict__ fail, double *__restrict__ logdet,
                                                     int always_inv) {
+  if (*fail) return;
+  const PieceDev P = pieces[list[blockIdx.x]];
+  const int jb = min(NB, P.c - j0);
+  const long long f = (long long)P.c + P.m;
+  double *__restrict__ M = F + P.off + (long long)j0 * f + j0;
+  __shared__ double L[NB][NB + 1];
+  __shared__ double Li[NB][NB + 1];
+  __shared__ double Ts[48][17];
+  __shared__ double rd[NB];
+  __shared__ int s_bad;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int i = e >> 6, j = e & 63;
+    L[i][j] = (i < jb && j <= i) ? M[(long long)i * f + j] : (i == j ? 1.0 : 0.0);
+  }
+  if (!blocked_potrf64(L, &s_bad, rd)) {
+    if (tid == 0) *fail = 1;
+    return;
+  }
+  if (tid < NB) {
+    // log det of the factored matrix (a cross-check of the whole factorisation for the tests; order of the sum free)
+    double lg = tid < jb ? 2.0 * log(L[tid][tid]) : 0.0;
+    for (int o = 32; o > 0; o >>= 1) lg += __shfl_xor(lg, o);
+    if (tid == 0) atomicAdd(logdet, lg);
+  }
+  for (int e = tid; e < jb * jb; e += 256) {
+    const int r_ = e / jb, j = e - r_ * jb;
+    if (j <= r_) M[(long long)r_ * f + j] = L[r_][j];
+  }
+  if (!always_inv && P.m == 0 && j0 + jb >= P.c) return;  // nothing below the last panel of a root
+  blocked_trtri64(L, Li, Ts, rd);
+  double *__restrict__ O = Linv + (size_t)blockIdx.x * NB * NB;
+  for (int e = tid; e < NB * NB; e += 256) O[e] = Li[e >> 6][e & 63];
+}
+
+// diagonal block of the current panel: LL^T of up to 64 columns in LDS, written back in place, and L^-1 for the
+// panel below.  A pivot that is not positive raises *fail.  (Measured and dropped: ONE wave with the block in registers,
+// lane i owning row i and v_readlane broadcasts instead of LDS and barriers -- 308 VGPRs, 11 800 readlanes, and slower:
+// sphere2500 PSD test 1.84 -> 2.35 ms, the VALU -> SGPR -> VALU hazard of every broadcast costs more than the barrier.)
+__global__ __launch_bounds__(256) void k_chol_potrf_v1(const PieceDev *__restrict__ pieces,
+                                                       const int *__restrict__ list, int j0, double *__restrict__ F,
+                                                       double *__restrict__ Linv, int *__restrict__ fail,
+                                                       double *__restrict__ logdet, int always_inv) {
   if (*fail) return;
   const PieceDev P = pieces[list[blockIdx.x]];
   const int jb = min(NB, P.c - j0);
@@ -137,6 +312,14 @@ __global__ __launch_bounds__(256) void k_chol_potrf(const PieceDev *__restrict__
   __syncthreads();
   double *__restrict__ O = Linv + (size_t)blockIdx.x * NB * NB;
   for (int e = tid; e < NB * NB; e += 256) O[e] = Li[e >> 6][e & 63];
+}
+
+inline bool potrf_v1() {
+  static const bool v = [] {
+    const char *e = std::getenv("DCORA_POTRF");
+    return e && std::strcmp(e, "v1") == 0;
+  }();
+  return v;
 }
 
 // acc[u][v] = sum_k A[(ty + 16 u)][k] B[(tx + 16 v)][k]; A and B are row-major with k contiguous; rows beyond
@@ -681,7 +864,7 @@ int factor_on_device(const HostCsr &A, int block, int top, int device, bool *pd,
                            img->fail.p);
         break;
       case 1:
-        hipLaunchKernelGGL(k_chol_potrf, dim3(L.gx), dim3(256), 0, st, img->pieces.p, list, L.j0, F, img->linv.p,
+        hipLaunchKernelGGL((potrf_v1() ? k_chol_potrf_v1 : k_chol_potrf), dim3(L.gx), dim3(256), 0, st, img->pieces.p, list, L.j0, F, img->linv.p,
                            img->fail.p, img->logdet.p, 0);
         break;
       case 2:
@@ -874,7 +1057,7 @@ int device_dense_spd_inverse(const HostCsr &A, int device, double *Minv, int ldm
   hipLaunchKernelGGL(k_dense_scatter, dim3(k), dim3(256), 0, st, k, rp.p, ci.p, v.p, L.p);
   for (int p = 0; p < nb; ++p) {
     const int j0 = p * NB, jb = std::min(NB, k - j0), rows = k - j0 - jb;
-    hipLaunchKernelGGL(k_chol_potrf, dim3(1), dim3(256), 0, st, piece.p, list.p, j0, L.p, linv.p + (size_t)p * NB * NB,
+    hipLaunchKernelGGL((potrf_v1() ? k_chol_potrf_v1 : k_chol_potrf), dim3(1), dim3(256), 0, st, piece.p, list.p, j0, L.p, linv.p + (size_t)p * NB * NB,
                        fail.p, logdet.p, 1);
     if (rows > 0) {
       const int T = (rows + NB - 1) / NB;
