@@ -57,7 +57,7 @@ enum ExchangeMode { kExchangeIpc = 1, kExchangeStaged = 2 };
 class Exchange {
  public:
   ~Exchange();
-  int init(RbcdSession *s, const char *job_name);
+  int init(ExchangeSession *s, const char *job_name);
   int post(const int *agents, int count);
   int wait(const int *agents, int count);
   int post_arr(const int *agents, int count, int r, const double *arr);
@@ -96,7 +96,7 @@ class Exchange {
   int num_peers() const;
 
  private:
-  RbcdSession *s_ = nullptr;
+  ExchangeSession *s_ = nullptr;
   std::string name_;
   void *map_ = nullptr;
   size_t map_bytes_ = 0;

@@ -156,7 +156,7 @@ int Exchange::num_peers() const {
 }
 
 Exchange::~Exchange() {
-  if (s_) (void)hipSetDevice(s_->opt.device);
+  if (s_) (void)hipSetDevice(s_->x_device());
   for (int q = 0; q < kMaxRanks; ++q)
     if (opened_[q] && peer_halo_[q]) (void)hipIpcCloseMemHandle(peer_halo_[q]);
   if (registered_ && map_) (void)hipHostUnregister(map_);
@@ -298,41 +298,44 @@ int Exchange::barrier(double timeout_s) {
   return DCORA_OK;
 }
 
-int Exchange::init(RbcdSession *s, const char *job_name) {
+int Exchange::init(ExchangeSession *s, const char *job_name) {
   s_ = s;
-  rank = s->opt.rank;
-  world = s->opt.world_size;
-  R_ = s->R;
-  const int R = s->R, dh = s->d + 1;
+  rank = s->x_rank();
+  world = s->x_world();
+  R_ = s->x_num_agents();
+  const int R = R_;
   if (world > kMaxRanks) return fail("too many ranks", DCORA_ERR_UNSUPPORTED);
   if (!job_name || !*job_name) return fail("empty job name", DCORA_ERR_BAD_ARG);
-  DCORA_HIP(hipSetDevice(s->opt.device));
+  DCORA_HIP(hipSetDevice(s->x_device()));
   const int per = (R + world - 1) / world;
   owner_.resize(R);
-  size_t maxpub = 1;
+  size_t maxcols = 1;
   std::vector<int> hosted;
   for (int a = 0; a < R; ++a) {
+    const XAgentView v = s->x_agent(a);
     owner_[a] = a / per;
-    maxpub = std::max(maxpub, s->agents[a].public_poses.size());
-    if (s->agents[a].hosted) hosted.push_back(a);
-    if (s->agents[a].hosted != (owner_[a] == rank)) return fail("agent-to-rank map out of step with the session", DCORA_ERR_BAD_ARG);
+    maxcols = std::max(maxcols, (size_t)v.ncols);
+    if (v.hosted) hosted.push_back(a);
+    if (v.hosted != (owner_[a] == rank)) return fail("agent-to-rank map out of step with the session", DCORA_ERR_BAD_ARG);
   }
   n_hosted_ = (int)hosted.size();
-  slot_ = align_up(maxpub * dh * (size_t)s->r, 16);
+  slot_ = align_up(maxcols * (size_t)s->x_rank_r(), 16);
   dests_.assign(R, {});
   needed_.assign(R, 0);
-  for (int a = 0; a < R; ++a)
-    for (int q : s->agents[a].neighbors) {
-      if (s->agents[a].hosted && owner_[q] != rank &&
-          std::find(dests_[a].begin(), dests_[a].end(), owner_[q]) == dests_[a].end())
+  for (int a = 0; a < R; ++a) {
+    const XAgentView va = s->x_agent(a);
+    for (int q : *va.neighbors) {
+      const XAgentView vq = s->x_agent(q);
+      if (va.hosted && owner_[q] != rank && std::find(dests_[a].begin(), dests_[a].end(), owner_[q]) == dests_[a].end())
         dests_[a].push_back(owner_[q]);
-      if (!s->agents[a].hosted && s->agents[q].hosted) needed_[a] = 1;
+      if (!va.hosted && vq.hosted) needed_[a] = 1;
     }
+  }
   for (int a = 0; a < R; ++a)
     if ((int)dests_[a].size() > kMaxDst) return fail("an agent has neighbours on more than 8 other ranks", DCORA_ERR_UNSUPPORTED);
   seq_.assign(R, 0);
 
-  int rc = map_segment(job_name, (size_t)s->r * dh * s->n);
+  int rc = map_segment(job_name, (size_t)s->x_rank_r() * (size_t)s->x_num_cols());
   if (rc) return rc;
   {
     const hipError_t e = hipHostRegister(map_, map_bytes_, hipHostRegisterMapped | hipHostRegisterPortable);
@@ -347,9 +350,9 @@ int Exchange::init(RbcdSession *s, const char *job_name) {
   {
     char bus[64] = {0};
     uint64_t h = 1469598103934665603ull;
-    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), s->opt.device) != hipSuccess) {
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), s->x_device()) != hipSuccess) {
       (void)hipGetLastError();
-      std::snprintf(bus, sizeof(bus), "device-%d", s->opt.device);
+      std::snprintf(bus, sizeof(bus), "device-%d", s->x_device());
     }
     for (const char *c = bus; *c; ++c) h = (h ^ (uint64_t)(unsigned char)*c) * 1099511628211ull;
     ranks_[rank].bus.store(h ? h : 1, std::memory_order_release);
@@ -396,7 +399,7 @@ int Exchange::init(RbcdSession *s, const char *job_name) {
 // Halo buffers mapped into every rank that writes to them, then one round of test stores checked by the owner.
 // Every rank passes the same two barriers whatever fails locally; the result is this rank's vote.
 int Exchange::setup_ipc(bool attempt) {
-  const int R = s_->R;
+  const int R = R_;
   const size_t test_off = 2 * (size_t)R * slot_;
   const int ntest = 64;
   devflag_off_ = align_up(test_off + (size_t)ntest * world, 8);
@@ -438,7 +441,7 @@ int Exchange::setup_ipc(bool attempt) {
     }
   }
   (void)hipGetLastError();
-  ranks_[rank].device.store(s_->opt.device);
+  ranks_[rank].device.store(s_->x_device());
   ranks_[rank].pid.store((int)getpid());
   ranks_[rank].published.store(ok ? 1 : -1, std::memory_order_release);
   int rc = barrier();
@@ -453,9 +456,9 @@ int Exchange::setup_ipc(bool attempt) {
       break;
     }
     const int pd = ranks_[q].device.load();
-    if (pd != s_->opt.device) {
+    if (pd != s_->x_device()) {
       int can = 0;
-      if (hipDeviceCanAccessPeer(&can, s_->opt.device, pd) == hipSuccess && can) {
+      if (hipDeviceCanAccessPeer(&can, s_->x_device(), pd) == hipSuccess && can) {
         const hipError_t e = hipDeviceEnablePeerAccess(pd, 0);
         if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) no("hipDeviceEnablePeerAccess");
       }
@@ -475,9 +478,9 @@ int Exchange::setup_ipc(bool attempt) {
   // self-test: a pattern into my strip of every peer's test area, checked by the owner after the barrier
   if (ok) {
     for (int q : peers)
-      hipLaunchKernelGGL(k_selftest_write, dim3(1), dim3(64), 0, s_->st,
+      hipLaunchKernelGGL(k_selftest_write, dim3(1), dim3(64), 0, s_->x_stream(),
                          peer_halo_[q] + test_off + (size_t)ntest * rank, ntest, 1000.0 * (rank + 1));
-    if (hipStreamSynchronize(s_->st) != hipSuccess) no("self-test stores");
+    if (hipStreamSynchronize(s_->x_stream()) != hipSuccess) no("self-test stores");
     (void)hipGetLastError();
   }
   rc = barrier();
@@ -498,20 +501,20 @@ int Exchange::setup_ipc(bool attempt) {
   return ok ? DCORA_OK : DCORA_ERR_UNSUPPORTED;
 }
 
-int Exchange::post(const int *agents, int count) { return post_arr(agents, count, s_->r, s_->Xg.p); }
-int Exchange::wait(const int *agents, int count) { return wait_arr(agents, count, s_->r, s_->Xg.p); }
+int Exchange::post(const int *agents, int count) { return post_arr(agents, count, s_->x_rank_r(), s_->x_mirror()); }
+int Exchange::wait(const int *agents, int count) { return wait_arr(agents, count, s_->x_rank_r(), s_->x_mirror()); }
 
 // the same exchange for any r x (d+1)n array laid out like X (the certificate's vectors: r = 1)
 int Exchange::post_arr(const int *agents, int count, int r, const double *arr) {
   const auto t0 = Clock::now();
-  DCORA_HIP(hipSetDevice(s_->opt.device));
-  const int R = s_->R, dh = s_->d + 1;
+  DCORA_HIP(hipSetDevice(s_->x_device()));
+  const int R = R_;
   for (int i = 0; i < count; ++i) {
     const int a = agents[i];
     if (a < 0 || a >= R) return fail("post: agent out of range", DCORA_ERR_BAD_ARG);
     const uint64_t q = ++seq_[a];
-    AgentDev &ag = s_->agents[a];
-    if (!ag.hosted || dests_[a].empty() || ag.public_poses.empty()) continue;
+    const XAgentView ag = s_->x_agent(a);
+    if (!ag.hosted || dests_[a].empty() || ag.ncols == 0) continue;
     const int parity = (int)(q & 1);
     // Back-pressure: the slot of this parity was last written by post q - 2; every rank that reads it must have
     // scattered that post before it is overwritten (the evaluation's heartbeat used to be the only thing between a
@@ -542,11 +545,11 @@ int Exchange::post_arr(const int *agents, int count, int r, const double *arr) {
     } else {
       dst.base[dst.n++] = (double *)(dev_map_ + off_staged_) + halo_off(parity, a);
     }
-    const int ncols = (int)ag.public_poses.size() * dh;
+    const int ncols = ag.ncols;
     const long N = (long)ncols * r;
     const int grid = (int)std::min<long>((N + kBlock - 1) / kBlock, 64);
     volatile uint64_t *flag = (volatile uint64_t *)(dev_map_ + off_flags_ + sizeof(ShmFlag) * ((size_t)parity * R + a));
-    hipLaunchKernelGGL(k_post_public, dim3(grid), dim3(kBlock), 0, s_->st, r, ncols, ag.public_cols.p, arr, dst,
+    hipLaunchKernelGGL(k_post_public, dim3(grid), dim3(kBlock), 0, s_->x_stream(), r, ncols, ag.cols_dev, arr, dst,
                        dflag, arrive_.p + a, flag, q);
     bytes_posted += 8.0 * N * dst.n;
     ++posts;
@@ -558,12 +561,13 @@ int Exchange::post_arr(const int *agents, int count, int r, const double *arr) {
 
 int Exchange::wait_arr(const int *agents, int count, int r, double *arr) {
   const auto t0 = Clock::now();
-  DCORA_HIP(hipSetDevice(s_->opt.device));
-  const int R = s_->R, dh = s_->d + 1;
+  DCORA_HIP(hipSetDevice(s_->x_device()));
+  const int R = R_;
   for (int i = 0; i < count; ++i) {
     const int a = agents[i];
     if (a < 0 || a >= R) return fail("wait: agent out of range", DCORA_ERR_BAD_ARG);
-    if (!needed_[a] || s_->agents[a].public_poses.empty()) continue;
+    const XAgentView ag = s_->x_agent(a);
+    if (!needed_[a] || ag.ncols == 0) continue;
     const uint64_t want = seq_[a];
     const int parity = (int)(want & 1);
     const ShmFlag *f = flags_ + (size_t)parity * R + a;
@@ -586,13 +590,13 @@ int Exchange::wait_arr(const int *agents, int count, int r, double *arr) {
     // host-visible word when the poses are staged in the shared segment
     const uint64_t *dflag = ipc ? (const uint64_t *)(halo_.p + devflag_off_ + ((size_t)parity * R + a) * 8)
                                 : (const uint64_t *)(dev_map_ + off_flags_ + sizeof(ShmFlag) * ((size_t)parity * R + a));
-    const int ncols = (int)s_->agents[a].public_poses.size() * dh;
+    const int ncols = ag.ncols;
     const long N = (long)ncols * r;
     const int grid = (int)std::min<long>((N + kBlock - 1) / kBlock, 32);
     uint64_t *cons = (uint64_t *)(dev_map_ + off_consumed_ + sizeof(ShmFlag) * ((size_t)rank * R + a));
     uint32_t *failed = (uint32_t *)(dev_map_ + offsetof(ShmHeader, failed));
     // updateNeighborStates: into the local mirror of X
-    hipLaunchKernelGGL(k_wait_scatter, dim3(grid), dim3(kBlock), 0, s_->st, r, ncols, s_->agents[a].public_cols.p, src,
+    hipLaunchKernelGGL(k_wait_scatter, dim3(grid), dim3(kBlock), 0, s_->x_stream(), r, ncols, ag.cols_dev, src,
                        arr, dflag, want, arrive2_.p + a, cons, failed);
     ++waits;
   }
@@ -603,15 +607,15 @@ int Exchange::wait_arr(const int *agents, int count, int r, double *arr) {
 // distributed form of the central evaluation (ref examples/MultiRobotExample.cpp:264-305): every rank evaluates the
 // agents it hosts against the neighbours' public poses it holds, publishes two scalars per agent, reads everybody's
 int Exchange::evaluate(double *cost2, double *gradnorm, double *block_norms, int *next_selected) {
-  const int R = s_->R;
-  int rc = s_->phase_evaluate_dev(evalbuf_.p);
+  const int R = R_;
+  int rc = s_->x_phase_evaluate_dev(evalbuf_.p);
   if (rc) return rc;
   const uint64_t want = ++eval_seq_;
   const int parity = (int)(want & 1);
   const size_t per_parity = (size_t)R + world;
   ShmEval *slots_dev = (ShmEval *)(dev_map_ + off_evals_) + (size_t)parity * per_parity;
   if (n_hosted_)
-    hipLaunchKernelGGL(k_eval_publish, dim3(1), dim3(64), 0, s_->st, n_hosted_, hosted_list_.p, evalbuf_.p, slots_dev,
+    hipLaunchKernelGGL(k_eval_publish, dim3(1), dim3(64), 0, s_->x_stream(), n_hosted_, hosted_list_.p, evalbuf_.p, slots_dev,
                        want);
   DCORA_HIP(hipGetLastError());
   const auto t0 = Clock::now();
@@ -664,18 +668,18 @@ int Exchange::evaluate(double *cost2, double *gradnorm, double *block_norms, int
 
 // one pass of the reference driver's loop body (examples/MultiRobotExample.cpp:223-307) across the ranks
 int Exchange::rbcd_iterate(int selected, double *cost2, double *gradnorm, double *block_norms, int *next_selected) {
-  const int R = s_->R;
+  const int R = R_;
   if (selected < 0 || selected >= R) return fail("selected agent out of range", DCORA_ERR_BAD_ARG);
   std::vector<int> others;
   for (int a = 0; a < R; ++a)
     if (a != selected) others.push_back(a);
-  int rc = s_->phase_nonselected(selected);  // Agent::iterate(false) of the hosted non-selected agents
+  int rc = s_->x_phase_nonselected(selected);  // Agent::iterate(false) of the hosted non-selected agents
   if (rc) return rc;
   rc = post(others.data(), (int)others.size());
   if (rc) return rc;
   rc = wait(others.data(), (int)others.size());  // the selected agent's pull (and everybody's for the evaluation)
   if (rc) return rc;
-  rc = s_->phase_selected(selected);  // Agent::iterate(true) where the selected agent lives
+  rc = s_->x_phase_selected(selected);  // Agent::iterate(true) where the selected agent lives
   if (rc) return rc;
   rc = post(&selected, 1);
   if (rc) return rc;
@@ -684,12 +688,12 @@ int Exchange::rbcd_iterate(int selected, double *cost2, double *gradnorm, double
   int nxt = selected;
   rc = evaluate(cost2, gradnorm, block_norms, &nxt);
   if (rc) return rc;
-  if (next_selected) *next_selected = s_->agents[selected].neighbors.empty() ? selected : nxt;
+  if (next_selected) *next_selected = s_->x_agent(selected).neighbors->empty() ? selected : nxt;
   return DCORA_OK;
 }
 
 int Exchange::rbcd_tick(const int *set, int count, int allow_adjacent) {
-  int rc = s_->iterate_set(set, count, allow_adjacent);
+  int rc = s_->x_iterate_set(set, count, allow_adjacent);
   if (rc) return rc;
   rc = post(set, count);
   if (rc) return rc;
@@ -699,25 +703,18 @@ int Exchange::rbcd_tick(const int *set, int count, int allow_adjacent) {
 int Exchange::set_X(const double *Xh) {
   int rc = barrier();
   if (rc) return rc;
-  rc = s_->set_X(Xh);
+  rc = s_->x_set_X(Xh);
   if (rc) return rc;
   return barrier();
 }
 
 // every rank's hosted blocks -> the shared segment -> every rank's copy of the whole X
 int Exchange::gather_X(double *Xh) {
-  DCORA_HIP(hipSetDevice(s_->opt.device));
-  const int r = s_->r, dh = s_->d + 1;
-  for (const AgentDev &a : s_->agents) {
-    if (!a.hosted) continue;
-    const size_t off = (size_t)a.col0 * r;
-    DCORA_HIP(hipMemcpyAsync(xarea_ + off, s_->Xg.p + off, sizeof(double) * (size_t)r * dh * a.n, hipMemcpyDeviceToHost,
-                             s_->st));
-  }
-  DCORA_HIP(hipStreamSynchronize(s_->st));
-  int rc = barrier();
+  int rc = s_->x_stage_hosted(xarea_);
   if (rc) return rc;
-  std::memcpy(Xh, xarea_, sizeof(double) * (size_t)r * dh * s_->n);
+  rc = barrier();
+  if (rc) return rc;
+  std::memcpy(Xh, xarea_, sizeof(double) * (size_t)s_->x_rank_r() * (size_t)s_->x_num_cols());
   return barrier();
 }
 

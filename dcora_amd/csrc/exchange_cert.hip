@@ -70,7 +70,12 @@ int Exchange::allreduce_sum(double *vals, int count) {
 
 int Exchange::certify(const HostCsr *Qglobal, double eta, int *certified, double *theta, double *lambda_min, double *v,
                       long long *matvecs, int *distributed) {
-  RbcdSession &S = *s_;
+  RbcdSession *pgo = dynamic_cast<RbcdSession *>(s_);
+  if (!pgo)
+    return fail("certify: the row-block certificate operator exists for pose-graph sessions (the range-aided certificate "
+                "is assembled centrally: dcora_cert_dual_matrix on the gathered X)",
+                DCORA_ERR_UNSUPPORTED);
+  RbcdSession &S = *pgo;
   DCORA_HIP(hipSetDevice(S.opt.device));
   const int R = S.R, r = S.r, d = S.d, dh = d + 1, ktot = dh * S.n;
   if (certified) *certified = 0;

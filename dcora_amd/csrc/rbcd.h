@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "device_problem.h"
+#include "exchange_session.h"
 #include "host_graph.h"
 
 namespace dcora {
@@ -35,7 +36,7 @@ struct AgentDev {
   bool last_skipped = false;
 };
 
-class RbcdSession {
+class RbcdSession : public ExchangeSession {
  public:
   int d = 0, r = 0, n = 0, R = 1;
   Partition P;
@@ -83,6 +84,31 @@ class RbcdSession {
   int agent_colours(int *colours, int *ncolours) const;
   int pack_public(int agent, double *packed_dev);
   int unpack_public(int agent, const double *packed_dev);
+
+  // ExchangeSession
+  int x_num_agents() const override { return R; }
+  int x_rank_r() const override { return r; }
+  long x_num_cols() const override { return (long)(d + 1) * n; }
+  int x_rank() const override { return opt.rank; }
+  int x_world() const override { return opt.world_size; }
+  int x_device() const override { return opt.device; }
+  hipStream_t x_stream() const override { return st; }
+  double *x_mirror() override { return Xg.p; }
+  XAgentView x_agent(int a) const override {
+    const AgentDev &ag = agents[(size_t)a];
+    XAgentView v;
+    v.hosted = ag.hosted;
+    v.ncols = (int)ag.public_poses.size() * (d + 1);
+    v.cols_dev = ag.public_cols.p;
+    v.neighbors = &ag.neighbors;
+    return v;
+  }
+  int x_phase_nonselected(int selected) override { return phase_nonselected(selected); }
+  int x_phase_selected(int selected) override { return phase_selected(selected); }
+  int x_phase_evaluate_dev(double *out_dev) override { return phase_evaluate_dev(out_dev); }
+  int x_iterate_set(const int *set, int count, int allow_adjacent) override { return iterate_set(set, count, allow_adjacent); }
+  int x_set_X(const double *Xh) override { return set_X(Xh); }
+  int x_stage_hosted(double *host_area) override;
 
  private:
   bool restart_now() const { return opt.acceleration && ((iteration + 1) % opt.restart_interval == 0); }

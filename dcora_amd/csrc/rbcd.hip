@@ -816,4 +816,16 @@ int RbcdSession::unpack_public(int agent, const double *packed_dev) {
   return DCORA_OK;
 }
 
+int RbcdSession::x_stage_hosted(double *host_area) {
+  DCORA_HIP(hipSetDevice(opt.device));
+  for (const AgentDev &a : agents) {
+    if (!a.hosted) continue;
+    const size_t off = (size_t)a.col0 * r;
+    DCORA_HIP(hipMemcpyAsync(host_area + off, Xg.p + off, sizeof(double) * (size_t)r * (d + 1) * a.n,
+                             hipMemcpyDeviceToHost, st));
+  }
+  DCORA_HIP(hipStreamSynchronize(st));
+  return DCORA_OK;
+}
+
 }  // namespace dcora
