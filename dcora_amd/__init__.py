@@ -598,7 +598,8 @@ class Exchange:
     def __init__(self, session, job_name):
         self.s = session
         self.h = C.c_void_p()
-        check(capi.lib().dcora_exchange_create(session.h, job_name.encode(), C.byref(self.h)))
+        create = capi.lib().dcora_exchange_create_ra if isinstance(session, RaRbcdSession) else capi.lib().dcora_exchange_create
+        check(create(session.h, job_name.encode(), C.byref(self.h)))
 
     def close(self):
         if getattr(self, "h", None):
@@ -680,11 +681,12 @@ class RaRbcdSession:
     """the agents of a multi-robot range-aided SLAM problem + the synchronous RBCD++ driver on the device
     (ref examples/MultiRobotExample_RASLAM.cpp); X is the merged r x k matrix in the RA ordering"""
 
-    def __init__(self, ra, r, acceleration=True, restart_interval=30, params=None, device=0):
+    def __init__(self, ra, r, acceleration=True, restart_interval=30, params=None, device=0, rank=0, world_size=1):
         self.ra, self.r, self.k = ra, r, ra.k
         o = RbcdOptions()
         capi.lib().dcora_rbcd_options_default(C.byref(o))
         o.r, o.acceleration, o.restart_interval, o.device = r, int(acceleration), restart_interval, device
+        o.rank, o.world_size = rank, world_size
         if params is not None:
             o.local = params.c
         dsh = ra.handle()

@@ -1029,6 +1029,19 @@ int dcora_ra_rbcd_create(dcora_radataset_t ds, const dcora_rbcd_options *opt, dc
   return DCORA_OK;
   DCORA_CATCH
 }
+int dcora_exchange_create_ra(dcora_ra_rbcd_t s, const char *job_name, dcora_exchange_t *out) {
+  if (!s || !job_name || !out) return bad("null argument");
+  DCORA_TRY
+  dcora_exchange_s *h = new dcora_exchange_s;
+  const int rc = h->e.init(&s->s, job_name);
+  if (rc) {
+    delete h;
+    return rc;
+  }
+  *out = h;
+  return DCORA_OK;
+  DCORA_CATCH
+}
 int dcora_ra_rbcd_destroy(dcora_ra_rbcd_t s) {
   delete s;
   return DCORA_OK;

@@ -37,9 +37,9 @@ int RaRbcdSession::init(const HostRADataset &ds, const dcora_rbcd_options &o) {
   b = ds.b;
   k = ds.k();
   r = o.r;
-  if (o.world_size != 1 || o.rank != 0) {
-    set_last_error("ra_rbcd: one process hosts every agent (world_size 1)");
-    return DCORA_ERR_UNSUPPORTED;
+  if (o.world_size < 1 || o.rank < 0 || o.rank >= o.world_size) {
+    set_last_error("ra_rbcd: bad rank / world_size");
+    return DCORA_ERR_BAD_ARG;
   }
   if (r < d || r > 16) {
     set_last_error("ra_rbcd: need d <= r <= 16");
@@ -80,10 +80,23 @@ int RaRbcdSession::init(const HostRADataset &ds, const dcora_rbcd_options &o) {
   DCORA_HIP(hipMemset(Xg.p, 0, sizeof(double) * N));
   DCORA_HIP(evalbuf.alloc(R + 8));
   agents.resize(R);
+  const int per = (R + o.world_size - 1) / o.world_size;  // consecutive agents share a rank, as in the pose-graph session
+  std::vector<int> owner_of((size_t)k, -1);               // global column -> agent
+  std::vector<std::set<int>> pub((size_t)R), nbr((size_t)R);
   int idx = 0;
   for (int robot : robots) {
-    RaAgentDev &a = agents[idx++];
+    RaAgentDev &a = agents[idx];
     a.robot = robot;
+    a.hosted = (idx / per) == o.rank;
+    int dims3[3];
+    ra_agent_columns(ds, robot, dims3, a.own_host);
+    for (int c : a.own_host) owner_of[(size_t)c] = idx;
+    ++idx;
+  }
+  idx = 0;
+  for (int robot : robots) {
+    RaAgentDev &a = agents[idx];
+    const int me = idx++;
     int dims3[3];
     std::vector<int> own;
     ra_agent_columns(ds, robot, dims3, own);
@@ -93,6 +106,16 @@ int RaRbcdSession::init(const HostRADataset &ds, const dcora_rbcd_options &o) {
     a.k = (int)own.size();
     HostCsr Qaa, C;
     extract_agent_blocks(Q, own, &Qaa, &C);
+    // the columns of OTHER agents my coupling block reaches are their public variables; their owners my neighbours
+    for (int c : C.ci) {
+      const int q = owner_of[(size_t)c];
+      if (q >= 0 && q != me) {
+        pub[(size_t)q].insert(c);
+        nbr[(size_t)me].insert(q);
+        nbr[(size_t)q].insert(me);
+      }
+    }
+    if (!a.hosted) continue;  // agents of other ranks: their columns and public variables are all this rank keeps
     int rc = device_precond_regularization(Qaa, o.device, &a.reg);  // ref src/Graph.cpp:1901-1960, per agent
     if (rc) return rc;
     a.prob.reset(new DeviceProblem);
@@ -110,10 +133,20 @@ int RaRbcdSession::init(const HostRADataset &ds, const dcora_rbcd_options &o) {
     DCORA_HIP(a.XPrev.alloc(Na));
     DCORA_HIP(a.tmp.alloc(Na));
   }
-  central.reset(new DeviceProblem);
-  dcora_dims dims{r, d, n, l, b};
-  int rc = central->init(dims, Q, nullptr, -1.0, o.device, st);
-  if (rc) return rc;
+  for (int i = 0; i < R; ++i) {
+    RaAgentDev &a = agents[(size_t)i];
+    a.neighbors.assign(nbr[(size_t)i].begin(), nbr[(size_t)i].end());
+    std::vector<int> pc(pub[(size_t)i].begin(), pub[(size_t)i].end());
+    a.n_public = (int)pc.size();
+    DCORA_HIP(a.public_cols.alloc(std::max<size_t>(pc.size(), 1)));
+    if (!pc.empty()) DCORA_HIP(hipMemcpy(a.public_cols.p, pc.data(), sizeof(int) * pc.size(), hipMemcpyHostToDevice));
+  }
+  if (o.world_size == 1) {  // the central evaluation of the one-process loop; ranks evaluate agent by agent
+    central.reset(new DeviceProblem);
+    dcora_dims dims{r, d, n, l, b};
+    int rc = central->init(dims, Q, nullptr, -1.0, o.device, st);
+    if (rc) return rc;
+  }
   iteration = 0;
   gamma = alpha = 0;
   setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -125,6 +158,7 @@ int RaRbcdSession::set_X(const double *Xh) {
   const size_t B = sizeof(double) * (size_t)r * k;
   DCORA_HIP(hipMemcpyAsync(Xg.p, Xh, B, hipMemcpyHostToDevice, st));
   for (RaAgentDev &a : agents) {
+    if (!a.hosted) continue;
     const size_t Ba = sizeof(double) * (size_t)r * a.k;
     launch_gather_cols(st, r, a.k, a.own.p, Xg.p, a.X.p);
     DCORA_HIP(hipMemcpyAsync(a.V.p, a.X.p, Ba, hipMemcpyDeviceToDevice, st));
@@ -172,7 +206,9 @@ int RaRbcdSession::solve(RaAgentDev &a, const double *start, double **result) {
   return DCORA_OK;
 }
 
-int RaRbcdSession::iterate(int selected, double *cost2, double *gradnorm, double *block_norms, int *next_selected) {
+// Agent::iterate(false) of the hosted non-selected agents (ref src/Agent.cpp:535-551, 1202-1214): the shared Nesterov
+// sequences advance once per round on every rank alike
+int RaRbcdSession::phase_nonselected(int selected) {
   if (selected < 0 || selected >= R) {
     set_last_error("ra_rbcd: selected agent out of range");
     return DCORA_ERR_BAD_ARG;
@@ -185,10 +221,11 @@ int RaRbcdSession::iterate(int selected, double *cost2, double *gradnorm, double
     alpha = 1.0 / (gamma * R);
   }
   const bool restart = restart_now();
-  // Agent::iterate(false) of the others (ref :535-551, 1202-1214): Y = proj((1 - alpha) X + alpha V), X = Y, V = proj(V)
+  // Y = proj((1 - alpha) X + alpha V), X = Y, V = proj(V)
   for (int i = 0; i < R; ++i) {
     if (i == selected) continue;
     RaAgentDev &a = agents[i];
+    if (!a.hosted) continue;
     const ManiDesc &m = a.prob->m;
     const size_t Ba = sizeof(double) * (size_t)r * a.k;
     DCORA_HIP(hipMemcpyAsync(a.XPrev.p, a.X.p, Ba, hipMemcpyDeviceToDevice, st));
@@ -203,9 +240,20 @@ int RaRbcdSession::iterate(int selected, double *cost2, double *gradnorm, double
       scatter(a);
     }
   }
-  // Agent::iterate(true) of the selected one
-  {
-    RaAgentDev &a = agents[selected];
+  return DCORA_OK;
+}
+
+// Agent::iterate(true) of the selected agent, where it lives
+int RaRbcdSession::phase_selected(int selected) {
+  if (selected < 0 || selected >= R) {
+    set_last_error("ra_rbcd: selected agent out of range");
+    return DCORA_ERR_BAD_ARG;
+  }
+  DCORA_HIP(hipSetDevice(opt.device));
+  const bool accel = opt.acceleration != 0;
+  const bool restart = restart_now();
+  RaAgentDev &a = agents[selected];
+  if (a.hosted) {
     const ManiDesc &m = a.prob->m;
     const size_t Ba = sizeof(double) * (size_t)r * a.k;
     DCORA_HIP(hipMemcpyAsync(a.XPrev.p, a.X.p, Ba, hipMemcpyDeviceToDevice, st));
@@ -231,15 +279,69 @@ int RaRbcdSession::iterate(int selected, double *cost2, double *gradnorm, double
     scatter(a);
   }
   if (restart) gamma = alpha = 0;
+  return DCORA_OK;
+}
+
+int RaRbcdSession::iterate(int selected, double *cost2, double *gradnorm, double *block_norms, int *next_selected) {
+  if (opt.world_size != 1) {
+    set_last_error("ra_rbcd: with one process per GPU the loop body is dcora_exchange_rbcd_iterate");
+    return DCORA_ERR_UNSUPPORTED;
+  }
+  int rc = phase_nonselected(selected);
+  if (rc) return rc;
+  rc = phase_selected(selected);
+  if (rc) return rc;
   int nxt = selected;
-  const int rc = evaluate(cost2, gradnorm, block_norms, &nxt);
+  rc = evaluate(cost2, gradnorm, block_norms, &nxt);
   if (rc) return rc;
   if (next_selected) *next_selected = (agents[selected].coupling.nnz > 0) ? nxt : selected;
   return DCORA_OK;
 }
 
+// distributed form of the evaluation: per hosted agent |Proj(X_a Q_aa + G_a)|^2 and <X_a, X_a Q_aa + G_a>, G_a from the
+// neighbours' public variables in the mirror
+int RaRbcdSession::phase_evaluate_dev(double *out_dev) {
+  DCORA_HIP(hipSetDevice(opt.device));
+  DCORA_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * 2 * R, st));
+  for (int i = 0; i < R; ++i) {
+    RaAgentDev &a = agents[i];
+    if (!a.hosted) continue;
+    DeviceProblem &pb = *a.prob;
+    launch_spmm(st, r, a.coupling.view(), buf1(Xg.p), 0, nullptr, buf1(pb.G.p), 0, nullptr, Gate{});
+    pb.has_G = true;
+    pb.enqueue_egrad(a.X.p, pb.EG1.p, nullptr);
+    launch_rgrad(st, pb.m, buf1(a.X.p), buf1(pb.EG1.p), buf1(pb.RG1.p), Buf2{{nullptr, nullptr}}, 0, pb.pB.p, Gate{});
+    launch_sum_partials(st, pb.pB.p, pb.npPose(), 1, 1, out_dev + 2 * i);
+    launch_dot(st, pb.nelem(), a.X.p, pb.EG1.p, pb.p3.p);
+    launch_sum_partials(st, pb.p3.p, pb.npVec(), 1, 1, out_dev + 2 * i + 1);
+  }
+  return DCORA_OK;
+}
+
+int RaRbcdSession::x_iterate_set(const int *, int, int) {
+  set_last_error("ra_rbcd: simultaneous updates are a pose-graph session feature");
+  return DCORA_ERR_UNSUPPORTED;
+}
+
+int RaRbcdSession::x_stage_hosted(double *host_area) {
+  DCORA_HIP(hipSetDevice(opt.device));
+  std::vector<double> whole((size_t)r * k);
+  DCORA_HIP(hipMemcpyAsync(whole.data(), Xg.p, sizeof(double) * whole.size(), hipMemcpyDeviceToHost, st));
+  DCORA_HIP(hipStreamSynchronize(st));
+  for (const RaAgentDev &a : agents) {
+    if (!a.hosted) continue;
+    for (int c : a.own_host)
+      std::copy(&whole[(size_t)c * r], &whole[(size_t)c * r] + r, host_area + (size_t)c * r);
+  }
+  return DCORA_OK;
+}
+
 // central evaluation of the driver: 2 f, |rgrad| of the merged problem, per-agent |rgrad_a|, greedy selection
 int RaRbcdSession::evaluate(double *cost2, double *gradnorm, double *block_norms, int *next_selected) {
+  if (!central) {
+    set_last_error("ra_rbcd: the central evaluation needs world_size == 1 (ranks: dcora_exchange_evaluate)");
+    return DCORA_ERR_UNSUPPORTED;
+  }
   DCORA_HIP(hipSetDevice(opt.device));
   DeviceProblem &c = *central;
   c.enqueue_egrad(Xg.p, c.EG0.p, c.pA.p);

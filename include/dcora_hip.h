@@ -398,6 +398,13 @@ int dcora_debug_exchange_leave_stale(const char *job_name, int world_size, int n
 typedef struct dcora_ra_rbcd_s *dcora_ra_rbcd_t;
 /* opt->num_robots is ignored (the file decides); opt->local are the agents' localOptimizationParams */
 int dcora_ra_rbcd_create(dcora_radataset_t ds, const dcora_rbcd_options *opt, dcora_ra_rbcd_t *out);
+/* the same exchange for the agents of a multi-robot range-aided SLAM problem (ref examples/MultiRobotExample_RASLAM.cpp;
+ * ownership by robot symbol, src/DCORA_utils.cpp:1370-1512): the session was created by dcora_ra_rbcd_create with
+ * rank / world_size (agent i on rank i / ceil(R / world_size)); an agent's public variables are its poses, unit spheres
+ * and landmarks that other agents' measurements reach.  dcora_exchange_set_X / _rbcd_iterate / _evaluate / _gather_X /
+ * _post / _wait / _all_ready work as for pose graphs; _rbcd_tick and _certify are pose-graph calls (the range-aided
+ * certificate is assembled from the gathered X: dcora_cert_dual_matrix + dcora_cert_fast_verification). */
+int dcora_exchange_create_ra(dcora_ra_rbcd_t s, const char *job_name, dcora_exchange_t *out);
 int dcora_ra_rbcd_destroy(dcora_ra_rbcd_t s);
 /* number of agents and (robots != NULL) their robot ids ('A' = 0, ...) */
 int dcora_ra_rbcd_info(dcora_ra_rbcd_t s, int *num_agents, int *robots);
