@@ -276,6 +276,14 @@ class QuadraticProblem:
         check(capi.lib().dcora_problem_hessvec(self.h, F(Y), F(V), out))
         return unF(out, self.r, self.k)
 
+    def HessVecSolverForm(self, Y, V):
+        """test hook: H[V] as the generic solver loop forms it (one launch) and {<V, H V> from that kernel's partial
+        sums, the same from the two-launch form}"""
+        out = self._out()
+        dots = np.zeros(2)
+        check(capi.lib().dcora_debug_hessvec_solver_form(self.h, F(Y), F(V), out, dots))
+        return unF(out, self.r, self.k), dots
+
     def PreCondition(self, Y, V):
         out = self._out()
         check(capi.lib().dcora_problem_precondition(self.h, F(Y), F(V), out))

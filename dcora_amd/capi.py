@@ -77,6 +77,7 @@ SIGNATURES = {
     "dcora_problem_eucgrad": (C.c_int, [_vp, _dp, _dp]),
     "dcora_problem_riegrad": (C.c_int, [_vp, _dp, _vp, _PD]),
     "dcora_problem_hessvec": (C.c_int, [_vp, _dp, _dp, _dp]),
+    "dcora_debug_hessvec_solver_form": (C.c_int, [_vp, _dp, _dp, _dp, _dp]),
     "dcora_problem_precondition": (C.c_int, [_vp, _dp, _dp, _dp]),
     "dcora_problem_retract": (C.c_int, [_vp, _dp, _dp, _dp]),
     "dcora_problem_tangent_project": (C.c_int, [_vp, _dp, _dp, _dp]),

@@ -149,6 +149,9 @@ int dcora_problem_riegrad(dcora_problem_t p, const double *X, double *out, doubl
 int dcora_problem_hessvec(dcora_problem_t p, const double *X, const double *V, double *out) {
   return p ? p->p.hessvec(X, V, out) : bad("null");
 }
+int dcora_debug_hessvec_solver_form(dcora_problem_t p, const double *X, const double *V, double *out, double *dots) {
+  return p ? p->p.hessvec_solver_form(X, V, out, dots) : bad("null");
+}
 int dcora_problem_precondition(dcora_problem_t p, const double *X, const double *V, double *out) {
   return p ? p->p.precondition(X, V, out) : bad("null");
 }

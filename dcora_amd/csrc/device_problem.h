@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <functional>
 #include <memory>
 #include <string>
 #include <vector>
@@ -88,6 +89,7 @@ struct DevBsr {
 struct DevCsr {
   int nrows = 0, ncols = 0, nnz = 0, n_long = 0;
   DevBuf<int> rp, ci, long_rows, long_cnt;
+  std::vector<int> long_host;  // the long rows' indices, host copy
   DevBuf<double> v, long_part;
   int upload(const HostCsr &A);
   int upload(int nrows, int ncols, const int *rp, const int *ci, const double *v);
@@ -156,7 +158,10 @@ class SparsePrecond {
   int launches() const { return (int)im->levels.size() + 2 + (im->nhub > 0 ? 1 : 0); }
   // Z = R A^-1 for r <= rcap right-hand sides (r x k column-major); R is picked by ctl->cur when g.ctl is set.
   // levels_only: the right-hand side is already in y and the result is read from y (fold())
-  void apply(hipStream_t st, int r, Buf2 R, double *Z, Gate g, bool levels_only = false) const;
+  // after_first: called once the first launch of the replay is enqueued; returning false ends the enqueue there (the
+  // caller has learnt meanwhile that the gate is closed and the remaining launches would be no-ops)
+  void apply(hipStream_t st, int r, Buf2 R, double *Z, Gate g, bool levels_only = false,
+             const std::function<bool()> *after_first = nullptr) const;
   double bytes_per_apply(int r) const;
 };
 
@@ -234,6 +239,10 @@ class DeviceProblem {
   int eucgrad(const double *Xh, double *out);
   int riegrad(const double *Xh, double *out, double *norm);
   int hessvec(const double *Xh, const double *Vh, double *out);
+  // the Hessian-vector product as the generic solver loop forms it (k_spmm_dir_fix: one launch); dots = {<V, H V>
+  // from that kernel's partial sums, the same from k_hessfix's}.  Tests of the kernel against hessvec().
+  int hessvec_solver_form(const double *Xh, const double *Vh, double *out, double *dots);
+  bool hess_one_launch() const;  // every long row is a Euclidean column and the partial slots fit
   int precondition(const double *Xh, const double *Vh, double *out);
   int retract(const double *Xh, const double *Vh, double *out);
   int tangent_project(const double *Xh, const double *Vh, double *out);

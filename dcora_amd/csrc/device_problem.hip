@@ -46,6 +46,7 @@ int DevCsr::upload(int nr, int nc, const int *rph, const int *cih, const double 
     n_long = 0;
     lr.clear();
   }
+  long_host = lr;
   DCORA_HIP(long_rows.alloc(std::max(n_long, 1)));
   if (n_long) DCORA_HIP(hipMemcpy(long_rows.p, lr.data(), sizeof(int) * n_long, hipMemcpyHostToDevice));
   DCORA_HIP(long_part.alloc((size_t)std::max(n_long, 1) * kLongSplit * 16));
@@ -462,6 +463,49 @@ int DeviceProblem::hessvec(const double *Xh, const double *Vh, double *out) {
   launch_hessfix(st, m, buf1(X0.p), buf1(S0.p), delta.p, W.p, Hd.p, p1.p, Gate{});
   return download(Hd.p, out, nelem());
 }
+bool DeviceProblem::hess_one_launch() const {
+  if (spmm_dir_fix_grid(m, m.k) <= 0 || spmm_dir_fix_grid(m, m.k) + Q.n_long > 4 * kMaxPartials) return false;
+  for (int jl : Q.long_host) {
+    const bool euclid = m.se ? (jl % (m.d + 1) == m.d) : (jl >= m.d * m.n + m.l);
+    if (!euclid) return false;
+  }
+  return true;
+}
+int DeviceProblem::hessvec_solver_form(const double *Xh, const double *Vh, double *out, double *dots) {
+  if (!hess_one_launch()) {
+    set_last_error("hessvec_solver_form: the one-launch form does not apply to this problem");
+    return DCORA_ERR_UNSUPPORTED;
+  }
+  DCORA_HIP(hipSetDevice(device));
+  int rc = upload(Xh, X0.p, nelem());
+  if (rc) return rc;
+  std::vector<double> neg(Vh, Vh + nelem());
+  for (double &v : neg) v = -v;
+  rc = upload(neg.data(), z.p, nelem());  // iteration 0 of the loop: delta = -z
+  if (rc) return rc;
+  rc = upload(Vh, delta2.p, nelem());
+  if (rc) return rc;
+  enqueue_egrad(X0.p, EG0.p, nullptr);
+  launch_rgrad(st, m, buf1(X0.p), buf1(EG0.p), buf1(RG0.p), buf1(S0.p), 0, pB.p, Gate{});
+  DCORA_HIP(hipMemsetAsync(p3.p, 0, sizeof(double), st));
+  const int np = launch_spmm_dir_fix(st, m, Q.view(), buf1(X0.p), buf1(S0.p), z.p, delta2.p, delta.p, Hd.p, p3.p, 1, p1.p,
+                                     ctl.p, 0, 0);
+  std::vector<double> part((size_t)np);
+  rc = download(p1.p, part.data(), part.size());
+  if (rc) return rc;
+  dots[0] = 0;
+  for (double v : part) dots[0] += v;
+  rc = download(Hd.p, out, nelem());
+  if (rc) return rc;
+  launch_spmm(st, m.r, Q.view(), buf1(delta.p), 0, nullptr, buf1(W.p), 0, nullptr, Gate{});
+  launch_hessfix(st, m, buf1(X0.p), buf1(S0.p), delta.p, W.p, Hd.p, p1.p, Gate{});
+  part.assign((size_t)npPose(), 0.0);
+  rc = download(p1.p, part.data(), part.size());
+  if (rc) return rc;
+  dots[1] = 0;
+  for (double v : part) dots[1] += v;
+  return DCORA_OK;
+}
 int DeviceProblem::precondition(const double *Xh, const double *Vh, double *out) {
   if (!has_precond) {
     set_last_error("problem has no preconditioner");
@@ -653,6 +697,7 @@ int DeviceProblem::rtr_dev(const dcora_ropt_params &prm, dcora_ropt_result *res_
   hf->last_seq_done = 0;
   hf->tcg_done_seq = 0;
   hf->outer_done_seq = 0;
+  hf->go_seq = 0;
   SolverCtl *c = ctl.p;
   const long N = nelem();
   const CsrDev Qv = Q.view();
@@ -675,6 +720,16 @@ int DeviceProblem::rtr_dev(const dcora_ropt_params &prm, dcora_ropt_result *res_
   std::vector<int> upd2_seq((size_t)std::max(1, h.max_inner));
   static const bool no_fold = std::getenv("DCORA_RA_NOFOLD") != nullptr;
   const SpFold sfg = (sparse_precond && !no_fold) ? sp.fold_generic() : SpFold();
+  // H d in one launch (k_spmm_dir_fix) when every long row is a Euclidean column and the partial slots fit
+  static const bool hess_split = [] {
+    const char *e = std::getenv("DCORA_HESS_FUSE");
+    return e && std::string(e) == "0";
+  }();
+  const bool hess_fused = !hess_split && hess_one_launch();
+  static const bool sp_lookahead_generic = [] {
+    const char *e = std::getenv("DCORA_SP_PACING");
+    return e && std::string(e) == "lookahead";
+  }();
   for (int outer = 0; outer < h.max_outer; ++outer) {
     // wait for the previous decision (rtr_init / rtr_decide) before committing to another outer iteration
     if (!spin_until([&] { return hf->last_seq_done >= last_pace_seq || hf->outer_done_seq != 0; }, 20.0))
@@ -702,14 +757,35 @@ int DeviceProblem::rtr_dev(const dcora_ropt_params &prm, dcora_ropt_result *res_
       }
       if (hf->tcg_done_seq >= tcg_first_seq) break;
       double *const dcur = db[j & 1];
-      launch_spmm_dir(st, m.r, Qv, z.p, db[(j + 1) & 1], dcur, W.p, p3.p, nP, c, ++seq, j);
-      launch_hessfix(st, m, Xb(), Sb(), dcur, W.p, Hd.p, p1.p, Gate{c, ++seq, 2});
+      int nP1 = nP;
+      if (hess_fused) {
+        nP1 = launch_spmm_dir_fix(st, m, Qv, Xb(), Sb(), z.p, db[(j + 1) & 1], dcur, Hd.p, p3.p, nP, p1.p, c, ++seq, j);
+      } else {
+        launch_spmm_dir(st, m.r, Qv, z.p, db[(j + 1) & 1], dcur, W.p, p3.p, nP, c, ++seq, j);
+        launch_hessfix(st, m, Xb(), Sb(), dcur, W.p, Hd.p, p1.p, Gate{c, ++seq, 2});
+      }
       // sparse preconditioner: its two permutations (and the hub correction) ride in the kernels either side of the
       // level replay -- two launches fewer per tCG iteration
-      launch_tcg_update1(st, N, dcur, Hd.p, eta.p, Heta.p, res.p, p1.p, nP, p2.p, c, hf_dev, ++seq, j, m.r, sfg);
-      if (sfg.y)
-        sp.apply(st, m.r, buf1(res.p), Zt.p, Gate{c, ++seq, 2}, true);
-      else
+      launch_tcg_update1(st, N, dcur, Hd.p, eta.p, Heta.p, res.p, p1.p, nP1, p2.p, c, hf_dev, ++seq, j, m.r, sfg);
+      if (sfg.y) {
+        // as in rtr_dev_fused: only the replay's first launch is enqueued before update1's verdict is known
+        const int seqB = seq;
+        bool timed = false;
+        const std::function<bool()> verdict = [&]() {
+          if (!spin_until(
+                  [&] {
+                    return hf->go_seq >= seqB || hf->tcg_done_seq >= tcg_first_seq || hf->outer_done_seq != 0;
+                  },
+                  20.0)) {
+            timed = true;
+            return false;
+          }
+          return !(hf->tcg_done_seq >= tcg_first_seq || hf->outer_done_seq != 0);
+        };
+        sp.apply(st, m.r, buf1(res.p), Zt.p, Gate{c, ++seq, 2}, true, sp_lookahead_generic ? nullptr : &verdict);
+        if (timed) return timed_out();
+        if (!sp_lookahead_generic && (hf->tcg_done_seq >= tcg_first_seq || hf->outer_done_seq != 0)) break;
+      } else
         enq_minv(buf1(res.p), Zt.p, p2.p, nV, Gate{c, ++seq, 2});
       launch_tangent(st, m, Xb(), Zt.p, z.p, res.p, p3.p, p2.p, nV, c, hf_dev, ++seq, 2, j, sfg);
       // the inner loop exhausted: the bookkeeping of the last direction update (status TR_MAXITER) has no next SpMM
@@ -771,6 +847,7 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
     hf->last_seq_done = 0;
     hf->tcg_done_seq = 0;
     hf->outer_done_seq = 0;
+    hf->go_seq = 0;
     seq_ = 0;
   }
   int &seq = seq_;
@@ -795,8 +872,20 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
   const bool folded = sparse_precond && sp.foldable() && !no_fold;
   const SpFold sf = folded ? sp.fold() : SpFold{};
   const int nsl = sparse_precond ? 1 : -1;
+  static const bool sp_lookahead = [] {
+    const char *e = std::getenv("DCORA_SP_PACING");
+    return e && std::string(e) == "lookahead";
+  }();
+  const bool sp_paced = sparse_precond && !sp_lookahead;
+  // the same verdict pacing for the dense B+C form is opt-in: on the headline the trace shows next to no no-op
+  // launches to save (69 of 38 800) and the tighter pacing opens more gaps than it closes
+  static const bool pc_verdict = [] {
+    const char *e = std::getenv("DCORA_PC_PACING");
+    return e && std::string(e) == "verdict";
+  }();
   // dense preconditioner: B and C are ONE launch (k_fused_pc); DCORA_SOLVER_BC=split keeps the three-launch form
   const bool pc = use_pc();
+  const bool pc_paced = pc && pc_verdict;
   const int nZ = pc ? fused_pc_blocks(m) : nPB;  // <z, r> partial slots A sums in its prologue
   double *dbuf[2] = {delta.p, delta2.p};
   double *rbuf[2] = {res.p, res2.p};
@@ -844,7 +933,16 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
       launch_fused_finish(st, m, Xb(), Zpart.p, rbuf[0], z.p, nullptr, 0, p3.p, c, hf_dev, ++seq, 0, 1, nsl, sf);
     }
     for (int j = 0; j < max_inner; ++j) {
-      if (j >= kLookahead) {
+      if (pc_paced && j >= 1) {
+        // B+C of iteration j-1 takes its boundary decision in its first microseconds and says so (go_seq): iteration
+        // j is enqueued behind that verdict, while the rest of that kernel runs, instead of two iterations ahead --
+        // a run that ends on the boundary or on negative curvature then leaves no no-op launches behind it, one
+        // that ends on the residual rule (known at the END of B+C) leaves one iteration of them instead of two
+        const int need = fin_seq[j - 1];
+        if (!spin_until([&] { return hf->go_seq >= need || hf->tcg_done_seq >= tcg_first_seq || outer_done(); },
+                        20.0))
+          return timed_out();
+      } else if (j >= kLookahead) {
         const int need = fin_seq[j - kLookahead];
         if (!spin_until(
                 [&] { return hf->last_seq_done >= need || hf->tcg_done_seq >= tcg_first_seq || outer_done(); }, 20.0))
@@ -860,7 +958,28 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
       } else {
         launch_fused_precond(st, m, ldm, Mi, RGb(), dbuf[par], Hd.p, eta.p, Heta.p, rbuf[par], rbuf[par ^ 1],
                              Zpart.p, p1.p, nP1, p2.p, c, hf_dev, ++seq, j, 0, sf);
-        if (sparse_precond) sp.apply(st, m.r, buf1(rbuf[par ^ 1]), Zpart.p, Gate{c, ++seq, 2}, folded);
+        if (sparse_precond) {
+          // B decides whether this tCG run goes on (boundary, negative curvature); the replay's launches behind a B
+          // that stopped are no-ops of ~4 us each, and runs of one or two iterations are the rule on the large
+          // blocks.  So only the replay's FIRST launch is enqueued on speculation: the host reads B's verdict while
+          // the GPU runs it, and enqueues the rest (and C) only behind a B that went on.
+          const int seqB = seq;
+          bool timed = false;
+          const std::function<bool()> verdict = [&]() {
+            if (!spin_until(
+                    [&] {
+                      return hf->go_seq >= seqB || hf->tcg_done_seq >= tcg_first_seq || outer_done();
+                    },
+                    20.0)) {
+              timed = true;
+              return false;
+            }
+            return !(hf->tcg_done_seq >= tcg_first_seq || outer_done());
+          };
+          sp.apply(st, m.r, buf1(rbuf[par ^ 1]), Zpart.p, Gate{c, ++seq, 2}, folded, sp_paced ? &verdict : nullptr);
+          if (timed) return timed_out();
+          if (sp_paced && (hf->tcg_done_seq >= tcg_first_seq || outer_done())) break;
+        }
         launch_fused_finish(st, m, Xb(), Zpart.p, rbuf[par ^ 1], z.p, p2.p, nPG, p3.p, c, hf_dev, ++seq, j, 0, nsl,
                             sf);
       }

@@ -91,6 +91,7 @@ struct HostFlags {
   volatile int last_seq_done;   // seq of the latest pacing kernel whose block 0 finished
   volatile int tcg_done_seq;    // seq at which the current/last tCG terminated
   volatile int outer_done_seq;  // seq at which the RTR loop terminated (0 = running)
+  volatile int go_seq;          // seq of the latest fused B (or B+C) kernel whose boundary test let the tCG run go on
 };
 
 // Solver-aware launches carry (ctl, seq, gate): gate 0 = always run, 1 = skip once the RTR loop is done,
@@ -105,6 +106,12 @@ struct Gate {
 int spmm_grid(int nrows, int r);
 // W = (-z + beta d_old) Q with the direction written to d_new and the tCG scalar recurrence of iteration `iter`
 // (k_tcg_init for iter 0, k_tcg_update2 of iteration iter - 1 otherwise) folded in
+// k_spmm_dir with k_hessfix folded in (one launch per tCG iteration of the generic layout); returns the number of
+// <delta, Hd> partial slots written to p1.  spmm_dir_fix_grid: 0 when r is too large for whole items per workgroup.
+int spmm_dir_fix_grid(const ManiDesc &m, int nrows);
+int launch_spmm_dir_fix(hipStream_t st, const ManiDesc &m, const CsrDev &A, Buf2 X, Buf2 Sblk, const double *z,
+                        const double *d_old, double *d_new, double *Hd, const double *p3, int np3, double *p1,
+                        SolverCtl *ctl, int seq, int iter);
 void launch_spmm_dir(hipStream_t st, int r, const CsrDev &A, const double *z, const double *d_old, double *d_new,
                      double *W, const double *p3, int np3, SolverCtl *ctl, int seq, int iter);
 inline int spmm_slots(const CsrDev &A, int r) { return spmm_grid(A.nrows, r) + A.n_long; }  // partial slots written

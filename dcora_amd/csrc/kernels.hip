@@ -406,6 +406,257 @@ __global__ __launch_bounds__(kBlock) void k_spmm_dir(int r, CsrDev A, const doub
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// The same with ROPTLIB's EucHvToHv (k_hessfix) folded in: one launch per tCG iteration instead of two.
+//   delta_new = -z + beta delta_old,  W = delta_new Q,  Hd = Proj_X(W - delta_new S),  partial <delta_new, Hd>
+// A workgroup owns whole manifold items: its rows-per-block count is a multiple of the rotation block's width (d,
+// or d + 1 in the pose layout), so the d columns a Stiefel projection couples sit in one workgroup and meet in LDS.
+// Long rows (served by their own workgroups) must be Euclidean columns (spmm_dir_fix_ok): their Hd is W itself.
+// The arithmetic follows k_hessfix term by term (sub_AS, sym_gram, sub_AS); only the order in which the partial
+// sums of <delta, Hd> are added differs.
+// ------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_spmm_dir_fix(ManiDesc m, CsrDev A, Buf2 Xb, Buf2 Sb,
+                                                         const double *__restrict__ z,
+                                                         const double *__restrict__ d_old, double *__restrict__ d_new,
+                                                         double *__restrict__ Hd, const double *__restrict__ p3,
+                                                         int np3, double *__restrict__ p1, SolverCtl *ctl, int seq,
+                                                         int iter, int main_grid) {
+  if (gated(ctl, seq, 2)) return;
+  __shared__ int s_ci[kSpmmTile];
+  __shared__ double s_v[kSpmmTile];
+  __shared__ double s_red[16];
+  __shared__ double s_V[kBlock], s_T[kBlock], s_Y[kBlock];
+  __shared__ int s_last;
+  const int r = m.r;
+  const int par = (iter - 1) & 1;
+  const double z_r_new = sum_partials(p3, np3, 1, 0, s_red);
+  const double beta = iter > 0 ? z_r_new / ctl->z_r[par] : 0.0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (iter == 0) {
+      ctl->z_r[0] = z_r_new;
+      ctl->d_Pd[0] = z_r_new;
+      ctl->e_Pe[0] = 0;
+      ctl->e_Pd[0] = 0;
+    } else {
+      const double alpha = ctl->alpha;
+      const double d_Pd = ctl->d_Pd[par], e_Pd = ctl->e_Pd[par];
+      ctl->z_r[par ^ 1] = z_r_new;
+      ctl->e_Pd[par ^ 1] = beta * (e_Pd + alpha * d_Pd);
+      ctl->d_Pd[par ^ 1] = z_r_new + beta * beta * d_Pd;
+      ctl->e_Pe[par ^ 1] = ctl->e_Pe_n;
+    }
+  }
+  const double *X = pick(Xb, ctl, 0);
+  const double *Sblk = pick(Sb, ctl, 0);
+  const int al = m.se ? D + 1 : D;
+  const int RB = ((kBlock / r) / al) * al;
+  const int nrb = (A.nrows + RB - 1) / RB;
+  const int lj = threadIdx.x / r, t = threadIdx.x - lj * r;
+  auto dir = [&](size_t o) -> double { return iter > 0 ? fma(beta, d_old[o], -z[o]) : -z[o]; };
+  if ((int)blockIdx.x >= main_grid) {  // a slice of a long (Euclidean) row
+    const int li = ((int)blockIdx.x - main_grid) / kLongSplit, sl = ((int)blockIdx.x - main_grid) % kLongSplit;
+    const int j = A.long_rows[li];
+    const int rb0 = A.rp[j], re0 = A.rp[j + 1];
+    const int per = (re0 - rb0 + kLongSplit - 1) / kLongSplit;
+    const int pb = rb0 + sl * per, pe = min(re0, pb + per);
+    const int RBl = kBlock / r;
+    double acc = 0;
+    if (lj < RBl) {
+      for (int p = pb + lj; p < pe; p += 8 * RBl) {
+        int c8[8];
+        double w8[8], x8[8], y8[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int pp = p + q * RBl;
+          const bool ok = pp < pe;
+          c8[q] = A.ci[ok ? pp : rb0];
+          w8[q] = ok ? A.v[pp] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const size_t o = (size_t)c8[q] * r + t;
+          x8[q] = z[o];
+          y8[q] = iter > 0 ? d_old[o] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc += w8[q] * fma(beta, y8[q], -x8[q]);
+      }
+    }
+    double *s_part = s_v;
+    __syncthreads();
+    s_part[threadIdx.x] = (lj < RBl) ? acc : 0.0;
+    __syncthreads();
+    if ((int)threadIdx.x < r) {
+      double y = 0;
+      for (int q = 0; q < RBl; ++q) y += s_part[q * r + threadIdx.x];
+      __hip_atomic_store(A.long_part + ((size_t)li * kLongSplit + sl) * 16 + threadIdx.x, y, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0)
+      s_last = (__hip_atomic_fetch_add(A.long_cnt + li, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) ==
+                kLongSplit - 1);
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) __hip_atomic_store(A.long_cnt + li, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < 64) {  // r <= 16: the row's r entries sit in the first wave
+      double dot = 0;
+      if ((int)threadIdx.x < r) {
+        double y = 0;
+        for (int q = 0; q < kLongSplit; ++q)
+          y += __hip_atomic_load(A.long_part + ((size_t)li * kLongSplit + q) * 16 + threadIdx.x, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+        const size_t o = (size_t)j * r + threadIdx.x;
+        const double dn = dir(o);
+        Hd[o] = y;
+        d_new[o] = dn;
+        dot = dn * y;
+      }
+      // ONE slot per long row, written by whichever slice arrives last: a slot per slice would move the row's term
+      // around the partial array from run to run, and with it the order of the consumer's sum
+      dot = wave_sum(dot);
+      if (threadIdx.x == 0) p1[main_grid + li] = dot;
+    }
+    return;
+  }
+  const int n_rot_rows = m.se ? A.nrows : m.n * D;  // rows below this bound belong to pose items
+  double dacc = 0;
+  for (int rb = blockIdx.x; rb < nrb; rb += main_grid) {
+    const int j0 = rb * RB;
+    const int j1 = min(A.nrows, j0 + RB);
+    const int j = j0 + lj;
+    const bool active = (lj < RB) && (j < j1);
+    const int pbeg = A.rp[j0], pend = A.rp[j1];
+    int myb = active ? A.rp[j] : 0, mye = active ? A.rp[j + 1] : 0;
+    const bool is_long = A.n_long > 0 && (mye - myb > kLongRow);  // served by its own workgroups
+    if (is_long) mye = myb;
+    const size_t o = (size_t)(active ? j : j0) * r + t;
+    const double own = active ? dir(o) : 0.0;
+    const double xo = active ? X[o] : 0.0;
+    double acc = 0;
+    for (int base = pbeg; base < pend; base += kSpmmTile) {
+      const int cnt = min(kSpmmTile, pend - base);
+      __syncthreads();
+      {
+        constexpr int SU = kSpmmTile / kBlock;
+        int ci_r[SU];
+        double v_r[SU];
+        const int last = base + cnt - 1;
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+          const int i = min(base + (int)threadIdx.x + u * kBlock, last);
+          ci_r[u] = A.ci[i];
+          v_r[u] = A.v[i];
+        }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+          const int i = threadIdx.x + u * kBlock;
+          if (i < cnt) {
+            s_ci[i] = ci_r[u];
+            s_v[i] = v_r[u];
+          }
+        }
+      }
+      __syncthreads();
+      const int lo = max(myb, base) - base, hi = min(mye, base + cnt) - base;
+      for (int p = lo; p < hi; p += 8) {
+        double x8[8], y8[8], w8[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const bool ok = p + q < hi;
+          const int pp = ok ? p + q : lo;
+          w8[q] = ok ? s_v[pp] : 0.0;
+          const size_t oc = (size_t)s_ci[pp] * r + t;
+          x8[q] = z[oc];
+          y8[q] = iter > 0 ? d_old[oc] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc += w8[q] * fma(beta, y8[q], -x8[q]);
+      }
+    }
+    // ---- EucHvToHv on the block's own items ----
+    // kind: 0 rotation column `a` of pose `it`, 1 unit-sphere column, 2 Euclidean column
+    int kind = 2, a = 0, it = 0;
+    if (active && j < n_rot_rows) {
+      const int q = j / al;
+      a = j - q * al;
+      it = q;
+      kind = (a < D) ? 0 : 2;
+    } else if (active && !m.se && j < n_rot_rows + m.l) {
+      kind = 1;
+      it = j - n_rot_rows;
+    }
+    __syncthreads();
+    s_V[threadIdx.x] = own;
+    s_Y[threadIdx.x] = xo;
+    __syncthreads();
+    double T = acc;
+    const int l0 = lj - a;  // local row of the item's first column
+    if (kind == 0) {
+      double sres = 0;
+#pragma unroll
+      for (int b = 0; b < D; ++b) sres += s_V[(l0 + b) * r + t] * Sblk[(size_t)it * D * D + b + a * D];
+      T = acc - sres;
+    } else if (kind == 1) {
+      T = acc - own * Sblk[(size_t)m.n * D * D + it];
+    }
+    s_T[threadIdx.x] = T;
+    __syncthreads();
+    double hv = T;
+    if (kind == 0) {
+      // S2 = sym(Y^T T); hv = T - sum_a' Y(t, a') S2[a'][a]
+      double sres = 0;
+#pragma unroll
+      for (int b = 0; b < D; ++b) {
+        double pba = 0, pab = 0;  // P[b][a] = sum_t Y(t, b) T(t, a), P[a][b] = sum_t Y(t, a) T(t, b)
+        for (int u = 0; u < r; ++u) {
+          pba += s_Y[(l0 + b) * r + u] * s_T[(l0 + a) * r + u];
+          pab += s_Y[(l0 + a) * r + u] * s_T[(l0 + b) * r + u];
+        }
+        sres += s_Y[(l0 + b) * r + t] * (0.5 * (pba + pab));
+      }
+      hv = T - sres;
+    } else if (kind == 1) {
+      double yt = 0;
+      for (int u = 0; u < r; ++u) yt += s_Y[lj * r + u] * s_T[lj * r + u];
+      hv = T - xo * yt;
+    }
+    if (active && !is_long) {
+      Hd[o] = hv;
+      d_new[o] = own;
+      dacc += own * hv;
+    }
+  }
+  const double tot = block_sum(dacc, s_red);
+  if (threadIdx.x == 0) p1[blockIdx.x] = tot;
+}
+
+int spmm_dir_fix_grid(const ManiDesc &m, int nrows) {
+  const int al = m.se ? m.d + 1 : m.d;
+  const int RB = ((kBlock / m.r) / al) * al;
+  if (RB < al) return 0;
+  long nrb = (nrows + RB - 1) / RB;
+  if (nrb < 1) nrb = 1;
+  if (nrb > kMaxPartials) nrb = kMaxPartials;
+  return (int)nrb;
+}
+
+int launch_spmm_dir_fix(hipStream_t st, const ManiDesc &m, const CsrDev &A, Buf2 X, Buf2 Sblk, const double *z,
+                        const double *d_old, double *d_new, double *Hd, const double *p3, int np3, double *p1,
+                        SolverCtl *ctl, int seq, int iter) {
+  const int main_grid = spmm_dir_fix_grid(m, A.nrows);
+  const int grid = main_grid + A.n_long * kLongSplit;
+  if (m.d == 3)
+    hipLaunchKernelGGL(k_spmm_dir_fix<3>, dim3(grid), dim3(kBlock), 0, st, m, A, X, Sblk, z, d_old, d_new, Hd, p3, np3,
+                       p1, ctl, seq, iter, main_grid);
+  else
+    hipLaunchKernelGGL(k_spmm_dir_fix<2>, dim3(grid), dim3(kBlock), 0, st, m, A, X, Sblk, z, d_old, d_new, Hd, p3, np3,
+                       p1, ctl, seq, iter, main_grid);
+  return main_grid + A.n_long;
+}
+
 void launch_spmm_dir(hipStream_t st, int r, const CsrDev &A, const double *z, const double *d_old, double *d_new,
                      double *W, const double *p3, int np3, SolverCtl *ctl, int seq, int iter) {
   const int main_grid = spmm_grid(A.nrows, r);
@@ -1350,6 +1601,9 @@ __global__ __launch_bounds__(kBlock) void k_tcg_update1(long nelem, const double
   const bool boundary = (d_Hd <= 0) || (e_Pe_new >= Delta * Delta);
   const double step =
       boundary ? (-e_Pd + sqrt(e_Pd * e_Pd + d_Pd * (Delta * Delta - e_Pe))) / d_Pd : alpha;
+  // a run that goes on says so before the vector work: the host enqueues the sparse replay behind this verdict
+  // (DeviceProblem::rtr_dev); a run that stops writes tcg_done_seq below
+  if (!boundary && blockIdx.x == 0 && threadIdx.x == 0) host_store(&hf->go_seq, seq);
   double acc = 0;
   for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < nelem; i += (long)gridDim.x * kBlock) {
     const double h = Hd[i];

@@ -754,6 +754,9 @@ __global__ __launch_bounds__(kBlock) void k_fused_precond(int r, int k, int ldm,
         ctl->inner_total += iter + 1;
         ctl->tcg_done_stamp = seq;
         f_host_store(&hf->tcg_done_seq, seq);
+      } else {
+        // the host enqueues what follows a B that goes on only once it knows (DeviceProblem::rtr_dev_fused)
+        f_host_store(&hf->go_seq, seq);
       }
     }
   }
@@ -1122,6 +1125,9 @@ __global__ __launch_bounds__(kPcBlock) void k_fused_pc(ManiDesc m, int ldm, int 
         ctl->inner_total += iter + 1;
         ctl->tcg_done_stamp = seq;
         f_host_store(&hf->tcg_done_seq, seq);
+      } else {
+        // the host enqueues what follows a B that goes on only once it knows (DeviceProblem::rtr_dev_fused)
+        f_host_store(&hf->go_seq, seq);
       }
     }
   }

@@ -578,7 +578,8 @@ int SparsePrecond::attach(std::shared_ptr<const SpImage> image, int rcap_) {
   return DCORA_OK;
 }
 
-void SparsePrecond::apply(hipStream_t st, int r, Buf2 R, double *Z, Gate g, bool levels_only) const {
+void SparsePrecond::apply(hipStream_t st, int r, Buf2 R, double *Z, Gate g, bool levels_only,
+                          const std::function<bool()> *after_first) const {
   const SpImage &I = *im;
   const int k = I.k, nhub = I.nhub;
   const DevBuf<int> &perm = I.perm, &out_off = I.out_off, &hub_idx = I.hub_idx, &hub_ap = I.hub_ap, &hub_apos = I.hub_apos,
@@ -590,8 +591,20 @@ void SparsePrecond::apply(hipStream_t st, int r, Buf2 R, double *Z, Gate g, bool
   const long n = (long)r * k;
   const int grid = (int)std::min<long>((n + kBlock - 1) / kBlock, 2048);
   levels_only = levels_only && im->in_pos.p != nullptr;
-  if (!levels_only) hipLaunchKernelGGL(k_sp_permute_in, dim3(grid), dim3(kBlock), 0, st, r, k, perm.p, R, y.p, g);
-  for (const SpLevel &lv : levels) launch_level(st, r, lv, tasks.p, segs.p, vals.p, idxs.p, y.p, g);
+  bool asked = false;
+  auto go_on = [&]() {
+    if (asked || !after_first) return true;
+    asked = true;
+    return (*after_first)();
+  };
+  if (!levels_only) {
+    hipLaunchKernelGGL(k_sp_permute_in, dim3(grid), dim3(kBlock), 0, st, r, k, perm.p, R, y.p, g);
+    if (!go_on()) return;
+  }
+  for (const SpLevel &lv : levels) {
+    launch_level(st, r, lv, tasks.p, segs.p, vals.p, idxs.p, y.p, g);
+    if (!go_on()) return;
+  }
   if (levels_only && nhub == 0) return;
   if (nhub > 0) {
     HubDev H{nhub, hub_idx.p, hub_ap.p, hub_apos.p, hub_aval.p, hub_U.p, hub_Sinv.p, hub_w.p};

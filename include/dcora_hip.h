@@ -95,6 +95,10 @@ int dcora_problem_eucgrad(dcora_problem_t p, const double *X, double *out);
 int dcora_problem_riegrad(dcora_problem_t p, const double *X, double *out, double *norm);
 /* Riemannian Hessian-vector product: EucHessianEta (ref :61-68) followed by ROPTLIB's EucHvToHv */
 int dcora_problem_hessvec(dcora_problem_t p, const double *X, const double *V, double *out);
+/* Test hook: the same product as the generic-layout solver loop forms it (delta Q, EucHvToHv and the partial sums of
+ * <V, H V> in ONE launch, k_spmm_dir_fix); dots[0] = <V, H V> from that kernel's partials, dots[1] = the same from the
+ * two-launch form.  DCORA_ERR_UNSUPPORTED when the one-launch form does not apply (a long row on a manifold column). */
+int dcora_debug_hessvec_solver_form(dcora_problem_t p, const double *X, const double *V, double *out, double *dots);
 /* PreCondition (ref :70-84, 261-297) */
 int dcora_problem_precondition(dcora_problem_t p, const double *X, const double *V, double *out);
 /* Retract (ref :125-136, 236-259) */

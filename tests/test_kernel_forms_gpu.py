@@ -2,7 +2,9 @@
 (k_spmm_bsr2, the default) against the LDS-staged one (DCORA_BSR_KERNEL=v1), which must agree BITWISE (same
 summation order), the form with 16-byte gathers (k_spmm_bsr3, DCORA_BSR_KERNEL=v3) against both to rounding, and the
 entry-per-lane level kernel of the sparse preconditioner (k_sp_level2) against the (entry, value)-per-lane one
-(DCORA_SP_KERNEL=v1), which sum in a different order and must agree to rounding.  One child process per form."""
+(DCORA_SP_KERNEL=v1), which sum in a different order and must agree to rounding.  One child process per form.
+The generic layout's Hessian product in one launch (k_spmm_dir_fix) is checked against the two-launch form through the
+library's test hook, and the solver loop on top of either form must repeat itself bit for bit."""
 import os
 import subprocess
 import sys
@@ -70,3 +72,91 @@ def test_both_forms_of_the_block_qapply_and_of_the_level_kernel_agree(built, tmp
         else:
             assert np.array_equal(new[key], old[key]), key
             assert common.rel(v3[key], old[key]) < 1e-13, key
+
+
+
+RA_CHILD = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import dcora_amd as da
+from test_raslam import ra_path
+out = {}
+for name, r in (("tiers", 3), ("range_aided_slam_test_3d", 4)):
+    ra = da.RADataset(ra_path(name))
+    if name == "tiers":
+        X0 = np.zeros((r, ra.k)); X0[:ra.d] = ra.X_odom
+    else:
+        rng = np.random.default_rng(5)
+        lift = np.linalg.qr(rng.standard_normal((r, ra.d)))[0]
+        X0 = da.manifold_project(r, ra.d, ra.n, lift @ ra.gt + 0.05 * rng.standard_normal((r, ra.k)), l=ra.l, b=ra.b)
+    for rep in range(3):
+        P = da.QuadraticProblem(r, ra.d, ra.n, ra.Q, l=ra.l, b=ra.b)
+        opt = da.QuadraticOptimizer(P, da.ROptParameters(RTR_iterations=6, RTR_tCG_iterations=40, gradnorm_tol=1e-12))
+        out["%s_X%d" % (name, rep)] = opt.optimize(X0)
+        res = opt.getOptResult()
+        out["%s_f%d" % (name, rep)] = np.array([res["fOpt"], res["gradNormOpt"], res["inner_iterations"]])
+        P.close()
+np.savez(sys.argv[2], **out)
+"""
+
+
+@pytest.mark.parametrize("form", ["one", "two"])
+def test_generic_solver_loop_repeats_bitwise(built, tmp_path, form):
+    """run to run the generic-layout RTR repeats itself bit for bit in both forms of its Hessian product (tiers has a
+    long row: its term of <delta, H delta> must not move around the partial array with the arrival order of the
+    workgroups that share the row -- it did in a first version of k_spmm_dir_fix, and the iterates drifted)"""
+    e = dict(os.environ)
+    if form == "two":
+        e["DCORA_HESS_FUSE"] = "0"
+    out = os.path.join(str(tmp_path), form + ".npz")
+    res = subprocess.run([sys.executable, "-c", RA_CHILD, os.path.dirname(common.HERE), out], env=e,
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    o = np.load(out)
+    for name in ("tiers", "range_aided_slam_test_3d"):
+        for rep in (1, 2):
+            assert np.array_equal(o[name + "_X0"], o[name + "_X%d" % rep]), (form, name, rep)
+            assert np.array_equal(o[name + "_f0"], o[name + "_f%d" % rep]), (form, name, rep)
+
+
+def _ra_case(name, r):
+    import dcora_amd as da
+    from test_raslam import ra_path
+    ra = da.RADataset(ra_path(name))
+    rng = np.random.default_rng(11)
+    X = da.manifold_project(r, ra.d, ra.n, rng.standard_normal((r, ra.k)), l=ra.l, b=ra.b)
+    return da.QuadraticProblem(r, ra.d, ra.n, ra.Q, l=ra.l, b=ra.b), X, rng.standard_normal((r, ra.k))
+
+
+def _pgo_case(name, r):
+    import dcora_amd as da
+    ds = common.product_dataset(name)
+    rng = np.random.default_rng(12)
+    k = (ds.d + 1) * ds.n
+    X = da.manifold_project(r, ds.d, ds.n, rng.standard_normal((r, k)))
+    return da.QuadraticProblem(r, ds.d, ds.n, da.build_Q_pgo(ds), G=rng.standard_normal((r, k)), reg=0.1), X, \
+        rng.standard_normal((r, k))
+
+
+@pytest.mark.parametrize("kind,name,r", [
+    ("ra", "tiers", 2), ("ra", "tiers", 3), ("ra", "tiers", 7),          # d = 2, a landmark every pose ranges to
+    ("ra", "range_aided_slam_test_3d", 3), ("ra", "range_aided_slam_test_3d", 4), ("ra", "range_aided_slam_test_3d", 9),
+    ("ra", "range_aided_slam_test_2d", 2), ("ra", "range_aided_slam_test_2d", 5),
+    ("pgo", "sphere2500", 3), ("pgo", "sphere2500", 5), ("pgo", "sphere2500", 16),   # pose layout, d = 3
+    ("pgo", "pose_graph_optimization_test_2d", 2), ("pgo", "pose_graph_optimization_test_2d", 6),
+])
+def test_hessian_in_one_launch_against_the_two_launch_form(built, kind, name, r):
+    """k_spmm_dir_fix (delta Q, EucHvToHv and the partial sums of <delta, H delta> in one launch -- the Hessian product
+    of the generic-layout tCG) against k_spmm + k_hessfix on the same point and direction: the same terms in the same
+    order per entry (rounding of a different FMA contraction at most), the inner product to the rounding of another
+    order of the partial sums"""
+    P, X, V = (_ra_case if kind == "ra" else _pgo_case)(name, r)
+    ref = P.HessVec(X, V)
+    one, dots = P.HessVecSolverForm(X, V)
+    P.close()
+    scale = np.max(np.abs(ref))
+    assert np.max(np.abs(one - ref)) <= 1e-13 * scale, np.max(np.abs(one - ref)) / scale
+    exact = float(np.sum(V * ref))
+    mag = float(np.sum(np.abs(V * ref)))
+    assert abs(dots[0] - exact) <= 1e-13 * mag and abs(dots[1] - exact) <= 1e-13 * mag, (dots, exact)
