@@ -323,12 +323,14 @@ int device_min_eig(const HostCsr &S, int maxit, double min_eig_tol, int ncv, uin
     const int nthreads = std::max(1, std::min(host_cpus_available(), 32));
     for (int i = 0; i < 10; ++i) {
       PartInvHost P;
+      DeviceWeightSink sink(device);  // the stored weights stream to the device while they are formed
+      P.sink = &sink;
       const int brc = build_partitioned_inverse_auto(csr_shift_diag(S, -sigma), 1, nthreads, device, &P);
       if (brc && brc != DCORA_ERR_NOT_PD) return brc;
       if (brc == DCORA_OK) {
         SparsePrecond inv;
         auto img = std::make_shared<SpImage>();
-        rc = img->upload(P);
+        rc = img->upload(P, &sink);
         if (rc) return rc;
         rc = inv.attach(img, 1);
         if (rc) return rc;

@@ -1,6 +1,8 @@
 // see device_chol.h
 #include "device_chol.h"
 
+#include <sys/mman.h>
+
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -414,6 +416,14 @@ __global__ __launch_bounds__(256) void k_chol_syrk(const PieceDev *__restrict__ 
   }
 }
 
+__global__ __launch_bounds__(256) void k_count_nonzero(long long n, const double *__restrict__ v,
+                                                       unsigned long long *__restrict__ out) {
+  unsigned long long c = 0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) c += v[i] != 0.0;
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
 // the first c columns of every front (diagonal block over the rows below), packed piece after piece
 __global__ __launch_bounds__(256) void k_chol_pack(const PieceDev *__restrict__ pieces,
                                                    const long long *__restrict__ panel_off,
@@ -638,6 +648,92 @@ __global__ __launch_bounds__(256) void k_piece_pack_inverted(int c, int m, const
     const int i = (int)(e / c), j = (int)(e - (long long)i * c);
     out[e] = i < c ? (j <= i ? YT[(long long)j * c + i] : 0.0) : W[(long long)(i - c) * c + j];
   }
+}
+
+// ---- the NARROW pieces (c <= 64: the leaves and the small separators, thousands of them) all at once ----
+// rows [0, c) of the packed panel <- L11^-1 (lower triangle): one workgroup per piece, column k of the inverse by lane
+// group k as in k_tri_inv64
+__global__ __launch_bounds__(256) void k_small_inv(const PieceDev *__restrict__ pieces, const int *__restrict__ list,
+                                                   const long long *__restrict__ panel_off,
+                                                   const double *__restrict__ F, double *__restrict__ out) {
+  __shared__ double T[NB][NB + 1];
+  __shared__ double Li[NB][NB + 1];
+  const int s = list[blockIdx.x];
+  const PieceDev P = pieces[s];
+  const int c = P.c;
+  const long long f = (long long)P.c + P.m;
+  const double *__restrict__ L = F + P.off;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int i = e >> 6, j = e & 63;
+    T[i][j] = (i < c && j <= i) ? L[(long long)i * f + j] : (i == j ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  const int k = tid >> 2, kq = tid & 3;
+  for (int r = kq; r < k; r += 4) Li[r][k] = 0.0;
+  if (kq == 0) Li[k][k] = 1.0 / T[k][k];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  for (int r = k + 1; r < NB; ++r) {
+    double sum = 0;
+    for (int l = k + kq; l < r; l += 4) sum += T[r][l] * Li[l][k];
+    sum += __shfl_xor(sum, 1);
+    sum += __shfl_xor(sum, 2);
+    if (kq == 0) Li[r][k] = -sum / T[r][r];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  double *__restrict__ O = out + panel_off[s];
+  for (int e = tid; e < c * c; e += 256) {
+    const int i = e / c, j = e - i * c;
+    O[e] = j <= i ? Li[i][j] : 0.0;
+  }
+}
+// rows [c, c + m) of the packed panel <- W = -L21 L11^-1: 64 rows below per workgroup (blockIdx.x), piece blockIdx.y
+__global__ __launch_bounds__(256) void k_small_w(const PieceDev *__restrict__ pieces, const int *__restrict__ list,
+                                                 const long long *__restrict__ panel_off,
+                                                 const double *__restrict__ F, double *__restrict__ out) {
+  const int s = list[blockIdx.y];
+  const PieceDev P = pieces[s];
+  const int c = P.c, m = P.m, a0 = blockIdx.x * NB;
+  if (a0 >= m) return;
+  __shared__ double As[NB][NB + 1];
+  __shared__ double Bs[NB][NB + 1];
+  const long long f = (long long)c + m;
+  const double *__restrict__ B = F + P.off + (long long)(c + a0) * f;
+  double *__restrict__ O = out + panel_off[s];
+  const int na = min(NB, m - a0);
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int i = e >> 6, kk = e & 63;
+    As[kk][i] = (i < na && kk < c) ? B[(long long)i * f + kk] : 0.0;  // L21(a0 + i, kk)
+    Bs[i][kk] = (i < c && kk <= i) ? O[(long long)i * c + kk] : 0.0;  // L11^-1(i, kk): [summed index][column]
+  }
+  __syncthreads();
+  double acc[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[u][v] = 0;
+#pragma unroll 8
+  for (int kk = 0; kk < NB; ++kk) {
+    double a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] = As[kk][ty + 16 * u];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) b[v] = Bs[kk][tx + 16 * v];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) acc[u][v] = fma(a[u], b[v], acc[u][v]);
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int a = ty + 16 * u, j = tx + 16 * v;
+      if (a < na && j < c) O[(long long)(c + a0 + a) * c + j] = -acc[u][v];
+    }
 }
 
 inline uint64_t mix64(uint64_t h, uint64_t w) {
@@ -884,6 +980,18 @@ int factor_on_device(const HostCsr &A, int block, int top, int device, bool *pd,
   DCORA_HIP(hipMemcpyAsync(&logdet, img->logdet.p, sizeof(double), hipMemcpyDeviceToHost, st));
   DCORA_HIP(hipStreamSynchronize(st));
   *pd = failed == 0;
+  static const bool init_timing = std::getenv("DCORA_INIT_TIMING") != nullptr;
+  auto tl = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!init_timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[factor] %-26s %9.1f ms\n", what, std::chrono::duration<double, std::milli>(now - tl).count());
+    tl = now;
+  };
+  if (init_timing)
+    fprintf(stderr, "[factor] %-26s %9.1f ms\n[factor] %-26s %9.1f ms\n", "hash + analysis / look-up",
+            std::chrono::duration<double, std::milli>(t1 - t0).count(), "numeric factorisation",
+            std::chrono::duration<double, std::milli>(tl - t1).count());
   if (panels && failed == 0) {
     // hand the factor over by pieces: pack the panels on the device, one copy to the host
     const int np = (int)S.pieces.size();
@@ -907,10 +1015,36 @@ int factor_on_device(const HostCsr &A, int block, int top, int device, bool *pd,
       const char *e = std::getenv("DCORA_PIECE_INVERSES");
       return !(e && std::strcmp(e, "host") == 0);
     }();
-    constexpr int kWide = 384;
-    std::vector<int> wide;
+    // every piece arrives inverted: the narrow ones (c <= 64) by two batched launches, the others one after the other
+    // with the right-looking kernels of the dense inverse (DCORA_PIECE_INVERSES=wide: only c >= 384, the rest on
+    // the host's threads -- 0.64 s for the whole 100k lattice)
+    static const bool only_wide = [] {
+      const char *e = std::getenv("DCORA_PIECE_INVERSES");
+      return e && std::strcmp(e, "wide") == 0;
+    }();
+    const int kWide = 384;
+    std::vector<int> wide, narrow;
     std::vector<long long> moff((size_t)np, -1);
     long long mtotal = 0;
+    if (invert_on_device && S.nhub == 0 && !only_wide) {
+      int mmax = 0;
+      for (int s2 = 0; s2 < np; ++s2)
+        if (S.pieces[s2].c <= NB) {
+          narrow.push_back(s2);
+          mmax = std::max(mmax, S.pieces[s2].m);
+        }
+      if (!narrow.empty()) {
+        DevBuf<int> dlist;
+        DCORA_HIP(dlist.alloc(narrow.size()));
+        DCORA_HIP(hipMemcpyAsync(dlist.p, narrow.data(), narrow.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_small_inv, dim3((unsigned)narrow.size()), dim3(256), 0, st, img->pieces.p, dlist.p, dpoff.p, F,
+                           packed.p);
+        if (mmax > 0)
+          hipLaunchKernelGGL(k_small_w, dim3((mmax + NB - 1) / NB, (unsigned)narrow.size()), dim3(256), 0, st,
+                             img->pieces.p, dlist.p, dpoff.p, F, packed.p);
+        DCORA_HIP(hipStreamSynchronize(st));  // dlist and narrow live on this frame
+      }
+    }
     if (invert_on_device && S.nhub == 0)
       for (int s2 = 0; s2 < np; ++s2)
         if (S.pieces[s2].c >= kWide) {
@@ -952,13 +1086,49 @@ int factor_on_device(const HostCsr &A, int block, int top, int device, bool *pd,
       }
       DCORA_HIP(hipGetLastError());
     }
-    std::vector<double> host((size_t)poff[np]), hostM((size_t)mtotal);
-    DCORA_HIP(hipMemcpyAsync(host.data(), packed.p, host.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-    if (mtotal > 0)
-      DCORA_HIP(hipMemcpyAsync(hostM.data(), mtop.p, hostM.size() * sizeof(double), hipMemcpyDeviceToHost, st));
     DCORA_HIP(hipStreamSynchronize(st));
+    lap("pack + wide inverses");
+    // one host block for all panels (and the wide pieces' M): not value-initialised -- the copy below writes every
+    // entry, and zeroing 3 GB first cost 0.76 s for the whole 100k lattice -- and handed to the pieces as views
+    // (2 MB-aligned and advised as huge pages: first touch and release of 3 GB in 4 KB pages cost 0.4 s each)
+    struct HostBlock {
+      double *panels = nullptr, *M = nullptr;
+      ~HostBlock() {
+        std::free(panels);
+        std::free(M);
+      }
+    };
+    auto huge_alloc = [](size_t doubles) -> double * {
+      const size_t two_mb = (size_t)2 << 20;
+      const size_t bytes = ((std::max<size_t>(doubles, 1) * sizeof(double) + two_mb - 1) / two_mb) * two_mb;
+      void *p = std::aligned_alloc(two_mb, bytes);
+      if (p) (void)madvise(p, bytes, MADV_HUGEPAGE);
+      return (double *)p;
+    };
+    auto blk = std::make_shared<HostBlock>();
+    blk->panels = huge_alloc((size_t)poff[np]);
+    blk->M = huge_alloc((size_t)mtotal);
+    if (!blk->panels || !blk->M) {
+      set_last_error("sparse Cholesky: no host memory for the factor's panels");
+      return DCORA_ERR_HIP;
+    }
+    double *host = blk->panels, *hostM = blk->M;
+    // non-zeros of the factor (reported as nnz(L)), counted where the factor is
+    DevBuf<unsigned long long> dnz;
+    DCORA_HIP(dnz.alloc(1));
+    DCORA_HIP(hipMemsetAsync(dnz.p, 0, sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(k_count_nonzero, dim3(2048), dim3(256), 0, st, (long long)poff[np], packed.p, dnz.p);
+    unsigned long long nz_dev = 0;
+    DCORA_HIP(hipMemcpyAsync(&nz_dev, dnz.p, sizeof nz_dev, hipMemcpyDeviceToHost, st));
+    lap("host buffers");
+    DCORA_HIP(hipMemcpyAsync(host, packed.p, (size_t)poff[np] * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (mtotal > 0)
+      DCORA_HIP(hipMemcpyAsync(hostM, mtop.p, (size_t)mtotal * sizeof(double), hipMemcpyDeviceToHost, st));
+    DCORA_HIP(hipStreamSynchronize(st));
+    lap("download");
     std::vector<char> is_wide((size_t)np, 0);
     for (int s2 : wide) is_wide[s2] = 1;
+    for (int s2 : narrow) is_wide[s2] = 1;  // narrow pieces arrive inverted as well
     PiecewiseFactor &W = *panels;
     W = PiecewiseFactor();
     W.n = S.n;
@@ -966,19 +1136,19 @@ int factor_on_device(const HostCsr &A, int block, int top, int device, bool *pd,
     W.perm = S.perm;
     W.iperm = S.iperm;
     W.pieces.assign((size_t)np, PieceFactor());
-    long nz = 0;
+    W.block = blk;
     for (int s2 = 0; s2 < np; ++s2) {
       const CholPiece &P = S.pieces[s2];
       PieceFactor &pf = W.pieces[s2];
       pf.c0 = P.c0;
       pf.c = P.c;
       pf.rows.assign(S.rows.begin() + P.rows_off, S.rows.begin() + P.rows_off + P.m);
-      pf.panel.assign(host.begin() + poff[s2], host.begin() + poff[s2 + 1]);
+      pf.panel_view = host + poff[s2];
       pf.inverted = is_wide[s2] != 0;
-      if (moff[s2] >= 0) pf.Mtop.assign(hostM.begin() + moff[s2], hostM.begin() + moff[s2] + (long long)P.c * P.c);
-      for (double v : pf.panel) nz += v != 0.0;
+      if (moff[s2] >= 0) pf.Mtop_view = hostM + moff[s2];
     }
-    W.nnzL = nz;
+    W.nnzL = (long)nz_dev;
+    lap("per-piece copies");
   }
   if (info6) {
     const auto t2 = std::chrono::steady_clock::now();
@@ -1087,10 +1257,12 @@ std::function<bool(const HostCsr &, int, int, const double *, double *)> device_
     if (nrhs < 1 || nrhs > 16) return false;
     if (hipSetDevice(device) != hipSuccess) return false;
     PartInvHost P;
+    DeviceWeightSink sink(device);  // the stored weights stream to the device while they are formed
+    P.sink = &sink;
     const int nthreads = std::max(2, host_cpus_available());
     if (build_partitioned_inverse_auto(A, block, nthreads, device, &P) != DCORA_OK) return false;
     auto img = std::make_shared<SpImage>();
-    if (img->upload(P) != DCORA_OK) return false;
+    if (img->upload(P, &sink) != DCORA_OK) return false;
     P = PartInvHost();  // the host image is no longer needed
     SparsePrecond sp;
     if (sp.attach(img, nrhs) != DCORA_OK) return false;
@@ -1111,9 +1283,16 @@ int build_partitioned_inverse_auto(const HostCsr &A, int block, int nthreads, in
   }();
   if (host_factor) return build_partitioned_inverse(A, block, nthreads, out) ? DCORA_OK : DCORA_ERR_NOT_PD;
   PiecewiseFactor F;
+  const auto t0 = std::chrono::steady_clock::now();
   const int rc = device_chol_piecewise_factor(A, block, nd_top_default(), device, &F);
   if (rc) return rc;
-  return build_partitioned_inverse_from(A, F, nthreads, out) ? DCORA_OK : DCORA_ERR_NOT_PD;
+  const auto t1 = std::chrono::steady_clock::now();
+  const bool ok = build_partitioned_inverse_from(A, F, nthreads, out);
+  if (std::getenv("DCORA_INIT_TIMING"))
+    fprintf(stderr, "[precond] factor on the device %.1f ms, partitioned inverse on the host %.1f ms\n",
+            std::chrono::duration<double, std::milli>(t1 - t0).count(),
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
+  return ok ? DCORA_OK : DCORA_ERR_NOT_PD;
 }
 
 }  // namespace dcora

@@ -132,8 +132,30 @@ struct SpImage {
   // original unknown -> position in image 0 of the replay vector / position of its final value (-1 on a hub):
   // lets the caller's kernels write the right-hand side into y and read the result from it (SpFold, kernels.h)
   DevBuf<int> in_pos, out_pos;
-  int upload(const PartInvHost &P);
+  // weights from P.vals, or -- when the build streamed them (P.sink) -- the sink's device buffer, which is taken over
+  int upload(const PartInvHost &P, struct DeviceWeightSink *streamed = nullptr);
   size_t device_bytes() const;
+};
+
+// WeightSink of the product: the stored weights go to the device in chunks of pinned host memory while the host's
+// threads form the next chunk (three buffers in flight, recycled process-wide)
+struct DeviceWeightSink : WeightSink {
+  explicit DeviceWeightSink(int device_) : device(device_) {}
+  ~DeviceWeightSink() override;
+  bool begin(long long total) override;
+  long long chunk_cap() const override { return kChunk; }
+  double *acquire(long long n) override;
+  bool commit(long long off, long long n) override;
+  bool end() override;
+  static constexpr long long kChunk = 8ll << 20;  // doubles per chunk: 64 MB
+  static constexpr int kBuffers = 3;
+  int device;
+  DevBuf<double> vals;
+  hipStream_t st = nullptr;
+  double *pin[kBuffers] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev[kBuffers] = {nullptr, nullptr, nullptr};
+  bool busy[kBuffers] = {false, false, false};
+  int cur = -1;
 };
 
 class SparsePrecond {

@@ -307,9 +307,20 @@ int DeviceProblem::build_preconditioner(const HostCsr &Qh, double reg) {
   precond_cache_hit = precond_cache_find(key, &ent);
   DCORA_HIP(hipSetDevice(device));
   if (!precond_cache_hit) {
+    if (std::getenv("DCORA_INIT_TIMING"))
+      fprintf(stderr, "[precond] key + cache look-up %.1f ms\n",
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     HostCsr M = csr_shift_diag(Qh, reg);
     if (want_sparse) {
       PartInvHost P;
+      // the stored weights stream to the device while the host's threads form them (DCORA_SP_WEIGHTS=host: build them
+      // in host memory first and upload in one piece)
+      static const bool weights_on_host = [] {
+        const char *e = std::getenv("DCORA_SP_WEIGHTS");
+        return e && std::string(e) == "host";
+      }();
+      DeviceWeightSink sink(device);
+      if (!weights_on_host) P.sink = &sink;
       const int brc = build_partitioned_inverse_auto(M, block, nthreads, device, &P);
       if (brc && brc != DCORA_ERR_NOT_PD) return brc;
       const bool ok = brc == DCORA_OK;
@@ -318,8 +329,17 @@ int DeviceProblem::build_preconditioner(const HostCsr &Qh, double reg) {
         return DCORA_ERR_NOT_PD;
       }
       auto img = std::make_shared<SpImage>();
-      const int rc = img->upload(P);
+      const auto tu = std::chrono::steady_clock::now();
+      const int rc = img->upload(P, P.sink ? &sink : nullptr);
       if (rc) return rc;
+      if (std::getenv("DCORA_INIT_TIMING"))
+        fprintf(stderr, "[precond] image upload %.1f ms (since start %.1f ms)\n",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tu).count(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+      if (std::getenv("DCORA_INIT_TIMING"))
+        fprintf(stderr, "[precond] host image: %.1f MB tasks, %.1f MB segments, %.1f MB indices, %.1f MB weights\n",
+                P.tasks.size() * sizeof(PTask) / 1e6, P.segs.size() * sizeof(PSeg) / 1e6, P.idxs.size() * 4 / 1e6,
+                P.vals.size() * 8 / 1e6);
       ent.sparse = img;
       ent.nnzL = P.nnzL;
       ent.bytes = img->device_bytes();
@@ -362,8 +382,12 @@ int DeviceProblem::build_preconditioner(const HostCsr &Qh, double reg) {
       ent.bytes = buf->n * sizeof(double);
     }
     ent.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (std::getenv("DCORA_INIT_TIMING")) fprintf(stderr, "[precond] built after %.1f ms\n", ent.build_ms);
     precond_cache_insert(key, ent);
   }
+  if (std::getenv("DCORA_INIT_TIMING"))
+    fprintf(stderr, "[precond] cached after %.1f ms\n",
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   precond_nnzL = ent.nnzL;
   if (want_sparse) {
     const int rc = sp.attach(ent.sparse, m.r);
@@ -376,6 +400,7 @@ int DeviceProblem::build_preconditioner(const HostCsr &Qh, double reg) {
   }
   has_precond = true;
   precond_setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (std::getenv("DCORA_INIT_TIMING")) fprintf(stderr, "[precond] attached after %.1f ms\n", precond_setup_ms);
   return DCORA_OK;
 }
 

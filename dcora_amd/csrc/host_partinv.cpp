@@ -80,7 +80,7 @@ void piecewise_solve(const PiecewiseFactor &F, int np, int k, std::vector<double
     const int c = p.c, m = (int)p.rows.size();
     double *us = &u[(size_t)p.c0];
     for (int i = 0; i < c; ++i) {
-      const double *di = &p.panel[(size_t)i * c];
+      const double *di = p.pan() + (size_t)i * c;
       double sum = us[i];
       for (int l = 0; l < i; ++l) sum -= di[l] * us[l];
       us[i] = sum / di[i];
@@ -88,7 +88,7 @@ void piecewise_solve(const PiecewiseFactor &F, int np, int k, std::vector<double
     for (int a2 = 0; a2 < m; ++a2) {
       const int row = p.rows[a2];
       if (row >= k) continue;
-      const double *ba = &p.panel[(size_t)(c + a2) * c];
+      const double *ba = p.pan() + (size_t)(c + a2) * c;
       double sum = 0;
       for (int j = 0; j < c; ++j) sum += ba[j] * us[j];
       u[(size_t)row] -= sum;
@@ -103,13 +103,13 @@ void piecewise_solve(const PiecewiseFactor &F, int np, int k, std::vector<double
       if (row >= k) continue;
       const double ur = u[(size_t)row];
       if (ur == 0.0) continue;
-      const double *ba = &p.panel[(size_t)(c + a2) * c];
+      const double *ba = p.pan() + (size_t)(c + a2) * c;
       for (int j = 0; j < c; ++j) us[j] -= ba[j] * ur;
     }
     for (int i = c - 1; i >= 0; --i) {
-      const double xi = us[i] / p.panel[(size_t)i * c + i];
+      const double xi = us[i] / p.pan()[(size_t)i * c + i];
       us[i] = xi;
-      const double *di = &p.panel[(size_t)i * c];
+      const double *di = p.pan() + (size_t)i * c;
       for (int l = 0; l < i; ++l) us[l] -= di[l] * xi;
     }
   }
@@ -140,7 +140,9 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
   const int h = (F.nhub > 0 && F.nhub <= 64 && F.nhub < kfull) ? F.nhub : 0;
   const int k = kfull - h;
   PartInvHost &P = *out;
+  WeightSink *const sink = P.sink;  // the caller's choice survives the reset
   P = PartInvHost();
+  P.sink = sink;
   P.k = k;
   P.kfull = kfull;
   P.perm.assign(F.perm.begin(), F.perm.begin() + k);
@@ -162,7 +164,7 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
     for (int a2 = 0; a2 < (int)f.rows.size(); ++a2) {
       const int i = f.rows[a2];
       if (i >= k) continue;
-      const double *ba = &f.panel[(size_t)(c + a2) * c];
+      const double *ba = f.pan() + (size_t)(c + a2) * c;
       bool any = false;
       for (int j = 0; j < c && !any; ++j) any = ba[j] != 0.0;
       if (!any) continue;
@@ -194,10 +196,11 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
     const PieceFactor &f = F.pieces[s];
     const Piece &p = pc[s];
     const int c = p.c, m = (int)p.rows.size();
-    D.assign(f.panel.begin(), f.panel.begin() + (size_t)c * c);
+    const double *fp = f.pan();
+    D.assign(fp, fp + (size_t)c * c);
     B.resize((size_t)m * c);
     for (int a2 = 0; a2 < m; ++a2)
-      std::copy(&f.panel[(size_t)(c + p.src[a2]) * c], &f.panel[(size_t)(c + p.src[a2]) * c] + c, &B[(size_t)a2 * c]);
+      std::copy(fp + (size_t)(c + p.src[a2]) * c, fp + (size_t)(c + p.src[a2]) * c + c, &B[(size_t)a2 * c]);
   };
   auto w_row = [](const double *ba, const std::vector<double> &Dinv, int c, double *wa) {
     for (int l = 0; l < c; ++l) {
@@ -214,11 +217,17 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
       if (F.pieces[s].inverted) {  // the device delivered L11^-1 over W: nothing to compute
         const PieceFactor &f = F.pieces[s];
         const int c = p.c, m = (int)p.rows.size();
-        p.Dinv.assign(f.panel.begin(), f.panel.begin() + (size_t)c * c);
-        p.W.resize((size_t)m * c);
-        for (int a2 = 0; a2 < m; ++a2)
-          std::copy(&f.panel[(size_t)(c + p.src[a2]) * c], &f.panel[(size_t)(c + p.src[a2]) * c] + c,
-                    &p.W[(size_t)a2 * c]);
+        const double *fp = f.pan();
+        p.Dinv_view = fp;
+        bool all_rows = true;
+        for (int a2 = 0; a2 < m; ++a2) all_rows = all_rows && p.src[a2] == a2;
+        if (all_rows) {
+          p.W_view = fp + (size_t)c * c;
+        } else {
+          p.W.resize((size_t)m * c);
+          for (int a2 = 0; a2 < m; ++a2)
+            std::copy(fp + (size_t)(c + p.src[a2]) * c, fp + (size_t)(c + p.src[a2]) * c + c, &p.W[(size_t)a2 * c]);
+        }
         continue;
       }
       if (p.c < kBigPiece || nthreads < 2) continue;
@@ -251,7 +260,7 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
   {
     std::vector<int> order;
     for (int s = 0; s < np; ++s)
-      if (pc[s].Dinv.empty()) order.push_back(s);
+      if (!pc[s].dinv()) order.push_back(s);
     std::sort(order.begin(), order.end(), [&](int a, int b) {
       const double wa = (double)pc[a].c * pc[a].c * (pc[a].c + 3.0 * pc[a].rows.size());
       const double wb = (double)pc[b].c * pc[b].c * (pc[b].c + 3.0 * pc[b].rows.size());
@@ -303,7 +312,7 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
   if (merged) {
     std::vector<const double *> Mgiven((size_t)np, nullptr);
     for (int s = 0; s < np; ++s)
-      if (!F.pieces[s].Mtop.empty()) Mgiven[s] = F.pieces[s].Mtop.data();
+      if (F.pieces[s].mtop()) Mgiven[s] = F.pieces[s].mtop();
     layout_merged(pc, Mgiven, piece_of, k, nlev, nthreads, timing, &P);
     if (timing)
       std::fprintf(stderr, "[partinv] k %d pieces %d levels %d: piece inverses %.1f, merged schedule %.1f ms\n", k, np, nlev,
@@ -320,7 +329,6 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
   std::vector<int> touched_stamp((size_t)np, -1);
   std::vector<std::vector<std::pair<int, int>>> hits((size_t)k);  // per row: (piece, local row) of this level
   double weights = 0;
-  std::vector<double> &vals = P.vals;
   // The weights of a segment ([entry j][tile row q], j < len) are only RESERVED while the schedule is laid out; the
   // (by far larger) job of writing them -- 0.8 G doubles for the whole 100k lattice -- is done afterwards by all threads
   std::vector<Fill> fills;
@@ -396,7 +404,7 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
           S.idx = 0;
           S.pad = 0;
           const int c = p.c;
-          S.w = reserve(0, nrows, S.len, p.Dinv.data(), c, a0, 0, nullptr);
+          S.w = reserve(0, nrows, S.len, p.dinv(), c, a0, 0, nullptr);
           P.segs.push_back(S);
         } else {
           T.carry = pos(bit[q], p.c0 + a0);
@@ -412,7 +420,7 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
             S.idx = 0;
             S.pad = 0;
             const int c = s.c;
-            S.w = reserve(1, nrows, S.len, s.W.data(), c, 0, 0, loc);
+            S.w = reserve(1, nrows, S.len, s.w(), c, 0, 0, loc);
             P.segs.push_back(S);
           }
         }
@@ -449,8 +457,8 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
       // top level only: D^-T D^-1 (c x c, symmetric), kept until the weights are written
       const double *Mtop = nullptr;
       if (t == nlev - 1) {
-        if (!F.pieces[s].Mtop.empty()) {  // formed on the device
-          Mtop = F.pieces[s].Mtop.data();
+        if (F.pieces[s].mtop()) {  // formed on the device
+          Mtop = F.pieces[s].mtop();
         } else {
         top_blocks.emplace_back((size_t)c * c, 0.0);
         std::vector<double> &M = top_blocks.back();
@@ -460,7 +468,7 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
           parallel_for(c, nthreads, 4, [&](int a) {
             double *ma = &M[(size_t)a * c];
             for (int i = a; i < c; ++i) {
-              const double *di = &p.Dinv[(size_t)i * c];
+              const double *di = p.dinv() + (size_t)i * c;
               const double v = di[a];
               if (v == 0.0) continue;
               for (int j = 0; j <= a; ++j) ma[j] += v * di[j];
@@ -470,7 +478,7 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
             for (int j = a + 1; j < c; ++j) M[(size_t)a * c + j] = M[(size_t)j * c + a];
         } else {
           for (int i = 0; i < c; ++i) {
-            const double *di = &p.Dinv[(size_t)i * c];
+            const double *di = p.dinv() + (size_t)i * c;
             for (int a = 0; a <= i; ++a) {
               const double v = di[a];
               if (v == 0.0) continue;
@@ -499,7 +507,7 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
           S.len = pad2(c - a0);
           S.src = pos(bit[s], p.c0 + a0);
           // (D^-T)(a0 + q, a0 + j) = Dinv(a0 + j, a0 + q), zero below the diagonal of the transpose
-          S.w = reserve(3, nrows, S.len, p.Dinv.data(), c, a0, 0, nullptr);
+          S.w = reserve(3, nrows, S.len, p.dinv(), c, a0, 0, nullptr);
         }
         P.segs.push_back(S);
         seg_len_sum += S.len;
@@ -510,7 +518,7 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
           Wt.src = -1;
           Wt.idx = idx0;
           Wt.pad = 0;
-          Wt.w = reserve(4, nrows, Wt.len, p.W.data(), c, a0, m, nullptr);
+          Wt.w = reserve(4, nrows, Wt.len, p.w(), c, a0, m, nullptr);
           P.segs.push_back(Wt);
           seg_len_sum += Wt.len;
           ++seg_cnt;
@@ -527,7 +535,7 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
     P.levels.push_back(lv);
   }
   // ---- write the weights ----
-  write_weights(fills, cursor, nthreads, &vals);
+  P.weights_ok = write_weights(fills, cursor, nthreads, &P);
   top_blocks.clear();
   P.out_off.resize((size_t)k);
   for (int j = 0; j < k; ++j) P.out_off[j] = pos(bit[piece_of[j]], j);
@@ -612,54 +620,136 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
   }
   if (P.idxs.size() & 1) P.idxs.push_back(0);
   if (P.idxs.empty()) P.idxs.assign(2, 0);
-  if (P.vals.empty()) P.vals.assign(2, 0.0);
-  return true;
+  if (!P.sink && P.vals.empty()) P.vals.assign(2, 0.0);
+  return P.weights_ok;
 }
 
 namespace partinv {
-void write_weights(const std::vector<Fill> &fills, long long total, int nthreads, std::vector<double> *vals_out) {
-  std::vector<double> &vals = *vals_out;
-  vals.assign((size_t)total, 0.0);
-  parallel_for((int)fills.size(), nthreads, 64, [&](int fi) {
-    const Fill &f = fills[(size_t)fi];
-    double *w = vals.data() + f.off;
-    const int nr = f.nrows, c = f.c, a0 = f.a0;
-    switch (f.kind) {
-      case 0:  // rows a0 + q of a lower-triangular matrix
-        for (int q = 0; q < nr; ++q) {
-          const double *src = f.base + (size_t)(a0 + q) * c;
-          const int hi = std::min(std::min(f.len, c), a0 + q + 1);
-          for (int j = 0; j < hi; ++j) w[(size_t)j * nr + q] = src[j];
-        }
-        break;
-      case 1:  // rows loc[q] of a matrix with c columns
-        for (int q = 0; q < nr; ++q) {
-          const double *src = f.base + (size_t)f.loc[q] * c;
-          const int hi = std::min(f.len, c);
-          for (int j = 0; j < hi; ++j) w[(size_t)j * nr + q] = src[j];
-        }
-        break;
-      case 2:  // rows a0 + q of a full c x c matrix
-        for (int q = 0; q < nr; ++q) {
-          const double *src = f.base + (size_t)(a0 + q) * c;
-          const int hi = std::min(f.len, c);
-          for (int j = 0; j < hi; ++j) w[(size_t)j * nr + q] = src[j];
-        }
-        break;
-      case 3:  // (D^-T)(a0 + q, a0 + j) = Dinv(a0 + j, a0 + q), j >= q
-        for (int j = 0; j < f.len && a0 + j < c; ++j) {
-          const double *src = f.base + (size_t)(a0 + j) * c + a0;
-          for (int q = 0; q < nr && q <= j; ++q) w[(size_t)j * nr + q] = src[q];
-        }
-        break;
-      default:  // transposed block: base(j, a0 + q)
-        for (int j = 0; j < f.len && j < f.m; ++j) {
-          const double *src = f.base + (size_t)j * c + a0;
-          for (int q = 0; q < nr; ++q) w[(size_t)j * nr + q] = src[q];
-        }
-        break;
+namespace {
+// the weights of one fill; w points at weight f.off and the extent of the fill is zero
+// w[j nr + q] = row_q[j] for j < hi[q]: the tile's rows are read side by side and the weights leave in storage order
+inline void interleave_rows(const double *const *row, const int *hi, int nr, double *w) {
+  int hmin = hi[0], hmax = hi[0];
+  for (int q = 1; q < nr; ++q) {
+    hmin = std::min(hmin, hi[q]);
+    hmax = std::max(hmax, hi[q]);
+  }
+  if (nr == 4) {
+    const double *r0 = row[0], *r1 = row[1], *r2 = row[2], *r3 = row[3];
+    for (int j = 0; j < hmin; ++j) {
+      double *o = w + (size_t)j * 4;
+      o[0] = r0[j];
+      o[1] = r1[j];
+      o[2] = r2[j];
+      o[3] = r3[j];
     }
-  });
+  } else {
+    for (int j = 0; j < hmin; ++j)
+      for (int q = 0; q < nr; ++q) w[(size_t)j * nr + q] = row[q][j];
+  }
+  for (int j = std::max(hmin, 0); j < hmax; ++j)
+    for (int q = 0; q < nr; ++q)
+      if (j < hi[q]) w[(size_t)j * nr + q] = row[q][j];
+}
+inline void fill_one(const Fill &f, double *w) {
+  const int nr = f.nrows, c = f.c, a0 = f.a0;
+  const double *row[kSpTile] = {nullptr, nullptr, nullptr, nullptr};
+  int hi[kSpTile] = {0, 0, 0, 0};
+  if (nr <= 0) return;
+  switch (f.kind) {
+    case 0:  // rows a0 + q of a lower-triangular matrix
+      for (int q = 0; q < nr; ++q) {
+        row[q] = f.base + (size_t)(a0 + q) * c;
+        hi[q] = std::max(0, std::min(std::min(f.len, c), a0 + q + 1));
+      }
+      interleave_rows(row, hi, nr, w);
+      break;
+    case 1:  // rows loc[q] of a matrix with c columns
+      for (int q = 0; q < nr; ++q) {
+        row[q] = f.base + (size_t)f.loc[q] * c;
+        hi[q] = std::max(0, std::min(f.len, c));
+      }
+      interleave_rows(row, hi, nr, w);
+      break;
+    case 2:  // rows a0 + q of a full c x c matrix
+      for (int q = 0; q < nr; ++q) {
+        row[q] = f.base + (size_t)(a0 + q) * c;
+        hi[q] = std::max(0, std::min(f.len, c));
+      }
+      interleave_rows(row, hi, nr, w);
+      break;
+    case 3:  // (D^-T)(a0 + q, a0 + j) = Dinv(a0 + j, a0 + q), j >= q
+      for (int j = 0; j < f.len && a0 + j < c; ++j) {
+        const double *src = f.base + (size_t)(a0 + j) * c + a0;
+        for (int q = 0; q < nr && q <= j; ++q) w[(size_t)j * nr + q] = src[q];
+      }
+      break;
+    default:  // transposed block: base(j, a0 + q)
+      for (int j = 0; j < f.len && j < f.m; ++j) {
+        const double *src = f.base + (size_t)j * c + a0;
+        for (int q = 0; q < nr; ++q) w[(size_t)j * nr + q] = src[q];
+      }
+      break;
+  }
+}
+}  // namespace
+
+bool write_weights(const std::vector<Fill> &fills, long long total, int nthreads, PartInvHost *P) {
+  P->nvals = total;
+  if (!P->sink) {
+    std::vector<double> &vals = P->vals;
+    vals.assign((size_t)total, 0.0);
+    parallel_for((int)fills.size(), nthreads, 64, [&](int fi) { fill_one(fills[(size_t)fi], vals.data() + fills[(size_t)fi].off); });
+    return true;
+  }
+  // Streamed: the fills are laid out in ascending order of their offsets, so a chunk is a run of consecutive fills;
+  // every fill zeroes its own extent (up to the next fill) before it writes, and the chunk travels while the next one
+  // is formed.
+  WeightSink &sink = *P->sink;
+  P->vals.clear();
+  if (!sink.begin(total)) return false;
+  const int nf = (int)fills.size();
+  std::vector<int> order;
+  for (int i = 1; i < nf; ++i)
+    if (fills[(size_t)i].off < fills[(size_t)i - 1].off) {
+      order.resize((size_t)nf);
+      for (int q = 0; q < nf; ++q) order[(size_t)q] = q;
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return fills[(size_t)a].off < fills[(size_t)b].off; });
+      break;
+    }
+  auto at = [&](int i) -> const Fill & { return fills[(size_t)(order.empty() ? i : order[(size_t)i])]; };
+  auto extent_end = [&](int i) { return i + 1 < nf ? at(i + 1).off : total; };
+  const long long cap = std::max<long long>(1, sink.chunk_cap());
+  int i0 = 0;
+  long long off0 = 0;  // start of the chunk: 0, then the offset of its first fill
+  while (off0 < total) {
+    int i1 = i0;
+    long long end = nf ? (i0 < nf ? at(i0).off : total) : total;
+    if (i0 < nf) {
+      // at least one fill per chunk (an extent never exceeds the cap: a fill is a tile of a few rows)
+      end = extent_end(i0);
+      i1 = i0 + 1;
+      while (i1 < nf && extent_end(i1) - off0 <= cap) {
+        end = extent_end(i1);
+        ++i1;
+      }
+    }
+    const long long n = end - off0;
+    if (n > cap) return false;
+    double *buf = sink.acquire(n);
+    if (!buf) return false;
+    if (i0 < nf && at(i0).off > off0) std::fill(buf, buf + (at(i0).off - off0), 0.0);  // before the first fill
+    parallel_for(i1 - i0, nthreads, 64, [&](int q) {
+      const Fill &f = at(i0 + q);
+      double *w = buf + (f.off - off0);
+      std::fill(w, w + (extent_end(i0 + q) - f.off), 0.0);
+      fill_one(f, w);
+    });
+    if (!sink.commit(off0, n)) return false;
+    i0 = i1;
+    off0 = end;
+  }
+  return sink.end();
 }
 }  // namespace partinv
 

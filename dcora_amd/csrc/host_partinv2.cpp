@@ -97,7 +97,7 @@ void layout_merged(const std::vector<Piece> &pc, const std::vector<const double 
       if (c >= kBig && nthreads > 1) {
         // row a of the lower triangle by one thread: M(a, j) = sum_{i >= a} Dinv(i, a) Dinv(i, j), j <= a
         std::vector<double> &Ms = Mown[s];
-        const std::vector<double> &Dinv = pc[s].Dinv;
+        const double *Dinv = pc[s].dinv();
         parallel_for(c, nthreads, 4, [&](int a) {
           double *ma = &Ms[(size_t)a * c];
           for (int i = a; i < c; ++i) {
@@ -117,7 +117,7 @@ void layout_merged(const std::vector<Piece> &pc, const std::vector<const double 
     parallel_for((int)small.size(), nthreads, 1, [&](int t) {
       const int s = small[(size_t)t], c = pc[s].c;
       std::vector<double> &Ms = Mown[s];
-      const std::vector<double> &Dinv = pc[s].Dinv;
+      const double *Dinv = pc[s].dinv();
       for (int i = 0; i < c; ++i) {
         const double *di = &Dinv[(size_t)i * c];
         for (int a = 0; a <= i; ++a) {
@@ -246,7 +246,7 @@ void layout_merged(const std::vector<Piece> &pc, const std::vector<const double 
         size_t u = 0;
         for (int a = 0; a < m; ++a) {
           while (R[u] != ps.rows[a]) ++u;
-          std::copy(&ps.W[(size_t)a * c], &ps.W[(size_t)a * c] + c, &V[u * c]);
+          std::copy(ps.w() + (size_t)a * c, ps.w() + (size_t)a * c + c, &V[u * c]);
         }
       }
       // through the pieces of level t + 1
@@ -261,11 +261,11 @@ void layout_merged(const std::vector<Piece> &pc, const std::vector<const double 
           for (int bb = 0; bb < mq; ++bb) {
             while (R[u] != pq.rows[bb]) ++u;
             double *dst = &V[u * c];
-            const double *wq = &pq.W[(size_t)bb * cq];
+            const double *wq = pq.w() + (size_t)bb * cq;
             for (int aa = a; aa < b; ++aa) {
               const double coef = wq[ps.rows[aa] - pq.c0];
               if (coef == 0.0) continue;
-              const double *ws = &ps.W[(size_t)aa * c];
+              const double *ws = ps.w() + (size_t)aa * c;
               for (int j = 0; j < c; ++j) dst[j] += coef * ws[j];
             }
           }
@@ -287,7 +287,7 @@ void layout_merged(const std::vector<Piece> &pc, const std::vector<const double 
     } else {
       S.rows = pc[s].rows.data();
       S.m = (int)pc[s].rows.size();
-      S.V = pc[s].W.data();
+      S.V = pc[s].w();
     }
     return S;
   };
@@ -531,7 +531,7 @@ void layout_merged(const std::vector<Piece> &pc, const std::vector<const double 
   }
   P.nforward = NG;
   const auto T3 = tnow();
-  write_weights(fills, cursor, nthreads, &P.vals);
+  P.weights_ok = write_weights(fills, cursor, nthreads, &P);
   P.out_off.resize((size_t)k);
   for (int j = 0; j < k; ++j) {
     const int s = piece_of[j];

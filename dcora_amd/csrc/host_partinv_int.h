@@ -18,6 +18,11 @@ struct Piece {
   int level = 0;
   std::vector<double> Dinv;   // D^-1, c x c row-major (lower triangular)
   std::vector<double> W;      // -B D^-1, m x c row-major
+  // a piece the device delivered inverted, with no row dropped, is read where it arrived (views into the factor's
+  // host block) instead of being copied: 3 GB for the whole 100k lattice
+  const double *Dinv_view = nullptr, *W_view = nullptr;
+  const double *dinv() const { return Dinv_view ? Dinv_view : (Dinv.empty() ? nullptr : Dinv.data()); }
+  const double *w() const { return W_view ? W_view : W.data(); }
 };
 
 inline int pad2(int x) { return (x + 1) & ~1; }
@@ -81,7 +86,8 @@ struct Fill {
   int kind, nrows, len, c, a0, m;
   int loc[kSpTile];
 };
-void write_weights(const std::vector<Fill> &fills, long long total, int nthreads, std::vector<double> *vals);
+// into P->vals, or chunk by chunk into P->sink when one is set; false when the sink failed
+bool write_weights(const std::vector<Fill> &fills, long long total, int nthreads, PartInvHost *P);
 
 // second schedule builder (host_partinv2.cpp).  pc: pieces with Dinv and W; Mgiven[s] (may be null): D^-T D^-1 of piece
 // s where the device delivered it.  Fills P->levels / tasks / segs / idxs / vals / out_off / weights_read_per_apply.

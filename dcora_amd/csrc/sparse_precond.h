@@ -15,6 +15,7 @@
 // value of a piece is known at build time and baked into the gather offsets.
 #pragma once
 #include <cstddef>
+#include <memory>
 #include <vector>
 
 #include "host_sparse.h"
@@ -52,6 +53,16 @@ struct SpLevel {
   int cls[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 };
 
+// Receiver of the stored weights of a schedule, in ascending chunks (write_weights, host_partinv.cpp)
+struct WeightSink {
+  virtual ~WeightSink() = default;
+  virtual bool begin(long long total) = 0;
+  virtual long long chunk_cap() const = 0;                  // most weights one chunk may hold
+  virtual double *acquire(long long n) = 0;                 // host memory for the next n <= chunk_cap() weights
+  virtual bool commit(long long off, long long n) = 0;      // the memory handed out last holds weights [off, off + n)
+  virtual bool end() = 0;
+};
+
 // host image of the partitioned inverse: built by build_partitioned_inverse, uploaded by SparsePrecond
 // Hubs: h unknowns coupled to a large share of all others (a landmark ranged from every pose).  They are kept
 // out of the dissection and handled by a Schur complement: with A = [A11 a; a^T alpha],
@@ -76,6 +87,11 @@ struct PartInvHost {
   std::vector<PTask> tasks;
   std::vector<PSeg> segs;
   std::vector<double> vals;
+  // set by the caller before the build: the stored weights are streamed there while they are formed and `vals` stays
+  // empty (the product: the 6.8 GB of the whole 100k lattice never exist on the host); null: weights in `vals`
+  struct WeightSink *sink = nullptr;
+  long long nvals = 0;  // number of stored weights, wherever they went
+  bool weights_ok = true;  // false: the sink refused them
   std::vector<int> idxs;
   std::vector<int> perm;         // permuted position -> original unknown
   std::vector<int> out_off;      // permuted position -> where its final value lives (buffer * k + position)
@@ -96,12 +112,18 @@ struct PieceFactor {
   // W = -L21 L11^-1, and for a piece without rows below Mtop = L11^-T L11^-1 (c x c, both triangles)
   bool inverted = false;
   std::vector<double> Mtop;
+  // the device factorisation hands all panels over in ONE host block (PiecewiseFactor::block): views instead of 3 GB
+  // of per-piece copies for the whole 100k lattice
+  const double *panel_view = nullptr, *Mtop_view = nullptr;
+  const double *pan() const { return panel_view ? panel_view : panel.data(); }
+  const double *mtop() const { return Mtop_view ? Mtop_view : (Mtop.empty() ? nullptr : Mtop.data()); }
 };
 struct PiecewiseFactor {
   int n = 0, nhub = 0;
   long nnzL = 0;
   std::vector<int> perm, iperm;
   std::vector<PieceFactor> pieces;
+  std::shared_ptr<void> block;  // keeps the storage behind the pieces' views alive
 };
 void piecewise_from_chol(const SparseChol &chol, PiecewiseFactor *out);
 

@@ -1,9 +1,12 @@
 // Device side of the sparse preconditioner (sparse_precond.h): uploads the partitioned inverse and replays its
 // level schedule, one gather kernel per level.
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 #include "device_problem.h"
 
@@ -501,14 +504,95 @@ void launch_level(hipStream_t st, int r, const SpLevel &lv, const PTask *tasks, 
 
 }  // namespace
 
-int SpImage::upload(const PartInvHost &P) {
+namespace {
+// pinned chunk buffers, recycled: pinning 64 MB costs milliseconds, and the agents of a session build side by side
+std::mutex g_pin_mu;
+std::vector<double *> g_pin_free;
+double *pin_acquire() {
+  {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    if (!g_pin_free.empty()) {
+      double *p = g_pin_free.back();
+      g_pin_free.pop_back();
+      return p;
+    }
+  }
+  double *p = nullptr;
+  if (hipHostMalloc((void **)&p, (size_t)DeviceWeightSink::kChunk * sizeof(double), hipHostMallocDefault) != hipSuccess)
+    return nullptr;
+  return p;
+}
+void pin_release(double *p) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(g_pin_mu);
+  if (g_pin_free.size() < 12) {
+    g_pin_free.push_back(p);
+    return;
+  }
+  (void)hipHostFree(p);
+}
+}  // namespace
+
+DeviceWeightSink::~DeviceWeightSink() {
+  if (st) {
+    (void)hipStreamSynchronize(st);
+    stream_release(device, st);
+  }
+  for (int i = 0; i < kBuffers; ++i) {
+    if (ev[i]) (void)hipEventDestroy(ev[i]);
+    pin_release(pin[i]);
+  }
+}
+bool DeviceWeightSink::begin(long long total) {
+  if (hipSetDevice(device) != hipSuccess) return false;
+  if (vals.alloc((size_t)std::max<long long>(2, total)) != hipSuccess) {
+    set_last_error("sparse preconditioner: no device memory for the stored weights");
+    return false;
+  }
+  if (total < 2 && hipMemset(vals.p, 0, 2 * sizeof(double)) != hipSuccess) return false;
+  if (stream_acquire(device, &st) != DCORA_OK) return false;
+  for (int i = 0; i < kBuffers; ++i) {
+    if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return false;
+  }
+  return true;
+}
+double *DeviceWeightSink::acquire(long long n) {
+  if (n > kChunk) return nullptr;
+  cur = (cur + 1) % kBuffers;
+  if (!pin[cur]) {
+    pin[cur] = pin_acquire();
+    if (!pin[cur]) {
+      set_last_error("sparse preconditioner: no pinned host memory for the weight chunks");
+      return nullptr;
+    }
+  }
+  if (busy[cur]) {
+    if (hipEventSynchronize(ev[cur]) != hipSuccess) return nullptr;
+    busy[cur] = false;
+  }
+  return pin[cur];
+}
+bool DeviceWeightSink::commit(long long off, long long n) {
+  if (hipMemcpyAsync(vals.p + off, pin[cur], (size_t)n * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
+    return false;
+  if (hipEventRecord(ev[cur], st) != hipSuccess) return false;
+  busy[cur] = true;
+  return true;
+}
+bool DeviceWeightSink::end() { return hipStreamSynchronize(st) == hipSuccess; }
+
+int SpImage::upload(const PartInvHost &P, DeviceWeightSink *streamed) {
   k = P.k;
   levels = P.levels;
   nnzL = P.nnzL;
   npieces = P.npieces;
   weights_per_apply = P.weights_read_per_apply;
-  DCORA_HIP(vals.alloc(P.vals.size()));
-  DCORA_HIP(hipMemcpy(vals.p, P.vals.data(), P.vals.size() * sizeof(double), hipMemcpyHostToDevice));
+  if (streamed && streamed->vals.p) {
+    vals = std::move(streamed->vals);
+  } else {
+    DCORA_HIP(vals.alloc(P.vals.size()));
+    DCORA_HIP(hipMemcpy(vals.p, P.vals.data(), P.vals.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
   DCORA_HIP(idxs.alloc(P.idxs.size()));
   DCORA_HIP(hipMemcpy(idxs.p, P.idxs.data(), P.idxs.size() * sizeof(int), hipMemcpyHostToDevice));
   DCORA_HIP(tasks.alloc(P.tasks.size()));
