@@ -324,8 +324,82 @@ inline bool potrf_v1() {
   return v;
 }
 
-// acc[u][v] = sum_k A[(ty + 16 u)][k] B[(tx + 16 v)][k]; A and B are row-major with k contiguous; rows beyond
-// arows / brows and k beyond K read as zero
+// ---- the 64 x 64 x 64 product of two LDS tiles, As[k][i] and Bs[k][j]: acc(i, j) += sum_k As[k][i] Bs[k][j] ----
+// MMA = false: 4 x 4 outputs per thread by FMAs (8 LDS reads per 16 FMAs: the LDS port is the bound, 128 clocks per k
+// for the workgroup against 64 of FMA).  MMA = true: v_mfma_f64_16x16x4_f64, every wave owns a 32 x 32 quadrant as
+// 2 x 2 blocks; 4 LDS reads per 4 MFMAs (8192 flop), the matrix pipe is the bound.  The two forms keep their 16 sums
+// per thread in acc[4][4] under different maps (acc_row / acc_col).
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+template <bool MMA>
+__device__ __forceinline__ int acc_row(int u, int v) {
+  if (MMA) return (int)(threadIdx.x >> 7) * 32 + (u >> 1) * 16 + (int)((threadIdx.x & 63) >> 4) + 4 * v;
+  return (int)(threadIdx.x >> 4) + 16 * u;
+}
+template <bool MMA>
+__device__ __forceinline__ int acc_col(int u, int v) {
+  if (MMA) return (int)((threadIdx.x >> 6) & 1) * 32 + (u & 1) * 16 + (int)(threadIdx.x & 15);
+  return (int)(threadIdx.x & 15) + 16 * v;
+}
+template <bool MMA>
+__device__ __forceinline__ void tile_inner(const double (*As)[NB + 1], const double (*Bs)[NB + 1], double acc[4][4]) {
+  if (MMA) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r0 = (w >> 1) * 32 + (lane & 15), c0 = (w & 1) * 32 + (lane & 15), kq = lane >> 4;
+    v4f64 c[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) c[u] = v4f64{acc[u][0], acc[u][1], acc[u][2], acc[u][3]};
+#pragma unroll 4
+    for (int k0 = 0; k0 < NB; k0 += 4) {
+      const double a0 = As[k0 + kq][r0], a1 = As[k0 + kq][r0 + 16];
+      const double b0 = Bs[k0 + kq][c0], b1 = Bs[k0 + kq][c0 + 16];
+      c[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c[0], 0, 0, 0);
+      c[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, c[1], 0, 0, 0);
+      c[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, c[2], 0, 0, 0);
+      c[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c[3], 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) acc[u][v] = c[u][v];
+  } else {
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+#pragma unroll 8
+    for (int k = 0; k < NB; ++k) {
+      double a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] = As[k][ty + 16 * u];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) b[v] = Bs[k][tx + 16 * v];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] = fma(a[u], b[v], acc[u][v]);
+    }
+  }
+}
+inline bool chol_mma() {
+  static const bool v = [] {
+    const char *e = std::getenv("DCORA_CHOL_MMA");
+    return !(e && std::strcmp(e, "fma") == 0);
+  }();
+  return v;
+}
+inline int chol_superpanel_blocks() {
+  static const int v = [] {
+    const char *e = std::getenv("DCORA_CHOL_SUPERPANEL");
+    return e ? std::max(1, std::min(16, atoi(e))) : 8;
+  }();
+  return v;
+}
+#define DCORA_LAUNCH_MMA(KERNEL, grid, st, ...)                                               \
+  do {                                                                                        \
+    if (chol_mma()) hipLaunchKernelGGL((KERNEL<true>), grid, dim3(256), 0, st, __VA_ARGS__);  \
+    else hipLaunchKernelGGL((KERNEL<false>), grid, dim3(256), 0, st, __VA_ARGS__);            \
+  } while (0)
+
+// acc(i, j) = sum_k A[i][k] B[j][k]; A and B are row-major with k contiguous; rows beyond arows / brows and k beyond K
+// read as zero
+template <bool MMA>
 __device__ __forceinline__ void chol_tile_product(const double *__restrict__ Ag, long long lda, int arows,
                                                   const double *__restrict__ Bg, long long ldb, int brows, int K,
                                                   double (*As)[NB + 1], double (*Bs)[NB + 1], double acc[4][4]) {
@@ -336,26 +410,15 @@ __device__ __forceinline__ void chol_tile_product(const double *__restrict__ Ag,
     Bs[k][i] = (i < brows && k < K) ? Bg[(long long)i * ldb + k] : 0.0;
   }
   __syncthreads();
-  const int ty = tid >> 4, tx = tid & 15;
 #pragma unroll
   for (int u = 0; u < 4; ++u)
 #pragma unroll
     for (int v = 0; v < 4; ++v) acc[u][v] = 0;
-#pragma unroll 8
-  for (int k = 0; k < NB; ++k) {
-    double a[4], b[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) a[u] = As[k][ty + 16 * u];
-#pragma unroll
-    for (int v = 0; v < 4; ++v) b[v] = Bs[k][tx + 16 * v];
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int v = 0; v < 4; ++v) acc[u][v] = fma(a[u], b[v], acc[u][v]);
-  }
+  tile_inner<MMA>(As, Bs, acc);
 }
 
 // panel below the diagonal block:  X = B L^-T, 64 rows per workgroup, in place
+template <bool MMA>
 __global__ __launch_bounds__(256) void k_chol_trsm(const PieceDev *__restrict__ pieces, const int *__restrict__ list,
                                                    int j0, double *__restrict__ F, const double *__restrict__ Linv,
                                                    const int *__restrict__ fail) {
@@ -369,51 +432,15 @@ __global__ __launch_bounds__(256) void k_chol_trsm(const PieceDev *__restrict__ 
   __shared__ double Bs[NB][NB + 1];
   double *__restrict__ A = F + P.off + (long long)r0 * f + j0;
   double acc[4][4];
-  chol_tile_product(A, f, min(NB, f - r0), Linv + (size_t)blockIdx.y * NB * NB, NB, jb, jb, As, Bs, acc);
-  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+  chol_tile_product<MMA>(A, f, min(NB, f - r0), Linv + (size_t)blockIdx.y * NB * NB, NB, jb, jb, As, Bs, acc);
+  __syncthreads();  // the tile is overwritten in place: every read of it (into LDS) is behind us
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int i = ty + 16 * u;
-    if (r0 + i >= f) continue;
+  for (int u = 0; u < 4; ++u)
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      const int j = tx + 16 * v;
-      if (j < jb) A[(long long)i * f + j] = acc[u][v];
+      const int i = acc_row<MMA>(u, v), j = acc_col<MMA>(u, v);
+      if (r0 + i < f && j < jb) A[(long long)i * f + j] = acc[u][v];
     }
-  }
-}
-
-// trailing update: C(ti, tj) -= X(ti) X(tj)^T over the 64 x 64 tiles of the lower triangle
-__global__ __launch_bounds__(256) void k_chol_syrk(const PieceDev *__restrict__ pieces, const int *__restrict__ list,
-                                                   int j0, double *__restrict__ F, const int *__restrict__ fail) {
-  if (*fail) return;
-  const PieceDev P = pieces[list[blockIdx.y]];
-  const int jb = min(NB, P.c - j0);
-  const int f = P.c + P.m;
-  const int base = j0 + jb;
-  int ti = (int)((sqrtf(8.0f * (float)blockIdx.x + 1.0f) - 1.0f) * 0.5f);
-  while ((ti + 1) * (ti + 2) / 2 <= (int)blockIdx.x) ++ti;
-  while (ti * (ti + 1) / 2 > (int)blockIdx.x) --ti;
-  const int tj = blockIdx.x - ti * (ti + 1) / 2;
-  const int ri0 = base + NB * ti, cj0 = base + NB * tj;
-  if (ri0 >= f) return;
-  __shared__ double As[NB][NB + 1];
-  __shared__ double Bs[NB][NB + 1];
-  double *__restrict__ M = F + P.off;
-  double acc[4][4];
-  chol_tile_product(M + (long long)ri0 * f + j0, f, min(NB, f - ri0), M + (long long)cj0 * f + j0, f,
-                    min(NB, f - cj0), jb, As, Bs, acc);
-  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int r = ri0 + ty + 16 * u;
-    if (r >= f) continue;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int c = cj0 + tx + 16 * v;
-      if (c <= r) M[(long long)r * f + c] -= acc[u][v];
-    }
-  }
 }
 
 __global__ __launch_bounds__(256) void k_count_nonzero(long long n, const double *__restrict__ v,
@@ -455,44 +482,99 @@ __global__ __launch_bounds__(256) void k_dense_scatter(int k, const int *__restr
 }
 
 // acc += A-rows x B-rows^T over K chunks of 64: A(ia, l) and B(ib, l), l in [l0, l1)
+template <bool MMA>
 __device__ __forceinline__ void tile_product_range(const double *__restrict__ Arow, const double *__restrict__ Brow,
                                                    long long ld, int arows, int brows, int l0, int l1,
                                                    double (*As)[NB + 1], double (*Bs)[NB + 1], double acc[4][4],
                                                    long long ldb = -1) {
   if (ldb < 0) ldb = ld;
-  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-  for (int l = l0; l < l1; l += NB) {
+  const int tid = threadIdx.x;
+  // software pipeline over the 64-column steps: the operands of step l + 1 are requested (into registers) before the
+  // products of step l, so their latency hides behind 64 MFMAs per wave instead of standing between two steps
+  constexpr int PER = NB * NB / 256;  // entries of each operand per thread
+  const int kk = tid & 63, ib = tid >> 6;  // entry q of a thread: row ib + 4 q, column kk of the step
+  double ra[PER], rb[PER];
+  auto fetch = [&](int l) {
     const int K = min(NB, l1 - l);
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int i = ib + 4 * q;
+      ra[q] = (i < arows && kk < K) ? Arow[(long long)i * ld + l + kk] : 0.0;
+      rb[q] = (i < brows && kk < K) ? Brow[(long long)i * ldb + l + kk] : 0.0;
+    }
+  };
+  if (l0 < l1) fetch(l0);
+  for (int l = l0; l < l1; l += NB) {
     __syncthreads();
-    for (int e = tid; e < NB * NB; e += 256) {
-      const int i = e >> 6, kk = e & 63;
-      As[kk][i] = (i < arows && kk < K) ? Arow[(long long)i * ld + l + kk] : 0.0;
-      Bs[kk][i] = (i < brows && kk < K) ? Brow[(long long)i * ldb + l + kk] : 0.0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      As[kk][ib + 4 * q] = ra[q];
+      Bs[kk][ib + 4 * q] = rb[q];
     }
     __syncthreads();
-#pragma unroll 8
-    for (int kk = 0; kk < NB; ++kk) {
-      double a[4], b[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) a[u] = As[kk][ty + 16 * u];
-#pragma unroll
-      for (int v = 0; v < 4; ++v) b[v] = Bs[kk][tx + 16 * v];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) acc[u][v] = fma(a[u], b[v], acc[u][v]);
-    }
+    if (l + NB < l1) fetch(l + NB);
+    tile_inner<MMA>(As, Bs, acc);
   }
+}
+
+// trailing update: C(ti, tj) -= sum_{l in [k0, base)} X(ti, l) X(tj, l) over 64 x 64 tiles of the lower triangle behind
+// base = min(kcap, c).  Two uses (build_image):
+//   inside a super-panel (ncb > 0): K = one 64-column block, only the ncb column blocks of the super-panel that are
+//     still to be factored are updated (columns < min(ccap, c)), blockIdx.x = ti ncb + tj;
+//   behind a super-panel (ncb = 0): K = the whole super-panel (up to 256 columns in 64-column steps through LDS), every
+//     tile of the trailing matrix, blockIdx.x = triangular index.  A rank-256 update reads and writes the trailing
+//     matrix once where four rank-64 updates did four times: the update is bound by exactly that traffic.
+template <bool MMA>
+__global__ __launch_bounds__(256) void k_chol_syrk(const PieceDev *__restrict__ pieces, const int *__restrict__ list,
+                                                   int k0, int kcap, int ccap, int ncb, double *__restrict__ F,
+                                                   const int *__restrict__ fail) {
+  if (*fail) return;
+  const PieceDev P = pieces[list[blockIdx.y]];
+  const int f = P.c + P.m;
+  const int base = min(kcap, P.c);
+  if (base <= k0) return;
+  const int colend = ccap >= 0 ? min(ccap, P.c) : f;
+  int ti, tj;
+  if (ncb > 0) {
+    ti = blockIdx.x / ncb;
+    tj = blockIdx.x - ti * ncb;
+    if (tj > ti) return;
+  } else {
+    ti = (int)((sqrtf(8.0f * (float)blockIdx.x + 1.0f) - 1.0f) * 0.5f);
+    while ((ti + 1) * (ti + 2) / 2 <= (int)blockIdx.x) ++ti;
+    while (ti * (ti + 1) / 2 > (int)blockIdx.x) --ti;
+    tj = blockIdx.x - ti * (ti + 1) / 2;
+  }
+  const int ri0 = base + NB * ti, cj0 = base + NB * tj;
+  if (ri0 >= f || cj0 >= colend) return;
+  __shared__ double As[NB][NB + 1];
+  __shared__ double Bs[NB][NB + 1];
+  double *__restrict__ M = F + P.off;
+  double acc[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[u][v] = 0;
+  tile_product_range<MMA>(M + (long long)ri0 * f, M + (long long)cj0 * f, f, min(NB, f - ri0), min(NB, f - cj0), k0, base,
+                          As, Bs, acc);
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int r = ri0 + acc_row<MMA>(u, v), c = cj0 + acc_col<MMA>(u, v);
+      if (r < f && c <= r && c < colend) M[(long long)r * f + c] -= acc[u][v];
+    }
 }
 
 // Y = L^-1 right-looking, one block row of L at a time; Y is kept transposed (YT(j, i) = Y(i, j)^T).  Step ib:
 //   finish:  YT(j, ib) = -TT(j, ib) Linv_ib^T for the block rows j < ib (TT accumulated in place), YT(ib, ib) = Linv_ib^T
 //   update:  TT(j, i) += YT(j, ib) L(i, ib)^T for every block row i > ib and j <= ib  -- (nb - ib - 1)(ib + 1) tiles
+template <bool MMA>
 __global__ __launch_bounds__(256) void k_dense_trtri_finish(int k, int ib, double *__restrict__ YT,
                                                             const double *__restrict__ Linv) {
   __shared__ double As[NB][NB + 1];
   __shared__ double Bs[NB][NB + 1];
-  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const int tid = threadIdx.x;
   const int i0 = ib * NB, ni = min(NB, k - i0);
   const double *__restrict__ Li = Linv + (size_t)ib * NB * NB;
   if ((int)blockIdx.x == ib) {  // diagonal block: the transpose of the inverse of the diagonal block of L
@@ -514,26 +596,16 @@ __global__ __launch_bounds__(256) void k_dense_trtri_finish(int k, int ib, doubl
   for (int u = 0; u < 4; ++u)
 #pragma unroll
     for (int v = 0; v < 4; ++v) acc[u][v] = 0;
-#pragma unroll 8
-  for (int mm = 0; mm < NB; ++mm) {
-    double a[4], b[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) a[u] = As[mm][ty + 16 * u];
-#pragma unroll
-    for (int v = 0; v < 4; ++v) b[v] = Bs[mm][tx + 16 * v];
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int v = 0; v < 4; ++v) acc[u][v] = fma(a[u], b[v], acc[u][v]);
-  }
+  tile_inner<MMA>(As, Bs, acc);
 #pragma unroll
   for (int u = 0; u < 4; ++u)
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      const int b = tx + 16 * v;
-      if (b < ni) YT[(size_t)(j0 + ty + 16 * u) * k + i0 + b] = -acc[u][v];
+      const int b = acc_col<MMA>(u, v);
+      if (b < ni) YT[(size_t)(j0 + acc_row<MMA>(u, v)) * k + i0 + b] = -acc[u][v];
     }
 }
+template <bool MMA>
 __global__ __launch_bounds__(256) void k_dense_trtri_update(int k, int ib, const double *__restrict__ L, long long ldl,
                                                             double *__restrict__ YT) {
   __shared__ double As[NB][NB + 1];
@@ -545,18 +617,18 @@ __global__ __launch_bounds__(256) void k_dense_trtri_update(int k, int ib, const
   for (int u = 0; u < 4; ++u)
 #pragma unroll
     for (int v = 0; v < 4; ++v) acc[u][v] = 0;
-  tile_product_range(YT + (size_t)j0 * k, L + (size_t)i0 * ldl, k, NB, ni, l0, l0 + NB, As, Bs, acc, ldl);
-  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+  tile_product_range<MMA>(YT + (size_t)j0 * k, L + (size_t)i0 * ldl, k, NB, ni, l0, l0 + NB, As, Bs, acc, ldl);
 #pragma unroll
   for (int u = 0; u < 4; ++u)
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      const int mm = tx + 16 * v;
-      if (mm < ni) YT[(size_t)(j0 + ty + 16 * u) * k + i0 + mm] += acc[u][v];
+      const int mm = acc_col<MMA>(u, v);
+      if (mm < ni) YT[(size_t)(j0 + acc_row<MMA>(u, v)) * k + i0 + mm] += acc[u][v];
     }
 }
 
 // M = Y^T Y = YT YT^T: tile (ta, tb), tb <= ta, sums over the columns l >= block ta; both triangles are written
+template <bool MMA>
 __global__ __launch_bounds__(256) void k_dense_lauum(int k, const double *__restrict__ YT, double *__restrict__ M,
                                                      int ldm) {
   __shared__ double As[NB][NB + 1];
@@ -572,13 +644,12 @@ __global__ __launch_bounds__(256) void k_dense_lauum(int k, const double *__rest
   for (int u = 0; u < 4; ++u)
 #pragma unroll
     for (int v = 0; v < 4; ++v) acc[u][v] = 0;
-  tile_product_range(YT + (size_t)a0 * k, YT + (size_t)b0 * k, k, na, nb, a0, k, As, Bs, acc);
-  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+  tile_product_range<MMA>(YT + (size_t)a0 * k, YT + (size_t)b0 * k, k, na, nb, a0, k, As, Bs, acc);
 #pragma unroll
   for (int u = 0; u < 4; ++u)
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      const int a = a0 + ty + 16 * u, b = b0 + tx + 16 * v;
+      const int a = a0 + acc_row<MMA>(u, v), b = b0 + acc_col<MMA>(u, v);
       if (a < k && b < k) {
         M[(size_t)a * ldm + b] = acc[u][v];
         M[(size_t)b * ldm + a] = acc[u][v];
@@ -619,6 +690,7 @@ __global__ __launch_bounds__(256) void k_tri_inv64(int c, const double *__restri
   for (int e = tid; e < NB * NB; e += 256) O[e] = Li[e >> 6][e & 63];
 }
 // W(a, j) = -sum_{l >= j0} B(a, l) YT(j, l): tile (ta over the m rows below, tj over the c columns)
+template <bool MMA>
 __global__ __launch_bounds__(256) void k_piece_w(int c, int m, const double *__restrict__ B, long long ldb,
                                                  const double *__restrict__ YT, double *__restrict__ W) {
   __shared__ double As[NB][NB + 1];
@@ -630,13 +702,12 @@ __global__ __launch_bounds__(256) void k_piece_w(int c, int m, const double *__r
   for (int u = 0; u < 4; ++u)
 #pragma unroll
     for (int v = 0; v < 4; ++v) acc[u][v] = 0;
-  tile_product_range(B + (long long)a0 * ldb, YT + (long long)j0 * c, ldb, na, nj, j0, c, As, Bs, acc, c);
-  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+  tile_product_range<MMA>(B + (long long)a0 * ldb, YT + (long long)j0 * c, ldb, na, nj, j0, c, As, Bs, acc, c);
 #pragma unroll
   for (int u = 0; u < 4; ++u)
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      const int a = a0 + ty + 16 * u, j = j0 + tx + 16 * v;
+      const int a = a0 + acc_row<MMA>(u, v), j = j0 + acc_col<MMA>(u, v);
       if (a < m && j < c) W[(long long)a * c + j] = -acc[u][v];
     }
 }
@@ -690,6 +761,7 @@ __global__ __launch_bounds__(256) void k_small_inv(const PieceDev *__restrict__ 
   }
 }
 // rows [c, c + m) of the packed panel <- W = -L21 L11^-1: 64 rows below per workgroup (blockIdx.x), piece blockIdx.y
+template <bool MMA>
 __global__ __launch_bounds__(256) void k_small_w(const PieceDev *__restrict__ pieces, const int *__restrict__ list,
                                                  const long long *__restrict__ panel_off,
                                                  const double *__restrict__ F, double *__restrict__ out) {
@@ -703,7 +775,7 @@ __global__ __launch_bounds__(256) void k_small_w(const PieceDev *__restrict__ pi
   const double *__restrict__ B = F + P.off + (long long)(c + a0) * f;
   double *__restrict__ O = out + panel_off[s];
   const int na = min(NB, m - a0);
-  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const int tid = threadIdx.x;
   for (int e = tid; e < NB * NB; e += 256) {
     const int i = e >> 6, kk = e & 63;
     As[kk][i] = (i < na && kk < c) ? B[(long long)i * f + kk] : 0.0;  // L21(a0 + i, kk)
@@ -715,23 +787,12 @@ __global__ __launch_bounds__(256) void k_small_w(const PieceDev *__restrict__ pi
   for (int u = 0; u < 4; ++u)
 #pragma unroll
     for (int v = 0; v < 4; ++v) acc[u][v] = 0;
-#pragma unroll 8
-  for (int kk = 0; kk < NB; ++kk) {
-    double a[4], b[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) a[u] = As[kk][ty + 16 * u];
-#pragma unroll
-    for (int v = 0; v < 4; ++v) b[v] = Bs[kk][tx + 16 * v];
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int v = 0; v < 4; ++v) acc[u][v] = fma(a[u], b[v], acc[u][v]);
-  }
+  tile_inner<MMA>(As, Bs, acc);
 #pragma unroll
   for (int u = 0; u < 4; ++u)
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      const int a = ty + 16 * u, j = tx + 16 * v;
+      const int a = acc_row<MMA>(u, v), j = acc_col<MMA>(u, v);
       if (a < na && j < c) O[(long long)(c + a0 + a) * c + j] = -acc[u][v];
     }
 }
@@ -759,6 +820,7 @@ struct Launch {
   int kind;  // 0 extend-add, 1 potrf, 2 trsm, 3 syrk
   int list;  // offset into the device list (children or level pieces)
   int gx, gy, j0;
+  int kcap = 0, ccap = -1, ncb = 0;  // syrk: K range [j0, min(kcap, c)), column cap (-1: the whole trailing matrix), column blocks
 };
 
 struct CholImage {
@@ -814,18 +876,39 @@ int build_image(const HostCsr &A, int block, int top, int device, std::shared_pt
     }
     const int lp = S.level_ptr[t], ln = S.level_ptr[t + 1] - lp;
     const int cmax = S.pieces[S.level_pieces[lp]].c;
-    for (int j0 = 0; j0 < cmax; j0 += NB) {
-      int active = 0, maxrows = 0;
-      while (active < ln && S.pieces[S.level_pieces[lp + active]].c > j0) {
-        const CholPiece &P = S.pieces[S.level_pieces[lp + active]];
-        maxrows = std::max(maxrows, P.c + P.m - j0 - std::min(NB, P.c - j0));
-        ++active;
+    // super-panels of spb 64-column blocks: inside one, a factored block updates only the column blocks of the
+    // super-panel that are still to come; behind it, ONE update of rank 64 spb sweeps the trailing matrix
+    const int spb = chol_superpanel_blocks(), spw = spb * NB;
+    for (int s0 = 0; s0 < cmax; s0 += spw) {
+      int active0 = 0, maxrows2 = 0;
+      while (active0 < ln && S.pieces[S.level_pieces[lp + active0]].c > s0) {
+        const CholPiece &P = S.pieces[S.level_pieces[lp + active0]];
+        maxrows2 = std::max(maxrows2, P.c + P.m - std::min(s0 + spw, P.c));
+        ++active0;
       }
-      img->plan.push_back(Launch{1, lp, active, 1, j0});
-      if (maxrows > 0) {
-        const int T = (maxrows + NB - 1) / NB;
-        img->plan.push_back(Launch{2, lp, T, active, j0});
-        img->plan.push_back(Launch{3, lp, T * (T + 1) / 2, active, j0});
+      for (int j0 = s0; j0 < std::min(cmax, s0 + spw); j0 += NB) {
+        int active = 0, maxrows = 0, ncb = 0;
+        while (active < ln && S.pieces[S.level_pieces[lp + active]].c > j0) {
+          const CholPiece &P = S.pieces[S.level_pieces[lp + active]];
+          const int base = j0 + std::min(NB, P.c - j0);
+          maxrows = std::max(maxrows, P.c + P.m - base);
+          ncb = std::max(ncb, (std::min(s0 + spw, P.c) - base + NB - 1) / NB);
+          ++active;
+        }
+        img->plan.push_back(Launch{1, lp, active, 1, j0});
+        if (maxrows > 0) {
+          const int T = (maxrows + NB - 1) / NB;
+          img->plan.push_back(Launch{2, lp, T, active, j0});
+          if (spb == 1) {
+            img->plan.push_back(Launch{3, lp, T * (T + 1) / 2, active, j0, j0 + NB, -1, 0});
+          } else if (ncb > 0) {
+            img->plan.push_back(Launch{3, lp, T * ncb, active, j0, j0 + NB, s0 + spw, ncb});
+          }
+        }
+      }
+      if (spb > 1 && maxrows2 > 0) {
+        const int T = (maxrows2 + NB - 1) / NB;
+        img->plan.push_back(Launch{3, lp, T * (T + 1) / 2, active0, s0, s0 + spw, -1, 0});
       }
     }
   }
@@ -964,11 +1047,11 @@ int factor_on_device(const HostCsr &A, int block, int top, int device, bool *pd,
                            img->fail.p, img->logdet.p, 0);
         break;
       case 2:
-        hipLaunchKernelGGL(k_chol_trsm, dim3(L.gx, L.gy), dim3(256), 0, st, img->pieces.p, list, L.j0, F, img->linv.p,
+        DCORA_LAUNCH_MMA(k_chol_trsm, dim3(L.gx, L.gy), st, img->pieces.p, list, L.j0, F, img->linv.p,
                            img->fail.p);
         break;
       default:
-        hipLaunchKernelGGL(k_chol_syrk, dim3(L.gx, L.gy), dim3(256), 0, st, img->pieces.p, list, L.j0, F,
+        DCORA_LAUNCH_MMA(k_chol_syrk, dim3(L.gx, L.gy), st, img->pieces.p, list, L.j0, L.kcap, L.ccap, L.ncb, F,
                            img->fail.p);
         break;
     }
@@ -1040,7 +1123,7 @@ int factor_on_device(const HostCsr &A, int block, int top, int device, bool *pd,
         hipLaunchKernelGGL(k_small_inv, dim3((unsigned)narrow.size()), dim3(256), 0, st, img->pieces.p, dlist.p, dpoff.p, F,
                            packed.p);
         if (mmax > 0)
-          hipLaunchKernelGGL(k_small_w, dim3((mmax + NB - 1) / NB, (unsigned)narrow.size()), dim3(256), 0, st,
+          DCORA_LAUNCH_MMA(k_small_w, dim3((mmax + NB - 1) / NB, (unsigned)narrow.size()), st,
                              img->pieces.p, dlist.p, dpoff.p, F, packed.p);
         DCORA_HIP(hipStreamSynchronize(st));  // dlist and narrow live on this frame
       }
@@ -1073,16 +1156,16 @@ int factor_on_device(const HostCsr &A, int block, int top, int device, bool *pd,
         hipLaunchKernelGGL(k_tri_inv64, dim3(nbk), dim3(256), 0, st, c, L11, f, tinv.p);
         DCORA_HIP(hipMemsetAsync(yt.p, 0, (size_t)c * c * sizeof(double), st));
         for (int ib = 0; ib < nbk; ++ib) {
-          hipLaunchKernelGGL(k_dense_trtri_finish, dim3(ib + 1), dim3(256), 0, st, c, ib, yt.p, tinv.p);
+          DCORA_LAUNCH_MMA(k_dense_trtri_finish, dim3(ib + 1), st, c, ib, yt.p, tinv.p);
           if (ib + 1 < nbk)
-            hipLaunchKernelGGL(k_dense_trtri_update, dim3(nbk - ib - 1, ib + 1), dim3(256), 0, st, c, ib, L11, f, yt.p);
+            DCORA_LAUNCH_MMA(k_dense_trtri_update, dim3(nbk - ib - 1, ib + 1), st, c, ib, L11, f, yt.p);
         }
         if (m > 0)
-          hipLaunchKernelGGL(k_piece_w, dim3((m + NB - 1) / NB, nbk), dim3(256), 0, st, c, m, L11 + (long long)c * f, f,
+          DCORA_LAUNCH_MMA(k_piece_w, dim3((m + NB - 1) / NB, nbk), st, c, m, L11 + (long long)c * f, f,
                              yt.p, wbuf.p);
         hipLaunchKernelGGL(k_piece_pack_inverted, dim3(std::min<long long>(4096, ((f * c) + 255) / 256)), dim3(256), 0,
                            st, c, m, yt.p, wbuf.p, packed.p + poff[s2]);
-        hipLaunchKernelGGL(k_dense_lauum, dim3(nbk * (nbk + 1) / 2), dim3(256), 0, st, c, yt.p, mtop.p + moff[s2], c);
+        DCORA_LAUNCH_MMA(k_dense_lauum, dim3(nbk * (nbk + 1) / 2), st, c, yt.p, mtop.p + moff[s2], c);
       }
       DCORA_HIP(hipGetLastError());
     }
@@ -1231,19 +1314,19 @@ int device_dense_spd_inverse(const HostCsr &A, int device, double *Minv, int ldm
                        fail.p, logdet.p, 1);
     if (rows > 0) {
       const int T = (rows + NB - 1) / NB;
-      hipLaunchKernelGGL(k_chol_trsm, dim3(T, 1), dim3(256), 0, st, piece.p, list.p, j0, L.p,
+      DCORA_LAUNCH_MMA(k_chol_trsm, dim3(T, 1), st, piece.p, list.p, j0, L.p,
                          linv.p + (size_t)p * NB * NB, fail.p);
-      hipLaunchKernelGGL(k_chol_syrk, dim3(T * (T + 1) / 2, 1), dim3(256), 0, st, piece.p, list.p, j0, L.p, fail.p);
+      DCORA_LAUNCH_MMA(k_chol_syrk, dim3(T * (T + 1) / 2, 1), st, piece.p, list.p, j0, j0 + NB, -1, 0, L.p, fail.p);
     }
   }
   // (a failed factorisation leaves garbage behind the flag: the products below are harmless, the caller drops Minv)
   for (int ib = 0; ib < nb; ++ib) {
-    hipLaunchKernelGGL(k_dense_trtri_finish, dim3(ib + 1), dim3(256), 0, st, k, ib, YT.p, linv.p);
+    DCORA_LAUNCH_MMA(k_dense_trtri_finish, dim3(ib + 1), st, k, ib, YT.p, linv.p);
     if (ib + 1 < nb)
-      hipLaunchKernelGGL(k_dense_trtri_update, dim3(nb - ib - 1, ib + 1), dim3(256), 0, st, k, ib, L.p, (long long)k,
+      DCORA_LAUNCH_MMA(k_dense_trtri_update, dim3(nb - ib - 1, ib + 1), st, k, ib, L.p, (long long)k,
                          YT.p);
   }
-  hipLaunchKernelGGL(k_dense_lauum, dim3(nb * (nb + 1) / 2), dim3(256), 0, st, k, YT.p, Minv, ldm);
+  DCORA_LAUNCH_MMA(k_dense_lauum, dim3(nb * (nb + 1) / 2), st, k, YT.p, Minv, ldm);
   DCORA_HIP(hipGetLastError());
   int failed = 0;
   DCORA_HIP(hipMemcpyAsync(&failed, fail.p, sizeof(int), hipMemcpyDeviceToHost, st));
