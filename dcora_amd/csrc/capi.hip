@@ -1334,6 +1334,65 @@ extern "C" int dcora_debug_partinv_selftest(int n, const int *rp, const int *ci,
   return DCORA_OK;
 }
 
+// debug / test hook (not part of the public header): the stored weights of the same matrix once written to host memory
+// in one piece and once STREAMED through a WeightSink in chunks of at most `cap` doubles (what the product does towards
+// the device, DeviceWeightSink) -- runs without a GPU.  out = {weights, chunks, weights that differ, largest chunk}
+extern "C" int dcora_debug_partinv_stream_check(int n, const int *rp, const int *ci, const double *v, int block,
+                                                long long cap, double *out) {
+  HostCsr A;
+  A.n = A.ncols = n;
+  A.rp.assign(rp, rp + n + 1);
+  A.ci.assign(ci, ci + rp[n]);
+  A.v.assign(v, v + rp[n]);
+  PartInvHost P, Q;
+  if (!build_partitioned_inverse(A, block, 4, &P)) return DCORA_ERR_NOT_PD;
+  struct HostSink : WeightSink {
+    std::vector<double> all, buf;
+    long long cap = 0, chunks = 0, largest = 0, expect = 0;
+    bool ordered = true, ended = false;
+    bool begin(long long total) override {
+      all.assign((size_t)total, -12345.0);  // a weight the sink never receives keeps this value
+      buf.resize((size_t)cap);
+      return true;
+    }
+    long long chunk_cap() const override { return cap; }
+    double *acquire(long long m) override {
+      if (m > cap) return nullptr;
+      std::fill(buf.begin(), buf.end(), 777.0);  // the builder must write (or zero) everything it commits
+      return buf.data();
+    }
+    bool commit(long long off, long long m) override {
+      ordered = ordered && off == expect;
+      expect = off + m;
+      ++chunks;
+      largest = std::max(largest, m);
+      std::copy(buf.begin(), buf.begin() + m, all.begin() + off);
+      return true;
+    }
+    bool end() override {
+      ended = true;
+      return true;
+    }
+  } sink;
+  sink.cap = cap;
+  Q.sink = &sink;
+  if (!build_partitioned_inverse(A, block, 3, &Q)) {
+    set_last_error("the streamed build failed (a fill larger than the chunk?)");
+    return DCORA_ERR_BAD_ARG;
+  }
+  long long differ = 0;
+  if ((long long)P.vals.size() != Q.nvals || !Q.vals.empty() || !sink.ordered || !sink.ended ||
+      sink.expect != Q.nvals)
+    differ = -1;
+  else
+    for (size_t i = 0; i < P.vals.size(); ++i) differ += std::memcmp(&P.vals[i], &sink.all[i], sizeof(double)) != 0;
+  out[0] = (double)Q.nvals;
+  out[1] = (double)sink.chunks;
+  out[2] = (double)differ;
+  out[3] = (double)sink.largest;
+  return DCORA_OK;
+}
+
 // measurement hook (bench.py, SURVEY 8(d): "verify with a stream-triad on the box"): a[i] = b[i] + s c[i] over three
 // arrays of n doubles, `reps` launches back to back between two HIP events; GB/s counts 24 n bytes per launch
 namespace {

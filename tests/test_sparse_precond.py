@@ -47,6 +47,29 @@ def test_schedule_on_the_range_aided_layout_and_scalar_blocks(built):
     assert rc == 0 and err < 1e-11
 
 
+@pytest.mark.parametrize("name,cap", [("smallGrid3D", 1 << 20), ("smallGrid3D", 3000), ("sphere2500", 50000),
+                                      ("pose_graph_optimization_test_2d", 4096)])
+def test_weights_streamed_in_chunks_equal_the_weights_written_in_one_piece(built, name, cap):
+    """the product never holds the stored weights on the host: write_weights hands them to a WeightSink in ascending
+    chunks (DeviceWeightSink forwards each to the device while the next is formed).  Here a host sink with a small
+    chunk collects them: every weight arrives exactly once, in order, bit-equal to the one-piece build, and padding
+    between fills arrives as zeros although the chunk memory is recycled dirty."""
+    import dcora_amd as da
+    from dcora_amd import capi
+    ds = common.product_dataset(name)
+    A = sp.csr_matrix(da.build_Q_pgo(ds).to_scipy() + 0.1 * sp.identity((ds.d + 1) * ds.n))
+    A.sort_indices()
+    rp, ci, v = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+    out = np.zeros(4)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    L = C.CDLL(capi.LIB_PATH)
+    rc = L.dcora_debug_partinv_stream_check(C.c_int(A.shape[0]), vp(rp), vp(ci), vp(v), C.c_int(ds.d + 1),
+                                            C.c_longlong(cap), vp(out))
+    assert rc == 0
+    assert out[0] > 0 and out[2] == 0, out
+    assert out[3] <= cap and out[1] >= np.ceil(out[0] / cap)
+
+
 def test_indefinite_matrix_is_reported(built):
     A = sp.diags([1.0, -1.0, 2.0]).tocsr()
     rc, err, info = _selftest(A, 1, 1)
