@@ -66,6 +66,28 @@ def test_ra_session_trace_matches_the_oracle_loop(env, name, r, accel, iters, re
     assert out["cost"][-1] < out["cost"][0]
 
 
+@pytest.mark.parametrize("inner,tol", [(3, 1e-10), (10, 1e-9)])
+def test_tiers_trace_is_tight_while_the_tcg_runs_are_short(env, inner, tol):
+    """the 5e-3 of the test above is conjugate gradients on cond(Q) ~ 1e6, not the loop: with the local solves capped
+    at 3 or 10 tCG iterations per trust-region step (same blocks, same restarts, same everything else) the session and
+    the oracle loop agree to 1e-12 over the same six iterations; runs of 50 iterations amplify the last-bit
+    differences of two summation orders to 1e-3 (measured: tools/dbg_tiers_trace.py)"""
+    da, orc = env
+    ra = da.RADataset(ra_path("tiers"))
+    r = 3
+    X0 = np.zeros((r, ra.k))
+    X0[:ra.d] = ra.X_odom
+    opt = dict(RTR_iterations=3, RTR_tCG_iterations=inner, gradnorm_tol=1e-2)
+    s = da.RaRbcdSession(ra, r, acceleration=True, restart_interval=4, params=da.ROptParameters(**opt))
+    s.set_X(X0)
+    out = s.run(max_iters=6, rgrad_tol=0.0)
+    Xo, tr = _oracle_loop(da, orc, ra, X0, r, 6, True, 4, opt)
+    assert np.array_equal(out["selected"], tr[:, 0].astype(int))
+    assert np.allclose(out["cost"], tr[:, 1], rtol=tol, atol=0.0), np.abs(out["cost"] - tr[:, 1]) / np.abs(tr[:, 1])
+    assert np.allclose(out["gradnorm"], tr[:, 2], rtol=1e-6)
+    assert common.rel(s.get_X(), Xo) < 1e-7
+
+
 @pytest.mark.parametrize("name", ["range_aided_slam_test_2d", "range_aided_slam_test_3d"])
 def test_ra_session_keeps_the_ground_truth_and_returns_to_it(env, name):
     """ref tests/testAgent.cpp:290-456 with the example's local parameters (RTR 200 x 200, tol 1e-4)"""
