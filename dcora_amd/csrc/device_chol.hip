@@ -66,62 +66,122 @@ __global__ __launch_bounds__(256) void k_chol_extend_add(const PieceDev *__restr
 //      the trailing update a rank-16 product over all threads; the inverse is four 16 x 16 inversions side by side
 //      (one per wave) and three rounds of 16 x 16 block products. ----
 // L: lower triangle in LDS, identity beyond the matrix' order; returns false (uniformly) on a non-positive pivot
-__device__ __forceinline__ bool blocked_potrf64(double (*L)[NB + 1], int *s_bad, double *rd) {
+// the value lane K of every 16-lane row holds, in all lanes of that row: DPP row_share (two 32-bit moves; a v_readlane
+// goes through an SGPR and pays the VALU -> SGPR -> VALU hazard on every use)
+template <int K>
+__device__ __forceinline__ double row_share_k(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, 0x150 + K, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x150 + K, 0xF, 0xF, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double row_share(double v, int k) {  // k: a constant once the caller's loops are unrolled
+  switch (k & 15) {
+    case 0: return row_share_k<0>(v);
+    case 1: return row_share_k<1>(v);
+    case 2: return row_share_k<2>(v);
+    case 3: return row_share_k<3>(v);
+    case 4: return row_share_k<4>(v);
+    case 5: return row_share_k<5>(v);
+    case 6: return row_share_k<6>(v);
+    case 7: return row_share_k<7>(v);
+    case 8: return row_share_k<8>(v);
+    case 9: return row_share_k<9>(v);
+    case 10: return row_share_k<10>(v);
+    case 11: return row_share_k<11>(v);
+    case 12: return row_share_k<12>(v);
+    case 13: return row_share_k<13>(v);
+    case 14: return row_share_k<14>(v);
+    default: return row_share_k<15>(v);
+  }
+}
+// 1 / sqrt(d) for a positive pivot: hardware estimate + two Newton steps (1-2 ulp, a dozen dependent instructions; the
+// IEEE division and square root are chains of about fifty each and sat on the critical path of every pivot)
+__device__ __forceinline__ double fast_rsqrt(double d) {
+  double y = __builtin_amdgcn_rsq(d);
+  y = y * fma(-0.5 * d * y, y, 1.5);
+  y = y * fma(-0.5 * d * y, y, 1.5);
+  return y;
+}
+__device__ __forceinline__ bool blocked_potrf64(double (*L)[NB + 1], int *s_bad, double *rd, double (*Dv)[16][17]) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if (tid == 0) *s_bad = 0;
   __syncthreads();
+#pragma unroll 1
   for (int j0 = 0; j0 < NB; j0 += 16) {
     if (wave == 0) {
-      // L D L^T elimination of the 16 x 16 block (no square root, one reciprocal and one wave barrier per column; the
-      // columns keep l_ij d_j until the end), then the scaling to L L^T by the whole wave
-      const int i = lane >> 2, kq = lane & 3;
+      // L D L^T elimination of the 16 x 16 block IN REGISTERS: lane i of every 16-lane row holds row i, the pivot and
+      // the entries of column j travel by DPP row_share (the loops are unrolled: every register and lane index is a
+      // constant) -- no LDS round trip, no barrier and no IEEE division per column.  The columns keep l_ij d_j until
+      // the end, then the scaling to L L^T.  All four rows of the wave compute the same thing; the first stores.
+      const int i = lane & 15;
+      double x[16], rdv[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) x[k] = (k <= i) ? L[j0 + i][j0 + k] : 0.0;
       bool bad = false;
+#pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const double d = L[j0 + j][j0 + j];  // the same word for every lane: the branch is uniform
-        if (!(d > 0.0)) {
-          bad = true;
-          break;
-        }
-        if (i > j) {
-          const double lij = L[j0 + i][j0 + j] * (1.0 / d);
-          for (int k = j + 1 + kq; k <= i; k += 4) L[j0 + i][j0 + k] -= lij * L[j0 + k][j0 + j];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        const double d = row_share(x[j], j);
+        bad = bad || !(d > 0.0);  // uniform
+        rdv[j] = fast_rsqrt(d);
+        const double lij = x[j] * (rdv[j] * rdv[j]);
+#pragma unroll
+        for (int k = j + 1; k < 16; ++k) x[k] -= lij * row_share(x[j], k);
       }
       if (bad) {
         if (lane == 0) *s_bad = 1;
       } else {
-        if (lane < 16) rd[j0 + lane] = 1.0 / sqrt(L[j0 + lane][j0 + lane]);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        for (int e = lane; e < 256; e += 64) {
-          const int a = e >> 4, c_ = e & 15;
-          if (c_ < a)
-            L[j0 + a][j0 + c_] *= rd[j0 + c_];
-          else if (c_ == a)
-            L[j0 + a][j0 + a] = sqrt(L[j0 + a][j0 + a]);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          // row i of the Cholesky factor of the block: l_ik = (l_ik d_k) / sqrt(d_k), l_ii = d_i / sqrt(d_i)
+          x[k] = (k <= i) ? x[k] * rdv[k] : 0.0;
+          if (lane == 0) rd[j0 + k] = rdv[k];
+          if (k <= i && lane < 16) L[j0 + i][j0 + k] = x[k];
         }
+        // the inverse of the block, column `i` by forward substitution in registers; factor(r_, l) is row r_ of lane r_.
+        // Kept for the panel below and for blocked_trtri64.
+        double y[16];
+#pragma unroll
+        for (int r_ = 0; r_ < 16; ++r_) {
+          double sacc = 0;
+#pragma unroll
+          for (int l = 0; l < 16; ++l)
+            if (l < r_) {
+              const double lrl = row_share(x[l], r_);
+              sacc += (l >= i) ? lrl * y[l] : 0.0;
+            }
+          y[r_] = (r_ == i) ? rdv[r_] : (r_ > i ? -sacc * rdv[r_] : 0.0);
+        }
+#pragma unroll
+        for (int r_ = 0; r_ < 16; ++r_)
+          if (lane < 16) Dv[j0 >> 4][r_][i] = y[r_];
       }
     }
     __syncthreads();
     if (*s_bad) return false;
     const int nrem = NB - j0 - 16;
     if (nrem > 0) {
-      // panel: row i of the rows below times D^-T, forward substitution along the row (reciprocal diagonal in rd)
-      if (tid < nrem) {
-        const int i = j0 + 16 + tid;
-        double x[16];
+      // panel: rows below times the transposed inverse of the block, X(a, k) = sum_{l <= k} B(a, l) Dinv(k, l); four
+      // threads per row (outputs k = q, q + 4, q + 8, q + 12), the row read before anyone overwrites it
+      double b[16], xo[4];
+      const int a = tid >> 2, q = tid & 3;
+      const bool on = a < nrem;
+      if (on) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          double sacc = L[i][j0 + k];
+        for (int l = 0; l < 16; ++l) b[l] = L[j0 + 16 + a][j0 + l];
 #pragma unroll
-          for (int l = 0; l < 16; ++l)
-            if (l < k) sacc -= x[l] * L[j0 + k][j0 + l];
-          x[k] = sacc * rd[j0 + k];
+        for (int u = 0; u < 4; ++u) {
+          const int k = q + 4 * u;
+          double sacc = 0;
+#pragma unroll
+          for (int l = 0; l < 16; ++l) sacc += (l <= k) ? b[l] * Dv[j0 >> 4][k][l] : 0.0;
+          xo[u] = sacc;
         }
+      }
+      __syncthreads();
+      if (on) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) L[i][j0 + k] = x[k];
+        for (int u = 0; u < 4; ++u) L[j0 + 16 + a][j0 + q + 4 * u] = xo[u];
       }
       __syncthreads();
       // trailing update of the lower triangle by the rank-16 product of the panel with itself
@@ -141,29 +201,16 @@ __device__ __forceinline__ bool blocked_potrf64(double (*L)[NB + 1], int *s_bad,
 }
 // Li = L^-1 (both lower triangular in LDS); Ts: 48 x 17 doubles of scratch
 __device__ __forceinline__ void blocked_trtri64(double (*L)[NB + 1], double (*Li)[NB + 1], double (*Ts)[17],
-                                                const double *rd /* 1 / L[k][k] */) {
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+                                                const double (*Dv)[16][17] /* inverses of the diagonal blocks */) {
+  const int tid = threadIdx.x;
   for (int e = tid; e < NB * NB; e += 256) {
     const int r_ = e >> 6, c_ = e & 63;
     if (c_ > r_ || (r_ >> 4) != (c_ >> 4)) Li[r_][c_] = 0.0;  // above the diagonal and the off-diagonal blocks
   }
-  {
-    // the diagonal block of this wave: column k by a group of 4 lanes (they share the sum over l)
-    const int j0 = 16 * wave, k = lane >> 2, kq = lane & 3;
-    if (kq == 0) Li[j0 + k][j0 + k] = rd[j0 + k];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (int r_ = 1; r_ < 16; ++r_) {
-      if (r_ > k) {
-        double sacc = 0;
-        for (int l = k + kq; l < r_; l += 4) sacc += L[j0 + r_][j0 + l] * Li[j0 + l][j0 + k];
-        sacc += __shfl_xor(sacc, 1);
-        sacc += __shfl_xor(sacc, 2);
-        if (kq == 0) Li[j0 + r_][j0 + k] = -sacc * rd[j0 + r_];
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
+  // the diagonal blocks' inverses come from the factorisation (blocked_potrf64)
+  for (int e = tid; e < 4 * 256; e += 256) {
+    const int bq = e >> 8, a = (e >> 4) & 15, c_ = e & 15;
+    if (c_ <= a) Li[16 * bq + a][16 * bq + c_] = Dv[bq][a][c_];
   }
   __syncthreads();
   // block (bi, bj), bi - bj = dist:  Li_ij = -Li_ii (sum_{bk = bj}^{bi - 1} L_i,bk Li_bk,j)
@@ -207,13 +254,14 @@ __global__ __launch_bounds__(256) void k_chol_potrf(const PieceDev *__restrict__
   __shared__ double Li[NB][NB + 1];
   __shared__ double Ts[48][17];
   __shared__ double rd[NB];
+  __shared__ double Dv[4][16][17];
   __shared__ int s_bad;
   const int tid = threadIdx.x;
   for (int e = tid; e < NB * NB; e += 256) {
     const int i = e >> 6, j = e & 63;
     L[i][j] = (i < jb && j <= i) ? M[(long long)i * f + j] : (i == j ? 1.0 : 0.0);
   }
-  if (!blocked_potrf64(L, &s_bad, rd)) {
+  if (!blocked_potrf64(L, &s_bad, rd, Dv)) {
     if (tid == 0) *fail = 1;
     return;
   }
@@ -228,7 +276,7 @@ __global__ __launch_bounds__(256) void k_chol_potrf(const PieceDev *__restrict__
     if (j <= r_) M[(long long)r_ * f + j] = L[r_][j];
   }
   if (!always_inv && P.m == 0 && j0 + jb >= P.c) return;  // nothing below the last panel of a root
-  blocked_trtri64(L, Li, Ts, rd);
+  blocked_trtri64(L, Li, Ts, Dv);
   double *__restrict__ O = Linv + (size_t)blockIdx.x * NB * NB;
   for (int e = tid; e < NB * NB; e += 256) O[e] = Li[e >> 6][e & 63];
 }

@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 o=gpurun_out/psdtr
 rm -rf $o; mkdir -p $o
-rocprofv3 --kernel-trace --stats --output-format csv -d $o -o t -- python3 tools/prof_psd.py lattice > $o/run.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $o -o t -- python3 tools/prof_psd.py ${1:-lattice} > $o/run.log 2>&1
 cat $o/run.log | grep rep
 f=$(ls $o/t_kernel_stats.csv $o/*/t_kernel_stats.csv 2>/dev/null | head -1)
 python3 - "$f" <<'PY'
