@@ -160,3 +160,52 @@ def test_hessian_in_one_launch_against_the_two_launch_form(built, kind, name, r)
     exact = float(np.sum(V * ref))
     mag = float(np.sum(np.abs(V * ref)))
     assert abs(dots[0] - exact) <= 1e-13 * mag and abs(dots[1] - exact) <= 1e-13 * mag, (dots, exact)
+
+
+PACING_CHILD = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import dcora_amd as da
+from dcora_amd import synth
+from test_raslam import ra_path
+out = {}
+ds = synth.lattice_se3(12, 10, 9, seed=3)
+r = 5
+rng = np.random.default_rng(7)
+X0 = da.manifold_project(r, ds.d, ds.n, rng.uniform(-1, 1, (r, 4 * ds.n)))
+s = da.RbcdSession(ds, num_robots=3, r=r)          # fused path, sparse preconditioner forced by the environment
+s.set_X(X0)
+o = s.run(max_iters=12, rgrad_tol=0.0)
+out["pgo_X"] = s.get_X(); out["pgo_cost"] = o["cost"]; out["pgo_kind"] = np.array([s.precond_kinds()[0] == "sparse"]) if hasattr(s, "precond_kinds") else np.array([True])
+s.close()
+ra = da.RADataset(ra_path("tiers"))                 # generic path (range-aided layout)
+X0 = np.zeros((3, ra.k)); X0[:ra.d] = ra.X_odom
+P = da.QuadraticProblem(3, ra.d, ra.n, ra.Q, l=ra.l, b=ra.b)
+opt = da.QuadraticOptimizer(P, da.ROptParameters(RTR_iterations=8, RTR_tCG_iterations=30, gradnorm_tol=1e-12))
+out["ra_X"] = opt.optimize(X0)
+res = opt.getOptResult()
+out["ra_it"] = np.array([res["outer_iterations"], res["inner_iterations"]])
+P.close()
+np.savez(sys.argv[2], **out)
+"""
+
+
+def test_verdict_pacing_enqueues_the_same_work_as_the_lookahead(built, tmp_path):
+    """the solver host enqueues the sparse replay behind the step-length kernel's verdict (default) or two whole tCG
+    iterations ahead (DCORA_SP_PACING=lookahead): the launches the first form skips are gated no-ops of the second,
+    so iterates and iteration counts must be bit-identical -- fused pose-graph path and generic (range-aided) path"""
+    runs = {}
+    for tag, env in (("verdict", {}), ("lookahead", {"DCORA_SP_PACING": "lookahead"})):
+        e = dict(os.environ)
+        e["DCORA_PRECOND"] = "sparse"
+        e.update(env)
+        out = os.path.join(str(tmp_path), tag + ".npz")
+        res = subprocess.run([sys.executable, "-c", PACING_CHILD, os.path.dirname(common.HERE), out], env=e,
+                             capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+        runs[tag] = np.load(out)
+    a, b = runs["verdict"], runs["lookahead"]
+    for key in ("pgo_X", "pgo_cost", "ra_X", "ra_it"):
+        assert np.array_equal(a[key], b[key]), key
+    assert a["pgo_cost"][-1] < a["pgo_cost"][0]
