@@ -1,7 +1,12 @@
 // Symbolic analysis for the multifrontal device Cholesky (device_chol.h) and a plain host executor of the same
 // schedule (validation only).  Setup-time code: once per sparsity pattern.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
+#include <vector>
 
 #include "device_chol.h"
 
@@ -14,7 +19,16 @@ void chol_symbolic(const HostCsr &A, int block, CholSymbolic *out, int top_unkno
   S.n = n;
   std::vector<int> cuts;
   int nhub = 0;
+  const bool timing = std::getenv("DCORA_INIT_TIMING") != nullptr;
+  auto tl = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[symbolic] %-22s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - tl).count());
+    tl = now;
+  };
   S.perm = amd_like_order(A, block, &cuts, &nhub, nullptr, 0, nullptr, top_unknowns);
+  lap("ordering");
   S.nhub = nhub;
   S.iperm.assign((size_t)n, 0);
   for (int i = 0; i < n; ++i) S.iperm[S.perm[i]] = i;
@@ -68,6 +82,7 @@ void chol_symbolic(const HostCsr &A, int block, CholSymbolic *out, int top_unkno
     const double c = P.c, m = P.m;
     S.flops += c * c * c / 3.0 + m * c * c + m * m * c;
   }
+  lap("piece structures");
   // fronts
   long long off = 0;
   for (CholPiece &P : S.pieces) {
@@ -96,25 +111,38 @@ void chol_symbolic(const HostCsr &A, int block, CholSymbolic *out, int top_unkno
       }
     }
   }
+  lap("fronts + positions");
   // scatter map of the entries of the lower triangle of P A P^T
   S.a_dest.assign((size_t)A.nnz(), -1);
-  for (int io = 0; io < n; ++io) {
-    const int i = S.iperm[io];
-    for (int p = A.rp[io]; p < A.rp[io + 1]; ++p) {
-      const int j = S.iperm[A.ci[p]];
-      if (i < j) continue;
-      const CholPiece &P = S.pieces[piece_of[j]];
-      const long long f = (long long)P.c + P.m;
-      long long li;
-      if (i < P.c0 + P.c) {
-        li = i - P.c0;
-      } else {
-        const int *r0 = &S.rows[(size_t)P.rows_off];
-        li = P.c + (std::lower_bound(r0, r0 + P.m, i) - r0);
+  {
+    // every entry on its own: the rows are shared out over the host's threads (6.2 M entries for the 100k lattice)
+    auto rows_range = [&](int lo, int hi) {
+      for (int io = lo; io < hi; ++io) {
+        const int i = S.iperm[io];
+        for (int p = A.rp[io]; p < A.rp[io + 1]; ++p) {
+          const int j = S.iperm[A.ci[p]];
+          if (i < j) continue;
+          const CholPiece &P = S.pieces[piece_of[j]];
+          const long long f = (long long)P.c + P.m;
+          long long li;
+          if (i < P.c0 + P.c) {
+            li = i - P.c0;
+          } else {
+            const int *r0 = &S.rows[(size_t)P.rows_off];
+            li = P.c + (std::lower_bound(r0, r0 + P.m, i) - r0);
+          }
+          S.a_dest[(size_t)p] = P.off + li * f + (j - P.c0);
+        }
       }
-      S.a_dest[(size_t)p] = P.off + li * f + (j - P.c0);
-    }
+    };
+    const int nt = n >= 20000 ? std::max(1, std::min(host_cpus_available(), 16)) : 1;
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t)
+      th.emplace_back(rows_range, (int)((long long)n * t / nt), (int)((long long)n * (t + 1) / nt));
+    rows_range(0, (int)((long long)n / nt));
+    for (auto &t : th) t.join();
   }
+  lap("scatter map");
   // schedule: pieces by level (widest first), children by level of the parent and position among the siblings
   std::vector<std::vector<int>> by_level((size_t)S.nlev);
   for (int s = 0; s < np; ++s) by_level[S.pieces[s].level].push_back(s);

@@ -403,6 +403,7 @@ std::vector<int> amd_like_order(const HostCsr &A, int block, std::vector<int> *p
   // top_unknowns unknowns (nd_top_default() for the replay; 0 for a plain factorisation, whose dense fronts would
   // only get more expensive); volume-like graphs, whose root separator alone is larger, keep the plain tree.
   int top_depth = 0;
+  bool have_plain = false;  // the probe below IS the final dissection when no dense top comes out of it
   {
     if (top_unknowns > 0 && (int)all.size() >= 16 * leaf_nodes) {
       std::vector<long> by_depth;
@@ -423,12 +424,21 @@ std::vector<int> amd_like_order(const HostCsr &A, int block, std::vector<int> *p
       // 96 / 192 / 384 unknowns: sphere2500 49 / 41 / 39 us, torus3D 89 / 75 / 74, tiers.pyfg 72 / 65 / 82,
       // an agent of the 100k lattice (two depths in the top) 169 / 190 / 235.
       if (top_depth >= 3 && std::getenv("DCORA_ND_LEAF") == nullptr) leaf_nodes *= 2;
+      if (top_depth == 0 && task_nodes == 0) {  // volume-like graph: the same recursion would run again (90 ms at k = 400 000)
+        comp_id.swap(comp0);
+        level.swap(level0);
+        border.swap(border0);
+        cuts.swap(cuts0);
+        next_cid = cid0;
+        have_plain = true;
+      }
       if (std::getenv("DCORA_FACTOR_TIMING"))
         std::fprintf(stderr, "[order] %d nodes: dense top of %d depths, leaves of %d nodes\n", (int)all.size(), top_depth,
                      leaf_nodes);
     }
   }
-  nd_recurse(G, all, comp_id, next_cid, level, border, cuts, leaf_nodes, task_nodes, tasks, waves, top_depth, nullptr);
+  if (!have_plain)
+    nd_recurse(G, all, comp_id, next_cid, level, border, cuts, leaf_nodes, task_nodes, tasks, waves, top_depth, nullptr);
   if (col_tasks) {
     col_tasks->clear();
     for (const auto &t : tasks)

@@ -525,7 +525,7 @@ double *pin_acquire() {
 void pin_release(double *p) {
   if (!p) return;
   std::lock_guard<std::mutex> lk(g_pin_mu);
-  if (g_pin_free.size() < 12) {
+  if (g_pin_free.size() < 6) {
     g_pin_free.push_back(p);
     return;
   }
