@@ -1416,7 +1416,10 @@ int build_partitioned_inverse_auto(const HostCsr &A, int block, int nthreads, in
     const char *e = std::getenv("DCORA_FACTOR");
     return e && std::strcmp(e, "host") == 0;
   }();
-  if (host_factor) return build_partitioned_inverse(A, block, nthreads, out) ? DCORA_OK : DCORA_ERR_NOT_PD;
+  if (host_factor) {
+    const bool okh = build_partitioned_inverse(A, block, nthreads, out);
+    return okh ? DCORA_OK : (out->weights_ok ? DCORA_ERR_NOT_PD : DCORA_ERR_HIP);
+  }
   PiecewiseFactor F;
   const auto t0 = std::chrono::steady_clock::now();
   const int rc = device_chol_piecewise_factor(A, block, nd_top_default(), device, &F);
@@ -1427,6 +1430,7 @@ int build_partitioned_inverse_auto(const HostCsr &A, int block, int nthreads, in
     fprintf(stderr, "[precond] factor on the device %.1f ms, partitioned inverse on the host %.1f ms\n",
             std::chrono::duration<double, std::milli>(t1 - t0).count(),
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
+  if (!ok && !out->weights_ok) return DCORA_ERR_HIP;  // the weight sink failed (device or pinned memory): not a verdict
   return ok ? DCORA_OK : DCORA_ERR_NOT_PD;
 }
 

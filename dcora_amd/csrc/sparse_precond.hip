@@ -573,9 +573,11 @@ double *DeviceWeightSink::acquire(long long n) {
   return pin[cur];
 }
 bool DeviceWeightSink::commit(long long off, long long n) {
-  if (hipMemcpyAsync(vals.p + off, pin[cur], (size_t)n * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
+  if (hipMemcpyAsync(vals.p + off, pin[cur], (size_t)n * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipEventRecord(ev[cur], st) != hipSuccess) {
+    set_last_error("sparse preconditioner: copying a chunk of stored weights to the device failed");
     return false;
-  if (hipEventRecord(ev[cur], st) != hipSuccess) return false;
+  }
   busy[cur] = true;
   return true;
 }
