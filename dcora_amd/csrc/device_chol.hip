@@ -960,6 +960,24 @@ int build_image(const HostCsr &A, int block, int top, int device, std::shared_pt
       }
     }
   }
+  if (const char *dump = std::getenv("DCORA_CHOL_PLAN_DUMP")) {  // kind list gx gy j0 kcap ccap ncb flop (syrk only)
+    if (FILE *fp = std::fopen(dump, "w")) {
+      for (const Launch &L : img->plan) {
+        double flop = 0;
+        if (L.kind == 3)
+          for (int q = 0; q < L.gy; ++q) {
+            const CholPiece &P = S.pieces[S.level_pieces[L.list + q]];
+            const double f = (double)P.c + P.m, base = std::min(L.kcap, P.c), K = base - L.j0;
+            if (K <= 0) continue;
+            const double colend = L.ccap >= 0 ? std::min((double)L.ccap, (double)P.c) : f;
+            const double w = std::max(0.0, colend - base);          // columns updated
+            flop += 2.0 * K * (w * (f - base) - 0.5 * w * w);       // rows >= column
+          }
+        std::fprintf(fp, "%d %d %d %d %d %d %d %d %.0f\n", L.kind, L.list, L.gx, L.gy, L.j0, L.kcap, L.ccap, L.ncb, flop);
+      }
+      std::fclose(fp);
+    }
+  }
   img->symbolic_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   DCORA_HIP(img->pieces.alloc(pd.size()));
   DCORA_HIP(hipMemcpy(img->pieces.p, pd.data(), pd.size() * sizeof(PieceDev), hipMemcpyHostToDevice));
