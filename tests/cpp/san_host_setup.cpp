@@ -25,5 +25,19 @@ int main(int argc,char**argv){
     // residual A Z^T = R^T
     double worst=0; for(int i=0;i<A.n;++i) for(int t=0;t<r;++t){ double s=0; for(int p=A.rp[i];p<A.rp[i+1];++p) s+=A.v[p]*Z[(size_t)A.ci[p]*r+t]; worst=std::max(worst,std::fabs(s-R[(size_t)i*r+t])); }
     printf("%s partinv ok %d levels %zu hub %d resid %.3e\n", argv[a], (int)ok, P.levels.size(), P.hub.h, worst);
+    // the same build with the stored weights streamed through a sink in small chunks of recycled (dirty) memory
+    struct Sink : WeightSink {
+      std::vector<double> all, buf; long long cap = 5000, expect = 0; bool ordered = true;
+      bool begin(long long total) override { all.assign((size_t)total, -1.0); buf.assign((size_t)cap, 7.0); return true; }
+      long long chunk_cap() const override { return cap; }
+      double *acquire(long long m) override { if (m > cap) return nullptr; std::fill(buf.begin(), buf.end(), 7.0); return buf.data(); }
+      bool commit(long long off, long long m) override { ordered = ordered && off == expect; expect = off + m; std::copy(buf.begin(), buf.begin() + m, all.begin() + off); return true; }
+      bool end() override { return true; }
+    } sink;
+    PartInvHost Q; Q.sink = &sink; bool ok2 = build_partitioned_inverse(A, block, 3, &Q);
+    long long differ = (long long)P.vals.size() != Q.nvals || !sink.ordered || sink.expect != Q.nvals;
+    if (!differ) for (size_t i = 0; i < P.vals.size(); ++i) differ += P.vals[i] != sink.all[i];
+    printf("%s streamed ok %d weights %lld differ %lld\n", argv[a], (int)ok2, Q.nvals, differ);
+    if (differ) return 3;
   }
 }

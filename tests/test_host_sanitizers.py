@@ -53,4 +53,4 @@ def test_host_setup_code_under_asan_ubsan(built, tmp_path):
     assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr[-2000:]
     resid = [float(x) for x in re.findall(r"resid ([0-9.eE+-]+)", out.stdout)]
     assert len(resid) == 3 and max(resid) < 1e-8, out.stdout
-    assert out.stdout.count("ok 1") == 9
+    assert out.stdout.count("ok 1") == 12 and out.stdout.count("differ 0") == 3, out.stdout
