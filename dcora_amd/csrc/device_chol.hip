@@ -21,6 +21,14 @@ namespace {
 constexpr int NB = kCholNb;
 constexpr int kEaRows = 8;  // rows of a child's Schur complement per workgroup of the extend-add
 
+// one piece of a batched inversion (blockIdx.z): offsets into the arrays the kernel is given
+struct InvJob {
+  int c, m;
+  long long l11, f;    // L11 inside the front arena, leading dimension of the front
+  long long yt, tinv;  // (L11^-1)^T (c x c) and the inverses of its 64 x 64 diagonal blocks
+  long long pk, mt;    // the packed panel; M = L11^-T L11^-1 (c x c) or -1
+};
+
 struct PieceDev {
   long long off;
   int c, m;
@@ -619,7 +627,15 @@ __global__ __launch_bounds__(256) void k_chol_syrk(const PieceDev *__restrict__ 
 //   update:  TT(j, i) += YT(j, ib) L(i, ib)^T for every block row i > ib and j <= ib  -- (nb - ib - 1)(ib + 1) tiles
 template <bool MMA>
 __global__ __launch_bounds__(256) void k_dense_trtri_finish(int k, int ib, double *__restrict__ YT,
-                                                            const double *__restrict__ Linv) {
+                                                            const double *__restrict__ Linv,
+                                                            const InvJob *__restrict__ jobs = nullptr) {
+  if (jobs) {
+    const InvJob J = jobs[blockIdx.z];
+    k = J.c;
+    YT += J.yt;
+    Linv += J.tinv;
+    if (ib * NB >= k) return;
+  }
   __shared__ double As[NB][NB + 1];
   __shared__ double Bs[NB][NB + 1];
   const int tid = threadIdx.x;
@@ -655,7 +671,16 @@ __global__ __launch_bounds__(256) void k_dense_trtri_finish(int k, int ib, doubl
 }
 template <bool MMA>
 __global__ __launch_bounds__(256) void k_dense_trtri_update(int k, int ib, const double *__restrict__ L, long long ldl,
-                                                            double *__restrict__ YT) {
+                                                            double *__restrict__ YT,
+                                                            const InvJob *__restrict__ jobs = nullptr) {
+  if (jobs) {
+    const InvJob J = jobs[blockIdx.z];
+    k = J.c;
+    L += J.l11;
+    ldl = J.f;
+    YT += J.yt;
+    if ((ib + 1 + (int)blockIdx.x) * NB >= k) return;
+  }
   __shared__ double As[NB][NB + 1];
   __shared__ double Bs[NB][NB + 1];
   const int i0 = (ib + 1 + blockIdx.x) * NB, j0 = blockIdx.y * NB, l0 = ib * NB;
@@ -710,7 +735,16 @@ __global__ __launch_bounds__(256) void k_dense_lauum(int k, const double *__rest
 //      W = -L21 L11^-1, and for pieces without rows below M = L11^-T L11^-1 ----
 // inverse of the 64 x 64 diagonal blocks of a lower-triangular matrix, one workgroup per block
 __global__ __launch_bounds__(256) void k_tri_inv64(int c, const double *__restrict__ L, long long ldl,
-                                                   double *__restrict__ Linv) {
+                                                   double *__restrict__ Linv,
+                                                   const InvJob *__restrict__ jobs = nullptr) {
+  if (jobs) {
+    const InvJob J = jobs[blockIdx.z];
+    c = J.c;
+    L += J.l11;
+    ldl = J.f;
+    Linv += J.tinv;
+    if ((int)blockIdx.x * NB >= c) return;
+  }
   __shared__ double T[NB][NB + 1];
   __shared__ double Li[NB][NB + 1];
   const int b0 = blockIdx.x * NB, nb = min(NB, c - b0);
@@ -740,7 +774,18 @@ __global__ __launch_bounds__(256) void k_tri_inv64(int c, const double *__restri
 // W(a, j) = -sum_{l >= j0} B(a, l) YT(j, l): tile (ta over the m rows below, tj over the c columns)
 template <bool MMA>
 __global__ __launch_bounds__(256) void k_piece_w(int c, int m, const double *__restrict__ B, long long ldb,
-                                                 const double *__restrict__ YT, double *__restrict__ W) {
+                                                 const double *__restrict__ YT, double *__restrict__ W,
+                                                 const InvJob *__restrict__ jobs = nullptr) {
+  if (jobs) {  // B: the front arena, W: the packed panels (rows [c, c + m) of the piece's panel are W)
+    const InvJob J = jobs[blockIdx.z];
+    c = J.c;
+    m = J.m;
+    B += J.l11 + (long long)J.c * J.f;
+    ldb = J.f;
+    YT += J.yt;
+    W += J.pk + (long long)J.c * J.c;
+    if ((int)blockIdx.x * NB >= m || (int)blockIdx.y * NB >= c) return;
+  }
   __shared__ double As[NB][NB + 1];
   __shared__ double Bs[NB][NB + 1];
   const int a0 = blockIdx.x * NB, j0 = blockIdx.y * NB;
@@ -761,7 +806,15 @@ __global__ __launch_bounds__(256) void k_piece_w(int c, int m, const double *__r
 }
 // panel of an inverted piece: rows [0, c) = L11^-1 (lower; = YT transposed), rows [c, c + m) = W
 __global__ __launch_bounds__(256) void k_piece_pack_inverted(int c, int m, const double *__restrict__ YT,
-                                                             const double *__restrict__ W, double *__restrict__ out) {
+                                                             const double *__restrict__ W, double *__restrict__ out,
+                                                             const InvJob *__restrict__ jobs = nullptr) {
+  if (jobs) {  // batched: W is already in place (k_piece_w wrote it into the panel), only L11^-1 is transposed in
+    const InvJob J = jobs[blockIdx.z];
+    c = J.c;
+    m = 0;
+    YT += J.yt;
+    out += J.pk;
+  }
   const long long n = (long long)(c + m) * c;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
     const int i = (int)(e / c), j = (int)(e - (long long)i * c);
@@ -1200,6 +1253,70 @@ int factor_on_device(const HostCsr &A, int block, int top, int device, bool *pd,
         DCORA_HIP(hipStreamSynchronize(st));  // dlist and narrow live on this frame
       }
     }
+    // the pieces in between (64 < c < 384: two thousand of them for the whole 100k lattice) in ONE batch of the
+    // right-looking kernels, a piece per blockIdx.z: 15 launches for all of them
+    std::vector<int> mid;
+    if (invert_on_device && S.nhub == 0 && !only_wide) {
+      std::vector<InvJob> jobs;
+      long long yt_total = 0, tinv_total = 0;
+      int nbkmax = 0, mmax = 0, cmax = 0;
+      for (int s2 = 0; s2 < np; ++s2) {
+        const CholPiece &P = S.pieces[s2];
+        if (P.c <= NB || P.c >= kWide) continue;
+        const int nbk = (P.c + NB - 1) / NB;
+        InvJob J;
+        J.c = P.c;
+        J.m = P.m;
+        J.l11 = P.off;
+        J.f = (long long)P.c + P.m;
+        J.yt = yt_total;
+        J.tinv = tinv_total;
+        J.pk = poff[s2];
+        J.mt = -1;
+        yt_total += (long long)P.c * P.c;
+        tinv_total += (long long)nbk * NB * NB;
+        nbkmax = std::max(nbkmax, nbk);
+        mmax = std::max(mmax, P.m);
+        cmax = std::max(cmax, P.c);
+        jobs.push_back(J);
+        mid.push_back(s2);
+      }
+      if (!jobs.empty()) {
+        const unsigned nj = (unsigned)jobs.size();
+        DevBuf<InvJob> djobs;
+        DevBuf<double> ytm, tinvm;
+        DCORA_HIP(djobs.alloc(jobs.size()));
+        DCORA_HIP(ytm.alloc((size_t)yt_total));
+        DCORA_HIP(tinvm.alloc((size_t)tinv_total));
+        DCORA_HIP(hipMemcpyAsync(djobs.p, jobs.data(), jobs.size() * sizeof(InvJob), hipMemcpyHostToDevice, st));
+        DCORA_HIP(hipMemsetAsync(ytm.p, 0, (size_t)yt_total * sizeof(double), st));
+        hipLaunchKernelGGL(k_tri_inv64, dim3(nbkmax, 1, nj), dim3(256), 0, st, 0, F, 0LL, tinvm.p, djobs.p);
+        for (int ib = 0; ib < nbkmax; ++ib) {
+          DCORA_LAUNCH_MMA(k_dense_trtri_finish, dim3(ib + 1, 1, nj), st, 0, ib, ytm.p, tinvm.p, djobs.p);
+          if (ib + 1 < nbkmax)
+            DCORA_LAUNCH_MMA(k_dense_trtri_update, dim3(nbkmax - ib - 1, ib + 1, nj), st, 0, ib, F, 0LL, ytm.p, djobs.p);
+        }
+        if (mmax > 0)
+          DCORA_LAUNCH_MMA(k_piece_w, dim3((mmax + NB - 1) / NB, nbkmax, nj), st, 0, 0, F, 0LL, ytm.p, packed.p, djobs.p);
+        hipLaunchKernelGGL(k_piece_pack_inverted, dim3(std::min(64, (cmax * cmax + 255) / 256), 1, nj), dim3(256), 0, st, 0,
+                           0, ytm.p, (const double *)nullptr, packed.p, djobs.p);
+        DCORA_HIP(hipGetLastError());
+        DCORA_HIP(hipStreamSynchronize(st));  // the job list and the scratch arenas live on this frame
+      }
+    }
+    if (init_timing) {
+      long cnt[3] = {0, 0, 0};
+      double vol[3] = {0, 0, 0}, c2[3] = {0, 0, 0};
+      for (int s2 = 0; s2 < np; ++s2) {
+        const CholPiece &P = S.pieces[s2];
+        const int b = P.c <= NB ? 0 : (P.c < kWide ? 1 : 2);
+        ++cnt[b];
+        vol[b] += (double)(P.c + P.m) * P.c;
+        c2[b] += (double)P.c * P.c;
+      }
+      fprintf(stderr, "[factor] pieces: narrow %ld (%.0f MB panels, %.0f MB c^2), mid %ld (%.0f MB, %.0f MB), wide %ld (%.0f MB, %.0f MB)\n",
+              cnt[0], vol[0] * 8e-6, c2[0] * 8e-6, cnt[1], vol[1] * 8e-6, c2[1] * 8e-6, cnt[2], vol[2] * 8e-6, c2[2] * 8e-6);
+    }
     if (invert_on_device && S.nhub == 0)
       for (int s2 = 0; s2 < np; ++s2)
         if (S.pieces[s2].c >= kWide) {
@@ -1284,6 +1401,7 @@ int factor_on_device(const HostCsr &A, int block, int top, int device, bool *pd,
     std::vector<char> is_wide((size_t)np, 0);
     for (int s2 : wide) is_wide[s2] = 1;
     for (int s2 : narrow) is_wide[s2] = 1;  // narrow pieces arrive inverted as well
+    for (int s2 : mid) is_wide[s2] = 1;     // and so do the ones in between
     PiecewiseFactor &W = *panels;
     W = PiecewiseFactor();
     W.n = S.n;
