@@ -703,7 +703,15 @@ __global__ __launch_bounds__(256) void k_dense_trtri_update(int k, int ib, const
 // M = Y^T Y = YT YT^T: tile (ta, tb), tb <= ta, sums over the columns l >= block ta; both triangles are written
 template <bool MMA>
 __global__ __launch_bounds__(256) void k_dense_lauum(int k, const double *__restrict__ YT, double *__restrict__ M,
-                                                     int ldm) {
+                                                     int ldm, const InvJob *__restrict__ jobs = nullptr) {
+  if (jobs) {
+    const InvJob J = jobs[blockIdx.z];
+    if (J.mt < 0) return;
+    k = J.c;
+    ldm = J.c;
+    YT += J.yt;
+    M += J.mt;
+  }
   __shared__ double As[NB][NB + 1];
   __shared__ double Bs[NB][NB + 1];
   int ta = (int)((sqrtf(8.0f * (float)blockIdx.x + 1.0f) - 1.0f) * 0.5f);
@@ -711,6 +719,7 @@ __global__ __launch_bounds__(256) void k_dense_lauum(int k, const double *__rest
   while (ta * (ta + 1) / 2 > (int)blockIdx.x) --ta;
   const int tb = blockIdx.x - ta * (ta + 1) / 2;
   const int a0 = ta * NB, b0 = tb * NB;
+  if (a0 >= k) return;  // (batched: the grid is sized for the widest piece)
   const int na = min(NB, k - a0), nb = min(NB, k - b0);
   double acc[4][4];
 #pragma unroll
@@ -827,7 +836,8 @@ __global__ __launch_bounds__(256) void k_piece_pack_inverted(int c, int m, const
 // group k as in k_tri_inv64
 __global__ __launch_bounds__(256) void k_small_inv(const PieceDev *__restrict__ pieces, const int *__restrict__ list,
                                                    const long long *__restrict__ panel_off,
-                                                   const double *__restrict__ F, double *__restrict__ out) {
+                                                   const double *__restrict__ F, double *__restrict__ out,
+                                                   const long long *__restrict__ m_off, double *__restrict__ Mout) {
   __shared__ double T[NB][NB + 1];
   __shared__ double Li[NB][NB + 1];
   const int s = list[blockIdx.x];
@@ -859,6 +869,15 @@ __global__ __launch_bounds__(256) void k_small_inv(const PieceDev *__restrict__ 
   for (int e = tid; e < c * c; e += 256) {
     const int i = e / c, j = e - i * c;
     O[e] = j <= i ? Li[i][j] : 0.0;
+  }
+  if (Mout) {  // M = L11^-T L11^-1, both triangles: M(a, b) = sum_{i >= max(a, b)} Li(i, a) Li(i, b), i ascending
+    double *__restrict__ Mo = Mout + m_off[s];
+    for (int e = tid; e < c * c; e += 256) {
+      const int a = e / c, b = e - a * c;
+      double sum = 0;
+      for (int i = max(a, b); i < c; ++i) sum += Li[i][a] * Li[i][b];
+      Mo[e] = sum;
+    }
   }
 }
 // rows [c, c + m) of the packed panel <- W = -L21 L11^-1: 64 rows below per workgroup (blockIdx.x), piece blockIdx.y
@@ -1234,6 +1253,20 @@ int factor_on_device(const HostCsr &A, int block, int top, int device, bool *pd,
     std::vector<int> wide, narrow;
     std::vector<long long> moff((size_t)np, -1);
     long long mtotal = 0;
+    // device sources (asked for by the caller whose weight sink fills on the device): every piece is inverted here, its
+    // M = L11^-T L11^-1 is formed here as well and stays here, like the panels
+    const bool dev_src = panels->want_device_sources && invert_on_device && S.nhub == 0 && !only_wide;
+    DevBuf<double> mall;
+    DevBuf<long long> dmoff;
+    if (dev_src) {
+      for (int s2 = 0; s2 < np; ++s2) {
+        moff[s2] = mtotal;
+        mtotal += (long long)S.pieces[s2].c * S.pieces[s2].c;
+      }
+      DCORA_HIP(mall.alloc((size_t)std::max<long long>(1, mtotal)));
+      DCORA_HIP(dmoff.alloc((size_t)np));
+      DCORA_HIP(hipMemcpyAsync(dmoff.p, moff.data(), (size_t)np * sizeof(long long), hipMemcpyHostToDevice, st));
+    }
     if (invert_on_device && S.nhub == 0 && !only_wide) {
       int mmax = 0;
       for (int s2 = 0; s2 < np; ++s2)
@@ -1246,7 +1279,7 @@ int factor_on_device(const HostCsr &A, int block, int top, int device, bool *pd,
         DCORA_HIP(dlist.alloc(narrow.size()));
         DCORA_HIP(hipMemcpyAsync(dlist.p, narrow.data(), narrow.size() * sizeof(int), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_small_inv, dim3((unsigned)narrow.size()), dim3(256), 0, st, img->pieces.p, dlist.p, dpoff.p, F,
-                           packed.p);
+                           packed.p, (const long long *)dmoff.p, dev_src ? mall.p : (double *)nullptr);
         if (mmax > 0)
           DCORA_LAUNCH_MMA(k_small_w, dim3((mmax + NB - 1) / NB, (unsigned)narrow.size()), st,
                              img->pieces.p, dlist.p, dpoff.p, F, packed.p);
@@ -1272,7 +1305,7 @@ int factor_on_device(const HostCsr &A, int block, int top, int device, bool *pd,
         J.yt = yt_total;
         J.tinv = tinv_total;
         J.pk = poff[s2];
-        J.mt = -1;
+        J.mt = dev_src ? moff[s2] : -1;
         yt_total += (long long)P.c * P.c;
         tinv_total += (long long)nbk * NB * NB;
         nbkmax = std::max(nbkmax, nbk);
@@ -1300,6 +1333,8 @@ int factor_on_device(const HostCsr &A, int block, int top, int device, bool *pd,
           DCORA_LAUNCH_MMA(k_piece_w, dim3((mmax + NB - 1) / NB, nbkmax, nj), st, 0, 0, F, 0LL, ytm.p, packed.p, djobs.p);
         hipLaunchKernelGGL(k_piece_pack_inverted, dim3(std::min(64, (cmax * cmax + 255) / 256), 1, nj), dim3(256), 0, st, 0,
                            0, ytm.p, (const double *)nullptr, packed.p, djobs.p);
+        if (dev_src)
+          DCORA_LAUNCH_MMA(k_dense_lauum, dim3(nbkmax * (nbkmax + 1) / 2, 1, nj), st, 0, ytm.p, mall.p, 0, djobs.p);
         DCORA_HIP(hipGetLastError());
         DCORA_HIP(hipStreamSynchronize(st));  // the job list and the scratch arenas live on this frame
       }
@@ -1323,10 +1358,12 @@ int factor_on_device(const HostCsr &A, int block, int top, int device, bool *pd,
           wide.push_back(s2);
           // L11^-T L11^-1 of every wide piece: the merged schedule (host_partinv2.cpp) applies the two triangular
           // products of a piece as this one symmetric product
-          moff[s2] = mtotal;
-          mtotal += (long long)S.pieces[s2].c * S.pieces[s2].c;
+          if (!dev_src) {
+            moff[s2] = mtotal;
+            mtotal += (long long)S.pieces[s2].c * S.pieces[s2].c;
+          }
         }
-    DevBuf<double> yt, wbuf, tinv, mtop;
+    DevBuf<double> yt, wbuf, tinv, mtop_own;
     if (!wide.empty()) {
       long long cmax = 0, wmax = 1;
       for (int s2 : wide) {
@@ -1336,7 +1373,7 @@ int factor_on_device(const HostCsr &A, int block, int top, int device, bool *pd,
       DCORA_HIP(yt.alloc((size_t)(cmax * cmax)));
       DCORA_HIP(wbuf.alloc((size_t)wmax));
       DCORA_HIP(tinv.alloc((size_t)((cmax + NB - 1) / NB) * NB * NB));
-      DCORA_HIP(mtop.alloc((size_t)std::max<long long>(1, mtotal)));
+      if (!dev_src) DCORA_HIP(mtop_own.alloc((size_t)std::max<long long>(1, mtotal)));
       for (int s2 : wide) {
         const CholPiece &P = S.pieces[s2];
         const int c = P.c, m = P.m, nbk = (c + NB - 1) / NB;
@@ -1354,7 +1391,7 @@ int factor_on_device(const HostCsr &A, int block, int top, int device, bool *pd,
                              yt.p, wbuf.p);
         hipLaunchKernelGGL(k_piece_pack_inverted, dim3(std::min<long long>(4096, ((f * c) + 255) / 256)), dim3(256), 0,
                            st, c, m, yt.p, wbuf.p, packed.p + poff[s2]);
-        DCORA_LAUNCH_MMA(k_dense_lauum, dim3(nbk * (nbk + 1) / 2), st, c, yt.p, mtop.p + moff[s2], c);
+        DCORA_LAUNCH_MMA(k_dense_lauum, dim3(nbk * (nbk + 1) / 2), st, c, yt.p, (dev_src ? mall.p : mtop_own.p) + moff[s2], c);
       }
       DCORA_HIP(hipGetLastError());
     }
@@ -1365,9 +1402,13 @@ int factor_on_device(const HostCsr &A, int block, int top, int device, bool *pd,
     // (2 MB-aligned and advised as huge pages: first touch and release of 3 GB in 4 KB pages cost 0.4 s each)
     struct HostBlock {
       double *panels = nullptr, *M = nullptr;
+      void *m_tokens = nullptr;  // reserved, unreadable addresses standing for the M that exist on the device only
+      size_t m_tokens_bytes = 0;
+      DevBuf<double> dev_panels, dev_M;  // device sources of a sink that fills on the device
       ~HostBlock() {
         std::free(panels);
         std::free(M);
+        if (m_tokens) munmap(m_tokens, m_tokens_bytes);
       }
     };
     auto huge_alloc = [](size_t doubles) -> double * {
@@ -1379,12 +1420,22 @@ int factor_on_device(const HostCsr &A, int block, int top, int device, bool *pd,
     };
     auto blk = std::make_shared<HostBlock>();
     blk->panels = huge_alloc((size_t)poff[np]);
-    blk->M = huge_alloc((size_t)mtotal);
-    if (!blk->panels || !blk->M) {
+    if (dev_src) {
+      blk->m_tokens_bytes = (size_t)std::max<long long>(1, mtotal) * sizeof(double);
+      void *tok = mmap(nullptr, blk->m_tokens_bytes, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+      if (tok == MAP_FAILED) {
+        set_last_error("sparse Cholesky: could not reserve the address range of the device-resident M");
+        return DCORA_ERR_HIP;
+      }
+      blk->m_tokens = tok;
+    } else {
+      blk->M = huge_alloc((size_t)mtotal);
+    }
+    if (!blk->panels || (!dev_src && !blk->M)) {
       set_last_error("sparse Cholesky: no host memory for the factor's panels");
       return DCORA_ERR_HIP;
     }
-    double *host = blk->panels, *hostM = blk->M;
+    double *host = blk->panels, *hostM = dev_src ? (double *)blk->m_tokens : blk->M;
     // non-zeros of the factor (reported as nnz(L)), counted where the factor is
     DevBuf<unsigned long long> dnz;
     DCORA_HIP(dnz.alloc(1));
@@ -1394,8 +1445,8 @@ int factor_on_device(const HostCsr &A, int block, int top, int device, bool *pd,
     DCORA_HIP(hipMemcpyAsync(&nz_dev, dnz.p, sizeof nz_dev, hipMemcpyDeviceToHost, st));
     lap("host buffers");
     DCORA_HIP(hipMemcpyAsync(host, packed.p, (size_t)poff[np] * sizeof(double), hipMemcpyDeviceToHost, st));
-    if (mtotal > 0)
-      DCORA_HIP(hipMemcpyAsync(hostM, mtop.p, (size_t)mtotal * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (mtotal > 0 && !dev_src)
+      DCORA_HIP(hipMemcpyAsync(hostM, mtop_own.p, (size_t)mtotal * sizeof(double), hipMemcpyDeviceToHost, st));
     DCORA_HIP(hipStreamSynchronize(st));
     lap("download");
     std::vector<char> is_wide((size_t)np, 0);
@@ -1421,6 +1472,13 @@ int factor_on_device(const HostCsr &A, int block, int top, int device, bool *pd,
       if (moff[s2] >= 0) pf.Mtop_view = hostM + moff[s2];
     }
     W.nnzL = (long)nz_dev;
+    if (dev_src) {
+      W.m_on_device_only = true;
+      W.mirrors.push_back(MirrorRange{host, (long long)poff[np], packed.p});
+      W.mirrors.push_back(MirrorRange{hostM, mtotal, mall.p});
+      blk->dev_panels = std::move(packed);
+      blk->dev_M = std::move(mall);
+    }
     lap("per-piece copies");
   }
   if (info6) {
@@ -1559,6 +1617,13 @@ int build_partitioned_inverse_auto(const HostCsr &A, int block, int nthreads, in
     return okh ? DCORA_OK : (out->weights_ok ? DCORA_ERR_NOT_PD : DCORA_ERR_HIP);
   }
   PiecewiseFactor F;
+  // a sink that forms the weights on the device wants the sources left there (merged schedule only: the per-level
+  // schedule computes some of its sources on the host)
+  static const bool schedule_v1 = [] {
+    const char *e = std::getenv("DCORA_SP_SCHEDULE");
+    return e && std::strcmp(e, "v1") == 0;
+  }();
+  F.want_device_sources = out->sink && out->sink->wants_device_sources() && !schedule_v1;
   const auto t0 = std::chrono::steady_clock::now();
   const int rc = device_chol_piecewise_factor(A, block, nd_top_default(), device, &F);
   if (rc) return rc;

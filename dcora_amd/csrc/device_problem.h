@@ -142,6 +142,9 @@ struct SpImage {
 struct DeviceWeightSink : WeightSink {
   explicit DeviceWeightSink(int device_) : device(device_) {}
   ~DeviceWeightSink() override;
+  bool fill_on_device(const std::vector<partinv::Fill> &fills, long long total, const std::vector<MirrorRange> &mirrors,
+                      int nthreads) override;
+  bool wants_device_sources() const override;
   bool begin(long long total) override;
   long long chunk_cap() const override { return kChunk; }
   double *acquire(long long n) override;

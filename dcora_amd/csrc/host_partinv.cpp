@@ -143,6 +143,8 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
   WeightSink *const sink = P.sink;  // the caller's choice survives the reset
   P = PartInvHost();
   P.sink = sink;
+  P.mirrors = F.mirrors;
+  P.sources_on_device_only = F.m_on_device_only;
   P.k = k;
   P.kfull = kfull;
   P.perm.assign(F.perm.begin(), F.perm.begin() + k);
@@ -696,6 +698,15 @@ inline void fill_one(const Fill &f, double *w) {
 
 bool write_weights(const std::vector<Fill> &fills, long long total, int nthreads, PartInvHost *P) {
   P->nvals = total;
+  if (P->sink && !P->mirrors.empty()) {
+    // the sources are on the device (the factor's panels, the pieces' M): the sink forms the weights there
+    if (P->sink->fill_on_device(fills, total, P->mirrors, nthreads)) {
+      P->vals.clear();
+      return true;
+    }
+    if (P->sources_on_device_only) return false;  // nothing on the host to fall back to
+  }
+  if (P->sources_on_device_only) return false;
   if (!P->sink) {
     std::vector<double> &vals = P->vals;
     vals.assign((size_t)total, 0.0);

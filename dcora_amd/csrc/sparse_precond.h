@@ -53,9 +53,29 @@ struct SpLevel {
   int cls[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 };
 
+// A host address range whose content also lives on the device (the factor's panels as the device factorisation left
+// them, the pieces' M = D^-T D^-1): the builder names its sources by host address, a sink that fills on the device
+// resolves them through these ranges.  `host` may be a reserved, unreadable range (the M of device-inverted pieces
+// never come to the host).
+struct MirrorRange {
+  const double *host = nullptr;
+  long long n = 0;
+  const double *dev = nullptr;
+};
+namespace partinv {
+struct Fill;
+}
+
 // Receiver of the stored weights of a schedule, in ascending chunks (write_weights, host_partinv.cpp)
 struct WeightSink {
   virtual ~WeightSink() = default;
+  // Optional: form ALL weights on the device from the fill records (sources resolved through `mirrors`, the others
+  // staged by the sink).  false: not supported / not applicable -- the caller streams chunks as below.
+  virtual bool fill_on_device(const std::vector<partinv::Fill> &, long long /*total*/,
+                              const std::vector<MirrorRange> & /*mirrors*/, int /*nthreads*/) {
+    return false;
+  }
+  virtual bool wants_device_sources() const { return false; }
   virtual bool begin(long long total) = 0;
   virtual long long chunk_cap() const = 0;                  // most weights one chunk may hold
   virtual double *acquire(long long n) = 0;                 // host memory for the next n <= chunk_cap() weights
@@ -90,6 +110,8 @@ struct PartInvHost {
   // set by the caller before the build: the stored weights are streamed there while they are formed and `vals` stays
   // empty (the product: the 6.8 GB of the whole 100k lattice never exist on the host); null: weights in `vals`
   struct WeightSink *sink = nullptr;
+  std::vector<MirrorRange> mirrors;  // device copies of the builder's sources (from the factor), for the sink
+  bool sources_on_device_only = false;  // some sources are NOT readable on the host: only a device fill can form the weights
   long long nvals = 0;  // number of stored weights, wherever they went
   bool weights_ok = true;  // false: the sink refused them
   std::vector<int> idxs;
@@ -124,6 +146,11 @@ struct PiecewiseFactor {
   std::vector<int> perm, iperm;
   std::vector<PieceFactor> pieces;
   std::shared_ptr<void> block;  // keeps the storage behind the pieces' views alive
+  // set by the caller BEFORE the factorisation: keep the panels and every piece's M on the device and describe them in
+  // `mirrors` (the M then exist on the device only: Mtop_view is an address, not data)
+  bool want_device_sources = false;
+  std::vector<MirrorRange> mirrors;
+  bool m_on_device_only = false;
 };
 void piecewise_from_chol(const SparseChol &chol, PiecewiseFactor *out);
 

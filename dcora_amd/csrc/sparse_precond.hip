@@ -6,9 +6,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "device_problem.h"
+#include "host_partinv_int.h"
 
 namespace dcora {
 
@@ -532,6 +534,167 @@ void pin_release(double *p) {
   (void)hipHostFree(p);
 }
 }  // namespace
+
+// ---- the stored weights formed ON THE DEVICE: a fill record names a tile of a source matrix (kinds of
+//      host_partinv_int.h); a wave per record writes the record's whole extent, zeros included ----
+namespace {
+struct DFill {
+  long long off, extent;
+  const double *src;
+  int kind, nrows, len, c, a0, m;
+  int loc[kSpTile];
+};
+__global__ __launch_bounds__(256) void k_fill_weights(long long nf, const DFill *__restrict__ fills,
+                                                      double *__restrict__ vals) {
+  const long long fi = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (fi >= nf) return;
+  const DFill F = fills[fi];
+  const int lane = threadIdx.x & 63;
+  double *__restrict__ w = vals + F.off;
+  const int nr = F.nrows, c = F.c, a0 = F.a0;
+  const long long n = (long long)F.len * nr;
+  const int jcap = min(F.len, c);
+  for (long long e = lane; e < F.extent; e += 64) {
+    double v = 0.0;
+    if (e < n) {
+      const int j = (int)(e / nr), q = (int)(e - (long long)j * nr);
+      const int lq = q == 0 ? F.loc[0] : q == 1 ? F.loc[1] : q == 2 ? F.loc[2] : F.loc[3];
+      switch (F.kind) {
+        case 0:
+          if (j < jcap && j <= a0 + q) v = F.src[(size_t)(a0 + q) * c + j];
+          break;
+        case 1:
+          if (j < jcap) v = F.src[(size_t)lq * c + j];
+          break;
+        case 2:
+          if (j < jcap) v = F.src[(size_t)(a0 + q) * c + j];
+          break;
+        case 3:
+          if (a0 + j < c && q <= j) v = F.src[(size_t)(a0 + j) * c + a0 + q];
+          break;
+        default:
+          if (j < F.m) v = F.src[(size_t)j * c + a0 + q];
+          break;
+      }
+    }
+    w[e] = v;
+  }
+}
+}  // namespace
+
+bool DeviceWeightSink::wants_device_sources() const {
+  static const bool host_fill = [] {
+    const char *e = std::getenv("DCORA_SP_FILL");
+    return e && std::strcmp(e, "host") == 0;
+  }();
+  return !host_fill;
+}
+
+bool DeviceWeightSink::fill_on_device(const std::vector<partinv::Fill> &fills, long long total,
+                                      const std::vector<MirrorRange> &mirrors, int nthreads) {
+  using partinv::Fill;
+  if (!wants_device_sources() || mirrors.empty()) return false;
+  if (hipSetDevice(device) != hipSuccess) return false;
+  const long long nf = (long long)fills.size();
+  // ascending order of the offsets (the builders lay the fills out that way; checked, not assumed)
+  std::vector<long long> order;
+  for (long long i = 1; i < nf; ++i)
+    if (fills[(size_t)i].off < fills[(size_t)i - 1].off) {
+      order.resize((size_t)nf);
+      for (long long q = 0; q < nf; ++q) order[(size_t)q] = q;
+      std::stable_sort(order.begin(), order.end(),
+                       [&](long long a, long long b) { return fills[(size_t)a].off < fills[(size_t)b].off; });
+      break;
+    }
+  auto at = [&](long long i) -> const Fill & { return fills[(size_t)(order.empty() ? i : order[(size_t)i])]; };
+  // sources: inside a mirrored range -> the device copy; anything else (merged products, compacted W of pieces with
+  // dropped rows) is staged: rows touched x columns of each distinct source, one upload
+  auto mirrored = [&](const double *b) -> const double * {
+    for (const MirrorRange &m : mirrors)
+      if (b >= m.host && b < m.host + m.n) return m.dev + (b - m.host);
+    return nullptr;
+  };
+  auto rows_touched = [](const Fill &f) -> long long {
+    switch (f.kind) {
+      case 0:
+      case 2: return (long long)f.a0 + f.nrows;
+      case 1: {
+        int mx = 0;
+        for (int q = 0; q < f.nrows; ++q) mx = std::max(mx, f.loc[q]);
+        return (long long)mx + 1;
+      }
+      case 3: return std::min<long long>((long long)f.a0 + f.len, f.c);
+      default: return std::min<long long>(f.len, f.m);
+    }
+  };
+  struct Staged {
+    long long doubles = 0, offset = 0;
+  };
+  std::unordered_map<const double *, Staged> staged;
+  for (const Fill &f : fills) {
+    if (f.len <= 0 || f.nrows <= 0 || mirrored(f.base)) continue;
+    Staged &sg = staged[f.base];
+    sg.doubles = std::max(sg.doubles, rows_touched(f) * (long long)f.c);
+  }
+  long long stage_total = 0;
+  std::vector<std::pair<const double *, Staged *>> slist;
+  for (auto &kv : staged) {
+    kv.second.offset = stage_total;
+    stage_total += (kv.second.doubles + 1) & ~1LL;
+    slist.emplace_back(kv.first, &kv.second);
+  }
+  DevBuf<double> dstage;
+  if (stage_total > 0) {
+    std::vector<double> hstage((size_t)stage_total);
+    partinv::parallel_for((int)slist.size(), std::max(1, nthreads), 4, [&](int i) {
+      std::copy(slist[(size_t)i].first, slist[(size_t)i].first + slist[(size_t)i].second->doubles,
+                hstage.begin() + slist[(size_t)i].second->offset);
+    });
+    if (dstage.alloc((size_t)stage_total) != hipSuccess ||
+        hipMemcpy(dstage.p, hstage.data(), (size_t)stage_total * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+      set_last_error("sparse preconditioner: staging the host-side sources of the weights failed");
+      return false;
+    }
+  }
+  std::vector<DFill> df((size_t)nf);
+  for (long long i = 0; i < nf; ++i) {
+    const Fill &f = at(i);
+    DFill &d = df[(size_t)i];
+    d.off = f.off;
+    d.extent = (i + 1 < nf ? at(i + 1).off : total) - f.off;
+    const double *dev = (f.len > 0 && f.nrows > 0) ? mirrored(f.base) : nullptr;
+    if (!dev && f.len > 0 && f.nrows > 0) dev = dstage.p + staged[f.base].offset;
+    d.src = dev;
+    d.kind = f.kind;
+    d.nrows = std::max(1, f.nrows);
+    d.len = dev ? f.len : 0;
+    d.c = f.c;
+    d.a0 = f.a0;
+    d.m = f.m;
+    for (int q = 0; q < kSpTile; ++q) d.loc[q] = f.loc[q];
+  }
+  if (vals.alloc((size_t)std::max<long long>(2, total)) != hipSuccess) {
+    set_last_error("sparse preconditioner: no device memory for the stored weights");
+    return false;
+  }
+  const long long head = nf ? df[0].off : std::max<long long>(2, total);  // weights in front of the first fill
+  DevBuf<DFill> ddf;
+  if (nf > 0 && (ddf.alloc((size_t)nf) != hipSuccess ||
+                 hipMemcpy(ddf.p, df.data(), (size_t)nf * sizeof(DFill), hipMemcpyHostToDevice) != hipSuccess))
+    return false;
+  hipStream_t fs = nullptr;
+  if (stream_acquire(device, &fs) != DCORA_OK) return false;
+  bool ok = true;
+  if (head > 0) ok = hipMemsetAsync(vals.p, 0, (size_t)head * sizeof(double), fs) == hipSuccess;
+  if (ok && nf > 0) {
+    hipLaunchKernelGGL(k_fill_weights, dim3((unsigned)((nf + 3) / 4)), dim3(256), 0, fs, nf, ddf.p, vals.p);
+    ok = hipGetLastError() == hipSuccess;
+  }
+  ok = ok && hipStreamSynchronize(fs) == hipSuccess;
+  stream_release(device, fs);
+  if (!ok) set_last_error("sparse preconditioner: forming the stored weights on the device failed");
+  return ok;
+}
 
 DeviceWeightSink::~DeviceWeightSink() {
   if (st) {
