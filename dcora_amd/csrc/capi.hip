@@ -259,6 +259,31 @@ int dcora_problem_precond_info(dcora_problem_t p, double *info) {
   return DCORA_OK;
 }
 
+// debug / test hook (not part of the public header): a digest of the stored weights of a problem's sparse
+// preconditioner image, read back from the device: {count, sum, sum of |w|, sum of w (i mod 97 + 1)} -- the last one
+// moves when a weight lands in another place.  Compares the ways the weights can be formed (device fill, streamed host
+// fill, one-piece upload).
+extern "C" int dcora_debug_sparse_weights_digest(dcora_problem_t p, double *out4) {
+  if (!p || !out4) return bad("null");
+  const DeviceProblem &P = p->p;
+  if (!P.sparse_precond || !P.sp.im) return bad("the problem has no sparse preconditioner");
+  const DevBuf<double> &v = P.sp.im->vals;
+  std::vector<double> h(v.n);
+  DCORA_HIP(hipSetDevice(P.device));
+  DCORA_HIP(hipMemcpy(h.data(), v.p, v.n * sizeof(double), hipMemcpyDeviceToHost));
+  long double s0 = 0, s1 = 0, s2 = 0;
+  for (size_t i = 0; i < h.size(); ++i) {
+    s0 += h[i];
+    s1 += std::fabs(h[i]);
+    s2 += h[i] * (double)(i % 97 + 1);
+  }
+  out4[0] = (double)h.size();
+  out4[1] = (double)s0;
+  out4[2] = (double)s1;
+  out4[3] = (double)s2;
+  return DCORA_OK;
+}
+
 // A CERTIFIED lower bound of the smallest eigenvalue of a matrix the PSD test has accepted.  Lanczos (full
 // re-orthogonalisation) on M^-1, M = S + eta I, through the sparse Cholesky factor the test computes (host), gives a
 // Ritz value theta <= theta_max(M^-1) -- so 1 / theta - eta errs UPWARD and is only an estimate.  The candidate bound

@@ -209,3 +209,50 @@ def test_verdict_pacing_enqueues_the_same_work_as_the_lookahead(built, tmp_path)
     for key in ("pgo_X", "pgo_cost", "ra_X", "ra_it"):
         assert np.array_equal(a[key], b[key]), key
     assert a["pgo_cost"][-1] < a["pgo_cost"][0]
+
+
+WEIGHTS_CHILD = r"""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import common
+import dcora_amd as da
+from dcora_amd import capi, synth
+L = C.CDLL(capi.LIB_PATH)
+out = {}
+for name, ds in (("lattice", synth.lattice_se3(14, 12, 10, seed=9)), ("sphere", common.product_dataset("sphere2500"))):
+    Q = da.build_Q_pgo(ds)
+    P = da.QuadraticProblem(5, ds.d, ds.n, Q, reg=0.1)
+    d = np.zeros(4)
+    assert L.dcora_debug_sparse_weights_digest(P.h, d.ctypes.data_as(C.c_void_p)) == 0
+    out[name] = d
+    rng = np.random.default_rng(2)
+    X = da.manifold_project(5, ds.d, ds.n, rng.standard_normal((5, (ds.d + 1) * ds.n)))
+    out[name + "_z"] = P.PreCondition(X, P.RieGrad(X))
+    P.close()
+np.savez(sys.argv[2], **out)
+"""
+
+
+def test_weights_formed_on_the_device_equal_the_weights_formed_on_the_host(built, tmp_path):
+    """the stored weights of the sparse preconditioner formed by k_fill_weights from device-resident sources (default),
+    by the host's threads streamed in chunks (DCORA_SP_FILL=host) and by the host in one piece (DCORA_SP_WEIGHTS=host):
+    same count, same place for every weight (position-weighted sum), values to the rounding of M = D^-T D^-1 computed
+    by the device's tile products instead of the host's loops; the preconditioned vectors agree to 1e-12"""
+    runs = {}
+    for tag, env in (("device", {}), ("streamed", {"DCORA_SP_FILL": "host"}), ("one_piece", {"DCORA_SP_WEIGHTS": "host"})):
+        e = dict(os.environ)
+        e["DCORA_PRECOND"] = "sparse"
+        e.update(env)
+        out = os.path.join(str(tmp_path), tag + ".npz")
+        res = subprocess.run([sys.executable, "-c", WEIGHTS_CHILD, os.path.dirname(common.HERE), out], env=e,
+                             capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+        runs[tag] = np.load(out)
+    for name in ("lattice", "sphere"):
+        a, b, c = runs["device"][name], runs["streamed"][name], runs["one_piece"][name]
+        assert np.array_equal(b, c), (name, b, c)                      # the two host fills: the same arithmetic
+        assert a[0] == b[0] and a[0] > 1000, (name, a, b)
+        assert np.allclose(a[1:], b[1:], rtol=1e-11, atol=1e-11 * a[2]), (name, a, b)
+        for tag in ("streamed", "one_piece"):
+            assert common.rel(runs["device"][name + "_z"], runs[tag][name + "_z"]) < 1e-12, (name, tag)
