@@ -110,6 +110,9 @@ int RbcdSession::init(const HostDataset &ds, const dcora_rbcd_options &o) {
   DCORA_HIP(evalbuf.alloc(2 * R + 16));
   DCORA_HIP(hipMemset(evalbuf.p, 0, sizeof(double) * (2 * R + 16)));
 
+  if (std::getenv("DCORA_INIT_TIMING"))
+    fprintf(stderr, "[session] buffers after %.1f ms\n",
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   // partition (ref examples/MultiRobotExample.cpp:56-118)
   std::vector<std::vector<PoseMeas>> touching(R);
   std::vector<std::set<int>> pub(R), nb(R), req(R);
@@ -173,6 +176,23 @@ int RbcdSession::init(const HostDataset &ds, const dcora_rbcd_options &o) {
     if (rc && err) *err = dcora_last_error();
     return rc;
   };
+  // the whole-graph problem of the evaluation (Q of all poses, no preconditioner) depends on none of the agents: its
+  // assembly (0.15 s of one host thread for the 100k lattice) and upload run beside the agents' builds
+  int central_rc = DCORA_OK;
+  std::string central_err;
+  auto build_central = [&]() {
+    if (o.world_size != 1) return;
+    if (hipSetDevice(o.device) != hipSuccess) {
+      central_rc = DCORA_ERR_HIP;
+      central_err = "hipSetDevice failed";
+      return;
+    }
+    HostCsr Qc = build_Q_pgo(d, n, 0, global);
+    central.reset(new DeviceProblem);
+    dcora_dims dims{r, d, n, 0, 0};
+    central_rc = central->init(dims, Qc, nullptr, -1.0, o.device, st);
+    if (central_rc) central_err = dcora_last_error();
+  };
   {
     const size_t nh = hosted_ids.size();
     std::vector<int> rcs(nh, DCORA_OK);
@@ -189,11 +209,13 @@ int RbcdSession::init(const HostDataset &ds, const dcora_rbcd_options &o) {
         }
       };
       std::vector<std::thread> th;
+      th.emplace_back(build_central);
       for (size_t t = 1; t < std::min<size_t>(nh, 8); ++t) th.emplace_back(worker);
       worker();
       for (std::thread &t : th) t.join();
     } else {
       for (size_t i = 0; i < nh; ++i) rcs[i] = build_agent(hosted_ids[i], &errs[i]);
+      build_central();
     }
     for (size_t i = 0; i < nh; ++i)
       if (rcs[i]) {
@@ -201,6 +223,10 @@ int RbcdSession::init(const HostDataset &ds, const dcora_rbcd_options &o) {
         return rcs[i];
       }
   }
+  const bool init_timing = std::getenv("DCORA_INIT_TIMING") != nullptr;
+  if (init_timing)
+    fprintf(stderr, "[session] agents built after %.1f ms\n",
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   DCORA_HIP(hipEventCreateWithFlags(&fork_ev_, hipEventDisableTiming));
   cs[R] = dh * n;
   {
@@ -211,13 +237,13 @@ int RbcdSession::init(const HostDataset &ds, const dcora_rbcd_options &o) {
   }
   DCORA_HIP(col_start.alloc(R + 1));
   DCORA_HIP(hipMemcpy(col_start.p, cs.data(), sizeof(int) * (R + 1), hipMemcpyHostToDevice));
-  if (o.world_size == 1) {
-    HostCsr Qc = build_Q_pgo(d, n, 0, global);
-    central.reset(new DeviceProblem);
-    dcora_dims dims{r, d, n, 0, 0};
-    int rc = central->init(dims, Qc, nullptr, -1.0, o.device, st);
-    if (rc) return rc;
+  if (central_rc) {
+    set_last_error(central_err);
+    return central_rc;
   }
+  if (init_timing)
+    fprintf(stderr, "[session] ready after %.1f ms\n",
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   iteration = 0;
   gamma = alpha = 0;
   setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
