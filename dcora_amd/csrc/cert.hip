@@ -163,27 +163,77 @@ int DeviceLanczos::largest_magnitude(double shift, int ncv, int maxit, double to
   int k = 0;
   double beta = 0;
   std::vector<int> ord(m);
-  for (int it = 0; it <= maxit; ++it) {
-    for (int j = k; j < m; ++j) {
-      double *vj = V.p + (size_t)j * n;
-      if (op) {
-        const int orc = op(vj, w.p);
-        if (orc) return orc;
-        if (shift != 0) launch_scale_shift(st, n, shift, vj, w.p);
-      } else if (inverse_op) {
-        inverse_op->apply(st, 1, buf1(vj), w.p, Gate{});
-      } else {
-        launch_spmm(st, 1, Sv, buf1(vj), 0, nullptr, buf1(w.p), 0, nullptr, Gate{});
-        if (shift != 0) launch_scale_shift(st, n, shift, vj, w.p);
-      }
-      out->matvecs++;
-      const int nv = j + 1;
+  // One Lanczos step = matvec, two passes of projection against the whole basis, the norm, the next vector.  The slow
+  // form reads the coefficients and the norm back after every step (needed when the sums go over ranks, and to handle a
+  // vanishing norm); the fast form keeps them on the device -- the subtraction sums the projection's partials in its
+  // prologue, the next vector is scaled by the kernel that sums <w, w> -- and the host reads a whole restart cycle's
+  // coefficients at once: 8 launches and no host round trip per step instead of 11 launches, two copies and a wait.
+  static const bool lanczos_slow = [] {
+    const char *e = std::getenv("DCORA_LANCZOS");
+    return e && std::string(e) == "sync";
+  }();
+  const bool fast = !rows && !lanczos_slow;
+  DevBuf<double> hdev, bdev;
+  DevBuf<int> fdev;
+  if (fast) {
+    DCORA_HIP(hdev.alloc((size_t)m * 64));
+    DCORA_HIP(bdev.alloc((size_t)m));
+    DCORA_HIP(fdev.alloc(1));
+    DCORA_HIP(hipMemsetAsync(fdev.p, 0, sizeof(int), st));
+  }
+  auto matvec = [&](int j) -> int {
+    double *vj = V.p + (size_t)j * n;
+    if (op) {
+      const int orc = op(vj, w.p);
+      if (orc) return orc;
+      if (shift != 0) launch_scale_shift(st, n, shift, vj, w.p);
+    } else if (inverse_op) {
+      inverse_op->apply(st, 1, buf1(vj), w.p, Gate{});
+    } else {
+      launch_spmm(st, 1, Sv, buf1(vj), 0, nullptr, buf1(w.p), 0, nullptr, Gate{});
+      if (shift != 0) launch_scale_shift(st, n, shift, vj, w.p);
+    }
+    out->matvecs++;
+    return DCORA_OK;
+  };
+  auto slow_step = [&](int j) -> int {
+    int orc = matvec(j);
+    if (orc) return orc;
+    const int nv = j + 1;
+    for (int pass = 0; pass < 2; ++pass) {
+      launch_lanczos_proj(st, n, nv, V.p, w.p, part.p);
+      launch_sum_partials(st, part.p, npart, 24, nv, small.p + 32 * pass);
+      const int rrc = reduce_dev(small.p + 32 * pass, nv);
+      if (rrc) return rrc;
+      launch_lanczos_sub(st, n, nv, V.p, small.p + 32 * pass, w.p);
+    }
+    launch_dot(st, n, w.p, w.p, part.p);
+    launch_sum_partials(st, part.p, npart, 1, 1, small.p + 64);
+    {
+      const int rrc = reduce_dev(small.p + 64, 1);
+      if (rrc) return rrc;
+    }
+    DCORA_HIP(hipMemcpyAsync(hbuf.data(), small.p, sizeof(double) * 64, hipMemcpyDeviceToHost, st));
+    double b2 = 0;
+    DCORA_HIP(hipMemcpyAsync(&b2, small.p + 64, sizeof(double), hipMemcpyDeviceToHost, st));
+    DCORA_HIP(hipStreamSynchronize(st));
+    for (int i = 0; i < nv; ++i) {
+      const double h = hbuf[i] + hbuf[32 + i];
+      H[(size_t)i * m + j] = h;
+      H[(size_t)j * m + i] = h;
+    }
+    beta = std::sqrt(b2);
+    if (beta < 1e-300) {
+      // invariant subspace: continue with a fresh random direction orthogonalised against the basis
+      double unused = 0;
+      whole_vector(seed + 7919 * (j + 1), nullptr, &unused);
+      DCORA_HIP(hipMemcpyAsync(w.p, host_v.data(), sizeof(double) * n, hipMemcpyHostToDevice, st));
       for (int pass = 0; pass < 2; ++pass) {
         launch_lanczos_proj(st, n, nv, V.p, w.p, part.p);
-        launch_sum_partials(st, part.p, npart, 24, nv, small.p + 32 * pass);
-        const int rrc = reduce_dev(small.p + 32 * pass, nv);
+        launch_sum_partials(st, part.p, npart, 24, nv, small.p);
+        const int rrc = reduce_dev(small.p, nv);
         if (rrc) return rrc;
-        launch_lanczos_sub(st, n, nv, V.p, small.p + 32 * pass, w.p);
+        launch_lanczos_sub(st, n, nv, V.p, small.p, w.p);
       }
       launch_dot(st, n, w.p, w.p, part.p);
       launch_sum_partials(st, part.p, npart, 1, 1, small.p + 64);
@@ -191,39 +241,72 @@ int DeviceLanczos::largest_magnitude(double shift, int ncv, int maxit, double to
         const int rrc = reduce_dev(small.p + 64, 1);
         if (rrc) return rrc;
       }
-      DCORA_HIP(hipMemcpyAsync(hbuf.data(), small.p, sizeof(double) * 64, hipMemcpyDeviceToHost, st));
-      double b2 = 0;
-      DCORA_HIP(hipMemcpyAsync(&b2, small.p + 64, sizeof(double), hipMemcpyDeviceToHost, st));
+      launch_scale(st, n, small.p + 64, w.p, V.p + (size_t)(j + 1) * n);
       DCORA_HIP(hipStreamSynchronize(st));
-      for (int i = 0; i < nv; ++i) {
-        const double h = hbuf[i] + hbuf[32 + i];
-        H[(size_t)i * m + j] = h;
-        H[(size_t)j * m + i] = h;
-      }
-      beta = std::sqrt(b2);
-      if (beta < 1e-300) {
-        // invariant subspace: continue with a fresh random direction orthogonalised against the basis
-        double unused = 0;
-        whole_vector(seed + 7919 * (j + 1), nullptr, &unused);
-        DCORA_HIP(hipMemcpyAsync(w.p, host_v.data(), sizeof(double) * n, hipMemcpyHostToDevice, st));
-        for (int pass = 0; pass < 2; ++pass) {
-          launch_lanczos_proj(st, n, nv, V.p, w.p, part.p);
-          launch_sum_partials(st, part.p, npart, 24, nv, small.p);
-          const int rrc = reduce_dev(small.p, nv);
-          if (rrc) return rrc;
-          launch_lanczos_sub(st, n, nv, V.p, small.p, w.p);
-        }
-        launch_dot(st, n, w.p, w.p, part.p);
-        launch_sum_partials(st, part.p, npart, 1, 1, small.p + 64);
-        {
-          const int rrc = reduce_dev(small.p + 64, 1);
-          if (rrc) return rrc;
-        }
-        launch_scale(st, n, small.p + 64, w.p, V.p + (size_t)(j + 1) * n);
-        DCORA_HIP(hipStreamSynchronize(st));
-        beta = 0;
+      beta = 0;
+    } else {
+      launch_axpby(st, n, 1.0 / beta, w.p, 0.0, nullptr, V.p + (size_t)(j + 1) * n);
+    }
+    return DCORA_OK;
+  };
+  auto fast_step = [&](int j) -> int {
+    const int orc = matvec(j);
+    if (orc) return orc;
+    const int nv = j + 1;
+    for (int pass = 0; pass < 2; ++pass) {
+      double *hout = hdev.p + (size_t)j * 64 + 32 * pass;
+      launch_lanczos_proj(st, n, nv, V.p, w.p, part.p);
+      if (npart <= kLanczosFuseParts) {
+        launch_lanczos_sub_sum(st, n, nv, V.p, part.p, npart, hout, w.p);
       } else {
-        launch_axpby(st, n, 1.0 / beta, w.p, 0.0, nullptr, V.p + (size_t)(j + 1) * n);
+        launch_sum_partials(st, part.p, npart, 24, nv, small.p + 32 * pass);
+        launch_lanczos_keep(st, nv, small.p + 32 * pass, hout);
+        launch_lanczos_sub(st, n, nv, V.p, small.p + 32 * pass, w.p);
+      }
+    }
+    launch_dot(st, n, w.p, w.p, part.p);
+    launch_lanczos_next(st, n, part.p, npart, bdev.p + j, fdev.p, w.p, V.p + (size_t)(j + 1) * n);
+    return DCORA_OK;
+  };
+  for (int it = 0; it <= maxit; ++it) {
+    if (!fast) {
+      for (int j = k; j < m; ++j) {
+        const int src = slow_step(j);
+        if (src) return src;
+      }
+    } else {
+      for (int j = k; j < m; ++j) {
+        const int frc = fast_step(j);
+        if (frc) return frc;
+      }
+      std::vector<double> hh((size_t)m * 64), bb((size_t)m);
+      int dead = 0;
+      DCORA_HIP(hipMemcpyAsync(hh.data(), hdev.p, sizeof(double) * hh.size(), hipMemcpyDeviceToHost, st));
+      DCORA_HIP(hipMemcpyAsync(bb.data(), bdev.p, sizeof(double) * bb.size(), hipMemcpyDeviceToHost, st));
+      DCORA_HIP(hipMemcpyAsync(&dead, fdev.p, sizeof(int), hipMemcpyDeviceToHost, st));
+      DCORA_HIP(hipStreamSynchronize(st));
+      int jdead = m;
+      if (dead)
+        for (int j = k; j < m; ++j)
+          if (!(bb[(size_t)j] >= 1e-300)) {
+            jdead = j;
+            break;
+          }
+      for (int j = k; j < jdead; ++j) {
+        for (int i = 0; i <= j; ++i) {
+          const double h = hh[(size_t)j * 64 + i] + hh[(size_t)j * 64 + 32 + i];
+          H[(size_t)i * m + j] = h;
+          H[(size_t)j * m + i] = h;
+        }
+        beta = bb[(size_t)j];
+      }
+      if (jdead < m) {  // a norm vanished at step jdead: that step and the rest of the cycle again, on the slow path
+        DCORA_HIP(hipMemsetAsync(fdev.p, 0, sizeof(int), st));
+        out->matvecs -= m - jdead;
+        for (int j = jdead; j < m; ++j) {
+          const int src = slow_step(j);
+          if (src) return src;
+        }
       }
     }
     jacobi_eig(m, H, Z, th);

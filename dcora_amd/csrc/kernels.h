@@ -205,6 +205,13 @@ void launch_lambda_blocks(hipStream_t st, const ManiDesc &m, const double *X, co
 // Lanczos helpers: partial h = V^T w over nv basis vectors (nv per block), w -= V h, y -= shift x
 void launch_lanczos_proj(hipStream_t st, int n, int nv, const double *V, const double *w, double *partials);
 void launch_lanczos_sub(hipStream_t st, int n, int nv, const double *V, const double *h, double *w);
+// sync-free Lanczos step (cert.hip): subtraction with the partial sums in its prologue, coefficient store, next vector
+constexpr int kLanczosFuseParts = 256;
+void launch_lanczos_sub_sum(hipStream_t st, int n, int nv, const double *V, const double *partials, int npart,
+                            double *hout, double *w);
+void launch_lanczos_keep(hipStream_t st, int nv, const double *h, double *hout);
+void launch_lanczos_next(hipStream_t st, int n, const double *partials, int npart, double *beta_out, int *flag,
+                         const double *w, double *vnext);
 void launch_scale_shift(hipStream_t st, int n, double shift, const double *x, double *y);
 void launch_scale(hipStream_t st, int n, const double *alpha_dev_inv_sqrt /*device: w /= sqrt(*p)*/,
                   const double *w, double *out);

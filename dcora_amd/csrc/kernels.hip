@@ -1857,6 +1857,64 @@ void launch_lanczos_proj(hipStream_t st, int n, int nv, const double *V, const d
 void launch_lanczos_sub(hipStream_t st, int n, int nv, const double *V, const double *h, double *w) {
   hipLaunchKernelGGL(k_lanczos_sub, dim3(vec_grid(n)), dim3(kBlock), 0, st, n, nv, V, h, w);
 }
+// The same subtraction with the sum over the blocks' partial projections in its prologue (every workgroup sums the
+// npart x nv partials for itself: for the problem sizes this is used at -- npart <= kLanczosFuseParts -- that is a
+// few KB from L2 per workgroup and saves the k_sum_partials launch); block 0 keeps the coefficients for the host,
+// which assembles the projected matrix once per restart cycle instead of once per step.
+__global__ __launch_bounds__(kBlock) void k_lanczos_sub_sum(int n, int nv, const double *__restrict__ V,
+                                                            const double *__restrict__ partials, int npart,
+                                                            double *__restrict__ hout, double *__restrict__ w) {
+  __shared__ double s_h[kLanczosMaxV];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int i = wave; i < nv; i += kBlock / 64) {
+    double s = 0;
+    for (int b = lane; b < npart; b += 64) s += partials[(size_t)b * kLanczosMaxV + i];
+    s = wave_sum(s);
+    if (lane == 0) s_h[i] = s;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && (int)threadIdx.x < nv) hout[threadIdx.x] = s_h[threadIdx.x];
+  for (long t = (long)blockIdx.x * kBlock + threadIdx.x; t < n; t += (long)gridDim.x * kBlock) {
+    double s = 0;
+    for (int i = 0; i < nv; ++i) s += V[(size_t)i * n + t] * s_h[i];
+    w[t] -= s;
+  }
+}
+// h only (large problems keep k_sum_partials + k_lanczos_sub): copies the summed coefficients to the per-step store
+__global__ void k_lanczos_keep(int nv, const double *__restrict__ h, double *__restrict__ hout) {
+  if ((int)threadIdx.x < nv) hout[threadIdx.x] = h[threadIdx.x];
+}
+// next basis vector: beta = |w| from the partial sums of <w, w> (summed by every workgroup in its prologue),
+// v_next = w / beta; block 0 keeps beta for the host.  A vanishing beta (invariant subspace) raises *flag and leaves
+// v_next = 0: the host redoes that step on its slow path.
+__global__ __launch_bounds__(kBlock) void k_lanczos_next(int n, const double *__restrict__ partials, int npart,
+                                                         double *__restrict__ beta_out, int *__restrict__ flag,
+                                                         const double *__restrict__ w, double *__restrict__ vnext) {
+  __shared__ double s_red[16];
+  double s = 0;
+  for (int b = threadIdx.x; b < npart; b += kBlock) s += partials[b];
+  const double b2 = block_sum(s, s_red);
+  const double beta = sqrt(b2);
+  const bool dead = !(beta >= 1e-300);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    *beta_out = dead ? 0.0 : beta;
+    if (dead) *flag = 1;
+  }
+  const double inv = dead ? 0.0 : 1.0 / beta;
+  for (long t = (long)blockIdx.x * kBlock + threadIdx.x; t < n; t += (long)gridDim.x * kBlock) vnext[t] = w[t] * inv;
+}
+void launch_lanczos_sub_sum(hipStream_t st, int n, int nv, const double *V, const double *partials, int npart,
+                            double *hout, double *w) {
+  hipLaunchKernelGGL(k_lanczos_sub_sum, dim3(vec_grid(n)), dim3(kBlock), 0, st, n, nv, V, partials, npart, hout, w);
+}
+void launch_lanczos_keep(hipStream_t st, int nv, const double *h, double *hout) {
+  hipLaunchKernelGGL(k_lanczos_keep, dim3(1), dim3(64), 0, st, nv, h, hout);
+}
+void launch_lanczos_next(hipStream_t st, int n, const double *partials, int npart, double *beta_out, int *flag,
+                         const double *w, double *vnext) {
+  hipLaunchKernelGGL(k_lanczos_next, dim3(vec_grid(n)), dim3(kBlock), 0, st, n, partials, npart, beta_out, flag, w,
+                     vnext);
+}
 __global__ __launch_bounds__(kBlock) void k_scale_shift(int n, double shift, const double *__restrict__ x,
                                                         double *__restrict__ y) {
   for (long t = (long)blockIdx.x * kBlock + threadIdx.x; t < n; t += (long)gridDim.x * kBlock) y[t] -= shift * x[t];
