@@ -257,15 +257,20 @@ int DeviceLanczos::largest_magnitude(double shift, int ncv, int maxit, double to
       double *hout = hdev.p + (size_t)j * 64 + 32 * pass;
       launch_lanczos_proj(st, n, nv, V.p, w.p, part.p);
       if (npart <= kLanczosFuseParts) {
-        launch_lanczos_sub_sum(st, n, nv, V.p, part.p, npart, hout, w.p);
+        // (the dot's partials go behind the projection's in `part`: this kernel still reads those)
+        launch_lanczos_sub_sum(st, n, nv, V.p, part.p, npart, hout, w.p, pass == 1 ? part.p + (size_t)npart * 24 : nullptr);
       } else {
         launch_sum_partials(st, part.p, npart, 24, nv, small.p + 32 * pass);
         launch_lanczos_keep(st, nv, small.p + 32 * pass, hout);
         launch_lanczos_sub(st, n, nv, V.p, small.p + 32 * pass, w.p);
       }
     }
-    launch_dot(st, n, w.p, w.p, part.p);
-    launch_lanczos_next(st, n, part.p, npart, bdev.p + j, fdev.p, w.p, V.p + (size_t)(j + 1) * n);
+    if (npart <= kLanczosFuseParts) {
+      launch_lanczos_next(st, n, part.p + (size_t)npart * 24, npart, bdev.p + j, fdev.p, w.p, V.p + (size_t)(j + 1) * n);
+    } else {
+      launch_dot(st, n, w.p, w.p, part.p);
+      launch_lanczos_next(st, n, part.p, npart, bdev.p + j, fdev.p, w.p, V.p + (size_t)(j + 1) * n);
+    }
     return DCORA_OK;
   };
   for (int it = 0; it <= maxit; ++it) {

@@ -208,7 +208,7 @@ void launch_lanczos_sub(hipStream_t st, int n, int nv, const double *V, const do
 // sync-free Lanczos step (cert.hip): subtraction with the partial sums in its prologue, coefficient store, next vector
 constexpr int kLanczosFuseParts = 256;
 void launch_lanczos_sub_sum(hipStream_t st, int n, int nv, const double *V, const double *partials, int npart,
-                            double *hout, double *w);
+                            double *hout, double *w, double *dotpart);
 void launch_lanczos_keep(hipStream_t st, int nv, const double *h, double *hout);
 void launch_lanczos_next(hipStream_t st, int n, const double *partials, int npart, double *beta_out, int *flag,
                          const double *w, double *vnext);

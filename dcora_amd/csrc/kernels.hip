@@ -1863,8 +1863,10 @@ void launch_lanczos_sub(hipStream_t st, int n, int nv, const double *V, const do
 // which assembles the projected matrix once per restart cycle instead of once per step.
 __global__ __launch_bounds__(kBlock) void k_lanczos_sub_sum(int n, int nv, const double *__restrict__ V,
                                                             const double *__restrict__ partials, int npart,
-                                                            double *__restrict__ hout, double *__restrict__ w) {
+                                                            double *__restrict__ hout, double *__restrict__ w,
+                                                            double *__restrict__ dotpart) {
   __shared__ double s_h[kLanczosMaxV];
+  __shared__ double s_red[16];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int i = wave; i < nv; i += kBlock / 64) {
     double s = 0;
@@ -1874,10 +1876,17 @@ __global__ __launch_bounds__(kBlock) void k_lanczos_sub_sum(int n, int nv, const
   }
   __syncthreads();
   if (blockIdx.x == 0 && (int)threadIdx.x < nv) hout[threadIdx.x] = s_h[threadIdx.x];
+  double ww = 0;
   for (long t = (long)blockIdx.x * kBlock + threadIdx.x; t < n; t += (long)gridDim.x * kBlock) {
     double s = 0;
     for (int i = 0; i < nv; ++i) s += V[(size_t)i * n + t] * s_h[i];
-    w[t] -= s;
+    const double wn = w[t] - s;
+    w[t] = wn;
+    ww += wn * wn;
+  }
+  if (dotpart) {  // second pass: <w, w> of the finished vector rides along (the norm's own launch saved)
+    const double tot = block_sum(ww, s_red);
+    if (threadIdx.x == 0) dotpart[blockIdx.x] = tot;
   }
 }
 // h only (large problems keep k_sum_partials + k_lanczos_sub): copies the summed coefficients to the per-step store
@@ -1904,8 +1913,9 @@ __global__ __launch_bounds__(kBlock) void k_lanczos_next(int n, const double *__
   for (long t = (long)blockIdx.x * kBlock + threadIdx.x; t < n; t += (long)gridDim.x * kBlock) vnext[t] = w[t] * inv;
 }
 void launch_lanczos_sub_sum(hipStream_t st, int n, int nv, const double *V, const double *partials, int npart,
-                            double *hout, double *w) {
-  hipLaunchKernelGGL(k_lanczos_sub_sum, dim3(vec_grid(n)), dim3(kBlock), 0, st, n, nv, V, partials, npart, hout, w);
+                            double *hout, double *w, double *dotpart) {
+  hipLaunchKernelGGL(k_lanczos_sub_sum, dim3(vec_grid(n)), dim3(kBlock), 0, st, n, nv, V, partials, npart, hout, w,
+                     dotpart);
 }
 void launch_lanczos_keep(hipStream_t st, int nv, const double *h, double *hout) {
   hipLaunchKernelGGL(k_lanczos_keep, dim3(1), dim3(64), 0, st, nv, h, hout);
