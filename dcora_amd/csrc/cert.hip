@@ -223,8 +223,11 @@ int DeviceLanczos::largest_magnitude(double shift, int ncv, int maxit, double to
       H[(size_t)j * m + i] = h;
     }
     beta = std::sqrt(b2);
-    if (beta < 1e-300) {
-      // invariant subspace: continue with a fresh random direction orthogonalised against the basis
+    double h2 = 0;
+    for (int i = 0; i < nv; ++i) h2 += H[(size_t)i * m + j] * H[(size_t)i * m + j];
+    if (!(beta > kLanczosDead * std::sqrt(h2 + b2)) || beta < 1e-300) {
+      // invariant subspace (the remainder is rounding noise of the orthogonalisation, or exactly zero): continue with
+      // a fresh random direction orthogonalised against the basis
       double unused = 0;
       whole_vector(seed + 7919 * (j + 1), nullptr, &unused);
       DCORA_HIP(hipMemcpyAsync(w.p, host_v.data(), sizeof(double) * n, hipMemcpyHostToDevice, st));
@@ -266,10 +269,11 @@ int DeviceLanczos::largest_magnitude(double shift, int ncv, int maxit, double to
       }
     }
     if (npart <= kLanczosFuseParts) {
-      launch_lanczos_next(st, n, part.p + (size_t)npart * 24, npart, bdev.p + j, fdev.p, w.p, V.p + (size_t)(j + 1) * n);
+      launch_lanczos_next(st, n, part.p + (size_t)npart * 24, npart, bdev.p + j, fdev.p, w.p, V.p + (size_t)(j + 1) * n,
+                          hdev.p + (size_t)j * 64, nv);
     } else {
       launch_dot(st, n, w.p, w.p, part.p);
-      launch_lanczos_next(st, n, part.p, npart, bdev.p + j, fdev.p, w.p, V.p + (size_t)(j + 1) * n);
+      launch_lanczos_next(st, n, part.p, npart, bdev.p + j, fdev.p, w.p, V.p + (size_t)(j + 1) * n, hdev.p + (size_t)j * 64, nv);
     }
     return DCORA_OK;
   };
@@ -398,6 +402,10 @@ int device_min_eig(const HostCsr &S, int maxit, double min_eig_tol, int ncv, uin
     return DCORA_OK;
   }
   const double lambda_lm = lm.lambda;
+  if (lambda_lm == 0) {  // S = 0: every vector is an eigenvector of the eigenvalue 0
+    *out = lm;
+    return DCORA_OK;
+  }
   const std::vector<double> x0 = min_eig_second_start(S, seed);
   LanczosResult sh;
   // The spectrum-shifted run resolves the smallest eigenvalue to min_eig_tol on a spectrum of width lambda_lm.  When that

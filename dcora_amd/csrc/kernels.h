@@ -210,8 +210,11 @@ constexpr int kLanczosFuseParts = 256;
 void launch_lanczos_sub_sum(hipStream_t st, int n, int nv, const double *V, const double *partials, int npart,
                             double *hout, double *w, double *dotpart);
 void launch_lanczos_keep(hipStream_t st, int nv, const double *h, double *hout);
+// a new direction whose norm is below this fraction of |S v_j| is rounding noise of the orthogonalisation, not a
+// direction: the Krylov space is exhausted (an invariant subspace) and the basis continues with a fresh vector
+constexpr double kLanczosDead = 1e-10;
 void launch_lanczos_next(hipStream_t st, int n, const double *partials, int npart, double *beta_out, int *flag,
-                         const double *w, double *vnext);
+                         const double *w, double *vnext, const double *hrow, int nv);
 void launch_scale_shift(hipStream_t st, int n, double shift, const double *x, double *y);
 void launch_scale(hipStream_t st, int n, const double *alpha_dev_inv_sqrt /*device: w /= sqrt(*p)*/,
                   const double *w, double *out);

@@ -1898,13 +1898,21 @@ __global__ void k_lanczos_keep(int nv, const double *__restrict__ h, double *__r
 // v_next = 0: the host redoes that step on its slow path.
 __global__ __launch_bounds__(kBlock) void k_lanczos_next(int n, const double *__restrict__ partials, int npart,
                                                          double *__restrict__ beta_out, int *__restrict__ flag,
-                                                         const double *__restrict__ w, double *__restrict__ vnext) {
+                                                         const double *__restrict__ w, double *__restrict__ vnext,
+                                                         const double *__restrict__ hrow, int nv) {
   __shared__ double s_red[16];
   double s = 0;
   for (int b = threadIdx.x; b < npart; b += kBlock) s += partials[b];
   const double b2 = block_sum(s, s_red);
   const double beta = sqrt(b2);
-  const bool dead = !(beta >= 1e-300);
+  // |S v_j|^2 = beta^2 + sum of the squared coefficients taken out by the two passes: a remainder at the rounding level
+  // of that norm is no direction (kLanczosDead, shared with the host's per-step form)
+  double h2 = 0;
+  for (int i = 0; i < nv; ++i) {
+    const double h = hrow[i] + hrow[32 + i];
+    h2 += h * h;
+  }
+  const bool dead = !(beta > kLanczosDead * sqrt(h2 + b2)) || !(beta >= 1e-300);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     *beta_out = dead ? 0.0 : beta;
     if (dead) *flag = 1;
@@ -1921,9 +1929,9 @@ void launch_lanczos_keep(hipStream_t st, int nv, const double *h, double *hout) 
   hipLaunchKernelGGL(k_lanczos_keep, dim3(1), dim3(64), 0, st, nv, h, hout);
 }
 void launch_lanczos_next(hipStream_t st, int n, const double *partials, int npart, double *beta_out, int *flag,
-                         const double *w, double *vnext) {
+                         const double *w, double *vnext, const double *hrow, int nv) {
   hipLaunchKernelGGL(k_lanczos_next, dim3(vec_grid(n)), dim3(kBlock), 0, st, n, partials, npart, beta_out, flag, w,
-                     vnext);
+                     vnext, hrow, nv);
 }
 __global__ __launch_bounds__(kBlock) void k_scale_shift(int n, double shift, const double *__restrict__ x,
                                                         double *__restrict__ y) {

@@ -256,3 +256,60 @@ def test_weights_formed_on_the_device_equal_the_weights_formed_on_the_host(built
         assert np.allclose(a[1:], b[1:], rtol=1e-11, atol=1e-11 * a[2]), (name, a, b)
         for tag in ("streamed", "one_piece"):
             assert common.rel(runs["device"][name + "_z"], runs[tag][name + "_z"]) < 1e-12, (name, tag)
+
+
+LANCZOS_CHILD = r"""
+import os, sys
+import numpy as np
+import scipy.sparse as sp
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import common
+import dcora_amd as da
+out = {}
+ds = common.product_dataset("sphere2500")
+Q = da.build_Q_pgo(ds)
+rng = np.random.default_rng(4)
+X = da.manifold_project(5, ds.d, ds.n, rng.standard_normal((5, 4 * ds.n)))
+S = da.dual_certificate(5, ds.d, ds.n, X, Q)                      # far from a critical point: indefinite
+ok, lam, v, mv = da.min_eig(S, tol=1e-6)
+out["sphere"] = np.array([ok, lam, mv]); out["sphere_v"] = v
+n = 400                                                          # a matrix the Krylov space dies on at once
+Z = da.Csr.from_scipy(sp.csr_matrix((np.zeros(n), (np.arange(n), np.arange(n))), shape=(n, n)))
+ok, lam, v, mv = da.min_eig(Z, tol=1e-6)
+out["zero"] = np.array([ok, lam, mv]); out["zero_v"] = v
+I2 = da.Csr.from_scipy((2.0 * sp.identity(n)).tocsr())           # every vector an eigenvector: the remainder of the
+ok, lam, v, mv = da.min_eig(I2, tol=1e-6)                        # first step is rounding noise, not a direction
+out["two_i"] = np.array([ok, lam, mv])
+D = da.Csr.from_scipy(sp.diags(np.r_[-2.0, np.ones(200), 3.0 * np.ones(199)]).tocsr())   # three distinct eigenvalues
+ok, lam, v, mv = da.min_eig(D, tol=1e-8)
+out["diag"] = np.array([ok, lam, mv]); out["diag_v"] = v
+np.savez(sys.argv[2], **out)
+"""
+
+
+def test_lanczos_cycles_on_the_device_against_the_per_step_form(built, tmp_path):
+    """the certificate's eigensolver keeps a restart cycle's coefficients on the device (default) or reads them back
+    after every step (DCORA_LANCZOS=sync, the form used across ranks): same eigenvalue, same eigenvector up to sign on
+    an indefinite certificate of sphere2500; a zero matrix (the next vector's norm vanishes at the first step: the fast
+    form flags it and redoes the step on the slow path), 2 I (the remainder is rounding noise: a relative test must call
+    the Krylov space exhausted -- with the absolute 1e-300 of rounds 1-2 the noise was normalised into the basis and
+    the run ended at -1.4e8) and a matrix with three distinct eigenvalues end where they must"""
+    runs = {}
+    for tag, env in (("device", {}), ("sync", {"DCORA_LANCZOS": "sync"})):
+        e = dict(os.environ)
+        e.update(env)
+        out = os.path.join(str(tmp_path), tag + ".npz")
+        res = subprocess.run([sys.executable, "-c", LANCZOS_CHILD, os.path.dirname(common.HERE), out], env=e,
+                             capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+        runs[tag] = np.load(out)
+    a, b = runs["device"], runs["sync"]
+    assert a["sphere"][0] == 1 and b["sphere"][0] == 1 and a["sphere"][1] < 0
+    assert abs(a["sphere"][1] - b["sphere"][1]) <= 1e-8 * abs(b["sphere"][1]), (a["sphere"], b["sphere"])
+    assert abs(abs(float(a["sphere_v"] @ b["sphere_v"])) - 1.0) < 1e-6
+    for r_ in (a, b):
+        assert r_["zero"][0] == 1 and abs(r_["zero"][1]) < 1e-12, r_["zero"]
+        assert abs(np.linalg.norm(r_["zero_v"]) - 1.0) < 1e-9
+        assert r_["two_i"][0] == 1 and abs(r_["two_i"][1] - 2.0) < 1e-12 and r_["two_i"][2] < 200, r_["two_i"]
+        assert r_["diag"][0] == 1 and abs(r_["diag"][1] + 2.0) < 1e-7, r_["diag"]
+        assert abs(abs(r_["diag_v"][0]) - 1.0) < 1e-6
