@@ -145,8 +145,12 @@ static EigResult lanczos_lm(int n, const Op &op, int ncv, int maxit, double tol,
       beta = 0;
       for (int t = 0; t < n; ++t) beta += w[t] * w[t];
       beta = std::sqrt(beta);
-      if (beta < 1e-300) {
-        // invariant subspace: continue with a random direction orthogonal to V
+      double h2 = 0;
+      for (int i = 0; i <= j; ++i) h2 += hcol[i] * hcol[i];
+      if (!(beta > 1e-10 * std::sqrt(h2 + beta * beta)) || beta < 1e-300) {
+        // invariant subspace (a remainder at the rounding level of |S v_j| is no direction: normalised into the basis
+        // it ruins it -- 2 I came out as -1.02 with the absolute test alone): continue with a random direction
+        // orthogonal to V
         for (int t = 0; t < n; ++t) w[t] = u01(s) - 0.5;
         for (int pass = 0; pass < 2; ++pass)
           for (int i = 0; i <= j; ++i) {
@@ -246,6 +250,7 @@ EigResult min_eig_pair(const CSR &S, int maxit, double min_eig_tol, int ncv, uin
   if (!lm.ok) return lm;
   if (lm.lambda < 0) return lm;
   const double lambda_lm = lm.lambda;
+  if (lambda_lm == 0) return lm;  // S = 0
   // x0 = row 0 of S, perturbed by ~3 %
   std::vector<double> x0(k, 0.0), pert(k);
   for (int p = S.rp[0]; p < S.rp[1]; ++p) x0[S.ci[p]] = S.v[p];

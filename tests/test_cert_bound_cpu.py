@@ -27,3 +27,21 @@ def test_unaccepted_certificate_is_refused(built):
     S = da.Csr.from_scipy(Q - 1e-2 * sp.identity(Q.shape[0]))
     with pytest.raises(Exception):
         da.lambda_min_certified(S, 1e-3, block=ds.d + 1)
+
+
+def test_oracle_min_eig_on_matrices_whose_krylov_space_is_exhausted(built):
+    """the oracle's Lanczos (the checker of dcora_cert_min_eig) on a zero matrix, on 2 I and on a matrix with three
+    distinct eigenvalues: the Krylov space ends after 0, 1 and 3 steps and the run must notice -- relative to |S v_j|,
+    the remainder of the orthogonalisation is rounding noise there, not a direction (with an absolute 1e-300 alone the
+    noise was normalised into the basis: 2 I came out as -1.02).  The product's two forms of the cycle are checked on
+    the same matrices in tests/test_kernel_forms_gpu.py."""
+    from oracle import orc
+    n = 400
+    zero = sp.csr_matrix((np.zeros(n), (np.arange(n), np.arange(n))), shape=(n, n))
+    ok, lam, v, mv = orc.min_eig(orc.CSR.from_scipy(zero), tol=1e-6)
+    assert ok and lam == 0.0 and abs(np.linalg.norm(v) - 1) < 1e-9
+    ok, lam, v, mv = orc.min_eig(orc.CSR.from_scipy((2.0 * sp.identity(n)).tocsr()), tol=1e-6)
+    assert ok and abs(lam - 2.0) < 1e-12 and mv < 200
+    D = sp.diags(np.r_[-2.0, np.ones(200), 3.0 * np.ones(199)]).tocsr()
+    ok, lam, v, mv = orc.min_eig(orc.CSR.from_scipy(D), tol=1e-8)
+    assert ok and abs(lam + 2.0) < 1e-7 and abs(abs(v[0]) - 1.0) < 1e-6
