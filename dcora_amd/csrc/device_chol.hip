@@ -622,6 +622,93 @@ __global__ __launch_bounds__(256) void k_chol_syrk(const PieceDev *__restrict__ 
     }
 }
 
+// The trailing update behind a super-panel on the VECTOR pipe: on this part sixteen independent v_fma_f64 chains per
+// lane run at 67-69 Tflop/s, the fp64 MFMA at 47 (tools/mfma_f64_peak.hip), and the operand reads of a register-tiled
+// product are LDS broadcasts.  A workgroup owns 128 rows x 64 columns, a thread 8 x 4 outputs (12 LDS reads per 32
+// FMAs), K in steps of 32 columns fetched into registers one step ahead; tiles (tr, tc) with tc <= 2 tr + 1 cover the
+// lower triangle, blockIdx.x = tr (tr + 1) + tc.  MEASURED AND NOT THE DEFAULT (DCORA_CHOL_TRAIL=fma selects it): 196
+// VGPRs leave two waves per SIMD, the large trailing updates run at 29 Tflop/s against 35-38 for k_chol_syrk<true>, the
+// factorisation of the whole 100k lattice takes 109 ms against 98.
+__global__ __launch_bounds__(256) void k_chol_syrk_fma(const PieceDev *__restrict__ pieces, const int *__restrict__ list,
+                                                       int k0, int kcap, double *__restrict__ F,
+                                                       const int *__restrict__ fail) {
+  if (*fail) return;
+  constexpr int KC = 32, TR = 128, TC = 64;
+  const PieceDev P = pieces[list[blockIdx.y]];
+  const int f = P.c + P.m;
+  const int base = min(kcap, P.c);
+  if (base <= k0) return;
+  int tr = (int)((sqrtf(4.0f * (float)blockIdx.x + 1.0f) - 1.0f) * 0.5f);
+  while ((tr + 1) * (tr + 2) <= (int)blockIdx.x) ++tr;
+  while (tr * (tr + 1) > (int)blockIdx.x) --tr;
+  const int tc = blockIdx.x - tr * (tr + 1);
+  const int ri0 = base + TR * tr, cj0 = base + TC * tc;
+  if (ri0 >= f || cj0 >= f) return;
+  __shared__ double As[KC][TR + 1];
+  __shared__ double Bs[KC][TC + 1];
+  double *__restrict__ M = F + P.off;
+  const double *__restrict__ Arow = M + (long long)ri0 * f;
+  const double *__restrict__ Brow = M + (long long)cj0 * f;
+  const int arows = min(TR, f - ri0), brows = min(TC, f - cj0);
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const int kk = tid & (KC - 1), ib = tid >> 5;  // entry q of a thread: row ib + 8 q, column kk of the step
+  double ra[TR * KC / 256], rb[TC * KC / 256];
+  auto fetch = [&](int l) {
+    const int K = min(KC, base - l);
+#pragma unroll
+    for (int q = 0; q < TR * KC / 256; ++q) {
+      const int i = ib + 8 * q;
+      ra[q] = (i < arows && kk < K) ? Arow[(long long)i * f + l + kk] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < TC * KC / 256; ++q) {
+      const int i = ib + 8 * q;
+      rb[q] = (i < brows && kk < K) ? Brow[(long long)i * f + l + kk] : 0.0;
+    }
+  };
+  double acc[8][4];
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[u][v] = 0;
+  fetch(k0);
+  for (int l = k0; l < base; l += KC) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < TR * KC / 256; ++q) As[kk][ib + 8 * q] = ra[q];
+#pragma unroll
+    for (int q = 0; q < TC * KC / 256; ++q) Bs[kk][ib + 8 * q] = rb[q];
+    __syncthreads();
+    if (l + KC < base) fetch(l + KC);
+#pragma unroll 4
+    for (int k = 0; k < KC; ++k) {
+      double a[8], b[4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] = As[k][ty + 16 * u];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) b[v] = Bs[k][tx + 16 * v];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] = fma(a[u], b[v], acc[u][v]);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int r = ri0 + ty + 16 * u, c = cj0 + tx + 16 * v;
+      if (r < f && c <= r) M[(long long)r * f + c] -= acc[u][v];
+    }
+}
+inline bool chol_trail_fma() {  // opt-in: measured slower than the MFMA form (29 against 35-38 Tflop/s, see above)
+  static const bool v = [] {
+    const char *e = std::getenv("DCORA_CHOL_TRAIL");
+    return e && std::strcmp(e, "fma") == 0;
+  }();
+  return v;
+}
+
 // Y = L^-1 right-looking, one block row of L at a time; Y is kept transposed (YT(j, i) = Y(i, j)^T).  Step ib:
 //   finish:  YT(j, ib) = -TT(j, ib) Linv_ib^T for the block rows j < ib (TT accumulated in place), YT(ib, ib) = Linv_ib^T
 //   update:  TT(j, i) += YT(j, ib) L(i, ib)^T for every block row i > ib and j <= ib  -- (nb - ib - 1)(ib + 1) tiles
@@ -1195,6 +1282,16 @@ int factor_on_device(const HostCsr &A, int block, int top, int device, bool *pd,
                            img->fail.p);
         break;
       default:
+        if (L.ncb == 0 && L.ccap < 0 && L.kcap - L.j0 > NB && chol_trail_fma()) {
+          // the rank-512 sweep of the trailing matrix: 128 x 64 tiles on the vector pipe (L.gx was sized for 64 x 64
+          // tiles over T block rows: T (T + 1) / 2 -> tr (tr + 1) + tc over ceil(T / 2) tile rows)
+          int T = (int)((std::sqrt(8.0 * L.gx + 1.0) - 1.0) * 0.5 + 0.5);
+          while (T * (T + 1) / 2 < L.gx) ++T;
+          const int TRn = (T + 1) / 2;
+          hipLaunchKernelGGL(k_chol_syrk_fma, dim3(TRn * (TRn + 1), L.gy), dim3(256), 0, st, img->pieces.p, list, L.j0,
+                             L.kcap, F, img->fail.p);
+          break;
+        }
         DCORA_LAUNCH_MMA(k_chol_syrk, dim3(L.gx, L.gy), st, img->pieces.p, list, L.j0, L.kcap, L.ccap, L.ncb, F,
                            img->fail.p);
         break;
