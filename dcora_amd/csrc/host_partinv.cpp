@@ -306,19 +306,22 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
   }
   const auto T2 = tnow();
   // ---- schedule: merged levels (host_partinv2.cpp) unless DCORA_SP_SCHEDULE=v1 asks for one launch per tree level ----
-  static const bool schedule_v1 = [] {
+  static const int schedule = [] {  // 3: panels (default), 2: merged 4-row tiles, 1: one launch per tree level
     const char *e = std::getenv("DCORA_SP_SCHEDULE");
-    return e && std::strcmp(e, "v1") == 0;
+    return e && std::strcmp(e, "v1") == 0 ? 1 : e && std::strcmp(e, "v2") == 0 ? 2 : 3;
   }();
-  const bool merged = !schedule_v1;
+  const bool merged = schedule != 1;
   if (merged) {
     std::vector<const double *> Mgiven((size_t)np, nullptr);
     for (int s = 0; s < np; ++s)
       if (F.pieces[s].mtop()) Mgiven[s] = F.pieces[s].mtop();
-    layout_merged(pc, Mgiven, piece_of, k, nlev, nthreads, timing, &P);
+    if (schedule == 3)
+      layout_mpipe(pc, Mgiven, piece_of, k, nlev, nthreads, timing, &P);
+    else
+      layout_merged(pc, Mgiven, piece_of, k, nlev, nthreads, timing, &P);
     if (timing)
-      std::fprintf(stderr, "[partinv] k %d pieces %d levels %d: piece inverses %.1f, merged schedule %.1f ms\n", k, np, nlev,
-                   tms(T1, T2), tms(T2, tnow()));
+      std::fprintf(stderr, "[partinv] k %d pieces %d levels %d: piece inverses %.1f, %s schedule %.1f ms\n", k, np, nlev,
+                   tms(T1, T2), schedule == 3 ? "matrix-pipe" : "merged", tms(T2, tnow()));
   } else {
   // ---- schedule.  Which buffer holds a piece's current value is static; start: everything in buffer 0.
   // A task is a tile of up to kSpTile consecutive output rows that gather from the same sources; the weights of
@@ -680,6 +683,17 @@ inline void fill_one(const Fill &f, double *w) {
       }
       interleave_rows(row, hi, nr, w);
       break;
+    case 5: {  // micro-blocks: rows a0 .. a0 + 3, micro-block columns [loc[0], loc[1])
+      const int cb0 = f.loc[0], cb1 = f.loc[1];
+      for (int cb = cb0; cb < cb1; ++cb)
+        for (int ee = 0; ee < 4; ++ee) {
+          const int e = cb * 4 + ee;
+          if (e >= c) break;
+          for (int aa = 0; aa < 4 && a0 + aa < f.m; ++aa)
+            w[(size_t)(cb - cb0) * 16 + ee * 4 + aa] = f.base[(size_t)(a0 + aa) * c + e];
+        }
+      break;
+    }
     case 3:  // (D^-T)(a0 + q, a0 + j) = Dinv(a0 + j, a0 + q), j >= q
       for (int j = 0; j < f.len && a0 + j < c; ++j) {
         const double *src = f.base + (size_t)(a0 + j) * c + a0;
@@ -766,12 +780,69 @@ bool write_weights(const std::vector<Fill> &fills, long long total, int nthreads
 
 void partitioned_inverse_apply_host(const PartInvHost &P, int r, const double *R, double *Z) {
   const int k = P.k;
-  std::vector<double> y((size_t)(2 * k + 2) * r, 0.0);  // padded pairs may touch one unknown past the end
+  std::vector<double> y((size_t)(2 * k + 4) * r, 0.0);  // padded pairs / K steps may touch up to three unknowns past the end
   for (int j = 0; j < k; ++j)
     for (int t = 0; t < r; ++t) y[(size_t)j * r + t] = R[(size_t)P.perm[j] * r + t];
   std::vector<double> acc;
   std::vector<double> outv;
   for (const SpLevel &lv : P.levels) {
+    if (lv.mpipe) {  // matrix-pipe schedule: the wave records executed by plain loops
+      struct Out {
+        int out, nrows;
+        std::vector<double> v;
+      };
+      std::vector<Out> outs;
+      for (int wg = 0; wg < lv.ntasks; ++wg) {
+        std::vector<double> part((size_t)kMtWaves * kSpTile * r, 0.0);
+        const MWave *W8 = &P.mwaves[(size_t)lv.task0 + (size_t)wg * kMtWaves];
+        for (int wv = 0; wv < kMtWaves; ++wv) {
+          if (W8[wv].nrows == 0) continue;
+          double *pa = &part[(size_t)wv * kSpTile * r];
+          for (const MWave *R = &W8[wv]; R; R = R->next >= 0 ? &P.mwaves[(size_t)lv.task0 + R->next] : nullptr) {
+            for (int half = 0; half < 2; ++half) {
+              const MSub &U = half == 0 ? R->a : R->b;
+              const double *w = &P.vals[(size_t)U.w];
+              for (int s = U.s0; s < U.s0 + U.n; ++s)
+                for (int e = 16 * s; e < 16 * s + 16 && e < 4 * U.ng; ++e) {
+                  const size_t u = R->kind == 0 ? (size_t)U.src + e : (size_t)P.idxs[(size_t)U.src + e];
+                  for (int i = 0; i < R->nrows; ++i) {
+                    double wj;
+                    if (R->kind == 0) {
+                      const int a = U.loc[i];
+                      if (a < 0) continue;
+                      wj = w[((size_t)(a >> 2) * U.ncb + (e >> 2)) * 16 + (e & 3) * 4 + (a & 3)];
+                    } else {
+                      const int col = U.loc[0] + i;
+                      wj = w[((size_t)(e >> 2) * U.ncb + (col >> 2)) * 16 + (col & 3) * 4 + (e & 3)];
+                    }
+                    if (wj == 0.0) continue;
+                    for (int t = 0; t < r; ++t) pa[(size_t)i * r + t] += wj * y[u * r + t];
+                  }
+                }
+            }
+          }
+        }
+        for (int wv = 0; wv < kMtWaves; ++wv) {
+          const MWave &R = W8[wv];
+          if (R.nrows == 0 || R.red_first != wv) continue;
+          Out o;
+          o.out = R.out;
+          o.nrows = R.nrows;
+          o.v.assign((size_t)R.nrows * r, 0.0);
+          for (int a = 0; a < R.nrows; ++a)
+            for (int t = 0; t < r; ++t) {
+              double v = 0;
+              for (int q = 0; q < R.red_n; ++q) v += part[((size_t)(wv + q) * kSpTile + a) * r + t];
+              o.v[(size_t)a * r + t] = v + (R.carry >= 0 ? y[((size_t)R.carry + a) * r + t] : 0.0);
+            }
+          outs.push_back(std::move(o));
+        }
+      }
+      for (const Out &o : outs)
+        for (int a = 0; a < o.nrows; ++a)
+          for (int t = 0; t < r; ++t) y[((size_t)o.out + a) * r + t] = o.v[(size_t)a * r + t];
+      continue;
+    }
     // every task of a level reads the state before the level: evaluate all, then store
     outv.assign((size_t)lv.ntasks * kSpTile * r, 0.0);
     for (int q = 0; q < lv.ntasks; ++q) {

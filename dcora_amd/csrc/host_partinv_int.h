@@ -80,6 +80,8 @@ void parallel_for(int n, int nthreads, int chunk, F body) {
 //   kind 2: rows a0 + q of a full c x c matrix
 //   kind 3: transposed lower triangle: w[j][q] = base(a0 + j, a0 + q), j >= q
 //   kind 4: transposed block: w[j][q] = base(j, a0 + q), j < m
+//   kind 5: micro-blocks (matrix-pipe schedule, sparse_precond.h): rows a0 .. a0 + 3 of an m x c matrix, micro-block columns
+//           [loc[0], loc[1]):  w[(cb - loc[0]) 16 + (e % 4) 4 + a % 4] = base(a, e), zero beyond the matrix
 struct Fill {
   long long off;
   const double *base;
@@ -93,6 +95,11 @@ bool write_weights(const std::vector<Fill> &fills, long long total, int nthreads
 // s where the device delivered it.  Fills P->levels / tasks / segs / idxs / vals / out_off / weights_read_per_apply.
 void layout_merged(const std::vector<Piece> &pc, const std::vector<const double *> &Mgiven,
                    const std::vector<int> &piece_of, int k, int nlev, int nthreads, bool timing, PartInvHost *P);
+// third builder (host_partinv3.cpp): the merged launches with their tiles on the matrix pipe, every piece's weights
+// stored once (sparse_precond.h, "matrix-pipe schedule").  Same arguments.
+void layout_mpipe(const std::vector<Piece> &pc, const std::vector<const double *> &Mgiven,
+                   const std::vector<int> &piece_of, int k, int nlev, int nthreads, bool timing, PartInvHost *P);
+inline int pad4(int x) { return (x + 3) & ~3; }
 
 }  // namespace partinv
 }  // namespace dcora

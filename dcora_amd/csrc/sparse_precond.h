@@ -42,8 +42,54 @@ struct PSeg {       // row q of the tile:  sum_j w[q][j] * y[src + j]   or   sum
   int len;
   int pad;
 };
+// ---- matrix-pipe schedule (host_partinv3.cpp, k_sp_mtile): the tiles of the merged schedule -- up to kSpTile consecutive
+// output rows that gather from the same sources -- with the sums over the gathered entries inside
+// v_mfma_f64_4x4x4_4b_f64: one instruction multiplies FOUR independent 4 x 4 blocks, D_b += A_b B_b; a step of a tile
+// feeds it four consecutive groups of four K entries (A_b = the tile's 4 rows x group b of weights, B_b = those 4
+// entries x 4 of the r vector values), so a step consumes 16 entries = 512 bytes of weights, ceil(r / 8) * 2 instructions
+// of ~17 clocks, and the four partial blocks are added by two DPP row rotations at the end of the tile.
+// The matrices a piece owns -- W (or the merged V) and M -- are stored ONCE, in 4 x 4 micro-blocks
+//     element (a, e) of an nr x nc matrix  ->  ((a / 4) ncb + e / 4) 16 + (e % 4) 4 + a % 4,      ncb = ceil(nc / 4)
+// (rows and columns padded to multiples of four with zeros) -- a micro-block IS one A_b -- and read two ways:
+//   kind 0, direct:      A[i][k] = Mat[loc[i]][4 g + k]       K runs over the columns   (forward: rows of W by destination)
+//   kind 1, transposed:  A[i][k] = Mat[4 g + k][col0 + i]     K runs over the rows      (backward: W^T; M, symmetric)
+// so the backward sweep streams the SAME weights the forward sweep did: stored weights = nnz(W) + nnz(M) where the
+// tile schedule of host_partinv2.cpp stores 2 nnz(W) + nnz(M), laid out per tile.
+// The unit the device reads is a WAVE RECORD (host_partinv3.cpp packs them, kMtWaves per workgroup): the contiguous range
+// of a tile's steps one wave executes -- cut so that it touches at most two segments, whose descriptions travel in the
+// record --, where the tile's result goes and which waves of the workgroup hold the other partial sums of the tile.  One
+// scalar load tells a wave everything; all loads of up to eight steps are requested together whatever segment they
+// belong to.
+struct MSub {      // a run of 16-entry steps of one segment
+  long long w;     // offset of the matrix in the weight array (multiple of 16)
+  int ncb;         // micro-block columns of the matrix
+  int ng;          // groups of four K entries of the segment
+  int src;         // kind 0: first unknown of the contiguous run the K entries are; kind 1: offset of the index list
+  int s0;          // first step of the run
+  int n;           // steps of the run
+  int pad;
+  int loc[4];      // kind 0: the matrix row of every tile row (-1: none); kind 1: loc[0] = col0 (multiple of 4)
+};
+static_assert(sizeof(MSub) == 48, "MSub is read as three 16-byte words");
+struct MWave {
+  int out;         // first destination, in unknowns (buffer * k + permuted row); written by the tile's first wave
+  int carry;       // first old value to add (same units) or -1
+  int nrows;       // <= kSpTile; 0: the wave has nothing to do
+  int kind;        // 0: direct weights, contiguous vector run; 1: transposed weights, gathered vector entries
+  int red_first;   // wave of the workgroup that holds the tile's first partial sum (adds the others and stores)
+  int red_n;       // waves of the tile (consecutive)
+  int next;        // record that continues this wave's work (tiles of many short segments), -1: none
+  int pad;
+  MSub a, b;
+};
+static_assert(sizeof(MWave) == 128, "MWave is read as eight 16-byte words");
+constexpr int kMtWaves = 8;  // waves per workgroup of the matrix-pipe kernel
+
 struct SpLevel {
   int task0 = 0, ntasks = 0, lanes = 8;  // lanes per task of the first kernel form (16, 32, 64, 128 or 256)
+  // matrix-pipe schedule: task0 = first wave record of the launch (PartInvHost::mwaves), ntasks = its workgroups (of
+  // kMtWaves records each); continuation records follow the launch's workgroups
+  int mpipe = 0;
   double avg_entries = 0;                // vector entries a tile gathers, on average (the launch picks the lanes from it)
   // Merged schedule (host_partinv2.cpp): the tasks of a launch gather anything from 8 to thousands of entries, so
   // they are sorted by entries, longest first, and every tile gets the lanes its own length asks for: tasks
@@ -106,6 +152,7 @@ struct PartInvHost {
   int nforward = 0;
   std::vector<PTask> tasks;
   std::vector<PSeg> segs;
+  std::vector<MWave> mwaves;   // matrix-pipe schedule
   std::vector<double> vals;
   // set by the caller before the build: the stored weights are streamed there while they are formed and `vals` stays
   // empty (the product: the 6.8 GB of the whole 100k lattice never exist on the host); null: weights in `vals`

@@ -388,6 +388,220 @@ __global__ __launch_bounds__(kBlock) void k_sp_multi(const PTask *__restrict__ t
   }
 }
 
+
+// ---- matrix-pipe schedule (sparse_precond.h, host_partinv3.cpp): one launch of tiles on v_mfma_f64_4x4x4_4b_f64 ----
+// The instruction multiplies four independent 4 x 4 blocks.  Measured on MI355X (tools/mfma_f64_4x4.hip): lane
+// l = 16 k + 4 b + i holds A_b[i][k], lane 16 k + 4 b + j holds B_b[k][j], lane 16 i + 4 b + j receives D_b[i][j];
+// 65-67 Tflop/s with two waves per SIMD (v_mfma_f64_16x16x4: 47), about 17 clocks per instruction.
+// A step of a tile: block b takes the group g = 4 s + b of four K entries -- one micro-block of the stored matrix
+// (128 bytes; direct: micro-block (row / 4, g), transposed: micro-block (g, col0 / 4) read across) -- and the r values of
+// its four entries, two columns per lane by one 16-byte load (lane j: columns 2 j and 2 j + 1; r > 8: a second load for
+// 8 + 2 j, 9 + 2 j), so a step is 512 bytes of weights, one weight load, NC vector loads, 2 NC MFMAs.  The four blocks
+// hold partial sums over different entries: two DPP row rotations add them at the end of the tile.
+// A wave executes one record (MWave): up to two runs of steps; the loads of U steps are requested together, whichever
+// run they belong to (uniform selects, straight-line code); the waves of a tile add their partial sums through LDS in
+// wave order: fixed summation order, bitwise reproducible.
+typedef double sp_v2f64u __attribute__((ext_vector_type(2), aligned(8)));  // a pair of vector values: 8-byte aligned
+constexpr int kMtBlock = kMtWaves * 64;
+
+// what a lane needs to address one run
+struct MtRun {
+  const double *W;
+  const int *ix;   // KIND 1: the index list
+  int abase, gstride, ng, src, s0, n;
+  bool valid;
+};
+template <int KIND>
+__device__ __forceinline__ MtRun mt_run(const MSub &U, const double *__restrict__ vals, const int *__restrict__ idxs,
+                                        int kq, int li, int nrows) {
+  MtRun R;
+  R.W = vals + U.w;
+  R.ng = U.ng;
+  R.s0 = U.s0;
+  R.n = U.n;
+  if (KIND == 0) {
+    const int a = li == 0 ? U.loc[0] : li == 1 ? U.loc[1] : li == 2 ? U.loc[2] : U.loc[3];
+    R.valid = a >= 0;
+    R.abase = (a >> 2) * U.ncb * 16 + kq * 4 + (a & 3);
+    R.gstride = 16;
+    R.src = U.src;
+    R.ix = nullptr;
+  } else {
+    const int col = U.loc[0] + li;
+    R.valid = li < nrows;
+    R.abase = (col >> 2) * 16 + (col & 3) * 4 + kq;
+    R.gstride = U.ncb * 16;
+    R.src = 0;
+    R.ix = idxs + U.src;
+  }
+  if (!R.valid) R.abase = 0;
+  return R;
+}
+
+// All steps of a record: flattened step f < a.n belongs to run a, the others to run b; the loads of U steps are requested
+// together whichever run they belong to (indices, then weights, then vector values; uniform selects, straight-line
+// code), then their MFMAs issue.  Measured against this form on a lattice agent (102 us per application): a rolling
+// window that refills every slot right after its MFMAs 123 us; U = 12 / 16 131 / 145 us; per-run linear pointers with
+// immediate offsets, four slots per run, 126 us (108 with two) -- SQ counters put 63 % of the wave cycles into waiting
+// for memory and 230 vector instructions into a wave: the kernel is bound by the three dependent round trips of a wave
+// (record, indices, operands) inside launches of 30 MB, not by its instruction stream.
+template <int KIND, int NC, int U>
+__device__ __forceinline__ void mt_record(const MtRun &a, const MtRun &b, int kq, int blk, int jj, int r,
+                                          const double *__restrict__ y, double (&d)[NC][2][2]) {
+  const int ntot = a.n + b.n;
+  for (int f0 = 0; f0 < ntot; f0 += U) {
+    int p[U], ao[U];
+    const double *wp[U];
+    bool ok[U];
+    double av[U];
+    sp_v2f64u bv[U][NC];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int f = f0 + u;
+      const bool ina = f < a.n;  // uniform
+      const int s = ina ? a.s0 + f : b.s0 + (f - a.n);
+      const int ng = ina ? a.ng : b.ng;
+      const int g = 4 * s + blk;
+      ok[u] = f < ntot && g < ng && (ina ? a.valid : b.valid);
+      const int gc = (f < ntot && g < ng) ? g : 0;
+      wp[u] = ina ? a.W : b.W;
+      ao[u] = (ina ? a.abase : b.abase) + gc * (ina ? a.gstride : b.gstride);
+      if (KIND == 0)
+        p[u] = (ina ? a.src : b.src) + 4 * gc + kq;
+      else
+        p[u] = (ina ? a.ix : b.ix)[4 * gc + kq];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) av[u] = ok[u] ? wp[u][ao[u]] : 0.0;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) bv[u][c] = *reinterpret_cast<const sp_v2f64u *>(y + (size_t)(p[u] * r + jj + 8 * c));
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        d[c][0][u & 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[u], bv[u][c].x, d[c][0][u & 1], 0, 0, 0);
+        d[c][1][u & 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[u], bv[u][c].y, d[c][1][u & 1], 0, 0, 0);
+      }
+  }
+}
+
+// a wave-uniform record, read through the scalar cache (constant address space) into SGPRs, field by field (a union
+// or a struct copy through this address space sends the record through scratch memory)
+__device__ __forceinline__ void mt_load_sub(const __attribute__((address_space(4))) int *p, MSub &U) {
+  U.w = (long long)(((unsigned long long)(unsigned)p[1] << 32) | (unsigned long long)(unsigned)p[0]);
+  U.ncb = p[2];
+  U.ng = p[3];
+  U.src = p[4];
+  U.s0 = p[5];
+  U.n = p[6];
+  U.pad = 0;
+  U.loc[0] = p[8];
+  U.loc[1] = p[9];
+  U.loc[2] = p[10];
+  U.loc[3] = p[11];
+}
+
+template <int NC, int U>
+__global__ __launch_bounds__(kMtBlock) void k_sp_mtile(const MWave *__restrict__ recs, const double *__restrict__ vals,
+                                                        const int *__restrict__ idxs, double *__restrict__ y, int r,
+                                                        Gate g, int exp) {
+  __shared__ double s_part[kMtWaves][NC * 2][64];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  typedef const __attribute__((address_space(4))) int *ConstInts;
+  ConstInts rp = (ConstInts)(recs + ((size_t)blockIdx.x * kMtWaves + wave));
+  const int t_out = rp[0], t_carry = rp[1], t_nrows = rp[2], t_kind = rp[3], t_first = rp[4], t_n = rp[5];
+  // the gate is tested AFTER the record has been requested: the two loads travel together
+  if (sp_gated(g.ctl, g.seq, g.gate)) return;
+  const int kq = lane >> 4, blk = (lane >> 2) & 3, li = lane & 3;  // operand roles: K entry, block, row (A) / pair (B)
+  const int jj = 2 * li;
+  // the old values this tile adds to (result roles: row kq, block 0, columns 8 c + 2 li + h); first wave of the tile only
+  const bool writer = t_nrows > 0 && t_first == wave && blk == 0 && kq < t_nrows;
+  if (exp == 1) {
+    if (writer && jj < r) y[(size_t)(t_out + kq) * r + jj] = 0.0;
+    return;
+  }
+  double cv[NC][2];
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int col = 8 * c + jj + h;
+      cv[c][h] = (writer && t_carry >= 0 && col < r) ? y[(size_t)(t_carry + kq) * r + col] : 0.0;
+    }
+  double d[NC][2][2];
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) d[c][h][0] = d[c][h][1] = 0.0;
+  for (;;) {
+    MSub sa, sb;
+    mt_load_sub(rp + 8, sa);
+    mt_load_sub(rp + 20, sb);
+    const int next = rp[6];
+    if (exp != 2) {
+      if (t_kind == 0)
+        mt_record<0, NC, U>(mt_run<0>(sa, vals, idxs, kq, li, t_nrows), mt_run<0>(sb, vals, idxs, kq, li, t_nrows), kq, blk,
+                            jj, r, y, d);
+      else
+        mt_record<1, NC, U>(mt_run<1>(sa, vals, idxs, kq, li, t_nrows), mt_run<1>(sb, vals, idxs, kq, li, t_nrows), kq, blk,
+                            jj, r, y, d);
+    }
+    if (next < 0) break;
+    rp = (ConstInts)(recs + next);  // tiles of many short segments: the wave's work continues in a chained record
+  }
+  double sum[NC][2];
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      double v = d[c][h][0] + d[c][h][1];
+      v += dpp_move<0x124>(v);  // row_ror:4
+      v += dpp_move<0x128>(v);  // row_ror:8: the four blocks of a 16-lane row summed
+      sum[c][h] = v;
+    }
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) s_part[wave][c * 2 + h][lane] = sum[c][h];
+  __syncthreads();
+  if (!writer) return;
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      double t = sum[c][h];
+      for (int w = 1; w < t_n; ++w) t += s_part[wave + w][c * 2 + h][lane];
+      const int col = 8 * c + jj + h;
+      if (col < r) y[(size_t)(t_out + kq) * r + col] = cv[c][h] + t;
+    }
+}
+
+bool launch_mtile(hipStream_t st, int r, const SpLevel &lv, const MWave *recs, const double *vals, const int *idxs,
+                  double *y, Gate g) {
+  if (r < 1 || r > 16) return false;
+  if (lv.ntasks == 0) return true;
+  static const int unroll = [] {
+    const char *e = std::getenv("DCORA_SP_UNROLL");
+    return e ? atoi(e) : 8;
+  }();
+  static const int exp = [] {
+    const char *e = std::getenv("DCORA_SP_EXP");
+    return e ? atoi(e) : 0;
+  }();
+  const MWave *rp = recs + lv.task0;
+  if (r <= 8) {
+    if (unroll == 4)
+      hipLaunchKernelGGL((k_sp_mtile<1, 4>), dim3(lv.ntasks), dim3(kMtBlock), 0, st, rp, vals, idxs, y, r, g, exp);
+    else
+      hipLaunchKernelGGL((k_sp_mtile<1, 8>), dim3(lv.ntasks), dim3(kMtBlock), 0, st, rp, vals, idxs, y, r, g, exp);
+  } else {
+    hipLaunchKernelGGL((k_sp_mtile<2, 4>), dim3(lv.ntasks), dim3(kMtBlock), 0, st, rp, vals, idxs, y, r, g, exp);
+  }
+  return true;
+}
+
 template <int R>
 void launch_multi_r(hipStream_t st, int grid, const PTask *tp, const SpClasses &C, const PSeg *segs, const double *vals,
                     const int *idxs, double *y, Gate g) {
@@ -572,10 +786,16 @@ __global__ __launch_bounds__(256) void k_fill_weights(long long nf, const DFill 
         case 3:
           if (a0 + j < c && q <= j) v = F.src[(size_t)(a0 + j) * c + a0 + q];
           break;
+        case 5:
+          break;
         default:
           if (j < F.m) v = F.src[(size_t)j * c + a0 + q];
           break;
       }
+    }
+    if (F.kind == 5) {  // micro-blocks: e = (cb - loc[0]) 16 + (col % 4) 4 + row % 4
+      const int cb = F.loc[0] + (int)(e >> 4), col = cb * 4 + (int)((e >> 2) & 3), row = a0 + (int)(e & 3);
+      v = (e < n && row < F.m && col < c) ? F.src[(size_t)row * c + col] : 0.0;
     }
     w[e] = v;
   }
@@ -624,6 +844,7 @@ bool DeviceWeightSink::fill_on_device(const std::vector<partinv::Fill> &fills, l
         return (long long)mx + 1;
       }
       case 3: return std::min<long long>((long long)f.a0 + f.len, f.c);
+      case 5: return std::min<long long>((long long)f.a0 + 4, f.m);
       default: return std::min<long long>(f.len, f.m);
     }
   };
@@ -752,6 +973,8 @@ int SpImage::upload(const PartInvHost &P, DeviceWeightSink *streamed) {
   nnzL = P.nnzL;
   npieces = P.npieces;
   weights_per_apply = P.weights_read_per_apply;
+  // (the matrix-pipe kernel may read up to three groups past the end of a matrix / an index list: P.vals and P.idxs end
+  // with that much padding, host_partinv3.cpp)
   if (streamed && streamed->vals.p) {
     vals = std::move(streamed->vals);
   } else {
@@ -764,6 +987,10 @@ int SpImage::upload(const PartInvHost &P, DeviceWeightSink *streamed) {
   DCORA_HIP(hipMemcpy(tasks.p, P.tasks.data(), P.tasks.size() * sizeof(PTask), hipMemcpyHostToDevice));
   DCORA_HIP(segs.alloc(P.segs.size()));
   DCORA_HIP(hipMemcpy(segs.p, P.segs.data(), P.segs.size() * sizeof(PSeg), hipMemcpyHostToDevice));
+  if (!P.mwaves.empty()) {  // matrix-pipe schedule
+    DCORA_HIP(mwaves.alloc(P.mwaves.size()));
+    DCORA_HIP(hipMemcpy(mwaves.p, P.mwaves.data(), P.mwaves.size() * sizeof(MWave), hipMemcpyHostToDevice));
+  }
   DCORA_HIP(perm.alloc(P.perm.size()));
   DCORA_HIP(hipMemcpy(perm.p, P.perm.data(), P.perm.size() * sizeof(int), hipMemcpyHostToDevice));
   DCORA_HIP(out_off.alloc(P.out_off.size()));
@@ -772,6 +999,13 @@ int SpImage::upload(const PartInvHost &P, DeviceWeightSink *streamed) {
   rows_total = 0;
   for (const PTask &t : P.tasks) rows_total += t.nrows;
   nsegs_total = (long)P.segs.size();
+  nmwaves_total = (long)P.mwaves.size();
+  for (const SpLevel &lv : P.levels)
+    if (lv.mpipe)
+      for (int q = 0; q < lv.ntasks * kMtWaves; ++q) {
+        const MWave &t = P.mwaves[(size_t)lv.task0 + q];
+        if (t.nrows > 0 && t.red_first == q % kMtWaves) rows_total += t.nrows;
+      }
   nhub = P.hub.h;
   hub_nnz = (long)P.hub.aval.size();
   {
@@ -808,7 +1042,8 @@ int SpImage::upload(const PartInvHost &P, DeviceWeightSink *streamed) {
 
 size_t SpImage::device_bytes() const {
   return vals.n * sizeof(double) + (idxs.n + perm.n + out_off.n + in_pos.n + out_pos.n) * sizeof(int) +
-         tasks.n * sizeof(PTask) + segs.n * sizeof(PSeg) + (hub_aval.n + hub_U.n + hub_Sinv.n) * sizeof(double) +
+         tasks.n * sizeof(PTask) + segs.n * sizeof(PSeg) + mwaves.n * sizeof(MWave) +
+         (hub_aval.n + hub_U.n + hub_Sinv.n) * sizeof(double) +
          (hub_idx.n + hub_ap.n + hub_apos.n) * sizeof(int);
 }
 
@@ -817,9 +1052,10 @@ int SparsePrecond::attach(std::shared_ptr<const SpImage> image, int rcap_) {
   rcap = rcap_;
   weights_per_apply = im->weights_per_apply;
   const int k = im->k;
-  // two ping-pong images of the vector; padded pairs may touch one unknown past the end
-  DCORA_HIP(y.alloc((size_t)(2 * k + 2) * rcap));
-  DCORA_HIP(hipMemset(y.p, 0, (size_t)(2 * k + 2) * rcap * sizeof(double)));
+  // two ping-pong images of the vector; padded pairs / K steps may touch up to three unknowns past the end
+  // (the matrix-pipe kernel: a step past the end of a run of the vector, 16 unknowns, and seven values past a pair)
+  DCORA_HIP(y.alloc((size_t)(2 * k + 20) * rcap + 8));
+  DCORA_HIP(hipMemset(y.p, 0, ((size_t)(2 * k + 20) * rcap + 8) * sizeof(double)));
   if (im->nhub > 0) {
     DCORA_HIP(hub_w.alloc((size_t)im->nhub * kHubSplit * rcap));
     DCORA_HIP(hipMemset(hub_w.p, 0, (size_t)im->nhub * kHubSplit * rcap * sizeof(double)));
@@ -851,7 +1087,10 @@ void SparsePrecond::apply(hipStream_t st, int r, Buf2 R, double *Z, Gate g, bool
     if (!go_on()) return;
   }
   for (const SpLevel &lv : levels) {
-    launch_level(st, r, lv, tasks.p, segs.p, vals.p, idxs.p, y.p, g);
+    if (lv.mpipe)
+      launch_mtile(st, r, lv, I.mwaves.p, vals.p, idxs.p, y.p, g);
+    else
+      launch_level(st, r, lv, tasks.p, segs.p, vals.p, idxs.p, y.p, g);
     if (!go_on()) return;
   }
   if (levels_only && nhub == 0) return;
@@ -883,7 +1122,8 @@ SpFold SparsePrecond::fold_generic() const {
 double SparsePrecond::bytes_per_apply(int r) const {
   // stored weights once, the task / segment tables, the vector in and out of every row tile, permutes, hub terms
   const SpImage &I = *im;
-  return 8.0 * I.weights_per_apply + 64.0 * I.ntasks_total + 24.0 * I.nsegs_total + 16.0 * r * I.rows_total +
+  return 8.0 * I.weights_per_apply + 64.0 * I.ntasks_total + 24.0 * I.nsegs_total + 128.0 * I.nmwaves_total +
+         16.0 * r * I.rows_total +
          32.0 * r * (double)I.k + 12.0 * I.hub_nnz + 8.0 * (double)I.nhub * I.k;
 }
 
