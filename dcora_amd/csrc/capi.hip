@@ -1584,29 +1584,3 @@ extern "C" int dcora_debug_grid_barrier(int device, int blocks, int iters, int l
   DCORA_CATCH
 }
 
-// debug / test hook: per-level shape of the partitioned-inverse schedule: out[4 * lev + {0,1,2,3}] =
-// {row tasks, segments, stored weights streamed, lanes per task}; returns the number of levels in *nlev
-extern "C" int dcora_debug_partinv_levels(int n, const int *rp, const int *ci, const double *v, int block, int max_levels,
-                                          int *nlev, double *out) {
-  HostCsr A;
-  A.n = A.ncols = n;
-  A.rp.assign(rp, rp + n + 1);
-  A.ci.assign(ci, ci + rp[n]);
-  A.v.assign(v, v + rp[n]);
-  PartInvHost P;
-  if (!build_partitioned_inverse(A, block, 8, &P)) return DCORA_ERR_NOT_PD;
-  *nlev = (int)P.levels.size();
-  for (int l = 0; l < *nlev && l < max_levels; ++l) {
-    const SpLevel &lv = P.levels[l];
-    double segs = 0, w = 0;
-    for (int t = lv.task0; t < lv.task0 + lv.ntasks; ++t) {
-      segs += P.tasks[t].nseg;
-      for (int s = P.tasks[t].seg0; s < P.tasks[t].seg0 + P.tasks[t].nseg; ++s) w += P.segs[s].len;
-    }
-    out[4 * l] = lv.ntasks;
-    out[4 * l + 1] = segs;
-    out[4 * l + 2] = w;
-    out[4 * l + 3] = lv.lanes;
-  }
-  return DCORA_OK;
-}

@@ -1714,13 +1714,8 @@ int build_partitioned_inverse_auto(const HostCsr &A, int block, int nthreads, in
     return okh ? DCORA_OK : (out->weights_ok ? DCORA_ERR_NOT_PD : DCORA_ERR_HIP);
   }
   PiecewiseFactor F;
-  // a sink that forms the weights on the device wants the sources left there (merged schedule only: the per-level
-  // schedule computes some of its sources on the host)
-  static const bool schedule_v1 = [] {
-    const char *e = std::getenv("DCORA_SP_SCHEDULE");
-    return e && std::strcmp(e, "v1") == 0;
-  }();
-  F.want_device_sources = out->sink && out->sink->wants_device_sources() && !schedule_v1;
+  // a sink that forms the weights on the device wants the sources left there
+  F.want_device_sources = out->sink && out->sink->wants_device_sources();
   const auto t0 = std::chrono::steady_clock::now();
   const int rc = device_chol_piecewise_factor(A, block, nd_top_default(), device, &F);
   if (rc) return rc;

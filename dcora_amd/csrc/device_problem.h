@@ -117,14 +117,12 @@ constexpr int kDensePrecondMaxK = 8000;
 // Q + reg I (the staircase levels, problems re-created per update) through the cache of precond_cache.h
 struct SpImage {
   int k = 0, npieces = 0;
-  long nnzL = 0, ntasks_total = 0, nsegs_total = 0, nmwaves_total = 0;
+  long nnzL = 0, nmwaves_total = 0;
   double weights_per_apply = 0, rows_total = 0;
   std::vector<SpLevel> levels;
   DevBuf<double> vals;
   DevBuf<int> idxs, perm, out_off;
-  DevBuf<PTask> tasks;
-  DevBuf<PSeg> segs;
-  DevBuf<MWave> mwaves;  // matrix-pipe schedule (sparse_precond.h)
+  DevBuf<MWave> mwaves;  // the wave records of the schedule (sparse_precond.h)
   // hubs (PartInvHub): Schur complement data
   int nhub = 0;
   long hub_nnz = 0;

@@ -337,9 +337,8 @@ int DeviceProblem::build_preconditioner(const HostCsr &Qh, double reg) {
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tu).count(),
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
       if (std::getenv("DCORA_INIT_TIMING"))
-        fprintf(stderr, "[precond] host image: %.1f MB tasks, %.1f MB segments, %.1f MB indices, %.1f MB weights\n",
-                P.tasks.size() * sizeof(PTask) / 1e6, P.segs.size() * sizeof(PSeg) / 1e6, P.idxs.size() * 4 / 1e6,
-                P.vals.size() * 8 / 1e6);
+        fprintf(stderr, "[precond] host image: %.1f MB wave records, %.1f MB indices, %.1f MB weights\n",
+                P.mwaves.size() * sizeof(MWave) / 1e6, P.idxs.size() * 4 / 1e6, P.vals.size() * 8 / 1e6);
       ent.sparse = img;
       ent.nnzL = P.nnzL;
       ent.bytes = img->device_bytes();

@@ -1,4 +1,5 @@
-// Host-side construction of the partitioned inverse of a nested-dissection Cholesky factor (sparse_precond.h).
+// Host-side construction of the partitioned inverse of a nested-dissection Cholesky factor (sparse_precond.h):
+// pieces, their inverses, hubs; the schedule of the replay and the layout of the stored weights are host_partinv3.cpp's.
 // Setup-time code: runs once per Q; the per-iteration path only replays the schedule on the device.
 #include <algorithm>
 #include <atomic>
@@ -20,14 +21,6 @@ using namespace partinv;
 namespace {
 
 constexpr int kBigPiece = 384;  // pieces this wide are inverted by all threads together (the merged top of the tree)
-
-int pick_lanes(double avg_entries_per_tile, int ntasks) {
-  (void)ntasks;
-  if (avg_entries_per_tile >= 160) return 256;
-  if (avg_entries_per_tile >= 20) return 64;
-  if (avg_entries_per_tile >= 8) return 32;
-  return 16;
-}
 
 }  // namespace
 
@@ -305,265 +298,16 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
     for (auto &t : th) t.join();
   }
   const auto T2 = tnow();
-  // ---- schedule: merged levels (host_partinv2.cpp) unless DCORA_SP_SCHEDULE=v1 asks for one launch per tree level ----
-  static const int schedule = [] {  // 3: panels (default), 2: merged 4-row tiles, 1: one launch per tree level
-    const char *e = std::getenv("DCORA_SP_SCHEDULE");
-    return e && std::strcmp(e, "v1") == 0 ? 1 : e && std::strcmp(e, "v2") == 0 ? 2 : 3;
-  }();
-  const bool merged = schedule != 1;
-  if (merged) {
+  // ---- schedule and stored weights: the matrix-pipe schedule (host_partinv3.cpp) ----
+  {
     std::vector<const double *> Mgiven((size_t)np, nullptr);
     for (int s = 0; s < np; ++s)
       if (F.pieces[s].mtop()) Mgiven[s] = F.pieces[s].mtop();
-    if (schedule == 3)
-      layout_mpipe(pc, Mgiven, piece_of, k, nlev, nthreads, timing, &P);
-    else
-      layout_merged(pc, Mgiven, piece_of, k, nlev, nthreads, timing, &P);
+    layout_mpipe(pc, Mgiven, piece_of, k, nlev, nthreads, timing, &P);
     if (timing)
-      std::fprintf(stderr, "[partinv] k %d pieces %d levels %d: piece inverses %.1f, %s schedule %.1f ms\n", k, np, nlev,
-                   tms(T1, T2), schedule == 3 ? "matrix-pipe" : "merged", tms(T2, tnow()));
-  } else {
-  // ---- schedule.  Which buffer holds a piece's current value is static; start: everything in buffer 0.
-  // A task is a tile of up to kSpTile consecutive output rows that gather from the same sources; the weights of
-  // a segment are stored entry-major over the tile's rows:  [entry j][row q]. ----
-  constexpr int RT = kSpTile;
-  std::vector<int> bit((size_t)np, 0);
-  std::vector<std::vector<int>> by_level((size_t)nlev);
-  for (int s = 0; s < np; ++s) by_level[pc[s].level].push_back(s);
-  auto pos = [&](int s_bit, int row) { return s_bit * k + row; };
-  std::vector<int> touched_stamp((size_t)np, -1);
-  std::vector<std::vector<std::pair<int, int>>> hits((size_t)k);  // per row: (piece, local row) of this level
-  double weights = 0;
-  // The weights of a segment ([entry j][tile row q], j < len) are only RESERVED while the schedule is laid out; the
-  // (by far larger) job of writing them -- 0.8 G doubles for the whole 100k lattice -- is done afterwards by all threads
-  std::vector<Fill> fills;
-  std::vector<std::vector<double>> top_blocks;  // D^-T D^-1 of the top pieces: alive until the fill
-  long long cursor = 0;
-  auto reserve = [&](int kind, int nrows, int len, const double *base, int c, int a0, int m, const int *loc) {
-    Fill f;
-    f.off = cursor;
-    f.base = base;
-    f.kind = kind;
-    f.nrows = nrows;
-    f.len = len;
-    f.c = c;
-    f.a0 = a0;
-    f.m = m;
-    for (int q = 0; q < kSpTile; ++q) f.loc[q] = loc ? loc[q] : 0;
-    fills.push_back(f);
-    cursor += (long long)len * nrows;
-    weights += (double)len * nrows;
-    return f.off;
-  };
-  // forward: y <- L_t^-1 y, leaves first.  The top level is skipped here: its pieces feed nobody (no rows below),
-  // so their forward and backward steps are adjacent and are applied together as the symmetric D^-T D^-1 below
-  for (int t = 0; t + 1 < nlev; ++t) {
-    SpLevel lv;
-    lv.task0 = (int)P.tasks.size();
-    std::vector<int> affected;
-    for (int s : by_level[t]) {
-      touched_stamp[s] = t;
-      affected.push_back(s);
-    }
-    std::vector<int> hit_rows;
-    for (int s : by_level[t]) {
-      const std::vector<int> &rows = pc[s].rows;
-      for (int a = 0; a < (int)rows.size(); ++a) {
-        const int i = rows[a], q = piece_of[i];
-        if (touched_stamp[q] != t) {
-          touched_stamp[q] = t;
-          affected.push_back(q);
-        }
-        if (hits[i].empty()) hit_rows.push_back(i);
-        hits[i].emplace_back(s, a);
-      }
-    }
-    long long seg_len_sum = 0, seg_cnt = 0;
-    for (int q : affected) {
-      const Piece &p = pc[q];
-      const bool own = (p.level == t);
-      for (int a0 = 0; a0 < p.c;) {
-        int nrows = 1;
-        if (own) {
-          nrows = std::min(RT, p.c - a0);
-        } else {
-          // consecutive rows fed by the same pieces share a tile
-          const auto &h0 = hits[p.c0 + a0];
-          while (nrows < RT && a0 + nrows < p.c) {
-            const auto &h1 = hits[p.c0 + a0 + nrows];
-            bool same = h1.size() == h0.size();
-            for (size_t u = 0; same && u < h0.size(); ++u) same = (h1[u].first == h0[u].first);
-            if (!same) break;
-            ++nrows;
-          }
-        }
-        PTask T;
-        T.out = pos(1 - bit[q], p.c0 + a0);
-        T.nrows = nrows;
-        T.seg0 = (int)P.segs.size();
-        if (own) {
-          T.carry = -1;
-          PSeg S;
-          S.len = pad2(a0 + nrows);
-          S.src = pos(bit[q], p.c0);
-          S.idx = 0;
-          S.pad = 0;
-          const int c = p.c;
-          S.w = reserve(0, nrows, S.len, p.dinv(), c, a0, 0, nullptr);
-          P.segs.push_back(S);
-        } else {
-          T.carry = pos(bit[q], p.c0 + a0);
-          const auto &h0 = hits[p.c0 + a0];
-          for (size_t u = 0; u < h0.size(); ++u) {
-            const int sid = h0[u].first;
-            const Piece &s = pc[sid];
-            int loc[RT] = {0};
-            for (int r_ = 0; r_ < nrows; ++r_) loc[r_] = hits[p.c0 + a0 + r_][u].second;
-            PSeg S;
-            S.len = pad2(s.c);
-            S.src = pos(bit[sid], s.c0);
-            S.idx = 0;
-            S.pad = 0;
-            const int c = s.c;
-            S.w = reserve(1, nrows, S.len, s.w(), c, 0, 0, loc);
-            P.segs.push_back(S);
-          }
-        }
-        T.nseg = (int)P.segs.size() - T.seg0;
-        for (int q2 = T.seg0; q2 < T.seg0 + T.nseg; ++q2) {
-          seg_len_sum += P.segs[q2].len;
-          ++seg_cnt;
-        }
-        inline_first_segment(T, P.segs);
-        P.tasks.push_back(T);
-        a0 += nrows;
-      }
-    }
-    for (int i : hit_rows) hits[i].clear();
-    for (int q : affected) bit[q] ^= 1;
-    lv.ntasks = (int)P.tasks.size() - lv.task0;
-    lv.avg_entries = lv.ntasks ? (double)seg_len_sum / lv.ntasks : 1.0;
-    lv.lanes = pick_lanes(lv.avg_entries, lv.ntasks);
-    P.levels.push_back(lv);
+      std::fprintf(stderr, "[partinv] k %d pieces %d levels %d: piece inverses %.1f, schedule %.1f ms\n", k, np, nlev,
+                   tms(T1, T2), tms(T2, tnow()));
   }
-  P.nforward = nlev - 1;
-  // backward: x <- L_t^-T x, root first.  Only the piece's own rows change; they gather from their own old
-  // values and from the (final) values of the rows below.
-  for (int t = nlev - 1; t >= 0; --t) {
-    SpLevel lv;
-    lv.task0 = (int)P.tasks.size();
-    long long seg_len_sum = 0, seg_cnt = 0;
-    for (int s : by_level[t]) {
-      const Piece &p = pc[s];
-      const int m = (int)p.rows.size(), c = p.c;
-      const int idx0 = (int)P.idxs.size();
-      for (int i : p.rows) P.idxs.push_back(pos(bit[piece_of[i]], i));
-      if (m & 1) P.idxs.push_back(P.idxs.back());  // padded pair: weight 0, any valid position
-      // top level only: D^-T D^-1 (c x c, symmetric), kept until the weights are written
-      const double *Mtop = nullptr;
-      if (t == nlev - 1) {
-        if (F.pieces[s].mtop()) {  // formed on the device
-          Mtop = F.pieces[s].mtop();
-        } else {
-        top_blocks.emplace_back((size_t)c * c, 0.0);
-        std::vector<double> &M = top_blocks.back();
-        Mtop = M.data();
-        if (c >= kBigPiece && nthreads > 1) {
-          // row a of the lower triangle by one thread: M(a, j) = sum_{i >= a} Dinv(i, a) Dinv(i, j), j <= a
-          parallel_for(c, nthreads, 4, [&](int a) {
-            double *ma = &M[(size_t)a * c];
-            for (int i = a; i < c; ++i) {
-              const double *di = p.dinv() + (size_t)i * c;
-              const double v = di[a];
-              if (v == 0.0) continue;
-              for (int j = 0; j <= a; ++j) ma[j] += v * di[j];
-            }
-          });
-          for (int a = 0; a < c; ++a)
-            for (int j = a + 1; j < c; ++j) M[(size_t)a * c + j] = M[(size_t)j * c + a];
-        } else {
-          for (int i = 0; i < c; ++i) {
-            const double *di = p.dinv() + (size_t)i * c;
-            for (int a = 0; a <= i; ++a) {
-              const double v = di[a];
-              if (v == 0.0) continue;
-              double *ma = &M[(size_t)a * c];
-              for (int j = 0; j <= i; ++j) ma[j] += v * di[j];
-            }
-          }
-        }
-        }
-      }
-      for (int a0 = 0; a0 < c; a0 += RT) {
-        const int nrows = std::min(RT, c - a0);
-        PTask T;
-        T.out = pos(1 - bit[s], p.c0 + a0);
-        T.carry = -1;
-        T.nrows = nrows;
-        T.seg0 = (int)P.segs.size();
-        PSeg S;
-        S.idx = 0;
-        S.pad = 0;
-        if (t == nlev - 1) {
-          S.len = pad2(c);
-          S.src = pos(bit[s], p.c0);
-          S.w = reserve(2, nrows, S.len, Mtop, c, a0, 0, nullptr);
-        } else {
-          S.len = pad2(c - a0);
-          S.src = pos(bit[s], p.c0 + a0);
-          // (D^-T)(a0 + q, a0 + j) = Dinv(a0 + j, a0 + q), zero below the diagonal of the transpose
-          S.w = reserve(3, nrows, S.len, p.dinv(), c, a0, 0, nullptr);
-        }
-        P.segs.push_back(S);
-        seg_len_sum += S.len;
-        ++seg_cnt;
-        if (m > 0) {
-          PSeg Wt;
-          Wt.len = pad2(m);
-          Wt.src = -1;
-          Wt.idx = idx0;
-          Wt.pad = 0;
-          Wt.w = reserve(4, nrows, Wt.len, p.w(), c, a0, m, nullptr);
-          P.segs.push_back(Wt);
-          seg_len_sum += Wt.len;
-          ++seg_cnt;
-        }
-        T.nseg = (int)P.segs.size() - T.seg0;
-        inline_first_segment(T, P.segs);
-        P.tasks.push_back(T);
-      }
-    }
-    for (int s : by_level[t]) bit[s] ^= 1;
-    lv.ntasks = (int)P.tasks.size() - lv.task0;
-    lv.avg_entries = lv.ntasks ? (double)seg_len_sum / lv.ntasks : 1.0;
-    lv.lanes = pick_lanes(lv.avg_entries, lv.ntasks);
-    P.levels.push_back(lv);
-  }
-  // ---- write the weights ----
-  P.weights_ok = write_weights(fills, cursor, nthreads, &P);
-  top_blocks.clear();
-  P.out_off.resize((size_t)k);
-  for (int j = 0; j < k; ++j) P.out_off[j] = pos(bit[piece_of[j]], j);
-  P.weights_read_per_apply = weights;
-  if (timing) {
-    int cmax = 0;
-    for (const Piece &p : pc) cmax = std::max(cmax, p.c);
-    std::fprintf(stderr, "[partinv] k %d pieces %d levels %d widest piece %d: piece inverses %.1f, schedule %.1f ms\n",
-                 k, np, nlev, cmax, tms(T1, T2), tms(T2, tnow()));
-    for (size_t li = 0; li < P.levels.size(); ++li) {
-      const SpLevel &lv = P.levels[li];
-      long long w = 0, sg = 0;
-      for (int t = lv.task0; t < lv.task0 + lv.ntasks; ++t) {
-        const PTask &T = P.tasks[(size_t)t];
-        for (int q = T.seg0; q < T.seg0 + T.nseg; ++q) w += (long long)P.segs[(size_t)q].len * T.nrows;
-        sg += T.nseg;
-      }
-      std::fprintf(stderr, "[partinv]   level %2zu%s tiles %6d lanes %3d waves %6lld segments/tile %.2f weights %.2f MB\n", li,
-                   (int)li < P.nforward ? "f" : "b", lv.ntasks, lv.lanes, (long long)lv.ntasks * lv.lanes / 64,
-                   lv.ntasks ? (double)sg / lv.ntasks : 0.0, 8e-6 * (double)w);
-    }
-  }
-  }  // schedule v1
   // ---- hubs: U = A11^-1 a with the leading block of L, Sc = alpha - a^T U ----
   if (h > 0) {
     PartInvHub &H = P.hub;
@@ -631,82 +375,17 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
 
 namespace partinv {
 namespace {
-// the weights of one fill; w points at weight f.off and the extent of the fill is zero
-// w[j nr + q] = row_q[j] for j < hi[q]: the tile's rows are read side by side and the weights leave in storage order
-inline void interleave_rows(const double *const *row, const int *hi, int nr, double *w) {
-  int hmin = hi[0], hmax = hi[0];
-  for (int q = 1; q < nr; ++q) {
-    hmin = std::min(hmin, hi[q]);
-    hmax = std::max(hmax, hi[q]);
-  }
-  if (nr == 4) {
-    const double *r0 = row[0], *r1 = row[1], *r2 = row[2], *r3 = row[3];
-    for (int j = 0; j < hmin; ++j) {
-      double *o = w + (size_t)j * 4;
-      o[0] = r0[j];
-      o[1] = r1[j];
-      o[2] = r2[j];
-      o[3] = r3[j];
-    }
-  } else {
-    for (int j = 0; j < hmin; ++j)
-      for (int q = 0; q < nr; ++q) w[(size_t)j * nr + q] = row[q][j];
-  }
-  for (int j = std::max(hmin, 0); j < hmax; ++j)
-    for (int q = 0; q < nr; ++q)
-      if (j < hi[q]) w[(size_t)j * nr + q] = row[q][j];
-}
+// the weights of one fill (micro-blocks: rows a0 .. a0 + 3 of an m x c matrix, micro-block columns [loc[0], loc[1]));
+// w points at weight f.off and the extent of the fill is zero
 inline void fill_one(const Fill &f, double *w) {
-  const int nr = f.nrows, c = f.c, a0 = f.a0;
-  const double *row[kSpTile] = {nullptr, nullptr, nullptr, nullptr};
-  int hi[kSpTile] = {0, 0, 0, 0};
-  if (nr <= 0) return;
-  switch (f.kind) {
-    case 0:  // rows a0 + q of a lower-triangular matrix
-      for (int q = 0; q < nr; ++q) {
-        row[q] = f.base + (size_t)(a0 + q) * c;
-        hi[q] = std::max(0, std::min(std::min(f.len, c), a0 + q + 1));
-      }
-      interleave_rows(row, hi, nr, w);
-      break;
-    case 1:  // rows loc[q] of a matrix with c columns
-      for (int q = 0; q < nr; ++q) {
-        row[q] = f.base + (size_t)f.loc[q] * c;
-        hi[q] = std::max(0, std::min(f.len, c));
-      }
-      interleave_rows(row, hi, nr, w);
-      break;
-    case 2:  // rows a0 + q of a full c x c matrix
-      for (int q = 0; q < nr; ++q) {
-        row[q] = f.base + (size_t)(a0 + q) * c;
-        hi[q] = std::max(0, std::min(f.len, c));
-      }
-      interleave_rows(row, hi, nr, w);
-      break;
-    case 5: {  // micro-blocks: rows a0 .. a0 + 3, micro-block columns [loc[0], loc[1])
-      const int cb0 = f.loc[0], cb1 = f.loc[1];
-      for (int cb = cb0; cb < cb1; ++cb)
-        for (int ee = 0; ee < 4; ++ee) {
-          const int e = cb * 4 + ee;
-          if (e >= c) break;
-          for (int aa = 0; aa < 4 && a0 + aa < f.m; ++aa)
-            w[(size_t)(cb - cb0) * 16 + ee * 4 + aa] = f.base[(size_t)(a0 + aa) * c + e];
-        }
-      break;
+  const int c = f.c, a0 = f.a0, cb0 = f.loc[0], cb1 = f.loc[1];
+  for (int cb = cb0; cb < cb1; ++cb)
+    for (int ee = 0; ee < 4; ++ee) {
+      const int e = cb * 4 + ee;
+      if (e >= c) break;
+      for (int aa = 0; aa < 4 && a0 + aa < f.m; ++aa)
+        w[(size_t)(cb - cb0) * 16 + ee * 4 + aa] = f.base[(size_t)(a0 + aa) * c + e];
     }
-    case 3:  // (D^-T)(a0 + q, a0 + j) = Dinv(a0 + j, a0 + q), j >= q
-      for (int j = 0; j < f.len && a0 + j < c; ++j) {
-        const double *src = f.base + (size_t)(a0 + j) * c + a0;
-        for (int q = 0; q < nr && q <= j; ++q) w[(size_t)j * nr + q] = src[q];
-      }
-      break;
-    default:  // transposed block: base(j, a0 + q)
-      for (int j = 0; j < f.len && j < f.m; ++j) {
-        const double *src = f.base + (size_t)j * c + a0;
-        for (int q = 0; q < nr; ++q) w[(size_t)j * nr + q] = src[q];
-      }
-      break;
-  }
 }
 }  // namespace
 
@@ -751,7 +430,7 @@ bool write_weights(const std::vector<Fill> &fills, long long total, int nthreads
     int i1 = i0;
     long long end = nf ? (i0 < nf ? at(i0).off : total) : total;
     if (i0 < nf) {
-      // at least one fill per chunk (an extent never exceeds the cap: a fill is a tile of a few rows)
+      // at least one fill per chunk (an extent never exceeds the cap: a fill is at most 2048 weights)
       end = extent_end(i0);
       i1 = i0 + 1;
       while (i1 < nf && extent_end(i1) - off0 <= cap) {
@@ -783,10 +462,8 @@ void partitioned_inverse_apply_host(const PartInvHost &P, int r, const double *R
   std::vector<double> y((size_t)(2 * k + 4) * r, 0.0);  // padded pairs / K steps may touch up to three unknowns past the end
   for (int j = 0; j < k; ++j)
     for (int t = 0; t < r; ++t) y[(size_t)j * r + t] = R[(size_t)P.perm[j] * r + t];
-  std::vector<double> acc;
-  std::vector<double> outv;
   for (const SpLevel &lv : P.levels) {
-    if (lv.mpipe) {  // matrix-pipe schedule: the wave records executed by plain loops
+    {  // the wave records executed by plain loops: every tile of a launch reads the state before the launch
       struct Out {
         int out, nrows;
         std::vector<double> v;
@@ -841,33 +518,6 @@ void partitioned_inverse_apply_host(const PartInvHost &P, int r, const double *R
       for (const Out &o : outs)
         for (int a = 0; a < o.nrows; ++a)
           for (int t = 0; t < r; ++t) y[((size_t)o.out + a) * r + t] = o.v[(size_t)a * r + t];
-      continue;
-    }
-    // every task of a level reads the state before the level: evaluate all, then store
-    outv.assign((size_t)lv.ntasks * kSpTile * r, 0.0);
-    for (int q = 0; q < lv.ntasks; ++q) {
-      const PTask &T = P.tasks[(size_t)lv.task0 + q];
-      acc.assign((size_t)T.nrows * r, 0.0);
-      for (int s = T.seg0; s < T.seg0 + T.nseg; ++s) {
-        const PSeg &S = P.segs[(size_t)s];
-        const double *w = &P.vals[(size_t)S.w];
-        for (int j = 0; j < S.len; ++j) {
-          const size_t u = (S.src >= 0) ? (size_t)S.src + j : (size_t)P.idxs[(size_t)S.idx + j];
-          for (int a = 0; a < T.nrows; ++a) {
-            const double wj = w[(size_t)j * T.nrows + a];
-            for (int t = 0; t < r; ++t) acc[(size_t)a * r + t] += wj * y[u * r + t];
-          }
-        }
-      }
-      for (int a = 0; a < T.nrows; ++a)
-        for (int t = 0; t < r; ++t)
-          outv[((size_t)q * kSpTile + a) * r + t] =
-              acc[(size_t)a * r + t] + (T.carry >= 0 ? y[((size_t)T.carry + a) * r + t] : 0.0);
-    }
-    for (int q = 0; q < lv.ntasks; ++q) {
-      const PTask &T = P.tasks[(size_t)lv.task0 + q];
-      for (int a = 0; a < T.nrows; ++a)
-        for (int t = 0; t < r; ++t) y[((size_t)T.out + a) * r + t] = outv[((size_t)q * kSpTile + a) * r + t];
     }
   }
   const PartInvHub &H = P.hub;

@@ -2,21 +2,27 @@
 // (ref src/QuadraticProblem.cpp:70-84; the factor of ref src/Graph.cpp:1901-1917) with the sums over the gathered
 // entries inside v_mfma_f64_4x4x4_4b_f64 (k_sp_mtile, sparse_precond.hip).
 //
-// The algebra and the launches are the merged schedule's (host_partinv2.cpp): with y_s the value of piece s once every
-// piece below it has been applied,
+// The launches (rounds 1-3 applied L^-1 = prod L_s^-1 and L^-T one tree level per launch, 2 depth - 1 dependent launches,
+// then regrouped them; the regrouped form is the only one left).  With y_s the value of piece s once every piece below
+// it has been applied ("pre" value),
 //     y_q = b_q + sum_{s below q} W_s[q] y_s        W_s = -B_s D_s^-1      (forward, leaves first)
 //     x_s = M_s y_s + W_s^T x_{rows(s)}             M_s = D_s^-T D_s^-1    (backward, root first)
-// M tiles spread over the launches between the one that completes y_s and the one that consumes M_s y_s, levels merged
-// in pairs where the fill of W'_s = W_s + sum_p W_p W_s[p] is cheaper than the launch it saves, tiles of up to four
-// consecutive output rows that gather from the same sources.  What changes is the storage and the arithmetic:
+// so D_s^-1 y_s alone is never needed: the two triangular products of a piece are ONE symmetric product z_s = M_s y_s
+// that nothing waits for until the backward sweep reaches s -- those M tiles are spread over the launches between the one
+// that completes y_s and the one that consumes z_s, so that every launch streams about the same number of bytes.  Levels
+// are merged in pairs (t, t + 1) where the fill of  W'_s[q] = W_s[q] + sum_p W_p[q] W_s[p]  (p on level t + 1, formed once
+// at set-up) is cheaper than the launch it saves: the pair's forward launch updates the rows of level t + 1 AND all rows
+// above at once, its backward launch computes x_p and x_s together.  A task is a tile of up to four consecutive output
+// rows that gather from the same sources.  Storage and arithmetic (round 4; the tile schedule before it kept one copy of
+// W per sweep laid out per tile, 4 r running sums per lane and a reduction over the lanes by DPP + LDS):
 //   * every matrix is stored ONCE in 4 x 4 micro-blocks and read directly (forward: the rows of W_s a tile's rows need)
-//     or transposed (backward: W_s^T; M_s, symmetric): the tile schedule kept one copy of W per sweep, laid out per
-//     tile.  Stored weights of one agent of the 100k lattice: 162 MB instead of 288 MB (137 MB without level pairs) --
-//     inside the 256 MB Infinity Cache;
+//     or transposed (backward: W_s^T; M_s, symmetric).  Stored weights of one agent of the 100k lattice: 162 MB instead
+//     of 288 MB (137 MB without level pairs) -- inside the 256 MB Infinity Cache;
 //   * a micro-block is one A operand of v_mfma_f64_4x4x4_4b_f64, which multiplies four independent 4 x 4 blocks per
 //     instruction: a step of a tile consumes 16 gathered entries (512 bytes of weights) in ceil(r / 8) * 2
-//     instructions and the sum over the entries happens in the matrix pipe; the tile kernel kept 4 r running sums per
-//     lane and reduced them over its lanes by DPP + LDS.
+//     instructions and the sum over the entries happens in the matrix pipe;
+//   * the device reads WAVE RECORDS (sparse_precond.h): the host cuts every tile's steps into contiguous shares of about
+//     eight steps, one per wave, and packs eight waves per workgroup.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -571,8 +577,6 @@ void layout_mpipe(const std::vector<Piece> &pc, const std::vector<const double *
     SpLevel lv;
     lv.task0 = (int)P.mwaves.size();
     lv.ntasks = (int)wgs.size();
-    lv.mpipe = 1;
-    lv.multi = 0;
     const size_t base = P.mwaves.size();
     MWave idle;
     std::memset(&idle, 0, sizeof idle);
@@ -642,10 +646,15 @@ void layout_mpipe(const std::vector<Piece> &pc, const std::vector<const double *
         wave += n;
       }
     }
+    for (size_t w = 0; w < wgs.size(); ++w) {
+      int solo = 1;
+      for (int q = 0; q < kMtWaves; ++q) solo &= P.mwaves[base + w * kMtWaves + (size_t)q].red_n <= 1;
+      for (int q = 0; q < kMtWaves; ++q) P.mwaves[base + w * kMtWaves + (size_t)q].solo = solo;
+    }
     P.mwaves.insert(P.mwaves.end(), chained.begin(), chained.end());
     n_records += (long long)wgs.size() * kMtWaves + (long long)chained.size();
     lv.avg_entries = Ln.tasks.empty() ? 1.0 : 16.0 * (double)sum / (double)Ln.tasks.size();
-    lv.lanes = (int)Ln.tasks.size();  // tiles of the launch (reporting)
+    lv.ntiles = (int)Ln.tasks.size();
     P.levels.push_back(lv);
   }
   for (int q = 0; q < 16; ++q) P.idxs.push_back(0);  // the kernel reads up to three groups past the end of a list
@@ -671,7 +680,7 @@ void layout_mpipe(const std::vector<Piece> &pc, const std::vector<const double *
       const SpLevel &lv = P.levels[li];
       int busy = 0;
       for (int q = 0; q < lv.ntasks * kMtWaves; ++q) busy += P.mwaves[(size_t)lv.task0 + q].nrows > 0;
-      std::fprintf(stderr, "[partinv3]   launch %2zu tiles %6d workgroups %5d waves %6d steps/tile %.1f\n", li, lv.lanes,
+      std::fprintf(stderr, "[partinv3]   launch %2zu tiles %6d workgroups %5d waves %6d steps/tile %.1f\n", li, lv.ntiles,
                    lv.ntasks, busy, lv.avg_entries / 16.0);
     }
   }

@@ -1,5 +1,5 @@
-// Shared between the two schedule builders of the partitioned inverse (host_partinv.cpp: one launch per tree level;
-// host_partinv2.cpp: merged levels).  Set-up time code, host only.
+// Shared between the builder of the partitioned inverse (host_partinv.cpp) and its schedule (host_partinv3.cpp).
+// Set-up time code, host only.
 #pragma once
 #include <algorithm>
 #include <atomic>
@@ -25,34 +25,7 @@ struct Piece {
   const double *w() const { return W_view ? W_view : W.data(); }
 };
 
-inline int pad2(int x) { return (x + 1) & ~1; }
-
-// the first two segments travel inside the task record: no dependent load of a segment record on the device
-inline void inline_first_segment(PTask &T, const std::vector<PSeg> &segs) {
-  T.len0 = 0;
-  T.src0 = 0;
-  T.idx0 = 0;
-  T.w0 = 0;
-  T.len1 = 0;
-  T.src1 = 0;
-  T.idx1 = 0;
-  T.w1 = 0;
-  T.pad = 0;
-  if (T.nseg > 0) {
-    const PSeg &S = segs[(size_t)T.seg0];
-    T.len0 = S.len;
-    T.src0 = S.src;
-    T.idx0 = S.idx;
-    T.w0 = S.w;
-  }
-  if (T.nseg > 1) {
-    const PSeg &S = segs[(size_t)T.seg0 + 1];
-    T.len1 = S.len;
-    T.src1 = S.src;
-    T.idx1 = S.idx;
-    T.w1 = S.w;
-  }
-}
+inline int pad4(int x) { return (x + 3) & ~3; }
 
 // body(i) for i in [0, n) on up to nthreads threads, dynamic chunks
 template <class F>
@@ -73,15 +46,11 @@ void parallel_for(int n, int nthreads, int chunk, F body) {
   for (auto &t : th) t.join();
 }
 
-// The weights of a segment ([entry j][tile row q], j < len) are only RESERVED while a schedule is laid out; writing
-// them -- 0.8 G doubles for the whole 100k lattice -- is done afterwards by all threads.
-//   kind 0: rows a0 + q of a lower-triangular c x c matrix (entries up to the diagonal)
-//   kind 1: rows loc[q] of an (any) x c matrix
-//   kind 2: rows a0 + q of a full c x c matrix
-//   kind 3: transposed lower triangle: w[j][q] = base(a0 + j, a0 + q), j >= q
-//   kind 4: transposed block: w[j][q] = base(j, a0 + q), j < m
-//   kind 5: micro-blocks (matrix-pipe schedule, sparse_precond.h): rows a0 .. a0 + 3 of an m x c matrix, micro-block columns
-//           [loc[0], loc[1]):  w[(cb - loc[0]) 16 + (e % 4) 4 + a % 4] = base(a, e), zero beyond the matrix
+// The stored weights are only RESERVED while a schedule is laid out; writing them -- 0.4 G doubles for the whole 100k
+// lattice -- is done afterwards, on the device where the sources are there, else by all host threads.  A fill is a
+// run of micro-blocks (sparse_precond.h): rows a0 .. a0 + 3 of an m x c matrix `base` (row-major), micro-block columns
+// [loc[0], loc[1]):  w[(cb - loc[0]) 16 + (e % 4) 4 + a % 4] = base(a, e), zero beyond the matrix; kind is 5 (kinds
+// 0 .. 4 were the per-tile layouts of the schedules this one replaced).
 struct Fill {
   long long off;
   const double *base;
@@ -91,15 +60,10 @@ struct Fill {
 // into P->vals, or chunk by chunk into P->sink when one is set; false when the sink failed
 bool write_weights(const std::vector<Fill> &fills, long long total, int nthreads, PartInvHost *P);
 
-// second schedule builder (host_partinv2.cpp).  pc: pieces with Dinv and W; Mgiven[s] (may be null): D^-T D^-1 of piece
-// s where the device delivered it.  Fills P->levels / tasks / segs / idxs / vals / out_off / weights_read_per_apply.
-void layout_merged(const std::vector<Piece> &pc, const std::vector<const double *> &Mgiven,
-                   const std::vector<int> &piece_of, int k, int nlev, int nthreads, bool timing, PartInvHost *P);
-// third builder (host_partinv3.cpp): the merged launches with their tiles on the matrix pipe, every piece's weights
-// stored once (sparse_precond.h, "matrix-pipe schedule").  Same arguments.
+// The schedule builder (host_partinv3.cpp).  pc: pieces with Dinv and W; Mgiven[s] (may be null): D^-T D^-1 of piece s
+// where the device delivered it.  Fills P->levels / mwaves / idxs / vals / out_off / weights_read_per_apply.
 void layout_mpipe(const std::vector<Piece> &pc, const std::vector<const double *> &Mgiven,
-                   const std::vector<int> &piece_of, int k, int nlev, int nthreads, bool timing, PartInvHost *P);
-inline int pad4(int x) { return (x + 3) & ~3; }
+                  const std::vector<int> &piece_of, int k, int nlev, int nthreads, bool timing, PartInvHost *P);
 
 }  // namespace partinv
 }  // namespace dcora

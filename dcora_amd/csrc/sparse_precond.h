@@ -9,10 +9,11 @@
 // and factors of pieces that do not feed each other commute, so all pieces of one level of the dissection tree are
 // applied by ONE launch: every output row is an independent gather (dot products of stored weights with the
 // current vector), no atomics, fixed summation order => bitwise reproducible.  A solve is
-//     permute-in, one launch per tree level (forward), one per level (backward), permute-out
-// i.e. 2 * depth + 2 launches with depth ~ log2(k / leaf) instead of the thousands of dependent steps of a
-// row-level triangular solve.  Vectors ping-pong between two buffers per piece; which buffer holds the current
-// value of a piece is known at build time and baked into the gather offsets.
+//     permute-in, one launch per group of tree levels (forward), the top, one per group (backward), permute-out
+// with depth ~ log2(k / leaf) instead of the thousands of dependent steps of a row-level triangular solve (how levels
+// are grouped and the diagonal blocks leave the dependent chain: host_partinv3.cpp).  Vectors ping-pong between two
+// buffers per piece; which buffer holds the current value of a piece is known at build time and baked into the gather
+// offsets.
 #pragma once
 #include <cstddef>
 #include <memory>
@@ -22,26 +23,8 @@
 
 namespace dcora {
 
-constexpr int kSpTile = 4;  // output rows per task: they share every gathered vector entry
+constexpr int kSpTile = 4;  // output rows per tile: they share every gathered vector entry
 
-struct PTask {  // a tile of nrows <= kSpTile consecutive output rows of one level
-  int out;      // first destination, in unknowns (buffer * k + permuted row)
-  int carry;    // first old value to keep (same units) or -1
-  int seg0, nseg;
-  int nrows;
-  int len0, src0, idx0;  // copies of the segments seg0 and seg0 + 1 (len = 0 when absent): tiles of up to two
-  long long w0;          // segments -- every tile of the backward sweep, most of the forward one -- need no
-  long long w1;          // dependent load of a segment record on the device
-  int len1, src1, idx1, pad;
-};
-static_assert(sizeof(PTask) == 64, "PTask is read as four 16-byte words");
-struct PSeg {       // row q of the tile:  sum_j w[q][j] * y[src + j]   or   sum_j w[q][j] * y[idx[j]]
-  long long w;      // offset into the weight array (even => 16-byte aligned); layout [entry j][row q], len even
-  int src;          // >= 0: contiguous run starting here (in unknowns); < 0: indexed through idx
-  int idx;          // offset into the index array when src < 0
-  int len;
-  int pad;
-};
 // ---- matrix-pipe schedule (host_partinv3.cpp, k_sp_mtile): the tiles of the merged schedule -- up to kSpTile consecutive
 // output rows that gather from the same sources -- with the sums over the gathered entries inside
 // v_mfma_f64_4x4x4_4b_f64: one instruction multiplies FOUR independent 4 x 4 blocks, D_b += A_b B_b; a step of a tile
@@ -79,24 +62,17 @@ struct MWave {
   int red_first;   // wave of the workgroup that holds the tile's first partial sum (adds the others and stores)
   int red_n;       // waves of the tile (consecutive)
   int next;        // record that continues this wave's work (tiles of many short segments), -1: none
-  int pad;
+  int solo;        // 1: no tile of this workgroup spans several waves (the same in its kMtWaves records): no LDS, no barrier
   MSub a, b;
 };
 static_assert(sizeof(MWave) == 128, "MWave is read as eight 16-byte words");
 constexpr int kMtWaves = 8;  // waves per workgroup of the matrix-pipe kernel
 
-struct SpLevel {
-  int task0 = 0, ntasks = 0, lanes = 8;  // lanes per task of the first kernel form (16, 32, 64, 128 or 256)
-  // matrix-pipe schedule: task0 = first wave record of the launch (PartInvHost::mwaves), ntasks = its workgroups (of
-  // kMtWaves records each); continuation records follow the launch's workgroups
-  int mpipe = 0;
-  double avg_entries = 0;                // vector entries a tile gathers, on average (the launch picks the lanes from it)
-  // Merged schedule (host_partinv2.cpp): the tasks of a launch gather anything from 8 to thousands of entries, so
-  // they are sorted by entries, longest first, and every tile gets the lanes its own length asks for: tasks
-  // [0, cls[g][0]) run on 256 lanes, [cls[g][0], cls[g][1]) on 128, then 64, 32, and the rest on 16; g = 0 for r >= 4,
-  // g = 1 for r < 4.
-  int multi = 0;
-  int cls[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+struct SpLevel {  // one launch of the replay
+  int task0 = 0;    // first wave record of the launch (PartInvHost::mwaves)
+  int ntasks = 0;   // its workgroups (of kMtWaves records each); continuation records follow the launch's workgroups
+  int ntiles = 0;   // tiles of the launch (reporting)
+  double avg_entries = 0;  // vector entries a tile gathers, on average (reporting)
 };
 
 // A host address range whose content also lives on the device (the factor's panels as the device factorisation left
@@ -150,9 +126,7 @@ struct PartInvHost {
   PartInvHub hub;
   std::vector<SpLevel> levels;   // forward levels (leaves first), then backward levels (root first)
   int nforward = 0;
-  std::vector<PTask> tasks;
-  std::vector<PSeg> segs;
-  std::vector<MWave> mwaves;   // matrix-pipe schedule
+  std::vector<MWave> mwaves;   // the wave records of all launches
   std::vector<double> vals;
   // set by the caller before the build: the stored weights are streamed there while they are formed and `vals` stays
   // empty (the product: the 6.8 GB of the whole 100k lattice never exist on the host); null: weights in `vals`

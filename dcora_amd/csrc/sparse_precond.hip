@@ -1,5 +1,5 @@
 // Device side of the sparse preconditioner (sparse_precond.h): uploads the partitioned inverse and replays its
-// level schedule, one gather kernel per level.
+// schedule, one launch of k_sp_mtile per group of tree levels.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -111,283 +111,6 @@ __global__ __launch_bounds__(kBlock) void k_sp_permute_out_hub(int r, int k, con
     Z[(size_t)perm[j] * r + t] = v;
   }
 }
-
-// Measured and dropped (MI355X, k = 50 000 lattice block, 181 us for the 21 launches below):
-//  * all levels in one launch, a level's blocks polling an arrival counter of the level before (task records
-//    prefetched before the wait, agent-scope release / acquire): 1.4-1.7 ms -- thousands of resident blocks polling
-//    one word starve the producers' atomics, also with padded counters and a slow-poll / fast-poll split;
-//  * larger dissection leaves (fewer levels): 192 / 384 / 768 unknowns per leaf -> 196 / 249 / 285 us;
-//  * batches of 6 entries per lane with all loads issued straight-line before the first use (what paid off in the
-//    fused tCG kernels): 184.6 us against 181.5 us on the same box;
-//  * occupancy targets (amdgpu_waves_per_eu 4 / 6 / 8 instead of the 5 the 92 VGPRs give): 190 / 242 / 238 us.
-// One level: LANES lanes per tile of up to kSpTile output rows (LANES = 256: one block per tile).
-// The r values of JP = LANES / r consecutive vector entries are one contiguous run of JP r doubles, so lane
-// l = j r + t loads exactly one of them (fully coalesced), multiplies it with the nrows weights of entry j (the
-// r lanes of an entry read the same 8 nrows bytes) and keeps nrows running sums for its own t.  The lanes that
-// share a t are summed through LDS in a fixed order => reproducible.  A vector entry is gathered once per tile.
-template <int LANES>
-__global__ __launch_bounds__(kBlock) void k_sp_level(int r, const PTask *__restrict__ tasks, int ntasks,
-                                                     const PSeg *__restrict__ segs,
-                                                     const double *__restrict__ vals,
-                                                     const int *__restrict__ idxs, double *__restrict__ y, Gate g) {
-  if (sp_gated(g.ctl, g.seq, g.gate)) return;
-  constexpr int RT = kSpTile;
-  constexpr int NE = (RT * 16 + LANES - 1) / LANES;  // output elements per lane (r <= 16)
-  __shared__ double s_acc[kBlock][RT];
-  const int tid = threadIdx.x;
-  const int lane = tid & (LANES - 1), grp0 = tid - lane;
-  const int task = (int)(((long)blockIdx.x * kBlock + tid) / LANES);
-  const bool active = task < ntasks;
-  PTask T;
-  T.out = 0; T.carry = -1; T.seg0 = 0; T.nseg = 0; T.nrows = 0;
-  T.len0 = 0; T.src0 = 0; T.idx0 = 0; T.w0 = 0;
-  if (active) T = tasks[task];
-  const int nrows = T.nrows, ne = nrows * r;
-  const int JP = LANES / r;            // vector entries per step
-  const int jl = lane / r, t = lane - jl * r;
-  const bool worker = jl < JP;
-  double cv[NE];
-#pragma unroll
-  for (int i = 0; i < NE; ++i) {
-    const int e = lane + i * LANES;
-    cv[i] = (T.carry >= 0 && e < ne) ? y[(size_t)T.carry * r + e] : 0.0;
-  }
-  double acc[RT];
-#pragma unroll
-  for (int q = 0; q < RT; ++q) acc[q] = 0;
-  for (int s = T.seg0; s < T.seg0 + T.nseg; ++s) {
-    PSeg S;
-    if (s == T.seg0) {  // the first segment came with the task record
-      S.w = T.w0;
-      S.src = T.src0;
-      S.idx = T.idx0;
-      S.len = T.len0;
-    } else {
-      S = segs[s];
-    }
-    if (!worker) continue;
-    const double *__restrict__ w = vals + S.w;
-    if (S.src >= 0) {
-      const double *__restrict__ ys = y + (size_t)S.src * r + t;
-      if (nrows == RT) {
-#pragma unroll 4
-        for (int j = jl; j < S.len; j += JP) {
-          const double yv = ys[(size_t)j * r];
-          const double2 a0 = *reinterpret_cast<const double2 *>(w + (size_t)j * RT);
-          const double2 a1 = *reinterpret_cast<const double2 *>(w + (size_t)j * RT + 2);
-          acc[0] += a0.x * yv;
-          acc[1] += a0.y * yv;
-          acc[2] += a1.x * yv;
-          acc[3] += a1.y * yv;
-        }
-      } else {
-#pragma unroll 2
-        for (int j = jl; j < S.len; j += JP) {
-          const double yv = ys[(size_t)j * r];
-          const double *__restrict__ wa = w + (size_t)j * nrows;
-#pragma unroll
-          for (int q = 0; q < RT; ++q)
-            if (q < nrows) acc[q] += wa[q] * yv;
-        }
-      }
-    } else {
-      const int *__restrict__ ix = idxs + S.idx;
-      if (nrows == RT) {
-#pragma unroll 4
-        for (int j = jl; j < S.len; j += JP) {
-          const double yv = y[(size_t)ix[j] * r + t];
-          const double2 a0 = *reinterpret_cast<const double2 *>(w + (size_t)j * RT);
-          const double2 a1 = *reinterpret_cast<const double2 *>(w + (size_t)j * RT + 2);
-          acc[0] += a0.x * yv;
-          acc[1] += a0.y * yv;
-          acc[2] += a1.x * yv;
-          acc[3] += a1.y * yv;
-        }
-      } else {
-#pragma unroll 2
-        for (int j = jl; j < S.len; j += JP) {
-          const double yv = y[(size_t)ix[j] * r + t];
-          const double *__restrict__ wa = w + (size_t)j * nrows;
-#pragma unroll
-          for (int q = 0; q < RT; ++q)
-            if (q < nrows) acc[q] += wa[q] * yv;
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < RT; ++q) s_acc[tid][q] = acc[q];
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < NE; ++i) {
-    const int e = lane + i * LANES;
-    if (e < ne) {
-      const int q = e / r, tt = e - q * r;
-      double v = cv[i];
-      for (int u = 0; u < JP; ++u) v += s_acc[grp0 + tt + u * r][q];
-      y[(size_t)T.out * r + e] = v;
-    }
-  }
-}
-
-// Second form of the level kernel: one lane per gathered ENTRY instead of one lane per (entry, value).  A lane reads the
-// RT weights of its entry once (32 distinct bytes per lane -- in the form above the r lanes of an entry read the same 32
-// bytes, and the address unit pays for every lane) and the entry's r vector values, and keeps RT x r running sums; a
-// tile of 1000 entries is 4 steps per lane on 256 lanes (20 above), so every load of a tile is in flight at once.  Sums
-// over the lanes of a tile: four DPP steps inside each 16-lane row, the row sums through LDS, added in a fixed order.
-__device__ __forceinline__ double sp_row16_sum(double v) {
-  v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
-  v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
-  v += dpp_move<0x141>(v);  // row_half_mirror
-  v += dpp_move<0x140>(v);  // row_mirror
-  return v;
-}
-// first_task: the task of the workgroup's first tile; s_part: RT * R * 16 doubles of LDS
-template <int LANES, int R>
-__device__ __forceinline__ void sp_tiles(int first_task, const PTask *__restrict__ tasks, int ntasks,
-                                         const PSeg *__restrict__ segs, const double *__restrict__ vals,
-                                         const int *__restrict__ idxs, double *__restrict__ y,
-                                         double *__restrict__ s_part_raw, Gate g) {
-  constexpr int RT = kSpTile, r = R;
-  constexpr int NROW = (LANES + 15) / 16;             // 16-lane rows per tile
-  constexpr int NE = (RT * R + LANES - 1) / LANES;    // output elements per lane
-  constexpr int UN = LANES >= 128 ? 4 : 2;            // steps in flight per lane
-  double(*s_part)[RT * R][NROW] = reinterpret_cast<double(*)[RT * R][NROW]>(s_part_raw);
-  const int tid = threadIdx.x;
-  const int lane = tid & (LANES - 1), tile = tid / LANES;
-  // a tile of 64+ lanes is the same for the whole wave: its record is read through the scalar cache into SGPRs
-  const int task = LANES >= 64 ? __builtin_amdgcn_readfirstlane(first_task + tile) : first_task + tile;
-  const bool active = task < ntasks;
-  PTask T;
-  T.out = 0; T.carry = -1; T.seg0 = 0; T.nseg = 0; T.nrows = 0;
-  T.len0 = 0; T.src0 = 0; T.idx0 = 0; T.w0 = 0;
-  T.len1 = 0; T.src1 = 0; T.idx1 = 0; T.w1 = 0;
-  if (active) T = tasks[task];
-  // the gate is tested AFTER the task record has been requested: the two loads travel together
-  if (sp_gated(g.ctl, g.seq, g.gate)) return;
-  const int nrows = T.nrows, ne = nrows * r;
-  double cv[NE];
-#pragma unroll
-  for (int i = 0; i < NE; ++i) {
-    const int e = lane + i * LANES;
-    cv[i] = (T.carry >= 0 && e < ne) ? y[(size_t)T.carry * r + e] : 0.0;
-  }
-  double acc[RT][R];
-#pragma unroll
-  for (int q = 0; q < RT; ++q)
-#pragma unroll
-    for (int t = 0; t < R; ++t) acc[q][t] = 0;
-  for (int s = T.seg0; s < T.seg0 + T.nseg; ++s) {
-    PSeg S;
-    if (s == T.seg0) {  // the first two segments came with the task record
-      S.w = T.w0;
-      S.src = T.src0;
-      S.idx = T.idx0;
-      S.len = T.len0;
-    } else if (s == T.seg0 + 1) {
-      S.w = T.w1;
-      S.src = T.src1;
-      S.idx = T.idx1;
-      S.len = T.len1;
-    } else {
-      S = segs[s];
-    }
-    const double *__restrict__ w = vals + S.w;
-    const int *__restrict__ ix = idxs + S.idx;
-    const bool direct = S.src >= 0;
-    if (nrows == RT) {
-#pragma unroll UN
-      for (int j = lane; j < S.len; j += LANES) {
-        const size_t pos = direct ? (size_t)(S.src + j) : (size_t)ix[j];
-        const double *__restrict__ ys = y + pos * r;
-        double yv[R];
-#pragma unroll
-        for (int t = 0; t < R; ++t) yv[t] = ys[t];
-        const double2 a0 = *reinterpret_cast<const double2 *>(w + (size_t)j * RT);
-        const double2 a1 = *reinterpret_cast<const double2 *>(w + (size_t)j * RT + 2);
-#pragma unroll
-        for (int t = 0; t < R; ++t) {
-          acc[0][t] += a0.x * yv[t];
-          acc[1][t] += a0.y * yv[t];
-          acc[2][t] += a1.x * yv[t];
-          acc[3][t] += a1.y * yv[t];
-        }
-      }
-    } else {
-#pragma unroll 2
-      for (int j = lane; j < S.len; j += LANES) {
-        const size_t pos = direct ? (size_t)(S.src + j) : (size_t)ix[j];
-        const double *__restrict__ ys = y + pos * r;
-        const double *__restrict__ wa = w + (size_t)j * nrows;
-        double yv[R];
-#pragma unroll
-        for (int t = 0; t < R; ++t) yv[t] = ys[t];
-#pragma unroll
-        for (int q = 0; q < RT; ++q)
-          if (q < nrows) {
-            const double a = wa[q];
-#pragma unroll
-            for (int t = 0; t < R; ++t) acc[q][t] += a * yv[t];
-          }
-      }
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < RT; ++q)
-#pragma unroll
-    for (int t = 0; t < R; ++t) {
-      const double v = sp_row16_sum(acc[q][t]);
-      if ((lane & 15) == 0) s_part[tile][q * R + t][lane >> 4] = v;
-    }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < NE; ++i) {
-    const int e = lane + i * LANES;
-    if (e < ne) {
-      double v = cv[i];
-#pragma unroll
-      for (int u = 0; u < NROW; ++u) v += s_part[tile][e][u];
-      y[(size_t)T.out * r + e] = v;
-    }
-  }
-}
-
-template <int LANES, int R>
-__global__ __launch_bounds__(kBlock) void k_sp_level2(const PTask *__restrict__ tasks, int ntasks,
-                                                      const PSeg *__restrict__ segs, const double *__restrict__ vals,
-                                                      const int *__restrict__ idxs, double *__restrict__ y, Gate g) {
-  __shared__ double s_part[kSpTile * R * 16];
-  sp_tiles<LANES, R>(blockIdx.x * (kBlock / LANES), tasks, ntasks, segs, vals, idxs, y, s_part, g);
-}
-
-// One launch of the merged schedule (host_partinv2.cpp): the tasks are sorted by the entries they gather and fall into
-// five classes of lanes per tile; the workgroups of a class are consecutive, so a workgroup learns its class from
-// blockIdx and the kernel arguments alone (no load in front of the task record).
-constexpr int kSpClasses = 5;  // 256, 128, 64, 32, 16 lanes per tile
-struct SpClasses {
-  int wg_end[kSpClasses];    // workgroups [wg_end[c-1], wg_end[c]) run class c
-  int task_beg[kSpClasses];  // first task of the class
-  int task_end[kSpClasses];
-};
-template <int R>
-__global__ __launch_bounds__(kBlock) void k_sp_multi(const PTask *__restrict__ tasks, SpClasses C,
-                                                     const PSeg *__restrict__ segs, const double *__restrict__ vals,
-                                                     const int *__restrict__ idxs, double *__restrict__ y, Gate g) {
-  __shared__ double s_part[kSpTile * R * 16];
-  const int b = blockIdx.x;
-  if (b < C.wg_end[0]) {
-    sp_tiles<256, R>(C.task_beg[0] + b, tasks, C.task_end[0], segs, vals, idxs, y, s_part, g);
-  } else if (b < C.wg_end[1]) {
-    sp_tiles<128, R>(C.task_beg[1] + (b - C.wg_end[0]) * 2, tasks, C.task_end[1], segs, vals, idxs, y, s_part, g);
-  } else if (b < C.wg_end[2]) {
-    sp_tiles<64, R>(C.task_beg[2] + (b - C.wg_end[1]) * 4, tasks, C.task_end[2], segs, vals, idxs, y, s_part, g);
-  } else if (b < C.wg_end[3]) {
-    sp_tiles<32, R>(C.task_beg[3] + (b - C.wg_end[2]) * 8, tasks, C.task_end[3], segs, vals, idxs, y, s_part, g);
-  } else {
-    sp_tiles<16, R>(C.task_beg[4] + (b - C.wg_end[3]) * 16, tasks, C.task_end[4], segs, vals, idxs, y, s_part, g);
-  }
-}
-
 
 // ---- matrix-pipe schedule (sparse_precond.h, host_partinv3.cpp): one launch of tiles on v_mfma_f64_4x4x4_4b_f64 ----
 // The instruction multiplies four independent 4 x 4 blocks.  Measured on MI355X (tools/mfma_f64_4x4.hip): lane
@@ -511,7 +234,7 @@ __global__ __launch_bounds__(kMtBlock) void k_sp_mtile(const MWave *__restrict__
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   typedef const __attribute__((address_space(4))) int *ConstInts;
   ConstInts rp = (ConstInts)(recs + ((size_t)blockIdx.x * kMtWaves + wave));
-  const int t_out = rp[0], t_carry = rp[1], t_nrows = rp[2], t_kind = rp[3], t_first = rp[4], t_n = rp[5];
+  const int t_out = rp[0], t_carry = rp[1], t_nrows = rp[2], t_kind = rp[3], t_first = rp[4], t_n = rp[5], t_solo = rp[7];
   // the gate is tested AFTER the record has been requested: the two loads travel together
   if (sp_gated(g.ctl, g.seq, g.gate)) return;
   const int kq = lane >> 4, blk = (lane >> 2) & 3, li = lane & 3;  // operand roles: K entry, block, row (A) / pair (B)
@@ -561,11 +284,13 @@ __global__ __launch_bounds__(kMtBlock) void k_sp_mtile(const MWave *__restrict__
       v += dpp_move<0x128>(v);  // row_ror:8: the four blocks of a 16-lane row summed
       sum[c][h] = v;
     }
+  if (!t_solo) {  // uniform over the workgroup
 #pragma unroll
-  for (int c = 0; c < NC; ++c)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
-    for (int h = 0; h < 2; ++h) s_part[wave][c * 2 + h][lane] = sum[c][h];
-  __syncthreads();
+      for (int h = 0; h < 2; ++h) s_part[wave][c * 2 + h][lane] = sum[c][h];
+    __syncthreads();
+  }
   if (!writer) return;
 #pragma unroll
   for (int c = 0; c < NC; ++c)
@@ -602,122 +327,6 @@ bool launch_mtile(hipStream_t st, int r, const SpLevel &lv, const MWave *recs, c
   return true;
 }
 
-template <int R>
-void launch_multi_r(hipStream_t st, int grid, const PTask *tp, const SpClasses &C, const PSeg *segs, const double *vals,
-                    const int *idxs, double *y, Gate g) {
-  hipLaunchKernelGGL((k_sp_multi<R>), dim3(grid), dim3(kBlock), 0, st, tp, C, segs, vals, idxs, y, g);
-}
-
-bool launch_multi(hipStream_t st, int r, const SpLevel &lv, const PTask *tasks, const PSeg *segs, const double *vals,
-                  const int *idxs, double *y, Gate g) {
-  if (r < 2 || r > 8) return false;
-  const int *cls = lv.cls[r >= 4 ? 0 : 1];
-  SpClasses C;
-  int beg = 0, wg = 0;
-  for (int c = 0; c < kSpClasses; ++c) {
-    const int end = c < kSpClasses - 1 ? cls[c] : lv.ntasks;
-    const int tpb = 1 << c;  // tiles per workgroup: 1, 2, 4, 8, 16
-    C.task_beg[c] = beg;
-    C.task_end[c] = end;
-    wg += (end - beg + tpb - 1) / tpb;
-    C.wg_end[c] = wg;
-    beg = end;
-  }
-  if (wg == 0) return true;
-  const PTask *tp = tasks + lv.task0;
-  switch (r) {
-    case 2: launch_multi_r<2>(st, wg, tp, C, segs, vals, idxs, y, g); break;
-    case 3: launch_multi_r<3>(st, wg, tp, C, segs, vals, idxs, y, g); break;
-    case 4: launch_multi_r<4>(st, wg, tp, C, segs, vals, idxs, y, g); break;
-    case 5: launch_multi_r<5>(st, wg, tp, C, segs, vals, idxs, y, g); break;
-    case 6: launch_multi_r<6>(st, wg, tp, C, segs, vals, idxs, y, g); break;
-    case 7: launch_multi_r<7>(st, wg, tp, C, segs, vals, idxs, y, g); break;
-    default: launch_multi_r<8>(st, wg, tp, C, segs, vals, idxs, y, g); break;
-  }
-  return true;
-}
-
-template <int LANES>
-bool launch_level2(hipStream_t st, int r, int grid, const PTask *tp, int ntasks, const PSeg *segs, const double *vals,
-                   const int *idxs, double *y, Gate g) {
-  switch (r) {
-#define DCORA_SP_CASE(RR)                                                                                              \
-  case RR:                                                                                                             \
-    hipLaunchKernelGGL((k_sp_level2<LANES, RR>), dim3(grid), dim3(kBlock), 0, st, tp, ntasks, segs, vals, idxs, y, g); \
-    return true;
-    DCORA_SP_CASE(2)
-    DCORA_SP_CASE(3)
-    DCORA_SP_CASE(4)
-    DCORA_SP_CASE(5)
-    DCORA_SP_CASE(6)
-    DCORA_SP_CASE(7)
-    DCORA_SP_CASE(8)
-#undef DCORA_SP_CASE
-    default:
-      return false;
-  }
-}
-
-// lanes per tile of the second kernel form, from the entries a tile gathers and the rank: a lane takes one entry per step
-// and ends with a reduction of RT r sums, so short tiles want narrow tiles (several per wave) the more the larger r is.
-// Measured (us per application, lattice agent r = 5 / sphere2500 r = 5 / tiers r = 2): 64 lanes from 20 entries and 32
-// from 8: 145.4 / 30.8 / 50.3; from 100 and 30: 140.1 / 30.9 / 58.4; from 140 and 40: 139.7 / 32.8 / 61.5.
-// DCORA_SP_LANES = "t256,t128,t64,t32" overrides the thresholds (measurements).
-int sp_pick_lanes(double avg, int r) {
-  static const int *ov = [] {
-    static int t[4];
-    const char *e = std::getenv("DCORA_SP_LANES");
-    if (!e || std::sscanf(e, "%d,%d,%d,%d", &t[0], &t[1], &t[2], &t[3]) != 4) return (const int *)nullptr;
-    return (const int *)t;
-  }();
-  const int t256 = ov ? ov[0] : 400, t128 = ov ? ov[1] : 160, t64 = ov ? ov[2] : (r >= 4 ? 100 : 20),
-            t32 = ov ? ov[3] : (r >= 4 ? 30 : 8);
-  return avg >= t256 ? 256 : avg >= t128 ? 128 : avg >= t64 ? 64 : avg >= t32 ? 32 : 16;
-}
-
-void launch_level(hipStream_t st, int r, const SpLevel &lv, const PTask *tasks, const PSeg *segs, const double *vals,
-                  const int *idxs, double *y, Gate g) {
-  static const bool v1 = [] {
-    const char *e = std::getenv("DCORA_SP_KERNEL");
-    return e && std::strcmp(e, "v1") == 0;
-  }();
-  if (lv.multi && !v1 && launch_multi(st, r, lv, tasks, segs, vals, idxs, y, g)) return;
-  const bool form2 = !v1 && r >= 2 && r <= 8;
-  const int lanes = form2 ? sp_pick_lanes(lv.avg_entries, r) : lv.lanes;
-  const long threads = (long)lv.ntasks * lanes;
-  const int grid = (int)((threads + kBlock - 1) / kBlock);
-  if (grid == 0) return;
-  const PTask *tp = tasks + lv.task0;
-  if (form2) {
-    bool done = false;
-    switch (lanes) {
-      case 256: done = launch_level2<256>(st, r, grid, tp, lv.ntasks, segs, vals, idxs, y, g); break;
-      case 128: done = launch_level2<128>(st, r, grid, tp, lv.ntasks, segs, vals, idxs, y, g); break;
-      case 64: done = launch_level2<64>(st, r, grid, tp, lv.ntasks, segs, vals, idxs, y, g); break;
-      case 32: done = launch_level2<32>(st, r, grid, tp, lv.ntasks, segs, vals, idxs, y, g); break;
-      default: done = launch_level2<16>(st, r, grid, tp, lv.ntasks, segs, vals, idxs, y, g); break;
-    }
-    if (done) return;
-  }
-  switch (lanes) {
-    case 256:
-      hipLaunchKernelGGL((k_sp_level<256>), dim3(grid), dim3(kBlock), 0, st, r, tp, lv.ntasks, segs, vals, idxs, y, g);
-      break;
-    case 128:
-      hipLaunchKernelGGL((k_sp_level<128>), dim3(grid), dim3(kBlock), 0, st, r, tp, lv.ntasks, segs, vals, idxs, y, g);
-      break;
-    case 64:
-      hipLaunchKernelGGL((k_sp_level<64>), dim3(grid), dim3(kBlock), 0, st, r, tp, lv.ntasks, segs, vals, idxs, y, g);
-      break;
-    case 32:
-      hipLaunchKernelGGL((k_sp_level<32>), dim3(grid), dim3(kBlock), 0, st, r, tp, lv.ntasks, segs, vals, idxs, y, g);
-      break;
-    default:
-      hipLaunchKernelGGL((k_sp_level<16>), dim3(grid), dim3(kBlock), 0, st, r, tp, lv.ntasks, segs, vals, idxs, y, g);
-      break;
-  }
-}
-
 }  // namespace
 
 namespace {
@@ -749,15 +358,15 @@ void pin_release(double *p) {
 }
 }  // namespace
 
-// ---- the stored weights formed ON THE DEVICE: a fill record names a tile of a source matrix (kinds of
-//      host_partinv_int.h); a wave per record writes the record's whole extent, zeros included ----
+// ---- the stored weights formed ON THE DEVICE: a fill record names a run of micro-blocks of a source matrix
+//      (host_partinv_int.h); a wave per record writes the record's whole extent, zeros included ----
 namespace {
 struct DFill {
   long long off, extent;
   const double *src;
-  int kind, nrows, len, c, a0, m;
-  int loc[kSpTile];
+  int c, a0, m, cb0, ncb;
 };
+// micro-blocks (host_partinv_int.h): e = (cb - cb0) 16 + (col % 4) 4 + row % 4
 __global__ __launch_bounds__(256) void k_fill_weights(long long nf, const DFill *__restrict__ fills,
                                                       double *__restrict__ vals) {
   const long long fi = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -765,39 +374,10 @@ __global__ __launch_bounds__(256) void k_fill_weights(long long nf, const DFill 
   const DFill F = fills[fi];
   const int lane = threadIdx.x & 63;
   double *__restrict__ w = vals + F.off;
-  const int nr = F.nrows, c = F.c, a0 = F.a0;
-  const long long n = (long long)F.len * nr;
-  const int jcap = min(F.len, c);
+  const long long n = (long long)F.ncb * 16;
   for (long long e = lane; e < F.extent; e += 64) {
-    double v = 0.0;
-    if (e < n) {
-      const int j = (int)(e / nr), q = (int)(e - (long long)j * nr);
-      const int lq = q == 0 ? F.loc[0] : q == 1 ? F.loc[1] : q == 2 ? F.loc[2] : F.loc[3];
-      switch (F.kind) {
-        case 0:
-          if (j < jcap && j <= a0 + q) v = F.src[(size_t)(a0 + q) * c + j];
-          break;
-        case 1:
-          if (j < jcap) v = F.src[(size_t)lq * c + j];
-          break;
-        case 2:
-          if (j < jcap) v = F.src[(size_t)(a0 + q) * c + j];
-          break;
-        case 3:
-          if (a0 + j < c && q <= j) v = F.src[(size_t)(a0 + j) * c + a0 + q];
-          break;
-        case 5:
-          break;
-        default:
-          if (j < F.m) v = F.src[(size_t)j * c + a0 + q];
-          break;
-      }
-    }
-    if (F.kind == 5) {  // micro-blocks: e = (cb - loc[0]) 16 + (col % 4) 4 + row % 4
-      const int cb = F.loc[0] + (int)(e >> 4), col = cb * 4 + (int)((e >> 2) & 3), row = a0 + (int)(e & 3);
-      v = (e < n && row < F.m && col < c) ? F.src[(size_t)row * c + col] : 0.0;
-    }
-    w[e] = v;
+    const int cb = F.cb0 + (int)(e >> 4), col = cb * 4 + (int)((e >> 2) & 3), row = F.a0 + (int)(e & 3);
+    w[e] = (e < n && row < F.m && col < F.c) ? F.src[(size_t)row * F.c + col] : 0.0;
   }
 }
 }  // namespace
@@ -834,20 +414,7 @@ bool DeviceWeightSink::fill_on_device(const std::vector<partinv::Fill> &fills, l
       if (b >= m.host && b < m.host + m.n) return m.dev + (b - m.host);
     return nullptr;
   };
-  auto rows_touched = [](const Fill &f) -> long long {
-    switch (f.kind) {
-      case 0:
-      case 2: return (long long)f.a0 + f.nrows;
-      case 1: {
-        int mx = 0;
-        for (int q = 0; q < f.nrows; ++q) mx = std::max(mx, f.loc[q]);
-        return (long long)mx + 1;
-      }
-      case 3: return std::min<long long>((long long)f.a0 + f.len, f.c);
-      case 5: return std::min<long long>((long long)f.a0 + 4, f.m);
-      default: return std::min<long long>(f.len, f.m);
-    }
-  };
+  auto rows_touched = [](const Fill &f) -> long long { return std::min<long long>((long long)f.a0 + 4, f.m); };
   struct Staged {
     long long doubles = 0, offset = 0;
   };
@@ -886,13 +453,11 @@ bool DeviceWeightSink::fill_on_device(const std::vector<partinv::Fill> &fills, l
     const double *dev = (f.len > 0 && f.nrows > 0) ? mirrored(f.base) : nullptr;
     if (!dev && f.len > 0 && f.nrows > 0) dev = dstage.p + staged[f.base].offset;
     d.src = dev;
-    d.kind = f.kind;
-    d.nrows = std::max(1, f.nrows);
-    d.len = dev ? f.len : 0;
     d.c = f.c;
     d.a0 = f.a0;
-    d.m = f.m;
-    for (int q = 0; q < kSpTile; ++q) d.loc[q] = f.loc[q];
+    d.m = dev ? f.m : 0;
+    d.cb0 = f.loc[0];
+    d.ncb = f.loc[1] - f.loc[0];
   }
   if (vals.alloc((size_t)std::max<long long>(2, total)) != hipSuccess) {
     set_last_error("sparse preconditioner: no device memory for the stored weights");
@@ -983,29 +548,20 @@ int SpImage::upload(const PartInvHost &P, DeviceWeightSink *streamed) {
   }
   DCORA_HIP(idxs.alloc(P.idxs.size()));
   DCORA_HIP(hipMemcpy(idxs.p, P.idxs.data(), P.idxs.size() * sizeof(int), hipMemcpyHostToDevice));
-  DCORA_HIP(tasks.alloc(P.tasks.size()));
-  DCORA_HIP(hipMemcpy(tasks.p, P.tasks.data(), P.tasks.size() * sizeof(PTask), hipMemcpyHostToDevice));
-  DCORA_HIP(segs.alloc(P.segs.size()));
-  DCORA_HIP(hipMemcpy(segs.p, P.segs.data(), P.segs.size() * sizeof(PSeg), hipMemcpyHostToDevice));
-  if (!P.mwaves.empty()) {  // matrix-pipe schedule
-    DCORA_HIP(mwaves.alloc(P.mwaves.size()));
+  DCORA_HIP(mwaves.alloc(std::max<size_t>(P.mwaves.size(), 1)));
+  if (!P.mwaves.empty())
     DCORA_HIP(hipMemcpy(mwaves.p, P.mwaves.data(), P.mwaves.size() * sizeof(MWave), hipMemcpyHostToDevice));
-  }
   DCORA_HIP(perm.alloc(P.perm.size()));
   DCORA_HIP(hipMemcpy(perm.p, P.perm.data(), P.perm.size() * sizeof(int), hipMemcpyHostToDevice));
   DCORA_HIP(out_off.alloc(P.out_off.size()));
   DCORA_HIP(hipMemcpy(out_off.p, P.out_off.data(), P.out_off.size() * sizeof(int), hipMemcpyHostToDevice));
-  ntasks_total = (long)P.tasks.size();
   rows_total = 0;
-  for (const PTask &t : P.tasks) rows_total += t.nrows;
-  nsegs_total = (long)P.segs.size();
   nmwaves_total = (long)P.mwaves.size();
   for (const SpLevel &lv : P.levels)
-    if (lv.mpipe)
-      for (int q = 0; q < lv.ntasks * kMtWaves; ++q) {
-        const MWave &t = P.mwaves[(size_t)lv.task0 + q];
-        if (t.nrows > 0 && t.red_first == q % kMtWaves) rows_total += t.nrows;
-      }
+    for (int q = 0; q < lv.ntasks * kMtWaves; ++q) {
+      const MWave &t = P.mwaves[(size_t)lv.task0 + q];
+      if (t.nrows > 0 && t.red_first == q % kMtWaves) rows_total += t.nrows;
+    }
   nhub = P.hub.h;
   hub_nnz = (long)P.hub.aval.size();
   {
@@ -1042,7 +598,7 @@ int SpImage::upload(const PartInvHost &P, DeviceWeightSink *streamed) {
 
 size_t SpImage::device_bytes() const {
   return vals.n * sizeof(double) + (idxs.n + perm.n + out_off.n + in_pos.n + out_pos.n) * sizeof(int) +
-         tasks.n * sizeof(PTask) + segs.n * sizeof(PSeg) + mwaves.n * sizeof(MWave) +
+         mwaves.n * sizeof(MWave) +
          (hub_aval.n + hub_U.n + hub_Sinv.n) * sizeof(double) +
          (hub_idx.n + hub_ap.n + hub_apos.n) * sizeof(int);
 }
@@ -1070,8 +626,6 @@ void SparsePrecond::apply(hipStream_t st, int r, Buf2 R, double *Z, Gate g, bool
   const DevBuf<int> &perm = I.perm, &out_off = I.out_off, &hub_idx = I.hub_idx, &hub_ap = I.hub_ap, &hub_apos = I.hub_apos,
                     &idxs = I.idxs;
   const DevBuf<double> &vals = I.vals, &hub_aval = I.hub_aval, &hub_U = I.hub_U, &hub_Sinv = I.hub_Sinv;
-  const DevBuf<PTask> &tasks = I.tasks;
-  const DevBuf<PSeg> &segs = I.segs;
   const std::vector<SpLevel> &levels = I.levels;
   const long n = (long)r * k;
   const int grid = (int)std::min<long>((n + kBlock - 1) / kBlock, 2048);
@@ -1087,10 +641,7 @@ void SparsePrecond::apply(hipStream_t st, int r, Buf2 R, double *Z, Gate g, bool
     if (!go_on()) return;
   }
   for (const SpLevel &lv : levels) {
-    if (lv.mpipe)
-      launch_mtile(st, r, lv, I.mwaves.p, vals.p, idxs.p, y.p, g);
-    else
-      launch_level(st, r, lv, tasks.p, segs.p, vals.p, idxs.p, y.p, g);
+    launch_mtile(st, r, lv, I.mwaves.p, vals.p, idxs.p, y.p, g);
     if (!go_on()) return;
   }
   if (levels_only && nhub == 0) return;
@@ -1120,9 +671,10 @@ SpFold SparsePrecond::fold_generic() const {
 }
 
 double SparsePrecond::bytes_per_apply(int r) const {
-  // stored weights once, the task / segment tables, the vector in and out of every row tile, permutes, hub terms
+  // the weights a solve streams (W twice, M once), the wave records, the vector in and out of every tile, permutes,
+  // hub terms
   const SpImage &I = *im;
-  return 8.0 * I.weights_per_apply + 64.0 * I.ntasks_total + 24.0 * I.nsegs_total + 128.0 * I.nmwaves_total +
+  return 8.0 * I.weights_per_apply + 128.0 * I.nmwaves_total +
          16.0 * r * I.rows_total +
          32.0 * r * (double)I.k + 12.0 * I.hub_nnz + 8.0 * (double)I.nhub * I.k;
 }

@@ -60,7 +60,7 @@ def test_both_forms_of_the_block_qapply_and_of_the_level_kernel_agree(built, tmp
     if os.environ.get("DCORA_SOLVER_V1"):
         pytest.skip("DCORA_SOLVER_V1 switches the block Q-apply off")
     new = _run(tmp_path, "new", {})
-    old = _run(tmp_path, "old", {"DCORA_BSR_KERNEL": "v1", "DCORA_SP_KERNEL": "v1"})
+    old = _run(tmp_path, "old", {"DCORA_BSR_KERNEL": "v1"})
     v3 = _run(tmp_path, "v3", {"DCORA_BSR_KERNEL": "v3"})  # 16-byte gathers, column pairs summed per pose (another order)
     assert set(new.files) == set(old.files) == set(v3.files)
     for key in new.files:

@@ -12,7 +12,7 @@ for i in idx:
         runs.append(cur); cur = []
     cur.append(i)
 if cur: runs.append(cur)
-runs = [r for r in runs if len(r) >= 10]
+runs = [r for r in runs if len(r) >= 5]
 run = runs[len(runs) // 2]
 t_end_prev = None
 tot = 0
