@@ -628,6 +628,13 @@ class Exchange:
                     peers=int(v[1]), posts=int(v[2]), waits=int(v[3]), bytes_posted=float(v[4]), post_s=float(v[5]),
                     wait_s=float(v[6]), eval_wait_s=float(v[7]))
 
+    def link_report(self):
+        """what the start-up link check of dcora_exchange_create did: rounds run, whether the device-side wait / the IPC
+        transport were given up, microseconds of the last round"""
+        v = np.zeros(4)
+        check(capi.lib().dcora_exchange_link_report(self.h, v))
+        return dict(rounds=int(v[0]), gave_up_device_wait=bool(v[1]), gave_up_ipc=bool(v[2]), last_round_us=float(v[3]))
+
     def all_ready(self, ready):
         """AND over the ranks of `ready` (Agent::shouldTerminate's team condition, ref src/Agent.cpp:1137-1153)"""
         out = C.c_int()

@@ -148,6 +148,7 @@ SIGNATURES = {
     "dcora_exchange_destroy": (C.c_int, [_vp]),
     "dcora_exchange_create_ra": (C.c_int, [_vp, C.c_char_p, C.POINTER(_vp)]),
     "dcora_exchange_info": (C.c_int, [_vp, _dp]),
+    "dcora_exchange_link_report": (C.c_int, [_vp, _dp]),
     "dcora_exchange_post": (C.c_int, [_vp, _ip, C.c_int]),
     "dcora_exchange_wait": (C.c_int, [_vp, _ip, C.c_int]),
     "dcora_exchange_evaluate": (C.c_int, [_vp, _PD, _PD, _vp, _PI]),

@@ -954,6 +954,15 @@ int dcora_exchange_info(dcora_exchange_t ex, double *info) {
   info[9] = e.waits_on_device() ? 1 : 0;
   return DCORA_OK;
 }
+int dcora_exchange_link_report(dcora_exchange_t ex, double *out4) {
+  if (!ex || !out4) return bad("null");
+  const Exchange &e = ex->e;
+  out4[0] = e.link_rounds;
+  out4[1] = e.link_gave_up_device_wait;
+  out4[2] = e.link_gave_up_ipc;
+  out4[3] = e.link_last_us;
+  return DCORA_OK;
+}
 int dcora_exchange_post(dcora_exchange_t ex, const int *agents, int count) {
   if (!ex || (!agents && count > 0)) return bad("null");
   DCORA_TRY

@@ -434,14 +434,25 @@ int device_min_eig(const HostCsr &S, int maxit, double min_eig_tol, int ncv, uin
     // Shift-and-invert fallback (ref :1878-1888 -> :1751-1805): Lanczos on (S - sigma I)^-1, sigma = -10, halved
     // on failure with the floor -2 eta.  The solve per step is the partitioned sparse inverse of the SPD matrix
     // S - sigma I replayed on the device (sparse_precond.h), one right-hand side.
+    // The factorisation is a Cholesky (the reference's Spectra run factors S - sigma I by a sparse LU, which exists for
+    // any shift): S - sigma I must be positive definite, i.e. sigma < lambda_min.  When the very first shift, -10, is
+    // refused, lambda_min lies below it: the shift moves OUTWARD by factors of ten -- at most to -lambda_lm, below
+    // which nothing of the spectrum can lie -- until the matrix factors.
     double sigma = -10.0;
+    bool outward = false;
     const int nthreads = std::max(1, std::min(host_cpus_available(), 32));
-    for (int i = 0; i < 10; ++i) {
+    for (int i = 0; i < 24; ++i) {
       PartInvHost P;
       DeviceWeightSink sink(device);  // the stored weights stream to the device while they are formed
       P.sink = &sink;
       const int brc = build_partitioned_inverse_auto(csr_shift_diag(S, -sigma), 1, nthreads, device, &P);
       if (brc && brc != DCORA_ERR_NOT_PD) return brc;
+      if (brc == DCORA_ERR_NOT_PD && (i == 0 || outward)) {
+        outward = true;
+        if (-sigma > 2.0 * lambda_lm + 10.0) break;  // (cannot happen in exact arithmetic)
+        sigma *= 10.0;
+        continue;
+      }
       if (brc == DCORA_OK) {
         SparsePrecond inv;
         auto img = std::make_shared<SpImage>();
@@ -463,8 +474,23 @@ int device_min_eig(const HostCsr &S, int maxit, double min_eig_tol, int ncv, uin
           return DCORA_OK;
         }
       }
+      if (outward) break;  // factored far out but Lanczos on the inverse did not converge: the shifted run below
+      if (i >= 9) break;
       sigma /= 2;
       if (i == 8 || sigma > -2 * min_eig_tol) sigma = -2 * min_eig_tol;
+    }
+    if (hopeless) {
+      // the shortcut skipped the reference's first attempt and the fallback delivered nothing: make that attempt now
+      LanczosResult late;
+      rc = L.largest_magnitude(2 * lambda_lm, ncv, maxit, min_eig_tol / lambda_lm, x0.data(), seed, &late);
+      if (rc) return rc;
+      late.matvecs += sh.matvecs;
+      if (late.ok) {
+        late.lambda += 2 * lambda_lm;
+        *out = late;
+        return DCORA_OK;
+      }
+      sh = late;
     }
     set_last_error("min_eig: neither the spectrum-shifted nor the shift-and-invert Lanczos run converged");
     *out = sh;

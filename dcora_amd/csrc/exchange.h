@@ -23,6 +23,7 @@ namespace dcora {
 
 constexpr int kMaxRanks = 64;
 constexpr uint32_t kShmMagic = 0x44434f52u;  // "DCOR"
+constexpr int kProbeDoubles = 512;           // the link check's payload: 4 KB
 
 struct alignas(64) ShmFlag {
   volatile uint64_t seq;
@@ -37,7 +38,9 @@ struct alignas(64) ShmRank {
   hipIpcMemHandle_t halo;  // 64 bytes
   std::atomic<int> device, pid, ipc_ok, published;
   std::atomic<uint64_t> bus;  // hash of the device's PCI bus id: two ranks with the same value share a GPU
-  uint64_t pad[5];
+  std::atomic<int> fine;      // 1: this rank's halo buffer is fine-grained device memory
+  std::atomic<int> probe;     // link check: +round passed, -round failed
+  uint64_t pad[4];
 };
 struct alignas(64) ShmRed {  // one rank's contribution to a sum over the ranks
   volatile uint64_t seq;
@@ -53,6 +56,10 @@ struct ShmHeader {
 };
 
 enum ExchangeMode { kExchangeIpc = 1, kExchangeStaged = 2 };
+
+// how long a rank waits for another before it gives up, raises `failed` for everybody and returns an error
+// (DCORA_EXCHANGE_TIMEOUT_S, default 120: a rank that died takes the job down within this time, never a hang)
+double exchange_timeout_s();
 
 class Exchange {
  public:
@@ -87,6 +94,9 @@ class Exchange {
 
   int mode = 0;
   int rank = 0, world = 1;
+  // link check (init): rounds run, whether the device-side wait / the IPC transport were given up, time of the last round
+  int link_rounds = 0, link_gave_up_device_wait = 0, link_gave_up_ipc = 0;
+  double link_last_us = 0;
   bool halo_is_finegrained() const { return halo_finegrained_; }
   // statistics since creation (host wall time spent in post / wait / the evaluation all-gather, bytes posted)
   bool waits_on_device() const { return device_wait_; }
@@ -113,6 +123,8 @@ class Exchange {
   uint64_t red_seq_ = 0;
   ShmFlag *consumed_ = nullptr;  // [consumer rank][agent]: the last post of the agent that rank has scattered
   size_t off_flags_ = 0, off_evals_ = 0, off_staged_ = 0, off_x_ = 0, off_consumed_ = 0;
+  size_t off_probe_flags_ = 0, off_probe_res_ = 0, off_probe_stage_ = 0;  // link check: [reader][writer] words / 4 KB
+  size_t probe_off_ = 0;  // in a halo buffer: [writer] x (kProbeDoubles payload + 8 doubles of flag)
   size_t devflag_off_ = 0;       // in a halo buffer, behind the slots and the self-test area: [parity][agent] x 64 bytes
   bool device_wait_ = true;      // the scatter kernel polls the flag itself (no host hop between post and scatter)
   DevBuf<unsigned> arrive2_;     // last-workgroup counters of the scatter kernels
@@ -136,7 +148,10 @@ class Exchange {
   int open_segment(const char *job_name, size_t bytes);
   int map_segment(const char *job_name, size_t x_doubles);
   int setup_ipc(bool attempt);
-  int fail(const std::string &msg, int code);
+  int link_check();
+  bool probe_round(uint64_t seq, std::string *why);
+  int fail(const std::string &msg, int code);   // a transport / peer failure: raises `failed` for every rank
+  int usage(const std::string &msg, int code);  // a refused call (bad argument, unsupported): this call only
 };
 
 }  // namespace dcora

@@ -22,7 +22,6 @@ namespace {
 
 using Clock = std::chrono::steady_clock;
 inline double since(Clock::time_point t0) { return std::chrono::duration<double>(Clock::now() - t0).count(); }
-
 constexpr int kMaxDst = 8;
 struct PostDst {
   double *base[kMaxDst];
@@ -126,6 +125,55 @@ __global__ void k_selftest_write(double *dst, int count, double base) {
   __threadfence_system();
 }
 
+// ---- link check (Exchange::link_check): the producer / consumer forms of k_post_public / k_wait_scatter on a 4 KB
+//      probe, one workgroup each ----
+__global__ __launch_bounds__(256) void k_probe_post(double *dst, uint64_t *dflag, volatile uint64_t *hflag, double base,
+                                                    uint64_t seq) {
+  for (int i = threadIdx.x; i < kProbeDoubles; i += 256) dst[i] = base + i;
+  __threadfence_system();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence_system();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (dflag) __hip_atomic_store(dflag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store((uint64_t *)hflag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+// result: 1 = flag seen and every word equal, 2 = the flag never came (budget), 3 = words differ
+__global__ __launch_bounds__(256) void k_probe_wait(const double *src, const uint64_t *flag, uint64_t want,
+                                                    long long budget_ticks, int poll, double base, int *result) {
+  __shared__ int s_bad, s_diff;
+  if (threadIdx.x == 0) {
+    int bad = 0;
+    s_diff = 0;
+    if (poll) {
+      const long long t0 = wall_clock64();
+      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+        __builtin_amdgcn_s_sleep(16);
+        if (wall_clock64() - t0 > budget_ticks) {
+          bad = 1;
+          break;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_bad = bad;
+  }
+  __syncthreads();
+  if (s_bad) {
+    if (threadIdx.x == 0) __hip_atomic_store(result, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
+  int diff = 0;
+  for (int i = threadIdx.x; i < kProbeDoubles; i += 256)
+    diff += __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != base + i;
+  if (diff) atomicAdd(&s_diff, diff);
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(result, s_diff ? 3 : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // host polling with back-off: a burst of pause instructions, then the core is handed over between polls (a rank per
@@ -142,6 +190,20 @@ inline void polite_spin(unsigned &spins) {
 }
 
 }  // namespace
+
+double exchange_timeout_s() {
+  static const double v = [] {
+    const char *e = std::getenv("DCORA_EXCHANGE_TIMEOUT_S");
+    const double x = e ? atof(e) : 0.0;
+    return x > 0 ? x : 120.0;
+  }();
+  return v;
+}
+
+int Exchange::usage(const std::string &msg, int code) {
+  set_last_error("exchange (rank " + std::to_string(rank) + "): " + msg);
+  return code;
+}
 
 int Exchange::fail(const std::string &msg, int code) {
   set_last_error("exchange (rank " + std::to_string(rank) + "): " + msg);
@@ -197,10 +259,30 @@ int Exchange::open_segment(const char *job_name, size_t bytes) {
     return DCORA_OK;
   }
   for (;;) {
-    if (since(t0) > 120.0) return fail("segment " + name_ + " did not appear", DCORA_ERR_IO);
+    if (since(t0) > exchange_timeout_s()) return fail("segment " + name_ + " did not appear", DCORA_ERR_IO);
     const int fd = shm_open(name_.c_str(), O_RDWR, 0600);
     struct stat sb;
     if (fd < 0 || fstat(fd, &sb) != 0 || (size_t)sb.st_size < bytes) {
+      // a segment of another size under the name: a live job of another shape says so in its header (a stale one, or
+      // one rank 0 is still creating, is waited out)
+      if (fd >= 0 && (size_t)sb.st_size >= sizeof(ShmHeader)) {
+        void *hp = mmap(nullptr, sizeof(ShmHeader), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        if (hp != MAP_FAILED) {
+          ShmHeader *h = (ShmHeader *)hp;
+          const bool live = h->magic.load(std::memory_order_acquire) == kShmMagic && h->creator_pid > 0 &&
+                            (kill((pid_t)h->creator_pid, 0) == 0 || errno == EPERM);
+          const bool other = live && (h->world != (uint32_t)world || h->R != (uint32_t)R_ || h->slot_doubles != slot_ ||
+                                      h->total_bytes != bytes);
+          if (other && since(t0) > 1.0) {  // (a second: a crashed job's segment is replaced by rank 0 within that)
+            h->failed.store(1);
+            munmap(hp, sizeof(ShmHeader));
+            close(fd);
+            return fail("segment " + name_ + " belongs to a job of another shape (a live job under the same name?)",
+                        DCORA_ERR_BAD_ARG);
+          }
+          munmap(hp, sizeof(ShmHeader));
+        }
+      }
       if (fd >= 0) close(fd);
       usleep(2000);
       continue;
@@ -259,6 +341,13 @@ int Exchange::map_segment(const char *job_name, size_t x_doubles) {
   off += sizeof(ShmFlag) * (size_t)world * R;
   off_red_ = off;
   off += sizeof(ShmRed) * 2 * (size_t)world;
+  off_probe_flags_ = off;  // link check: [reader][writer] flag words, then result words
+  off += sizeof(ShmFlag) * (size_t)world * world;
+  off_probe_res_ = off;
+  off += sizeof(ShmFlag) * (size_t)world * world;
+  off = align_up(off, 4096);
+  off_probe_stage_ = off;  // ... and 4 KB per (reader, writer) for the staged transport's probe
+  off += sizeof(double) * kProbeDoubles * (size_t)world * world;
   off = align_up(off, 4096);
   off_staged_ = off;
   off += sizeof(double) * 2 * R * slot_;
@@ -280,6 +369,7 @@ int Exchange::map_segment(const char *job_name, size_t x_doubles) {
 
 int Exchange::barrier(double timeout_s) {
   if (world == 1) return DCORA_OK;
+  timeout_s = std::min(timeout_s, exchange_timeout_s());
   const auto t0 = Clock::now();
   const uint32_t gen = hdr_->bar_gen.load(std::memory_order_acquire);
   if (hdr_->bar_count.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)world) {
@@ -386,10 +476,22 @@ int Exchange::init(ExchangeSession *s, const char *job_name) {
     bool shared_gpu = false;
     for (int q = 0; q < world; ++q)
       if (q != rank && ranks_[q].bus.load(std::memory_order_acquire) == ranks_[rank].bus.load()) shared_gpu = true;
+    // A peer GPU's stores into a COARSE-grained halo buffer are not guaranteed visible to a kernel of this GPU that is
+    // already running (lines may be served from the local L2; the host-wait form relies on the invalidate of the
+    // kernel boundary): the kernel polls only where every rank's halo is fine-grained device memory.
+    bool all_fine = true;
+    for (int q = 0; q < world; ++q) all_fine = all_fine && ranks_[q].fine.load(std::memory_order_acquire) == 1;
+    const bool poll_is_safe = mode != kExchangeIpc || all_fine;
     const char *wm = std::getenv("DCORA_EXCHANGE_WAIT");
-    device_wait_ = wm ? std::strcmp(wm, "host") != 0 : !shared_gpu;
+    device_wait_ = (wm ? std::strcmp(wm, "host") != 0 : !shared_gpu) && poll_is_safe;
   }
   if (force && std::strcmp(force, "ipc") == 0 && !all) return fail("DCORA_EXCHANGE=ipc but the IPC transport is not usable", DCORA_ERR_HIP);
+  rc = barrier();
+  if (rc) return rc;
+  if (world > 1) {
+    rc = link_check();
+    if (rc) return rc;
+  }
   rc = barrier();
   if (rc) return rc;
   if (rank == 0) shm_unlink(name_.c_str());  // every rank has it mapped: nothing is left in /dev/shm after the job
@@ -403,7 +505,8 @@ int Exchange::setup_ipc(bool attempt) {
   const size_t test_off = 2 * (size_t)R * slot_;
   const int ntest = 64;
   devflag_off_ = align_up(test_off + (size_t)ntest * world, 8);
-  const size_t halo_doubles = devflag_off_ + 2 * (size_t)R * 8;  // + one 64-byte flag word per (parity, agent)
+  probe_off_ = devflag_off_ + 2 * (size_t)R * 8;  // behind one 64-byte flag word per (parity, agent)
+  const size_t halo_doubles = probe_off_ + (size_t)world * (kProbeDoubles + 8);  // + the link check's area per writer
   bool ok = attempt;
   std::string why;
   auto no = [&](const std::string &m) {
@@ -443,6 +546,7 @@ int Exchange::setup_ipc(bool attempt) {
   (void)hipGetLastError();
   ranks_[rank].device.store(s_->x_device());
   ranks_[rank].pid.store((int)getpid());
+  ranks_[rank].fine.store(ok && halo_finegrained_ ? 1 : 0);
   ranks_[rank].published.store(ok ? 1 : -1, std::memory_order_release);
   int rc = barrier();
   if (rc) return rc;
@@ -501,6 +605,146 @@ int Exchange::setup_ipc(bool attempt) {
   return ok ? DCORA_OK : DCORA_ERR_UNSUPPORTED;
 }
 
+// One round of the link check: a 4 KB pattern and a flag from every rank into each rank it will write to, through the
+// transport (mode) and the form of the wait (device_wait_) in force; true when everything THIS rank reads arrived intact
+// within the budget.  Never blocks longer than a few seconds whatever a peer does.
+bool Exchange::probe_round(uint64_t seq, std::string *why) {
+  const int R = R_;
+  const bool ipc = mode == kExchangeIpc;
+  std::set<int> peers, writers;
+  for (int a = 0; a < R; ++a) {
+    peers.insert(dests_[a].begin(), dests_[a].end());
+    if (needed_[a]) writers.insert(owner_[a]);
+  }
+  auto pattern = [&](int writer, int reader) { return 1e6 * (double)seq + 4096.0 * writer + 64.0 * reader; };
+  auto hflag_dev = [&](int reader, int writer) {
+    return (volatile uint64_t *)(dev_map_ + off_probe_flags_ + sizeof(ShmFlag) * ((size_t)reader * world + writer));
+  };
+  bool ok = true;
+  auto no = [&](const std::string &m) {
+    if (ok && why) *why = m;
+    ok = false;
+  };
+  if (hipSetDevice(s_->x_device()) != hipSuccess) no("hipSetDevice");
+  hipStream_t st = s_->x_stream();
+  for (int q : peers) {
+    if (!ok) break;
+    double *dst = ipc ? peer_halo_[q] + probe_off_ + (size_t)rank * (kProbeDoubles + 8)
+                      : (double *)(dev_map_ + off_probe_stage_) + ((size_t)q * world + rank) * kProbeDoubles;
+    uint64_t *dflag = ipc ? (uint64_t *)(peer_halo_[q] + probe_off_ + (size_t)rank * (kProbeDoubles + 8) + kProbeDoubles) : nullptr;
+    if (ipc && !peer_halo_[q]) {
+      no("no mapping of rank " + std::to_string(q) + "'s halo buffer");
+      break;
+    }
+    hipLaunchKernelGGL(k_probe_post, dim3(1), dim3(256), 0, st, dst, dflag, hflag_dev(q, rank), pattern(rank, q), seq);
+  }
+  if (hipGetLastError() != hipSuccess) no("probe post launch");
+  const double budget_s = 3.0;
+  for (int p : writers) {
+    if (!ok) break;
+    const ShmFlag *hf = (const ShmFlag *)((char *)map_ + off_probe_flags_) + ((size_t)rank * world + p);
+    if (!device_wait_) {  // the host waits for the flag, as wait_arr does
+      const auto w0 = Clock::now();
+      unsigned spins = 0;
+      while (hf->seq < seq) {
+        polite_spin(spins);
+        if ((spins & 255u) == 0 && (hdr_->failed.load() || since(w0) > budget_s)) {
+          no("the probe flag of rank " + std::to_string(p) + " never arrived (host wait)");
+          break;
+        }
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+      if (!ok) break;
+    }
+    const double *src = ipc ? halo_.p + probe_off_ + (size_t)p * (kProbeDoubles + 8)
+                            : (const double *)(dev_map_ + off_probe_stage_) + ((size_t)rank * world + p) * kProbeDoubles;
+    const uint64_t *flag = ipc ? (const uint64_t *)(halo_.p + probe_off_ + (size_t)p * (kProbeDoubles + 8) + kProbeDoubles)
+                               : (const uint64_t *)hflag_dev(rank, p);
+    int *res = (int *)(dev_map_ + off_probe_res_ + sizeof(ShmFlag) * ((size_t)rank * world + p));
+    hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(256), 0, st, src, flag, seq, (long long)(budget_s * 1e8),
+                       device_wait_ ? 1 : 0, pattern(p, rank), res);
+  }
+  if (hipGetLastError() != hipSuccess) no("probe wait launch");
+  // the stream drains within the kernels' own budgets; a bounded host wait on top (never hipStreamSynchronize blindly)
+  {
+    const auto w0 = Clock::now();
+    hipError_t e;
+    while ((e = hipStreamQuery(st)) == hipErrorNotReady) {
+      usleep(200);
+      if (since(w0) > 4.0 * budget_s) {
+        no("the probe kernels did not finish");
+        break;
+      }
+    }
+    if (e != hipSuccess && e != hipErrorNotReady) {
+      (void)hipGetLastError();
+      no(std::string("probe kernels: ") + hipGetErrorString(e));
+    }
+  }
+  for (int p : writers) {
+    if (!ok) break;
+    const volatile int *res = (const volatile int *)((char *)map_ + off_probe_res_ + sizeof(ShmFlag) * ((size_t)rank * world + p));
+    if (*res != 1)
+      no("probe of rank " + std::to_string(p) + (*res == 2 ? ": the flag never arrived" : *res == 3 ? ": the 4 KB pattern arrived damaged" : ": no result"));
+    *(volatile int *)res = 0;
+  }
+  return ok;
+}
+
+// Start-up check of the links this rank will use (dcora_hip.h, dcora_exchange_info): rounds of probe_round, all ranks
+// stepping down together -- device-side wait -> host wait -> staged transport -- until a round passes on every rank.
+int Exchange::link_check() {
+  std::string why, first_why;
+  // test hook: DCORA_EXCHANGE_PROBE_FAULT=n makes the last rank report its first n rounds as failed
+  static const int fault_rounds = [] {
+    const char *e = std::getenv("DCORA_EXCHANGE_PROBE_FAULT");
+    return e ? atoi(e) : 0;
+  }();
+  for (int round = 1; round <= 3; ++round) {
+    const auto t0 = Clock::now();
+    bool mine = probe_round((uint64_t)round, &why);
+    if (mine && rank == world - 1 && round <= fault_rounds) {
+      mine = false;
+      why = "injected fault (DCORA_EXCHANGE_PROBE_FAULT)";
+    }
+    if (!mine && first_why.empty()) first_why = why;
+    ranks_[rank].probe.store(mine ? round : -round, std::memory_order_release);
+    int rc = barrier(30.0);
+    if (rc) return rc;
+    bool all = true;
+    for (int q = 0; q < world; ++q) all = all && ranks_[q].probe.load(std::memory_order_acquire) == round;
+    rc = barrier(30.0);  // nobody overwrites its vote before everybody has read the votes
+    if (rc) return rc;
+    link_rounds = round;
+    link_last_us = 1e6 * since(t0);
+    if (all) {
+      if (round > 1)
+        set_last_error("exchange: link check passed after stepping down (" + first_why + "): " +
+                       (mode == kExchangeIpc ? "IPC peer stores, host wait" : "shared host segment"));
+      return DCORA_OK;
+    }
+    // the same step on every rank (all read the same votes)
+    if (mode == kExchangeIpc && device_wait_) {
+      device_wait_ = false;
+      link_gave_up_device_wait = 1;
+    } else if (mode == kExchangeIpc) {
+      const char *force = std::getenv("DCORA_EXCHANGE");
+      if (force && std::strcmp(force, "ipc") == 0) break;
+      mode = kExchangeStaged;
+      link_gave_up_ipc = 1;
+      const char *wm = std::getenv("DCORA_EXCHANGE_WAIT");
+      device_wait_ = wm ? std::strcmp(wm, "host") != 0 : device_wait_;
+    } else if (device_wait_) {
+      device_wait_ = false;
+      link_gave_up_device_wait = 1;
+    } else {
+      break;
+    }
+  }
+  return fail("link check: no transport between the ranks works (" + (first_why.empty() ? why : first_why) + ")",
+              DCORA_ERR_EXCHANGE_LINK);
+}
+
 int Exchange::post(const int *agents, int count) { return post_arr(agents, count, s_->x_rank_r(), s_->x_mirror()); }
 int Exchange::wait(const int *agents, int count) { return wait_arr(agents, count, s_->x_rank_r(), s_->x_mirror()); }
 
@@ -511,7 +755,7 @@ int Exchange::post_arr(const int *agents, int count, int r, const double *arr) {
   const int R = R_;
   for (int i = 0; i < count; ++i) {
     const int a = agents[i];
-    if (a < 0 || a >= R) return fail("post: agent out of range", DCORA_ERR_BAD_ARG);
+    if (a < 0 || a >= R) return usage("post: agent out of range", DCORA_ERR_BAD_ARG);
     const uint64_t q = ++seq_[a];
     const XAgentView ag = s_->x_agent(a);
     if (!ag.hosted || dests_[a].empty() || ag.ncols == 0) continue;
@@ -528,7 +772,7 @@ int Exchange::post_arr(const int *agents, int count, int r, const double *arr) {
           polite_spin(spins);
           if ((spins & 1023u) == 0) {
             if (hdr_->failed.load()) return fail("another rank failed", DCORA_ERR_HIP);
-            if (since(b0) > 120.0)
+            if (since(b0) > exchange_timeout_s())
               return fail("rank " + std::to_string(p) + " never read post " + std::to_string(q - 2) + " of agent " +
                               std::to_string(a),
                           DCORA_ERR_HIP);
@@ -565,7 +809,7 @@ int Exchange::wait_arr(const int *agents, int count, int r, double *arr) {
   const int R = R_;
   for (int i = 0; i < count; ++i) {
     const int a = agents[i];
-    if (a < 0 || a >= R) return fail("wait: agent out of range", DCORA_ERR_BAD_ARG);
+    if (a < 0 || a >= R) return usage("wait: agent out of range", DCORA_ERR_BAD_ARG);
     const XAgentView ag = s_->x_agent(a);
     if (!needed_[a] || ag.ncols == 0) continue;
     const uint64_t want = seq_[a];
@@ -578,7 +822,7 @@ int Exchange::wait_arr(const int *agents, int count, int r, double *arr) {
         polite_spin(spins);
         if ((spins & 1023u) == 0) {
           if (hdr_->failed.load()) return fail("another rank failed", DCORA_ERR_HIP);
-          if (since(w0) > 120.0)
+          if (since(w0) > exchange_timeout_s())
             return fail("public poses of agent " + std::to_string(a) + " never arrived", DCORA_ERR_HIP);
         }
       }
@@ -632,7 +876,7 @@ int Exchange::evaluate(double *cost2, double *gradnorm, double *block_norms, int
       polite_spin(spins);
       if ((spins & 1023u) == 0) {
         if (hdr_->failed.load()) return fail("another rank failed", DCORA_ERR_HIP);
-        if (since(t0) > 120.0) return fail("rank " + std::to_string(q) + " never entered the evaluation", DCORA_ERR_HIP);
+        if (since(t0) > exchange_timeout_s()) return fail("rank " + std::to_string(q) + " never entered the evaluation", DCORA_ERR_HIP);
       }
     }
   }
@@ -644,7 +888,7 @@ int Exchange::evaluate(double *cost2, double *gradnorm, double *block_norms, int
       polite_spin(spins);
       if ((spins & 1023u) == 0) {
         if (hdr_->failed.load()) return fail("another rank failed", DCORA_ERR_HIP);
-        if (since(t0) > 120.0) return fail("evaluation of agent " + std::to_string(a) + " never arrived", DCORA_ERR_HIP);
+        if (since(t0) > exchange_timeout_s()) return fail("evaluation of agent " + std::to_string(a) + " never arrived", DCORA_ERR_HIP);
       }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
@@ -669,7 +913,7 @@ int Exchange::evaluate(double *cost2, double *gradnorm, double *block_norms, int
 // one pass of the reference driver's loop body (examples/MultiRobotExample.cpp:223-307) across the ranks
 int Exchange::rbcd_iterate(int selected, double *cost2, double *gradnorm, double *block_norms, int *next_selected) {
   const int R = R_;
-  if (selected < 0 || selected >= R) return fail("selected agent out of range", DCORA_ERR_BAD_ARG);
+  if (selected < 0 || selected >= R) return usage("selected agent out of range", DCORA_ERR_BAD_ARG);
   std::vector<int> others;
   for (int a = 0; a < R; ++a)
     if (a != selected) others.push_back(a);
@@ -764,7 +1008,7 @@ int Exchange::host_selftest(const char *job_name, int rank_, int world_, int R, 
       while (f->seq < (uint64_t)q) {
         if ((++spins & 1023u) == 0) {
           if (hdr_->failed.load()) return fail("another rank failed", DCORA_ERR_HIP);
-          if (since(t0) > 60.0) return fail("host selftest: a post never arrived", DCORA_ERR_HIP);
+          if (since(t0) > exchange_timeout_s()) return fail("host selftest: a post never arrived", DCORA_ERR_HIP);
           sched_yield();
         }
       }
@@ -791,7 +1035,7 @@ int Exchange::host_selftest(const char *job_name, int rank_, int world_, int R, 
         while (hb[p2].seq < (uint64_t)q) {
           if ((++spins & 1023u) == 0) {
             if (hdr_->failed.load()) return fail("another rank failed", DCORA_ERR_HIP);
-            if (since(t0) > 60.0) return fail("host selftest: a heartbeat never arrived", DCORA_ERR_HIP);
+            if (since(t0) > exchange_timeout_s()) return fail("host selftest: a heartbeat never arrived", DCORA_ERR_HIP);
             sched_yield();
           }
         }
@@ -803,7 +1047,7 @@ int Exchange::host_selftest(const char *job_name, int rank_, int world_, int R, 
       while (e->seq < (uint64_t)q) {
         if ((++spins & 1023u) == 0) {
           if (hdr_->failed.load()) return fail("another rank failed", DCORA_ERR_HIP);
-          if (since(t0) > 60.0) return fail("host selftest: an evaluation never arrived", DCORA_ERR_HIP);
+          if (since(t0) > exchange_timeout_s()) return fail("host selftest: an evaluation never arrived", DCORA_ERR_HIP);
           sched_yield();
         }
       }

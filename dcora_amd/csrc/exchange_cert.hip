@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void k_apply_lambda(int n, int d, const double
 }  // namespace
 
 int Exchange::allreduce_sum(double *vals, int count) {
-  if (count < 0 || count > 31) return fail("allreduce_sum: at most 31 values", DCORA_ERR_BAD_ARG);
+  if (count < 0 || count > 31) return usage("allreduce_sum: at most 31 values", DCORA_ERR_BAD_ARG);
   if (world == 1) return DCORA_OK;
   const uint64_t q = ++red_seq_;
   ShmRed *slots = red_ + (size_t)(q & 1) * world;
@@ -57,7 +57,7 @@ int Exchange::allreduce_sum(double *vals, int count) {
         sched_yield();
         if ((spins & 255u) == 0) {
           if (hdr_->failed.load()) return fail("another rank failed", DCORA_ERR_HIP);
-          if (since(t0) > 120.0) return fail("rank " + std::to_string(p) + " never joined a sum", DCORA_ERR_HIP);
+          if (since(t0) > exchange_timeout_s()) return fail("rank " + std::to_string(p) + " never joined a sum", DCORA_ERR_HIP);
         }
       }
     }
@@ -72,7 +72,7 @@ int Exchange::certify(const HostCsr *Qglobal, double eta, int *certified, double
                       long long *matvecs, int *distributed) {
   RbcdSession *pgo = dynamic_cast<RbcdSession *>(s_);
   if (!pgo)
-    return fail("certify: the row-block certificate operator exists for pose-graph sessions (the range-aided certificate "
+    return usage("certify: the row-block certificate operator exists for pose-graph sessions (the range-aided certificate "
                 "is assembled centrally: dcora_cert_dual_matrix on the gathered X)",
                 DCORA_ERR_UNSUPPORTED);
   RbcdSession &S = *pgo;

@@ -36,7 +36,8 @@ typedef enum {
   DCORA_ERR_NO_CONVERGENCE = 5,  /* Lanczos did not converge */
   DCORA_ERR_NO_PRECONDITIONER = 6,
   DCORA_ERR_IO = 7,
-  DCORA_ERR_UNSUPPORTED = 8
+  DCORA_ERR_UNSUPPORTED = 8,
+  DCORA_ERR_EXCHANGE_LINK = 9    /* dcora_exchange_create: no transport between the ranks passed its start-up check */
 } dcora_status;
 
 const char *dcora_status_string(int status);
@@ -339,8 +340,18 @@ int dcora_exchange_destroy(dcora_exchange_t ex);
 /* info[10] = {transport (1 = IPC peer stores, 2 = shared host segment), ranks this rank stores to, posts, waits,
  * bytes posted so far, host seconds in post, host seconds in wait, host seconds waiting for the evaluation scalars,
  * 1 when this rank's halo buffer is fine-grained device memory (remote stores never served stale from the local L2),
- * 1 when the scatter kernel itself waits for the producer's flag (default; DCORA_EXCHANGE_WAIT=host: the host spins)} */
+ * 1 when the scatter kernel itself waits for the producer's flag (default where every rank has a GPU of its own and a
+ * fine-grained halo buffer; DCORA_EXCHANGE_WAIT=host: the host spins)}.
+ * dcora_exchange_create ends with a LINK CHECK when there is more than one rank: every rank stores a 4 KB pattern and a
+ * flag into each rank it will write to, through the transport and the form of the wait it is about to use, and every
+ * reader waits for the flag (bounded: 3 s) and compares the pattern word for word.  When any rank's check fails all
+ * ranks step down together -- device-side wait -> host wait -> shared host segment instead of IPC peer stores -- and
+ * check again; when nothing passes, the call returns DCORA_ERR_EXCHANGE_LINK on every rank within seconds instead of
+ * hanging in the first post.  dcora_exchange_link_report says what was tried. */
 int dcora_exchange_info(dcora_exchange_t ex, double *info10);
+/* out[4] = {rounds of the link check run, 1 if the device-side wait was given up, 1 if the IPC transport was given up,
+ * microseconds of the last (passed) round} */
+int dcora_exchange_link_report(dcora_exchange_t ex, double *out4);
 /* getSharedStateDicts of `agents`: each hosted one is written to its neighbours' ranks and flagged (one kernel per
  * agent on the session's stream; returns without synchronising).  A slot is re-used two posts later: the call first
  * waits until every reading rank has scattered that older post (an error after 120 s, never a torn read), so a post

@@ -23,7 +23,19 @@ def main():
     # one GPU per rank where the box has them (peer access + cross-device IPC over xGMI); all ranks on device 0 otherwise
     device = rank % max(da.device_count(), 1)
     s = da.RbcdSession(ds, num_robots=R, r=r, acceleration=accel, rank=rank, world_size=world, device=device)
+    if os.environ.get("DCORA_TEST_EXPECT_LINK_ERROR"):
+        # the link check is made to fail on every transport: every rank gets the distinct error code, quickly
+        import time
+        t0 = time.time()
+        try:
+            da.Exchange(s, job)
+        except Exception as e:
+            np.savez(os.path.join(out_dir, "rank%d.npz" % rank), error=str(e), seconds=time.time() - t0)
+            s.close()
+            return
+        raise SystemExit("the exchange was created although its link check cannot pass")
     ex = da.Exchange(s, job)
+    link = ex.link_report()
     ex.set_X(X0)
     cost, gn, sel = [], [], []
     if mode == "greedy":
@@ -57,7 +69,8 @@ def main():
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), cost=np.array(cost), gradnorm=np.array(gn),
              selected=np.array(sel), X=X, mode=info["mode"], posts=info["posts"], waits=info["waits"],
              bytes_posted=info["bytes_posted"], peers=info["peers"], finegrained=info["halo_finegrained"],
-             wait=info["wait"], device=device,
+             wait=info["wait"], device=device, link_rounds=link["rounds"], link_no_device_wait=link["gave_up_device_wait"],
+             link_no_ipc=link["gave_up_ipc"], link_us=link["last_round_us"],
              **({} if cert is None else dict(cert_ok=cert[0], cert_theta=cert[1], cert_lambda=cert[2], cert_v=cert[3],
                                              cert_matvecs=cert[4], cert_distributed=cert[5])))
     ex.close()

@@ -303,3 +303,37 @@ def test_exchange_bootstrap_does_not_attach_to_a_stale_segment(built, tmp_path):
         rc, cs = np.load(tmp_path / ("cs%d.npy" % k))
         assert rc == 0 and abs(cs - want) <= 1e-9 * abs(want)
     assert not os.path.exists("/dev/shm/dcora_" + job)
+
+
+def _selftest_rank_slow(rank, world, job, R, rounds, tmpdir, timeout_s):
+    os.environ["DCORA_EXCHANGE_TIMEOUT_S"] = str(timeout_s)
+    _selftest_rank(rank, world, job, R, rounds, tmpdir)
+
+
+def test_a_rank_that_dies_takes_the_others_down_within_the_timeout(built, tmp_path):
+    """one of three ranks is killed in the middle of a long run: the other two must notice (the posts / heartbeats of
+    the dead rank never arrive), raise the job's failure flag and exit NON-ZERO within DCORA_EXCHANGE_TIMEOUT_S --
+    never hang (a first multi-GPU run must fail fast)"""
+    import multiprocessing as mp
+    import signal
+    import uuid
+    world, R, rounds, timeout_s = 3, 6, 50_000_000, 3.0
+    job = "cpu%s" % uuid.uuid4().hex[:10]
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_selftest_rank_slow, args=(k, world, job, R, rounds, str(tmp_path), timeout_s))
+             for k in range(world)]
+    for p in procs:
+        p.start()
+    time.sleep(2.0)  # bootstrap done, the rounds are running
+    assert all(p.is_alive() for p in procs), "the run ended before a rank could be killed"
+    os.kill(procs[1].pid, signal.SIGKILL)
+    t0 = time.time()
+    for k in (0, 2):
+        procs[k].join(timeout_s + 20)
+        assert procs[k].exitcode is not None, "rank %d still runs %.0f s after rank 1 died" % (k, time.time() - t0)
+        assert procs[k].exitcode != 0
+    procs[1].join(5)
+    assert time.time() - t0 < timeout_s + 20
+    for k in (0, 2):
+        rc, _ = np.load(tmp_path / ("cs%d.npy" % k))
+        assert rc != 0

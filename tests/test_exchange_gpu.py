@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 WORKER = os.path.join(common.HERE, "exchange_worker.py")
 
 
-def run_ranks(tmp_path, world, name, R, r, iters, mode, X0, transport=None, wait=None, certify=None):
+def run_ranks(tmp_path, world, name, R, r, iters, mode, X0, transport=None, wait=None, certify=None, extra_env=None):
     np.save(os.path.join(tmp_path, "X0.npy"), X0)
     job = "t%s" % uuid.uuid4().hex[:12]
     env = dict(os.environ)
@@ -35,6 +35,8 @@ def run_ranks(tmp_path, world, name, R, r, iters, mode, X0, transport=None, wait
         env["DCORA_TEST_CERTIFY"] = repr(certify)
     else:
         env.pop("DCORA_TEST_CERTIFY", None)
+    for k_, v_ in (extra_env or {}).items():
+        env[k_] = v_
     procs = [subprocess.Popen([sys.executable, WORKER, str(k), str(world), job, name, str(R), str(r), str(iters),
                                str(tmp_path), mode], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
              for k in range(world)]
@@ -238,3 +240,40 @@ def test_two_sessions_pack_unpack_one_process():
         s.close()
     for p in [send, recv] + evs:
         hip.free(p)
+
+
+@pytest.mark.parametrize("faults,wait", [(0, None), (1, "device"), (2, "device"), (1, None)])
+def test_link_check_steps_down_together(tmp_path, faults, wait):
+    """dcora_exchange_create ends with a link check: a 4 KB pattern + flag per neighbour through the transport and the
+    wait about to be used.  With injected failures of the last rank's first rounds all ranks step down the same ladder
+    (device-side wait -> host wait -> shared host segment) and the run still reproduces the single session bit for bit."""
+    import dcora_amd as da
+    name, R, world, iters, r = "sphere2500", 5, 2, 5, 5
+    ds = common.product_dataset(name)
+    X0 = common.random_point(r, ds.d, ds.n, 11, lambda r_, d_, n_, M: da.manifold_project(r_, d_, n_, M))
+    cost, gn, sel, X = single(da, ds, R, r, iters, "greedy", X0)
+    res = run_ranks(str(tmp_path), world, name, R, r, iters, "greedy", X0, None, wait,
+                    extra_env={"DCORA_EXCHANGE_PROBE_FAULT": str(faults)})
+    for k, o in enumerate(res):
+        assert int(o["link_rounds"]) == faults + 1, (k, int(o["link_rounds"]))
+        started_on_device = str(wait) == "device" or (wait is None and da.device_count() >= world)
+        ladder = (["device"] if started_on_device else []) + ["host", "staged"]
+        now = ladder[min(faults, len(ladder) - 1)]
+        assert int(o["mode"]) == (2 if now == "staged" else 1), (k, now, int(o["mode"]))
+        assert bool(o["link_no_ipc"]) == (now == "staged")
+        if faults == 0:
+            assert not bool(o["link_no_device_wait"]) and not bool(o["link_no_ipc"]) and float(o["link_us"]) < 2e6
+        assert np.array_equal(o["X"], X) and np.array_equal(o["selected"], sel)
+
+
+def test_link_check_that_cannot_pass_fails_fast_on_every_rank(tmp_path):
+    """no transport passes the check: every rank returns DCORA_ERR_EXCHANGE_LINK within seconds -- never a hang in the
+    first post"""
+    import dcora_amd as da
+    name, R, world, r = "sphere2500", 5, 2, 5
+    ds = common.product_dataset(name)
+    X0 = common.random_point(r, ds.d, ds.n, 11, lambda r_, d_, n_, M: da.manifold_project(r_, d_, n_, M))
+    res = run_ranks(str(tmp_path), world, name, R, r, 1, "greedy", X0, None, None,
+                    extra_env={"DCORA_EXCHANGE_PROBE_FAULT": "9", "DCORA_TEST_EXPECT_LINK_ERROR": "1"})
+    for o in res:
+        assert "link check" in str(o["error"]) and float(o["seconds"]) < 60

@@ -269,6 +269,31 @@ def test_min_eig_shift_invert_fallback(env):
     assert oko and abs(lamo - want) < 1e-8
 
 
+def test_min_eig_far_below_the_first_shift_under_a_huge_spectrum(env):
+    """lambda_min = -50 (below the fallback's first shift, -10) under lambda_lm = 4e6 (tolerance ratio 2.5e-10: the
+    spectrum-shifted run is skipped as hopeless): the Cholesky-based shift-and-invert fallback must move its shift
+    OUTWARD until S - sigma I factors instead of giving up with v = 0 (the reference's LU-based Spectra run has no such
+    limit: ref src/DCORA_utils.cpp:1751-1805).  ADVICE round 3."""
+    import scipy.sparse as sp
+    da, orc = env
+    n = 400
+    rng = np.random.default_rng(5)
+    d = np.concatenate(([-50.0], rng.uniform(1.0, 30.0, n - 2), [4e6]))
+    # an orthogonal similarity that keeps the matrix sparse: a product of plane rotations on neighbouring pairs
+    A = sp.diags(d).tocsr()
+    for off in (0, 1):
+        c, s_ = np.cos(0.7), np.sin(0.7)
+        blocks = [np.array([[c, -s_], [s_, c]])] * ((n - off) // 2)
+        G = sp.block_diag(([np.eye(1)] if off else []) + blocks + ([np.eye(1)] if (n - off) % 2 else []), format="csr")
+        A = (G @ A @ G.T).tocsr()
+    A = ((A + A.T) * 0.5).tocsr()
+    A.sort_indices()
+    S = da.Csr.from_scipy(A)
+    ok, lam, v, mv = da.min_eig(S, tol=1e-3)
+    assert ok and abs(lam + 50.0) < 1e-6, (ok, lam)
+    assert np.linalg.norm(A @ v - lam * v) < 1e-5 and abs(np.linalg.norm(v) - 1) < 1e-12
+
+
 def test_planar_pose_graph_csail_rbcd_and_certificate(env):
     """a planar (d = 2) dataset of the reference's data directory through the whole path: CSAIL.g2o (1045 poses, 1171
     measurements), 4 agents, r = 3: chordal start, RBCD++ trace against the oracle, certificate at the solution"""
