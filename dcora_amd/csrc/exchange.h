@@ -53,6 +53,7 @@ struct ShmHeader {
   std::atomic<uint32_t> bar_count, bar_gen;
   std::atomic<uint32_t> failed;  // a rank gave up: everybody waiting returns an error instead of spinning on
   int32_t creator_pid;           // rank 0's process: a segment whose creator is gone is a stale one (crashed job)
+  uint64_t creator_start;        // ... and its start time (/proc/<pid>/stat): a recycled pid is not the creator
 };
 
 enum ExchangeMode { kExchangeIpc = 1, kExchangeStaged = 2 };

@@ -176,6 +176,30 @@ __global__ __launch_bounds__(256) void k_probe_wait(const double *src, const uin
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// start time of a process in clock ticks since boot (field 22 of /proc/<pid>/stat), 0 when it cannot be read
+uint64_t proc_start_time(int pid) {
+  char path[64], buf[1024];
+  std::snprintf(path, sizeof path, "/proc/%d/stat", pid);
+  FILE *fp = std::fopen(path, "r");
+  if (!fp) return 0;
+  const size_t n = std::fread(buf, 1, sizeof buf - 1, fp);
+  std::fclose(fp);
+  buf[n] = 0;
+  const char *p = std::strrchr(buf, ')');  // the command may hold spaces and parentheses: fields resume behind the last ')'
+  if (!p) return 0;
+  int field = 2;
+  for (++p; *p; ++p)
+    if (*p == ' ' && ++field == 22) return std::strtoull(p + 1, nullptr, 10);
+  return 0;
+}
+// is the creator of a segment still the process that wrote the header?
+bool creator_alive(const ShmHeader *h) {
+  if (h->creator_pid <= 0) return false;
+  if (!(kill((pid_t)h->creator_pid, 0) == 0 || errno == EPERM)) return false;
+  const uint64_t now = proc_start_time(h->creator_pid);
+  return now == 0 || h->creator_start == 0 || now == h->creator_start;  // (no /proc: the pid test alone)
+}
+
 // host polling with back-off: a burst of pause instructions, then the core is handed over between polls (a rank per
 // core is not guaranteed: the four-ranks-on-one-GPU rehearsal runs on whatever cores the container has)
 inline void polite_spin(unsigned &spins) {
@@ -255,6 +279,7 @@ int Exchange::open_segment(const char *job_name, size_t bytes) {
     hdr_->slot_doubles = slot_;
     hdr_->total_bytes = bytes;
     hdr_->creator_pid = (int32_t)getpid();
+    hdr_->creator_start = proc_start_time((int)getpid());
     hdr_->magic.store(kShmMagic, std::memory_order_release);
     return DCORA_OK;
   }
@@ -269,8 +294,7 @@ int Exchange::open_segment(const char *job_name, size_t bytes) {
         void *hp = mmap(nullptr, sizeof(ShmHeader), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
         if (hp != MAP_FAILED) {
           ShmHeader *h = (ShmHeader *)hp;
-          const bool live = h->magic.load(std::memory_order_acquire) == kShmMagic && h->creator_pid > 0 &&
-                            (kill((pid_t)h->creator_pid, 0) == 0 || errno == EPERM);
+          const bool live = h->magic.load(std::memory_order_acquire) == kShmMagic && creator_alive(h);
           const bool other = live && (h->world != (uint32_t)world || h->R != (uint32_t)R_ || h->slot_doubles != slot_ ||
                                       h->total_bytes != bytes);
           if (other && since(t0) > 1.0) {  // (a second: a crashed job's segment is replaced by rank 0 within that)
@@ -306,8 +330,7 @@ int Exchange::open_segment(const char *job_name, size_t bytes) {
       const int fd2 = shm_open(name_.c_str(), O_RDONLY, 0600);
       const bool same = fd2 >= 0 && fstat(fd2, &now) == 0 && now.st_ino == sb.st_ino && now.st_dev == sb.st_dev;
       if (fd2 >= 0) close(fd2);
-      const bool alive = h->creator_pid > 0 && (kill((pid_t)h->creator_pid, 0) == 0 || errno == EPERM);
-      good = same && alive;
+      good = same && creator_alive(h);
     }
     if (!good) {
       munmap(mp, bytes);

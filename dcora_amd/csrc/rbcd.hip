@@ -396,7 +396,44 @@ int RbcdSession::update_selected_agent(AgentDev &a, bool restart) {
       return true;
     };
     if (a.detached && !cache_complete(opt.acceleration ? 1 : 0)) {
-      a.last_skipped = true;  // "cannot construct data matrices... Skip optimization" (ref src/Agent.cpp:1243-1249)
+      // "cannot construct data matrices... Skip optimization" (ref src/Agent.cpp:1243-1249): only updateX is skipped;
+      // updateGamma / updateAlpha / updateY have run before it and updateV and the restart follow (Agent::iterate, ref
+      // src/Agent.cpp:535-596) -- X stays, Y <- proj((1 - alpha) X + alpha V), V <- proj(V + gamma (X - Y))
+      a.last_skipped = true;
+      if (opt.acceleration) {
+        if (staged_selected_ != a.id || staged_iteration_ != iteration)
+          nesterov(st, pb.m, 1, 0, -1, -1, alpha, gamma, Xg.p + off, Vg.p + off, Yg.p + off, XPrevg.p + off, pb.X0.p,
+                   Buf2{{nullptr, nullptr}}, nullptr);
+        staged_selected_ = -1;
+        const Buf2 Xself{{Xg.p + off, Xg.p + off}};
+        nesterov(st, pb.m, 2, 0, -1, -1, alpha, gamma, Xg.p + off, Vg.p + off, Yg.p + off, XPrevg.p + off, nullptr, Xself,
+                 nullptr);
+        a.v_feasible = true;
+        if (restart) {
+          // restartNesterovAcceleration: X = XPrev; updateX(true, false) reads the PLAIN cache; V = X; Y = X
+          const Buf2 Xprev{{XPrevg.p + off, XPrevg.p + off}};
+          bool solved = false;
+          if (cache_complete(0)) {
+            launch_spmm(st, r, a.coupling.view(), buf1(a.nbr[0].p), 0, nullptr, buf1(pb.G.p), 0, nullptr, Gate{});
+            pb.has_G = true;
+            last_solver = &pb;
+            Buf2 Xres{{nullptr, nullptr}};
+            const SolverCtl *cs = nullptr;
+            DCORA_HIP(hipMemcpyAsync(pb.X0.p, XPrevg.p + off, B, hipMemcpyDeviceToDevice, st));
+            rc = pb.optimize_dev(opt.local, &Xres, &cs);
+            if (rc) return rc;
+            rc = resolve_pick(pb, &Xres, &cs);
+            if (rc) return rc;
+            nesterov(st, pb.m, 3, 0, -1, -1, alpha, gamma, Xg.p + off, Vg.p + off, Yg.p + off, XPrevg.p + off, nullptr,
+                     Xres, cs);
+            a.last_skipped = false;
+            solved = true;
+          }
+          if (!solved)
+            nesterov(st, pb.m, 3, 0, -1, -1, alpha, gamma, Xg.p + off, Vg.p + off, Yg.p + off, XPrevg.p + off, nullptr,
+                     Xprev, nullptr);
+        }
+      }
       return DCORA_OK;
     }
     const double *nsrc = a.detached ? a.nbr[opt.acceleration ? 1 : 0].p : Xg.p;
@@ -420,19 +457,28 @@ int RbcdSession::update_selected_agent(AgentDev &a, bool restart) {
       a.v_feasible = true;  // V = proj(V + gamma (X - Y))
       if (restart) {
         // restartNesterovAcceleration: X = XPrev; updateX(true, false); V = X; Y = X
+        bool plain_ok = true;
         if (a.detached) {  // updateX(.., false) reads the PLAIN cache (ref src/Agent.cpp:1237-1240)
-          if (cache_complete(0))
+          if (cache_complete(0)) {
             launch_spmm(st, r, a.coupling.view(), buf1(a.nbr[0].p), 0, nullptr, buf1(pb.G.p), 0, nullptr, Gate{});
-          else
-            a.last_skipped = true;
+          } else {
+            a.last_skipped = true;  // no G can be built from an incomplete cache: X = XPrev without the solve
+            plain_ok = false;
+          }
         }
-        DCORA_HIP(hipMemcpyAsync(pb.X0.p, XPrevg.p + off, B, hipMemcpyDeviceToDevice, st));
-        rc = pb.optimize_dev(opt.local, &Xres, &cs);
-        if (rc) return rc;
-        rc = resolve_pick(pb, &Xres, &cs);
-        if (rc) return rc;
-        nesterov(st, pb.m, 3, 0, -1, -1, alpha, gamma, Xg.p + off, Vg.p + off, Yg.p + off, XPrevg.p + off, nullptr,
-                 Xres, cs);
+        if (plain_ok) {
+          DCORA_HIP(hipMemcpyAsync(pb.X0.p, XPrevg.p + off, B, hipMemcpyDeviceToDevice, st));
+          rc = pb.optimize_dev(opt.local, &Xres, &cs);
+          if (rc) return rc;
+          rc = resolve_pick(pb, &Xres, &cs);
+          if (rc) return rc;
+          nesterov(st, pb.m, 3, 0, -1, -1, alpha, gamma, Xg.p + off, Vg.p + off, Yg.p + off, XPrevg.p + off, nullptr,
+                   Xres, cs);
+        } else {
+          const Buf2 Xprev{{XPrevg.p + off, XPrevg.p + off}};
+          nesterov(st, pb.m, 3, 0, -1, -1, alpha, gamma, Xg.p + off, Vg.p + off, Yg.p + off, XPrevg.p + off, nullptr,
+                   Xprev, nullptr);
+        }
       }
     } else {
       DCORA_HIP(hipMemcpyAsync(XPrevg.p + off, Xg.p + off, B, hipMemcpyDeviceToDevice, st));
