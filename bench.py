@@ -41,6 +41,58 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md; about 6.3
 SUSTAINED_STEPS = 300
 
 
+CACHE_PATH = os.path.join(ROOT, "gpurun_out", "bench_n1_cache.json")
+
+
+def cache_store(obj):
+    """the N = 1 run leaves what the N > 1 lines quote beside their own numbers (the CPU baseline, the one-GPU
+    denominators of the scaling ratios): best effort, never an error"""
+    try:
+        os.makedirs(os.path.dirname(CACHE_PATH), exist_ok=True)
+        with open(CACHE_PATH, "w") as fh:
+            json.dump(obj, fh)
+    except Exception:
+        pass
+
+
+def cache_load():
+    try:
+        with open(CACHE_PATH) as fh:
+            return json.load(fh)
+    except Exception:
+        return None
+
+
+def scaling_block(world, strong, c5, cached):
+    """The workload that CAN scale, named at the top level of the line at every N: the 100k-pose lattice, coloured
+    simultaneous ticks with R = 2 N agents (agents 2g and 2g + 1 -- one of each colour -- on rank g), same graph, start
+    point and sweeps at every N; beside it the sequential RBCD++ rate on the same graph (8 agents, BASELINE config 5),
+    which updates one block per iteration and is not expected to rise with N."""
+    out = {"workload": "synthetic 50x50x40 SE(3) lattice (100000 poses, seed 20250310), r = 5; same graph, start point "
+                       "and number of sweeps at every N",
+           "n_gpus": world, "scaling": "strong",
+           "how_to_read": "speed-up(N) = coloured_ticks.sweeps_per_s at N GPUs / one_gpu_same_R.sweeps_per_s (the N = 1 "
+                          "run measures R = 4, 8, 16 on one GPU: the denominators for N = 2, 4, 8)"}
+    R = 2 * world
+    if strong is not None:
+        if world == 1:
+            out["one_gpu"] = strong.get("one_gpu")
+        else:
+            out["coloured_ticks"] = strong.get("R=%d" % R)
+            one = ((cached or {}).get("strong_one_gpu") or {}).get("R=%d" % R)
+            if one and "sweeps_per_s" in one and out["coloured_ticks"] and "sweeps_per_s" in out["coloured_ticks"]:
+                out["one_gpu_same_R"] = {"sweeps_per_s": one["sweeps_per_s"], "source": "the N = 1 run of this bench on this "
+                                         "box (gpurun_out/bench_n1_cache.json)"}
+                out["speedup_vs_one_gpu_same_R"] = out["coloured_ticks"]["sweeps_per_s"] / one["sweeps_per_s"]
+            else:
+                out["one_gpu_same_R"] = None
+                out["one_gpu_same_R_note"] = "no N = 1 run of this bench left its cache on this box: see the N = 1 line"
+    if c5 is not None:
+        out["sequential_rbcd_8_agents"] = {k: c5.get(k) for k in ("value", "unit", "ms_per_step", "parallelism", "exchange",
+                                                                  "staircase_ranks", "error") if k in c5}
+    return out
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -500,7 +552,7 @@ def committed_profile(nbytes):
     passes): NOT measured in this run, reported under their own key with their source"""
     import csv
     out = {"note": "read from committed rocprofv3 summaries, not measured in this run"}
-    for tag in ("r03", "r02", "r01"):
+    for tag in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_kernel_stats_headline_loop.csv" % tag)
         if not os.path.exists(path):
             continue
@@ -518,7 +570,7 @@ def committed_profile(nbytes):
         except Exception:
             pass
         break
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
         pmc = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pmc):
             try:
@@ -559,31 +611,45 @@ def roofline(da, ds, r, robots):
     Pb.f(np.zeros((r, kb)))
     ms, nbytes = Pb.time_precond(reps=300)
     pinfo = Pb.precond_info()
-    ach = nbytes / (ms * 1e-3) / 1e9
-    sec8d = 2.0 * pinfo["nnzL"] * 12 + 2.0 * r * kb * 8
+    ach_streamed = nbytes / (ms * 1e-3) / 1e9
+    # the ALGORITHMIC bytes of one tCG-iteration's preconditioner step are those of a sparse-factor solve,
+    # 2 nnz(L) 12, plus the 7 passes over r x k vectors this launch also makes (r_old, H delta in; eta, H eta, r, z through)
+    sec8d = 2.0 * pinfo["nnzL"] * 12 + 7.0 * r * kb * 8
+    ach = sec8d / (ms * 1e-3) / 1e9
     one_launch = os.environ.get("DCORA_SOLVER_BC") != "split" and r <= 7 and r * kb <= 12800
     kname = "k_fused_pc (step length + vector updates + dense preconditioner product + projection + stopping rule, " \
             "one launch)" if one_launch else "k_fused_precond (step length + vector updates + dense preconditioner slices)"
     main = {"bound": "hbm", "kernel": "%s, one agent, k=%d" % (kname, kb),
             "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+            "algorithmic_bytes_per_launch": sec8d,
+            "frac_algorithmic": ach / HBM_PEAK_GBPS,
+            "frac_streamed": ach_streamed / HBM_PEAK_GBPS,
+            "achieved_streamed": ach_streamed,
             "bytes_per_launch": nbytes, "avg_launch_us": ms * 1e3,
+            "frac_note": "`achieved` / `frac` use SURVEY 8(d)'s algorithmic bytes (a sparse-factor solve: 2 nnz(L) 12 + "
+                         "7 r k 8); `frac_streamed` counts the dense symmetric inverse (8 k^2) the kernel actually "
+                         "streams: it trades bytes for launches at k = 2000, where the loop is latency-bound",
             "peak_note": "spec peak of HBM3E; measured_stream_triad is what a = b + s c over 6.4 GB reaches on this box in "
                          "this run, and at this kernel's size the operands sit in the 256 MiB Infinity Cache",
             "measured_stream_triad_GBps": da.stream_triad_gbps(),
-            "bytes_counted": "what the kernel's data structure streams once: the dense symmetric inverse (8 k^2) and 7 "
-                             "passes over r x k vectors (r_old, H delta in; eta, H eta, r, z through); not counted: "
-                             "every workgroup re-reading r_old and H delta from L2 to rebuild the residual",
-            "survey_8d": {"formula": "bytes_precond = 2 nnz(L) 12 + 2 r k 8 (a sparse-factor solve)",
+            "bytes_counted": "streamed: the dense symmetric inverse (8 k^2) and 7 passes over r x k vectors (r_old, "
+                             "H delta in; eta, H eta, r, z through); not counted: every workgroup re-reading r_old and "
+                             "H delta from L2 to rebuild the residual",
+            "survey_8d": {"formula": "bytes_precond = 2 nnz(L) 12 (a sparse-factor solve) + 7 r k 8",
                           "nnz_L": pinfo["nnzL"], "bytes_precond": sec8d,
-                          "achieved_GBps": sec8d / (ms * 1e-3) / 1e9,
-                          "frac": sec8d / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                          "dense_bytes_over_8d_bytes": nbytes / sec8d,
-                          "note": "the dense inverse trades bandwidth for latency at k = 2000 (one launch instead of "
-                                  "a chain of dependent sparse levels); by the sparse-factor byte count the kernel "
-                                  "sits at a few percent of the roofline, and the loop is latency-bound"},
+                          "dense_bytes_over_8d_bytes": nbytes / sec8d},
             "measured": "HIP events on the solver's stream around 300 back-to-back launches of the kernel in its "
                         "in-loop form, in this run"}
     main["from_committed_profile"] = committed_profile(nbytes)
+    tb = main["from_committed_profile"].get("traffic_bytes_per_launch")
+    if tb:
+        main["traffic"] = tb
+        main["traffic_note"] = ("HBM-side bytes per launch of this kernel from the committed rocprofv3 PMC passes (%s; "
+                                "FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE), not collected in this run; "
+                                "%.1f x the algorithmic bytes: the dense inverse is streamed on purpose"
+                                % (main["from_committed_profile"].get("traffic_source"), tb / sec8d))
+    else:
+        main["traffic_note"] = "no committed PMC pass found under profiles/"
     Pb.close()
     try:  # the same kernel on a block 2.5 x larger (sphere2500 split in two, k = 5000): a longer launch
         nb2, ids2, vals2 = agent_block(ds, 2, 0)
@@ -637,15 +703,23 @@ def roofline(da, ds, r, robots):
         ms, nbytes = Pa.time_precond(reps=50)
         info = Pa.precond_info()
         Pa.close()
+        by_rank = {}
+        for rr in (6, 7):  # the staircase ranks: the matrix-pipe kernel's time does not depend on r <= 8
+            Pr = da.QuadraticProblem(rr, big.d, nb, Qa, G=np.zeros((rr, ka)), reg=0.1)
+            Pr.f(np.zeros((rr, ka)))
+            by_rank["r=%d" % rr] = {"avg_application_us": 1e3 * Pr.time_precond(reps=50)[0]}
+            Pr.close()
         ach = nbytes / (ms * 1e-3) / 1e9
         s8 = 2.0 * info["nnzL"] * 12 + 2.0 * r * ka * 8
         out["precond_sparse_lattice100k_agent"] = {
-            "kernel": "partitioned sparse inverse replay (z = r (Q + 0.1 I)^-1): k_sp_multi, merged-level schedule, "
-                      "%d launches (two of them the permutations the solver folds into its own kernels)" % info["launches"],
+            "kernel": "partitioned sparse inverse replay (z = r (Q + 0.1 I)^-1): k_sp_mtile (4-row tiles on "
+                      "v_mfma_f64_4x4x4_4b, weights stored once in 4 x 4 micro-blocks), merged-level schedule, %d launches "
+                      "(two of them the permutations the solver folds into its own kernels)" % info["launches"],
             "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
             "bytes_per_application": nbytes, "avg_application_us": ms * 1e3, "launches": info["launches"], "k": ka,
             "nnz_L": info["nnzL"], "survey_8d_bytes_precond": s8,
-            "survey_8d_frac": s8 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "dense_inverse_bytes_avoided": 8.0 * ka * ka}
+            "survey_8d_frac": s8 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "dense_inverse_bytes_avoided": 8.0 * ka * ka,
+            "by_rank": by_rank}
     except Exception as e:  # the headline line must not depend on the side measurement
         out["qapply_lattice100k"] = {"error": str(e)}
     return main, out
@@ -924,6 +998,7 @@ def config5_central(da, r=5):
                                     "gradnorm_last": float(o8["gradnorm"][-1]),
                                     "excess_over_optimum": {str(i): float(c8[min(i, len(c8)) - 1] / f_star2 - 1.0)
                                                             for i in (100, 300, 1000)}}
+        chordal["distributed_loop_to_the_drivers_stopping_rule"] = distributed_to_tolerance(da, ds, Xc, r, f_star2)
     except Exception as e:
         chordal = {"error": str(e)}
         Y = None
@@ -952,6 +1027,53 @@ def config5_central(da, r=5):
             "from_the_chordal_start": chordal,
             "cpu_port": None, "cpu_note": "no CPU leg: the oracle's sparse Cholesky of this matrix does not finish in "
                                           "minutes (DESIGN.md section 8)"}
+
+
+DIST_BUDGET_S = 25.0
+
+
+def distributed_to_tolerance(da, ds, X0, r, f_star2, R=8, budget_s=DIST_BUDGET_S):
+    """What the DISTRIBUTED loop needs on config 5 to reach the reference driver's stopping rule |rgrad| < 0.1
+    (examples/MultiRobotExample.cpp:284) from the chordal start, or where it stands when the budget runs out: RBCD++ (greedy
+    selection, acceleration with restarts) and coloured simultaneous ticks, 8 agents on one GPU.  Lets "ms to certified
+    optimum" of config 5 be read without the centralised shortcut: the certificate itself adds
+    config5_central_certified.certification_s."""
+    out = {"stopping_rule": "|rgrad| < 0.1 (ref examples/MultiRobotExample.cpp:284)", "budget_s_per_mode": budget_s,
+           "agents": R}
+    s = da.RbcdSession(ds, num_robots=R, r=r)
+    s.set_X(X0)
+    t0 = time.perf_counter()
+    iters, gn, c2 = 0, None, None
+    while time.perf_counter() - t0 < budget_s:
+        o = s.run(max_iters=500, rgrad_tol=0.1)  # continues from the session's state
+        iters += int(o["iters"])
+        gn, c2 = float(o["gradnorm"][-1]), float(o["cost"][-1])
+        if gn < 0.1:
+            break
+    dt = time.perf_counter() - t0
+    out["rbcd_pp"] = {"reached": bool(gn is not None and gn < 0.1), "iterations": iters, "seconds": dt, "gradnorm": gn,
+                      "cost_2f": c2, "excess_over_optimum": None if c2 is None else c2 / f_star2 - 1.0}
+    s.close()
+    s = da.RbcdSession(ds, num_robots=R, r=r, acceleration=False)
+    s.set_X(X0)
+    col, nc = s.colours()
+    sets = [np.flatnonzero(col == c).astype(np.int32) for c in range(nc)]
+    t0 = time.perf_counter()
+    sweeps, gn, c2 = 0, None, None
+    while time.perf_counter() - t0 < budget_s:
+        for S in sets:
+            s.iterate_set(S)
+        sweeps += 1
+        if sweeps % 5 == 0:
+            c2, gn = [float(x) for x in s.evaluate()[:2]]
+            if gn < 0.1:
+                break
+    c2, gn = [float(x) for x in s.evaluate()[:2]]
+    dt = time.perf_counter() - t0
+    out["coloured_ticks"] = {"reached": bool(gn < 0.1), "sweeps": sweeps, "block_updates": sweeps * R, "seconds": dt,
+                             "gradnorm": gn, "cost_2f": c2, "excess_over_optimum": c2 / f_star2 - 1.0}
+    s.close()
+    return out
 
 
 def side_multi(da, torch, dist, rank, world, ds, R, r, workload, iters=60, sweeps=8, more_ranks=()):
@@ -1264,6 +1386,10 @@ def main():
                    "parallelism": "agents in consecutive groups over %d rank(s)" % world,
                    "timed_iterations": "%d..%d of the trajectory from the start point" %
                                        (args.warmup + 2, args.warmup + 1 + args.steps),
+                   "window_note": "iterations early in the trajectory are cheaper on BOTH sides (tCG exits early): a short "
+                                  "window such as the driver's --steps 20 --warmup 5 reads ~1.6 x the sustained rate; "
+                                  "`sustained` continues the same trajectory for %d more iterations and "
+                                  "cpu_baseline.same_window_as_value is the CPU port over the same window" % SUSTAINED_STEPS,
                    "final_cost_2f": c2, "final_gradnorm": gn},
     }
     if getattr(run_single, "samples", None):
@@ -1287,6 +1413,24 @@ def main():
         line["config5_lattice100k"] = c5
     if strong is not None:
         line["strong_scaling"] = strong
+    if multi:
+        cached = cache_load()
+        line["scaling_100k_lattice"] = scaling_block(world, strong, c5, cached)
+        if not args.no_cpu_baseline:
+            # the CPU port is timed ONCE (rank 0 of the N = 1 run); the N > 1 lines quote that figure -- or time it
+            # here, on rank 0 only and after the timed region, when no N = 1 run left it on this box
+            if cached and cached.get("cpu_baseline") and cached.get("steps") == args.steps and \
+                    cached.get("warmup") == args.warmup:
+                cb = dict(cached["cpu_baseline"])
+                cb["source"] = "timed by the N = 1 run of this bench on this box (not re-timed per N)"
+            else:
+                cb = cpu_baseline(args, args.dataset, X0)
+                cb["source"] = "timed in this run on rank 0 after the timed region (no N = 1 cache on this box)"
+            line["cpu_baseline"] = cb
+            try:
+                line["config"]["speedup_vs_cpu_port"] = line["value"] / cb["same_window_as_value"]["value"]
+            except Exception:
+                pass
     line["roofline"], line["roofline_qapply"] = roofline(da, ds, args.rank_r, args.robots)
     if world == 1 and not multi:
         try:
@@ -1304,11 +1448,8 @@ def main():
             except Exception as e:
                 line["psd_test"] = {"error": str(e)}
         if not args.no_config5:
-            try:
-                line["config5_central_certified"] = config5_central(da)
-            except Exception as e:
-                line["config5_central_certified"] = {"error": str(e)}
-        if not args.no_config5:
+            # (the throughput windows first: the centralised solve and the 2 x 25 s of the distributed loop behind them
+            # leave the GPU at a lower clock -- the same 60-iteration window read 877 instead of 1160 it/s after them)
             try:
                 line["config5_lattice100k"] = config5_run(da, not args.no_cpu_baseline)
             except Exception as e:
@@ -1317,6 +1458,11 @@ def main():
                 line["strong_scaling"] = strong_scaling_single(da)
             except Exception as e:
                 line["strong_scaling"] = {"error": str(e)}
+        if not args.no_config5:
+            try:
+                line["config5_central_certified"] = config5_central(da)
+            except Exception as e:
+                line["config5_central_certified"] = {"error": str(e)}
         if not args.no_config4:
             try:
                 line["config4_tiers"] = config4_run(da, not args.no_cpu_baseline, args.cpu_c4_staircase)
@@ -1327,6 +1473,10 @@ def main():
             # like for like: each GPU window against the oracle's rate over the same iterations
             line["config"]["speedup_vs_cpu_port"] = line["value"] / cb["same_window_as_value"]["value"]
             line["sustained"]["speedup_vs_cpu_port"] = line["sustained"]["value"] / cb["value"]
+        line["scaling_100k_lattice"] = scaling_block(1, line.get("strong_scaling"), line.get("config5_lattice100k"), None)
+        cache_store({"cpu_baseline": line.get("cpu_baseline"),
+                     "strong_one_gpu": (line.get("strong_scaling") or {}).get("one_gpu"),
+                     "steps": args.steps, "warmup": args.warmup})
     real_stdout.write(json.dumps(line) + "\n")
     real_stdout.flush()
 
