@@ -108,6 +108,8 @@ SIGNATURES = {
     "dcora_graph_build_Q_pgo": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _ip, _dp, C.POINTER(_vp)]),
     "dcora_radataset_load_pyfg": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
     "dcora_radataset_info": (C.c_int, [_vp, _ip]),
+    "dcora_radataset_create": (C.c_int, [C.c_int] * 5 + [_vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "dcora_radataset_copy": (C.c_int, [_vp] * 7),
     "dcora_radataset_ground_truth": (C.c_int, [_vp, _dp]),
     "dcora_radataset_build_Q": (C.c_int, [_vp, C.POINTER(_vp)]),
     "dcora_radataset_odometry_init": (C.c_int, [_vp, C.c_ulonglong, _dp]),

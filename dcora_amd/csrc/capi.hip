@@ -690,6 +690,124 @@ int dcora_radataset_load_pyfg(const char *path, dcora_radataset_t *out) {
   return DCORA_OK;
   DCORA_CATCH
 }
+// Graph::setMeasurements(const RelativeMeasurements &) of a range-aided graph (ref src/Graph.cpp:374-470): the three
+// kinds of measurements as arrays, states numbered as the Graph numbers them (poses 0 .. n - 1, unit spheres 0 .. l - 1 --
+// one per range measurement --, landmarks 0 .. b - 1); every state is owned by robot 0 (the centralised agent)
+int dcora_radataset_create(int d, int n, int l, int b, int m_pp, const int *pp_ids, const double *pp_vals, int m_pl,
+                           const int *pl_ids, const double *pl_vals, int m_rg, const int *rg_ids, const double *rg_vals,
+                           const double *gt, dcora_radataset_t *out) {
+  if (!out || (m_pp > 0 && (!pp_ids || !pp_vals)) || (m_pl > 0 && (!pl_ids || !pl_vals)) ||
+      (m_rg > 0 && (!rg_ids || !rg_vals)))
+    return bad("null argument");
+  if ((d != 2 && d != 3) || n < 0 || l < 0 || b < 0 || m_pp < 0 || m_pl < 0 || m_rg < 0) return bad("bad dimensions");
+  DCORA_TRY
+  auto h = std::make_unique<dcora_radataset_s>();
+  HostRADataset &ds = h->ds;
+  ds.d = d;
+  ds.n = n;
+  ds.l = l;
+  ds.b = b;
+  const int w = d * d + d + 3;
+  for (int i = 0; i < m_pp; ++i) {
+    PoseMeas m;
+    m.p1 = pp_ids[2 * i];
+    m.p2 = pp_ids[2 * i + 1];
+    if (m.p1 < 0 || m.p1 >= n || m.p2 < 0 || m.p2 >= n) return bad("pose-pose measurement: pose out of range");
+    const double *v = pp_vals + (size_t)i * w;
+    for (int c = 0; c < d; ++c)
+      for (int a = 0; a < d; ++a) m.R[c * d + a] = v[c * d + a];
+    for (int a = 0; a < d; ++a) m.t[a] = v[d * d + a];
+    m.kappa = v[d * d + d];
+    m.tau = v[d * d + d + 1];
+    m.weight = v[d * d + d + 2];
+    ds.pose_pose.push_back(m);
+  }
+  for (int i = 0; i < m_pl; ++i) {
+    PoseLandmarkMeasH m;
+    m.i = pl_ids[2 * i];
+    m.j = pl_ids[2 * i + 1];
+    if (m.i < 0 || m.i >= n || m.j < 0 || m.j >= b) return bad("pose-landmark measurement: state out of range");
+    const double *v = pl_vals + (size_t)i * (d + 2);
+    for (int a = 0; a < d; ++a) m.t[a] = v[a];
+    m.tau = v[d];
+    m.weight = v[d + 1];
+    ds.pose_landmark.push_back(m);
+  }
+  for (int i = 0; i < m_rg; ++i) {
+    RangeMeasH m;
+    m.type1 = rg_ids[5 * i];
+    m.i = rg_ids[5 * i + 1];
+    m.type2 = rg_ids[5 * i + 2];
+    m.j = rg_ids[5 * i + 3];
+    m.l = rg_ids[5 * i + 4];
+    const bool ok1 = m.type1 == 0 ? (m.i >= 0 && m.i < n) : (m.type1 == 1 && m.i >= 0 && m.i < b);
+    const bool ok2 = m.type2 == 0 ? (m.j >= 0 && m.j < n) : (m.type2 == 1 && m.j >= 0 && m.j < b);
+    if (!ok1 || !ok2 || m.l < 0 || m.l >= l) return bad("range measurement: state out of range");
+    m.range = rg_vals[3 * i];
+    m.precision = rg_vals[3 * i + 1];
+    m.weight = rg_vals[3 * i + 2];
+    ds.ranges.push_back(m);
+  }
+  ds.gt.assign((size_t)d * ds.k(), 0.0);
+  if (gt) std::copy(gt, gt + (size_t)d * ds.k(), ds.gt.begin());
+  ds.pose_robot.assign((size_t)n, 0);
+  ds.sphere_robot.assign((size_t)l, 0);
+  ds.landmark_robot.assign((size_t)b, 0);
+  *out = h.release();
+  return DCORA_OK;
+  DCORA_CATCH
+}
+// the measurements of a dataset in the arrays dcora_radataset_create takes (sizes: dcora_radataset_info); any may be NULL
+int dcora_radataset_copy(dcora_radataset_t h, int *pp_ids, double *pp_vals, int *pl_ids, double *pl_vals, int *rg_ids,
+                         double *rg_vals) {
+  if (!h) return bad("null");
+  const HostRADataset &ds = h->ds;
+  const int d = ds.d, w = d * d + d + 3;
+  for (size_t i = 0; i < ds.pose_pose.size(); ++i) {
+    const PoseMeas &m = ds.pose_pose[i];
+    if (pp_ids) {
+      pp_ids[2 * i] = m.p1;
+      pp_ids[2 * i + 1] = m.p2;
+    }
+    if (pp_vals) {
+      double *v = pp_vals + i * w;
+      for (int c = 0; c < d * d; ++c) v[c] = m.R[c];
+      for (int a = 0; a < d; ++a) v[d * d + a] = m.t[a];
+      v[d * d + d] = m.kappa;
+      v[d * d + d + 1] = m.tau;
+      v[d * d + d + 2] = m.weight;
+    }
+  }
+  for (size_t i = 0; i < ds.pose_landmark.size(); ++i) {
+    const PoseLandmarkMeasH &m = ds.pose_landmark[i];
+    if (pl_ids) {
+      pl_ids[2 * i] = m.i;
+      pl_ids[2 * i + 1] = m.j;
+    }
+    if (pl_vals) {
+      double *v = pl_vals + i * (d + 2);
+      for (int a = 0; a < d; ++a) v[a] = m.t[a];
+      v[d] = m.tau;
+      v[d + 1] = m.weight;
+    }
+  }
+  for (size_t i = 0; i < ds.ranges.size(); ++i) {
+    const RangeMeasH &m = ds.ranges[i];
+    if (rg_ids) {
+      rg_ids[5 * i] = m.type1;
+      rg_ids[5 * i + 1] = m.i;
+      rg_ids[5 * i + 2] = m.type2;
+      rg_ids[5 * i + 3] = m.j;
+      rg_ids[5 * i + 4] = m.l;
+    }
+    if (rg_vals) {
+      rg_vals[3 * i] = m.range;
+      rg_vals[3 * i + 1] = m.precision;
+      rg_vals[3 * i + 2] = m.weight;
+    }
+  }
+  return DCORA_OK;
+}
 int dcora_radataset_info(dcora_radataset_t h, int *info) {
   if (!h || !info) return bad("null");
   info[0] = h->ds.d;

@@ -34,6 +34,7 @@
 
 #include "DCORA_types.h"
 #include "Graph.h"
+#include "QuadraticOptimizer.h"
 
 namespace DCORA {
 
@@ -48,8 +49,10 @@ struct AgentParameters {
   bool verbose = false, logData = false;
   std::string logDirectory;
   int device = 0;
-  AgentParameters(unsigned dIn, unsigned rIn, const std::set<unsigned> &robotIDsIn)
-      : d(dIn), r(rIn), robotIDs(robotIDsIn), numRobots((unsigned)robotIDsIn.size()) {}
+  GraphType graphType = GraphType::PoseGraph;
+  AgentParameters(unsigned dIn, unsigned rIn, const std::set<unsigned> &robotIDsIn,
+                  GraphType graphTypeIn = GraphType::PoseGraph)
+      : d(dIn), r(rIn), robotIDs(robotIDsIn), numRobots((unsigned)robotIDsIn.size()), graphType(graphTypeIn) {}
   AgentParameters(unsigned dIn, unsigned rIn, unsigned numRobotsIn) : d(dIn), r(rIn), numRobots(numRobotsIn) {
     for (unsigned i = 0; i < numRobotsIn; ++i) robotIDs.insert(i);
   }
@@ -138,6 +141,17 @@ class Agent {
   // has been constructed, given its measurements and initialised in this process
   Agent(unsigned ID, const AgentParameters &params) : mID(ID), params_(params) {
     if (!params.robotIDs.count(ID)) throw std::invalid_argument("Agent: ID is not in AgentParameters::robotIDs");
+    if (params.graphType == GraphType::RangeAidedSLAMGraph) {
+      // An agent on a range-aided graph that holds ALL measurements of its states: the centralised agent of the
+      // reference's CORA flow and tests (ref tests/testAgent.cpp:157-242, examples/SingleRobotExample_RASLAM.cpp).  It
+      // owns its Graph, problem and iterate; the robots of a multi-robot range-aided job share a device-resident
+      // session instead (dcora_ra_rbcd_*).
+      if (params.robotIDs.size() != 1)
+        throw std::invalid_argument("Agent: several robots on a RangeAidedSLAMGraph share a session (dcora_ra_rbcd_*)");
+      ra_ = std::make_shared<RangeAidedState>();
+      ra_->graph = std::make_shared<Graph>(ID, params.r, params.d, GraphType::RangeAidedSLAMGraph);
+      return;
+    }
     std::lock_guard<std::mutex> lk(detail::team_registry_mutex());
     const detail::TeamKey key{params.d, params.r, params.robotIDs, params.acceleration};
     std::shared_ptr<detail::PendingTeam> p = detail::team_registry()[key].lock();
@@ -151,10 +165,13 @@ class Agent {
   unsigned getID() const { return mID; }
   unsigned relaxation_rank() const { return params_.r; }
   unsigned dimension() const { return params_.d; }
-  unsigned num_poses() const { return info().first; }
-  unsigned problem_dimension() const { return (dimension() + 1) * num_poses(); }
+  unsigned num_poses() const { return ra_ ? ra_->graph->n() : info().first; }
+  unsigned num_unit_spheres() const { return ra_ ? ra_->graph->l() : 0; }
+  unsigned num_landmarks() const { return ra_ ? ra_->graph->b() : 0; }
+  unsigned problem_dimension() const { return (dimension() + 1) * num_poses() + num_unit_spheres() + num_landmarks(); }
   unsigned instance_number() const { return 0; }
   unsigned iteration_number() const {
+    if (ra_) return ra_->iterations;
     int it = 0;
     check_status(dcora_rbcd_agent_info(session(), (int)mID, nullptr, nullptr, &it), "iteration_number");
     return (unsigned)it;
@@ -169,6 +186,62 @@ class Agent {
     pending_->odometry[mID] = inputOdometry;
     pending_->private_lc[mID] = inputPrivateLoopClosures;
     pending_->shared_lc[mID] = inputSharedLoopClosures;
+  }
+  // ref include/DCORA/Agent.h:286-292: all relative measurements of a range-aided graph
+  void setMeasurements(const RelativeMeasurements &measurements) {
+    if (!ra_) throw std::logic_error("Agent::setMeasurements(RelativeMeasurements): the agent is on a pose graph");
+    ra_->graph->setMeasurements(measurements);
+    ra_->problem.reset();
+  }
+  // ref include/DCORA/Agent.h:315-330, src/Agent.cpp:396-458: the start point from an estimate of the states in the
+  // robot's frame (the tests hand over the ground truth), lifted by the shared YLift
+  void initialize(const PoseArray *TInitPtr, const PointArray *UnitSphereInitPtr, const PointArray *LandmarkInitPtr) {
+    if (!ra_) throw std::logic_error("Agent::initialize(states): the agent is on a pose graph");
+    const unsigned d = dimension(), r = relaxation_rank(), n = num_poses(), l = num_unit_spheres(), b = num_landmarks();
+    if (!TInitPtr || TInitPtr->n() != n || (l && (!UnitSphereInitPtr || UnitSphereInitPtr->n() != l)) ||
+        (b && (!LandmarkInitPtr || LandmarkInitPtr->n() != b)))
+      throw std::invalid_argument("Agent::initialize: the estimate does not match the graph's states");
+    Matrix local(d, problem_dimension());  // RA ordering [R_1 .. R_n | s | t_1 .. t_n | L]
+    for (unsigned i = 0; i < n; ++i)
+      for (unsigned a = 0; a < d; ++a) {
+        for (unsigned c = 0; c < d; ++c) local(a, (size_t)i * d + c) = TInitPtr->getData()(a, (size_t)i * (d + 1) + c);
+        local(a, (size_t)d * n + l + i) = TInitPtr->getData()(a, (size_t)i * (d + 1) + d);
+      }
+    for (unsigned i = 0; i < l; ++i)
+      for (unsigned a = 0; a < d; ++a) local(a, (size_t)d * n + i) = UnitSphereInitPtr->getData()(a, i);
+    for (unsigned i = 0; i < b; ++i)
+      for (unsigned a = 0; a < d; ++a) local(a, (size_t)(d + 1) * n + l + i) = LandmarkInitPtr->getData()(a, i);
+    Matrix YLift(r, d), Tid(d, d + 1);
+    check_status(dcora_fixed_stiefel_variable((int)r, (int)d, YLift.data()), "Agent::initialize");
+    for (unsigned a = 0; a < d; ++a) Tid(a, a) = 1.0;
+    dcora_dims dims{(int)r, (int)d, (int)n, (int)l, (int)b};
+    ra_->X = Matrix(r, problem_dimension());
+    check_status(dcora_agent_initialize_in_global_frame(&dims, Tid.data(), local.data(), YLift.data(), ra_->X.data()),
+                 "Agent::initialize");
+    ra_->iterations = 0;
+  }
+  // ref src/Agent.cpp:950-1034: the estimate rounded to SE(d)^n x (S^{d-1})^l x R^{d b} in the frame of the first pose
+  bool getStatesInLocalFrame(Matrix *Trajectory, Matrix *UnitSpheres, Matrix *Landmarks) {
+    if (!ra_) throw std::logic_error("Agent::getStatesInLocalFrame(3): the agent is on a pose graph");
+    if (ra_->X.rows() == 0) return false;
+    const unsigned d = dimension(), n = num_poses(), l = num_unit_spheres(), b = num_landmarks();
+    dcora_dims dims{(int)relaxation_rank(), (int)d, (int)n, (int)l, (int)b};
+    Matrix T(d, (size_t)(d + 1) * n), S(d, l), L(d, b);
+    check_status(dcora_round_align_trajectory(&dims, ra_->X.data(), nullptr, 0, T.data(), l ? S.data() : nullptr,
+                                              b ? L.data() : nullptr, params_.device),
+                 "getStatesInLocalFrame");
+    if (Trajectory) *Trajectory = T;
+    if (UnitSpheres) *UnitSpheres = S;
+    if (Landmarks) *Landmarks = L;
+    return true;
+  }
+  // ref src/Agent.cpp:598-648: back to the state before setMeasurements
+  void reset() {
+    if (!ra_) return;
+    ra_->graph = std::make_shared<Graph>(mID, params_.r, params_.d, GraphType::RangeAidedSLAMGraph);
+    ra_->problem.reset();
+    ra_->X = Matrix();
+    ra_->iterations = 0;
   }
   // ref include/DCORA/Agent.h:315 (the trajectory / frame arguments of the reference's initialisation do not apply: the
   // driver sets X itself, :208-217).  The last robot to arrive forms the team.
@@ -199,16 +272,34 @@ class Agent {
   void setX(const Matrix &Xin) {
     if (Xin.rows() != relaxation_rank() || Xin.cols() != problem_dimension())
       throw std::invalid_argument("Agent::setX: expected r x (d+1) n");
+    if (ra_) {
+      ra_->X = Xin;
+      return;
+    }
     check_status(dcora_rbcd_agent_set_X(session(), (int)mID, Xin.data()), "setX");
   }
   // ref src/Agent.cpp:98-105
   bool getX(Matrix *Mout) {
+    if (ra_) {
+      *Mout = ra_->X;
+      return ra_->X.rows() != 0;
+    }
     *Mout = Matrix(relaxation_rank(), problem_dimension());
     return dcora_rbcd_agent_get_X(session(), (int)mID, Mout->data()) == DCORA_OK;
   }
   // ref src/Agent.cpp:535-596; false when the optimisation was skipped because a required neighbour pose has never
   // been handed over (ref :1243-1249)
   bool iterate(bool doOptimization = true) {
+    if (ra_) {
+      // no neighbours: updateX is one QuadraticOptimizer::optimize of the agent's own problem from X (ref :1216-1278)
+      if (ra_->X.rows() == 0) return false;
+      ++ra_->iterations;
+      if (!doOptimization) return true;
+      if (!ra_->problem) ra_->problem = std::make_shared<QuadraticProblem>(ra_->graph, true, params_.device);
+      QuadraticOptimizer opt(ra_->problem.get(), params_.localOptimizationParams);
+      ra_->X = opt.optimize(ra_->X);
+      return true;
+    }
     check_status(dcora_rbcd_agent_iterate(session(), (int)mID, doOptimization ? 1 : 0), "iterate");
     int skipped = 0;
     check_status(dcora_rbcd_agent_last_skipped(session(), (int)mID, &skipped), "iterate");
@@ -353,6 +444,13 @@ class Agent {
     p.team = t;
   }
 
+  struct RangeAidedState {  // the centralised agent of a range-aided graph
+    std::shared_ptr<Graph> graph;
+    std::shared_ptr<QuadraticProblem> problem;  // kept over the iterations: Q and its preconditioner do not change
+    Matrix X;
+    unsigned iterations = 0;
+  };
+  std::shared_ptr<RangeAidedState> ra_;
   unsigned mID;
   AgentParameters params_;
   mutable unsigned n_ = 0, first_pose_ = 0;

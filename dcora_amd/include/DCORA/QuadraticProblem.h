@@ -25,15 +25,20 @@ class QuadraticProblem {
                                       pd.G.rows() ? pd.G.data() : nullptr, pd.precond_reg, pd.device, &h_),
                  "QuadraticProblem");
   }
-  // the reference's constructor (ref include/DCORA/QuadraticProblem.h:28, src/QuadraticProblem.cpp:19-34): (r, d, n) and
-  // Q from the Graph; no linear term (the central problems of the drivers have none); the preconditioner with the
-  // pose-graph regularisation of ref src/Graph.cpp:1906 is built when withPreconditioner is set (escapeSaddle needs it)
+  // the reference's constructor (ref include/DCORA/QuadraticProblem.h:28, src/QuadraticProblem.cpp:19-34): (r, d, n, l, b),
+  // Q and the linear term from the Graph -- the SE manifold when the graph is PGO-compatible, the RA manifold otherwise;
+  // the preconditioner (Q + reg I)^-1 with the Graph's regularisation (ref src/Graph.cpp:1901-1960) is built when
+  // withPreconditioner is set (the local solver and escapeSaddle need it)
   explicit QuadraticProblem(const std::shared_ptr<Graph> &graph, bool withPreconditioner = false, int device = 0)
-      : r_(graph->r()), d_(graph->d()), n_(graph->n()), l_(0), b_(0), graph_(graph) {
+      : r_(graph->r()), d_(graph->d()), n_(graph->n()), l_(graph->l()), b_(graph->b()), graph_(graph) {
     const SparseMatrix &Q = graph->quadraticMatrix();
-    dcora_dims dims{(int)r_, (int)d_, (int)n_, 0, 0};
-    check_status(dcora_problem_create(&dims, Q.rowptr.data(), Q.colidx.data(), Q.vals.data(), nullptr,
-                                      withPreconditioner ? 0.1 : -1.0, device, &h_),
+    const Matrix G = graph->linearMatrix();
+    bool has_G = false;
+    for (size_t i = 0; i < G.rows() * G.cols() && !has_G; ++i) has_G = G.data()[i] != 0.0;
+    dcora_dims dims{(int)r_, (int)d_, (int)n_, (int)l_, (int)b_};
+    check_status(dcora_problem_create(&dims, Q.rowptr.data(), Q.colidx.data(), Q.vals.data(), has_G ? G.data() : nullptr,
+                                      withPreconditioner ? graph->preconditionerRegularization(device) : -1.0, device,
+                                      &h_),
                  "QuadraticProblem");
   }
   ~QuadraticProblem() { dcora_problem_destroy(h_); }

@@ -208,6 +208,21 @@ typedef struct dcora_radataset_s *dcora_radataset_t;
 int dcora_radataset_load_pyfg(const char *path, dcora_radataset_t *out);
 /* info[7] = {d, n poses, l unit spheres, b landmarks, #pose-pose, #pose-landmark, #range measurements} */
 int dcora_radataset_info(dcora_radataset_t ds, int *info);
+/* Graph::setMeasurements(const RelativeMeasurements &) of a range-aided graph (ref include/DCORA/Graph.h:57-147,
+ * src/Graph.cpp:374-470): the dataset from measurement arrays instead of a file.  States are numbered as the Graph
+ * numbers them: poses 0 .. n - 1, unit spheres 0 .. l - 1 (one per range measurement), landmarks 0 .. b - 1, all owned
+ * by robot 0 (the centralised agent).
+ *   pose-pose:     pp_ids m_pp x 2 (pose i, pose j); pp_vals m_pp x (d d + d + 3): R column-major, t, kappa, tau, weight
+ *   pose-landmark: pl_ids m_pl x 2 (pose i, landmark j); pl_vals m_pl x (d + 2): t, tau, weight
+ *   range:         rg_ids m_rg x 5 (type1, i, type2, j, unit sphere; type 0 = pose, 1 = landmark); rg_vals m_rg x 3:
+ *                  range, precision, weight
+ * gt: d x k ground truth in the RA ordering, or NULL.  dcora_radataset_copy writes a dataset's measurements into the
+ * same arrays (any of them may be NULL; sizes from dcora_radataset_info). */
+int dcora_radataset_create(int d, int n, int l, int b, int m_pp, const int *pp_ids, const double *pp_vals, int m_pl,
+                           const int *pl_ids, const double *pl_vals, int m_rg, const int *rg_ids, const double *rg_vals,
+                           const double *gt, dcora_radataset_t *out);
+int dcora_radataset_copy(dcora_radataset_t ds, int *pp_ids, double *pp_vals, int *pl_ids, double *pl_vals, int *rg_ids,
+                         double *rg_vals);
 /* ground truth of the VERTEX records in RA ordering, d x k column-major (unit spheres = normalised state1 - state2) */
 int dcora_radataset_ground_truth(dcora_radataset_t ds, double *gt);
 int dcora_radataset_build_Q(dcora_radataset_t ds, dcora_csr_t *Q);

@@ -113,6 +113,18 @@ def test_cpp_agent_facade_runs_the_reference_driver_loop(built):
 
 
 @pytest.mark.gpu
+def test_cpp_range_aided_agent_facade(built):
+    """the reference's range-aided agent test through the facade (ref tests/testAgent.cpp:157-242): centralised Agent
+    on a RangeAidedSLAMGraph from RelativeMeasurements, ground truth a fixed point of iterate(); Graph l() / b() /
+    linearMatrix() and QuadraticProblem(shared_ptr<Graph>) on the RA manifold (ref src/QuadraticProblem.cpp:19-34)"""
+    exe = os.path.join(common.HERE, "cpp", "_build", "test_ra_facade")
+    assert os.path.exists(exe), "build() compiles tests/cpp/test_ra_facade.cpp"
+    files = [common.plain_path("range_aided_slam_test_2d", ext="pyfg"), common.plain_path("range_aided_slam_test_3d", ext="pyfg")]
+    p = subprocess.run([exe] + files, capture_output=True, text=True, timeout=180)
+    assert p.returncode == 0, p.stdout + p.stderr
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name,rank", [("smallGrid3D", 3), ("sphere2500", 5)])
 def test_cpp_staircase_driver_matches_the_python_driver(built, tmp_path, name, rank):
     """dcora_amd/examples/MultiRobotExample.cpp -- the reference's driver with the Riemannian staircase, as a C++
