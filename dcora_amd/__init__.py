@@ -338,8 +338,7 @@ QuadraticProblem.precond_info = _precond_info
 def _qapply_info(self):
     info = np.zeros(4)
     check(capi.lib().dcora_problem_qapply_info(self.h, info))
-    bsr = "k_spmm_bsr" if os.environ.get("DCORA_BSR_KERNEL") == "v1" else "k_spmm_bsr2"
-    return {"kernel": bsr if info[0] else "k_spmm", "nnz": int(info[1]), "blocks": int(info[2]),
+    return {"kernel": "k_spmm_bsr2" if info[0] else "k_spmm", "nnz": int(info[1]), "blocks": int(info[2]),
             "stored_matrix_bytes": float(info[3])}
 
 

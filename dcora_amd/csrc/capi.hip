@@ -1072,6 +1072,10 @@ int dcora_exchange_info(dcora_exchange_t ex, double *info) {
   info[9] = e.waits_on_device() ? 1 : 0;
   return DCORA_OK;
 }
+int dcora_debug_exchange_probe_fault(int rounds) {
+  g_probe_fault_rounds.store(rounds);
+  return DCORA_OK;
+}
 int dcora_exchange_link_report(dcora_exchange_t ex, double *out4) {
   if (!ex || !out4) return bad("null");
   const Exchange &e = ex->e;
@@ -1589,7 +1593,7 @@ extern "C" int dcora_debug_stream_triad(int device, size_t n, int reps, double *
   hipEvent_t e0, e1;
   DCORA_HIP(hipEventCreate(&e0));
   DCORA_HIP(hipEventCreate(&e1));
-  const int grid = getenv("DCORA_TRIAD_GRID") ? atoi(getenv("DCORA_TRIAD_GRID")) : 1024;  // 1024 / 2048 / 8192 workgroups: 5.01 / 4.85 / 4.48 TB/s
+  const int grid = 1024;  // 1024 / 2048 / 8192 workgroups: 5.01 / 4.85 / 4.48 TB/s
   for (int w = 0; w < 3; ++w)
     hipLaunchKernelGGL(k_stream_triad, dim3(grid), dim3(256), 0, nullptr, n / 2, (const double2 *)B.p,
                        (const double2 *)Cc.p, (double2 *)A.p, 0.5);

@@ -11,6 +11,7 @@
 #include <thread>
 
 #include "cert.h"
+#include "env.h"
 #include "device_chol.h"
 #include "device_problem.h"
 
@@ -168,10 +169,7 @@ int DeviceLanczos::largest_magnitude(double shift, int ncv, int maxit, double to
   // vanishing norm); the fast form keeps them on the device -- the subtraction sums the projection's partials in its
   // prologue, the next vector is scaled by the kernel that sums <w, w> -- and the host reads a whole restart cycle's
   // coefficients at once: 8 launches and no host round trip per step instead of 11 launches, two copies and a wait.
-  static const bool lanczos_slow = [] {
-    const char *e = std::getenv("DCORA_LANCZOS");
-    return e && std::string(e) == "sync";
-  }();
+  const bool lanczos_slow = env::lanczos_sync();
   const bool fast = !rows && !lanczos_slow;
   DevBuf<double> hdev, bdev;
   DevBuf<int> fdev;
@@ -412,12 +410,8 @@ int device_min_eig(const HostCsr &S, int maxit, double min_eig_tol, int ncv, uin
   // ratio is hopeless for a 20-vector Krylov space (tiers.pyfg: the landmark every pose ranges to puts lambda_lm at
   // 2e6, the ratio at 5e-10) the reference's run spends its 1000 restarts -- 10 020 matvecs, 0.6 s per certificate here --
   // and then takes the shift-and-invert fallback below anyway; this goes there at once.  The eigenpair returned is the
-  // fallback's either way.  DCORA_MIN_EIG_SHIFTED=always keeps the reference's order of attempts.
-  static const bool always_shifted = [] {
-    const char *e = std::getenv("DCORA_MIN_EIG_SHIFTED");
-    return e && std::string(e) == "always";
-  }();
-  const bool hopeless = !always_shifted && min_eig_tol / lambda_lm < 1e-8;
+  // fallback's either way.
+  const bool hopeless = min_eig_tol / lambda_lm < 1e-8;
   if (hopeless) {
     sh.ok = false;
     sh.v.assign((size_t)k, 0.0);
@@ -427,7 +421,7 @@ int device_min_eig(const HostCsr &S, int maxit, double min_eig_tol, int ncv, uin
     if (rc) return rc;
   }
   sh.matvecs += lm.matvecs;
-  if (std::getenv("DCORA_INIT_TIMING"))
+  if (env::init_timing())
     fprintf(stderr, "[min_eig] k %d: largest-magnitude run %ld matvecs (lambda %.3e), shifted run %ld matvecs, converged %d\n", k,
             lm.matvecs, lm.lambda, sh.matvecs - lm.matvecs, (int)sh.ok);
   if (!sh.ok) {
@@ -465,7 +459,7 @@ int device_min_eig(const HostCsr &S, int maxit, double min_eig_tol, int ncv, uin
         rc = L.largest_magnitude(0.0, ncv, 1000, 1e-10, nullptr, seed, &si);
         L.inverse_op = nullptr;
         if (rc) return rc;
-        if (std::getenv("DCORA_INIT_TIMING"))
+        if (env::init_timing())
           fprintf(stderr, "[min_eig] shift-and-invert at sigma %.3g: %ld solves, converged %d\n", sigma, si.matvecs, (int)si.ok);
         if (si.ok) {
           si.matvecs += sh.matvecs;
@@ -602,12 +596,8 @@ int device_fast_verification(const HostCsr &S, double eta, int block, int device
                              std::vector<double> *x, double *lambda_min, long *matvecs) {
   HostCsr M = csr_shift_diag(S, eta);
   // the PSD test: LL^T of S + eta I succeeds <=> PSD up to eta (ref src/DCORA_utils.cpp:1737-1747), factorised on the
-  // device (device_chol.h); DCORA_PSD_HOST=1 keeps the host factorisation for A/B measurements
-  static const bool on_host = [] {
-    const char *e = std::getenv("DCORA_PSD_HOST");
-    return e && atoi(e) != 0;
-  }();
-  int rc = on_host ? host_is_psd(M, block, psd) : device_chol_is_pd(M, block, device, psd);
+  // device (device_chol.h)
+  int rc = device_chol_is_pd(M, block, device, psd);
   if (rc) return rc;
   if (*psd) return DCORA_OK;
   LanczosResult e;

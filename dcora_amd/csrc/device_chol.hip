@@ -1,5 +1,6 @@
 // see device_chol.h
 #include "device_chol.h"
+#include "env.h"
 
 #include <sys/mman.h>
 
@@ -289,96 +290,7 @@ __global__ __launch_bounds__(256) void k_chol_potrf(const PieceDev *__restrict__
   for (int e = tid; e < NB * NB; e += 256) O[e] = Li[e >> 6][e & 63];
 }
 
-// diagonal block of the current panel: LL^T of up to 64 columns in LDS, written back in place, and L^-1 for the
-// panel below.  A pivot that is not positive raises *fail.  (Measured and dropped: ONE wave with the block in registers,
-// lane i owning row i and v_readlane broadcasts instead of LDS and barriers -- 308 VGPRs, 11 800 readlanes, and slower:
-// sphere2500 PSD test 1.84 -> 2.35 ms, the VALU -> SGPR -> VALU hazard of every broadcast costs more than the barrier.)
-__global__ __launch_bounds__(256) void k_chol_potrf_v1(const PieceDev *__restrict__ pieces,
-                                                       const int *__restrict__ list, int j0, double *__restrict__ F,
-                                                       double *__restrict__ Linv, int *__restrict__ fail,
-                                                       double *__restrict__ logdet, int always_inv) {
-  if (*fail) return;
-  const PieceDev P = pieces[list[blockIdx.x]];
-  const int jb = min(NB, P.c - j0);
-  const long long f = (long long)P.c + P.m;
-  double *__restrict__ M = F + P.off + (long long)j0 * f + j0;
-  __shared__ double L[NB][NB + 1];
-  __shared__ double Li[NB][NB + 1];
-  __shared__ double dg[NB];
-  const int tid = threadIdx.x;
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int i = e >> 6, j = e & 63;
-    L[i][j] = (i < jb && j <= i) ? M[(long long)i * f + j] : (i == j ? 1.0 : 0.0);
-  }
-  __syncthreads();
-  const int i = tid >> 2, kq = tid & 3;
-  bool bad = false;
-  for (int j = 0; j < jb; ++j) {
-    const double d = L[j][j];  // the same word for every lane: the branch below is uniform
-    if (!(d > 0.0)) {
-      bad = true;
-      break;
-    }
-    if (i > j) {
-      const double lij = L[i][j] * (1.0 / d);
-      for (int k = j + 1 + kq; k <= i; k += 4) L[i][k] -= lij * L[k][j];
-    }
-    __syncthreads();
-  }
-  if (bad) {
-    if (tid == 0) *fail = 1;
-    return;
-  }
-  if (tid < NB) {
-    dg[tid] = sqrt(L[tid][tid]);
-    // log det of the factored matrix (a cross-check of the whole factorisation for the tests; order of the sum free)
-    double lg = tid < jb ? log(L[tid][tid]) : 0.0;
-    for (int o = 32; o > 0; o >>= 1) lg += __shfl_xor(lg, o);
-    if (tid == 0) atomicAdd(logdet, lg);
-  }
-  __syncthreads();
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int r = e >> 6, j = e & 63;
-    if (j < r)
-      L[r][j] = L[r][j] / dg[j];
-    else if (j == r)
-      L[r][j] = dg[j];
-  }
-  __syncthreads();
-  for (int e = tid; e < jb * jb; e += 256) {
-    const int r = e / jb, j = e - r * jb;
-    if (j <= r) M[(long long)r * f + j] = L[r][j];
-  }
-  if (!always_inv && P.m == 0 && j0 + jb >= P.c) return;  // nothing below the last panel of a root
-  // inverse of the triangular block, column k by lane group k (4 lanes share the sum over l)
-  {
-    const int k = tid >> 2;
-    for (int r = kq; r < k; r += 4) Li[r][k] = 0.0;
-    if (kq == 0) Li[k][k] = 1.0 / L[k][k];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    for (int r = k + 1; r < NB; ++r) {
-      double s = 0;
-      for (int l = k + kq; l < r; l += 4) s += L[r][l] * Li[l][k];
-      s += __shfl_xor(s, 1);
-      s += __shfl_xor(s, 2);
-      if (kq == 0) Li[r][k] = -s / L[r][r];
-      // the other lanes of the group read Li[r][k] in the next round: same wave, LDS operations stay in order
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-  __syncthreads();
-  double *__restrict__ O = Linv + (size_t)blockIdx.x * NB * NB;
-  for (int e = tid; e < NB * NB; e += 256) O[e] = Li[e >> 6][e & 63];
-}
 
-inline bool potrf_v1() {
-  static const bool v = [] {
-    const char *e = std::getenv("DCORA_POTRF");
-    return e && std::strcmp(e, "v1") == 0;
-  }();
-  return v;
-}
 
 // ---- the 64 x 64 x 64 product of two LDS tiles, As[k][i] and Bs[k][j]: acc(i, j) += sum_k As[k][i] Bs[k][j] ----
 // MMA = false: 4 x 4 outputs per thread by FMAs (8 LDS reads per 16 FMAs: the LDS port is the bound, 128 clocks per k
@@ -433,25 +345,10 @@ __device__ __forceinline__ void tile_inner(const double (*As)[NB + 1], const dou
     }
   }
 }
-inline bool chol_mma() {
-  static const bool v = [] {
-    const char *e = std::getenv("DCORA_CHOL_MMA");
-    return !(e && std::strcmp(e, "fma") == 0);
-  }();
-  return v;
-}
-inline int chol_superpanel_blocks() {
-  static const int v = [] {
-    const char *e = std::getenv("DCORA_CHOL_SUPERPANEL");
-    return e ? std::max(1, std::min(16, atoi(e))) : 8;
-  }();
-  return v;
-}
-#define DCORA_LAUNCH_MMA(KERNEL, grid, st, ...)                                               \
-  do {                                                                                        \
-    if (chol_mma()) hipLaunchKernelGGL((KERNEL<true>), grid, dim3(256), 0, st, __VA_ARGS__);  \
-    else hipLaunchKernelGGL((KERNEL<false>), grid, dim3(256), 0, st, __VA_ARGS__);            \
-  } while (0)
+constexpr int chol_superpanel_blocks() { return 8; }  // measured: 4 -> 157 ms, 8 -> 99 ms (1: a trailing update per block, 217)
+// the tile products run on the matrix pipe (MMA = true); the 4 x 4-per-thread FMA form of the same templates measured
+// 126 ms against 98 for the factorisation of the 100k lattice and is not instantiated
+#define DCORA_LAUNCH_MMA(KERNEL, grid, st, ...) hipLaunchKernelGGL((KERNEL<true>), grid, dim3(256), 0, st, __VA_ARGS__)
 
 // acc(i, j) = sum_k A[i][k] B[j][k]; A and B are row-major with k contiguous; rows beyond arows / brows and k beyond K
 // read as zero
@@ -622,92 +519,6 @@ __global__ __launch_bounds__(256) void k_chol_syrk(const PieceDev *__restrict__ 
     }
 }
 
-// The trailing update behind a super-panel on the VECTOR pipe: on this part sixteen independent v_fma_f64 chains per
-// lane run at 67-69 Tflop/s, the fp64 MFMA at 47 (tools/mfma_f64_peak.hip), and the operand reads of a register-tiled
-// product are LDS broadcasts.  A workgroup owns 128 rows x 64 columns, a thread 8 x 4 outputs (12 LDS reads per 32
-// FMAs), K in steps of 32 columns fetched into registers one step ahead; tiles (tr, tc) with tc <= 2 tr + 1 cover the
-// lower triangle, blockIdx.x = tr (tr + 1) + tc.  MEASURED AND NOT THE DEFAULT (DCORA_CHOL_TRAIL=fma selects it): 196
-// VGPRs leave two waves per SIMD, the large trailing updates run at 29 Tflop/s against 35-38 for k_chol_syrk<true>, the
-// factorisation of the whole 100k lattice takes 109 ms against 98.
-__global__ __launch_bounds__(256) void k_chol_syrk_fma(const PieceDev *__restrict__ pieces, const int *__restrict__ list,
-                                                       int k0, int kcap, double *__restrict__ F,
-                                                       const int *__restrict__ fail) {
-  if (*fail) return;
-  constexpr int KC = 32, TR = 128, TC = 64;
-  const PieceDev P = pieces[list[blockIdx.y]];
-  const int f = P.c + P.m;
-  const int base = min(kcap, P.c);
-  if (base <= k0) return;
-  int tr = (int)((sqrtf(4.0f * (float)blockIdx.x + 1.0f) - 1.0f) * 0.5f);
-  while ((tr + 1) * (tr + 2) <= (int)blockIdx.x) ++tr;
-  while (tr * (tr + 1) > (int)blockIdx.x) --tr;
-  const int tc = blockIdx.x - tr * (tr + 1);
-  const int ri0 = base + TR * tr, cj0 = base + TC * tc;
-  if (ri0 >= f || cj0 >= f) return;
-  __shared__ double As[KC][TR + 1];
-  __shared__ double Bs[KC][TC + 1];
-  double *__restrict__ M = F + P.off;
-  const double *__restrict__ Arow = M + (long long)ri0 * f;
-  const double *__restrict__ Brow = M + (long long)cj0 * f;
-  const int arows = min(TR, f - ri0), brows = min(TC, f - cj0);
-  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-  const int kk = tid & (KC - 1), ib = tid >> 5;  // entry q of a thread: row ib + 8 q, column kk of the step
-  double ra[TR * KC / 256], rb[TC * KC / 256];
-  auto fetch = [&](int l) {
-    const int K = min(KC, base - l);
-#pragma unroll
-    for (int q = 0; q < TR * KC / 256; ++q) {
-      const int i = ib + 8 * q;
-      ra[q] = (i < arows && kk < K) ? Arow[(long long)i * f + l + kk] : 0.0;
-    }
-#pragma unroll
-    for (int q = 0; q < TC * KC / 256; ++q) {
-      const int i = ib + 8 * q;
-      rb[q] = (i < brows && kk < K) ? Brow[(long long)i * f + l + kk] : 0.0;
-    }
-  };
-  double acc[8][4];
-#pragma unroll
-  for (int u = 0; u < 8; ++u)
-#pragma unroll
-    for (int v = 0; v < 4; ++v) acc[u][v] = 0;
-  fetch(k0);
-  for (int l = k0; l < base; l += KC) {
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < TR * KC / 256; ++q) As[kk][ib + 8 * q] = ra[q];
-#pragma unroll
-    for (int q = 0; q < TC * KC / 256; ++q) Bs[kk][ib + 8 * q] = rb[q];
-    __syncthreads();
-    if (l + KC < base) fetch(l + KC);
-#pragma unroll 4
-    for (int k = 0; k < KC; ++k) {
-      double a[8], b[4];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) a[u] = As[k][ty + 16 * u];
-#pragma unroll
-      for (int v = 0; v < 4; ++v) b[v] = Bs[k][tx + 16 * v];
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) acc[u][v] = fma(a[u], b[v], acc[u][v]);
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < 8; ++u)
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int r = ri0 + ty + 16 * u, c = cj0 + tx + 16 * v;
-      if (r < f && c <= r) M[(long long)r * f + c] -= acc[u][v];
-    }
-}
-inline bool chol_trail_fma() {  // opt-in: measured slower than the MFMA form (29 against 35-38 Tflop/s, see above)
-  static const bool v = [] {
-    const char *e = std::getenv("DCORA_CHOL_TRAIL");
-    return e && std::strcmp(e, "fma") == 0;
-  }();
-  return v;
-}
 
 // Y = L^-1 right-looking, one block row of L at a time; Y is kept transposed (YT(j, i) = Y(i, j)^T).  Step ib:
 //   finish:  YT(j, ib) = -TT(j, ib) Linv_ib^T for the block rows j < ib (TT accumulated in place), YT(ib, ib) = Linv_ib^T
@@ -1121,24 +932,6 @@ int build_image(const HostCsr &A, int block, int top, int device, std::shared_pt
       }
     }
   }
-  if (const char *dump = std::getenv("DCORA_CHOL_PLAN_DUMP")) {  // kind list gx gy j0 kcap ccap ncb flop (syrk only)
-    if (FILE *fp = std::fopen(dump, "w")) {
-      for (const Launch &L : img->plan) {
-        double flop = 0;
-        if (L.kind == 3)
-          for (int q = 0; q < L.gy; ++q) {
-            const CholPiece &P = S.pieces[S.level_pieces[L.list + q]];
-            const double f = (double)P.c + P.m, base = std::min(L.kcap, P.c), K = base - L.j0;
-            if (K <= 0) continue;
-            const double colend = L.ccap >= 0 ? std::min((double)L.ccap, (double)P.c) : f;
-            const double w = std::max(0.0, colend - base);          // columns updated
-            flop += 2.0 * K * (w * (f - base) - 0.5 * w * w);       // rows >= column
-          }
-        std::fprintf(fp, "%d %d %d %d %d %d %d %d %.0f\n", L.kind, L.list, L.gx, L.gy, L.j0, L.kcap, L.ccap, L.ncb, flop);
-      }
-      std::fclose(fp);
-    }
-  }
   img->symbolic_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   DCORA_HIP(img->pieces.alloc(pd.size()));
   DCORA_HIP(hipMemcpy(img->pieces.p, pd.data(), pd.size() * sizeof(PieceDev), hipMemcpyHostToDevice));
@@ -1162,7 +955,6 @@ int build_image(const HostCsr &A, int block, int top, int device, std::shared_pt
 // more than the factorisation); larger ones are allocated per call.  Default: a quarter of the device's memory.
 size_t arena_keep_bytes() {
   static const size_t b = [] {
-    if (const char *e = std::getenv("DCORA_CHOL_ARENA_KEEP_MB")) return (size_t)(std::atof(e) * 1024.0 * 1024.0);
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) != hipSuccess) return (size_t)2048 << 20;
     return tot / 4;
@@ -1191,10 +983,7 @@ int factor_on_device(const HostCsr &A, int block, int top, int device, bool *pd,
   }
   DCORA_HIP(hipSetDevice(device));
   const auto t0 = std::chrono::steady_clock::now();
-  static const bool use_cache = [] {
-    const char *e = std::getenv("DCORA_CHOL_CACHE");
-    return !(e && atoi(e) == 0);
-  }();
+  constexpr bool use_cache = true;
   uint64_t h0 = 0x243F6A8885A308D3ull, h1 = 0x13198A2E03707344ull;
   hash_ints(A.rp.data(), A.rp.size(), &h0, &h1);
   hash_ints(A.ci.data(), A.ci.size(), &h0, &h1);
@@ -1274,7 +1063,7 @@ int factor_on_device(const HostCsr &A, int block, int top, int device, bool *pd,
                            img->fail.p);
         break;
       case 1:
-        hipLaunchKernelGGL((potrf_v1() ? k_chol_potrf_v1 : k_chol_potrf), dim3(L.gx), dim3(256), 0, st, img->pieces.p, list, L.j0, F, img->linv.p,
+        hipLaunchKernelGGL(k_chol_potrf, dim3(L.gx), dim3(256), 0, st, img->pieces.p, list, L.j0, F, img->linv.p,
                            img->fail.p, img->logdet.p, 0);
         break;
       case 2:
@@ -1282,16 +1071,6 @@ int factor_on_device(const HostCsr &A, int block, int top, int device, bool *pd,
                            img->fail.p);
         break;
       default:
-        if (L.ncb == 0 && L.ccap < 0 && L.kcap - L.j0 > NB && chol_trail_fma()) {
-          // the rank-512 sweep of the trailing matrix: 128 x 64 tiles on the vector pipe (L.gx was sized for 64 x 64
-          // tiles over T block rows: T (T + 1) / 2 -> tr (tr + 1) + tc over ceil(T / 2) tile rows)
-          int T = (int)((std::sqrt(8.0 * L.gx + 1.0) - 1.0) * 0.5 + 0.5);
-          while (T * (T + 1) / 2 < L.gx) ++T;
-          const int TRn = (T + 1) / 2;
-          hipLaunchKernelGGL(k_chol_syrk_fma, dim3(TRn * (TRn + 1), L.gy), dim3(256), 0, st, img->pieces.p, list, L.j0,
-                             L.kcap, F, img->fail.p);
-          break;
-        }
         DCORA_LAUNCH_MMA(k_chol_syrk, dim3(L.gx, L.gy), st, img->pieces.p, list, L.j0, L.kcap, L.ccap, L.ncb, F,
                            img->fail.p);
         break;
@@ -1304,7 +1083,7 @@ int factor_on_device(const HostCsr &A, int block, int top, int device, bool *pd,
   DCORA_HIP(hipMemcpyAsync(&logdet, img->logdet.p, sizeof(double), hipMemcpyDeviceToHost, st));
   DCORA_HIP(hipStreamSynchronize(st));
   *pd = failed == 0;
-  static const bool init_timing = std::getenv("DCORA_INIT_TIMING") != nullptr;
+  const bool init_timing = env::init_timing();
   auto tl = std::chrono::steady_clock::now();
   auto lap = [&](const char *what) {
     if (!init_timing) return;
@@ -1335,17 +1114,10 @@ int factor_on_device(const HostCsr &A, int block, int top, int device, bool *pd,
                        packed.p);
     // wide pieces (no hubs): their inverses are formed here, on the device, instead of by the host's threads -- for the
     // whole 100k lattice 310 Gflop, 7.7 s on the 16 cores of the container
-    static const bool invert_on_device = [] {
-      const char *e = std::getenv("DCORA_PIECE_INVERSES");
-      return !(e && std::strcmp(e, "host") == 0);
-    }();
-    // every piece arrives inverted: the narrow ones (c <= 64) by two batched launches, the others one after the other
-    // with the right-looking kernels of the dense inverse (DCORA_PIECE_INVERSES=wide: only c >= 384, the rest on
-    // the host's threads -- 0.64 s for the whole 100k lattice)
-    static const bool only_wide = [] {
-      const char *e = std::getenv("DCORA_PIECE_INVERSES");
-      return e && std::strcmp(e, "wide") == 0;
-    }();
+    // every piece arrives inverted: the narrow ones (c <= 64) by two batched launches, the ones up to 384 columns in one
+    // batch of the right-looking kernels, the wide ones one after the other (on the 16 host cores of the container the
+    // inverses of the whole 100k lattice, 310 Gflop, took 7.7 s)
+    constexpr bool invert_on_device = true, only_wide = false;
     const int kWide = 384;
     std::vector<int> wide, narrow;
     std::vector<long long> moff((size_t)np, -1);
@@ -1655,7 +1427,7 @@ int device_dense_spd_inverse(const HostCsr &A, int device, double *Minv, int ldm
   hipLaunchKernelGGL(k_dense_scatter, dim3(k), dim3(256), 0, st, k, rp.p, ci.p, v.p, L.p);
   for (int p = 0; p < nb; ++p) {
     const int j0 = p * NB, jb = std::min(NB, k - j0), rows = k - j0 - jb;
-    hipLaunchKernelGGL((potrf_v1() ? k_chol_potrf_v1 : k_chol_potrf), dim3(1), dim3(256), 0, st, piece.p, list.p, j0, L.p, linv.p + (size_t)p * NB * NB,
+    hipLaunchKernelGGL(k_chol_potrf, dim3(1), dim3(256), 0, st, piece.p, list.p, j0, L.p, linv.p + (size_t)p * NB * NB,
                        fail.p, logdet.p, 1);
     if (rows > 0) {
       const int T = (rows + NB - 1) / NB;
@@ -1705,10 +1477,7 @@ std::function<bool(const HostCsr &, int, int, const double *, double *)> device_
 }
 
 int build_partitioned_inverse_auto(const HostCsr &A, int block, int nthreads, int device, PartInvHost *out) {
-  static const bool host_factor = [] {
-    const char *e = std::getenv("DCORA_FACTOR");
-    return e && std::strcmp(e, "host") == 0;
-  }();
+  const bool host_factor = env::factor_on_host();
   if (host_factor) {
     const bool okh = build_partitioned_inverse(A, block, nthreads, out);
     return okh ? DCORA_OK : (out->weights_ok ? DCORA_ERR_NOT_PD : DCORA_ERR_HIP);
@@ -1721,7 +1490,7 @@ int build_partitioned_inverse_auto(const HostCsr &A, int block, int nthreads, in
   if (rc) return rc;
   const auto t1 = std::chrono::steady_clock::now();
   const bool ok = build_partitioned_inverse_from(A, F, nthreads, out);
-  if (std::getenv("DCORA_INIT_TIMING"))
+  if (env::init_timing())
     fprintf(stderr, "[precond] factor on the device %.1f ms, partitioned inverse on the host %.1f ms\n",
             std::chrono::duration<double, std::milli>(t1 - t0).count(),
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());

@@ -2,6 +2,7 @@
 #include <atomic>
 
 #include "device_problem.h"
+#include "env.h"
 #include "device_chol.h"
 #include "precond_cache.h"
 
@@ -163,7 +164,7 @@ int DeviceProblem::init(const dcora_dims &dims, const HostCsr &Qh, const double 
     set_last_error("bad dims (need 1 <= r <= 16, d in {2,3})");
     return DCORA_ERR_BAD_ARG;
   }
-  const bool init_timing = std::getenv("DCORA_INIT_TIMING") != nullptr;
+  const bool init_timing = env::init_timing();
   const auto ti0 = std::chrono::steady_clock::now();
   auto lap = [&](const char *what) {
     if (init_timing)
@@ -196,10 +197,9 @@ int DeviceProblem::init(const dcora_dims &dims, const HostCsr &Qh, const double 
   if (rc) return rc;
   lap("Q upload");
   // block form of Q for graphs large enough to be bandwidth-bound (the scalar-CSR kernel exposes more parallelism
-  // and wins while the launch is latency-bound); DCORA_QAPPLY=bsr|csr overrides
-  const char *qa = std::getenv("DCORA_QAPPLY");
-  const bool want_bsr = qa ? (std::string(qa) == "bsr") : (m.n >= 8192);
-  if (m.se && m.r <= 8 && m.n > 0 && want_bsr && std::getenv("DCORA_SOLVER_V1") == nullptr) {
+  // and wins while the launch is latency-bound)
+  const bool want_bsr = m.n >= 8192;
+  if (m.se && m.r <= 8 && m.n > 0 && want_bsr && !env::generic_solver()) {
     rc = Qb.upload(bsr_from_csr(Qh, m.d + 1));
     if (rc) return rc;
     has_bsr = true;
@@ -207,8 +207,8 @@ int DeviceProblem::init(const dcora_dims &dims, const HostCsr &Qh, const double 
   const size_t N = (size_t)nelem();
   const size_t NS = (size_t)m.n * m.d * m.d + m.l + 1;
   // (the fused Hessian kernel stages the first matrix tile with clamped, unconditional loads: it needs nnz > 0)
-  fused = fused_supported(m) && Qh.nnz() > 0 && (std::getenv("DCORA_SOLVER_V1") == nullptr);
-  group = group_supported(m) && (std::getenv("DCORA_SOLVER_V1") == nullptr);
+  fused = fused_supported(m) && Qh.nnz() > 0 && !env::generic_solver();
+  group = group_supported(m) && !env::generic_solver();
   // One allocation for the whole solver workspace, zeroed by one memset: the reference re-creates its problem on
   // every Agent::updateX (ref src/Agent.cpp:1252), so creation must cost a fraction of a solve -- thirty hipMalloc
   // and ten synchronous hipMemset calls took 4-8 ms.
@@ -290,8 +290,7 @@ int DeviceProblem::build_preconditioner(const HostCsr &Qh, double reg) {
   const int nthreads = std::max(2, host_cpus_available() / std::max(1, builder.active));
   // Large blocks: partitioned sparse inverse replayed level by level (sparse_precond.h).  Small blocks: the dense
   // inverse streams faster than 2 * depth + 2 dependent launches.  DCORA_PRECOND=dense|sparse overrides.
-  const char *pc = std::getenv("DCORA_PRECOND");
-  const bool want_sparse = pc ? (std::string(pc) == "sparse") : (k > kDensePrecondMaxK);
+  const bool want_sparse = env::precond_mode() ? env::precond_mode() == 2 : (k > kDensePrecondMaxK);
   const int block = m.se ? m.d + 1 : 1;
   if (want_sparse && m.r > 16) {
     set_last_error("sparse preconditioner supports r <= 16");
@@ -307,20 +306,15 @@ int DeviceProblem::build_preconditioner(const HostCsr &Qh, double reg) {
   precond_cache_hit = precond_cache_find(key, &ent);
   DCORA_HIP(hipSetDevice(device));
   if (!precond_cache_hit) {
-    if (std::getenv("DCORA_INIT_TIMING"))
+    if (env::init_timing())
       fprintf(stderr, "[precond] key + cache look-up %.1f ms\n",
               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     HostCsr M = csr_shift_diag(Qh, reg);
     if (want_sparse) {
       PartInvHost P;
-      // the stored weights stream to the device while the host's threads form them (DCORA_SP_WEIGHTS=host: build them
-      // in host memory first and upload in one piece)
-      static const bool weights_on_host = [] {
-        const char *e = std::getenv("DCORA_SP_WEIGHTS");
-        return e && std::string(e) == "host";
-      }();
+      // the stored weights are formed on the device, or stream there while the host's threads form them
       DeviceWeightSink sink(device);
-      if (!weights_on_host) P.sink = &sink;
+      P.sink = &sink;
       const int brc = build_partitioned_inverse_auto(M, block, nthreads, device, &P);
       if (brc && brc != DCORA_ERR_NOT_PD) return brc;
       const bool ok = brc == DCORA_OK;
@@ -332,11 +326,11 @@ int DeviceProblem::build_preconditioner(const HostCsr &Qh, double reg) {
       const auto tu = std::chrono::steady_clock::now();
       const int rc = img->upload(P, P.sink ? &sink : nullptr);
       if (rc) return rc;
-      if (std::getenv("DCORA_INIT_TIMING"))
+      if (env::init_timing())
         fprintf(stderr, "[precond] image upload %.1f ms (since start %.1f ms)\n",
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tu).count(),
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-      if (std::getenv("DCORA_INIT_TIMING"))
+      if (env::init_timing())
         fprintf(stderr, "[precond] host image: %.1f MB wave records, %.1f MB indices, %.1f MB weights\n",
                 P.mwaves.size() * sizeof(MWave) / 1e6, P.idxs.size() * 4 / 1e6, P.vals.size() * 8 / 1e6);
       ent.sparse = img;
@@ -347,10 +341,7 @@ int DeviceProblem::build_preconditioner(const HostCsr &Qh, double reg) {
       ent.ldm = ((k + 127) / 128) * 128;
       auto buf = std::make_shared<DevBuf<double>>();
       DCORA_HIP(buf->alloc((size_t)k * ent.ldm + 16));
-      static const bool host_factor = [] {
-        const char *e = std::getenv("DCORA_FACTOR");
-        return e && std::string(e) == "host";
-      }();
+      const bool host_factor = env::factor_on_host();
       if (host_factor) {  // A/B measurements: sparse Cholesky and k solves on host threads, one upload
         SparseChol chol;
         if (!chol.factor(M, block)) {
@@ -381,10 +372,10 @@ int DeviceProblem::build_preconditioner(const HostCsr &Qh, double reg) {
       ent.bytes = buf->n * sizeof(double);
     }
     ent.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if (std::getenv("DCORA_INIT_TIMING")) fprintf(stderr, "[precond] built after %.1f ms\n", ent.build_ms);
+    if (env::init_timing()) fprintf(stderr, "[precond] built after %.1f ms\n", ent.build_ms);
     precond_cache_insert(key, ent);
   }
-  if (std::getenv("DCORA_INIT_TIMING"))
+  if (env::init_timing())
     fprintf(stderr, "[precond] cached after %.1f ms\n",
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   precond_nnzL = ent.nnzL;
@@ -399,7 +390,7 @@ int DeviceProblem::build_preconditioner(const HostCsr &Qh, double reg) {
   }
   has_precond = true;
   precond_setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  if (std::getenv("DCORA_INIT_TIMING")) fprintf(stderr, "[precond] attached after %.1f ms\n", precond_setup_ms);
+  if (env::init_timing()) fprintf(stderr, "[precond] attached after %.1f ms\n", precond_setup_ms);
   return DCORA_OK;
 }
 
@@ -742,18 +733,9 @@ int DeviceProblem::rtr_dev(const dcora_ropt_params &prm, dcora_ropt_result *res_
   int last_pace_seq = seq;
 
   std::vector<int> upd2_seq((size_t)std::max(1, h.max_inner));
-  static const bool no_fold = std::getenv("DCORA_RA_NOFOLD") != nullptr;
-  const SpFold sfg = (sparse_precond && !no_fold) ? sp.fold_generic() : SpFold();
+  const SpFold sfg = sparse_precond ? sp.fold_generic() : SpFold();
   // H d in one launch (k_spmm_dir_fix) when every long row is a Euclidean column and the partial slots fit
-  static const bool hess_split = [] {
-    const char *e = std::getenv("DCORA_HESS_FUSE");
-    return e && std::string(e) == "0";
-  }();
-  const bool hess_fused = !hess_split && hess_one_launch();
-  static const bool sp_lookahead_generic = [] {
-    const char *e = std::getenv("DCORA_SP_PACING");
-    return e && std::string(e) == "lookahead";
-  }();
+  const bool hess_fused = hess_one_launch();
   for (int outer = 0; outer < h.max_outer; ++outer) {
     // wait for the previous decision (rtr_init / rtr_decide) before committing to another outer iteration
     if (!spin_until([&] { return hf->last_seq_done >= last_pace_seq || hf->outer_done_seq != 0; }, 20.0))
@@ -806,9 +788,9 @@ int DeviceProblem::rtr_dev(const dcora_ropt_params &prm, dcora_ropt_result *res_
           }
           return !(hf->tcg_done_seq >= tcg_first_seq || hf->outer_done_seq != 0);
         };
-        sp.apply(st, m.r, buf1(res.p), Zt.p, Gate{c, ++seq, 2}, true, sp_lookahead_generic ? nullptr : &verdict);
+        sp.apply(st, m.r, buf1(res.p), Zt.p, Gate{c, ++seq, 2}, true, &verdict);
         if (timed) return timed_out();
-        if (!sp_lookahead_generic && (hf->tcg_done_seq >= tcg_first_seq || hf->outer_done_seq != 0)) break;
+        if (hf->tcg_done_seq >= tcg_first_seq || hf->outer_done_seq != 0) break;
       } else
         enq_minv(buf1(res.p), Zt.p, p2.p, nV, Gate{c, ++seq, 2});
       launch_tangent(st, m, Xb(), Zt.p, z.p, res.p, p3.p, p2.p, nV, c, hf_dev, ++seq, 2, j, sfg);
@@ -848,10 +830,7 @@ int DeviceProblem::rtr_dev(const dcora_ropt_params &prm, dcora_ropt_result *res_
 //   C (stopping rule + slice sum + tangent projection + <z,r>)
 // B + C as one launch (k_fused_pc) where that form wins; DCORA_SOLVER_BC = pc / split forces one or the other
 bool DeviceProblem::use_pc() const {
-  static const int forced = [] {
-    const char *e = std::getenv("DCORA_SOLVER_BC");
-    return !e ? 0 : (std::strcmp(e, "split") == 0 ? -1 : (std::strcmp(e, "pc") == 0 ? 1 : 0));
-  }();
+  const int forced = env::solver_bc();
   if (sparse_precond || !has_precond) return false;
   if (forced < 0) return false;
   if (!forced && !fused_pc_preferred(m, ldm)) return false;
@@ -860,7 +839,7 @@ bool DeviceProblem::use_pc() const {
 }
 
 int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
-  static const int kLookahead = std::getenv("DCORA_LOOKAHEAD") ? std::max(1, atoi(std::getenv("DCORA_LOOKAHEAD"))) : 2;
+  constexpr int kLookahead = 2;
   const auto t0 = std::chrono::steady_clock::now();
   t0_ms_ = std::chrono::duration<double, std::milli>(t0.time_since_epoch()).count();
   const bool single = (prm.RTR_iterations == 1);
@@ -892,24 +871,14 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
   const int nPG = sparse_precond ? fused_update_grid(m) : fused_precond_grid(m);
   const double *Mi = sparse_precond ? nullptr : Minv.p;  // null: B only updates, the sparse levels follow
   // without hubs the sparse preconditioner's two permutations ride in B (scatter of the residual) and C (gather of z)
-  static const bool no_fold = std::getenv("DCORA_SP_NOFOLD") != nullptr;
-  const bool folded = sparse_precond && sp.foldable() && !no_fold;
+  const bool folded = sparse_precond && sp.foldable();
   const SpFold sf = folded ? sp.fold() : SpFold{};
   const int nsl = sparse_precond ? 1 : -1;
-  static const bool sp_lookahead = [] {
-    const char *e = std::getenv("DCORA_SP_PACING");
-    return e && std::string(e) == "lookahead";
-  }();
-  const bool sp_paced = sparse_precond && !sp_lookahead;
-  // the same verdict pacing for the dense B+C form is opt-in: on the headline the trace shows next to no no-op
-  // launches to save (69 of 38 800) and the tighter pacing opens more gaps than it closes
-  static const bool pc_verdict = [] {
-    const char *e = std::getenv("DCORA_PC_PACING");
-    return e && std::string(e) == "verdict";
-  }();
+  // With the sparse preconditioner the host enqueues the replay behind the step-length kernel's verdict (below); the
+  // same pacing on the dense one-launch form measured slower (1846 -> 1729-1857 it/s on the headline: its trace holds 69
+  // gated no-op launches among 38 800, and waiting for a verdict there only opens gaps) and is not kept.
   // dense preconditioner: B and C are ONE launch (k_fused_pc); DCORA_SOLVER_BC=split keeps the three-launch form
   const bool pc = use_pc();
-  const bool pc_paced = pc && pc_verdict;
   const int nZ = pc ? fused_pc_blocks(m) : nPB;  // <z, r> partial slots A sums in its prologue
   double *dbuf[2] = {delta.p, delta2.p};
   double *rbuf[2] = {res.p, res2.p};
@@ -920,8 +889,7 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
   auto outer_done = [&]() { return hf->outer_done_seq >= solve_first; };
   // f(x0), grad(x0) from buffer 0 (null gate: the control block of this solve does not exist yet)
   // cost + gradient of an evaluation in one launch where the kernel exists (small CSR blocks), else Q-apply + rgrad
-  static const bool grad_split = std::getenv("DCORA_GRAD_SPLIT") != nullptr;
-  const bool gf = !has_bsr && Q.n_long == 0 && !grad_split;
+  const bool gf = !has_bsr && Q.n_long == 0;
   const int nAe = gf ? nPB : nA;  // {<XQ,X>, <X,G>} partial slots of an evaluation
   int nG;
   ++seq;
@@ -957,16 +925,7 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
       launch_fused_finish(st, m, Xb(), Zpart.p, rbuf[0], z.p, nullptr, 0, p3.p, c, hf_dev, ++seq, 0, 1, nsl, sf);
     }
     for (int j = 0; j < max_inner; ++j) {
-      if (pc_paced && j >= 1) {
-        // B+C of iteration j-1 takes its boundary decision in its first microseconds and says so (go_seq): iteration
-        // j is enqueued behind that verdict, while the rest of that kernel runs, instead of two iterations ahead --
-        // a run that ends on the boundary or on negative curvature then leaves no no-op launches behind it, one
-        // that ends on the residual rule (known at the END of B+C) leaves one iteration of them instead of two
-        const int need = fin_seq[j - 1];
-        if (!spin_until([&] { return hf->go_seq >= need || hf->tcg_done_seq >= tcg_first_seq || outer_done(); },
-                        20.0))
-          return timed_out();
-      } else if (j >= kLookahead) {
+      if (j >= kLookahead) {
         const int need = fin_seq[j - kLookahead];
         if (!spin_until(
                 [&] { return hf->last_seq_done >= need || hf->tcg_done_seq >= tcg_first_seq || outer_done(); }, 20.0))
@@ -1000,9 +959,9 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
             }
             return !(hf->tcg_done_seq >= tcg_first_seq || outer_done());
           };
-          sp.apply(st, m.r, buf1(rbuf[par ^ 1]), Zpart.p, Gate{c, ++seq, 2}, folded, sp_paced ? &verdict : nullptr);
+          sp.apply(st, m.r, buf1(rbuf[par ^ 1]), Zpart.p, Gate{c, ++seq, 2}, folded, &verdict);
           if (timed) return timed_out();
-          if (sp_paced && (hf->tcg_done_seq >= tcg_first_seq || outer_done())) break;
+          if (hf->tcg_done_seq >= tcg_first_seq || outer_done()) break;
         }
         launch_fused_finish(st, m, Xb(), Zpart.p, rbuf[par ^ 1], z.p, p2.p, nPG, p3.p, c, hf_dev, ++seq, j, 0, nsl,
                             sf);
@@ -1115,9 +1074,8 @@ int DeviceProblem::time_precond(int reps, double *avg_ms, double *bytes) {
   DCORA_HIP(hipEventCreate(&e0));
   DCORA_HIP(hipEventCreate(&e1));
   // The dense kernel is timed in its in-loop form (step length from the <d, H d> partials, vector updates, |r|^2),
-  // not in the shorter form that opens a tCG run (DCORA_TIME_PRECOND_FIRST=1 for that one); the partials are set so
-  // that the step is a no-op.
-  static const bool step_form = std::getenv("DCORA_TIME_PRECOND_FIRST") == nullptr;
+  // not in the shorter form that opens a tCG run; the partials are set so that the step is a no-op.
+  constexpr bool step_form = true;
   const int nPB = fused_pose_blocks(m);
   if (step_form && !sparse_precond) {
     std::vector<double> ones(std::max((size_t)nPB, (size_t)nelem()), 1.0);
@@ -1133,7 +1091,7 @@ int DeviceProblem::time_precond(int reps, double *avg_ms, double *bytes) {
       sp.apply(st, m.r, buf1(RG0.p), Zt.p, Gate{});
     else if (!bc_split)  // the one-launch B + C of the dense path, in its in-loop form
       launch_fused_pc(st, m, ldm, Minv.p, RGb(), Xb(), delta.p, Hd.p, eta.p, Heta.p, res.p, res2.p, z.p, p1.p,
-                      std::getenv("DCORA_PC_EXP") ? -1 : nPB, p3.p, ctl.p, hf_dev, 1, 1, 0);
+                      nPB, p3.p, ctl.p, hf_dev, 1, 1, 0);
     else if (step_form)
       launch_fused_precond(st, m, ldm, Minv.p, RGb(), delta.p, Hd.p, eta.p, Heta.p, res.p, res2.p, Zpart.p, p1.p, nPB,
                            p2.p, ctl.p, hf_dev, 1, 1, 0);
@@ -1142,33 +1100,14 @@ int DeviceProblem::time_precond(int reps, double *avg_ms, double *bytes) {
                            nullptr, 0, p2.p, ctl.p, hf_dev, 1, 0, 1);
   };
   for (int i = 0; i < 3; ++i) run();
-  // DCORA_TIME_PRECOND_GRAPH=1: the same launches captured once in a hipGraph and replayed (measurement of what the
-  // stream's per-launch dispatch costs next to the kernels themselves)
-  static const bool as_graph = std::getenv("DCORA_TIME_PRECOND_GRAPH") != nullptr;
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t gexec = nullptr;
-  if (as_graph) {
-    DCORA_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    run();
-    DCORA_HIP(hipStreamEndCapture(st, &graph));
-    DCORA_HIP(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
-    for (int i = 0; i < 3; ++i) DCORA_HIP(hipGraphLaunch(gexec, st));
-  }
   DCORA_HIP(hipEventRecord(e0, st));
-  for (int i = 0; i < reps; ++i) {
-    if (as_graph)
-      DCORA_HIP(hipGraphLaunch(gexec, st));
-    else
-      run();
-  }
+  for (int i = 0; i < reps; ++i) run();
   DCORA_HIP(hipEventRecord(e1, st));
   DCORA_HIP(hipEventSynchronize(e1));
   float ms = 0;
   DCORA_HIP(hipEventElapsedTime(&ms, e0, e1));
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
-  if (gexec) (void)hipGraphExecDestroy(gexec);
-  if (graph) (void)hipGraphDestroy(graph);
   *avg_ms = (double)ms / reps;
   // algorithmic bytes: the k x k inverse once, the residual in, the split-K slices out
   // algorithmic bytes, dense form: the k x k inverse once; split form: + the residual in and the split-K slices out;

@@ -61,6 +61,7 @@ enum ExchangeMode { kExchangeIpc = 1, kExchangeStaged = 2 };
 // how long a rank waits for another before it gives up, raises `failed` for everybody and returns an error
 // (DCORA_EXCHANGE_TIMEOUT_S, default 120: a rank that died takes the job down within this time, never a hang)
 double exchange_timeout_s();
+extern std::atomic<int> g_probe_fault_rounds;  // test hook of the link check (dcora_debug_exchange_probe_fault)
 
 class Exchange {
  public:

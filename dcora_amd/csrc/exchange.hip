@@ -1,5 +1,6 @@
 // Neighbour exchange of public poses between the ranks of one node (see exchange.h).
 #include "exchange.h"
+#include "env.h"
 
 #include <fcntl.h>
 #include <sched.h>
@@ -215,14 +216,9 @@ inline void polite_spin(unsigned &spins) {
 
 }  // namespace
 
-double exchange_timeout_s() {
-  static const double v = [] {
-    const char *e = std::getenv("DCORA_EXCHANGE_TIMEOUT_S");
-    const double x = e ? atof(e) : 0.0;
-    return x > 0 ? x : 120.0;
-  }();
-  return v;
-}
+double exchange_timeout_s() { return env::exchange_timeout_s(); }
+
+std::atomic<int> g_probe_fault_rounds{0};
 
 int Exchange::usage(const std::string &msg, int code) {
   set_last_error("exchange (rank " + std::to_string(rank) + "): " + msg);
@@ -476,7 +472,7 @@ int Exchange::init(ExchangeSession *s, const char *job_name) {
   if (n_hosted_)
     DCORA_HIP(hipMemcpy(hosted_list_.p, hosted.data(), sizeof(int) * n_hosted_, hipMemcpyHostToDevice));
 
-  const char *force = std::getenv("DCORA_EXCHANGE");
+  const char *force = env::exchange();
   const bool want_ipc = !(force && std::strcmp(force, "staged") == 0);
   int ok = 1;
   if (world > 1) {
@@ -505,7 +501,7 @@ int Exchange::init(ExchangeSession *s, const char *job_name) {
     bool all_fine = true;
     for (int q = 0; q < world; ++q) all_fine = all_fine && ranks_[q].fine.load(std::memory_order_acquire) == 1;
     const bool poll_is_safe = mode != kExchangeIpc || all_fine;
-    const char *wm = std::getenv("DCORA_EXCHANGE_WAIT");
+    const char *wm = env::exchange_wait();
     device_wait_ = (wm ? std::strcmp(wm, "host") != 0 : !shared_gpu) && poll_is_safe;
   }
   if (force && std::strcmp(force, "ipc") == 0 && !all) return fail("DCORA_EXCHANGE=ipc but the IPC transport is not usable", DCORA_ERR_HIP);
@@ -542,8 +538,7 @@ int Exchange::setup_ipc(bool attempt) {
   if (ok) {
     const size_t bytes = sizeof(double) * halo_doubles;
     void *hp = nullptr;
-    static const bool coarse = std::getenv("DCORA_EXCHANGE_COARSE") != nullptr;
-    if (!coarse && hipExtMallocWithFlags(&hp, bytes, hipDeviceMallocFinegrained) == hipSuccess && hp) {
+    if (hipExtMallocWithFlags(&hp, bytes, hipDeviceMallocFinegrained) == hipSuccess && hp) {
       halo_.p = (double *)hp;  // released with hipFree like any DevBuf
       halo_.n = halo_doubles;
       halo_finegrained_ = true;
@@ -718,17 +713,14 @@ bool Exchange::probe_round(uint64_t seq, std::string *why) {
 // stepping down together -- device-side wait -> host wait -> staged transport -- until a round passes on every rank.
 int Exchange::link_check() {
   std::string why, first_why;
-  // test hook: DCORA_EXCHANGE_PROBE_FAULT=n makes the last rank report its first n rounds as failed
-  static const int fault_rounds = [] {
-    const char *e = std::getenv("DCORA_EXCHANGE_PROBE_FAULT");
-    return e ? atoi(e) : 0;
-  }();
+  // test hook (dcora_debug_exchange_probe_fault): the last rank reports its first n rounds as failed
+  const int fault_rounds = g_probe_fault_rounds.load();
   for (int round = 1; round <= 3; ++round) {
     const auto t0 = Clock::now();
     bool mine = probe_round((uint64_t)round, &why);
     if (mine && rank == world - 1 && round <= fault_rounds) {
       mine = false;
-      why = "injected fault (DCORA_EXCHANGE_PROBE_FAULT)";
+      why = "injected fault (dcora_debug_exchange_probe_fault)";
     }
     if (!mine && first_why.empty()) first_why = why;
     ranks_[rank].probe.store(mine ? round : -round, std::memory_order_release);
@@ -751,11 +743,11 @@ int Exchange::link_check() {
       device_wait_ = false;
       link_gave_up_device_wait = 1;
     } else if (mode == kExchangeIpc) {
-      const char *force = std::getenv("DCORA_EXCHANGE");
+      const char *force = env::exchange();
       if (force && std::strcmp(force, "ipc") == 0) break;
       mode = kExchangeStaged;
       link_gave_up_ipc = 1;
-      const char *wm = std::getenv("DCORA_EXCHANGE_WAIT");
+      const char *wm = env::exchange_wait();
       device_wait_ = wm ? std::strcmp(wm, "host") != 0 : device_wait_;
     } else if (device_wait_) {
       device_wait_ = false;

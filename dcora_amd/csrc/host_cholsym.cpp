@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "device_chol.h"
+#include "env.h"
 
 namespace dcora {
 
@@ -19,7 +20,7 @@ void chol_symbolic(const HostCsr &A, int block, CholSymbolic *out, int top_unkno
   S.n = n;
   std::vector<int> cuts;
   int nhub = 0;
-  const bool timing = std::getenv("DCORA_INIT_TIMING") != nullptr;
+  const bool timing = env::init_timing();
   auto tl = std::chrono::steady_clock::now();
   auto lap = [&](const char *what) {
     if (!timing) return;

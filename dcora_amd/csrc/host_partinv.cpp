@@ -12,6 +12,7 @@
 #include <thread>
 
 #include "host_partinv_int.h"
+#include "env.h"
 #include "sparse_precond.h"
 
 namespace dcora {
@@ -110,7 +111,7 @@ void piecewise_solve(const PiecewiseFactor &F, int np, int k, std::vector<double
 }  // namespace
 
 bool build_partitioned_inverse(const HostCsr &A, int block, int nthreads, PartInvHost *out) {
-  const bool timing = std::getenv("DCORA_INIT_TIMING") != nullptr;
+  const bool timing = env::init_timing();
   const auto T0 = std::chrono::steady_clock::now();
   SparseChol chol;
   if (!chol.factor(A, block, nd_top_default())) return false;
@@ -123,7 +124,7 @@ bool build_partitioned_inverse(const HostCsr &A, int block, int nthreads, PartIn
 }
 
 bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, int nthreads, PartInvHost *out) {
-  const bool timing = std::getenv("DCORA_INIT_TIMING") != nullptr;
+  const bool timing = env::init_timing();
   auto tnow = [] { return std::chrono::steady_clock::now(); };
   auto tms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   const auto T1 = tnow();
@@ -173,16 +174,6 @@ bool build_partitioned_inverse_from(const HostCsr &A, const PiecewiseFactor &F, 
   }
   int nlev = 0;
   for (const Piece &p : pc) nlev = std::max(nlev, p.level + 1);
-  if (const char *dump = std::getenv("DCORA_PARTINV_DUMP")) {  // structure only: c0 c level m rows...
-    if (FILE *fp = std::fopen(dump, "w")) {
-      for (const Piece &p : pc) {
-        std::fprintf(fp, "%d %d %d %d", p.c0, p.c, p.level, (int)p.rows.size());
-        for (int i : p.rows) std::fprintf(fp, " %d", i);
-        std::fprintf(fp, "\n");
-      }
-      std::fclose(fp);
-    }
-  }
   // ---- numeric part: D^-1 and W = -B D^-1 of every piece.  Wide pieces first, one at a time with all threads on the
   //      columns of the inverse (column k of D^-1 is an independent forward substitution); then the many small
   //      pieces in parallel, most expensive first ----

@@ -60,14 +60,8 @@ struct Source {        // what a piece contributes to the rows above it in one f
 };
 
 // steps a wave should get: it requests the loads of up to eight steps together, so eight steps are one memory round trip
-int steps_per_wave() {
-  static const int v = [] {
-    const char *e = std::getenv("DCORA_SP_WAVE_STEPS");
-    const int x = e ? atoi(e) : 0;
-    return x > 0 ? x : 8;
-  }();
-  return v;
-}
+// (measured per application on a lattice agent: 4 -> 105 us, 8 -> 102, 16 -> 106)
+constexpr int steps_per_wave() { return 8; }
 
 }  // namespace
 
@@ -135,10 +129,6 @@ void layout_mpipe(const std::vector<Piece> &pc, const std::vector<const double *
 
   // ---- which levels merge.  Levels below the top: 0 .. nlo - 1; the top level is a launch of its own. ----
   const int nlo = nlev - 1;
-  static const bool merge_on = [] {
-    const char *e = std::getenv("DCORA_SP_MERGE");
-    return !(e && std::strcmp(e, "0") == 0);
-  }();
   std::vector<std::vector<int>> merged_rows((size_t)np);  // rows of V_s for the lower pieces of CHOSEN pairs
   auto union_rows = [&](int s, int t, std::vector<int> *rows_out, double *flops) {
     const Piece &ps = pc[s];
@@ -161,8 +151,7 @@ void layout_mpipe(const std::vector<Piece> &pc, const std::vector<const double *
   };
   // the fill of a pair is stored once and streamed by both sweeps
   std::vector<double> pair_bytes((size_t)std::max(nlo, 1), 0.0), pair_flops((size_t)std::max(nlo, 1), 0.0);
-  if (merge_on)
-    for (int t = 0; t + 1 < nlo; ++t) {
+  for (int t = 0; t + 1 < nlo; ++t) {
       std::vector<int> rows;
       for (int s : by_level[t]) {
         union_rows(s, t, &rows, &pair_flops[t]);
@@ -170,12 +159,9 @@ void layout_mpipe(const std::vector<Piece> &pc, const std::vector<const double *
       }
     }
   // a launch saved is worth a dependent launch boundary plus the ramp of a burst (~3 us = ~15 MB at the streaming rate)
-  static const double max_bytes = [] {
-    const char *e = std::getenv("DCORA_SP_MERGE_MB");
-    return 1e6 * (e ? atof(e) : 30.0);
-  }();
+  const double max_bytes = 30e6;
   static const double max_flops = 12e9;
-  auto pair_ok = [&](int t) { return merge_on && pair_bytes[t] <= max_bytes && pair_flops[t] <= max_flops; };
+  auto pair_ok = [&](int t) { return pair_bytes[t] <= max_bytes && pair_flops[t] <= max_flops; };
   std::vector<int> is_pair_lo((size_t)std::max(nlo, 1), 0);
   {
     std::vector<int> cnt((size_t)nlo + 2, 0);

@@ -1,5 +1,6 @@
 // Host-side sparse helpers of the product (setup-time only; see host_sparse.h).
 #include "host_sparse.h"
+#include "env.h"
 
 #include <sched.h>
 
@@ -310,7 +311,7 @@ void nd_recurse(const NDGraph &G, std::vector<int> nodes, std::vector<int> &comp
 
 int host_cpus_available() {
   static const int n = [] {
-    if (const char *e = std::getenv("DCORA_HOST_THREADS")) return std::max(1, atoi(e));
+    if (env::host_threads() > 0) return env::host_threads();
     long best = (long)std::max(1u, std::thread::hardware_concurrency());
     cpu_set_t set;
     CPU_ZERO(&set);
@@ -346,11 +347,7 @@ int host_cpus_available() {
 
 int nd_top_default() {
   // measured on sphere2500 / torus3D / tiers.pyfg / a 100k-lattice agent: best of 1536 / 2048 / 3072 / 4096
-  static const int v = [] {
-    const char *e = std::getenv("DCORA_ND_TOP");
-    return e ? atoi(e) : 3072;
-  }();
-  return v;
+  return 3072;
 }
 
 std::vector<int> amd_like_order(const HostCsr &A, int block, std::vector<int> *pieces, int *nhub_cols,
@@ -389,10 +386,7 @@ std::vector<int> amd_like_order(const HostCsr &A, int block, std::vector<int> *p
   int next_cid = 0;
   std::vector<int> cuts;
   // leaf sub-domains of ~96 unknowns: 24 pose blocks, or 96 scalar unknowns when the graph is not block-compressed
-  static const int leaf_unknowns = [] {
-    const char *e = std::getenv("DCORA_ND_LEAF");
-    return e ? std::max(8, atoi(e)) : 96;
-  }();
+  constexpr int leaf_unknowns = 96;
   int leaf_nodes = std::max(leaf_unknowns / 4, leaf_unknowns / block);
   std::vector<std::pair<int, int>> tasks;
   const int task_nodes = (col_tasks && want_tasks > 1) ? std::max(4 * leaf_nodes, (int)all.size() / want_tasks) : 0;
@@ -423,7 +417,7 @@ std::vector<int> amd_like_order(const HostCsr &A, int block, std::vector<int> *p
       // their leaf level is small next to the launch it saves.  Measured per application of the replay, leaves of
       // 96 / 192 / 384 unknowns: sphere2500 49 / 41 / 39 us, torus3D 89 / 75 / 74, tiers.pyfg 72 / 65 / 82,
       // an agent of the 100k lattice (two depths in the top) 169 / 190 / 235.
-      if (top_depth >= 3 && std::getenv("DCORA_ND_LEAF") == nullptr) leaf_nodes *= 2;
+      if (top_depth >= 3) leaf_nodes *= 2;
       if (top_depth == 0 && task_nodes == 0) {  // volume-like graph: the same recursion would run again (90 ms at k = 400 000)
         comp_id.swap(comp0);
         level.swap(level0);
@@ -432,7 +426,7 @@ std::vector<int> amd_like_order(const HostCsr &A, int block, std::vector<int> *p
         next_cid = cid0;
         have_plain = true;
       }
-      if (std::getenv("DCORA_FACTOR_TIMING"))
+      if (env::init_timing())
         std::fprintf(stderr, "[order] %d nodes: dense top of %d depths, leaves of %d nodes\n", (int)all.size(), top_depth,
                      leaf_nodes);
     }
@@ -485,11 +479,10 @@ bool SparseChol::factor(const HostCsr &A, int block, int top_unknowns) {
   const int n = n_;
   // sub-tree parallel numeric phase for matrices that are worth it
   int nthreads = (n >= 4096) ? std::max(1, std::min(host_cpus_available(), 16)) : 1;
-  if (const char *e = std::getenv("DCORA_FACTOR_THREADS")) nthreads = std::max(1, atoi(e));
   std::vector<std::pair<int, int>> tasks;
   std::vector<std::vector<std::pair<int, int>>> waves;  // separators above the tasks, by dissection depth
   perm_ = amd_like_order(A, block, &pieces_, &nhub_, &tasks, 4 * nthreads, &waves, top_unknowns);
-  const bool timing = std::getenv("DCORA_FACTOR_TIMING") != nullptr;
+  const bool timing = env::init_timing();
   auto tnow = [] { return std::chrono::steady_clock::now(); };
   auto tms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   const auto T0 = tnow();

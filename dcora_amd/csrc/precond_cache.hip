@@ -1,5 +1,6 @@
 // see precond_cache.h
 #include "precond_cache.h"
+#include "env.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -42,8 +43,7 @@ double g_hits = 0, g_misses = 0;
 
 size_t budget() {
   static const size_t b = [] {
-    const char *e = std::getenv("DCORA_PRECOND_CACHE_MB");
-    const double mb = e ? std::atof(e) : 8192.0;
+    const double mb = env::precond_cache_mb();
     return (size_t)(mb * 1024.0 * 1024.0);
   }();
   return b;

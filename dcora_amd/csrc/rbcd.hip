@@ -1,5 +1,6 @@
 // RBCD++ session on the device (see rbcd.h).
 #include "rbcd.h"
+#include "env.h"
 
 #include <algorithm>
 #include <atomic>
@@ -13,8 +14,7 @@
 namespace dcora {
 
 static bool group_kernels(const ManiDesc &m) {
-  static const bool v1 = std::getenv("DCORA_NESTEROV_V1") != nullptr;
-  return group_supported(m) && !v1;
+  return group_supported(m) && !env::generic_solver();
 }
 
 static void nesterov(hipStream_t st, const ManiDesc &m, int mode, int restart, int skip_lo, int skip_hi, double alpha,
@@ -110,7 +110,7 @@ int RbcdSession::init(const HostDataset &ds, const dcora_rbcd_options &o) {
   DCORA_HIP(evalbuf.alloc(2 * R + 16));
   DCORA_HIP(hipMemset(evalbuf.p, 0, sizeof(double) * (2 * R + 16)));
 
-  if (std::getenv("DCORA_INIT_TIMING"))
+  if (env::init_timing())
     fprintf(stderr, "[session] buffers after %.1f ms\n",
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   // partition (ref examples/MultiRobotExample.cpp:56-118)
@@ -197,7 +197,7 @@ int RbcdSession::init(const HostDataset &ds, const dcora_rbcd_options &o) {
     const size_t nh = hosted_ids.size();
     std::vector<int> rcs(nh, DCORA_OK);
     std::vector<std::string> errs(nh);
-    static const bool serial = std::getenv("DCORA_SERIAL_SETUP") != nullptr;
+    constexpr bool serial = false;
     // small blocks build in well under a millisecond of host work each: threads only pay off for large ones
     if (nh > 1 && !serial && (long)(n / R) * dh >= 1024) {
       std::atomic<size_t> next(0);
@@ -223,7 +223,7 @@ int RbcdSession::init(const HostDataset &ds, const dcora_rbcd_options &o) {
         return rcs[i];
       }
   }
-  const bool init_timing = std::getenv("DCORA_INIT_TIMING") != nullptr;
+  const bool init_timing = env::init_timing();
   if (init_timing)
     fprintf(stderr, "[session] agents built after %.1f ms\n",
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
@@ -655,8 +655,7 @@ int RbcdSession::evaluate_central(double *cost2, double *gradnorm, double *block
     return DCORA_ERR_UNSUPPORTED;
   }
   DeviceProblem &c = *central;
-  static const bool grad_split = std::getenv("DCORA_GRAD_SPLIT") != nullptr;
-  const bool gf = c.group && c.fused && !c.has_bsr && c.Q.n_long == 0 && !grad_split;
+  const bool gf = c.group && c.fused && !c.has_bsr && c.Q.n_long == 0;
   if (!gf) c.enqueue_egrad(Xg.p, c.EG0.p, c.pA.p);
   if (c.group) {
     int nA = c.npA();

@@ -1496,117 +1496,9 @@ __global__ __launch_bounds__(kBlock) void k_g_nesterov(ManiDesc m, GNesterovArgs
 // 27.2 -> 36.8 us, cold 33.7 -> 37.1 us.  Per launch the kernel also moves 717 MB through LDS (every lane reads the
 // (d+1)^2 values of its block: 9 us of LDS time per CU) and issues 350 k gather instructions of 8+ lines each (another
 // 9 us of address-unit time), next to 21 us of HBM time at the measured triad rate: balanced, not HBM-bound alone.
-constexpr int kBsrGather = 2;
-template <int D, bool DOTS>
-__global__ __launch_bounds__(kBlock) void k_spmm_bsr(int r, BsrDev A, Buf2 Xb, int selX,
-                                                     const double *__restrict__ G, Buf2 Yb, int selY,
-                                                     double *__restrict__ partials, Gate g) {
-  if (g.ctl && g.gate && f_gated(g.ctl, g.seq, g.gate)) return;
-  constexpr int DH = D + 1, BS = DH * DH;
-  __shared__ double s_bv[kBsrTile * BS];
-  __shared__ int s_bc[kBsrTile];
-  __shared__ double s_red[16];
-  const int cur = g.ctl ? (g.ctl->cur & 1) : 0;
-  const double *__restrict__ X = Xb.p[g.ctl ? ((cur ^ selX) & 1) : 0];
-  double *__restrict__ Y = Yb.p[g.ctl ? ((cur ^ selY) & 1) : 0];
-  const int t = threadIdx.x & (GW - 1);
-  double d0 = 0, d1 = 0;
-  // (an XCD-aware walk -- one contiguous eighth of the pose chunks per XCD -- was measured on the 100k lattice:
-  // 36.0 vs 34.9 us, no gain over the plain interleaved walk, so the simple mapping stays)
-  // Balanced ranges instead of one 32-pose chunk per workgroup: at most 8 workgroups of 256 threads are resident per
-  // CU (2048 on the chip), so a grid of 3125 chunks ran as one full round plus a half-empty one.  Workgroup b takes
-  // the poses [n b / grid, n (b + 1) / grid) in passes of at most 32 (equal-sized passes).
-  const int range_lo = (int)((long)A.nbrows * blockIdx.x / gridDim.x);
-  const int range_hi = (int)((long)A.nbrows * (blockIdx.x + 1) / gridDim.x);
-  const int npass = max(1, (range_hi - range_lo + kPosesPerBlock - 1) / kPosesPerBlock);
-  const int per_pass = (range_hi - range_lo + npass - 1) / npass;
-  for (int pose0 = range_lo; pose0 < range_hi; pose0 += per_pass) {
-    const int pend_pose = min(range_hi, pose0 + per_pass);
-    const int pose = pose0 + (threadIdx.x >> 3);
-    const bool inr = pose < pend_pose;
-    const bool active = inr && (t < r);
-    const int bbeg = A.bp[pose0], bend = A.bp[pend_pose];
-    const int myb = inr ? A.bp[pose] : 0, mye = inr ? A.bp[pose + 1] : 0;
-    double acc[DH];
-#pragma unroll
-    for (int a = 0; a < DH; ++a) acc[a] = 0;
-    for (int base = bbeg; base < bend; base += kBsrTile) {
-      const int cnt = min(kBsrTile, bend - base);
-      __syncthreads();
-      {
-        // the whole tile is requested before any of it is stored to LDS (clamped index, straight-line 16-byte
-        // loads): one memory round trip per tile instead of one per 256 doubles
-        constexpr int SU = (kBsrTile * BS / 2 + kBlock - 1) / kBlock;  // double2 loads per thread
-        const double2 *__restrict__ src = reinterpret_cast<const double2 *>(A.bv + (size_t)base * BS);
-        const int n2 = cnt * BS / 2;  // BS is even ((d+1)^2 = 9 only for d = 2: handled below)
-        double2 v_r[SU];
-        const int bc_r = A.bc[base + min((int)threadIdx.x, cnt - 1)];
-        if ((BS & 1) == 0) {
-#pragma unroll
-          for (int u = 0; u < SU; ++u) v_r[u] = src[min((int)threadIdx.x + u * kBlock, n2 - 1)];
-#pragma unroll
-          for (int u = 0; u < SU; ++u) {
-            const int i = threadIdx.x + u * kBlock;
-            if (i < n2) reinterpret_cast<double2 *>(s_bv)[i] = v_r[u];
-          }
-        } else {
-          for (int i = threadIdx.x; i < cnt * BS; i += kBlock) s_bv[i] = A.bv[(size_t)base * BS + i];
-        }
-        if ((int)threadIdx.x < cnt) s_bc[threadIdx.x] = bc_r;
-        for (int i = threadIdx.x + kBlock; i < cnt; i += kBlock) s_bc[i] = A.bc[base + i];
-      }
-      __syncthreads();
-      const int lo = max(myb, base) - base, hi = min(mye, base + cnt) - base;
-      for (int b = lo; b < hi; b += kBsrGather) {
-        // kBsrGather matrix blocks per step: their (d+1) gathers each are in flight together (index clamped, operand
-        // masked)
-        double x[kBsrGather][DH];
-        int bb[kBsrGather];
-#pragma unroll
-        for (int q = 0; q < kBsrGather; ++q) {
-          const bool ok = active && (b + q < hi);
-          bb[q] = (b + q < hi) ? b + q : b;
-          const size_t o = (size_t)s_bc[bb[q]] * DH * r + t;
-#pragma unroll
-          for (int c = 0; c < DH; ++c) x[q][c] = ok ? X[o + c * r] : 0.0;
-        }
-#pragma unroll
-        for (int q = 0; q < kBsrGather; ++q) {
-          const double *__restrict__ Bq = s_bv + bb[q] * BS;
-#pragma unroll
-          for (int a = 0; a < DH; ++a) {
-            double s = 0;
-#pragma unroll
-            for (int c = 0; c < DH; ++c) s += Bq[a * DH + c] * x[q][c];
-            acc[a] += s;
-          }
-        }
-      }
-    }
-    if (active) {
-      const size_t o = (size_t)pose * DH * r + t;
-#pragma unroll
-      for (int a = 0; a < DH; ++a) {
-        double y = acc[a];
-        if (DOTS) {
-          const double x = X[o + a * r];
-          d0 += acc[a] * x;
-          if (G) d1 += x * G[o + a * r];
-        }
-        if (G) y += G[o + a * r];
-        Y[o + a * r] = y;
-      }
-    }
-  }
-  if (DOTS) {
-    const double a = f_block_sum(d0, s_red);
-    const double b = f_block_sum(d1, s_red);
-    if (threadIdx.x == 0) {
-      partials[2 * blockIdx.x] = a;
-      partials[2 * blockIdx.x + 1] = b;
-    }
-  }
-}
+// (The first form staged block values and column indices of 32 block rows in LDS and read them back as broadcasts:
+// 27.4 / 33.9 us warm / cold on the 100k lattice, 717 MB through LDS per launch; replaced by the LDS-free form below,
+// which sums in the same order.)
 
 // Second form of the block Q-apply: no LDS.  The 8 lanes of a pose read the block themselves -- lane t loads row t & 3
 // of the (d+1)^2 block (32 bytes; the two quads of a pose load the same 128 bytes, which the address unit merges) -- and
@@ -1737,137 +1629,12 @@ __global__ __launch_bounds__(kBlock) void k_spmm_bsr2(int r, BsrDev A, Buf2 Xb, 
   }
 }
 
-// Third form of the block Q-apply (d = 3): HALF the load instructions.  The kernels above are bound by the number of
-// loads they issue (each touches the lines of 8 poses), and a lane there issues six per matrix block: two for its row of
-// the block and d + 1 = 4 gathers of 8 bytes, one per column of the neighbour's r x 4 block.  Here a lane issues three
-// 16-byte loads: the 8 lanes of a pose are (column pair c2, row pair rp); the lane gathers rows (2 rp, 2 rp + 1) of the
-// neighbour's columns 2 c2 and 2 c2 + 1 -- 16 bytes each, 8-byte aligned in the tight r x k layout, which
-// global_load_dwordx4 takes -- and loads the 16 bytes B[rp][2 c2 .. 2 c2 + 1] of the block, whose other rows arrive by
-// DPP quad broadcasts (8 per block instead of 16).  It accumulates the products of ITS two columns for its two rows and
-// all four output columns; the two column pairs of a pose are added once per pose (lane t and t ^ 4), not per block.
-// At odd r the last row pair is loaded one row lower (rows r - 2, r - 1) and its first half ignored: nothing is read
-// beyond a column.  The summation order differs from k_spmm_bsr2 (rounding-level differences, still deterministic).
-// MEASURED AND NOT THE DEFAULT (DCORA_BSR_KERNEL=v3; round 3, 100k lattice, warm / cold us): r = 5: 28.6 / 36.7 against
-// 24.6 / 33.1 for k_spmm_bsr2; r = 7: 31.8 / 38.8 against 27.8 / 37.9; and at EVEN r, where every 16-byte gather is
-// 16-byte aligned -- what an internal padded leading dimension (ld = 6 at r = 5) would buy at +20 % vector bytes --
-// r = 4: 26.9 / 33.9 against 23.4 / 30.7, r = 6: 29.9 / 36.7 against 26.1 / 34.7, r = 8: 31.6 / 40.0 against 28.2 / 35.9.
-// Half the load instructions, 6 of 8 lanes working, and slower everywhere: the Q-apply is not bound by the number of
-// its loads but by the dependent chain (row pointer -> column indices -> gather) at the head of each of its ~3000
-// short-lived workgroups and by what the fabric delivers to scattered 128-byte requests.
-struct __attribute__((packed, aligned(8))) Pair8 {
-  double x, y;
-};
-constexpr int kBsrGather3 = 4;
-template <bool DOTS>
-__global__ __launch_bounds__(kBlock) void k_spmm_bsr3(int r, BsrDev A, Buf2 Xb, int selX,
-                                                      const double *__restrict__ G, Buf2 Yb, int selY,
-                                                      double *__restrict__ partials, Gate g) {
-  if (g.ctl && g.gate && f_gated(g.ctl, g.seq, g.gate)) return;
-  constexpr int DH = 4, BS = 16;
-  __shared__ double s_red[16];
-  const int cur = g.ctl ? (g.ctl->cur & 1) : 0;
-  const double *__restrict__ X = Xb.p[g.ctl ? ((cur ^ selX) & 1) : 0];
-  double *__restrict__ Y = Yb.p[g.ctl ? ((cur ^ selY) & 1) : 0];
-  const int t = threadIdx.x & (GW - 1);
-  const int c2 = t >> 2, rp = t & 3;
-  const int r0 = 2 * rp;
-  const bool have0 = r0 < r, have1 = r0 + 1 < r;
-  const bool tail = have0 && !have1;               // odd r: the last row alone
-  const int lo = have1 ? r0 : (have0 ? r0 - 1 : 0);  // first row of the 16 bytes this lane gathers (r >= 2)
-  double d0 = 0, d1 = 0;
-  const int range_lo = (int)((long)A.nbrows * blockIdx.x / gridDim.x);
-  const int range_hi = (int)((long)A.nbrows * (blockIdx.x + 1) / gridDim.x);
-  const int npass = max(1, (range_hi - range_lo + kPosesPerBlock - 1) / kPosesPerBlock);
-  const int per_pass = (range_hi - range_lo + npass - 1) / npass;
-  for (int pose0 = range_lo; pose0 < range_hi; pose0 += per_pass) {
-    const int pend_pose = min(range_hi, pose0 + per_pass);
-    const int pose = pose0 + (threadIdx.x >> 3);
-    const bool inr = pose < pend_pose;
-    const int myb = inr ? A.bp[pose] : 0, mye = inr ? A.bp[pose + 1] : 0;
-    double acc[DH][2];
-#pragma unroll
-    for (int a = 0; a < DH; ++a) acc[a][0] = acc[a][1] = 0;
-    for (int b0 = myb; b0 < mye; b0 += GW) {
-      const int nb = min(GW, mye - b0);
-      const int mybc = (t < nb) ? A.bc[b0 + t] : 0;
-      for (int q0 = 0; q0 < nb; q0 += kBsrGather3) {
-        Pair8 xa[kBsrGather3], xb[kBsrGather3];
-        double2 w[kBsrGather3];
-#pragma unroll
-        for (int q = 0; q < kBsrGather3; ++q) {
-          const bool ok = q0 + q < nb;
-          const int qc = ok ? q0 + q : q0;
-          const int col = __shfl(mybc, qc, GW);
-          const double *__restrict__ xc = X + ((size_t)col * DH + 2 * c2) * r + lo;
-          xa[q] = *reinterpret_cast<const Pair8 *>(xc);
-          xb[q] = *reinterpret_cast<const Pair8 *>(xc + r);
-          w[q] = *reinterpret_cast<const double2 *>(A.bv + (size_t)(b0 + qc) * BS + rp * DH + 2 * c2);
-          if (!ok) w[q] = make_double2(0.0, 0.0);
-        }
-#pragma unroll
-        for (int q = 0; q < kBsrGather3; ++q) {
-          const double xa0 = tail ? xa[q].y : xa[q].x, xa1 = tail ? 0.0 : xa[q].y;
-          const double xb0 = tail ? xb[q].y : xb[q].x, xb1 = tail ? 0.0 : xb[q].y;
-          {
-            const double b0v = quad_bcast<0>(w[q].x), b1v = quad_bcast<0>(w[q].y);
-            acc[0][0] += b0v * xa0 + b1v * xb0;
-            acc[0][1] += b0v * xa1 + b1v * xb1;
-          }
-          {
-            const double b0v = quad_bcast<1>(w[q].x), b1v = quad_bcast<1>(w[q].y);
-            acc[1][0] += b0v * xa0 + b1v * xb0;
-            acc[1][1] += b0v * xa1 + b1v * xb1;
-          }
-          {
-            const double b0v = quad_bcast<2>(w[q].x), b1v = quad_bcast<2>(w[q].y);
-            acc[2][0] += b0v * xa0 + b1v * xb0;
-            acc[2][1] += b0v * xa1 + b1v * xb1;
-          }
-          {
-            const double b0v = quad_bcast<3>(w[q].x), b1v = quad_bcast<3>(w[q].y);
-            acc[3][0] += b0v * xa0 + b1v * xb0;
-            acc[3][1] += b0v * xa1 + b1v * xb1;
-          }
-        }
-      }
-    }
-    // the two column pairs of the pose meet; lane c2 then owns output columns 2 c2 and 2 c2 + 1 of its two rows
-    double tot[2][2];
-#pragma unroll
-    for (int a = 0; a < DH; ++a)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const double other = __shfl_xor(acc[a][h], 4, GW);
-        const double sum = c2 == 0 ? acc[a][h] + other : other + acc[a][h];  // same order in both lanes
-        if ((a >> 1) == c2) tot[a & 1][h] = sum;
-      }
-    if (inr && have0) {
-#pragma unroll
-      for (int a2 = 0; a2 < 2; ++a2)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          if (h == 1 && !have1) continue;
-          const size_t o = ((size_t)pose * DH + 2 * c2 + a2) * r + r0 + h;
-          double y = tot[a2][h];
-          if (DOTS) {
-            const double x = X[o];
-            d0 += y * x;
-            if (G) d1 += x * G[o];
-          }
-          if (G) y += G[o];
-          Y[o] = y;
-        }
-    }
-  }
-  if (DOTS) {
-    const double a = f_block_sum(d0, s_red);
-    const double b = f_block_sum(d1, s_red);
-    if (threadIdx.x == 0) {
-      partials[2 * blockIdx.x] = a;
-      partials[2 * blockIdx.x + 1] = b;
-    }
-  }
-}
+// (Measured and dropped, round 3: a third form with HALF the load instructions -- lanes as (column pair, row pair) of a
+// pose, two 16-byte gathers and one 16-byte block load per lane and block instead of six loads -- was slower everywhere,
+// also at even r where every gather is 16-byte aligned: r = 5 28.6 / 36.7 us warm / cold against 24.6 / 33.1.  Round 4:
+// a locality ordering of the poses (sub-cubes of the lattice, 4x4x2 .. 2x2x8, instead of the trajectory order) changed
+// nothing: 24.0-24.3 / 32.8-33.3 against 24.0 / 32.6, tools/qapply_order.py.  The Q-apply is bound by the dependent
+// chain (row pointer -> column indices -> gather) at the head of its ~3000 short-lived workgroups.)
 
 int group_grid(int n) {
   long g = ((long)n + kPosesPerBlock - 1) / kPosesPerBlock;
@@ -1996,16 +1763,8 @@ int eval_split_doubles() { return kMaxAgents * kEvalSplit; }
 // one chunk of 32 poses per workgroup up to kBsrMaxGrid workgroups (the Q-apply partial buffer holds that many
 // slots): at 100k poses more resident workgroups mean more gathers in flight (34.9 us at 1024, 30.1 us at 2048)
 int spmm_bsr_grid(int nbrows) {
-  // one resident round: 8 workgroups of 256 threads per CU on 256 CUs (DCORA_BSR_GRID overrides, for measurements)
-  static const int cap = [] {
-    const char *e = std::getenv("DCORA_BSR_GRID");
-    const int v = e ? atoi(e) : kBsrMaxGrid;
-    return std::max(1, std::min(v, kBsrMaxGrid));
-  }();
-  static const int per = [] {
-    const char *e = std::getenv("DCORA_BSR_POSES");
-    return e ? std::max(1, atoi(e)) : kPosesPerBlock;
-  }();
+  // one resident round: 8 workgroups of 256 threads per CU on 256 CUs
+  const int cap = kBsrMaxGrid, per = kPosesPerBlock;
   long g = ((long)nbrows + per - 1) / per;
   if (g < 1) g = 1;
   if (g > cap) g = cap;
@@ -2014,43 +1773,14 @@ int spmm_bsr_grid(int nbrows) {
 void launch_spmm_bsr(hipStream_t st, int r, int d, const BsrDev &A, Buf2 X, int selX, const double *G, Buf2 Y,
                      int selY, double *partials, Gate g) {
   const int grid = spmm_bsr_grid(A.nbrows);
-  // DCORA_BSR_KERNEL=v1: the LDS-staged form, v3: 16-byte gathers (A/B measurements, tests); default: k_spmm_bsr2
-  static const int form = [] {
-    const char *e = std::getenv("DCORA_BSR_KERNEL");
-    return !e ? 2 : std::strcmp(e, "v1") == 0 ? 1 : std::strcmp(e, "v3") == 0 ? 3 : 2;
-  }();
-  const bool v1 = form == 1;
-  if (form == 3 && d == 3 && r >= 2 && r <= 8) {
-    if (partials)
-      hipLaunchKernelGGL((k_spmm_bsr3<true>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials, g);
-    else
-      hipLaunchKernelGGL((k_spmm_bsr3<false>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials, g);
-    return;
-  }
-  if (!v1) {
-    if (d == 3 && partials)
-      hipLaunchKernelGGL((k_spmm_bsr2<3, true>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials, g);
-    else if (d == 3)
-      hipLaunchKernelGGL((k_spmm_bsr2<3, false>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials, g);
-    else if (partials)
-      hipLaunchKernelGGL((k_spmm_bsr2<2, true>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials, g);
-    else
-      hipLaunchKernelGGL((k_spmm_bsr2<2, false>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials, g);
-    return;
-  }
-  if (d == 3) {
-    if (partials)
-      hipLaunchKernelGGL((k_spmm_bsr<3, true>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials, g);
-    else
-      hipLaunchKernelGGL((k_spmm_bsr<3, false>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials,
-                         g);
-  } else {
-    if (partials)
-      hipLaunchKernelGGL((k_spmm_bsr<2, true>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials, g);
-    else
-      hipLaunchKernelGGL((k_spmm_bsr<2, false>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials,
-                         g);
-  }
+  if (d == 3 && partials)
+    hipLaunchKernelGGL((k_spmm_bsr2<3, true>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials, g);
+  else if (d == 3)
+    hipLaunchKernelGGL((k_spmm_bsr2<3, false>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials, g);
+  else if (partials)
+    hipLaunchKernelGGL((k_spmm_bsr2<2, true>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials, g);
+  else
+    hipLaunchKernelGGL((k_spmm_bsr2<2, false>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials, g);
 }
 
 // the 8-lanes-per-pose kernels (rgrad / retract / Nesterov / BSR Q-apply) walk the poses with a capped grid: any n
@@ -2065,8 +1795,7 @@ int fused_pose_blocks(const ManiDesc &m) {
 }
 int fused_nsplit(const ManiDesc &m) {
   const int njc = (m.k + kJChunk - 1) / kJChunk;
-  static const int aim = std::getenv("DCORA_PRECOND_BLOCKS") ? atoi(std::getenv("DCORA_PRECOND_BLOCKS")) : 512;
-  static const int cap = std::getenv("DCORA_PRECOND_NSPLIT_MAX") ? atoi(std::getenv("DCORA_PRECOND_NSPLIT_MAX")) : 32;
+  const int aim = 512, cap = 32;
   int ns = (aim + njc - 1) / njc;  // aim for ~512 blocks of 4 waves
   if (ns < 1) ns = 1;
   if (ns > cap) ns = cap;
@@ -2169,11 +1898,17 @@ static int fused_pc_dispatch(hipStream_t st, const ManiDesc &m, int ldm, const d
 #define DCORA_PC(D_, PB_, R_, MULTI_)                                                                                \
   return pc_launch<D_, PB_, R_, MULTI_>(st, m, ldm, Minv, grad, X, delta, Hd, eta, Heta, res_old, res_new, z, p1, np1, \
                                         p3, ctl, hf, seq, iter, first, prepare_only)
-#define DCORA_PC_R(D_, PB_, MULTI_)             \
+#define DCORA_PC_FIXED_R(D_, PB_, MULTI_)      \
   do {                                          \
+    if (D_ == 3 && m.r == 3) DCORA_PC(D_, PB_, 3, MULTI_); \
+    if (D_ == 3 && m.r == 4) DCORA_PC(D_, PB_, 4, MULTI_); \
     if (D_ == 3 && m.r == 5) DCORA_PC(D_, PB_, 5, MULTI_); \
     if (D_ == 3 && m.r == 6) DCORA_PC(D_, PB_, 6, MULTI_); \
     if (D_ == 3 && m.r == 7) DCORA_PC(D_, PB_, 7, MULTI_); \
+  } while (0)
+#define DCORA_PC_R(D_, PB_, MULTI_)             \
+  do {                                          \
+    DCORA_PC_FIXED_R(D_, PB_, MULTI_);          \
     DCORA_PC(D_, PB_, 0, MULTI_);               \
   } while (0)
   const int pb = fused_pc_pb(m);
@@ -2181,12 +1916,16 @@ static int fused_pc_dispatch(hipStream_t st, const ManiDesc &m, int ldm, const d
   if (m.d == 3) {
     if (pb == 2 && !multi) DCORA_PC_R(3, 2, false);
     if (pb == 2) DCORA_PC_R(3, 2, true);
-    DCORA_PC_R(3, 4, true);
+    // four poses per thread with r only known at run time does not fit the register file (208 B/lane of scratch when
+    // it was instantiated): r > 7 takes the three-launch form, which fused_pc_preferred() chooses there anyway
+    DCORA_PC_FIXED_R(3, 4, true);
+    return -1;
   }
   if (pb == 2 && !multi) DCORA_PC(2, 2, 0, false);
   if (pb == 2) DCORA_PC(2, 2, 0, true);
   DCORA_PC(2, 4, 0, true);
 #undef DCORA_PC_R
+#undef DCORA_PC_FIXED_R
 #undef DCORA_PC
 }
 int launch_fused_pc(hipStream_t st, const ManiDesc &m, int ldm, const double *Minv, Buf2 grad, Buf2 X,

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "device_problem.h"
+#include "env.h"
 #include "host_partinv_int.h"
 
 namespace dcora {
@@ -229,7 +230,7 @@ __device__ __forceinline__ void mt_load_sub(const __attribute__((address_space(4
 template <int NC, int U>
 __global__ __launch_bounds__(kMtBlock) void k_sp_mtile(const MWave *__restrict__ recs, const double *__restrict__ vals,
                                                         const int *__restrict__ idxs, double *__restrict__ y, int r,
-                                                        Gate g, int exp) {
+                                                        Gate g) {
   __shared__ double s_part[kMtWaves][NC * 2][64];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   typedef const __attribute__((address_space(4))) int *ConstInts;
@@ -241,10 +242,6 @@ __global__ __launch_bounds__(kMtBlock) void k_sp_mtile(const MWave *__restrict__
   const int jj = 2 * li;
   // the old values this tile adds to (result roles: row kq, block 0, columns 8 c + 2 li + h); first wave of the tile only
   const bool writer = t_nrows > 0 && t_first == wave && blk == 0 && kq < t_nrows;
-  if (exp == 1) {
-    if (writer && jj < r) y[(size_t)(t_out + kq) * r + jj] = 0.0;
-    return;
-  }
   double cv[NC][2];
 #pragma unroll
   for (int c = 0; c < NC; ++c)
@@ -263,7 +260,7 @@ __global__ __launch_bounds__(kMtBlock) void k_sp_mtile(const MWave *__restrict__
     mt_load_sub(rp + 8, sa);
     mt_load_sub(rp + 20, sb);
     const int next = rp[6];
-    if (exp != 2) {
+    {
       if (t_kind == 0)
         mt_record<0, NC, U>(mt_run<0>(sa, vals, idxs, kq, li, t_nrows), mt_run<0>(sb, vals, idxs, kq, li, t_nrows), kq, blk,
                             jj, r, y, d);
@@ -307,23 +304,11 @@ bool launch_mtile(hipStream_t st, int r, const SpLevel &lv, const MWave *recs, c
                   double *y, Gate g) {
   if (r < 1 || r > 16) return false;
   if (lv.ntasks == 0) return true;
-  static const int unroll = [] {
-    const char *e = std::getenv("DCORA_SP_UNROLL");
-    return e ? atoi(e) : 8;
-  }();
-  static const int exp = [] {
-    const char *e = std::getenv("DCORA_SP_EXP");
-    return e ? atoi(e) : 0;
-  }();
   const MWave *rp = recs + lv.task0;
-  if (r <= 8) {
-    if (unroll == 4)
-      hipLaunchKernelGGL((k_sp_mtile<1, 4>), dim3(lv.ntasks), dim3(kMtBlock), 0, st, rp, vals, idxs, y, r, g, exp);
-    else
-      hipLaunchKernelGGL((k_sp_mtile<1, 8>), dim3(lv.ntasks), dim3(kMtBlock), 0, st, rp, vals, idxs, y, r, g, exp);
-  } else {
-    hipLaunchKernelGGL((k_sp_mtile<2, 4>), dim3(lv.ntasks), dim3(kMtBlock), 0, st, rp, vals, idxs, y, r, g, exp);
-  }
+  if (r <= 8)
+    hipLaunchKernelGGL((k_sp_mtile<1, 8>), dim3(lv.ntasks), dim3(kMtBlock), 0, st, rp, vals, idxs, y, r, g);
+  else
+    hipLaunchKernelGGL((k_sp_mtile<2, 4>), dim3(lv.ntasks), dim3(kMtBlock), 0, st, rp, vals, idxs, y, r, g);
   return true;
 }
 
@@ -383,11 +368,7 @@ __global__ __launch_bounds__(256) void k_fill_weights(long long nf, const DFill 
 }  // namespace
 
 bool DeviceWeightSink::wants_device_sources() const {
-  static const bool host_fill = [] {
-    const char *e = std::getenv("DCORA_SP_FILL");
-    return e && std::strcmp(e, "host") == 0;
-  }();
-  return !host_fill;
+  return !env::fill_on_host();
 }
 
 bool DeviceWeightSink::fill_on_device(const std::vector<partinv::Fill> &fills, long long total,

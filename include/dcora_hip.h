@@ -417,6 +417,10 @@ int dcora_exchange_host_selftest(const char *job_name, int rank, int world_size,
 /* test hook: leaves under the job's name what a crashed job of the same shape would (an initialised segment whose
  * creator is gone); a job started afterwards under that name must not attach to it */
 int dcora_debug_exchange_leave_stale(const char *job_name, int world_size, int num_agents);
+/* test hook: the link check of exchanges created afterwards in this process reports its first `rounds` rounds as failed
+ * on the last rank (every rank of the job calls it with the same value), so the step-down ladder and
+ * DCORA_ERR_EXCHANGE_LINK can be exercised on healthy hardware */
+int dcora_debug_exchange_probe_fault(int rounds);
 
 /* ------------------------------------------------------------------------- *
  * RBCD session for multi-robot range-aided SLAM (replaces the Agents on a RangeAidedSLAMGraph and the loop body of

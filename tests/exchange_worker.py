@@ -23,6 +23,11 @@ def main():
     # one GPU per rank where the box has them (peer access + cross-device IPC over xGMI); all ranks on device 0 otherwise
     device = rank % max(da.device_count(), 1)
     s = da.RbcdSession(ds, num_robots=R, r=r, acceleration=accel, rank=rank, world_size=world, device=device)
+    if os.environ.get("DCORA_TEST_PROBE_FAULT"):
+        # the library's test hook (not an environment switch of the library): the last rank reports its first n rounds
+        # of the link check as failed
+        from dcora_amd import capi
+        assert capi.lib().dcora_debug_exchange_probe_fault(int(os.environ["DCORA_TEST_PROBE_FAULT"])) == 0
     if os.environ.get("DCORA_TEST_EXPECT_LINK_ERROR"):
         # the link check is made to fail on every transport: every rank gets the distinct error code, quickly
         import time

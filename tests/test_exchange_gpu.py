@@ -253,7 +253,7 @@ def test_link_check_steps_down_together(tmp_path, faults, wait):
     X0 = common.random_point(r, ds.d, ds.n, 11, lambda r_, d_, n_, M: da.manifold_project(r_, d_, n_, M))
     cost, gn, sel, X = single(da, ds, R, r, iters, "greedy", X0)
     res = run_ranks(str(tmp_path), world, name, R, r, iters, "greedy", X0, None, wait,
-                    extra_env={"DCORA_EXCHANGE_PROBE_FAULT": str(faults)})
+                    extra_env={"DCORA_TEST_PROBE_FAULT": str(faults)})
     for k, o in enumerate(res):
         assert int(o["link_rounds"]) == faults + 1, (k, int(o["link_rounds"]))
         started_on_device = str(wait) == "device" or (wait is None and da.device_count() >= world)
@@ -274,6 +274,6 @@ def test_link_check_that_cannot_pass_fails_fast_on_every_rank(tmp_path):
     ds = common.product_dataset(name)
     X0 = common.random_point(r, ds.d, ds.n, 11, lambda r_, d_, n_, M: da.manifold_project(r_, d_, n_, M))
     res = run_ranks(str(tmp_path), world, name, R, r, 1, "greedy", X0, None, None,
-                    extra_env={"DCORA_EXCHANGE_PROBE_FAULT": "9", "DCORA_TEST_EXPECT_LINK_ERROR": "1"})
+                    extra_env={"DCORA_TEST_PROBE_FAULT": "9", "DCORA_TEST_EXPECT_LINK_ERROR": "1"})
     for o in res:
         assert "link check" in str(o["error"]) and float(o["seconds"]) < 60

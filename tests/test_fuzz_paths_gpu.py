@@ -1,5 +1,5 @@
 """Differential test of the solver paths on random problems (a short form of tools/fuzz_paths.py): the same lattice solved
-by the default kernels, by the generic path (DCORA_SOLVER_V1, read when a problem is created) and with the sparse
+by the default kernels, by the generic path (DCORA_SOLVER=generic, read when a problem is created) and with the sparse
 preconditioner forced must give the same iteration counts and iterates, and the solver's own cost bookkeeping must be
 the cost of its iterates (scipy)."""
 import os
@@ -9,7 +9,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-SWITCHES = ("DCORA_SOLVER_V1", "DCORA_PRECOND")
+SWITCHES = ("DCORA_SOLVER", "DCORA_PRECOND")
 
 
 @pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16])
@@ -30,8 +30,8 @@ def test_paths_agree_on_a_random_lattice(built, seed):
     saved = {s: os.environ.get(s) for s in SWITCHES}
     outs = {}
     try:
-        for tag, env in (("default", {}), ("generic", {"DCORA_SOLVER_V1": "1"}), ("sparse", {"DCORA_PRECOND": "sparse"}),
-                         ("generic+sparse", {"DCORA_SOLVER_V1": "1", "DCORA_PRECOND": "sparse"})):
+        for tag, env in (("default", {}), ("generic", {"DCORA_SOLVER": "generic"}), ("sparse", {"DCORA_PRECOND": "sparse"}),
+                         ("generic+sparse", {"DCORA_SOLVER": "generic", "DCORA_PRECOND": "sparse"})):
             for s in SWITCHES:
                 os.environ.pop(s, None)
             os.environ.update(env)

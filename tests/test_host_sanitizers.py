@@ -13,7 +13,7 @@ import scipy.sparse as sp
 import common
 
 ROOT = os.path.dirname(common.HERE)
-SRC = [os.path.join(ROOT, "dcora_amd", "csrc", f) for f in ("host_cholsym.cpp", "host_sparse.cpp", "host_partinv.cpp", "host_partinv3.cpp")]
+SRC = [os.path.join(ROOT, "dcora_amd", "csrc", f) for f in ("host_cholsym.cpp", "host_sparse.cpp", "host_partinv.cpp", "host_partinv3.cpp", "env.cpp")]
 
 
 def _dump(A, path):

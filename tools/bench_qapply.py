@@ -16,4 +16,4 @@ for P in Ps:
     P.f(X)
 ms, nbytes = Ps[0].time_qapply(reps=100)
 msc = da.time_qapply_rotating(Ps, reps=96)
-print("grid %s r=%d: warm %.2f us %.1f %%   cold %.2f us %.1f %%" % (os.environ.get("DCORA_BSR_GRID", "default"), r, ms * 1e3, nbytes / ms / 1e6 / 80, msc * 1e3, nbytes / msc / 1e6 / 80))
+print("r=%d: warm %.2f us %.1f %%   cold %.2f us %.1f %%" % (r, ms * 1e3, nbytes / ms / 1e6 / 80, msc * 1e3, nbytes / msc / 1e6 / 80))

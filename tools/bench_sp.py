@@ -1,5 +1,5 @@
 """The sparse replay of one 100k-lattice agent (k = 50 000) and of sphere2500 / tiers as single problems: us per
-application, launches and stored bytes under the schedule DCORA_SP_SCHEDULE selects (default: panels).
+application, launches and stored bytes.
   python tools/bench_sp.py [lattice] [sphere] [tiers]"""
 import json, os, sys
 import numpy as np
@@ -10,7 +10,7 @@ import dcora_amd as da
 from dcora_amd import synth
 os.environ["DCORA_PRECOND"] = "sparse"
 what = sys.argv[1:] or ["lattice"]
-tag = {"schedule": os.environ.get("DCORA_SP_SCHEDULE", "v3"), "merge": os.environ.get("DCORA_SP_MERGE", "1")}
+tag = {}
 if "lattice" in what:
     lat = synth.lattice_se3()
     nb, ids, vals = bench.agent_block(lat, 8, 0)

@@ -1,5 +1,5 @@
 """differential fuzzing of the solver paths: the same random problem solved by the default kernels and by the generic
-path (DCORA_SOLVER_V1=1), with the dense and with the sparse preconditioner -- iteration counts, cost and iterate must
+path (DCORA_SOLVER=generic), with the dense and with the sparse preconditioner -- iteration counts, cost and iterate must
 agree; cost / gradient norm are also checked against scipy"""
 import os
 import sys
@@ -27,9 +27,9 @@ for case in range(ncases):
     withG = bool(np.any(G))
     f = lambda Y: 0.5 * float(np.sum((A @ Y.T).T * Y)) + float(np.sum(Y * G))
     outs = {}
-    for tag, env in (("default", {}), ("generic", {"DCORA_SOLVER_V1": "1"}), ("sparse", {"DCORA_PRECOND": "sparse"}),
-                     ("generic+sparse", {"DCORA_SOLVER_V1": "1", "DCORA_PRECOND": "sparse"})):
-        for kk in ("DCORA_SOLVER_V1", "DCORA_PRECOND"):
+    for tag, env in (("default", {}), ("generic", {"DCORA_SOLVER": "generic"}), ("sparse", {"DCORA_PRECOND": "sparse"}),
+                     ("generic+sparse", {"DCORA_SOLVER": "generic", "DCORA_PRECOND": "sparse"})):
+        for kk in ("DCORA_SOLVER", "DCORA_PRECOND"):
             os.environ.pop(kk, None)
         os.environ.update(env)
         P = da.QuadraticProblem(r, 3, n, Q, G=G if withG else None)
@@ -43,7 +43,7 @@ for case in range(ncases):
         if e0 > 1e-10 or e1 > 1e-10:
             bad += 1
             print("BOOKKEEPING", dims, r, tag, e0, e1, flush=True)
-    for kk in ("DCORA_SOLVER_V1", "DCORA_PRECOND"):
+    for kk in ("DCORA_SOLVER", "DCORA_PRECOND"):
         os.environ.pop(kk, None)
     Xr, rr = outs["default"]
     line = "case %2d dims %s n %4d r %d G %s:" % (case, dims, n, r, withG)
