@@ -104,6 +104,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config5", action="store_true", help="skip the 100k-pose side measurement")
     ap.add_argument("--no-config4", action="store_true", help="skip the tiers.pyfg side measurement")
+    ap.add_argument("--no-coloured", action="store_true",
+                    help="skip the coloured simultaneous-update measurements (agents solving on concurrent host threads): "
+                         "rocprofv3 --kernel-trace of the WHOLE default run dies in its own buffers there (DESIGN.md 5)")
     ap.add_argument("--no-config3", action="store_true", help="skip the torus3D 8-agent side measurement (N > 1)")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the timed loop (for a kernel trace of exactly that loop): no side measurements")
@@ -191,6 +194,7 @@ class RankDriver:
         self.ex = da.Exchange(self.s, job)
         self.setup_s = time.perf_counter() - t0
         self.transport = self.ex.info()["transport"]
+        self.link = self.ex.link_report()  # the start-up link check of dcora_exchange_create
         self._mark = self.ex.info()
 
     def set_X(self, X):
@@ -213,7 +217,7 @@ class RankDriver:
         self._mark = now
         it = max(1, iterations)
         return {"transport": now["transport"], "halo_finegrained": now["halo_finegrained"], "wait": now["wait"],
-                "ranks_this_rank_stores_to": now["peers"],
+                "ranks_this_rank_stores_to": now["peers"], "link_check": self.link,
                 "post_us_per_iteration": 1e6 * (now["post_s"] - was["post_s"]) / it,
                 "wait_us_per_iteration": 1e6 * (now["wait_s"] - was["wait_s"]) / it,
                 "evaluation_allgather_wait_us_per_iteration": 1e6 * (now["eval_wait_s"] - was["eval_wait_s"]) / it,
@@ -417,10 +421,15 @@ class CollectiveDriver:
         return float(t.item()), out
 
 
+SKIP_COLOURED = False
+
+
 def coloured_sweeps(drv, X0, sweeps, warm=2):
     """Block updates per second when the agents of one colour update at the same time (non-accelerated agents, as
     the reference's asynchronous mode; fixed colour order; one evaluation per sweep).  A separate mode, never
     `value`: an iteration here is a tick of several block updates."""
+    if SKIP_COLOURED:
+        raise RuntimeError("skipped (--no-coloured)")
     s = drv.s
     col, nc = s.colours()
     sets = [np.flatnonzero(col == c).astype(np.int32) for c in range(nc)]
@@ -1054,6 +1063,9 @@ def distributed_to_tolerance(da, ds, X0, r, f_star2, R=8, budget_s=DIST_BUDGET_S
     out["rbcd_pp"] = {"reached": bool(gn is not None and gn < 0.1), "iterations": iters, "seconds": dt, "gradnorm": gn,
                       "cost_2f": c2, "excess_over_optimum": None if c2 is None else c2 / f_star2 - 1.0}
     s.close()
+    if SKIP_COLOURED:
+        out["coloured_ticks"] = {"skipped": "--no-coloured"}
+        return out
     s = da.RbcdSession(ds, num_robots=R, r=r, acceleration=False)
     s.set_X(X0)
     col, nc = s.colours()
@@ -1323,6 +1335,8 @@ def cpu_r_threads(args, dso, X0, orc, tr1):
 
 def main():
     args = parse()
+    global SKIP_COLOURED
+    SKIP_COLOURED = bool(args.no_coloured)
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         # no launcher: start one rank per GPU as a child process, before anything here has touched the GPU
@@ -1364,7 +1378,7 @@ def main():
         dist.destroy_process_group()
     else:
         s, dt, c2, gn, sustained, setup_s = run_single(args, da, torch, ds, X0)
-        coloured = None if args.headline_only else coloured_sweeps(SingleDriver(s), X0, sweeps=40)
+        coloured = None if (args.headline_only or SKIP_COLOURED) else coloured_sweeps(SingleDriver(s), X0, sweeps=40)
     if rank != 0:
         return
     ms = 1e3 * dt / args.steps
@@ -1455,7 +1469,7 @@ def main():
             except Exception as e:
                 line["config5_lattice100k"] = {"error": str(e)}
             try:
-                line["strong_scaling"] = strong_scaling_single(da)
+                line["strong_scaling"] = None if SKIP_COLOURED else strong_scaling_single(da)
             except Exception as e:
                 line["strong_scaling"] = {"error": str(e)}
         if not args.no_config5:

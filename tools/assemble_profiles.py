@@ -1,11 +1,13 @@
-"""copies what tools/collect_profiles.sh left in gpurun_out/r03 into profiles/r03_* and recomputes r03_pmc_traffic.json"""
-import csv, json, re, shutil
-o = 'gpurun_out/r03'
-shutil.copy(o + '/headline/t_kernel_stats.csv', 'profiles/r03_kernel_stats_headline_loop.csv')
-shutil.copy(o + '/default/t_kernel_stats.csv', 'profiles/r03_kernel_stats_bench_default.csv')
-shutil.copy(o + '/pmc_FETCH_SIZE_summary.csv', 'profiles/r03_pmc_fetch_size_summary.csv')
-shutil.copy(o + '/pmc_WRITE_SIZE_summary.csv', 'profiles/r03_pmc_write_size_summary.csv')
-shutil.copy(o + '/bench.json', 'profiles/r03_bench.json')
+"""copies what tools/collect_profiles.sh left in gpurun_out/<tag> into profiles/<tag>_* and recomputes
+<tag>_pmc_traffic.json: python tools/assemble_profiles.py [tag]"""
+import csv, json, os, re, shutil, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r04'
+o = 'gpurun_out/' + tag
+shutil.copy(o + '/headline/t_kernel_stats.csv', 'profiles/' + tag + '_kernel_stats_headline_loop.csv')
+shutil.copy(o + '/default/t_kernel_stats.csv', 'profiles/' + tag + '_kernel_stats_bench_default.csv')
+shutil.copy(o + '/pmc_FETCH_SIZE_summary.csv', 'profiles/' + tag + '_pmc_fetch_size_summary.csv')
+shutil.copy(o + '/pmc_WRITE_SIZE_summary.csv', 'profiles/' + tag + '_pmc_write_size_summary.csv')
+shutil.copy(o + '/bench.json', 'profiles/' + tag + '_bench.json')
 rows = lambda f: list(csv.DictReader(open(f)))
 F, W = rows(o + '/pmc_FETCH_SIZE_summary.csv'), rows(o + '/pmc_WRITE_SIZE_summary.csv')
 pick = lambda R, pat, col: [(r['kernel'], int(r['grid_size']), int(r['launches']), float(r[col])) for r in R if re.search(pat, r['kernel'])]
@@ -19,16 +21,21 @@ out['k_fused_pc_counters'] = {'FETCH_SIZE_KB_median': pf[3], 'WRITE_SIZE_KB_medi
 sf, sw = pick(F, r'^k_spmm_bsr2?<', 'FETCH_SIZE_median'), pick(W, r'^k_spmm_bsr2?<', 'WRITE_SIZE_median')
 out['k_spmm_bsr_lattice100k_counters'] = {'kernels': [x[0] for x in sf], 'FETCH_SIZE_KB': [x[3] for x in sf], 'WRITE_SIZE_KB': [x[3] for x in sw], 'launches': [x[2] for x in sf],
     'note': '8-B gathers and 16-B block-row loads mixed: (FETCH+WRITE)*1024 and (2*FETCH+WRITE)*1024 bracket the traffic; algorithmic (CSR convention) 124.1 MB'}
-lf = [x for x in pick(F, r'^k_sp_multi<5>', 'FETCH_SIZE_median') if x[2] == 53]
-lw = [x for x in pick(W, r'^k_sp_multi<5>', 'WRITE_SIZE_median') if x[2] == 53]
+# the replay of the lattice agent inside bench.roofline: the grids of k_sp_mtile<1, 8> launched most often
+allf = pick(F, r'^k_sp_mtile<1, 8>', 'FETCH_SIZE_median')
+ncalls = max(x[2] for x in allf) if allf else 0
+lf = [x for x in allf if x[2] == ncalls]
+lw = [x for x in pick(W, r'^k_sp_mtile<1, 8>', 'WRITE_SIZE_median') if x[2] == ncalls]
 fk, wk = sum(x[3] for x in lf), sum(x[3] for x in lw)
-out['k_sp_multi_lattice100k_agent'] = {'launches_per_application_with_53_calls_each': len(lf),
+out['k_sp_mtile_lattice100k_agent'] = {'distinct_grids_with_%d_calls_each' % ncalls: len(lf),
     'FETCH_SIZE_KB_per_launch': [x[3] for x in lf], 'WRITE_SIZE_KB_per_launch': [x[3] for x in lw],
     'FETCH_SIZE_KB_per_application': fk, 'WRITE_SIZE_KB_per_application': wk,
     'bytes_per_application_fetch_plus_write': (fk + wk) * 1024, 'bytes_per_application_2fetch_plus_write': (2 * fk + wk) * 1024,
     'algorithmic_bytes_per_application': b['roofline_qapply']['precond_sparse_lattice100k_agent']['bytes_per_application'],
-    'note': 'k_sp_multi (merged-level schedule, round 3) mixes 16-B weight loads and 8-B vector loads: (FETCH+WRITE)*1024 and (2*FETCH+WRITE)*1024 bracket the traffic; 9 level launches per application'}
-json.dump(out, open('profiles/r03_pmc_traffic.json', 'w'), indent=1)
+    'note': 'k_sp_mtile (4-row tiles on the fp64 matrix pipe, round 4): 8-B weight loads and 16-B vector pair loads: (FETCH+WRITE)*1024 and (2*FETCH+WRITE)*1024 bracket the traffic; 9 level launches per application; launches of equal grid size are merged by the summary, so fewer than 9 rows may appear'}
+json.dump(out, open('profiles/' + tag + '_pmc_traffic.json', 'w'), indent=1)
+if os.path.exists(o + '/bench_2ranks_on_one_gpu.json') and os.path.getsize(o + '/bench_2ranks_on_one_gpu.json') > 100:
+    shutil.copy(o + '/bench_2ranks_on_one_gpu.json', 'profiles/' + tag + '_bench_2ranks_on_one_gpu_gloo.json')
 q = b['roofline_qapply']
 print('value', b['value'], 'sustained', b['sustained']['value'], 'c5', b['config5_lattice100k']['value'], 'tiers', b['config4_tiers']['tcg_iterations_per_s'])
 print('qapply warm/cold', q['qapply_lattice100k']['avg_launch_us'], q['qapply_lattice100k_cold']['avg_launch_us'], q['qapply_lattice100k']['kernel'])

@@ -1,11 +1,13 @@
 #!/bin/bash
-# collects the round's rocprofv3 summaries into gpurun_out/r03 (run on the GPU box; copy what is quoted into profiles/)
+# collects the round's rocprofv3 summaries into gpurun_out/<tag> (run on the GPU box; tools/assemble_profiles.py <tag>
+# copies what is quoted into profiles/): collect_profiles.sh [tag]
 export TMPDIR=/tmp
-o=gpurun_out/r03
+tag=${1:-r04}
+o=gpurun_out/$tag
 rm -rf $o; mkdir -p $o
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/headline -o t -- python3 bench.py --headline-only > $o/headline.log 2>&1
 python3 tools/kstats.py $o/headline 20 > $o/headline_top.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d $o/default -o t -- python3 bench.py --no-cpu-baseline > $o/default.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/default -o t -- python3 bench.py --no-cpu-baseline --no-coloured > $o/default.log 2>&1
 python3 tools/kstats.py $o/default 30 > $o/default_top.txt
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $o/pmc_fetch -o t -- python3 tools/pmc_run.py > $o/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $o/pmc_write -o t -- python3 tools/pmc_run.py > $o/pmc_write.log 2>&1
@@ -15,6 +17,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
   python3 tools/pmc_summarize.py $f $c > $o/pmc_${c}_summary.csv
 done
 python3 bench.py > $o/bench.json 2> $o/bench.err
+echo "bench done" >&2
+# the N > 1 path rehearsed on ONE GPU (2 ranks over gloo, both on device 0): not a scaling figure
+DCORA_DIST_BACKEND=gloo python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 > $o/bench_2ranks_on_one_gpu.json 2> $o/bench_2ranks.err
 # keep the merged output small
 find $o -name "*kernel_trace.csv" -delete; find $o -name "*counter_collection.csv" -delete
 ls -la $o
