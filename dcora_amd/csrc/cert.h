@@ -32,6 +32,9 @@ class DeviceLanczos {
   std::function<int(const double *v, double *w)> op;
   std::function<int(double *vals, int count)> allreduce;
   int n_global = 0, lo = 0;
+  // rows of this rank that are NOT one contiguous range of the whole problem (range-aided sessions: an agent's
+  // variables are scattered over the global ordering): global index of every local row; empty = [lo, lo + n)
+  std::vector<int> row_map;
   DevBuf<double> V, Vtmp, w, part, small;
   ~DeviceLanczos();
   int init(const HostCsr &S, int device_);

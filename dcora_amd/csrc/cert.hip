@@ -129,11 +129,20 @@ int DeviceLanczos::largest_magnitude(double shift, int ncv, int maxit, double to
   const int keep = std::max(1, std::min(m - 1, m / 2));
   std::vector<double> H((size_t)m * m, 0.0), Z, th, host_v((size_t)std::max(n, 1)), hbuf(64);
   // a vector of the whole problem from the seeded stream (or x0, given for the whole problem), this rank's slice of it
+  std::vector<int> local_of;  // row_map inverted (scattered rows only)
+  if (rows && !row_map.empty()) {
+    local_of.assign((size_t)ng, -1);
+    for (int i = 0; i < n; ++i) local_of[(size_t)row_map[(size_t)i]] = i;
+  }
   auto whole_vector = [&](uint64_t s, const double *given, double *norm) {
     double nn = 0;
     for (int i = 0; i < ng; ++i) {
       const double x = given ? given[i] : (u01(s) - 0.5);
-      if (i >= lo && i < lo + n) host_v[(size_t)(i - lo)] = x;
+      if (!local_of.empty()) {
+        if (local_of[(size_t)i] >= 0) host_v[(size_t)local_of[(size_t)i]] = x;
+      } else if (i >= lo && i < lo + n) {
+        host_v[(size_t)(i - lo)] = x;
+      }
       nn += x * x;
     }
     *norm = std::sqrt(nn);

@@ -11,6 +11,7 @@
 #include "cert.h"
 #include "device_chol.h"
 #include "exchange.h"
+#include "ra_rbcd.h"
 
 namespace dcora {
 
@@ -19,21 +20,50 @@ namespace {
 using Clock = std::chrono::steady_clock;
 inline double since(Clock::time_point t0) { return std::chrono::duration<double>(Clock::now() - t0).count(); }
 
-// w += eta v - Lambda v on the poses of one agent: Lambda_i (d x d, column-major) acts on the d rotation columns of
-// pose i (ref constructDualCertificateMatrixPGO, src/DCORA_utils.cpp:1898-1931); r = 1 vectors, (d+1) entries per pose
-__global__ __launch_bounds__(256) void k_apply_lambda(int n, int d, const double *__restrict__ L, double eta,
+// w += eta v - Lambda v on the variables of one agent, r = 1 vectors in the agent's ordering: Lambda is block diagonal
+// -- a d x d block (column-major) on the d rotation columns of every pose, a scalar on every unit sphere, nothing on
+// translations and landmarks (ref constructDualCertificateMatrixPGO / ...RASLAM, src/DCORA_utils.cpp:1898-1982); L as
+// k_lambda leaves it: n blocks, then l scalars.  Pose layout: d + 1 entries per pose; range-aided layout: rotations,
+// unit spheres, translations, landmarks.
+__global__ __launch_bounds__(256) void k_apply_lambda(ManiDesc m, const double *__restrict__ L, double eta,
                                                       const double *__restrict__ v, double *__restrict__ w) {
-  const int dh = d + 1;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < (long)n * dh; e += (long)gridDim.x * 256) {
-    const int i = (int)(e / dh), c = (int)(e - (long)i * dh);
+  const int d = m.d;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < (long)m.k; e += (long)gridDim.x * 256) {
     double acc = eta * v[e];
-    if (c < d) {
+    if (m.se) {
+      const int dh = d + 1, i = (int)(e / dh), c = (int)(e - (long)i * dh);
+      if (c < d) {
+        const double *__restrict__ Li = L + (size_t)i * d * d;
+        for (int b = 0; b < d; ++b) acc -= Li[c + b * d] * v[(size_t)i * dh + b];
+      }
+    } else if (e < (long)d * m.n) {
+      const int i = (int)(e / d), c = (int)(e - (long)i * d);
       const double *__restrict__ Li = L + (size_t)i * d * d;
-      for (int b = 0; b < d; ++b) acc -= Li[c + b * d] * v[(size_t)i * dh + b];
+      for (int b = 0; b < d; ++b) acc -= Li[c + b * d] * v[(size_t)i * d + b];
+    } else if (e < (long)d * m.n + m.l) {
+      acc -= L[(size_t)m.n * d * d + (e - (long)d * m.n)] * v[e];
     }
     w[e] += acc;
   }
 }
+
+// whole[map[i]] = local[i]
+__global__ __launch_bounds__(256) void k_scatter_rows(int n, const int *__restrict__ map, const double *__restrict__ local,
+                                                      double *__restrict__ whole) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) whole[map[i]] = local[i];
+}
+
+// one hosted agent of either session kind, as the row-block operator sees it
+struct CertBlock {
+  int k = 0;                     // its unknowns
+  int loc0 = 0;                  // where they start in this rank's local vectors
+  int col0 = 0;                  // pose-graph session: its first column of the global ordering (contiguous)
+  const int *own_dev = nullptr;  // range-aided session: the global column of each of its columns
+  DeviceProblem *prob = nullptr;
+  CsrDev coupling;
+  const double *X = nullptr;     // r x k, its ordering
+  DevBuf<double> L, tmp;
+};
 
 }  // namespace
 
@@ -70,14 +100,18 @@ int Exchange::allreduce_sum(double *vals, int count) {
 
 int Exchange::certify(const HostCsr *Qglobal, double eta, int *certified, double *theta, double *lambda_min, double *v,
                       long long *matvecs, int *distributed) {
+  // the pose-graph and the range-aided session through one flow: what differs is where an agent's variables sit in the
+  // global ordering (a contiguous range / scattered: CertBlock) and the layout its Lambda blocks act on
   RbcdSession *pgo = dynamic_cast<RbcdSession *>(s_);
-  if (!pgo)
-    return usage("certify: the row-block certificate operator exists for pose-graph sessions (the range-aided certificate "
-                "is assembled centrally: dcora_cert_dual_matrix on the gathered X)",
-                DCORA_ERR_UNSUPPORTED);
-  RbcdSession &S = *pgo;
-  DCORA_HIP(hipSetDevice(S.opt.device));
-  const int R = S.R, r = S.r, d = S.d, dh = d + 1, ktot = dh * S.n;
+  RaRbcdSession *ras = dynamic_cast<RaRbcdSession *>(s_);
+  if (!pgo && !ras) return usage("certify: unknown session kind", DCORA_ERR_UNSUPPORTED);
+  const int device = s_->x_device();
+  hipStream_t st = s_->x_stream();
+  DCORA_HIP(hipSetDevice(device));
+  const int R = s_->x_num_agents(), r = s_->x_rank_r(), ktot = (int)s_->x_num_cols();
+  const dcora_dims dims = pgo ? dcora_dims{r, pgo->d, pgo->n, 0, 0} : dcora_dims{r, ras->d, ras->n, ras->l, ras->b};
+  const int chol_block = pgo ? pgo->d + 1 : 1;
+  double *mirror = s_->x_mirror();
   if (certified) *certified = 0;
   if (theta) *theta = 0;
   if (lambda_min) *lambda_min = 0;
@@ -100,13 +134,12 @@ int Exchange::certify(const HostCsr *Qglobal, double eta, int *certified, double
     if (!Qglobal) {
       verdict[1] = DCORA_ERR_BAD_ARG;
     } else {
-      dcora_dims dims{r, d, S.n, 0, 0};
       HostCsr Sh;
-      int c = device_dual_certificate(dims, Xh.data(), *Qglobal, S.opt.device, &Sh);
+      int c = device_dual_certificate(dims, Xh.data(), *Qglobal, device, &Sh);
       bool psd = false;
       if (!c) {
         M = csr_shift_diag(Sh, eta);
-        c = device_chol_is_pd(M, dh, S.opt.device, &psd);
+        c = device_chol_is_pd(M, chol_block, device, &psd);
       }
       verdict[0] = c ? 0 : (psd ? 1 : 2);
       verdict[1] = c;
@@ -120,53 +153,86 @@ int Exchange::certify(const HostCsr *Qglobal, double eta, int *certified, double
     return DCORA_OK;
   }
   // ---- minimum eigenpair of M = S + eta I by all ranks ----
-  int lo = -1, nloc = 0;
-  for (const AgentDev &a : S.agents)
-    if (a.hosted) {
+  std::vector<CertBlock> blocks;
+  int nloc = 0, lo = -1;
+  std::vector<int> row_map;  // global index of every local row (range-aided sessions)
+  if (pgo) {
+    for (AgentDev &a : pgo->agents) {
+      if (!a.hosted) continue;
+      CertBlock B;
+      B.k = (pgo->d + 1) * a.n;
+      B.loc0 = nloc;
+      B.col0 = a.col0;
+      B.prob = a.prob.get();
+      B.coupling = a.coupling.view();
+      B.X = pgo->Xg.p + (size_t)a.col0 * r;
       if (lo < 0) lo = a.col0;
-      nloc += dh * a.n;
+      nloc += B.k;
+      blocks.push_back(std::move(B));
     }
+  } else {
+    for (RaAgentDev &a : ras->agents) {
+      if (!a.hosted) continue;
+      CertBlock B;
+      B.k = a.k;
+      B.loc0 = nloc;
+      B.own_dev = a.own.p;
+      B.prob = a.prob.get();
+      B.coupling = a.coupling.view();
+      B.X = a.X.p;
+      row_map.insert(row_map.end(), a.own_host.begin(), a.own_host.end());
+      nloc += B.k;
+      blocks.push_back(std::move(B));
+    }
+  }
   if (lo < 0) lo = 0;
-  // Lambda blocks of the hosted agents: EG_b = X_b Q_bb + X C_b, Lambda_i = sym(X_i^T EG_i)
-  std::vector<DevBuf<double>> Lblk(S.agents.size()), tmpv(S.agents.size());
-  for (AgentDev &a : S.agents) {
-    if (!a.hosted) continue;
-    DeviceProblem &pb = *a.prob;
-    const double *Xb = S.Xg.p + (size_t)a.col0 * r;
-    launch_spmm(S.st, r, a.coupling.view(), buf1(S.Xg.p), 0, nullptr, buf1(pb.G.p), 0, nullptr, Gate{});
+  // Lambda blocks of the hosted agents: EG_b = X_b Q_bb + X C_b, Lambda = SymBlockDiag(X_b^T EG_b)
+  for (CertBlock &B : blocks) {
+    DeviceProblem &pb = *B.prob;
+    launch_spmm(st, r, B.coupling, buf1(mirror), 0, nullptr, buf1(pb.G.p), 0, nullptr, Gate{});
     pb.has_G = true;
-    pb.enqueue_egrad(Xb, pb.EG1.p, nullptr);
-    DCORA_HIP(Lblk[(size_t)a.id].alloc((size_t)a.n * d * d));
-    DCORA_HIP(tmpv[(size_t)a.id].alloc((size_t)dh * a.n));
-    launch_lambda_blocks(S.st, pb.m, Xb, pb.EG1.p, Lblk[(size_t)a.id].p);
+    pb.enqueue_egrad(B.X, pb.EG1.p, nullptr);
+    DCORA_HIP(B.L.alloc((size_t)pb.m.n * pb.m.d * pb.m.d + (size_t)std::max(pb.m.l, 1)));
+    DCORA_HIP(B.tmp.alloc((size_t)B.k));
+    launch_lambda_blocks(st, pb.m, B.X, pb.EG1.p, B.L.p);
   }
   DevBuf<double> vg;  // the Lanczos vector of the whole problem: own entries + the neighbours' public ones are current
   DCORA_HIP(vg.alloc((size_t)ktot));
-  DCORA_HIP(hipMemsetAsync(vg.p, 0, sizeof(double) * ktot, S.st));
+  DCORA_HIP(hipMemsetAsync(vg.p, 0, sizeof(double) * ktot, st));
   DeviceLanczos L;
-  rc = L.init_rows(nloc, ktot, lo, S.opt.device, S.st);
+  rc = L.init_rows(nloc, ktot, lo, device, st);
   if (rc) return rc;
+  L.row_map = row_map;
   L.allreduce = [this](double *vals, int count) { return allreduce_sum(vals, count); };
   L.op = [&](const double *vj, double *w) -> int {
-    if (nloc > 0)
-      DCORA_HIP(hipMemcpyAsync(vg.p + lo, vj, sizeof(double) * nloc, hipMemcpyDeviceToDevice, S.st));
+    for (CertBlock &B : blocks) {
+      if (B.own_dev)
+        hipLaunchKernelGGL(k_scatter_rows, dim3(std::min((B.k + 255) / 256, 1024)), dim3(256), 0, st, B.k, B.own_dev,
+                           vj + B.loc0, vg.p);
+      else
+        DCORA_HIP(hipMemcpyAsync(vg.p + B.col0, vj + B.loc0, sizeof(double) * B.k, hipMemcpyDeviceToDevice, st));
+    }
     int c = post_arr(all.data(), R, 1, vg.p);
     if (c) return c;
     c = wait_arr(all.data(), R, 1, vg.p);
     if (c) return c;
-    for (AgentDev &a : S.agents) {
-      if (!a.hosted) continue;
-      DeviceProblem &pb = *a.prob;
-      double *t = tmpv[(size_t)a.id].p;
-      double *wa = w + (a.col0 - lo);
-      launch_spmm(S.st, 1, a.coupling.view(), buf1(vg.p), 0, nullptr, buf1(t), 0, nullptr, Gate{});
-      launch_spmm(S.st, 1, pb.Q.view(), buf1(vg.p + a.col0), 0, t, buf1(wa), 0, nullptr, Gate{});
-      const long ne = (long)dh * a.n;
-      hipLaunchKernelGGL(k_apply_lambda, dim3((int)std::min<long>((ne + 255) / 256, 1024)), dim3(256), 0, S.st, a.n, d,
-                         Lblk[(size_t)a.id].p, eta, vg.p + a.col0, wa);
+    for (CertBlock &B : blocks) {
+      DeviceProblem &pb = *B.prob;
+      double *wa = w + B.loc0;
+      launch_spmm(st, 1, B.coupling, buf1(vg.p), 0, nullptr, buf1(B.tmp.p), 0, nullptr, Gate{});
+      launch_spmm(st, 1, pb.Q.view(), buf1(vj + B.loc0), 0, B.tmp.p, buf1(wa), 0, nullptr, Gate{});
+      hipLaunchKernelGGL(k_apply_lambda, dim3(std::min((B.k + 255) / 256, 1024)), dim3(256), 0, st, pb.m, B.L.p, eta,
+                         vj + B.loc0, wa);
     }
     DCORA_HIP(hipGetLastError());
     return DCORA_OK;
+  };
+  // this rank's rows of a vector of the whole problem, and back
+  auto local_of_whole = [&](const double *whole, double *local) {
+    for (int i = 0; i < nloc; ++i) local[i] = whole[row_map.empty() ? (size_t)lo + i : (size_t)row_map[(size_t)i]];
+  };
+  auto whole_of_local = [&](const double *local, double *whole) {
+    for (int i = 0; i < nloc; ++i) whole[row_map.empty() ? (size_t)lo + i : (size_t)row_map[(size_t)i]] = local[i];
   };
   const uint64_t seed = 12345;
   const int ncv = std::min(20, ktot);
@@ -205,7 +271,7 @@ int Exchange::certify(const HostCsr *Qglobal, double eta, int *certified, double
     double out2[2] = {0, 0};
     if (rank == 0) {
       LanczosResult e;
-      const int c = device_min_eig(M, 1000, eta, 20, seed, S.opt.device, &e);
+      const int c = device_min_eig(M, 1000, eta, 20, seed, device, &e);
       if (c && c != DCORA_ERR_NO_CONVERGENCE) out2[1] = c;
       out2[0] = e.lambda;
       mv += e.matvecs;
@@ -223,7 +289,7 @@ int Exchange::certify(const HostCsr *Qglobal, double eta, int *certified, double
     if (rc) return rc;
   } else {
     if (distributed) *distributed = 1;
-    if (nloc > 0) std::memcpy(xarea_ + lo, res.v.data(), sizeof(double) * nloc);
+    whole_of_local(res.v.data(), xarea_);  // every rank its own rows of the shared vector
     rc = barrier();
     if (rc) return rc;
     std::memcpy(vfull.data(), xarea_, sizeof(double) * ktot);
@@ -235,17 +301,18 @@ int Exchange::certify(const HostCsr *Qglobal, double eta, int *certified, double
     DevBuf<double> vl, wl;
     DCORA_HIP(vl.alloc((size_t)std::max(nloc, 1)));
     DCORA_HIP(wl.alloc((size_t)std::max(nloc, 1)));
-    if (nloc > 0)
-      DCORA_HIP(hipMemcpyAsync(vl.p, vfull.data() + lo, sizeof(double) * nloc, hipMemcpyHostToDevice, S.st));
+    std::vector<double> vloc((size_t)std::max(nloc, 1));
+    local_of_whole(vfull.data(), vloc.data());
+    if (nloc > 0) DCORA_HIP(hipMemcpyAsync(vl.p, vloc.data(), sizeof(double) * nloc, hipMemcpyHostToDevice, st));
     rc = L.op(vl.p, wl.p);
     if (rc) return rc;
     std::vector<double> wh((size_t)std::max(nloc, 1));
-    if (nloc > 0) DCORA_HIP(hipMemcpyAsync(wh.data(), wl.p, sizeof(double) * nloc, hipMemcpyDeviceToHost, S.st));
-    DCORA_HIP(hipStreamSynchronize(S.st));
+    if (nloc > 0) DCORA_HIP(hipMemcpyAsync(wh.data(), wl.p, sizeof(double) * nloc, hipMemcpyDeviceToHost, st));
+    DCORA_HIP(hipStreamSynchronize(st));
     double dots[2] = {0, 0};
     for (int i = 0; i < nloc; ++i) {
-      dots[0] += vfull[(size_t)lo + i] * wh[(size_t)i];
-      dots[1] += vfull[(size_t)lo + i] * vfull[(size_t)lo + i];
+      dots[0] += vloc[(size_t)i] * wh[(size_t)i];
+      dots[1] += vloc[(size_t)i] * vloc[(size_t)i];
     }
     rc = allreduce_sum(dots, 2);
     if (rc) return rc;

@@ -1,5 +1,5 @@
 """one rank of a multi-process range-aided RBCD run through the library's exchange (dcora_exchange_create_ra); started by
-tests/test_ra_exchange_gpu.py and by nothing else.  argv: rank world job dataset r iters out_dir accel restart"""
+tests/test_ra_exchange_gpu.py and by nothing else.  argv: rank world job dataset r iters out_dir accel restart [eta]"""
 import os
 import sys
 
@@ -31,11 +31,16 @@ def main():
         gn.append(g)
         sel.append(selected)
         selected = nxt
+    cert = None
+    if len(sys.argv) > 10:  # fastVerification across the ranks: the global data matrix on rank 0 only
+        cert = ex.certify(ra.Q if rank == 0 else None, float(sys.argv[10]), ra.k)
     X = ex.gather_X()
     info = ex.info()
     ex.barrier()
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), cost=np.array(cost), gradnorm=np.array(gn),
-             selected=np.array(sel), X=X, mode=info["mode"], posts=info["posts"], peers=info["peers"], wait=info["wait"])
+             selected=np.array(sel), X=X, mode=info["mode"], posts=info["posts"], peers=info["peers"], wait=info["wait"],
+             **({} if cert is None else dict(cert_ok=cert[0], cert_theta=cert[1], cert_lambda=cert[2], cert_v=cert[3],
+                                             cert_matvecs=cert[4], cert_distributed=cert[5])))
     ex.close()
     s.close()
 
