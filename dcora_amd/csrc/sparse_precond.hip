@@ -169,7 +169,7 @@ __device__ __forceinline__ MtRun mt_run(const MSub &U, const double *__restrict_
 // immediate offsets, four slots per run, 126 us (108 with two) -- SQ counters put 63 % of the wave cycles into waiting
 // for memory and 230 vector instructions into a wave: the kernel is bound by the three dependent round trips of a wave
 // (record, indices, operands) inside launches of 30 MB, not by its instruction stream.
-template <int KIND, int NC, int U>
+template <int KIND, int NC, int U, bool HALF>
 __device__ __forceinline__ void mt_record(const MtRun &a, const MtRun &b, int kq, int blk, int jj, int r,
                                           const double *__restrict__ y, double (&d)[NC][2][2]) {
   const int ntot = a.n + b.n;
@@ -200,13 +200,18 @@ __device__ __forceinline__ void mt_record(const MtRun &a, const MtRun &b, int kq
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int c = 0; c < NC; ++c) bv[u][c] = *reinterpret_cast<const sp_v2f64u *>(y + (size_t)(p[u] * r + jj + 8 * c));
+      for (int c = 0; c < NC; ++c) {
+        if (HALF)  // r <= 4: lane j holds column j, one 8-byte load
+          bv[u][c].x = y[(size_t)(p[u] * r + jj)];
+        else
+          bv[u][c] = *reinterpret_cast<const sp_v2f64u *>(y + (size_t)(p[u] * r + jj + 8 * c));
+      }
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         d[c][0][u & 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[u], bv[u][c].x, d[c][0][u & 1], 0, 0, 0);
-        d[c][1][u & 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[u], bv[u][c].y, d[c][1][u & 1], 0, 0, 0);
+        if (!HALF) d[c][1][u & 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[u], bv[u][c].y, d[c][1][u & 1], 0, 0, 0);
       }
   }
 }
@@ -227,7 +232,9 @@ __device__ __forceinline__ void mt_load_sub(const __attribute__((address_space(4
   U.loc[3] = p[11];
 }
 
-template <int NC, int U>
+// HALF (r <= 4): one column per lane instead of a pair -- half the vector bytes, half the MFMAs, 16 registers fewer (8
+// waves per SIMD instead of 6): the same sums in the same order as the pair form
+template <int NC, int U, bool HALF>
 __global__ __launch_bounds__(kMtBlock) void k_sp_mtile(const MWave *__restrict__ recs, const double *__restrict__ vals,
                                                         const int *__restrict__ idxs, double *__restrict__ y, int r,
                                                         Gate g) {
@@ -239,14 +246,15 @@ __global__ __launch_bounds__(kMtBlock) void k_sp_mtile(const MWave *__restrict__
   // the gate is tested AFTER the record has been requested: the two loads travel together
   if (sp_gated(g.ctl, g.seq, g.gate)) return;
   const int kq = lane >> 4, blk = (lane >> 2) & 3, li = lane & 3;  // operand roles: K entry, block, row (A) / pair (B)
-  const int jj = 2 * li;
+  constexpr int NH = HALF ? 1 : 2;  // columns a lane holds per 8-column group
+  const int jj = HALF ? li : 2 * li;
   // the old values this tile adds to (result roles: row kq, block 0, columns 8 c + 2 li + h); first wave of the tile only
   const bool writer = t_nrows > 0 && t_first == wave && blk == 0 && kq < t_nrows;
   double cv[NC][2];
 #pragma unroll
   for (int c = 0; c < NC; ++c)
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NH; ++h) {
       const int col = 8 * c + jj + h;
       cv[c][h] = (writer && t_carry >= 0 && col < r) ? y[(size_t)(t_carry + kq) * r + col] : 0.0;
     }
@@ -262,11 +270,11 @@ __global__ __launch_bounds__(kMtBlock) void k_sp_mtile(const MWave *__restrict__
     const int next = rp[6];
     {
       if (t_kind == 0)
-        mt_record<0, NC, U>(mt_run<0>(sa, vals, idxs, kq, li, t_nrows), mt_run<0>(sb, vals, idxs, kq, li, t_nrows), kq, blk,
-                            jj, r, y, d);
+        mt_record<0, NC, U, HALF>(mt_run<0>(sa, vals, idxs, kq, li, t_nrows), mt_run<0>(sb, vals, idxs, kq, li, t_nrows),
+                                  kq, blk, jj, r, y, d);
       else
-        mt_record<1, NC, U>(mt_run<1>(sa, vals, idxs, kq, li, t_nrows), mt_run<1>(sb, vals, idxs, kq, li, t_nrows), kq, blk,
-                            jj, r, y, d);
+        mt_record<1, NC, U, HALF>(mt_run<1>(sa, vals, idxs, kq, li, t_nrows), mt_run<1>(sb, vals, idxs, kq, li, t_nrows),
+                                  kq, blk, jj, r, y, d);
     }
     if (next < 0) break;
     rp = (ConstInts)(recs + next);  // tiles of many short segments: the wave's work continues in a chained record
@@ -275,7 +283,7 @@ __global__ __launch_bounds__(kMtBlock) void k_sp_mtile(const MWave *__restrict__
 #pragma unroll
   for (int c = 0; c < NC; ++c)
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NH; ++h) {
       double v = d[c][h][0] + d[c][h][1];
       v += dpp_move<0x124>(v);  // row_ror:4
       v += dpp_move<0x128>(v);  // row_ror:8: the four blocks of a 16-lane row summed
@@ -285,14 +293,14 @@ __global__ __launch_bounds__(kMtBlock) void k_sp_mtile(const MWave *__restrict__
 #pragma unroll
     for (int c = 0; c < NC; ++c)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) s_part[wave][c * 2 + h][lane] = sum[c][h];
+      for (int h = 0; h < NH; ++h) s_part[wave][c * 2 + h][lane] = sum[c][h];
     __syncthreads();
   }
   if (!writer) return;
 #pragma unroll
   for (int c = 0; c < NC; ++c)
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NH; ++h) {
       double t = sum[c][h];
       for (int w = 1; w < t_n; ++w) t += s_part[wave + w][c * 2 + h][lane];
       const int col = 8 * c + jj + h;
@@ -305,10 +313,12 @@ bool launch_mtile(hipStream_t st, int r, const SpLevel &lv, const MWave *recs, c
   if (r < 1 || r > 16) return false;
   if (lv.ntasks == 0) return true;
   const MWave *rp = recs + lv.task0;
-  if (r <= 8)
-    hipLaunchKernelGGL((k_sp_mtile<1, 8>), dim3(lv.ntasks), dim3(kMtBlock), 0, st, rp, vals, idxs, y, r, g);
+  if (r <= 4)
+    hipLaunchKernelGGL((k_sp_mtile<1, 8, true>), dim3(lv.ntasks), dim3(kMtBlock), 0, st, rp, vals, idxs, y, r, g);
+  else if (r <= 8)
+    hipLaunchKernelGGL((k_sp_mtile<1, 8, false>), dim3(lv.ntasks), dim3(kMtBlock), 0, st, rp, vals, idxs, y, r, g);
   else
-    hipLaunchKernelGGL((k_sp_mtile<2, 4>), dim3(lv.ntasks), dim3(kMtBlock), 0, st, rp, vals, idxs, y, r, g);
+    hipLaunchKernelGGL((k_sp_mtile<2, 4, false>), dim3(lv.ntasks), dim3(kMtBlock), 0, st, rp, vals, idxs, y, r, g);
   return true;
 }
 
