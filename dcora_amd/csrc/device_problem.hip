@@ -890,11 +890,14 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
   // f(x0), grad(x0) from buffer 0 (null gate: the control block of this solve does not exist yet)
   // cost + gradient of an evaluation in one launch where the kernel exists (small CSR blocks), else Q-apply + rgrad
   const bool gf = !has_bsr && Q.n_long == 0;
+  const bool gfb = has_bsr;       // large blocks: the same in one launch on the block structure (k_spmm_bsr2<.., GRAD>)
   const int nAe = gf ? nPB : nA;  // {<XQ,X>, <X,G>} partial slots of an evaluation
   int nG;
   ++seq;
   if (gf) {
     nG = launch_fused_grad(st, m, Qv, Xb(), Gp, EGb(), RGb(), Sb(), 0, pA.p, pB.p, nullptr, Gate{});
+  } else if (gfb) {
+    nG = launch_fused_grad_bsr(st, m.r, m.d, Qbv, Xb(), Gp, EGb(), RGb(), Sb(), 0, pA.p, pB.p, nullptr, Gate{});
   } else {
     enq_qapply(Xb(), 0, Gp, EGb(), 0, pA.p, Gate{});
     ++seq;
@@ -971,6 +974,9 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
     const int nR = enq_retract(Xb(), eta.p, 1.0, Xb(), 1, RGb(), Heta.p, pC.p, Gate{c, ++seq, 1});
     if (gf) {
       nG = launch_fused_grad(st, m, Qv, Xb(), Gp, EGb(), RGb(), Sb(), 1, pA.p, pB.p, nullptr, Gate{c, ++seq, 1});
+    } else if (gfb) {
+      nG = launch_fused_grad_bsr(st, m.r, m.d, Qbv, Xb(), Gp, EGb(), RGb(), Sb(), 1, pA.p, pB.p, nullptr,
+                                 Gate{c, ++seq, 1});
     } else {
       enq_qapply(Xb(), 1, Gp, EGb(), 1, pA.p, Gate{c, ++seq, 1});
       nG = enq_rgrad(Xb(), EGb(), RGb(), Sb(), 1, pB.p, Gate{c, ++seq, 1});

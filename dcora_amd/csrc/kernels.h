@@ -249,6 +249,8 @@ void launch_fused_finish(hipStream_t st, const ManiDesc &m, Buf2 X, const double
                          double *z, const double *p2, int np2, double *p3, SolverCtl *ctl, HostFlags *hf, int seq,
                          int iter, int first, int nsplit = -1 /* -1: fused_nsplit(m) */, SpFold sf = SpFold());
 // group-style (8 lanes per pose) rgrad / retract / Nesterov; return the number of partial slots written
+int launch_fused_grad_bsr(hipStream_t st, int r, int d, const BsrDev &A, Buf2 X, const double *G, Buf2 EG, Buf2 RG, Buf2 S,
+                          int sel, double *pA, double *pB, double *posenorm, Gate g);
 int launch_fused_grad(hipStream_t st, const ManiDesc &m, const CsrDev &Q, Buf2 X, const double *G, Buf2 EG, Buf2 RG,
                       Buf2 Sblk, int sel, double *pA, double *pB, double *posenorm, Gate g);
 int launch_g_rgrad(hipStream_t st, const ManiDesc &m, Buf2 X, Buf2 EG, Buf2 RG, Buf2 Sblk, int sel, double *partials,

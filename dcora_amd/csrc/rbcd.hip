@@ -656,12 +656,16 @@ int RbcdSession::evaluate_central(double *cost2, double *gradnorm, double *block
   }
   DeviceProblem &c = *central;
   const bool gf = c.group && c.fused && !c.has_bsr && c.Q.n_long == 0;
-  if (!gf) c.enqueue_egrad(Xg.p, c.EG0.p, c.pA.p);
+  const bool gfb = c.group && c.fused && c.has_bsr;  // the same on the block structure of Q (large graphs)
+  if (!gf && !gfb) c.enqueue_egrad(Xg.p, c.EG0.p, c.pA.p);
   if (c.group) {
     int nA = c.npA();
     if (gf)  // X Q, the cost dots, the Riemannian gradient and the per-pose norms in one launch
       nA = launch_fused_grad(st, c.m, c.Q.view(), buf1(Xg.p), nullptr, buf1(c.EG0.p), buf1(c.RG0.p),
                              Buf2{{nullptr, nullptr}}, 0, c.pA.p, c.pB.p, posenorm.p, Gate{});
+    else if (gfb)
+      nA = launch_fused_grad_bsr(st, c.m.r, c.m.d, c.Qb.view(), buf1(Xg.p), nullptr, buf1(c.EG0.p), buf1(c.RG0.p),
+                                 Buf2{{nullptr, nullptr}}, 0, c.pA.p, c.pB.p, posenorm.p, Gate{});
     else
       c.enq_rgrad(buf1(Xg.p), buf1(c.EG0.p), buf1(c.RG0.p), Buf2{{nullptr, nullptr}}, 0, c.pB.p, Gate{}, posenorm.p);
     const int want = ++eval_seq;

@@ -1523,19 +1523,30 @@ template <int A_>
 __device__ __forceinline__ double quad_bcast(double v) {
   return dpp_move<A_ * 0x55>(v);  // quad_perm [A, A, A, A]
 }
-template <int D, bool DOTS>
+// GRAD: the whole evaluation of an RTR iteration in this launch -- a lane group already holds EG_i = (X Q + G)_i in the
+// layout k_g_rgrad works in, so RG_i = Proj_X(EG_i), S_i = sym(Y_i^T EG_i), the partial |RG|^2 and the per-pose norms
+// follow as an epilogue (the same operations in the same order as k_g_rgrad) instead of a launch of their own that
+// reads EG and X back: one dependent launch less per evaluation, four per local solve of a large block.
+struct BsrGradOut {
+  Buf2 RG, S;
+  double *pB = nullptr;        // partial |RG|^2, one per workgroup
+  double *posenorm = nullptr;  // |RG_i|^2 per pose, or null
+};
+template <int D, bool DOTS, bool GRAD>
 __global__ __launch_bounds__(kBlock) void k_spmm_bsr2(int r, BsrDev A, Buf2 Xb, int selX,
                                                       const double *__restrict__ G, Buf2 Yb, int selY,
-                                                      double *__restrict__ partials, Gate g) {
+                                                      double *__restrict__ partials, Gate g, BsrGradOut go) {
   if (g.ctl && g.gate && f_gated(g.ctl, g.seq, g.gate)) return;
   constexpr int DH = D + 1, BS = DH * DH;
   __shared__ double s_red[16];
   const int cur = g.ctl ? (g.ctl->cur & 1) : 0;
   const double *__restrict__ X = Xb.p[g.ctl ? ((cur ^ selX) & 1) : 0];
   double *__restrict__ Y = Yb.p[g.ctl ? ((cur ^ selY) & 1) : 0];
+  double *__restrict__ RG = GRAD ? go.RG.p[g.ctl ? ((cur ^ selY) & 1) : 0] : nullptr;
+  double *__restrict__ Sblk = GRAD ? go.S.p[g.ctl ? ((cur ^ selY) & 1) : 0] : nullptr;
   const int t = threadIdx.x & (GW - 1);
   const int rowq = min(t & 3, DH - 1);  // the block row this lane holds
-  double d0 = 0, d1 = 0;
+  double d0 = 0, d1 = 0, dg = 0;
   const int range_lo = (int)((long)A.nbrows * blockIdx.x / gridDim.x);
   const int range_hi = (int)((long)A.nbrows * (blockIdx.x + 1) / gridDim.x);
   const int npass = max(1, (range_hi - range_lo + kPosesPerBlock - 1) / kPosesPerBlock);
@@ -1604,7 +1615,38 @@ __global__ __launch_bounds__(kBlock) void k_spmm_bsr2(int r, BsrDev A, Buf2 Xb, 
         }
       }
     }
-    if (active) {
+    if (GRAD) {
+      // every lane of a group takes part in the group's sums; inactive lanes carry zeros
+      const size_t ob = (size_t)(inr ? pose : 0) * DH * r;
+      Row<D> Yr, E;
+#pragma unroll
+      for (int a = 0; a < DH; ++a) {
+        const double x = active ? X[ob + t + a * r] : 0.0;
+        const double gg = (active && G) ? G[ob + t + a * r] : 0.0;
+        d0 += acc[a] * x;
+        d1 += x * gg;
+        Yr.e[a] = x;
+        E.e[a] = active ? acc[a] + gg : 0.0;
+      }
+      st_row<D>(Y + ob, r, t, active, E);
+      double S[D][D];
+      grp_sym_gram<D>(Yr, E, S);
+      if (Sblk && inr && t == 0)
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+          for (int b = 0; b < D; ++b) Sblk[(size_t)pose * D * D + a + b * D] = S[a][b];
+      row_sub_AS<D>(E, Yr, S);
+      double pa = 0;
+#pragma unroll
+      for (int a = 0; a < DH; ++a) pa += E.e[a] * E.e[a];
+      dg += pa;
+      if (go.posenorm) {
+        const double ps = grp_sum(pa);
+        if (inr && t == 0) go.posenorm[pose] = ps;
+      }
+      if (RG) st_row<D>(RG + ob, r, t, active, E);
+    } else if (active) {
       const size_t o = (size_t)pose * DH * r + t;
 #pragma unroll
       for (int a = 0; a < DH; ++a) {
@@ -1626,6 +1668,10 @@ __global__ __launch_bounds__(kBlock) void k_spmm_bsr2(int r, BsrDev A, Buf2 Xb, 
       partials[2 * blockIdx.x] = a;
       partials[2 * blockIdx.x + 1] = b;
     }
+  }
+  if (GRAD) {
+    const double c = f_block_sum(dg, s_red);
+    if (threadIdx.x == 0) go.pB[blockIdx.x] = c;
   }
 }
 
@@ -1773,14 +1819,35 @@ int spmm_bsr_grid(int nbrows) {
 void launch_spmm_bsr(hipStream_t st, int r, int d, const BsrDev &A, Buf2 X, int selX, const double *G, Buf2 Y,
                      int selY, double *partials, Gate g) {
   const int grid = spmm_bsr_grid(A.nbrows);
+  const BsrGradOut none{};
   if (d == 3 && partials)
-    hipLaunchKernelGGL((k_spmm_bsr2<3, true>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials, g);
+    hipLaunchKernelGGL((k_spmm_bsr2<3, true, false>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials,
+                       g, none);
   else if (d == 3)
-    hipLaunchKernelGGL((k_spmm_bsr2<3, false>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials, g);
+    hipLaunchKernelGGL((k_spmm_bsr2<3, false, false>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY,
+                       partials, g, none);
   else if (partials)
-    hipLaunchKernelGGL((k_spmm_bsr2<2, true>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials, g);
+    hipLaunchKernelGGL((k_spmm_bsr2<2, true, false>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials,
+                       g, none);
   else
-    hipLaunchKernelGGL((k_spmm_bsr2<2, false>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials, g);
+    hipLaunchKernelGGL((k_spmm_bsr2<2, false, false>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY,
+                       partials, g, none);
+}
+// EG = X Q + G, RG = Proj_X(EG), S blocks, partials {<XQ,X>, <X,G>} in pA (2 per block), |RG|^2 in pB (1 per block) and
+// the per-pose norms in ONE launch on the block structure of Q; returns the number of blocks
+int launch_fused_grad_bsr(hipStream_t st, int r, int d, const BsrDev &A, Buf2 X, const double *G, Buf2 EG, Buf2 RG, Buf2 S,
+                          int sel, double *pA, double *pB, double *posenorm, Gate g) {
+  const int grid = spmm_bsr_grid(A.nbrows);
+  BsrGradOut go;
+  go.RG = RG;
+  go.S = S;
+  go.pB = pB;
+  go.posenorm = posenorm;
+  if (d == 3)
+    hipLaunchKernelGGL((k_spmm_bsr2<3, true, true>), dim3(grid), dim3(kBlock), 0, st, r, A, X, sel, G, EG, sel, pA, g, go);
+  else
+    hipLaunchKernelGGL((k_spmm_bsr2<2, true, true>), dim3(grid), dim3(kBlock), 0, st, r, A, X, sel, G, EG, sel, pA, g, go);
+  return grid;
 }
 
 // the 8-lanes-per-pose kernels (rgrad / retract / Nesterov / BSR Q-apply) walk the poses with a capped grid: any n
