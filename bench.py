@@ -593,6 +593,28 @@ def committed_profile(nbytes):
     return out
 
 
+def qapply_in_loop():
+    """the block Q-apply as it runs INSIDE the RBCD loop of the 100k lattice (agent blocks of 12 500 poses, with the
+    evaluation's epilogue fused in, plus one whole-graph launch per iteration): from the committed per-iteration
+    breakdown of a kernel trace (tools/trace_c5.sh), not measured in this run"""
+    for tag in ("r04", "r03"):
+        path = os.path.join(ROOT, "profiles", "%s_c5_loop_breakdown.txt" % tag)
+        if not os.path.exists(path):
+            continue
+        try:
+            for line in open(path):
+                f = line.split()
+                if f and f[0] == "k_spmm_bsr2":
+                    return {"kernel": "k_spmm_bsr2 in the RBCD loop of the 100k lattice (8 agents)",
+                            "launches_per_rbcd_iteration": float(f[1]), "avg_launch_us": float(f[2]),
+                            "us_per_rbcd_iteration": float(f[3]),
+                            "note": "mostly agent blocks of 15 MB: launch-bound, not a bandwidth figure",
+                            "source": "profiles/%s_c5_loop_breakdown.txt (read from the committed file)" % tag}
+        except Exception:
+            pass
+    return None
+
+
 def qapply_entry(P, ms, nbytes, extra=None):
     ach = nbytes / (ms * 1e-3) / 1e9
     qi = P.qapply_info()
@@ -702,6 +724,9 @@ def roofline(da, ds, r, robots):
                                                     "of a set): every launch streams from HBM" % (4 * nbytes / 1e6)})
         for Pg in Ps:
             Pg.close()
+        inl = qapply_in_loop()
+        if inl:
+            out["qapply_in_loop"] = inl
         # the preconditioner of one agent block of that lattice (k = 50 000): partitioned sparse inverse, one gather
         # kernel per dissection level; bytes = stored inverse factors + tables + the vector in / out of every tile
         nb, ids, vals = agent_block(big, 8, 0)

@@ -656,7 +656,7 @@ int RbcdSession::evaluate_central(double *cost2, double *gradnorm, double *block
   }
   DeviceProblem &c = *central;
   const bool gf = c.group && c.fused && !c.has_bsr && c.Q.n_long == 0;
-  const bool gfb = c.group && c.fused && c.has_bsr;  // the same on the block structure of Q (large graphs)
+  const bool gfb = c.group && c.has_bsr;  // the same on the block structure of Q (large graphs: any number of poses)
   if (!gf && !gfb) c.enqueue_egrad(Xg.p, c.EG0.p, c.pA.p);
   if (c.group) {
     int nA = c.npA();
