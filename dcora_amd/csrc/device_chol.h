@@ -56,7 +56,7 @@ void chol_symbolic(const HostCsr &A, int block, CholSymbolic *out, int top_unkno
 bool chol_numeric_host(const CholSymbolic &S, const double *vals, std::vector<double> *fronts);
 
 // device numeric factorisation of the matrix whose values (CSR order of the analysed pattern) are vals (host).
-// *pd = every pivot positive.  Symbolic analyses are cached on the pattern; DCORA_CHOL_CACHE=0 disables the cache.
+// *pd = every pivot positive.  Symbolic analyses are cached on the pattern.
 int device_chol_is_pd(const HostCsr &A, int block, int device, bool *pd, double *info8 = nullptr);
 
 // the factor itself, by pieces (sparse_precond.h), for the builder of the partitioned inverse: ordered with

@@ -67,9 +67,9 @@ __global__ __launch_bounds__(256) void k_chol_extend_add(const PieceDev *__restr
   }
 }
 
-// ---- 64 x 64 Cholesky and triangular inverse of a workgroup, blocked by 16 (round 3).  The column-by-column forms
-//      below (k_chol_potrf_v1, DCORA_POTRF=v1) pay a workgroup barrier per column and a 64-step dependent walk per
-//      column of the inverse: 83 us per diagonal block, 13 of the 21 ms of the headline's agent set-up and half of
+// ---- 64 x 64 Cholesky and triangular inverse of a workgroup, blocked by 16 (round 3).  The column-by-column form of
+//      round 2 (deleted) paid a workgroup barrier per column and a 64-step dependent walk per column of the inverse:
+//      83 us per diagonal block, 13 of the 21 ms of the headline's agent set-up and half of
 //      sphere2500's PSD test.  Blocked: the 16 x 16 diagonal block is factored by ONE wave (LDS operations of a wave
 //      stay in order: no workgroup barrier inside its 16 steps), the panel below it is a 16-step substitution per row,
 //      the trailing update a rank-16 product over all threads; the inverse is four 16 x 16 inversions side by side
@@ -1225,7 +1225,7 @@ int factor_on_device(const HostCsr &A, int block, int top, int device, bool *pd,
       for (int s2 = 0; s2 < np; ++s2)
         if (S.pieces[s2].c >= kWide) {
           wide.push_back(s2);
-          // L11^-T L11^-1 of every wide piece: the merged schedule (host_partinv2.cpp) applies the two triangular
+          // L11^-T L11^-1 of every wide piece: the schedule (host_partinv3.cpp) applies the two triangular
           // products of a piece as this one symmetric product
           if (!dev_src) {
             moff[s2] = mtotal;

@@ -1062,8 +1062,8 @@ __global__ __launch_bounds__(kPcBlock) void k_fused_pc(ManiDesc m, int ldm, int 
   const bool own = e < nrow * r;
   const size_t oown = (size_t)j0 * r + e;
   const int pi1 = (np1 <= 64) ? lane : (int)threadIdx.x;
-  // np1 < 0: timing experiment (DCORA_PC_EXP=1, time_precond only): <d, H d> is taken from the control block, as it would
-  // be if the PRODUCER's last workgroup had summed its partials and stored the scalar -- what that scheme can save here
+  // np1 < 0: timing form (time_precond only): <d, H d> is taken from the control block, as it would be if the
+  // PRODUCER's last workgroup had summed its partials and stored the scalar -- measured in round 3: it saves nothing
   double myp = (!first && np1 >= 0 && pi1 < np1) ? p1[pi1] : 0.0;
   double o_r = 0, o_h = 0, o_d = 0, o_eta = 0, o_Heta = 0;
   if (own) {
@@ -1505,7 +1505,7 @@ __global__ __launch_bounds__(kBlock) void k_g_nesterov(ManiDesc m, GNesterovArgs
 // every lane gets the rows it does not hold by DPP quad broadcasts (VALU, per SIMD) instead of 16 broadcast reads of LDS
 // per block (one LDS pipe per CU: 717 MB per launch on the 100k lattice).  No staging pass, no barrier.  The column
 // indices of up to 8 blocks of a pose come with one load and are handed round with ds_bpermute.  Same summation order
-// as k_spmm_bsr: bitwise the same result (tools/cmp_bsr.py).  Measured on the 100k lattice, warm / cold us:
+// as the staged form had: bitwise the same result (checked before that form was deleted).  Measured on the 100k lattice, warm / cold us:
 // k_spmm_bsr 27.4 / 33.9; this form with 2 / 3 / 4 blocks gathered together 26.6 / 35.6, 24.8 / 33.1, 26.6 / 34.2;
 // with the rows of the next batch and G requested one step ahead (software pipeline, 114 instead of 80 VGPRs)
 // 26.9 / 33.3 (3 blocks), 27.0 / 32.6 (2 blocks): the cold figure does not move with the kernel's structure.

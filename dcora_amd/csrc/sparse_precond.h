@@ -37,7 +37,7 @@ constexpr int kSpTile = 4;  // output rows per tile: they share every gathered v
 //   kind 0, direct:      A[i][k] = Mat[loc[i]][4 g + k]       K runs over the columns   (forward: rows of W by destination)
 //   kind 1, transposed:  A[i][k] = Mat[4 g + k][col0 + i]     K runs over the rows      (backward: W^T; M, symmetric)
 // so the backward sweep streams the SAME weights the forward sweep did: stored weights = nnz(W) + nnz(M) where the
-// tile schedule of host_partinv2.cpp stores 2 nnz(W) + nnz(M), laid out per tile.
+// tile schedule of round 3 stored 2 nnz(W) + nnz(M), laid out per tile.
 // The unit the device reads is a WAVE RECORD (host_partinv3.cpp packs them, kMtWaves per workgroup): the contiguous range
 // of a tile's steps one wave executes -- cut so that it touches at most two segments, whose descriptions travel in the
 // record --, where the tile's result goes and which waves of the workgroup hold the other partial sums of the tile.  One
