@@ -40,6 +40,14 @@ for t, dlt in ev:
         if depth >= 2: two += t - last
         elif depth == 1: one += t - last
     depth += dlt; last = t
+ea = sorted(((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, int(r.get("Grid_Size", 0)) // 256) for r in sel if "extend_add" in r["Kernel_Name"])
+if ea:
+    import bisect
+    tot = sum(d for d, _ in ea)
+    for lim in (6, 12, 25, 50, 100, 1e9):
+        part = [d for d, _ in ea if d < lim]
+        print("  extend_add launches under %g us: %d, %.2f ms" % (lim, len(part), sum(part) / 1e3))
+    print("  longest extend_add launches (us, workgroups):", [(round(d, 1), g) for d, g in ea[-8:]])
 print("  time with >= 2 kernels in flight %.2f ms, exactly one %.2f ms, none %.2f ms" % (two / 1e6, one / 1e6, (t1 - t0 - two - one) / 1e6))
 PY
 rm -f $o/t_kernel_trace.csv $o/*/t_kernel_trace.csv
