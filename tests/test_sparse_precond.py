@@ -91,8 +91,8 @@ def sparse_env(built):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,r", [("smallGrid3D", 5), ("sphere2500", 5), ("sphere2500", 7),
                                     ("pose_graph_optimization_test_2d", 3),
-                                    # every instantiation of the entry-per-lane level kernel (r = 2 .. 8; r = 2 runs on
-                                    # the 2-D graph) and the round-1 form behind it (r > 8)
+                                    # every instantiation of k_sp_mtile: one column per lane (r <= 4; r = 2 runs on the
+                                    # 2-D graph), a column pair per lane (r = 5 .. 8), two pairs (r > 8)
                                     ("pose_graph_optimization_test_2d", 2), ("sphere2500", 3), ("sphere2500", 4),
                                     ("sphere2500", 6), ("sphere2500", 8), ("sphere2500", 9), ("smallGrid3D", 12)])
 def test_device_replay_matches_oracle_preconditioner(sparse_env, name, r):
