@@ -110,9 +110,9 @@ HostCsr csr_shift_diag(const HostCsr &A, double s) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Ordering: automatic nested dissection on the block-compressed graph.  Separators are the middle level of
-// a BFS level structure rooted at a pseudo-peripheral node (George); leaves are ordered by a cheap local
-// minimum-degree pass.  Produces shallow elimination trees, which is what a level-scheduled device
+// Ordering: automatic nested dissection on the block-compressed graph.  A component is bisected along a level of a
+// BFS level structure rooted at a pseudo-peripheral node (George), the bisection is refined and its separator is a
+// minimum vertex cover of the cut edges (CutCover below); leaves are ordered by a cheap local minimum-degree pass.  Produces shallow elimination trees, which is what a level-scheduled device
 // triangular solve will want ("next").
 // ---------------------------------------------------------------------------------------------------
 namespace {
@@ -152,6 +152,178 @@ void leaf_order(const NDGraph &G, const std::vector<int> &nodes, std::vector<int
   for (auto &e : dn) out.push_back(e.second);
 }
 
+// ---- vertex separators from edge bisections (round 4).  A whole BFS level is a poor separator of a sparse pose graph
+//      (trajectory chains + loop closures: 3.4 neighbours per pose): most of its nodes touch only one side.  For a
+//      bisection (side 0 / 1 of the nodes of a component) the smallest set of nodes covering every cut edge is a minimum
+//      vertex cover of the bipartite graph of the cut edges (Koenig: its size is a maximum matching, Hopcroft-Karp).
+//      Measured on the pose graph of a 100k-lattice agent: nnz(L) 635 k -> 460 k blocks with the level chosen among the
+//      balanced ones, a greedy refinement of the bisection and the cover (a spectral bisection gives 414 k, minimum degree
+//      300 k); the whole lattice: 23.4 M -> 15.4 M, the factorisation's flops -47 %. ----
+constexpr double kNdBalance = 0.42;  // either side of a bisection keeps at least this share of the component's nodes
+struct CutCover {
+  // local ids 0 .. m - 1 of a component; nbr lists through lid (global -> local, -1 outside)
+  const NDGraph &G;
+  const std::vector<int> &nodes;
+  const std::vector<int> &lid;
+  std::vector<int> aidx, bidx;        // boundary nodes of side 0 / side 1 (local ids)
+  std::vector<int> apos, bpos;        // local id -> position in aidx / bidx, or -1
+  std::vector<int> xadj, adj;         // A position -> B positions
+  std::vector<int> matchA, matchB, dist;
+  CutCover(const NDGraph &G_, const std::vector<int> &nodes_, const std::vector<int> &lid_)
+      : G(G_), nodes(nodes_), lid(lid_) {}
+  bool bfs() {
+    std::vector<int> q;
+    const int INF = 1 << 30;
+    bool found = false;
+    for (size_t a = 0; a < aidx.size(); ++a) {
+      dist[a] = matchA[a] < 0 ? 0 : INF;
+      if (matchA[a] < 0) q.push_back((int)a);
+    }
+    for (size_t h = 0; h < q.size(); ++h) {
+      const int a = q[h];
+      for (int p = xadj[a]; p < xadj[a + 1]; ++p) {
+        const int a2 = matchB[adj[p]];
+        if (a2 < 0) {
+          found = true;
+        } else if (dist[a2] == INF) {
+          dist[a2] = dist[a] + 1;
+          q.push_back(a2);
+        }
+      }
+    }
+    return found;
+  }
+  bool dfs(int a) {
+    for (int p = xadj[a]; p < xadj[a + 1]; ++p) {
+      const int b = adj[p], a2 = matchB[b];
+      if (a2 < 0 || (dist[a2] == dist[a] + 1 && dfs(a2))) {
+        matchA[a] = b;
+        matchB[b] = a;
+        return true;
+      }
+    }
+    dist[a] = 1 << 30;
+    return false;
+  }
+  // minimum vertex cover of the cut of `side`; cover (local ids) returned in `out`
+  int run(const std::vector<char> &side, std::vector<int> *out) {
+    const int m = (int)nodes.size();
+    aidx.clear();
+    bidx.clear();
+    apos.assign((size_t)m, -1);
+    bpos.assign((size_t)m, -1);
+    for (int i = 0; i < m; ++i) {
+      const int u = nodes[(size_t)i];
+      bool cut = false;
+      for (int p = G.xadj[u]; p < G.xadj[u + 1] && !cut; ++p) {
+        const int j = lid[(size_t)G.adj[p]];
+        cut = j >= 0 && side[(size_t)j] != side[(size_t)i];
+      }
+      if (!cut) continue;
+      if (side[(size_t)i]) {
+        bpos[(size_t)i] = (int)bidx.size();
+        bidx.push_back(i);
+      } else {
+        apos[(size_t)i] = (int)aidx.size();
+        aidx.push_back(i);
+      }
+    }
+    xadj.assign(aidx.size() + 1, 0);
+    adj.clear();
+    for (size_t a = 0; a < aidx.size(); ++a) {
+      const int u = nodes[(size_t)aidx[a]];
+      for (int p = G.xadj[u]; p < G.xadj[u + 1]; ++p) {
+        const int j = lid[(size_t)G.adj[p]];
+        if (j >= 0 && side[(size_t)j]) adj.push_back(bpos[(size_t)j]);
+      }
+      xadj[a + 1] = (int)adj.size();
+    }
+    matchA.assign(aidx.size(), -1);
+    matchB.assign(bidx.size(), -1);
+    dist.assign(aidx.size(), 0);
+    int matched = 0;
+    while (bfs())
+      for (size_t a = 0; a < aidx.size(); ++a)
+        if (matchA[a] < 0 && dfs((int)a)) ++matched;
+    if (!out) return matched;
+    // Koenig: Z = everything reachable from the unmatched A nodes along alternating paths; cover = (A \ Z) + (B & Z)
+    std::vector<char> za(aidx.size(), 0), zb(bidx.size(), 0);
+    std::vector<int> st;
+    for (size_t a = 0; a < aidx.size(); ++a)
+      if (matchA[a] < 0) {
+        za[a] = 1;
+        st.push_back((int)a);
+      }
+    while (!st.empty()) {
+      const int a = st.back();
+      st.pop_back();
+      for (int p = xadj[a]; p < xadj[a + 1]; ++p) {
+        const int b = adj[p];
+        if (zb[(size_t)b] || matchA[(size_t)a] == b) continue;
+        zb[(size_t)b] = 1;
+        const int a2 = matchB[(size_t)b];
+        if (a2 >= 0 && !za[(size_t)a2]) {
+          za[(size_t)a2] = 1;
+          st.push_back(a2);
+        }
+      }
+    }
+    out->clear();
+    for (size_t a = 0; a < aidx.size(); ++a)
+      if (!za[a]) out->push_back(aidx[a]);
+    for (size_t b = 0; b < bidx.size(); ++b)
+      if (zb[b]) out->push_back(bidx[b]);
+    return (int)out->size();
+  }
+};
+
+// single-node moves that reduce the number of cut edges, largest gain first, both sides kept above `lo` of the component
+void refine_bisection(const NDGraph &G, const std::vector<int> &nodes, const std::vector<int> &lid,
+                      std::vector<char> &side, double lo) {
+  const int m = (int)nodes.size();
+  int n1 = 0;
+  for (char c : side) n1 += c;
+  const int min_side = (int)(lo * m);
+  std::vector<std::pair<int, int>> cand;
+  for (int pass = 0; pass < 8; ++pass) {
+    cand.clear();
+    for (int i = 0; i < m; ++i) {
+      const int u = nodes[(size_t)i];
+      int ext = 0, inn = 0;
+      for (int p = G.xadj[u]; p < G.xadj[u + 1]; ++p) {
+        const int j = lid[(size_t)G.adj[p]];
+        if (j < 0) continue;
+        if (side[(size_t)j] != side[(size_t)i])
+          ++ext;
+        else
+          ++inn;
+      }
+      if (ext > inn) cand.emplace_back(-(ext - inn), i);
+    }
+    if (cand.empty()) break;
+    std::sort(cand.begin(), cand.end());
+    int moved = 0;
+    for (const auto &c : cand) {
+      const int i = c.second, u = nodes[(size_t)i];
+      int ext = 0, inn = 0;
+      for (int p = G.xadj[u]; p < G.xadj[u + 1]; ++p) {
+        const int j = lid[(size_t)G.adj[p]];
+        if (j < 0) continue;
+        if (side[(size_t)j] != side[(size_t)i])
+          ++ext;
+        else
+          ++inn;
+      }
+      if (ext <= inn) continue;
+      if (side[(size_t)i] ? (n1 - 1 < min_side) : (m - n1 - 1 < min_side)) continue;
+      side[(size_t)i] = !side[(size_t)i];
+      n1 += side[(size_t)i] ? 1 : -1;
+      ++moved;
+    }
+    if (!moved) break;
+  }
+}
+
 void nd_recurse(const NDGraph &G, std::vector<int> nodes, std::vector<int> &comp_id, int &next_cid,
                 std::vector<int> &level, std::vector<int> &out, std::vector<int> &cuts, int leaf_nodes,
                 int task_nodes, std::vector<std::pair<int, int>> &tasks,
@@ -165,6 +337,7 @@ void nd_recurse(const NDGraph &G, std::vector<int> nodes, std::vector<int> &comp
   // at most task_nodes nodes are reported as independent tasks (their columns depend on nothing outside the run).
   // Separators above the tasks are reported by depth (sep_waves[depth]): separators of one depth head disjoint
   // sub-trees, so a wave can be factorised concurrently once everything deeper is done.
+  std::vector<int> lid((size_t)G.nb, -1);  // global node -> local id inside the component being split
   std::vector<std::vector<int>> stack;
   std::vector<char> stack_in_task;
   std::vector<int> stack_depth;
@@ -201,16 +374,76 @@ void nd_recurse(const NDGraph &G, std::vector<int> nodes, std::vector<int> &comp
     }
     const int depth = level[order.back()];
     if (depth < 2) return 2;
-    // separator = level closest to the median node
-    const int mid = level[order[order.size() / 2]];
-    const int sep_level = std::min(std::max(mid, 1), depth - 1);
-    for (int u : order) {
-      if (level[u] == sep_level)
+    // bisections {level < s} | {level >= s} for the levels s that leave 42 .. 58 % of the nodes on either side (at most
+    // nine of them, evenly spaced; the level of the median node when none does); their minimum vertex covers; the two
+    // smallest are refined (single-node moves that remove cut edges) and covered again; the smallest separator wins
+    const int m = (int)cur.size();
+    for (int i = 0; i < m; ++i) lid[(size_t)cur[(size_t)i]] = i;
+    std::vector<int> below((size_t)depth + 2, 0);  // below[s] = nodes with level < s
+    for (int u : cur) ++below[(size_t)level[u] + 1];
+    for (int l = 1; l <= depth + 1; ++l) below[(size_t)l] += below[(size_t)l - 1];
+    std::vector<int> cands;
+    for (int sl = 1; sl <= depth; ++sl)
+      if (below[(size_t)sl] >= kNdBalance * m && below[(size_t)sl] <= (1.0 - kNdBalance) * m) cands.push_back(sl);
+    if (cands.empty()) {
+      const int mid = level[order[order.size() / 2]];
+      cands.push_back(std::min(std::max(mid, 1), depth));
+    }
+    if (cands.size() > 9) {
+      std::vector<int> pick;
+      for (int q = 0; q < 9; ++q) pick.push_back(cands[(size_t)((cands.size() - 1) * q / 8)]);
+      cands.swap(pick);
+    }
+    CutCover cc(G, cur, lid);
+    std::vector<char> side((size_t)m), best_side;
+    std::vector<int> cover, best_cover;
+    std::vector<std::pair<std::pair<int, int>, int>> sized;  // ((cover size, imbalance), level): ties go to the balanced cut
+    auto set_side = [&](int sl) {
+      for (int i = 0; i < m; ++i) side[(size_t)i] = level[cur[(size_t)i]] >= sl ? 1 : 0;
+    };
+    for (int sl : cands) {
+      set_side(sl);
+      sized.push_back({{cc.run(side, nullptr), std::abs(2 * below[(size_t)sl] - m)}, sl});
+    }
+    std::sort(sized.begin(), sized.end());
+    int best = -1;
+    for (size_t q = 0; q < sized.size() && q < 2; ++q)
+      for (int refined = 0; refined < 2; ++refined) {
+        set_side(sized[q].second);
+        if (refined) refine_bisection(G, cur, lid, side, kNdBalance);
+        const int sz = cc.run(side, &cover);
+        if (best < 0 || sz < best) {
+          best = sz;
+          best_side = side;
+          best_cover = cover;
+        }
+      }
+    std::vector<char> in_sep((size_t)m, 0);
+    for (int i : best_cover) in_sep[(size_t)i] = 1;
+    for (int i = 0; i < m; ++i) {
+      const int u = cur[(size_t)i];
+      if (in_sep[(size_t)i])
         sep.push_back(u);  // separators are eliminated last
-      else if (level[u] < sep_level)
+      else if (!best_side[(size_t)i])
         left.push_back(u);
       else
         right.push_back(u);
+    }
+    for (int u : cur) lid[(size_t)u] = -1;
+    if (left.empty() || right.empty()) {  // (a degenerate cut: everything on one side of the cover)
+      sep.clear();
+      left.clear();
+      right.clear();
+      const int mid = level[order[order.size() / 2]];
+      const int sep_level = std::min(std::max(mid, 1), depth - 1);
+      for (int u : order) {
+        if (level[u] == sep_level)
+          sep.push_back(u);
+        else if (level[u] < sep_level)
+          left.push_back(u);
+        else
+          right.push_back(u);
+      }
     }
     return 0;
   };
