@@ -14,6 +14,7 @@
 #include <numeric>
 #include <queue>
 #include <thread>
+#include <unordered_map>
 
 namespace dcora {
 
@@ -285,7 +286,7 @@ void refine_bisection(const NDGraph &G, const std::vector<int> &nodes, const std
   for (char c : side) n1 += c;
   const int min_side = (int)(lo * m);
   std::vector<std::pair<int, int>> cand;
-  for (int pass = 0; pass < 8; ++pass) {
+  for (int pass = 0; pass < 4; ++pass) {
     cand.clear();
     for (int i = 0; i < m; ++i) {
       const int u = nodes[(size_t)i];
@@ -324,11 +325,29 @@ void refine_bisection(const NDGraph &G, const std::vector<int> &nodes, const std
   }
 }
 
+// the splits of one dissection, kept for a second pass over the same graph (amd_like_order probes the separator sizes
+// per depth before it fixes the dense top and the leaf size: the final pass meets the same components again)
+struct SplitMemo {
+  struct Entry {
+    std::vector<int> nodes, sep, left, right;
+    int how;
+  };
+  std::unordered_map<unsigned long long, std::vector<Entry>> map;
+  static unsigned long long key(const std::vector<int> &v) {
+    unsigned long long h = 1469598103934665603ull ^ v.size();
+    for (int x : v) h = (h ^ (unsigned long long)(unsigned)x) * 1099511628211ull;
+    return h;
+  }
+};
+
 void nd_recurse(const NDGraph &G, std::vector<int> nodes, std::vector<int> &comp_id, int &next_cid,
                 std::vector<int> &level, std::vector<int> &out, std::vector<int> &cuts, int leaf_nodes,
                 int task_nodes, std::vector<std::pair<int, int>> &tasks,
                 std::vector<std::vector<std::pair<int, int>>> &sep_waves, int top_depth,
-                std::vector<long> *sep_nodes_by_depth) {
+                std::vector<long> *sep_nodes_by_depth, int max_depth = -1, SplitMemo *memo = nullptr) {
+  // max_depth >= 0: a component that is still larger than a leaf at this depth becomes a leaf all the same when it is at
+  // most three leaves large -- bisections that are balanced only to 42 : 58 would otherwise add a tree level (two
+  // dependent launches of the device replay) for a handful of stragglers
   // top_depth > 0: the separators of the first top_depth dissection depths are not placed between their sub-trees
   // but collected and eliminated last, as ONE piece (see amd_like_order).  sep_nodes_by_depth (optional) receives the
   // number of separator nodes per depth.
@@ -374,50 +393,94 @@ void nd_recurse(const NDGraph &G, std::vector<int> nodes, std::vector<int> &comp
     }
     const int depth = level[order.back()];
     if (depth < 2) return 2;
-    // bisections {level < s} | {level >= s} for the levels s that leave 42 .. 58 % of the nodes on either side (at most
-    // nine of them, evenly spaced; the level of the median node when none does); their minimum vertex covers; the two
-    // smallest are refined (single-node moves that remove cut edges) and covered again; the smallest separator wins
+    const int level_of_median = level[order[order.size() / 2]];
+    // Bisections {f < t} | {f >= t} of three node functions -- the BFS level from one end u of the pseudo-diameter,
+    // the level from its other end v, and their difference (whose level sets are the bisectors between the two ends:
+    // straighter than either family of "spheres") -- at the thresholds t that leave 42 .. 58 % of the nodes on either
+    // side.  The thresholds of a function are ranked by the smaller of the two boundaries of their cuts (one pass for
+    // all of them); the best one is covered as it is and after a refinement (single-node moves that remove cut edges);
+    // the smallest separator of the six wins, ties go to the more balanced cut.  (Pose graph of a 100k-lattice agent, nnz(L) in
+    // blocks: a whole BFS level 635 k; level of u + cover 488 k; + levels of v 448 k; + the difference 419 k; a
+    // spectral bisection 414 k.)
     const int m = (int)cur.size();
     for (int i = 0; i < m; ++i) lid[(size_t)cur[(size_t)i]] = i;
-    std::vector<int> below((size_t)depth + 2, 0);  // below[s] = nodes with level < s
-    for (int u : cur) ++below[(size_t)level[u] + 1];
-    for (int l = 1; l <= depth + 1; ++l) below[(size_t)l] += below[(size_t)l - 1];
-    std::vector<int> cands;
-    for (int sl = 1; sl <= depth; ++sl)
-      if (below[(size_t)sl] >= kNdBalance * m && below[(size_t)sl] <= (1.0 - kNdBalance) * m) cands.push_back(sl);
-    if (cands.empty()) {
-      const int mid = level[order[order.size() / 2]];
-      cands.push_back(std::min(std::max(mid, 1), depth));
-    }
-    if (cands.size() > 9) {
-      std::vector<int> pick;
-      for (int q = 0; q < 9; ++q) pick.push_back(cands[(size_t)((cands.size() - 1) * q / 8)]);
-      cands.swap(pick);
+    std::vector<int> lev_u((size_t)m), lev_v((size_t)m), fv((size_t)m);
+    for (int i = 0; i < m; ++i) lev_u[(size_t)i] = level[cur[(size_t)i]];
+    {
+      const int v_end = order.back();
+      for (int u : cur) level[u] = -1;
+      std::vector<int> order_v;
+      bfs_levels(G, comp_id, cid, v_end, level, order_v);
+      for (int i = 0; i < m; ++i) lev_v[(size_t)i] = level[cur[(size_t)i]];
     }
     CutCover cc(G, cur, lid);
     std::vector<char> side((size_t)m), best_side;
     std::vector<int> cover, best_cover;
-    std::vector<std::pair<std::pair<int, int>, int>> sized;  // ((cover size, imbalance), level): ties go to the balanced cut
-    auto set_side = [&](int sl) {
-      for (int i = 0; i < m; ++i) side[(size_t)i] = level[cur[(size_t)i]] >= sl ? 1 : 0;
-    };
-    for (int sl : cands) {
-      set_side(sl);
-      sized.push_back({{cc.run(side, nullptr), std::abs(2 * below[(size_t)sl] - m)}, sl});
-    }
-    std::sort(sized.begin(), sized.end());
-    int best = -1;
-    for (size_t q = 0; q < sized.size() && q < 2; ++q)
+    int best = -1, best_imb = 0;
+    for (int fn = 0; fn < 3; ++fn) {
+      int fmin = 1 << 30, fmax = -(1 << 30);
+      for (int i = 0; i < m; ++i) {
+        fv[(size_t)i] = fn == 0 ? lev_u[(size_t)i] : fn == 1 ? lev_v[(size_t)i] : lev_u[(size_t)i] - lev_v[(size_t)i];
+        fmin = std::min(fmin, fv[(size_t)i]);
+        fmax = std::max(fmax, fv[(size_t)i]);
+      }
+      std::vector<int> below((size_t)(fmax - fmin) + 2, 0);  // below[t - fmin] = nodes with f < t
+      for (int i = 0; i < m; ++i) ++below[(size_t)(fv[(size_t)i] - fmin) + 1];
+      for (size_t l = 1; l < below.size(); ++l) below[l] += below[l - 1];
+      // boundary sizes of EVERY threshold in one pass: node i lies on the low side's boundary for the thresholds
+      // f_i < t <= (largest f among its neighbours), on the high side's for (smallest f among its neighbours) < t <= f_i;
+      // the smaller of the two boundaries bounds the cover and ranks the thresholds
+      const int range = fmax - fmin + 2;
+      std::vector<int> lowb((size_t)range + 1, 0), highb((size_t)range + 1, 0);
+      for (int i = 0; i < m; ++i) {
+        const int u = cur[(size_t)i];
+        int hi = fv[(size_t)i], lo = fv[(size_t)i];
+        for (int p2 = G.xadj[u]; p2 < G.xadj[u + 1]; ++p2) {
+          const int j = lid[(size_t)G.adj[p2]];
+          if (j < 0) continue;
+          hi = std::max(hi, fv[(size_t)j]);
+          lo = std::min(lo, fv[(size_t)j]);
+        }
+        if (hi > fv[(size_t)i]) {  // thresholds fv + 1 .. hi
+          ++lowb[(size_t)(fv[(size_t)i] + 1 - fmin)];
+          --lowb[(size_t)(hi + 1 - fmin)];
+        }
+        if (lo < fv[(size_t)i]) {  // thresholds lo + 1 .. fv
+          ++highb[(size_t)(lo + 1 - fmin)];
+          --highb[(size_t)(fv[(size_t)i] + 1 - fmin)];
+        }
+      }
+      for (int q = 1; q <= range; ++q) {
+        lowb[(size_t)q] += lowb[(size_t)q - 1];
+        highb[(size_t)q] += highb[(size_t)q - 1];
+      }
+      std::vector<std::pair<std::pair<int, int>, int>> ranked;  // ((boundary bound, imbalance), threshold)
+      for (int t = fmin + 1; t <= fmax; ++t) {
+        const int nlow = below[(size_t)(t - fmin)];
+        if (nlow >= kNdBalance * m && nlow <= (1.0 - kNdBalance) * m)
+          ranked.push_back({{std::min(lowb[(size_t)(t - fmin)], highb[(size_t)(t - fmin)]), std::abs(2 * nlow - m)}, t});
+      }
+      if (ranked.empty() && fn == 0)
+        ranked.push_back({{0, 0}, std::min(std::max(level_of_median, fmin + 1), fmax)});
+      if (ranked.empty()) continue;
+      std::sort(ranked.begin(), ranked.end());
+      // the best-ranked threshold as it is and refined
       for (int refined = 0; refined < 2; ++refined) {
-        set_side(sized[q].second);
+        for (int i = 0; i < m; ++i) side[(size_t)i] = fv[(size_t)i] >= ranked[0].second ? 1 : 0;
         if (refined) refine_bisection(G, cur, lid, side, kNdBalance);
         const int sz = cc.run(side, &cover);
-        if (best < 0 || sz < best) {
+        int n1 = 0;
+        for (char c : side) n1 += c;
+        const int imb = std::abs(2 * n1 - m);
+        if (best < 0 || sz < best || (sz == best && imb < best_imb)) {
           best = sz;
+          best_imb = imb;
           best_side = side;
           best_cover = cover;
         }
       }
+    }
+    for (int i = 0; i < m; ++i) level[cur[(size_t)i]] = lev_u[(size_t)i];  // (the fallback below reads the levels of u)
     std::vector<char> in_sep((size_t)m, 0);
     for (int i : best_cover) in_sep[(size_t)i] = 1;
     for (int i = 0; i < m; ++i) {
@@ -481,7 +544,7 @@ void nd_recurse(const NDGraph &G, std::vector<int> nodes, std::vector<int> &comp
     }
     const int cid = next_cid++;
     label(cur, cid);
-    if ((int)cur.size() <= leaf_nodes) {
+    if ((int)cur.size() <= leaf_nodes || (max_depth >= 0 && dep >= max_depth && (int)cur.size() <= 3 * leaf_nodes)) {
       std::vector<int> lo;
       leaf_order(G, cur, comp_id, cid, lo);
       for (auto it = lo.rbegin(); it != lo.rend(); ++it) rev.push_back(*it);
@@ -489,7 +552,25 @@ void nd_recurse(const NDGraph &G, std::vector<int> nodes, std::vector<int> &comp
       unlabel(cur);
       continue;
     }
-    const int how = try_split(cur, cid, sep, left, right);
+    int how = -1;
+    unsigned long long mkey = 0;
+    if (memo) {
+      mkey = SplitMemo::key(cur);
+      auto it = memo->map.find(mkey);
+      if (it != memo->map.end())
+        for (const SplitMemo::Entry &e : it->second)
+          if (e.nodes == cur) {
+            sep = e.sep;
+            left = e.left;
+            right = e.right;
+            how = e.how;
+            break;
+          }
+    }
+    if (how < 0) {
+      how = try_split(cur, cid, sep, left, right);
+      if (memo) memo->map[mkey].push_back(SplitMemo::Entry{cur, sep, left, right, how});
+    }
     if (how == 1) {  // disconnected: split off the reached component
       unlabel(cur);
       push(std::move(right), in_task, dep);
@@ -629,6 +710,13 @@ std::vector<int> amd_like_order(const HostCsr &A, int block, std::vector<int> *p
   // separators of the first L depths is applied by a single symmetric dense product.  L = as many depths as fit
   // top_unknowns unknowns (nd_top_default() for the replay; 0 for a plain factorisation, whose dense fronts would
   // only get more expensive); volume-like graphs, whose root separator alone is larger, keep the plain tree.
+  // the depth a perfectly balanced dissection needs (nd_recurse: max_depth)
+  auto depth_cap = [&](int leaf) {
+    int dcap = 1;
+    while (((long)leaf << dcap) < (long)all.size()) ++dcap;
+    return dcap;
+  };
+  SplitMemo memo;
   int top_depth = 0;
   bool have_plain = false;  // the probe below IS the final dissection when no dense top comes out of it
   {
@@ -638,19 +726,41 @@ std::vector<int> amd_like_order(const HostCsr &A, int block, std::vector<int> *p
       std::vector<std::pair<int, int>> tasks0;
       std::vector<std::vector<std::pair<int, int>>> waves0;
       int cid0 = 0;
-      nd_recurse(G, all, comp0, cid0, level0, border0, cuts0, leaf_nodes, 0, tasks0, waves0, 0, &by_depth);
+      nd_recurse(G, all, comp0, cid0, level0, border0, cuts0, leaf_nodes, 0, tasks0, waves0, 0, &by_depth,
+                 depth_cap(leaf_nodes), &memo);
+      // as many depths as fit top_unknowns -- but no more than pay: with D separator depths in all, a top of t depths
+      // leaves D - t + 1 levels below it, applied in pairs (2 ceil((D - t + 1) / 2) + 1 launches of ~10 us), and costs its
+      // dense symmetric product (c_t^2 doubles at ~5 TB/s); the cheapest t wins, the smaller on a tie (tiers.pyfg: an
+      // eighth depth fits, saves no launch and doubles the bytes of the top)
       long sum = 0;
+      int t_fit = 0;
+      std::vector<long> cum;
       for (size_t dpt = 0; dpt < by_depth.size(); ++dpt) {
         sum += by_depth[dpt] * block;
         if (sum > top_unknowns) break;
-        top_depth = (int)dpt + 1;
+        cum.push_back(sum);
+        t_fit = (int)dpt + 1;
       }
-      if (top_depth < 2) top_depth = 0;  // one depth alone is the plain tree
-      // Surface-like graphs (many depths fit the dense top) also want leaves twice as large: one depth less, and
-      // their leaf level is small next to the launch it saves.  Measured per application of the replay, leaves of
-      // 96 / 192 / 384 unknowns: sphere2500 49 / 41 / 39 us, torus3D 89 / 75 / 74, tiers.pyfg 72 / 65 / 82,
-      // an agent of the 100k lattice (two depths in the top) 169 / 190 / 235.
-      if (top_depth >= 3) leaf_nodes *= 2;
+      const int D = (int)by_depth.size();
+      // ... and leaves twice as large take one more depth away (their dense blocks double: 8 n block^2 leaf bytes).
+      // Measured per application of the replay with the BFS-level separators of round 2, leaves of 96 / 192 / 384 unknowns:
+      // sphere2500 49 / 41 / 39 us, torus3D 89 / 75 / 74, tiers.pyfg 72 / 65 / 82, a lattice agent 169 / 190 / 235 -- the
+      // model below reproduces those choices and follows the smaller separators of round 4.
+      double best_cost = 0;
+      int best_mult = 1;
+      for (int mult = 1; mult <= 2; ++mult)
+        for (int t = 2; t <= t_fit; ++t) {
+          const int below = std::max(1, D - (mult - 1) - t + 1);
+          const double bytes = 8.0 * (double)cum[(size_t)t - 1] * (double)cum[(size_t)t - 1] +
+                               8.0 * (double)all.size() * block * block * leaf_nodes * mult;
+          const double cost = 10.0 * (2 * ((below + 1) / 2) + 1) + bytes / 5e6;
+          if (top_depth == 0 || cost < best_cost) {
+            best_cost = cost;
+            top_depth = t;
+            best_mult = mult;
+          }
+        }
+      leaf_nodes *= best_mult;
       if (top_depth == 0 && task_nodes == 0) {  // volume-like graph: the same recursion would run again (90 ms at k = 400 000)
         comp_id.swap(comp0);
         level.swap(level0);
@@ -659,13 +769,15 @@ std::vector<int> amd_like_order(const HostCsr &A, int block, std::vector<int> *p
         next_cid = cid0;
         have_plain = true;
       }
-      if (env::init_timing())
-        std::fprintf(stderr, "[order] %d nodes: dense top of %d depths, leaves of %d nodes\n", (int)all.size(), top_depth,
-                     leaf_nodes);
+      if (env::init_timing()) {
+        std::fprintf(stderr, "[order] %d nodes: %d separator depths, %d fit the dense top, dense top of %d depths (%ld unknowns), leaves of %d nodes\n",
+                     (int)all.size(), D, t_fit, top_depth, top_depth > 0 ? cum[(size_t)top_depth - 1] : 0L, leaf_nodes);
+      }
     }
   }
   if (!have_plain)
-    nd_recurse(G, all, comp_id, next_cid, level, border, cuts, leaf_nodes, task_nodes, tasks, waves, top_depth, nullptr);
+    nd_recurse(G, all, comp_id, next_cid, level, border, cuts, leaf_nodes, task_nodes, tasks, waves, top_depth, nullptr,
+               depth_cap(leaf_nodes), &memo);
   if (col_tasks) {
     col_tasks->clear();
     for (const auto &t : tasks)

@@ -162,7 +162,7 @@ def test_device_verdict_config5_full_size(built):
     n = Q.shape[0]
     assert n == 400000
     pd, info = da.is_psd_device(da.Csr.from_scipy((Q + 1e-3 * sp.identity(n)).tocsr()), 4, info=True)
-    assert pd and info["flops"] > 1e12
+    assert pd and info["flops"] > 5e11  # (1.94e12 with whole BFS levels as separators, 0.92e12 with vertex covers)
     # log det against the sum over a 2 x 2 block split?  no closed form: check the factor through the shift instead:
     # Q is PSD with a 1-dimensional kernel per connected component => Q - eps I is indefinite for every eps > 0
     assert not da.is_psd_device(da.Csr.from_scipy((Q - 1e-6 * sp.identity(n)).tocsr()), 4)
