@@ -7,6 +7,9 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -325,6 +328,148 @@ void refine_bisection(const NDGraph &G, const std::vector<int> &nodes, const std
   }
 }
 
+// one dissection step of a labelled component (comp_id == cid, level == -1 on its nodes; lid == -1 everywhere):
+// 0 = split into sep / left / right, 1 = disconnected (reached / rest returned in left / right), 2 = too shallow.
+// All scratch arrays are the caller's: the serial recursion and the workers of the parallel pre-pass bring their own.
+int split_component(const NDGraph &G, const std::vector<int> &cur, int cid, const std::vector<int> &comp_id,
+                    std::vector<int> &level, std::vector<int> &lid, std::vector<int> &order, std::vector<int> &sep,
+                    std::vector<int> &left, std::vector<int> &right) {
+  sep.clear();
+  left.clear();
+  right.clear();
+  int root = cur[0];
+  bfs_levels(G, comp_id, cid, root, level, order);  // pseudo-peripheral root: two more sweeps below
+  if (order.size() < cur.size()) {
+    for (int u : cur)
+      if (level[u] < 0) right.push_back(u);
+    left = order;
+    return 1;
+  }
+  for (int sweep = 0; sweep < 2; ++sweep) {
+    root = order.back();
+    for (int u : cur) level[u] = -1;
+    bfs_levels(G, comp_id, cid, root, level, order);
+  }
+  const int depth = level[order.back()];
+  if (depth < 2) return 2;
+  const int level_of_median = level[order[order.size() / 2]];
+  // Bisections {f < t} | {f >= t} of three node functions -- the BFS level from one end u of the pseudo-diameter,
+  // the level from its other end v, and their difference (whose level sets are the bisectors between the two ends:
+  // straighter than either family of "spheres") -- at the thresholds t that leave 42 .. 58 % of the nodes on either
+  // side.  The thresholds of a function are ranked by the smaller of the two boundaries of their cuts (one pass for
+  // all of them); the best one is covered as it is and after a refinement (single-node moves that remove cut edges);
+  // the smallest separator of the six wins, ties go to the more balanced cut.  (Pose graph of a 100k-lattice agent, nnz(L) in
+  // blocks: a whole BFS level 635 k; level of u + cover 488 k; + levels of v 448 k; + the difference 419 k; a
+  // spectral bisection 414 k.)
+  const int m = (int)cur.size();
+  for (int i = 0; i < m; ++i) lid[(size_t)cur[(size_t)i]] = i;
+  std::vector<int> lev_u((size_t)m), lev_v((size_t)m), fv((size_t)m);
+  for (int i = 0; i < m; ++i) lev_u[(size_t)i] = level[cur[(size_t)i]];
+  {
+    const int v_end = order.back();
+    for (int u : cur) level[u] = -1;
+    std::vector<int> order_v;
+    bfs_levels(G, comp_id, cid, v_end, level, order_v);
+    for (int i = 0; i < m; ++i) lev_v[(size_t)i] = level[cur[(size_t)i]];
+  }
+  CutCover cc(G, cur, lid);
+  std::vector<char> side((size_t)m), best_side;
+  std::vector<int> cover, best_cover;
+  int best = -1, best_imb = 0;
+  for (int fn = 0; fn < 3; ++fn) {
+    int fmin = 1 << 30, fmax = -(1 << 30);
+    for (int i = 0; i < m; ++i) {
+      fv[(size_t)i] = fn == 0 ? lev_u[(size_t)i] : fn == 1 ? lev_v[(size_t)i] : lev_u[(size_t)i] - lev_v[(size_t)i];
+      fmin = std::min(fmin, fv[(size_t)i]);
+      fmax = std::max(fmax, fv[(size_t)i]);
+    }
+    std::vector<int> below((size_t)(fmax - fmin) + 2, 0);  // below[t - fmin] = nodes with f < t
+    for (int i = 0; i < m; ++i) ++below[(size_t)(fv[(size_t)i] - fmin) + 1];
+    for (size_t l = 1; l < below.size(); ++l) below[l] += below[l - 1];
+    // boundary sizes of EVERY threshold in one pass: node i lies on the low side's boundary for the thresholds
+    // f_i < t <= (largest f among its neighbours), on the high side's for (smallest f among its neighbours) < t <= f_i;
+    // the smaller of the two boundaries bounds the cover and ranks the thresholds
+    const int range = fmax - fmin + 2;
+    std::vector<int> lowb((size_t)range + 1, 0), highb((size_t)range + 1, 0);
+    for (int i = 0; i < m; ++i) {
+      const int u = cur[(size_t)i];
+      int hi = fv[(size_t)i], lo = fv[(size_t)i];
+      for (int p2 = G.xadj[u]; p2 < G.xadj[u + 1]; ++p2) {
+        const int j = lid[(size_t)G.adj[p2]];
+        if (j < 0) continue;
+        hi = std::max(hi, fv[(size_t)j]);
+        lo = std::min(lo, fv[(size_t)j]);
+      }
+      if (hi > fv[(size_t)i]) {  // thresholds fv + 1 .. hi
+        ++lowb[(size_t)(fv[(size_t)i] + 1 - fmin)];
+        --lowb[(size_t)(hi + 1 - fmin)];
+      }
+      if (lo < fv[(size_t)i]) {  // thresholds lo + 1 .. fv
+        ++highb[(size_t)(lo + 1 - fmin)];
+        --highb[(size_t)(fv[(size_t)i] + 1 - fmin)];
+      }
+    }
+    for (int q = 1; q <= range; ++q) {
+      lowb[(size_t)q] += lowb[(size_t)q - 1];
+      highb[(size_t)q] += highb[(size_t)q - 1];
+    }
+    std::vector<std::pair<std::pair<int, int>, int>> ranked;  // ((boundary bound, imbalance), threshold)
+    for (int t = fmin + 1; t <= fmax; ++t) {
+      const int nlow = below[(size_t)(t - fmin)];
+      if (nlow >= kNdBalance * m && nlow <= (1.0 - kNdBalance) * m)
+        ranked.push_back({{std::min(lowb[(size_t)(t - fmin)], highb[(size_t)(t - fmin)]), std::abs(2 * nlow - m)}, t});
+    }
+    if (ranked.empty() && fn == 0)
+      ranked.push_back({{0, 0}, std::min(std::max(level_of_median, fmin + 1), fmax)});
+    if (ranked.empty()) continue;
+    std::sort(ranked.begin(), ranked.end());
+    // the best-ranked threshold as it is and refined
+    for (int refined = 0; refined < 2; ++refined) {
+      for (int i = 0; i < m; ++i) side[(size_t)i] = fv[(size_t)i] >= ranked[0].second ? 1 : 0;
+      if (refined) refine_bisection(G, cur, lid, side, kNdBalance);
+      const int sz = cc.run(side, &cover);
+      int n1 = 0;
+      for (char c : side) n1 += c;
+      const int imb = std::abs(2 * n1 - m);
+      if (best < 0 || sz < best || (sz == best && imb < best_imb)) {
+        best = sz;
+        best_imb = imb;
+        best_side = side;
+        best_cover = cover;
+      }
+    }
+  }
+  for (int i = 0; i < m; ++i) level[cur[(size_t)i]] = lev_u[(size_t)i];  // (the fallback below reads the levels of u)
+  std::vector<char> in_sep((size_t)m, 0);
+  for (int i : best_cover) in_sep[(size_t)i] = 1;
+  for (int i = 0; i < m; ++i) {
+    const int u = cur[(size_t)i];
+    if (in_sep[(size_t)i])
+      sep.push_back(u);  // separators are eliminated last
+    else if (!best_side[(size_t)i])
+      left.push_back(u);
+    else
+      right.push_back(u);
+  }
+  for (int u : cur) lid[(size_t)u] = -1;
+  if (left.empty() || right.empty()) {  // (a degenerate cut: everything on one side of the cover)
+    sep.clear();
+    left.clear();
+    right.clear();
+    const int mid = level[order[order.size() / 2]];
+    const int sep_level = std::min(std::max(mid, 1), depth - 1);
+    for (int u : order) {
+      if (level[u] == sep_level)
+        sep.push_back(u);
+      else if (level[u] < sep_level)
+        left.push_back(u);
+      else
+        right.push_back(u);
+    }
+  }
+  return 0;
+}
+
 // the splits of one dissection, kept for a second pass over the same graph (amd_like_order probes the separator sizes
 // per depth before it fixes the dense top and the leaf size: the final pass meets the same components again)
 struct SplitMemo {
@@ -339,6 +484,65 @@ struct SplitMemo {
     return h;
   }
 };
+
+// Parallel pre-pass of a large dissection: the components of one depth are independent, so a pool of host threads splits
+// them side by side (every worker with scratch arrays of its own) and leaves the splits in the memo; the serial passes of
+// amd_like_order then only assemble the order.  (The whole 100k lattice: 331 ms of ordering on one thread.)
+void prefill_splits(const NDGraph &G, const std::vector<int> &all, int leaf_nodes, int max_depth, int nthreads,
+                    SplitMemo *memo) {
+  struct Item {
+    std::vector<int> nodes;
+    int dep;
+  };
+  std::deque<Item> queue;
+  std::mutex mu;
+  std::condition_variable cv;
+  int active = 0;
+  queue.push_back(Item{all, 0});
+  auto worker = [&]() {
+    std::vector<int> comp_id((size_t)G.nb, -1), level((size_t)G.nb, -1), lid((size_t)G.nb, -1), order, sep, left, right;
+    for (;;) {
+      Item it;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !queue.empty() || active == 0; });
+        if (queue.empty()) return;
+        it = std::move(queue.front());
+        queue.pop_front();
+        ++active;
+      }
+      const std::vector<int> &cur = it.nodes;
+      int how = 2;
+      const bool leaf = (int)cur.size() <= leaf_nodes ||
+                        (max_depth >= 0 && it.dep >= max_depth && (int)cur.size() <= 3 * leaf_nodes);
+      if (!leaf && !cur.empty()) {
+        for (int u : cur) {
+          comp_id[(size_t)u] = 1;
+          level[(size_t)u] = -1;
+        }
+        how = split_component(G, cur, 1, comp_id, level, lid, order, sep, left, right);
+        for (int u : cur) comp_id[(size_t)u] = -1;
+      }
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        if (!leaf && !cur.empty()) {
+          memo->map[SplitMemo::key(cur)].push_back(SplitMemo::Entry{cur, sep, left, right, how});
+          if (how == 0 || how == 1) {
+            const int d2 = how == 0 ? it.dep + 1 : it.dep;
+            queue.push_back(Item{std::move(left), d2});
+            queue.push_back(Item{std::move(right), d2});
+          }
+        }
+        --active;
+      }
+      cv.notify_all();
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < nthreads; ++t) pool.emplace_back(worker);
+  worker();
+  for (std::thread &t : pool) t.join();
+}
 
 void nd_recurse(const NDGraph &G, std::vector<int> nodes, std::vector<int> &comp_id, int &next_cid,
                 std::vector<int> &level, std::vector<int> &out, std::vector<int> &cuts, int leaf_nodes,
@@ -371,144 +575,9 @@ void nd_recurse(const NDGraph &G, std::vector<int> nodes, std::vector<int> &comp
     if ((int)sep_waves.size() <= dep) sep_waves.resize(dep + 1);
     sep_waves[dep].emplace_back(start, count);
   };
-  // one dissection step of a labelled component (comp_id == cid, level == -1 on its nodes):
-  // 0 = split into sep / left / right, 1 = disconnected (reached / rest returned in left / right), 2 = too shallow
   auto try_split = [&](const std::vector<int> &cur, int cid, std::vector<int> &sep, std::vector<int> &left,
                        std::vector<int> &right) -> int {
-    sep.clear();
-    left.clear();
-    right.clear();
-    int root = cur[0];
-    bfs_levels(G, comp_id, cid, root, level, order);  // pseudo-peripheral root: two more sweeps below
-    if (order.size() < cur.size()) {
-      for (int u : cur)
-        if (level[u] < 0) right.push_back(u);
-      left = order;
-      return 1;
-    }
-    for (int sweep = 0; sweep < 2; ++sweep) {
-      root = order.back();
-      for (int u : cur) level[u] = -1;
-      bfs_levels(G, comp_id, cid, root, level, order);
-    }
-    const int depth = level[order.back()];
-    if (depth < 2) return 2;
-    const int level_of_median = level[order[order.size() / 2]];
-    // Bisections {f < t} | {f >= t} of three node functions -- the BFS level from one end u of the pseudo-diameter,
-    // the level from its other end v, and their difference (whose level sets are the bisectors between the two ends:
-    // straighter than either family of "spheres") -- at the thresholds t that leave 42 .. 58 % of the nodes on either
-    // side.  The thresholds of a function are ranked by the smaller of the two boundaries of their cuts (one pass for
-    // all of them); the best one is covered as it is and after a refinement (single-node moves that remove cut edges);
-    // the smallest separator of the six wins, ties go to the more balanced cut.  (Pose graph of a 100k-lattice agent, nnz(L) in
-    // blocks: a whole BFS level 635 k; level of u + cover 488 k; + levels of v 448 k; + the difference 419 k; a
-    // spectral bisection 414 k.)
-    const int m = (int)cur.size();
-    for (int i = 0; i < m; ++i) lid[(size_t)cur[(size_t)i]] = i;
-    std::vector<int> lev_u((size_t)m), lev_v((size_t)m), fv((size_t)m);
-    for (int i = 0; i < m; ++i) lev_u[(size_t)i] = level[cur[(size_t)i]];
-    {
-      const int v_end = order.back();
-      for (int u : cur) level[u] = -1;
-      std::vector<int> order_v;
-      bfs_levels(G, comp_id, cid, v_end, level, order_v);
-      for (int i = 0; i < m; ++i) lev_v[(size_t)i] = level[cur[(size_t)i]];
-    }
-    CutCover cc(G, cur, lid);
-    std::vector<char> side((size_t)m), best_side;
-    std::vector<int> cover, best_cover;
-    int best = -1, best_imb = 0;
-    for (int fn = 0; fn < 3; ++fn) {
-      int fmin = 1 << 30, fmax = -(1 << 30);
-      for (int i = 0; i < m; ++i) {
-        fv[(size_t)i] = fn == 0 ? lev_u[(size_t)i] : fn == 1 ? lev_v[(size_t)i] : lev_u[(size_t)i] - lev_v[(size_t)i];
-        fmin = std::min(fmin, fv[(size_t)i]);
-        fmax = std::max(fmax, fv[(size_t)i]);
-      }
-      std::vector<int> below((size_t)(fmax - fmin) + 2, 0);  // below[t - fmin] = nodes with f < t
-      for (int i = 0; i < m; ++i) ++below[(size_t)(fv[(size_t)i] - fmin) + 1];
-      for (size_t l = 1; l < below.size(); ++l) below[l] += below[l - 1];
-      // boundary sizes of EVERY threshold in one pass: node i lies on the low side's boundary for the thresholds
-      // f_i < t <= (largest f among its neighbours), on the high side's for (smallest f among its neighbours) < t <= f_i;
-      // the smaller of the two boundaries bounds the cover and ranks the thresholds
-      const int range = fmax - fmin + 2;
-      std::vector<int> lowb((size_t)range + 1, 0), highb((size_t)range + 1, 0);
-      for (int i = 0; i < m; ++i) {
-        const int u = cur[(size_t)i];
-        int hi = fv[(size_t)i], lo = fv[(size_t)i];
-        for (int p2 = G.xadj[u]; p2 < G.xadj[u + 1]; ++p2) {
-          const int j = lid[(size_t)G.adj[p2]];
-          if (j < 0) continue;
-          hi = std::max(hi, fv[(size_t)j]);
-          lo = std::min(lo, fv[(size_t)j]);
-        }
-        if (hi > fv[(size_t)i]) {  // thresholds fv + 1 .. hi
-          ++lowb[(size_t)(fv[(size_t)i] + 1 - fmin)];
-          --lowb[(size_t)(hi + 1 - fmin)];
-        }
-        if (lo < fv[(size_t)i]) {  // thresholds lo + 1 .. fv
-          ++highb[(size_t)(lo + 1 - fmin)];
-          --highb[(size_t)(fv[(size_t)i] + 1 - fmin)];
-        }
-      }
-      for (int q = 1; q <= range; ++q) {
-        lowb[(size_t)q] += lowb[(size_t)q - 1];
-        highb[(size_t)q] += highb[(size_t)q - 1];
-      }
-      std::vector<std::pair<std::pair<int, int>, int>> ranked;  // ((boundary bound, imbalance), threshold)
-      for (int t = fmin + 1; t <= fmax; ++t) {
-        const int nlow = below[(size_t)(t - fmin)];
-        if (nlow >= kNdBalance * m && nlow <= (1.0 - kNdBalance) * m)
-          ranked.push_back({{std::min(lowb[(size_t)(t - fmin)], highb[(size_t)(t - fmin)]), std::abs(2 * nlow - m)}, t});
-      }
-      if (ranked.empty() && fn == 0)
-        ranked.push_back({{0, 0}, std::min(std::max(level_of_median, fmin + 1), fmax)});
-      if (ranked.empty()) continue;
-      std::sort(ranked.begin(), ranked.end());
-      // the best-ranked threshold as it is and refined
-      for (int refined = 0; refined < 2; ++refined) {
-        for (int i = 0; i < m; ++i) side[(size_t)i] = fv[(size_t)i] >= ranked[0].second ? 1 : 0;
-        if (refined) refine_bisection(G, cur, lid, side, kNdBalance);
-        const int sz = cc.run(side, &cover);
-        int n1 = 0;
-        for (char c : side) n1 += c;
-        const int imb = std::abs(2 * n1 - m);
-        if (best < 0 || sz < best || (sz == best && imb < best_imb)) {
-          best = sz;
-          best_imb = imb;
-          best_side = side;
-          best_cover = cover;
-        }
-      }
-    }
-    for (int i = 0; i < m; ++i) level[cur[(size_t)i]] = lev_u[(size_t)i];  // (the fallback below reads the levels of u)
-    std::vector<char> in_sep((size_t)m, 0);
-    for (int i : best_cover) in_sep[(size_t)i] = 1;
-    for (int i = 0; i < m; ++i) {
-      const int u = cur[(size_t)i];
-      if (in_sep[(size_t)i])
-        sep.push_back(u);  // separators are eliminated last
-      else if (!best_side[(size_t)i])
-        left.push_back(u);
-      else
-        right.push_back(u);
-    }
-    for (int u : cur) lid[(size_t)u] = -1;
-    if (left.empty() || right.empty()) {  // (a degenerate cut: everything on one side of the cover)
-      sep.clear();
-      left.clear();
-      right.clear();
-      const int mid = level[order[order.size() / 2]];
-      const int sep_level = std::min(std::max(mid, 1), depth - 1);
-      for (int u : order) {
-        if (level[u] == sep_level)
-          sep.push_back(u);
-        else if (level[u] < sep_level)
-          left.push_back(u);
-        else
-          right.push_back(u);
-      }
-    }
-    return 0;
+    return split_component(G, cur, cid, comp_id, level, lid, order, sep, left, right);
   };
   auto label = [&](const std::vector<int> &nodes_, int cid) {
     for (int u : nodes_) {
@@ -717,6 +786,10 @@ std::vector<int> amd_like_order(const HostCsr &A, int block, std::vector<int> *p
     return dcap;
   };
   SplitMemo memo;
+  if ((int)all.size() >= 30000) {  // (agents of a session are set up side by side on host threads: small graphs stay serial)
+    const int nthreads = std::max(1, std::min(host_cpus_available(), 16));
+    if (nthreads > 1) prefill_splits(G, all, leaf_nodes, depth_cap(leaf_nodes), nthreads, &memo);
+  }
   int top_depth = 0;
   bool have_plain = false;  // the probe below IS the final dissection when no dense top comes out of it
   {
