@@ -60,7 +60,8 @@ struct Source {        // what a piece contributes to the rows above it in one f
 };
 
 // steps a wave should get: it requests the loads of up to eight steps together, so eight steps are one memory round trip
-// (measured per application on a lattice agent: 4 -> 105 us, 8 -> 102, 16 -> 106)
+// (measured per application on a lattice agent: 4 -> 105 us, 8 -> 102, 16 -> 106; with the round-4 ordering 8 -> 90.4,
+// 16 -> 89.5, sphere2500 26.5 / 28.0)
 constexpr int steps_per_wave() { return 8; }
 
 }  // namespace
@@ -127,10 +128,19 @@ void layout_mpipe(const std::vector<Piece> &pc, const std::vector<const double *
   }
   const auto T1 = tnow();
 
-  // ---- which levels merge.  Levels below the top: 0 .. nlo - 1; the top level is a launch of its own. ----
+  // ---- which levels merge.  Levels below the top: 0 .. nlo - 1; the top level is a launch of its own.
+  //      A GROUP is a run of consecutive levels [lo, hi] applied by ONE forward and ONE backward launch.  With
+  //      apply_L(X) = X + sum_{q on level L} W_q X[rows of q], a piece s of the group on level l < hi contributes to
+  //      everything above it through V_s = apply_hi(... apply_{l+1}(W_s)) = W_s + sum_{q in the group above s} V_q W_s[q]
+  //      (V_q = W_q on level hi): the sources of the group's forward launch read their values from BEFORE the launch, the
+  //      propagation inside the group is in the matrices.  Backward: x_s = M_s y_s + sum_{q in the group above s}
+  //      V_s[q]^T (M_q y_q) + V_s[above]^T x_above.  Pairs (round 3) are the groups of two levels; round 4 merges on while a
+  //      merge costs fewer streamed bytes than the two launches it saves are worth. ----
   const int nlo = nlev - 1;
-  std::vector<std::vector<int>> merged_rows((size_t)np);  // rows of V_s for the lower pieces of CHOSEN pairs
-  auto union_rows = [&](int s, int t, std::vector<int> *rows_out, double *flops) {
+  std::vector<std::vector<int>> merged_rows((size_t)np);  // rows of V_s for the pieces of CHOSEN groups (below their top level)
+  // rows of V_s for s on level l of the group [lo, hi], given the rows of the pieces above it in the group (rows_of)
+  auto union_rows = [&](int s, int hi, const std::vector<std::vector<int>> &rows_of, std::vector<int> *rows_out,
+                        double *flops) {
     const Piece &ps = pc[s];
     std::vector<int> acc(ps.rows);
     int last = -1;
@@ -138,123 +148,125 @@ void layout_mpipe(const std::vector<Piece> &pc, const std::vector<const double *
       const int q = piece_of[ps.rows[a]];
       if (q == last) continue;
       last = q;
-      if (pc[q].level != t + 1) continue;
+      if (pc[q].level <= ps.level || pc[q].level > hi) continue;
       size_t b = a;
       while (b < ps.rows.size() && piece_of[ps.rows[b]] == q) ++b;
-      if (flops) *flops += 2.0 * (double)pc[q].rows.size() * (double)(b - a) * ps.c;
+      const std::vector<int> &rq = rows_of[(size_t)q].empty() ? pc[q].rows : rows_of[(size_t)q];
+      if (flops) *flops += 2.0 * (double)rq.size() * (double)(b - a) * ps.c;
       std::vector<int> tmp;
-      tmp.reserve(acc.size() + pc[q].rows.size());
-      std::set_union(acc.begin(), acc.end(), pc[q].rows.begin(), pc[q].rows.end(), std::back_inserter(tmp));
+      tmp.reserve(acc.size() + rq.size());
+      std::set_union(acc.begin(), acc.end(), rq.begin(), rq.end(), std::back_inserter(tmp));
       acc.swap(tmp);
     }
     rows_out->swap(acc);
   };
-  // the fill of a pair is stored once and streamed by both sweeps
-  std::vector<double> pair_bytes((size_t)std::max(nlo, 1), 0.0), pair_flops((size_t)std::max(nlo, 1), 0.0);
-  for (int t = 0; t + 1 < nlo; ++t) {
-      std::vector<int> rows;
-      for (int s : by_level[t]) {
-        union_rows(s, t, &rows, &pair_flops[t]);
-        pair_bytes[t] += 16.0 * (double)(rows.size() - pc[s].rows.size()) * pc[s].c;
+  // streamed bytes (stored once, read by both sweeps) and set-up flops a group [lo, hi] adds over its unmerged levels
+  auto group_cost = [&](int lo, int hi, double *bytes, double *flops) {
+    *bytes = 0;
+    *flops = 0;
+    std::vector<std::vector<int>> rows_of((size_t)np);
+    for (int l = hi - 1; l >= lo; --l)
+      for (int s : by_level[(size_t)l]) {
+        std::vector<int> R;
+        union_rows(s, hi, rows_of, &R, flops);
+        *bytes += 16.0 * (double)(R.size() - pc[s].rows.size()) * pc[s].c;
+        if (R.size() != pc[s].rows.size()) rows_of[(size_t)s].swap(R);
       }
-    }
-  // a launch saved is worth a dependent launch boundary plus the ramp of a burst (~3 us = ~15 MB at the streaming rate)
-  const double max_bytes = 30e6;
-  static const double max_flops = 12e9;
-  auto pair_ok = [&](int t) { return pair_bytes[t] <= max_bytes && pair_flops[t] <= max_flops; };
-  std::vector<int> is_pair_lo((size_t)std::max(nlo, 1), 0);
-  {
-    std::vector<int> cnt((size_t)nlo + 2, 0);
-    std::vector<double> cost((size_t)nlo + 2, 0.0);
-    std::vector<char> take((size_t)nlo + 2, 0);
-    for (int i = nlo - 1; i >= 0; --i) {
-      cnt[i] = cnt[i + 1];
-      cost[i] = cost[i + 1];
-      take[i] = 0;
-      if (i + 1 < nlo && pair_ok(i)) {
-        const int c2 = cnt[i + 2] + 1;
-        const double b2 = cost[i + 2] + pair_bytes[i];
-        if (c2 > cnt[i] || (c2 == cnt[i] && b2 < cost[i])) {
-          cnt[i] = c2;
-          cost[i] = b2;
-          take[i] = 1;
-        }
-      }
-    }
-    for (int i = 0; i < nlo;) {
-      if (take[i]) {
-        is_pair_lo[i] = 1;
-        i += 2;
-      } else {
-        i += 1;
-      }
-    }
-  }
+  };
   struct Group {
-    int lo, hi;  // hi = -1: single level
+    int lo, hi;  // levels lo .. hi (hi == lo: a single level)
+    double bytes = 0, flops = 0;
   };
   std::vector<Group> groups;
-  for (int i = 0; i < nlo;) {
-    if (is_pair_lo[i]) {
-      groups.push_back({i, i + 1});
-      i += 2;
-    } else {
-      groups.push_back({i, -1});
-      i += 1;
+  for (int i = 0; i < nlo; ++i) groups.push_back(Group{i, i});
+  {
+    // a launch saved is worth a dependent launch boundary plus the ramp of a burst: two launches (forward + backward)
+    // ~ 13 us ~ 60 MB at the streaming rate; a merge is taken while its fill costs half of that at most (the fill is
+    // also set-up work: products on the host, bytes on the device) and its products stay below 12 Gflop.  Cheapest
+    // merge first; at most four levels per group.
+    const double max_bytes = 30e6, max_flops = 12e9;
+    for (;;) {
+      int best = -1;
+      double best_extra = 0, bb = 0, bf = 0;
+      for (size_t g = 0; g + 1 < groups.size(); ++g) {
+        const Group &A = groups[g], &B = groups[g + 1];
+        if (B.hi - A.lo + 1 > 4) continue;
+        double by, fl;
+        group_cost(A.lo, B.hi, &by, &fl);
+        const double extra = by - A.bytes - B.bytes;
+        if (extra > max_bytes || fl > max_flops) continue;
+        if (best < 0 || extra < best_extra) {
+          best = (int)g;
+          best_extra = extra;
+          bb = by;
+          bf = fl;
+        }
+      }
+      if (best < 0) break;
+      groups[(size_t)best].hi = groups[(size_t)best + 1].hi;
+      groups[(size_t)best].bytes = bb;
+      groups[(size_t)best].flops = bf;
+      groups.erase(groups.begin() + best + 1);
     }
   }
   const int NG = (int)groups.size();
   const int NL = 2 * NG + 1;  // forward groups, the top, backward groups
+  std::vector<int> group_of_level((size_t)std::max(nlev, 1), -1);
+  for (int g = 0; g < NG; ++g)
+    for (int l = groups[(size_t)g].lo; l <= groups[(size_t)g].hi; ++l) group_of_level[(size_t)l] = g;
 
-  // ---- V_s of the lower pieces of merged pairs: rows(s) united with the rows of the level-(t+1) pieces s feeds ----
+  // ---- V_s of the pieces below the top level of their group, the highest level first ----
   std::vector<std::vector<double>> Vown((size_t)np);
-  {
-    std::vector<int> todo;
-    for (const Group &g : groups)
-      if (g.hi >= 0)
-        for (int s : by_level[g.lo]) todo.push_back(s);
-    std::sort(todo.begin(), todo.end(), [&](int a, int b) {
-      return (double)pc[a].c * pc[a].rows.size() > (double)pc[b].c * pc[b].rows.size();
-    });
-    parallel_for((int)todo.size(), nthreads, 1, [&](int ti) {
-      const int s = todo[(size_t)ti];
-      const Piece &ps = pc[s];
-      const int t = ps.level, c = ps.c, m = (int)ps.rows.size();
-      std::vector<int> &R = merged_rows[s];
-      union_rows(s, t, &R, nullptr);
-      std::vector<double> &V = Vown[s];
-      V.assign(R.size() * (size_t)c, 0.0);
-      {
-        size_t u = 0;
-        for (int a = 0; a < m; ++a) {
-          while (R[u] != ps.rows[a]) ++u;
-          std::copy(ps.w() + (size_t)a * c, ps.w() + (size_t)a * c + c, &V[u * c]);
-        }
-      }
-      for (int a = 0; a < m;) {
-        const int q = piece_of[ps.rows[a]];
-        int b = a;
-        while (b < m && piece_of[ps.rows[b]] == q) ++b;
-        if (pc[q].level == t + 1) {
-          const Piece &pq = pc[q];
-          const int cq = pq.c, mq = (int)pq.rows.size();
+  for (const Group &g : groups)
+    for (int l = g.hi - 1; l >= g.lo; --l) {
+      std::vector<int> todo(by_level[(size_t)l]);
+      std::sort(todo.begin(), todo.end(), [&](int a, int b) {
+        return (double)pc[a].c * pc[a].rows.size() > (double)pc[b].c * pc[b].rows.size();
+      });
+      parallel_for((int)todo.size(), nthreads, 1, [&](int ti) {
+        const int s = todo[(size_t)ti];
+        const Piece &ps = pc[s];
+        const int c = ps.c, m = (int)ps.rows.size();
+        std::vector<int> R;
+        union_rows(s, g.hi, merged_rows, &R, nullptr);
+        std::vector<double> &V = Vown[s];
+        V.assign(R.size() * (size_t)c, 0.0);
+        {
           size_t u = 0;
-          for (int bb = 0; bb < mq; ++bb) {
-            while (R[u] != pq.rows[bb]) ++u;
-            double *dst = &V[u * c];
-            const double *wq = pq.w() + (size_t)bb * cq;
-            for (int aa = a; aa < b; ++aa) {
-              const double coef = wq[ps.rows[aa] - pq.c0];
-              if (coef == 0.0) continue;
-              const double *ws = ps.w() + (size_t)aa * c;
-              for (int j = 0; j < c; ++j) dst[j] += coef * ws[j];
-            }
+          for (int a = 0; a < m; ++a) {
+            while (R[u] != ps.rows[a]) ++u;
+            std::copy(ps.w() + (size_t)a * c, ps.w() + (size_t)a * c + c, &V[u * c]);
           }
         }
-        a = b;
-      }
-    });
-  }
+        for (int a = 0; a < m;) {
+          const int q = piece_of[ps.rows[a]];
+          int b = a;
+          while (b < m && piece_of[ps.rows[b]] == q) ++b;
+          if (pc[q].level > l && pc[q].level <= g.hi) {
+            // V_q of a piece above s in the group (its own W on the group's top level)
+            const Piece &pq = pc[q];
+            const bool mq_merged = !merged_rows[(size_t)q].empty();
+            const std::vector<int> &rq = mq_merged ? merged_rows[(size_t)q] : pq.rows;
+            const double *vq = mq_merged ? Vown[(size_t)q].data() : pq.w();
+            const int cq = pq.c, mq = (int)rq.size();
+            size_t u = 0;
+            for (int bb = 0; bb < mq; ++bb) {
+              while (R[u] != rq[(size_t)bb]) ++u;
+              double *dst = &V[u * c];
+              const double *wq = vq + (size_t)bb * cq;
+              for (int aa = a; aa < b; ++aa) {
+                const double coef = wq[ps.rows[aa] - pq.c0];
+                if (coef == 0.0) continue;
+                const double *ws = ps.w() + (size_t)aa * c;
+                for (int j = 0; j < c; ++j) dst[j] += coef * ws[j];
+              }
+            }
+          }
+          a = b;
+        }
+        merged_rows[(size_t)s].swap(R);  // (written by the one thread that owns s; pieces above s were finished a level ago)
+      });
+    }
   const auto T2 = tnow();
 
   auto source_of = [&](int s) {
@@ -356,9 +368,8 @@ void layout_mpipe(const std::vector<Piece> &pc, const std::vector<const double *
     const Group &G = groups[g];
     Launch &Ln = L[(size_t)g];
     std::vector<Source> srcs;
-    for (int s : by_level[G.lo]) srcs.push_back(source_of(s));
-    if (G.hi >= 0)
-      for (int s : by_level[G.hi]) srcs.push_back(source_of(s));
+    for (int l = G.lo; l <= G.hi; ++l)
+      for (int s : by_level[(size_t)l]) srcs.push_back(source_of(s));
     for (int s : by_level[G.lo]) {
       ybuf[s] = cur[s];
       m_first[s] = g;
@@ -416,8 +427,8 @@ void layout_mpipe(const std::vector<Piece> &pc, const std::vector<const double *
     }
     for (int i : hit_rows) hits[i].clear();
     for (int q : affected) cur[q] ^= 1;
-    if (G.hi >= 0)
-      for (int s : by_level[G.hi]) {
+    for (int l = G.lo + 1; l <= G.hi; ++l)
+      for (int s : by_level[(size_t)l]) {
         ybuf[s] = cur[s];
         m_first[s] = g + 1;
         m_last[s] = 2 * NG - g - 1;
@@ -433,7 +444,7 @@ void layout_mpipe(const std::vector<Piece> &pc, const std::vector<const double *
   for (int g = NG - 1; g >= 0; --g) {
     const Group &G = groups[g];
     Launch &Ln = L[(size_t)(2 * NG - g)];
-    auto emit = [&](int s, int pair_hi_level) {
+    auto emit = [&](int s) {
       const Piece &p = pc[s];
       const Source S = source_of(s);
       if (S.m == 0) return;
@@ -442,8 +453,9 @@ void layout_mpipe(const std::vector<Piece> &pc, const std::vector<const double *
       const int idx0 = (int)P.idxs.size();
       for (int a = 0; a < S.m; ++a) {
         const int i = S.rows[a], q = piece_of[i];
-        // a row of the pair's upper level: its z (the pair's launch computes x_q at the same time); else the final x
-        const bool upper = pc[q].level == pair_hi_level;
+        // a row of a piece above s in the SAME group: its z = M_q y_q (this launch computes x_q at the same time);
+        // else the final x
+        const bool upper = pc[q].level > p.level && pc[q].level <= G.hi;
         const int b = upper ? 1 - ybuf[q] : (pc[q].rows.empty() ? 1 - ybuf[q] : ybuf[q]);
         P.idxs.push_back(pos(b, i));
       }
@@ -466,9 +478,8 @@ void layout_mpipe(const std::vector<Piece> &pc, const std::vector<const double *
         push_task(Ln, T, std::vector<MSeg>(1, Wt));
       }
     };
-    if (G.hi >= 0)
-      for (int s : by_level[G.hi]) emit(s, -1);
-    for (int s : by_level[G.lo]) emit(s, G.hi);
+    for (int l = G.hi; l >= G.lo; --l)
+      for (int s : by_level[(size_t)l]) emit(s);
   }
   // ---- M tiles, spread: earliest deadline first, up to an even share of the bytes that are left ----
   {
@@ -658,9 +669,9 @@ void layout_mpipe(const std::vector<Piece> &pc, const std::vector<const double *
                  nlev, NG, NL, 8e-6 * (double)cursor, 8e-6 * weights, tms(T0, T1), tms(T1, T2), tms(T2, T3),
                  tms(T3, tnow()));
     for (int g = 0; g < NG; ++g)
-      if (groups[g].hi >= 0)
-        std::fprintf(stderr, "[partinv3]   pair (%d,%d): fill %.2f MB, %.2f Gflop\n", groups[g].lo, groups[g].hi,
-                     1e-6 * pair_bytes[groups[g].lo], 1e-9 * pair_flops[groups[g].lo]);
+      if (groups[g].hi > groups[g].lo)
+        std::fprintf(stderr, "[partinv3]   levels %d..%d in one launch: fill %.2f MB, %.2f Gflop\n", groups[g].lo,
+                     groups[g].hi, 1e-6 * groups[g].bytes, 1e-9 * groups[g].flops);
     std::fprintf(stderr, "[partinv3]   %lld wave records (%lld chained)\n", n_records, n_chained);
     for (size_t li = 0; li < P.levels.size(); ++li) {
       const SpLevel &lv = P.levels[li];

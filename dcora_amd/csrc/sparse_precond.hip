@@ -128,6 +128,10 @@ __global__ __launch_bounds__(kBlock) void k_sp_permute_out_hub(int r, int k, con
 typedef double sp_v2f64u __attribute__((ext_vector_type(2), aligned(8)));  // a pair of vector values: 8-byte aligned
 constexpr int kMtBlock = kMtWaves * 64;
 
+template <typename T>
+__device__ __forceinline__ const T *mt_at(const void *base, unsigned byte_offset) {
+  return reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_offset);
+}
 // what a lane needs to address one run
 struct MtRun {
   const double *W;
@@ -193,18 +197,20 @@ __device__ __forceinline__ void mt_record(const MtRun &a, const MtRun &b, int kq
       if (KIND == 0)
         p[u] = (ina ? a.src : b.src) + 4 * gc + kq;
       else
-        p[u] = (ina ? a.ix : b.ix)[4 * gc + kq];
+        p[u] = *mt_at<int>(ina ? a.ix : b.ix, 4u * (unsigned)(4 * gc + kq));
     }
+    // (uniform base + 32-bit byte offset: the address arithmetic of a load is one 32-bit multiply-add instead of a
+    // 64-bit one -- a wave spends most of its vector instructions on addresses)
 #pragma unroll
-    for (int u = 0; u < U; ++u) av[u] = ok[u] ? wp[u][ao[u]] : 0.0;
+    for (int u = 0; u < U; ++u) av[u] = ok[u] ? *mt_at<double>(wp[u], 8u * (unsigned)ao[u]) : 0.0;
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         if (HALF)  // r <= 4: lane j holds column j, one 8-byte load
-          bv[u][c].x = y[(size_t)(p[u] * r + jj)];
+          bv[u][c].x = *mt_at<double>(y, 8u * (unsigned)(p[u] * r + jj));
         else
-          bv[u][c] = *reinterpret_cast<const sp_v2f64u *>(y + (size_t)(p[u] * r + jj + 8 * c));
+          bv[u][c] = *mt_at<sp_v2f64u>(y, 8u * (unsigned)(p[u] * r + jj + 8 * c));
       }
 #pragma unroll
     for (int u = 0; u < U; ++u)
