@@ -178,36 +178,36 @@ void layout_mpipe(const std::vector<Piece> &pc, const std::vector<const double *
     double bytes = 0, flops = 0;
   };
   std::vector<Group> groups;
-  for (int i = 0; i < nlo; ++i) groups.push_back(Group{i, i});
   {
-    // a launch saved is worth a dependent launch boundary plus the ramp of a burst: two launches (forward + backward)
-    // ~ 13 us ~ 60 MB at the streaming rate; a merge is taken while its fill costs half of that at most (the fill is
-    // also set-up work: products on the host, bytes on the device) and its products stay below 12 Gflop.  Cheapest
-    // merge first; at most four levels per group.
-    const double max_bytes = 30e6, max_flops = 12e9;
-    for (;;) {
-      int best = -1;
-      double best_extra = 0, bb = 0, bf = 0;
-      for (size_t g = 0; g + 1 < groups.size(); ++g) {
-        const Group &A = groups[g], &B = groups[g + 1];
-        if (B.hi - A.lo + 1 > 4) continue;
-        double by, fl;
-        group_cost(A.lo, B.hi, &by, &fl);
-        const double extra = by - A.bytes - B.bytes;
-        if (extra > max_bytes || fl > max_flops) continue;
-        if (best < 0 || extra < best_extra) {
-          best = (int)g;
-          best_extra = extra;
-          bb = by;
-          bf = fl;
+    // The grouping that minimises  launch pairs x 10 us + fill / 4 TB/s  over all splits of the levels into runs of at
+    // most four (dynamic programme over the level boundaries); the fill of a group is stored once and streamed by both
+    // sweeps; set-up products of a group stay below 12 Gflop.  Calibrated on a lattice agent (8 levels below the top):
+    // {0} {1..4} {5..7}, 7 launches and 38 MB of fill: 89 us per application; {0,1} {2..7}, 5 launches and 109 MB: 96 us;
+    // pairs, 9 launches and 36 MB: 91 us.
+    const double us_per_launch_pair = 10.0, bytes_per_us = 4e6, max_flops = 12e9;
+    const int kMaxRun = 4;
+    std::vector<std::vector<Group>> cand((size_t)std::max(nlo, 1));  // cand[lo][len - 1]
+    for (int lo = 0; lo < nlo; ++lo)
+      for (int len = 1; len <= kMaxRun && lo + len <= nlo; ++len) {
+        Group g{lo, lo + len - 1};
+        if (len > 1) group_cost(g.lo, g.hi, &g.bytes, &g.flops);
+        cand[(size_t)lo].push_back(g);
+      }
+    std::vector<double> best((size_t)nlo + 1, 1e300);
+    std::vector<int> from((size_t)nlo + 1, -1);
+    best[0] = 0;
+    for (int i = 1; i <= nlo; ++i)
+      for (int len = 1; len <= kMaxRun && len <= i; ++len) {
+        const Group &g = cand[(size_t)(i - len)][(size_t)len - 1];
+        if (g.flops > max_flops) continue;
+        const double c = best[(size_t)(i - len)] + us_per_launch_pair + g.bytes / bytes_per_us;
+        if (c < best[(size_t)i]) {
+          best[(size_t)i] = c;
+          from[(size_t)i] = len;
         }
       }
-      if (best < 0) break;
-      groups[(size_t)best].hi = groups[(size_t)best + 1].hi;
-      groups[(size_t)best].bytes = bb;
-      groups[(size_t)best].flops = bf;
-      groups.erase(groups.begin() + best + 1);
-    }
+    for (int i = nlo; i > 0; i -= from[(size_t)i]) groups.push_back(cand[(size_t)(i - from[(size_t)i])][(size_t)from[(size_t)i] - 1]);
+    std::reverse(groups.begin(), groups.end());
   }
   const int NG = (int)groups.size();
   const int NL = 2 * NG + 1;  // forward groups, the top, backward groups
