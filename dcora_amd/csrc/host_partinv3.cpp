@@ -61,7 +61,8 @@ struct Source {        // what a piece contributes to the rows above it in one f
 
 // steps a wave should get: it requests the loads of up to eight steps together, so eight steps are one memory round trip
 // (measured per application on a lattice agent: 4 -> 105 us, 8 -> 102, 16 -> 106; with the round-4 ordering 8 -> 90.4,
-// 16 -> 89.5, sphere2500 26.5 / 28.0)
+// 16 -> 89.5, sphere2500 26.5 / 28.0; the whole lattice as one problem, 3.6 GB per application: 8 / 16 / 32 -> 1.10 /
+// 1.08 / 1.09 ms -- the number of waves is not what bounds the replay at either size)
 constexpr int steps_per_wave() { return 8; }
 
 }  // namespace
