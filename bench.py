@@ -682,11 +682,20 @@ def roofline(da, ds, r, robots):
     else:
         main["traffic_note"] = "no committed PMC pass found under profiles/"
     Pb.close()
-    try:  # the same kernel on a block 2.5 x larger (sphere2500 split in two, k = 5000): a longer launch
+    try:  # the dense kernel on a block 2.5 x larger (sphere2500 split in two, k = 5000): a longer launch.  The library
+        # would take the sparse preconditioner at this size (crossover 2200 since round 4): dense is forced for this entry
         nb2, ids2, vals2 = agent_block(ds, 2, 0)
         Q2 = da.build_Q_pgo(ds, n=nb2, agent=0, ids=ids2, vals=vals2)
         k2 = (ds.d + 1) * nb2
-        P2 = da.QuadraticProblem(r, ds.d, nb2, Q2, G=np.zeros((r, k2)), reg=0.1)
+        saved = os.environ.get("DCORA_PRECOND")
+        os.environ["DCORA_PRECOND"] = "dense"
+        try:
+            P2 = da.QuadraticProblem(r, ds.d, nb2, Q2, G=np.zeros((r, k2)), reg=0.1)
+        finally:
+            if saved is None:
+                os.environ.pop("DCORA_PRECOND", None)
+            else:
+                os.environ["DCORA_PRECOND"] = saved
         P2.f(np.zeros((r, k2)))
         ms2, nbytes2 = P2.time_precond(reps=100)
         kind2 = P2.precond_info()["kind"]

@@ -109,9 +109,12 @@ struct DevCsr {
 };
 
 // device image of the partitioned inverse (sparse_precond.h) and its level-by-level replay
-// above this the preconditioner is the partitioned sparse inverse (measured crossover on MI355X, r = 5: dense
-// 42 us vs sparse 75 us at k = 5000, dense 158 us vs sparse 97 us at k = 10000)
-constexpr int kDensePrecondMaxK = 8000;
+// above this the preconditioner is the partitioned sparse inverse.  Measured on MI355X in round 4 (RBCD iterations/s of
+// sphere2500 split into 5 / 4 / 3 / 2 agents, tools/bench_crossover.py), dense against sparse:
+//   k = 2000: 1849 / 1297 (r = 5), 821 / 560 (r = 3), 1466 / 1489 (r = 7)  -- the one-launch form k_fused_pc exists there
+//   k = 2500: 1018 / 1112, 487 / 536, 1025 / 1154;  k = 3336: 654 / 784;  k = 5000: 209 / 355
+// (rounds 1-3, with the replay and the ordering of the time: 8000)
+constexpr int kDensePrecondMaxK = 2200;
 
 // immutable device image of a partitioned inverse: shared between the problems that precondition with the same
 // Q + reg I (the staircase levels, problems re-created per update) through the cache of precond_cache.h

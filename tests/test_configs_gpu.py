@@ -320,8 +320,9 @@ def test_large_single_problem_reports_the_cost_of_its_iterates(env):
 
 
 @pytest.mark.parametrize("dims,r,expect", [
-    ((10, 10, 20), 5, ("dense", "k_spmm")),       # k = 8000: the largest dense preconditioner
-    ((3, 23, 29), 5, ("sparse", "k_spmm")),       # k = 8004: the first sparse one
+    ((5, 10, 11), 5, ("dense", "k_spmm")),        # k = 2200: the largest dense preconditioner
+    ((1, 19, 29), 5, ("sparse", "k_spmm")),       # k = 2204: the first sparse one
+    ((10, 10, 20), 5, ("sparse", "k_spmm")),      # k = 8000 (dense until round 4)
     ((13, 21, 30), 5, ("sparse", "k_spmm")),      # n = 8190: the last CSR Q-apply
     ((16, 16, 32), 5, ("sparse", "k_spmm_bsr2")),  # n = 8192: the first block-CSR one
     ((32, 32, 24), 5, ("sparse", "k_spmm_bsr2")),  # n = 24576: 2048 pose blocks, the last fused solve at r = 5

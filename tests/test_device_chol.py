@@ -81,7 +81,7 @@ def test_device_tiny_matrices(built):
 
 @pytest.mark.gpu
 def test_dense_inverse_built_on_the_device(built):
-    """the dense preconditioner (k <= 8000) is formed by the device (LL^T, L^-1, L^-T L^-1): against a direct solve"""
+    """the dense preconditioner (k <= 2200) is formed by the device (LL^T, L^-1, L^-T L^-1): against a direct solve"""
     import dcora_amd as da
     if os.environ.get("DCORA_PRECOND"):
         pytest.skip("DCORA_PRECOND overrides the choice of preconditioner this test is about")
