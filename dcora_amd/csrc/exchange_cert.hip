@@ -147,7 +147,10 @@ int Exchange::certify(const HostCsr *Qglobal, double eta, int *certified, double
   }
   rc = allreduce_sum(verdict, 2);  // the other ranks add zeros: a broadcast
   if (rc) return rc;
-  if (verdict[1] != 0) return fail("certify: the PSD test failed on rank 0 (global Q missing?)", (int)verdict[1]);
+  // (every rank learns the code from the sum above and leaves the call together: a missing Q on rank 0 is a usage error
+  // of the caller, not a failure of the job)
+  if ((int)verdict[1] == DCORA_ERR_BAD_ARG) return usage("certify: rank 0 needs the global Q", DCORA_ERR_BAD_ARG);
+  if (verdict[1] != 0) return fail("certify: the PSD test failed on rank 0", (int)verdict[1]);
   if (verdict[0] == 1) {
     if (certified) *certified = 1;
     return DCORA_OK;

@@ -64,6 +64,16 @@ def main():
     assert ex.all_ready(True) is True
     assert ex.all_ready(rank != world - 1) is False
     cert = None
+    if os.environ.get("DCORA_TEST_CERTIFY_USAGE"):
+        # a usage error of certify (no global Q on rank 0) is reported on every rank and does NOT poison the job: the
+        # exchange keeps working afterwards
+        try:
+            ex.certify(None, 1e-3, (ds.d + 1) * ds.n)
+            raise SystemExit("certify accepted a call without the global Q")
+        except RuntimeError as e:
+            assert "global Q" in str(e), str(e)
+        c2, g, bn, nxt = ex.evaluate()
+        assert np.isfinite(c2) and np.isfinite(g)
     if os.environ.get("DCORA_TEST_CERTIFY"):
         eta = float(os.environ["DCORA_TEST_CERTIFY"])
         Q = da.build_Q_pgo(ds) if rank == 0 else None

@@ -277,3 +277,16 @@ def test_link_check_that_cannot_pass_fails_fast_on_every_rank(tmp_path):
                     extra_env={"DCORA_TEST_PROBE_FAULT": "9", "DCORA_TEST_EXPECT_LINK_ERROR": "1"})
     for o in res:
         assert "link check" in str(o["error"]) and float(o["seconds"]) < 60
+
+
+def test_a_usage_error_of_certify_does_not_poison_the_job(tmp_path):
+    """certify without the global Q on rank 0: every rank gets the usage error, the exchange goes on working and a
+    proper certify afterwards gives the one-GPU verdict (such errors used to mark the job as failed)"""
+    import dcora_amd as da
+    name, R, world, iters, r = "sphere2500", 5, 2, 3, 5
+    ds = common.product_dataset(name)
+    X0 = common.random_point(r, ds.d, ds.n, 11, lambda r_, d_, n_, M: da.manifold_project(r_, d_, n_, M))
+    res = run_ranks(str(tmp_path), world, name, R, r, iters, "greedy", X0, certify=1e-3,
+                    extra_env={"DCORA_TEST_CERTIFY_USAGE": "1"})
+    for o in res:
+        assert not bool(o["cert_ok"]) and int(o["cert_matvecs"]) > 0
