@@ -846,6 +846,20 @@ def config5_run(da, with_cpu, iters=60, cpu_iters=4):
     res = {"workload": "synthetic 50x50x40 SE(3) lattice (100000 poses, %d edges, seed 20250310), 8 agents, r=5" % ds.m,
            "iterations": iters, "value": iters / dt, "unit": "RBCD iterations/s", "ms_per_step": 1e3 * dt / iters,
            "setup_s": setup_s, "cost_2f_first": float(out["cost"][0]), "cost_2f_last": float(out["cost"][-1])}
+    def solver_work(sess, X, n):
+        """untimed: the same iterations once more with the selected agent's solver statistics read back after each
+        (dcora_rbcd_last_result) -- what an RBCD iteration of this stretch of the trajectory holds"""
+        sess.set_X(X)
+        sel = sess.evaluate()[3]
+        outer = inner = 0
+        for _ in range(n):
+            sel = sess.iterate(sel)[3]
+            lr = sess.last_result()
+            outer += int(lr["outer_iterations"])
+            inner += int(lr["inner_iterations"])
+        return {"rtr_outer_per_iteration": outer / n, "tcg_per_iteration": inner / n}
+
+    res["solver_work"] = solver_work(s, X0, iters)
     try:
         res["coloured_rbcd"] = coloured_sweeps(SingleDriver(s), X0, sweeps=8, warm=1)
     except Exception as e:
@@ -855,7 +869,11 @@ def config5_run(da, with_cpu, iters=60, cpu_iters=4):
     # the next levels of the Riemannian staircase (BASELINE: r = 5..7): the same loop at r = 6 and 7 from the r = 5
     # iterate embedded in the higher rank (zero rows appended, as escapeSaddle's lift does before its step); the
     # agents' preconditioners come from the cache (they do not depend on r)
-    res["staircase_ranks"] = {"5": {"value": res["value"], "ms_per_step": res["ms_per_step"], "setup_s": setup_s}}
+    res["staircase_ranks"] = {"5": {"value": res["value"], "ms_per_step": res["ms_per_step"], "setup_s": setup_s,
+                                    **res["solver_work"]},
+                              "note": "ranks 6 and 7 start where rank 5 stopped: a later stretch of the trajectory, whose "
+                                      "local solves run about twice the tCG iterations (tcg_per_iteration) -- the lower "
+                                      "rate is solver work, the kernels cost the same per call"}
     for rr in (6, 7):
         try:
             t0 = time.perf_counter()
@@ -868,9 +886,10 @@ def config5_run(da, with_cpu, iters=60, cpu_iters=4):
             t0 = time.perf_counter()
             o2 = sr.run(max_iters=30, rgrad_tol=0.0)
             d2 = time.perf_counter() - t0
+            work = solver_work(sr, Xr, 30)
             sr.close()
             res["staircase_ranks"][str(rr)] = {"value": 30 / d2, "ms_per_step": 1e3 * d2 / 30, "setup_s": st_s,
-                                               "cost_2f_last": float(o2["cost"][-1])}
+                                               "cost_2f_last": float(o2["cost"][-1]), **work}
         except Exception as e:
             res["staircase_ranks"][str(rr)] = {"error": str(e)}
     if with_cpu:

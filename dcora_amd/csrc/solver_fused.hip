@@ -156,36 +156,118 @@ __device__ __forceinline__ void row_qf(Row<D> &A) {
     A.e[j] *= 1.0 / sqrt(nn);
   }
 }
-// polar factor of the rotation part by one-sided Jacobi (wave-uniform sweep loop)
+// polar factor of the rotation part.  The RBCD++ sequences hand in blocks that are orthonormal up to the size of a
+// step ((1 - alpha) x + alpha v, v + gamma (x - y): ref src/Agent.cpp:1196-1214 project them with a thin SVD), so the
+// common case runs on the Gram matrix: G = A^T A by D (D + 1) / 2 group sums, Z = G^(-1/2) by the coupled Newton-Schulz
+// iteration (Y <- Y T, Z <- T Z, T = (3 I - Z Y) / 2: products of D x D symmetric matrices in registers, no division, no
+// square root, nothing crosses lanes), A <- A Z.  G is the same in the eight lanes of a pose, so they take the same
+// steps; the iteration converges quadratically for |I - G| < 1 and the Gram form loses nothing at condition numbers
+// near one.  Blocks further than kPolarGramRadius from orthonormal (set_X of a rough point, a long step) take the
+// one-sided Jacobi sweeps below, as every block did before: k_g_nesterov over the 100k lattice 36 us with Jacobi for all
+// (the sweeps' divisions and square roots, 12 waves deep per SIMD, not the memory), with this form see DESIGN.md.
+constexpr double kPolarGramRadius = 0.25;
+template <int D>
+__device__ __forceinline__ void sym_mul(const double (&A)[D][D], const double (&B)[D][D], double (&C)[D][D]) {
+  // the product of two commuting symmetric matrices is symmetric: upper triangle, mirrored
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int b = a; b < D; ++b) {
+      double s = 0;
+#pragma unroll
+      for (int c = 0; c < D; ++c) s += A[a][c] * B[c][b];
+      C[a][b] = s;
+      C[b][a] = s;
+    }
+}
 template <int D>
 __device__ __forceinline__ void row_polar(Row<D> &A, bool live) {
+  double G[D][D];
+  double dist2 = 0;
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int b = a; b < D; ++b) {
+      const double s = grp_sum(A.e[a] * A.e[b]);
+      G[a][b] = s;
+      G[b][a] = s;
+      const double e = s - (a == b ? 1.0 : 0.0);
+      dist2 += (a == b ? 1.0 : 2.0) * e * e;
+    }
+  const bool gram = live && dist2 <= kPolarGramRadius * kPolarGramRadius;  // the same in the lanes of a pose
+  if (gram) {
+    double Y[D][D], Z[D][D];
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int b = 0; b < D; ++b) {
+        Y[a][b] = G[a][b];
+        Z[a][b] = (a == b) ? 1.0 : 0.0;
+      }
+    for (int it = 0; it < 12; ++it) {
+      double T[D][D], ZY[D][D], Yn[D][D], Zn[D][D];
+      sym_mul<D>(Z, Y, ZY);
+      double e2 = 0;
+#pragma unroll
+      for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b < D; ++b) {
+          const double rr = (a == b ? 1.0 : 0.0) - ZY[a][b];
+          e2 += rr * rr;
+          T[a][b] = (a == b ? 1.0 : 0.0) + 0.5 * rr;
+        }
+      sym_mul<D>(Y, T, Yn);
+      sym_mul<D>(T, Z, Zn);
+#pragma unroll
+      for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b < D; ++b) {
+          Y[a][b] = Yn[a][b];
+          Z[a][b] = Zn[a][b];
+        }
+      if (e2 < 1e-16) break;  // |I - Z Y| < 1e-8 before this step: below 1e-16 after it
+    }
+    double o[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      double s = 0;
+#pragma unroll
+      for (int j = 0; j < D; ++j) s += A.e[j] * Z[j][c];
+      o[c] = s;
+    }
+#pragma unroll
+    for (int c = 0; c < D; ++c) A.e[c] = o[c];
+  }
+  // one-sided Jacobi for the others.  The sweep loop is wave-uniform (the group sums are cross-lane operations), but a
+  // pose stops rotating once ITS sweep has converged: the result of a pose must not depend on which poses share its
+  // wave (a launch over one agent's poses and a launch over the whole graph place a pose next to different neighbours).
+  bool settled = !live || gram;
+  if (__all(settled)) return;
+  const bool jacobi = !settled;
   double Vm[D][D];
 #pragma unroll
   for (int a = 0; a < D; ++a)
 #pragma unroll
     for (int b = 0; b < D; ++b) Vm[a][b] = (a == b) ? 1.0 : 0.0;
-  // The sweep loop is wave-uniform (the group sums are cross-lane operations), but a pose stops rotating once ITS
-  // sweep has converged: the result of a pose must not depend on which poses share its wave (a launch over one
-  // agent's poses and a launch over the whole graph place a pose next to different neighbours).
-  bool settled = !live;
+  Row<D> B = A;
   for (int sweep = 0; sweep < 40; ++sweep) {
     double off = 0;
 #pragma unroll
     for (int p = 0; p < D - 1; ++p)
 #pragma unroll
       for (int q = p + 1; q < D; ++q) {
-        const double app = grp_sum(A.e[p] * A.e[p]);
-        const double aqq = grp_sum(A.e[q] * A.e[q]);
-        const double apq = grp_sum(A.e[p] * A.e[q]);
+        const double app = grp_sum(B.e[p] * B.e[p]);
+        const double aqq = grp_sum(B.e[q] * B.e[q]);
+        const double apq = grp_sum(B.e[p] * B.e[q]);
         const double sc = sqrt(app * aqq);
         if (!settled && fabs(apq) > 1e-16 * sc && fabs(apq) > 1e-300) {
           off = fmax(off, fabs(apq) / sc);
           const double zeta = (aqq - app) / (2.0 * apq);
           const double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
           const double cs = 1.0 / sqrt(1.0 + tt * tt), sn = cs * tt;
-          const double x = A.e[p], y = A.e[q];
-          A.e[p] = cs * x - sn * y;
-          A.e[q] = sn * x + cs * y;
+          const double x = B.e[p], y = B.e[q];
+          B.e[p] = cs * x - sn * y;
+          B.e[q] = sn * x + cs * y;
 #pragma unroll
           for (int i = 0; i < D; ++i) {
             const double vx = Vm[p][i], vy = Vm[q][i];
@@ -200,16 +282,17 @@ __device__ __forceinline__ void row_polar(Row<D> &A, bool live) {
   double u[D];
 #pragma unroll
   for (int j = 0; j < D; ++j) {
-    const double nn = grp_sum(A.e[j] * A.e[j]);
-    u[j] = A.e[j] * (nn > 0 ? 1.0 / sqrt(nn) : 0.0);
+    const double nn = grp_sum(B.e[j] * B.e[j]);
+    u[j] = B.e[j] * (nn > 0 ? 1.0 / sqrt(nn) : 0.0);
   }
+  if (jacobi)
 #pragma unroll
-  for (int c = 0; c < D; ++c) {
-    double s = 0;
+    for (int c = 0; c < D; ++c) {
+      double s = 0;
 #pragma unroll
-    for (int j = 0; j < D; ++j) s += u[j] * Vm[j][c];
-    A.e[c] = s;
-  }
+      for (int j = 0; j < D; ++j) s += u[j] * Vm[j][c];
+      A.e[c] = s;
+    }
 }
 
 constexpr int kHessTile = 1536;              // nnz staged per pass (18 KiB of LDS)
