@@ -422,7 +422,6 @@ __global__ __launch_bounds__(kBlock) void k_spmm_dir_fix(ManiDesc m, CsrDev A, B
                                                          double *__restrict__ Hd, const double *__restrict__ p3,
                                                          int np3, double *__restrict__ p1, SolverCtl *ctl, int seq,
                                                          int iter, int main_grid) {
-  if (gated(ctl, seq, 2)) return;
   __shared__ int s_ci[kSpmmTile];
   __shared__ double s_v[kSpmmTile];
   __shared__ double s_red[16];
@@ -430,8 +429,36 @@ __global__ __launch_bounds__(kBlock) void k_spmm_dir_fix(ManiDesc m, CsrDev A, B
   __shared__ int s_last;
   const int r = m.r;
   const int par = (iter - 1) & 1;
-  const double z_r_new = sum_partials(p3, np3, 1, 0, s_red);
-  const double beta = iter > 0 ? z_r_new / ctl->z_r[par] : 0.0;
+  // Loads that depend on nothing are requested before the gate is looked at (one round trip instead of four in a row):
+  // the partials of <z, r>, its old value, the row pointers of the workgroup's first row block and the thread's own
+  // entries of z and delta.  The empty asm keeps the compiler from sinking them behind the early return.
+  double pv = ((int)threadIdx.x < np3) ? p3[threadIdx.x] : 0.0;
+  const double zr_old = iter > 0 ? ctl->z_r[par] : 1.0;
+  int rp_pre[4] = {0, 0, 0, 0};
+  double z_pre = 0, d_pre = 0;
+  {
+    const int al_ = m.se ? D + 1 : D;
+    const int RB_ = ((kBlock / r) / al_) * al_;
+    const int j0 = (int)blockIdx.x * RB_, lj_ = threadIdx.x / r;
+    if ((int)blockIdx.x < main_grid && j0 < A.nrows) {
+      const int j1 = min(A.nrows, j0 + RB_), j = j0 + lj_;
+      rp_pre[0] = A.rp[j0];
+      rp_pre[1] = A.rp[j1];
+      if (lj_ < RB_ && j < j1) {
+        rp_pre[2] = A.rp[j];
+        rp_pre[3] = A.rp[j + 1];
+        const size_t o = (size_t)j * r + (threadIdx.x - lj_ * r);
+        z_pre = z[o];
+        d_pre = iter > 0 ? d_old[o] : 0.0;
+      }
+    }
+  }
+  asm volatile("" ::"v"(pv), "v"(zr_old), "v"(rp_pre[0]), "v"(rp_pre[1]), "v"(rp_pre[2]), "v"(rp_pre[3]), "v"(z_pre),
+               "v"(d_pre));
+  if (gated(ctl, seq, 2)) return;
+  for (int i = threadIdx.x + blockDim.x; i < np3; i += blockDim.x) pv += p3[i];
+  const double z_r_new = block_sum(pv, s_red);
+  const double beta = iter > 0 ? z_r_new / zr_old : 0.0;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (iter == 0) {
       ctl->z_r[0] = z_r_new;
@@ -528,12 +555,13 @@ __global__ __launch_bounds__(kBlock) void k_spmm_dir_fix(ManiDesc m, CsrDev A, B
     const int j1 = min(A.nrows, j0 + RB);
     const int j = j0 + lj;
     const bool active = (lj < RB) && (j < j1);
-    const int pbeg = A.rp[j0], pend = A.rp[j1];
-    int myb = active ? A.rp[j] : 0, mye = active ? A.rp[j + 1] : 0;
+    const bool first = rb == (int)blockIdx.x;  // requested in the prologue
+    const int pbeg = first ? rp_pre[0] : A.rp[j0], pend = first ? rp_pre[1] : A.rp[j1];
+    int myb = active ? (first ? rp_pre[2] : A.rp[j]) : 0, mye = active ? (first ? rp_pre[3] : A.rp[j + 1]) : 0;
     const bool is_long = A.n_long > 0 && (mye - myb > kLongRow);  // served by its own workgroups
     if (is_long) mye = myb;
     const size_t o = (size_t)(active ? j : j0) * r + t;
-    const double own = active ? dir(o) : 0.0;
+    const double own = !active ? 0.0 : !first ? dir(o) : iter > 0 ? fma(beta, d_pre, -z_pre) : -z_pre;
     const double xo = active ? X[o] : 0.0;
     double acc = 0;
     for (int base = pbeg; base < pend; base += kSpmmTile) {
@@ -897,13 +925,43 @@ __global__ __launch_bounds__(kBlock) void k_tangent(ManiDesc m, Buf2 Xb, const d
                                                     double *__restrict__ partials, const double *__restrict__ p2,
                                                     int np2, SolverCtl *ctl, HostFlags *hf, int seq, int gate,
                                                     int iter, SpFold sf) {
-  if (gated(ctl, seq, gate)) return;
   __shared__ double s_red[16];
   __shared__ double s_x2[64 * 16];
+  // Loads that depend on nothing are requested before the gate is looked at -- the stopping rule's partials and |r0|,
+  // the hub's index, the places of the thread's first columns in the replay's images: with the gate they are one
+  // memory round trip where they were five in a row (k_tangent on tiers.pyfg: 9.9 us for 0.6 MB vectors, all of it
+  // dependent round trips).  The empty asm keeps the compiler from sinking them behind the early return.
+  const int r = m.r;
+  const long items = (long)m.n + m.l + m.num_euc();
+  const bool folded = sf.y != nullptr;
+  double pv = (p2 && (int)threadIdx.x < np2) ? p2[threadIdx.x] : 0.0;
+  const double n0 = p2 ? ctl->norm_r0 : 0.0;
+  const bool hub0 = folded && sf.h > 0 && (int)threadIdx.x < sf.h * r;
+  int hidx0 = hub0 ? sf.hub_idx[threadIdx.x / r] : 0;
+  const long it0 = (long)blockIdx.x * kBlock + threadIdx.x;
+  int jp_pre[D], op_pre[D];
+#pragma unroll
+  for (int a = 0; a < D; ++a) jp_pre[a] = op_pre[a] = 0;
+  if (folded && it0 < items) {
+    const size_t c0 = it0 < m.n ? (size_t)m.rot_col((int)it0)
+                                : it0 < m.n + m.l ? (size_t)m.sphere_col((int)(it0 - m.n))
+                                                  : (size_t)m.euc_col((int)(it0 - m.n - m.l));
+    const int nc0 = it0 < m.n ? D : 1;
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+      if (a < nc0) {
+        jp_pre[a] = sf.in_pos[c0 + a];
+        op_pre[a] = sf.out_pos[c0 + a];
+      }
+  }
+#pragma unroll
+  for (int a = 0; a < D; ++a) asm volatile("" ::"v"(jp_pre[a]), "v"(op_pre[a]));
+  asm volatile("" ::"v"(pv), "v"(n0), "v"(hidx0));
+  if (gated(ctl, seq, gate)) return;
   if (p2) {
     // ROPTLIB tCG_TR stopping rule (theta = 1, kappa = 0.1): |r| <= |r0| min(|r0|^theta, kappa)
-    const double nr = sqrt(sum_partials(p2, np2, 1, 0, s_red));
-    const double n0 = ctl->norm_r0;
+    for (int i = threadIdx.x + blockDim.x; i < np2; i += blockDim.x) pv += p2[i];
+    const double nr = sqrt(block_sum(pv, s_red));
     const double kappa = 0.1;
     const double tempnum = n0;  // pow(n0, theta = 1)
     if (nr <= n0 * fmin(tempnum, kappa)) {
@@ -918,18 +976,16 @@ __global__ __launch_bounds__(kBlock) void k_tangent(ManiDesc m, Buf2 Xb, const d
     }
   }
   const double *X = pick(Xb, ctl, 0);
-  const int r = m.r;
-  const long items = (long)m.n + m.l + m.num_euc();
   // sparse preconditioner folded in (generic layout): V(col, t) is read from where the level replay left it, with the
   // hub correction of k_sp_permute_out_hub; x2 = Sinv (R(hub) - a^T y1) is rebuilt by every workgroup
-  const bool folded = sf.y != nullptr;
   if (folded && sf.h > 0) {
     // two steps with all slice loads of a step in flight together (same summation order as the one-loop form: every
     // w(q2, t) is R minus its slices in slice order, every x2(q, t) the sum over q2 in order)
     __shared__ double s_w[64 * 16];
     for (int e = threadIdx.x; e < sf.h * r; e += kBlock) {
       const int q2 = e / r, t = e - q2 * r;
-      double w = R[(size_t)sf.hub_idx[q2] * r + t];
+      const int hidx = (e == (int)threadIdx.x) ? hidx0 : sf.hub_idx[q2];
+      double w = R[(size_t)hidx * r + t];
       const double *__restrict__ hw = sf.hub_w + (size_t)q2 * sf.hub_split * r + t;
       int sl = 0;
       for (; sl + 8 <= sf.hub_split; sl += 8) {
@@ -951,15 +1007,15 @@ __global__ __launch_bounds__(kBlock) void k_tangent(ManiDesc m, Buf2 Xb, const d
     }
     __syncthreads();
   }
-  // NC consecutive columns starting at col0: positions first, then every value, straight line (a hub column -- rare --
-  // is patched afterwards)
-  auto vcols = [&](size_t col0, auto nc_tag, double (*vv)[RM]) {
+  // NC consecutive columns starting at col0: positions first (the thread's first item: requested in the prologue), then
+  // every value, straight line (a hub column -- rare -- is patched afterwards)
+  auto vcols = [&](size_t col0, auto nc_tag, double (*vv)[RM], bool first) {
     constexpr int NC = decltype(nc_tag)::value;
     int jp[NC], op[NC];
 #pragma unroll
     for (int a = 0; a < NC; ++a) {
-      jp[a] = sf.in_pos[col0 + a];
-      op[a] = sf.out_pos[col0 + a];
+      jp[a] = first ? jp_pre[a] : sf.in_pos[col0 + a];
+      op[a] = first ? op_pre[a] : sf.out_pos[col0 + a];
     }
 #pragma unroll
     for (int a = 0; a < NC; ++a)
@@ -994,7 +1050,7 @@ __global__ __launch_bounds__(kBlock) void k_tangent(ManiDesc m, Buf2 Xb, const d
       Blk<D, RM> Y, W;
       ld_blk<D, RM>(X + o, r, Y);
       if (folded) {
-        vcols((size_t)m.rot_col((int)it), std::integral_constant<int, D>{}, W.a);
+        vcols((size_t)m.rot_col((int)it), std::integral_constant<int, D>{}, W.a, it == it0);
       } else {
         ld_blk<D, RM>(V + o, r, W);
       }
@@ -1012,7 +1068,7 @@ __global__ __launch_bounds__(kBlock) void k_tangent(ManiDesc m, Buf2 Xb, const d
       const size_t o = col * r;
       double vv1[1][RM];
       if (folded) {
-        vcols(col, std::integral_constant<int, 1>{}, vv1);
+        vcols(col, std::integral_constant<int, 1>{}, vv1, it == it0);
       } else {
 #pragma unroll
         for (int t = 0; t < RM; ++t) vv1[0][t] = (t < r) ? V[o + t] : 0.0;
@@ -1034,7 +1090,7 @@ __global__ __launch_bounds__(kBlock) void k_tangent(ManiDesc m, Buf2 Xb, const d
       const size_t o = col * r;
       double ve[1][RM];
       if (folded) {
-        vcols(col, std::integral_constant<int, 1>{}, ve);
+        vcols(col, std::integral_constant<int, 1>{}, ve, it == it0);
       } else {
 #pragma unroll
         for (int t = 0; t < RM; ++t) ve[0][t] = (t < r) ? V[o + t] : 0.0;
@@ -1590,12 +1646,32 @@ __global__ __launch_bounds__(kBlock) void k_tcg_update1(long nelem, const double
                                                         const double *__restrict__ p1, int np1,
                                                         double *__restrict__ p2, SolverCtl *ctl, HostFlags *hf,
                                                         int seq, int iter, int r, SpFold sf) {
-  if (gated(ctl, seq, 2)) return;
   __shared__ double s_red[16];
   const int par = iter & 1;
-  const double d_Hd = sum_partials(p1, np1, 1, 0, s_red);
+  // Every load that depends on nothing is requested before the gate is looked at: control words, the partials, the
+  // thread's first element of every vector and its place in the replay's image -- one memory round trip where the
+  // gate, the partial sum, the control scalars and the vectors were four in a row (5.7 us on tiers.pyfg for 0.6 MB
+  // vectors).  The empty asm keeps the compiler from sinking the loads behind the early return.
+  const long i0 = (long)blockIdx.x * kBlock + threadIdx.x;
+  const bool in0 = i0 < nelem;
+  double pv = ((int)threadIdx.x < np1) ? p1[threadIdx.x] : 0.0;
   const double z_r = ctl->z_r[par], d_Pd = ctl->d_Pd[par], e_Pe = ctl->e_Pe[par], e_Pd = ctl->e_Pd[par];
   const double Delta = ctl->Delta;
+  double h0 = 0, dl0 = 0, et0 = 0, he0 = 0, rs0 = 0;
+  int jp0 = -1;
+  const long col0 = in0 ? i0 / r : 0;
+  if (in0) {
+    h0 = Hd[i0];
+    dl0 = delta[i0];
+    et0 = eta[i0];
+    he0 = Heta[i0];
+    rs0 = res[i0];
+    if (sf.y) jp0 = sf.in_pos[col0];
+  }
+  asm volatile("" ::"v"(pv), "v"(h0), "v"(dl0), "v"(et0), "v"(he0), "v"(rs0), "v"(jp0));
+  if (gated(ctl, seq, 2)) return;
+  for (int i = threadIdx.x + blockDim.x; i < np1; i += blockDim.x) pv += p1[i];
+  const double d_Hd = block_sum(pv, s_red);
   const double alpha = z_r / d_Hd;
   const double e_Pe_new = e_Pe + 2.0 * alpha * e_Pd + alpha * alpha * d_Pd;
   const bool boundary = (d_Hd <= 0) || (e_Pe_new >= Delta * Delta);
@@ -1605,7 +1681,17 @@ __global__ __launch_bounds__(kBlock) void k_tcg_update1(long nelem, const double
   // (DeviceProblem::rtr_dev); a run that stops writes tcg_done_seq below
   if (!boundary && blockIdx.x == 0 && threadIdx.x == 0) host_store(&hf->go_seq, seq);
   double acc = 0;
-  for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < nelem; i += (long)gridDim.x * kBlock) {
+  if (in0) {
+    eta[i0] = et0 + step * dl0;
+    Heta[i0] = he0 + step * h0;
+    if (!boundary) {
+      const double rr = rs0 + alpha * h0;
+      res[i0] = rr;
+      acc += rr * rr;
+      if (sf.y && jp0 >= 0) sf.y[(size_t)jp0 * r + (i0 - col0 * r)] = rr;
+    }
+  }
+  for (long i = i0 + (long)gridDim.x * kBlock; i < nelem; i += (long)gridDim.x * kBlock) {
     const double h = Hd[i];
     eta[i] += step * delta[i];
     Heta[i] += step * h;
