@@ -21,6 +21,24 @@ __device__ __forceinline__ bool gated(const SolverCtl *ctl, int seq, int gate) {
   if (gate == 2 && seq > ctl->tcg_done_stamp) return true;
   return false;
 }
+// the gate's two words requested early (with a kernel's other independent loads), tested later
+struct GateWords {
+  int outer, tcg;
+};
+__device__ __forceinline__ GateWords gate_words(const SolverCtl *ctl) {
+  GateWords w{0x7fffffff, 0x7fffffff};
+  if (ctl) {
+    w.outer = ctl->outer_done_stamp;
+    w.tcg = ctl->tcg_done_stamp;
+  }
+  return w;
+}
+__device__ __forceinline__ bool gated(const GateWords &w, const SolverCtl *ctl, int seq, int gate) {
+  if (ctl == nullptr || gate == 0) return false;
+  if (seq > w.outer) return true;
+  if (gate == 2 && seq > w.tcg) return true;
+  return false;
+}
 __device__ __forceinline__ double *pick(const Buf2 &b, const SolverCtl *ctl, int sel) {
   return b.p[ctl ? ((ctl->cur ^ sel) & 1) : 0];
 }
@@ -432,6 +450,7 @@ __global__ __launch_bounds__(kBlock) void k_spmm_dir_fix(ManiDesc m, CsrDev A, B
   // Loads that depend on nothing are requested before the gate is looked at (one round trip instead of four in a row):
   // the partials of <z, r>, its old value, the row pointers of the workgroup's first row block and the thread's own
   // entries of z and delta.  The empty asm keeps the compiler from sinking them behind the early return.
+  const GateWords gw = gate_words(ctl);
   double pv = ((int)threadIdx.x < np3) ? p3[threadIdx.x] : 0.0;
   const double zr_old = iter > 0 ? ctl->z_r[par] : 1.0;
   int rp_pre[4] = {0, 0, 0, 0};
@@ -454,8 +473,8 @@ __global__ __launch_bounds__(kBlock) void k_spmm_dir_fix(ManiDesc m, CsrDev A, B
     }
   }
   asm volatile("" ::"v"(pv), "v"(zr_old), "v"(rp_pre[0]), "v"(rp_pre[1]), "v"(rp_pre[2]), "v"(rp_pre[3]), "v"(z_pre),
-               "v"(d_pre));
-  if (gated(ctl, seq, 2)) return;
+               "v"(d_pre), "s"(gw.outer), "s"(gw.tcg));
+  if (gated(gw, ctl, seq, 2)) return;
   for (int i = threadIdx.x + blockDim.x; i < np3; i += blockDim.x) pv += p3[i];
   const double z_r_new = block_sum(pv, s_red);
   const double beta = iter > 0 ? z_r_new / zr_old : 0.0;
@@ -934,6 +953,7 @@ __global__ __launch_bounds__(kBlock) void k_tangent(ManiDesc m, Buf2 Xb, const d
   const int r = m.r;
   const long items = (long)m.n + m.l + m.num_euc();
   const bool folded = sf.y != nullptr;
+  const GateWords gw = gate_words(ctl);
   double pv = (p2 && (int)threadIdx.x < np2) ? p2[threadIdx.x] : 0.0;
   const double n0 = p2 ? ctl->norm_r0 : 0.0;
   const bool hub0 = folded && sf.h > 0 && (int)threadIdx.x < sf.h * r;
@@ -956,8 +976,8 @@ __global__ __launch_bounds__(kBlock) void k_tangent(ManiDesc m, Buf2 Xb, const d
   }
 #pragma unroll
   for (int a = 0; a < D; ++a) asm volatile("" ::"v"(jp_pre[a]), "v"(op_pre[a]));
-  asm volatile("" ::"v"(pv), "v"(n0), "v"(hidx0));
-  if (gated(ctl, seq, gate)) return;
+  asm volatile("" ::"v"(pv), "v"(n0), "v"(hidx0), "s"(gw.outer), "s"(gw.tcg));
+  if (gated(gw, ctl, seq, gate)) return;
   if (p2) {
     // ROPTLIB tCG_TR stopping rule (theta = 1, kappa = 0.1): |r| <= |r0| min(|r0|^theta, kappa)
     for (int i = threadIdx.x + blockDim.x; i < np2; i += blockDim.x) pv += p2[i];
@@ -988,12 +1008,12 @@ __global__ __launch_bounds__(kBlock) void k_tangent(ManiDesc m, Buf2 Xb, const d
       double w = R[(size_t)hidx * r + t];
       const double *__restrict__ hw = sf.hub_w + (size_t)q2 * sf.hub_split * r + t;
       int sl = 0;
-      for (; sl + 8 <= sf.hub_split; sl += 8) {
-        double v[8];
+      for (; sl + 32 <= sf.hub_split; sl += 32) {  // (the split is 32: every slice of a hub in flight at once)
+        double v[32];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = hw[(size_t)(sl + u) * r];
+        for (int u = 0; u < 32; ++u) v[u] = hw[(size_t)(sl + u) * r];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) w -= v[u];
+        for (int u = 0; u < 32; ++u) w -= v[u];
       }
       for (; sl < sf.hub_split; ++sl) w -= hw[(size_t)sl * r];
       s_w[e] = w;
@@ -1654,6 +1674,7 @@ __global__ __launch_bounds__(kBlock) void k_tcg_update1(long nelem, const double
   // vectors).  The empty asm keeps the compiler from sinking the loads behind the early return.
   const long i0 = (long)blockIdx.x * kBlock + threadIdx.x;
   const bool in0 = i0 < nelem;
+  const GateWords gw = gate_words(ctl);
   double pv = ((int)threadIdx.x < np1) ? p1[threadIdx.x] : 0.0;
   const double z_r = ctl->z_r[par], d_Pd = ctl->d_Pd[par], e_Pe = ctl->e_Pe[par], e_Pd = ctl->e_Pd[par];
   const double Delta = ctl->Delta;
@@ -1668,8 +1689,8 @@ __global__ __launch_bounds__(kBlock) void k_tcg_update1(long nelem, const double
     rs0 = res[i0];
     if (sf.y) jp0 = sf.in_pos[col0];
   }
-  asm volatile("" ::"v"(pv), "v"(h0), "v"(dl0), "v"(et0), "v"(he0), "v"(rs0), "v"(jp0));
-  if (gated(ctl, seq, 2)) return;
+  asm volatile("" ::"v"(pv), "v"(h0), "v"(dl0), "v"(et0), "v"(he0), "v"(rs0), "v"(jp0), "s"(gw.outer), "s"(gw.tcg));
+  if (gated(gw, ctl, seq, 2)) return;
   for (int i = threadIdx.x + blockDim.x; i < np1; i += blockDim.x) pv += p1[i];
   const double d_Hd = block_sum(pv, s_red);
   const double alpha = z_r / d_Hd;
