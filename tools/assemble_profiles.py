@@ -22,17 +22,17 @@ sf, sw = pick(F, r'^k_spmm_bsr2?<', 'FETCH_SIZE_median'), pick(W, r'^k_spmm_bsr2
 out['k_spmm_bsr_lattice100k_counters'] = {'kernels': [x[0] for x in sf], 'FETCH_SIZE_KB': [x[3] for x in sf], 'WRITE_SIZE_KB': [x[3] for x in sw], 'launches': [x[2] for x in sf],
     'note': '8-B gathers and 16-B block-row loads mixed: (FETCH+WRITE)*1024 and (2*FETCH+WRITE)*1024 bracket the traffic; algorithmic (CSR convention) 124.1 MB'}
 # the replay of the lattice agent inside bench.roofline: the grids of k_sp_mtile<1, 8> launched most often
-allf = pick(F, r'^k_sp_mtile<1, 8>', 'FETCH_SIZE_median')
+allf = pick(F, r'^k_sp_mtile<1, 8', 'FETCH_SIZE_median')
 ncalls = max(x[2] for x in allf) if allf else 0
 lf = [x for x in allf if x[2] == ncalls]
-lw = [x for x in pick(W, r'^k_sp_mtile<1, 8>', 'WRITE_SIZE_median') if x[2] == ncalls]
+lw = [x for x in pick(W, r'^k_sp_mtile<1, 8', 'WRITE_SIZE_median') if x[2] == ncalls]
 fk, wk = sum(x[3] for x in lf), sum(x[3] for x in lw)
 out['k_sp_mtile_lattice100k_agent'] = {'distinct_grids_with_%d_calls_each' % ncalls: len(lf),
     'FETCH_SIZE_KB_per_launch': [x[3] for x in lf], 'WRITE_SIZE_KB_per_launch': [x[3] for x in lw],
     'FETCH_SIZE_KB_per_application': fk, 'WRITE_SIZE_KB_per_application': wk,
     'bytes_per_application_fetch_plus_write': (fk + wk) * 1024, 'bytes_per_application_2fetch_plus_write': (2 * fk + wk) * 1024,
     'algorithmic_bytes_per_application': b['roofline_qapply']['precond_sparse_lattice100k_agent']['bytes_per_application'],
-    'note': 'k_sp_mtile (4-row tiles on the fp64 matrix pipe, round 4): 8-B weight loads and 16-B vector pair loads: (FETCH+WRITE)*1024 and (2*FETCH+WRITE)*1024 bracket the traffic; 9 level launches per application; launches of equal grid size are merged by the summary, so fewer than 9 rows may appear'}
+    'note': 'k_sp_mtile (4-row tiles on the fp64 matrix pipe, round 4): 8-B weight loads and 16-B vector pair loads: (FETCH+WRITE)*1024 and (2*FETCH+WRITE)*1024 bracket the traffic; 7 level launches per application; launches of equal grid size are merged by the summary, so fewer than 7 rows may appear'}
 json.dump(out, open('profiles/' + tag + '_pmc_traffic.json', 'w'), indent=1)
 if os.path.exists(o + '/bench_2ranks_on_one_gpu.json') and os.path.getsize(o + '/bench_2ranks_on_one_gpu.json') > 100:
     shutil.copy(o + '/bench_2ranks_on_one_gpu.json', 'profiles/' + tag + '_bench_2ranks_on_one_gpu_gloo.json')
