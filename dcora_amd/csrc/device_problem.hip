@@ -891,13 +891,14 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
   // cost + gradient of an evaluation in one launch where the kernel exists (small CSR blocks), else Q-apply + rgrad
   const bool gf = !has_bsr && Q.n_long == 0;
   const bool gfb = has_bsr;       // large blocks: the same in one launch on the block structure (k_spmm_bsr2<.., GRAD>)
+  const Buf2 kNoBuf{{nullptr, nullptr}};  // EG of the fused evaluation: nobody reads it, so it is not written
   const int nAe = gf ? nPB : nA;  // {<XQ,X>, <X,G>} partial slots of an evaluation
   int nG;
   ++seq;
   if (gf) {
     nG = launch_fused_grad(st, m, Qv, Xb(), Gp, EGb(), RGb(), Sb(), 0, pA.p, pB.p, nullptr, Gate{});
   } else if (gfb) {
-    nG = launch_fused_grad_bsr(st, m.r, m.d, Qbv, Xb(), Gp, EGb(), RGb(), Sb(), 0, pA.p, pB.p, nullptr, Gate{});
+    nG = launch_fused_grad_bsr(st, m.r, m.d, Qbv, Xb(), Gp, kNoBuf, RGb(), Sb(), 0, pA.p, pB.p, nullptr, Gate{});
   } else {
     enq_qapply(Xb(), 0, Gp, EGb(), 0, pA.p, Gate{});
     ++seq;
@@ -975,7 +976,7 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
     if (gf) {
       nG = launch_fused_grad(st, m, Qv, Xb(), Gp, EGb(), RGb(), Sb(), 1, pA.p, pB.p, nullptr, Gate{c, ++seq, 1});
     } else if (gfb) {
-      nG = launch_fused_grad_bsr(st, m.r, m.d, Qbv, Xb(), Gp, EGb(), RGb(), Sb(), 1, pA.p, pB.p, nullptr,
+      nG = launch_fused_grad_bsr(st, m.r, m.d, Qbv, Xb(), Gp, kNoBuf, RGb(), Sb(), 1, pA.p, pB.p, nullptr,
                                  Gate{c, ++seq, 1});
     } else {
       enq_qapply(Xb(), 1, Gp, EGb(), 1, pA.p, Gate{c, ++seq, 1});

@@ -664,8 +664,11 @@ int RbcdSession::evaluate_central(double *cost2, double *gradnorm, double *block
       nA = launch_fused_grad(st, c.m, c.Q.view(), buf1(Xg.p), nullptr, buf1(c.EG0.p), buf1(c.RG0.p),
                              Buf2{{nullptr, nullptr}}, 0, c.pA.p, c.pB.p, posenorm.p, Gate{});
     else if (gfb)
-      nA = launch_fused_grad_bsr(st, c.m.r, c.m.d, c.Qb.view(), buf1(Xg.p), nullptr, buf1(c.EG0.p), buf1(c.RG0.p),
-                                 Buf2{{nullptr, nullptr}}, 0, c.pA.p, c.pB.p, posenorm.p, Gate{});
+      // (only the dots and the per-pose norms leave the kernel: writing EG and RG of the whole graph, 2 x 16 MB on the
+      // 100k lattice, would be written back at the kernel's end for nobody)
+      nA = launch_fused_grad_bsr(st, c.m.r, c.m.d, c.Qb.view(), buf1(Xg.p), nullptr, Buf2{{nullptr, nullptr}},
+                                 Buf2{{nullptr, nullptr}}, Buf2{{nullptr, nullptr}}, 0, c.pA.p, c.pB.p, posenorm.p,
+                                 Gate{});
     else
       c.enq_rgrad(buf1(Xg.p), buf1(c.EG0.p), buf1(c.RG0.p), Buf2{{nullptr, nullptr}}, 0, c.pB.p, Gate{}, posenorm.p);
     const int want = ++eval_seq;

@@ -1711,7 +1711,7 @@ __global__ __launch_bounds__(kBlock) void k_spmm_bsr2(int r, BsrDev A, Buf2 Xb, 
         Yr.e[a] = x;
         E.e[a] = active ? acc[a] + gg : 0.0;
       }
-      st_row<D>(Y + ob, r, t, active, E);
+      if (Y) st_row<D>(Y + ob, r, t, active, E);  // (nobody reads EG behind the fused evaluation: callers pass null)
       double S[D][D];
       grp_sym_gram<D>(Yr, E, S);
       if (Sblk && inr && t == 0)
