@@ -713,6 +713,7 @@ int DeviceProblem::rtr_dev(const dcora_ropt_params &prm, dcora_ropt_result *res_
   hf->tcg_done_seq = 0;
   hf->outer_done_seq = 0;
   hf->go_seq = 0;
+  hf->reject_seq = 0;
   SolverCtl *c = ctl.p;
   const long N = nelem();
   const CsrDev Qv = Q.view();
@@ -851,6 +852,7 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
     hf->tcg_done_seq = 0;
     hf->outer_done_seq = 0;
     hf->go_seq = 0;
+    hf->reject_seq = 0;
     seq_ = 0;
   }
   int &seq = seq_;
@@ -925,8 +927,17 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
       launch_fused_precond(st, m, ldm, Mi, RGb(), nullptr, nullptr, eta.p, Heta.p, nullptr, rbuf[0], Zpart.p,
                            nullptr, 0, p2.p, c, hf_dev, ++seq, 0, 1, sf);
       tcg_first_seq = seq;
-      if (sparse_precond) sp.apply(st, m.r, buf1(rbuf[0]), Zpart.p, Gate{c, ++seq, 1}, folded);
-      launch_fused_finish(st, m, Xb(), Zpart.p, rbuf[0], z.p, nullptr, 0, p3.p, c, hf_dev, ++seq, 0, 1, nsl, sf);
+      // A rejected step (k_rtr_decide said so in reject_seq) left the iterate and its gradient where they were: z0 is
+      // the one of the iteration before, whose unprojected form the finish kernel kept in W (free on this path) --
+      // one application of the sparse preconditioner less per rejection (0.25 per RBCD iteration on the 100k lattice).
+      const bool reuse_z0 = sparse_precond && outer > 0 && hf->reject_seq == last_pace_seq;
+      if (reuse_z0) {
+        launch_fused_finish(st, m, Xb(), W.p, rbuf[0], z.p, nullptr, 0, p3.p, c, hf_dev, ++seq, 0, 1, 1, SpFold{});
+      } else {
+        if (sparse_precond) sp.apply(st, m.r, buf1(rbuf[0]), Zpart.p, Gate{c, ++seq, 1}, folded);
+        launch_fused_finish(st, m, Xb(), Zpart.p, rbuf[0], z.p, nullptr, 0, p3.p, c, hf_dev, ++seq, 0, 1, nsl, sf,
+                            sparse_precond ? W.p : nullptr);
+      }
     }
     for (int j = 0; j < max_inner; ++j) {
       if (j >= kLookahead) {

@@ -92,6 +92,7 @@ struct HostFlags {
   volatile int tcg_done_seq;    // seq at which the current/last tCG terminated
   volatile int outer_done_seq;  // seq at which the RTR loop terminated (0 = running)
   volatile int go_seq;          // seq of the latest fused B (or B+C) kernel whose boundary test let the tCG run go on
+  volatile int reject_seq;      // seq of the latest k_rtr_decide that rejected its step (the iterate did not move)
 };
 
 // Solver-aware launches carry (ctl, seq, gate): gate 0 = always run, 1 = skip once the RTR loop is done,
@@ -247,7 +248,8 @@ int launch_fused_pc(hipStream_t st, const ManiDesc &m, int ldm, const double *Mi
                     int seq, int iter, int first);
 void launch_fused_finish(hipStream_t st, const ManiDesc &m, Buf2 X, const double *Zpart, const double *res,
                          double *z, const double *p2, int np2, double *p3, SolverCtl *ctl, HostFlags *hf, int seq,
-                         int iter, int first, int nsplit = -1 /* -1: fused_nsplit(m) */, SpFold sf = SpFold());
+                         int iter, int first, int nsplit = -1 /* -1: fused_nsplit(m) */, SpFold sf = SpFold(),
+                         double *zraw = nullptr /* the unprojected P r, kept for a rejected step */);
 // group-style (8 lanes per pose) rgrad / retract / Nesterov; return the number of partial slots written
 int launch_fused_grad_bsr(hipStream_t st, int r, int d, const BsrDev &A, Buf2 X, const double *G, Buf2 EG, Buf2 RG, Buf2 S,
                           int sel, double *pA, double *pB, double *posenorm, Gate g);

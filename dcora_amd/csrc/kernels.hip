@@ -1800,6 +1800,7 @@ __global__ __launch_bounds__(kBlock) void k_rtr_decide(const double *pA, int npA
       ctl->last_accepted = 1;
     } else {
       ctl->last_accepted = 0;
+      host_store(&hf->reject_seq, seq);  // before last_seq_done below: the host reads it behind that word
     }
     ctl->outer_it += 1;
     if (ctl->ngf < ctl->tol || ctl->outer_it >= ctl->max_outer || (ctl->stop_on_accept && accept)) {

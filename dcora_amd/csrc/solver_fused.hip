@@ -987,7 +987,8 @@ __global__ __launch_bounds__(kBlock) void k_fused_finish(ManiDesc m, int nsplit,
                                                          const double *__restrict__ res, double *__restrict__ z,
                                                          const double *__restrict__ p2, int np2,
                                                          double *__restrict__ p3, SolverCtl *ctl, HostFlags *hf,
-                                                         int seq, int iter, int first, SpFold sf) {
+                                                         int seq, int iter, int first, SpFold sf,
+                                                         double *__restrict__ zraw) {
   const int st_o = ctl->outer_done_stamp, st_t = ctl->tcg_done_stamp, cur = ctl->cur & 1;
   const double c_n0 = ctl->norm_r0;
   const int c_max_inner = ctl->max_inner;
@@ -1033,6 +1034,9 @@ __global__ __launch_bounds__(kBlock) void k_fused_finish(ManiDesc m, int nsplit,
     }
     s_Z[e] = zs;
     s_R[e] = rres;
+    // z0 = P grad of an RTR iteration, unprojected: a rejected step leaves the iterate and its gradient where they
+    // were, and the next iteration starts from this copy instead of another application of the preconditioner
+    if (zraw) zraw[base + e] = zs;
   }
   myp += myp2;
   if (!first)
@@ -2092,15 +2096,15 @@ bool fused_pc_ready(const ManiDesc &m, int ldm) {
 }
 void launch_fused_finish(hipStream_t st, const ManiDesc &m, Buf2 X, const double *Zpart, const double *res,
                          double *z, const double *p2, int np2, double *p3, SolverCtl *ctl, HostFlags *hf, int seq,
-                         int iter, int first, int nsplit, SpFold sf) {
+                         int iter, int first, int nsplit, SpFold sf, double *zraw) {
   const int grid = fused_pose_blocks(m);
   const int ns = nsplit > 0 ? nsplit : fused_nsplit(m);
   if (m.d == 3)
     hipLaunchKernelGGL(k_fused_finish<3>, dim3(grid), dim3(kBlock), 0, st, m, ns, X, Zpart, res, z, p2, np2, p3, ctl,
-                       hf, seq, iter, first, sf);
+                       hf, seq, iter, first, sf, zraw);
   else
     hipLaunchKernelGGL(k_fused_finish<2>, dim3(grid), dim3(kBlock), 0, st, m, ns, X, Zpart, res, z, p2, np2, p3, ctl,
-                       hf, seq, iter, first, sf);
+                       hf, seq, iter, first, sf, zraw);
 }
 
 int launch_g_rgrad(hipStream_t st, const ManiDesc &m, Buf2 X, Buf2 EG, Buf2 RG, Buf2 Sblk, int sel, double *partials,
