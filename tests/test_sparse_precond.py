@@ -144,3 +144,31 @@ def test_rbcd_with_sparse_preconditioner_matches_oracle(sparse_env):
     assert np.array_equal(out["selected"], tr["selected"])
     assert np.allclose(out["cost"], tr["cost"], rtol=1e-7)
     assert common.rel(s.get_X(), tr["X"]) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,radius,seed", [("smallGrid3D", 100.0, 5), ("smallGrid3D", 1e4, 7), ("tinyGrid3D", 1e4, 7)])
+def test_rtr_with_rejected_steps_reuses_z0_and_matches_oracle(sparse_env, name, radius, seed):
+    """from a random point several of ten RTR iterations are rejected (ref src/QuadraticOptimizer.cpp:234-280, ROPTLIB's
+    acceptance rule rho > 0.1): the iterate and its gradient stay, and the device solver starts the next iteration from
+    the kept z0 = P grad instead of another application of the preconditioner -- same outer, tCG
+    and accepted counts as the oracle, which applies the preconditioner again, and the same optimum"""
+    import dcora_amd as da
+    from oracle import orc
+    r = 5
+    ds, dso = common.product_dataset(name), common.oracle_dataset(name)
+    P = da.QuadraticProblem(r, ds.d, ds.n, da.build_Q_pgo(ds), reg=0.1)
+    Po = orc.Problem(r, ds.d, ds.n, orc.build_Q_pgo(dso))
+    assert P.precond_info()["kind"] == "sparse"
+    X0 = common.random_point(r, ds.d, ds.n, seed, orc.project_to_manifold)
+    opt = da.QuadraticOptimizer(P, da.ROptParameters(RTR_iterations=10, RTR_initial_radius=radius, gradnorm_tol=1e-6))
+    X = opt.optimize(X0)
+    res = opt.getOptResult()
+    Xo, reso = Po.optimize(X0, RTR_iterations=10, RTR_initial_radius=radius, gradnorm_tol=1e-6)
+    assert reso["accepted"] < reso["outer_iters"]  # the case holds rejected steps
+    assert res["outer_iterations"] == reso["outer_iters"], (res, reso)
+    assert res["inner_iterations"] == reso["inner_iters"], (res, reso)
+    assert res["accepted_steps"] == reso["accepted"], (res, reso)
+    assert abs(res["fOpt"] - reso["fOpt"]) <= 1e-9 * abs(reso["fOpt"])
+    assert common.rel(X, Xo) < 1e-7
+    P.close()
