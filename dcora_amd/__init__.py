@@ -53,7 +53,7 @@ class Dataset:
     def __init__(self, d, n, ids, vals):
         self.d, self.n = int(d), int(n)
         self.ids = np.ascontiguousarray(ids, dtype=np.int32).reshape(-1, 4)
-        self.vals = np.ascontiguousarray(vals, dtype=np.float64).reshape(self.ids.shape[0], -1)
+        self.vals = np.ascontiguousarray(vals, dtype=np.float64).reshape(self.ids.shape[0], self.d * self.d + self.d + 3)
 
     @property
     def m(self):

@@ -299,3 +299,14 @@ def test_no_cpu_fallback(da):
         da.RbcdSession(ds, num_robots=2, r=3)
     with pytest.raises(da.DcoraError):
         da.manifold_project(3, ds.d, ds.n, np.zeros((3, 4 * ds.n)))
+
+
+def test_a_graph_without_measurements_builds(built):
+    """one pose, no measurement: Q = 0 (k = d + 1), on the host builder and in the oracle"""
+    import dcora_amd as da
+    from oracle import orc
+    ids, vals = np.zeros((0, 4), np.int32), np.zeros((0, 15))
+    Q = da.build_Q_pgo(da.Dataset(3, 1, ids, vals)).to_scipy()
+    Qo = orc.build_Q_pgo(orc.Dataset(3, 1, ids, vals)).to_scipy()
+    assert Q.shape == (4, 4) and Qo.shape == (4, 4)
+    assert abs(Q).sum() == 0 and abs(Qo).sum() == 0
