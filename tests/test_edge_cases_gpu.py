@@ -114,3 +114,44 @@ def test_operators_at_the_widest_rank_on_a_real_graph(env):
     assert res["outer_iterations"] == reso["outer_iters"] and res["inner_iterations"] == reso["inner_iters"]
     assert abs(res["fOpt"] - reso["fOpt"]) <= 1e-9 * abs(reso["fOpt"])
     P.close()
+
+
+@pytest.mark.parametrize("d", [2, 3])
+@pytest.mark.parametrize("l,b", [(0, 0), (7, 0), (0, 5), (7, 5)])
+def test_range_aided_layout_in_its_four_presence_cases(env, d, l, b):
+    """ref src/manifold/LiftedManifold.cpp:67-88: the product manifold St(r,d)^n x OB(r,l) x R^(r x n) x R^(r x b) is
+    built in four ways, with and without unit-sphere variables and landmarks.  A random sparse positive semidefinite Q
+    of the layout's size stands in for the data matrix: every operator against the oracle, at r = d and r = d + 3"""
+    import scipy.sparse as sp
+    da, orc = env
+    n = 12
+    k = d * n + l + n + b
+    rng = np.random.default_rng(100 * d + 10 * l + b)
+    A = sp.random(3 * k, k, density=4.0 / k, random_state=np.random.RandomState(d + l + b), format="csr")
+    Q = sp.csr_matrix(A.T @ A + 1e-3 * sp.identity(k))
+    Q.sort_indices()
+    for r in (d, d + 3):
+        X = orc.project_to_manifold(r, d, n, rng.standard_normal((r, k)), l=l, b=b)
+        V = rng.standard_normal((r, k))
+        P = da.QuadraticProblem(r, d, n, da.Csr.from_scipy(Q), reg=0.05, l=l, b=b)
+        Po = orc.Problem(r, d, n, orc.CSR.from_scipy(Q), reg=0.05, l=l, b=b)
+        assert np.isclose(P.f(X), Po.f(X), rtol=1e-12)
+        assert common.rel(P.RieGrad(X), Po.rgrad(X)) < 1e-12
+        Vt = orc.tangent_project(r, d, n, X, V, l=l, b=b)
+        assert common.rel(P.projectToTangentSpace(X, V), Vt) < 1e-13
+        assert common.rel(P.HessVec(X, Vt), Po.hess(X, Vt)) < 1e-11
+        assert common.rel(P.Retract(X, 0.2 * Vt), orc.retract(r, d, n, X, 0.2 * Vt, l=l, b=b)) < 1e-13
+        assert common.rel(P.PreCondition(X, Vt), Po.precondition(X, Vt)) < 1e-9
+        M = X + 0.3 * V
+        assert common.rel(da.manifold_project(r, d, n, M, l=l, b=b),
+                          orc.project_to_manifold(r, d, n, M, l=l, b=b)) < 1e-12
+        S = da.dual_certificate(r, d, n, X, da.Csr.from_scipy(Q), l=l, b=b).to_scipy()
+        So = orc.dual_certificate(r, d, n, X, orc.CSR.from_scipy(Q), l=l, b=b).to_scipy()
+        assert abs(S - So).max() < 1e-9 * max(1.0, abs(So).max())
+        opt = da.QuadraticOptimizer(P)
+        Xs = opt.optimize(X)
+        res = opt.getOptResult()
+        Xo, reso = Po.optimize(X)
+        assert res["outer_iterations"] == reso["outer_iters"] and res["inner_iterations"] == reso["inner_iters"]
+        assert abs(res["fOpt"] - reso["fOpt"]) <= 1e-9 * abs(reso["fOpt"])
+        P.close()
