@@ -252,7 +252,8 @@ void launch_fused_finish(hipStream_t st, const ManiDesc &m, Buf2 X, const double
                          double *zraw = nullptr /* the unprojected P r, kept for a rejected step */);
 // group-style (8 lanes per pose) rgrad / retract / Nesterov; return the number of partial slots written
 int launch_fused_grad_bsr(hipStream_t st, int r, int d, const BsrDev &A, Buf2 X, const double *G, Buf2 EG, Buf2 RG, Buf2 S,
-                          int sel, double *pA, double *pB, double *posenorm, Gate g);
+                          int sel, double *pA, double *pB, double *posenorm, Gate g,
+                          const int *agent_start = nullptr, int agents = 0, int *wg_per_agent = nullptr);
 int launch_fused_grad(hipStream_t st, const ManiDesc &m, const CsrDev &Q, Buf2 X, const double *G, Buf2 EG, Buf2 RG,
                       Buf2 Sblk, int sel, double *pA, double *pB, double *posenorm, Gate g);
 int launch_g_rgrad(hipStream_t st, const ManiDesc &m, Buf2 X, Buf2 EG, Buf2 RG, Buf2 Sblk, int sel, double *partials,
@@ -260,7 +261,8 @@ int launch_g_rgrad(hipStream_t st, const ManiDesc &m, Buf2 X, Buf2 EG, Buf2 RG, 
 void launch_ctl_init(hipStream_t st, SolverCtl *c, double tol, double Delta, double maxDelta, int max_outer,
                      int stop_on_accept, int max_inner);
 void launch_eval_finish(hipStream_t st, int R, const int *pose_start, const double *posenorm, const double *pA,
-                        int npA, EvalOut *out_dev, int seq, double *split_scratch = nullptr, int nposes = 0);
+                        int npA, EvalOut *out_dev, int seq, double *split_scratch = nullptr, int nposes = 0,
+                        const double *agent_partials = nullptr, int wg_per_agent = 0);
 int eval_split_doubles();
 int launch_g_retract(hipStream_t st, const ManiDesc &m, Buf2 X, const double *V, double alpha, Buf2 out, int selOut,
                      Buf2 grad, const double *HV, double *partials, Gate g);

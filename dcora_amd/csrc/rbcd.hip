@@ -660,6 +660,7 @@ int RbcdSession::evaluate_central(double *cost2, double *gradnorm, double *block
   if (!gf && !gfb) c.enqueue_egrad(Xg.p, c.EG0.p, c.pA.p);
   if (c.group) {
     int nA = c.npA();
+    int wpa = 0;  // > 0: the evaluation dealt its workgroups to the agents and pB holds their sums (BsrGradOut)
     if (gf)  // X Q, the cost dots, the Riemannian gradient and the per-pose norms in one launch
       nA = launch_fused_grad(st, c.m, c.Q.view(), buf1(Xg.p), nullptr, buf1(c.EG0.p), buf1(c.RG0.p),
                              Buf2{{nullptr, nullptr}}, 0, c.pA.p, c.pB.p, posenorm.p, Gate{});
@@ -668,11 +669,12 @@ int RbcdSession::evaluate_central(double *cost2, double *gradnorm, double *block
       // 100k lattice, would be written back at the kernel's end for nobody)
       nA = launch_fused_grad_bsr(st, c.m.r, c.m.d, c.Qb.view(), buf1(Xg.p), nullptr, Buf2{{nullptr, nullptr}},
                                  Buf2{{nullptr, nullptr}}, Buf2{{nullptr, nullptr}}, 0, c.pA.p, c.pB.p, posenorm.p,
-                                 Gate{});
+                                 Gate{}, pose_start.p, R, &wpa);
     else
       c.enq_rgrad(buf1(Xg.p), buf1(c.EG0.p), buf1(c.RG0.p), Buf2{{nullptr, nullptr}}, 0, c.pB.p, Gate{}, posenorm.p);
     const int want = ++eval_seq;
-    launch_eval_finish(st, R, pose_start.p, posenorm.p, c.pA.p, nA, eval_dev, want, eval_split.p, n);
+    launch_eval_finish(st, R, pose_start.p, posenorm.p, c.pA.p, nA, eval_dev, want, eval_split.p, n,
+                       wpa > 0 ? c.pB.p : nullptr, wpa);
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
     while (eval_host->seq != want) {

@@ -1618,6 +1618,11 @@ struct BsrGradOut {
   Buf2 RG, S;
   double *pB = nullptr;        // partial |RG|^2, one per workgroup
   double *posenorm = nullptr;  // |RG_i|^2 per pose, or null
+  // central evaluation of an RBCD pass: the workgroups are dealt to the agents (wg_per_agent each, a slice of the
+  // agent's poses per workgroup), so pB holds every agent's |rgrad_b|^2 in wg_per_agent consecutive slots and the
+  // epilogue kernel adds those -- no per-pose norms, no launch that sums them per agent
+  const int *agent_start = nullptr;
+  int wg_per_agent = 0;
 };
 template <int D, bool DOTS, bool GRAD>
 __global__ __launch_bounds__(kBlock) void k_spmm_bsr2(int r, BsrDev A, Buf2 Xb, int selX,
@@ -1634,8 +1639,14 @@ __global__ __launch_bounds__(kBlock) void k_spmm_bsr2(int r, BsrDev A, Buf2 Xb, 
   const int t = threadIdx.x & (GW - 1);
   const int rowq = min(t & 3, DH - 1);  // the block row this lane holds
   double d0 = 0, d1 = 0, dg = 0;
-  const int range_lo = (int)((long)A.nbrows * blockIdx.x / gridDim.x);
-  const int range_hi = (int)((long)A.nbrows * (blockIdx.x + 1) / gridDim.x);
+  int range_lo = (int)((long)A.nbrows * blockIdx.x / gridDim.x);
+  int range_hi = (int)((long)A.nbrows * (blockIdx.x + 1) / gridDim.x);
+  if (GRAD && go.agent_start) {
+    const int a = blockIdx.x / go.wg_per_agent, sl = blockIdx.x - a * go.wg_per_agent;
+    const int lo = go.agent_start[a], hi = go.agent_start[a + 1];
+    range_lo = lo + (int)((long)(hi - lo) * sl / go.wg_per_agent);
+    range_hi = lo + (int)((long)(hi - lo) * (sl + 1) / go.wg_per_agent);
+  }
   const int npass = max(1, (range_hi - range_lo + kPosesPerBlock - 1) / kPosesPerBlock);
   const int per_pass = (range_hi - range_lo + npass - 1) / npass;
   for (int pose0 = range_lo; pose0 < range_hi; pose0 += per_pass) {
@@ -1828,13 +1839,30 @@ __global__ __launch_bounds__(kBlock) void k_eval_partial(const int *__restrict__
 __global__ __launch_bounds__(kBlock) void k_eval_finish(int R, const int *__restrict__ pose_start,
                                                         const double *__restrict__ posenorm,
                                                         const double *__restrict__ pA, int npA, EvalOut *out,
-                                                        int seq, const double *__restrict__ part) {
+                                                        int seq, const double *__restrict__ part,
+                                                        const double *__restrict__ agent_partials, int wpa) {
   __shared__ double s_red[16];
   __shared__ double s_bn[kMaxAgents];
   // the cost partials first (loads in flight under the per-agent sums below)
   double q0 = ((int)threadIdx.x < npA) ? pA[2 * threadIdx.x] : 0.0;
   double q1 = ((int)threadIdx.x < npA) ? pA[2 * threadIdx.x + 1] : 0.0;
-  if (part) {  // the slices of k_eval_partial, in slice order
+  if (agent_partials) {  // wpa consecutive partials per agent, written by the evaluation itself (BsrGradOut): one wave
+                         // per agent, eight loads in flight per lane, fixed order
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = kBlock / 64;
+    for (int b = w; b < R; b += nw) {
+      const int lo = b * wpa, hi = lo + wpa;
+      double v = 0;
+      for (int i0 = lo + lane; i0 < hi; i0 += 64 * 8) {
+        double t8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t8[u] = agent_partials[min(i0 + 64 * u, hi - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += (i0 + 64 * u < hi) ? t8[u] : 0.0;
+      }
+      v = f_wave_sum(v);
+      if (lane == 0) s_bn[b] = v;
+    }
+  } else if (part) {  // the slices of k_eval_partial, in slice order
     if ((int)threadIdx.x < R) {
       double v = 0;
       for (int u = 0; u < kEvalSplit; ++u) v += part[threadIdx.x * kEvalSplit + u];
@@ -1884,12 +1912,13 @@ __global__ __launch_bounds__(kBlock) void k_eval_finish(int R, const int *__rest
   }
 }
 void launch_eval_finish(hipStream_t st, int R, const int *pose_start, const double *posenorm, const double *pA,
-                        int npA, EvalOut *out_dev, int seq, double *split_scratch, int nposes) {
-  const bool split = split_scratch && nposes >= 16384;
+                        int npA, EvalOut *out_dev, int seq, double *split_scratch, int nposes,
+                        const double *agent_partials, int wg_per_agent) {
+  const bool split = !agent_partials && split_scratch && nposes >= 16384;
   if (split)
     hipLaunchKernelGGL(k_eval_partial, dim3(R * kEvalSplit), dim3(kBlock), 0, st, pose_start, posenorm, split_scratch);
   hipLaunchKernelGGL(k_eval_finish, dim3(1), dim3(kBlock), 0, st, R, pose_start, posenorm, pA, npA, out_dev, seq,
-                     split ? split_scratch : nullptr);
+                     split ? split_scratch : nullptr, agent_partials, wg_per_agent);
 }
 int eval_split_doubles() { return kMaxAgents * kEvalSplit; }
 
@@ -1923,13 +1952,22 @@ void launch_spmm_bsr(hipStream_t st, int r, int d, const BsrDev &A, Buf2 X, int 
 // EG = X Q + G, RG = Proj_X(EG), S blocks, partials {<XQ,X>, <X,G>} in pA (2 per block), |RG|^2 in pB (1 per block) and
 // the per-pose norms in ONE launch on the block structure of Q; returns the number of blocks
 int launch_fused_grad_bsr(hipStream_t st, int r, int d, const BsrDev &A, Buf2 X, const double *G, Buf2 EG, Buf2 RG, Buf2 S,
-                          int sel, double *pA, double *pB, double *posenorm, Gate g) {
-  const int grid = spmm_bsr_grid(A.nbrows);
+                          int sel, double *pA, double *pB, double *posenorm, Gate g, const int *agent_start, int agents,
+                          int *wg_per_agent) {
+  int grid = spmm_bsr_grid(A.nbrows);
   BsrGradOut go;
   go.RG = RG;
   go.S = S;
   go.pB = pB;
   go.posenorm = posenorm;
+  if (agent_start && agents > 0 && wg_per_agent) {
+    const int wpa = std::max(1, grid / agents);
+    grid = wpa * agents;
+    go.agent_start = agent_start;
+    go.wg_per_agent = wpa;
+    go.posenorm = nullptr;
+    *wg_per_agent = wpa;
+  }
   if (d == 3)
     hipLaunchKernelGGL((k_spmm_bsr2<3, true, true>), dim3(grid), dim3(kBlock), 0, st, r, A, X, sel, G, EG, sel, pA, g, go);
   else
