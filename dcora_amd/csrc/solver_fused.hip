@@ -1886,9 +1886,21 @@ __global__ __launch_bounds__(kBlock) void k_eval_finish(int R, const int *__rest
       if (lane == 0) s_bn[b] = v;
     }
   }
-  for (int i = threadIdx.x + kBlock; i < npA; i += kBlock) {
-    q0 += pA[2 * i];
-    q1 += pA[2 * i + 1];
+  // (the block evaluation of a large graph leaves thousands of partials: eight trips' loads in flight at once, added in
+  // the order a plain loop would add them)
+  for (int i0 = threadIdx.x + kBlock; i0 < npA; i0 += 8 * kBlock) {
+    double a8[8], c8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * kBlock;
+      a8[u] = i < npA ? pA[2 * i] : 0.0;
+      c8[u] = i < npA ? pA[2 * i + 1] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      q0 += a8[u];
+      q1 += c8[u];
+    }
   }
   const double fq = f_block_sum(q0, s_red);  // (its barriers also publish s_bn)
   const double fg = f_block_sum(q1, s_red);
