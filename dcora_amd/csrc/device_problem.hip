@@ -952,7 +952,7 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
                                         c, ++seq, j, has_bsr ? &Qbv : nullptr);
       if (pc) {
         launch_fused_pc(st, m, ldm, Mi, RGb(), Xb(), dbuf[par], Hd.p, eta.p, Heta.p, rbuf[par], rbuf[par ^ 1], z.p,
-                        p1.p, nP1, p3.p, c, hf_dev, ++seq, j, 0);
+                        p1.p, nP1, p3.p, c, hf_dev, ++seq, j, 0, pC.p);
       } else {
         launch_fused_precond(st, m, ldm, Mi, RGb(), dbuf[par], Hd.p, eta.p, Heta.p, rbuf[par], rbuf[par ^ 1],
                              Zpart.p, p1.p, nP1, p2.p, c, hf_dev, ++seq, j, 0, sf);
@@ -983,7 +983,8 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
       }
       fin_seq[j] = seq;
     }
-    const int nR = enq_retract(Xb(), eta.p, 1.0, Xb(), 1, RGb(), Heta.p, pC.p, Gate{c, ++seq, 1});
+    // (one-launch dense form: the kernel that ended the tCG run has retracted already, one partial pair per workgroup)
+    const int nR = pc ? nZ : enq_retract(Xb(), eta.p, 1.0, Xb(), 1, RGb(), Heta.p, pC.p, Gate{c, ++seq, 1});
     if (gf) {
       nG = launch_fused_grad(st, m, Qv, Xb(), Gp, EGb(), RGb(), Sb(), 1, pA.p, pB.p, nullptr, Gate{c, ++seq, 1});
     } else if (gfb) {

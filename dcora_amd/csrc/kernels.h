@@ -245,7 +245,7 @@ bool fused_pc_ready(const ManiDesc &m, int ldm);      // the current device gran
 int launch_fused_pc(hipStream_t st, const ManiDesc &m, int ldm, const double *Minv, Buf2 grad, Buf2 X,
                     const double *delta, const double *Hd, double *eta, double *Heta, const double *res_old,
                     double *res_new, double *z, const double *p1, int np1, double *p3, SolverCtl *ctl, HostFlags *hf,
-                    int seq, int iter, int first);
+                    int seq, int iter, int first, double *pC = nullptr /* set: the launch that ends a tCG run retracts */);
 void launch_fused_finish(hipStream_t st, const ManiDesc &m, Buf2 X, const double *Zpart, const double *res,
                          double *z, const double *p2, int np2, double *p3, SolverCtl *ctl, HostFlags *hf, int seq,
                          int iter, int first, int nsplit = -1 /* -1: fused_nsplit(m) */, SpFold sf = SpFold(),

@@ -1124,7 +1124,7 @@ __global__ __launch_bounds__(kPcBlock) void k_fused_pc(ManiDesc m, int ldm, int 
                                                        double *__restrict__ res_new, double *__restrict__ z,
                                                        const double *__restrict__ p1, int np1,
                                                        double *__restrict__ p3, SolverCtl *ctl, HostFlags *hf, int seq,
-                                                       int iter, int first) {
+                                                       int iter, int first, double *__restrict__ pC) {
   constexpr int DH = D + 1, NR = PB * DH, RM = R ? R : 8;
   constexpr int MB = kPcLoads / NR;  // steps of a wave per batch: MB * NR 16-byte loads of the inverse in flight
   extern __shared__ double s_res[];  // the residual chunk, column-major as in memory: cpad * r doubles
@@ -1194,6 +1194,36 @@ __global__ __launch_bounds__(kPcBlock) void k_fused_pc(ManiDesc m, int ldm, int 
   if (!first)
     for (int i = threadIdx.x + kPcBlock; i < np1; i += kPcBlock) myp += p1[i];
   if (seq > st_o || (!first && seq > st_t)) return;  // finished: no-op (uniform over the grid)
+  // The launch in which a tCG run ends (boundary, negative curvature, residual rule, iteration cap -- every workgroup
+  // knows: the tests are uniform over the grid) also takes the step: X_trial = Retr_X(eta) for the workgroup's own
+  // poses and the partial <eta, grad>, <eta, H eta> of the model decrease, what a launch of k_g_retract did next
+  // (pC != null).  Same retraction, same entries; the partials are per workgroup of PB poses instead of 32.
+  auto retract_tail = [&]() {
+    if (!pC) return;
+    __syncthreads();  // (the z part of wave 0 may still be reading s_R)
+    double a0 = 0, a1 = 0;
+    if (own) {
+      const double en = eta[oown], hn = Heta[oown], gr = gradb.p[cur][oown];  // eta, H eta: this thread's own stores
+      a0 = en * gr;
+      a1 = en * hn;
+      const int lc = e / r, t = e - lc * r;
+      s_R[lc * RM + t] = en;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      Row<D> Yn = Y;
+#pragma unroll
+      for (int a = 0; a < DH; ++a) Yn.e[a] += 1.0 * (pact ? s_R[(g * DH + a) * RM + tt] : 0.0);
+      row_qf<D>(Yn);
+      st_row<D>(Xb.p[cur ^ 1] + o, r, tt, pact, Yn);
+    }
+    const double t0 = f_block_sum(a0, s_red);
+    const double t1 = f_block_sum(a1, s_red);
+    if (threadIdx.x == 0) {
+      pC[2 * blockIdx.x] = t0;
+      pC[2 * blockIdx.x + 1] = t1;
+    }
+  };
   // ---- step length / trust-region boundary (ROPTLIB tCG_TR), as in B ----
   double alpha = 0, step = 0;
   bool boundary = false;
@@ -1241,7 +1271,10 @@ __global__ __launch_bounds__(kPcBlock) void k_fused_pc(ManiDesc m, int ldm, int 
       }
     }
   }
-  if (boundary) return;
+  if (boundary) {
+    retract_tail();
+    return;
+  }
   // ---- the whole updated residual through LDS, chunk by chunk; product with the workgroup's rows ----
   double acc[NR][RM];
 #pragma unroll
@@ -1372,6 +1405,7 @@ __global__ __launch_bounds__(kPcBlock) void k_fused_pc(ManiDesc m, int ldm, int 
         ctl->tcg_done_stamp = seq;
         f_host_store(&hf->tcg_done_seq, seq);
       }
+      retract_tail();
       return;
     }
   }
@@ -1400,6 +1434,7 @@ __global__ __launch_bounds__(kPcBlock) void k_fused_pc(ManiDesc m, int ldm, int 
     }
     f_host_store(&hf->last_seq_done, seq);
   }
+  if (!first && iter + 1 >= c_max_inner) retract_tail();
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -2068,7 +2103,7 @@ template <int D, int PB, int R, bool MULTI>
 static int pc_launch(hipStream_t st, const ManiDesc &m, int ldm, const double *Minv, Buf2 grad, Buf2 X,
                      const double *delta, const double *Hd, double *eta, double *Heta, const double *res_old,
                      double *res_new, double *z, const double *p1, int np1, double *p3, SolverCtl *ctl, HostFlags *hf,
-                     int seq, int iter, int first, bool prepare_only) {
+                     int seq, int iter, int first, double *pC, bool prepare_only) {
   // The dynamic-LDS limit is an attribute of (function, DEVICE): it is set once per device the instantiation runs on
   // (one bit per device; a process drives R GPUs from R host threads, SURVEY 8(b) threading).  -1 = this device refuses
   // the attribute or the launch; use_pc() asks with st == nullptr before choosing the one-launch form.
@@ -2091,17 +2126,17 @@ static int pc_launch(hipStream_t st, const ManiDesc &m, int ldm, const double *M
   const int grid = (m.n + PB - 1) / PB;
   if (prepare_only) return grid;
   hipLaunchKernelGGL((k_fused_pc<D, PB, R, MULTI>), dim3(grid), dim3(kPcBlock), lds, st, m, ldm, chk, Minv, grad, X,
-                     delta, Hd, eta, Heta, res_old, res_new, z, p1, np1, p3, ctl, hf, seq, iter, first);
+                     delta, Hd, eta, Heta, res_old, res_new, z, p1, np1, p3, ctl, hf, seq, iter, first, pC);
   if (hipGetLastError() != hipSuccess) return -1;
   return grid;
 }
 static int fused_pc_dispatch(hipStream_t st, const ManiDesc &m, int ldm, const double *Minv, Buf2 grad, Buf2 X,
                              const double *delta, const double *Hd, double *eta, double *Heta, const double *res_old,
                              double *res_new, double *z, const double *p1, int np1, double *p3, SolverCtl *ctl,
-                             HostFlags *hf, int seq, int iter, int first, bool prepare_only) {
+                             HostFlags *hf, int seq, int iter, int first, double *pC, bool prepare_only) {
 #define DCORA_PC(D_, PB_, R_, MULTI_)                                                                                \
   return pc_launch<D_, PB_, R_, MULTI_>(st, m, ldm, Minv, grad, X, delta, Hd, eta, Heta, res_old, res_new, z, p1, np1, \
-                                        p3, ctl, hf, seq, iter, first, prepare_only)
+                                        p3, ctl, hf, seq, iter, first, pC, prepare_only)
 #define DCORA_PC_FIXED_R(D_, PB_, MULTI_)      \
   do {                                          \
     if (D_ == 3 && m.r == 3) DCORA_PC(D_, PB_, 3, MULTI_); \
@@ -2135,14 +2170,14 @@ static int fused_pc_dispatch(hipStream_t st, const ManiDesc &m, int ldm, const d
 int launch_fused_pc(hipStream_t st, const ManiDesc &m, int ldm, const double *Minv, Buf2 grad, Buf2 X,
                     const double *delta, const double *Hd, double *eta, double *Heta, const double *res_old,
                     double *res_new, double *z, const double *p1, int np1, double *p3, SolverCtl *ctl, HostFlags *hf,
-                    int seq, int iter, int first) {
+                    int seq, int iter, int first, double *pC) {
   return fused_pc_dispatch(st, m, ldm, Minv, grad, X, delta, Hd, eta, Heta, res_old, res_new, z, p1, np1, p3, ctl, hf,
-                           seq, iter, first, false);
+                           seq, iter, first, pC, false);
 }
 bool fused_pc_ready(const ManiDesc &m, int ldm) {
   Buf2 none{};
   return fused_pc_dispatch(nullptr, m, ldm, nullptr, none, none, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                           nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, true) >= 0;
+                           nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, true) >= 0;
 }
 void launch_fused_finish(hipStream_t st, const ManiDesc &m, Buf2 X, const double *Zpart, const double *res,
                          double *z, const double *p2, int np2, double *p3, SolverCtl *ctl, HostFlags *hf, int seq,
