@@ -909,24 +909,39 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
   launch_rtr_init(st, pA.p, nAe, pB.p, nG, c, hf_dev, ++seq, ci);
   int last_pace_seq = seq;
   std::vector<int> fin_seq((size_t)std::max(1, max_inner));
-  for (int outer = 0; outer < max_outer; ++outer) {
-    if (!spin_until([&] { return hf->last_seq_done >= last_pace_seq || outer_done(); }, 20.0)) return timed_out();
-    if (outer_done()) break;
-    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0) break;  // TimeBound :252
-    // z0 = P(grad): B in "first" mode streams the preconditioner over grad, C projects and forms <z0, r0>
-    int tcg_first_seq;
+  // The first kernel of an RTR iteration (z0 = P grad: B in "first" mode, or B + C in one launch) needs nothing the host
+  // has to decide: it is gated by the RTR loop's own stamp and picks the accepted iterate's buffers from the control
+  // block when it starts.  So it is enqueued BEHIND k_rtr_init / k_rtr_decide at once, before the host has seen their
+  // verdict: the GPU runs it while the host reads the flag and enqueues the tCG iteration behind it, instead of idling
+  // for that round trip at every iteration (a loop that had ended leaves one gated no-op).  Returns its seq, < 0 when
+  // the launch failed.
+  auto enqueue_first = [&]() -> int {
     if (pc) {
       if (launch_fused_pc(st, m, ldm, Mi, RGb(), Xb(), nullptr, nullptr, eta.p, Heta.p, nullptr, rbuf[0], z.p, nullptr,
-                          0, p3.p, c, hf_dev, ++seq, 0, 1) < 0) {
-        DCORA_HIP(hipStreamSynchronize(st));
-        set_last_error("k_fused_pc could not be launched on this device");
-        return DCORA_ERR_HIP;
-      }
-      tcg_first_seq = seq;
+                          0, p3.p, c, hf_dev, ++seq, 0, 1) < 0)
+        return -1;
     } else {
       launch_fused_precond(st, m, ldm, Mi, RGb(), nullptr, nullptr, eta.p, Heta.p, nullptr, rbuf[0], Zpart.p,
                            nullptr, 0, p2.p, c, hf_dev, ++seq, 0, 1, sf);
-      tcg_first_seq = seq;
+    }
+    return seq;
+  };
+  auto time_is_up = [&]() {  // TimeBound :252
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0;
+  };
+  int next_first_seq = time_is_up() ? 0 : enqueue_first();
+  for (int outer = 0; outer < max_outer; ++outer) {
+    if (next_first_seq < 0) {
+      DCORA_HIP(hipStreamSynchronize(st));
+      set_last_error("k_fused_pc could not be launched on this device");
+      return DCORA_ERR_HIP;
+    }
+    if (!spin_until([&] { return hf->last_seq_done >= last_pace_seq || outer_done(); }, 20.0)) return timed_out();
+    if (outer_done()) break;
+    if (next_first_seq == 0) break;  // the time bound had passed when this iteration's first kernel was due
+    // z0 = P(grad): B in "first" mode streams the preconditioner over grad, C projects and forms <z0, r0>
+    const int tcg_first_seq = next_first_seq;
+    if (!pc) {
       // A rejected step (k_rtr_decide said so in reject_seq) left the iterate and its gradient where they were: z0 is
       // the one of the iteration before, whose unprojected form the finish kernel kept in W (free on this path) --
       // one application of the sparse preconditioner less per rejection (0.25 per RBCD iteration on the 100k lattice).
@@ -996,6 +1011,7 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
     }
     launch_rtr_decide(st, pA.p, nAe, pB.p, nG, pC.p, nR, c, hf_dev, ++seq);
     last_pace_seq = seq;
+    if (outer + 1 < max_outer) next_first_seq = time_is_up() ? 0 : enqueue_first();
   }
   return DCORA_OK;
 }
