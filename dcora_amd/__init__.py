@@ -210,12 +210,14 @@ class ROptParameters:
 class QuadraticProblem:
     """ref include/DCORA/QuadraticProblem.h: f, RieGrad, RieGradNorm, Retract, PreCondition, escapeSaddle"""
 
-    def __init__(self, r, d, n, Q, G=None, reg=0.1, l=0, b=0, device=0):
+    def __init__(self, r, d, n, Q, G=None, reg=0.1, l=0, b=0, device=0, layout=0):
+        """layout: 0 = SE ordering when l = b = 0, RA otherwise; capi.LAYOUT_RA keeps the RA ordering of a range-aided
+        graph that holds neither ranges nor landmarks (ref src/Graph.cpp:68-75)"""
         self.r, self.d, self.n, self.l, self.b = r, d, n, l, b
         self.k = (d + 1) * n + l + b
         if Q.n != self.k:
             raise ValueError("Q is %d x %d, expected %d" % (Q.n, Q.n, self.k))
-        dims = Dims(r, d, n, l, b)
+        dims = Dims(r, d, n, l, b, layout)
         g = None
         if G is not None:
             self._G = F(G)
@@ -382,18 +384,18 @@ class QuadraticOptimizer:
         return self.result.as_dict()
 
 
-def manifold_project(r, d, n, M, l=0, b=0, device=0):
+def manifold_project(r, d, n, M, l=0, b=0, device=0, layout=0):
     """projectToSEMatrix / projectToRAMatrix (ref src/DCORA_utils.cpp:2201-2220)"""
-    dims = Dims(r, d, n, l, b)
+    dims = Dims(r, d, n, l, b, layout)
     k = (d + 1) * n + l + b
     out = np.zeros(r * k)
     check(capi.lib().dcora_manifold_project(C.byref(dims), F(M), out, device))
     return unF(out, r, k)
 
 
-def dual_certificate(r, d, n, X, Q, l=0, b=0, device=0):
+def dual_certificate(r, d, n, X, Q, l=0, b=0, device=0, layout=0):
     """constructDualCertificateMatrixPGO / RASLAM (ref src/DCORA_utils.cpp:1898-1982)"""
-    dims = Dims(r, d, n, l, b)
+    dims = Dims(r, d, n, l, b, layout)
     h = C.c_void_p()
     check(capi.lib().dcora_cert_dual_matrix(C.byref(dims), F(X), Q.rp, Q.ci, Q.v, device, C.byref(h)))
     return Csr(*capi.take_csr(h))
@@ -778,7 +780,7 @@ def align_lifted_trajectory_to_frame(X, anchor, d, n, global_alignment=True, dev
 def ra_states_in_local_frame(X, r, d, n, l, b, device=0):
     """Agent::getStatesInLocalFrame (ref src/Agent.cpp:950-1003): X r x k (RA ordering) -> (trajectory d x (d+1) n in
     the SE ordering, unit spheres d x l, landmarks d x b), all in the frame of pose 0"""
-    dims = Dims(r, d, n, l, b)
+    dims = Dims(r, d, n, l, b, capi.LAYOUT_RA)
     T, S, Lm = np.zeros(d * (d + 1) * n), np.zeros(max(d * l, 1)), np.zeros(max(d * b, 1))
     check(capi.lib().dcora_round_align_trajectory(C.byref(dims), F(X), None, 0, T, S.ctypes.data_as(C.c_void_p),
                                                   Lm.ctypes.data_as(C.c_void_p), device))
@@ -787,7 +789,7 @@ def ra_states_in_local_frame(X, r, d, n, l, b, device=0):
 
 def project_solution_raslam(X, r, d, n, l, b, device=0):
     """projectSolutionRASLAM (ref src/DCORA_utils.cpp:1984-2031): r x k -> d x k"""
-    dims = Dims(r, d, n, l, b)
+    dims = Dims(r, d, n, l, b, capi.LAYOUT_RA)
     k = (d + 1) * n + l + b
     out = np.zeros(d * k)
     check(capi.lib().dcora_round_project_solution_raslam(C.byref(dims), F(X), out, device))

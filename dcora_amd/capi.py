@@ -22,7 +22,10 @@ class DcoraError(RuntimeError):
 
 
 class Dims(C.Structure):
-    _fields_ = [("r", C.c_int), ("d", C.c_int), ("n", C.c_int), ("l", C.c_int), ("b", C.c_int)]
+    _fields_ = [("r", C.c_int), ("d", C.c_int), ("n", C.c_int), ("l", C.c_int), ("b", C.c_int), ("layout", C.c_int)]
+
+
+LAYOUT_AUTO, LAYOUT_SE, LAYOUT_RA = 0, 1, 2
 
 
 class ROptParams(C.Structure):

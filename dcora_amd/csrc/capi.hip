@@ -70,6 +70,11 @@ int bad(const char *msg) {
   set_last_error(msg);
   return DCORA_ERR_BAD_ARG;
 }
+// DCORA_LAYOUT_SE names a pose graph: it cannot hold unit spheres or landmarks
+bool layout_ok(const dcora_dims *dims) {
+  return dims->layout >= DCORA_LAYOUT_AUTO && dims->layout <= DCORA_LAYOUT_RA &&
+         !(dims->layout == DCORA_LAYOUT_SE && (dims->l != 0 || dims->b != 0));
+}
 }  // namespace
 
 #define DCORA_TRY try {
@@ -122,6 +127,7 @@ void dcora_ropt_params_default(dcora_ropt_params *p) {
 int dcora_problem_create(const dcora_dims *dims, const int *rowptr, const int *colidx, const double *vals,
                          const double *G, double precond_reg, int device, dcora_problem_t *out) {
   if (!dims || !rowptr || !colidx || !vals || !out) return bad("null argument");
+  if (!layout_ok(dims)) return bad("dims: layout SE needs l = b = 0");
   DCORA_TRY
   const int k = (dims->d + 1) * dims->n + dims->l + dims->b;
   dcora_problem_s *h = new dcora_problem_s;
@@ -170,13 +176,14 @@ int dcora_problem_escape_saddle(dcora_problem_t p, const double *Xopt, double th
 }
 int dcora_manifold_project(const dcora_dims *dims, const double *M, double *out, int device) {
   if (!dims || !M || !out) return bad("null argument");
+  if (!layout_ok(dims)) return bad("dims: layout SE needs l = b = 0");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     set_last_error("no HIP device available: libdcora_hip has no CPU fallback");
     return DCORA_ERR_NO_DEVICE;
   }
   DCORA_HIP(hipSetDevice(device));
-  const ManiDesc m = make_mani(dims->r, dims->d, dims->n, dims->l, dims->b);
+  const ManiDesc m = make_mani(*dims);
   const size_t N = (size_t)m.r * m.k;
   DevBuf<double> a, b;
   DCORA_HIP(a.alloc(N));
@@ -411,7 +418,8 @@ int dcora_cert_lambda_min_certified(int k, const int *rp, const int *ci, const d
 int dcora_cert_suboptimality_gap(const dcora_dims *dims, const double *X, double lambda_lower_bound, double *gap,
                                  double *n_eff) {
   if (!dims || !X || !gap) return bad("null argument");
-  const ManiDesc m = make_mani(dims->r, dims->d, dims->n, dims->l, dims->b);
+  if (!layout_ok(dims)) return bad("dims: layout SE needs l = b = 0");
+  const ManiDesc m = make_mani(*dims);
   const int r = m.r;
   double rot = 0;
   for (int i = 0; i < m.n; ++i)
@@ -475,6 +483,7 @@ int dcora_csr_destroy(dcora_csr_t m) {
 int dcora_cert_dual_matrix(const dcora_dims *dims, const double *X, const int *rp, const int *ci, const double *v,
                            int device, dcora_csr_t *S) {
   if (!dims || !X || !rp || !S) return bad("null argument");
+  if (!layout_ok(dims)) return bad("dims: layout SE needs l = b = 0");
   DCORA_TRY
   const int k = (dims->d + 1) * dims->n + dims->l + dims->b;
   dcora_csr_s *h = new dcora_csr_s;
@@ -1376,7 +1385,9 @@ int dcora_agent_initialize_in_global_frame(const dcora_dims *dims, const double 
                                            const double *T_local, const double *YLift, double *X) {
   if (!dims || !T_world_robot || !T_local || !YLift || !X) return bad("null argument");
   if ((dims->d != 2 && dims->d != 3) || dims->r < dims->d || dims->n < 1) return bad("bad dims");
-  initialize_in_global_frame(dims->r, dims->d, dims->n, dims->l, dims->b, T_world_robot, T_local, YLift, X);
+  if (!layout_ok(dims)) return bad("dims: layout SE needs l = b = 0");
+  initialize_in_global_frame(dims->r, dims->d, dims->n, dims->l, dims->b, make_mani(*dims).se != 0, T_world_robot, T_local,
+                             YLift, X);
   return DCORA_OK;
 }
 int dcora_measurement_errors(dcora_dataset_t ds, int r, const double *X, double *out, int device) {
@@ -1405,12 +1416,14 @@ int dcora_solve_robust_pgo(dcora_dataset_t ds, const dcora_ropt_params *params, 
 int dcora_round_align_trajectory(const dcora_dims *dims, const double *X, const double *anchor, int global_alignment,
                                  double *trajectory, double *unit_spheres, double *landmarks, int device) {
   if (!dims || !X || !trajectory) return bad("null argument");
+  if (!layout_ok(dims)) return bad("dims: layout SE needs l = b = 0");
   DCORA_TRY
   return round_align(*dims, X, anchor, global_alignment, trajectory, unit_spheres, landmarks, device);
   DCORA_CATCH
 }
 int dcora_round_project_solution_raslam(const dcora_dims *dims, const double *X, double *out, int device) {
   if (!dims || !X || !out) return bad("null argument");
+  if (!layout_ok(dims)) return bad("dims: layout SE needs l = b = 0");
   DCORA_TRY
   return round_project_solution(*dims, X, out, device);
   DCORA_CATCH

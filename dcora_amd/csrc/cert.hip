@@ -511,7 +511,7 @@ int device_dual_certificate(const dcora_dims &dims, const double *Xh, const Host
     set_last_error("bad dims (need 1 <= r <= 16, d in {2,3})");
     return DCORA_ERR_BAD_ARG;
   }
-  const ManiDesc m = make_mani(dims.r, dims.d, dims.n, dims.l, dims.b);
+  const ManiDesc m = make_mani(dims);
   if (Q.n != m.k) {
     set_last_error("Q dimension does not match (d+1) n + l + b");
     return DCORA_ERR_BAD_ARG;

@@ -171,7 +171,7 @@ int DeviceProblem::init(const dcora_dims &dims, const HostCsr &Qh, const double 
       std::fprintf(stderr, "[init] %-12s %.3f ms\n", what,
                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ti0).count());
   };
-  m = make_mani(dims.r, dims.d, dims.n, dims.l, dims.b);
+  m = make_mani(dims);
   if (Qh.n != m.k) {
     set_last_error("Q dimension does not match (d+1) n + l + b");
     return DCORA_ERR_BAD_ARG;

@@ -109,7 +109,7 @@ int Exchange::certify(const HostCsr *Qglobal, double eta, int *certified, double
   hipStream_t st = s_->x_stream();
   DCORA_HIP(hipSetDevice(device));
   const int R = s_->x_num_agents(), r = s_->x_rank_r(), ktot = (int)s_->x_num_cols();
-  const dcora_dims dims = pgo ? dcora_dims{r, pgo->d, pgo->n, 0, 0} : dcora_dims{r, ras->d, ras->n, ras->l, ras->b};
+  const dcora_dims dims = pgo ? dcora_dims{r, pgo->d, pgo->n, 0, 0} : dcora_dims{r, ras->d, ras->n, ras->l, ras->b, DCORA_LAYOUT_RA};
   const int chol_block = pgo ? pgo->d + 1 : 1;
   double *mirror = s_->x_mirror();
   if (certified) *certified = 0;

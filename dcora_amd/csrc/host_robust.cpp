@@ -272,11 +272,10 @@ void fixed_stiefel_variable(int r, int d, double *Y) {
   }
 }
 
-void initialize_in_global_frame(int r, int d, int n, int l, int b, const double *Twr, const double *Tlocal,
+void initialize_in_global_frame(int r, int d, int n, int l, int b, bool se, const double *Twr, const double *Tlocal,
                                 const double *YLift, double *X) {
   const int dh = d + 1;
-  const bool se = (l == 0 && b == 0);
-  const int k = se ? dh * n : dh * n + l + b;
+  const int k = dh * n + l + b;
   auto lifted = [&](int col, const double *g) {  // X(:, col) = YLift g
     for (int a = 0; a < r; ++a) {
       double s = 0;

@@ -49,7 +49,7 @@ bool robust_neighbor_transform(int d, int m, const double *cand, bool two_stage,
 void fixed_stiefel_variable(int r, int d, double *Y);
 // Agent::initializeInGlobalFrame: X = YLift * (T_world_robot applied to the local estimate); Tlocal d x k in this
 // ABI's ordering (SE when l = b = 0, RA otherwise), YLift r x d, X r x k
-void initialize_in_global_frame(int r, int d, int n, int l, int b, const double *T_world_robot, const double *Tlocal,
+void initialize_in_global_frame(int r, int d, int n, int l, int b, bool se, const double *T_world_robot, const double *Tlocal,
                                 const double *YLift, double *X);
 
 }  // namespace dcora

@@ -27,12 +27,18 @@ struct ManiDesc {
   __host__ __device__ int num_euc() const { return se ? n : n + b; }
   __host__ __device__ int euc_col(int e) const { return se ? e * (d + 1) + d : d * n + l + e; }
 };
-inline ManiDesc make_mani(int r, int d, int n, int l, int b) {
+// layout: 0 = SE ordering when l = b = 0 (DCORA_LAYOUT_AUTO), 1 = SE, 2 = RA whatever l and b are (a range-aided
+// graph without ranges or landmarks keeps the RA ordering: ref src/Graph.cpp:68-75)
+inline ManiDesc make_mani(int r, int d, int n, int l, int b, int layout = 0) {
   ManiDesc m;
   m.r = r; m.d = d; m.n = n; m.l = l; m.b = b;
-  m.se = (l == 0 && b == 0) ? 1 : 0;
+  m.se = (layout == 2) ? 0 : ((l == 0 && b == 0) ? 1 : 0);
   m.k = (d + 1) * n + l + b;
   return m;
+}
+template <class Dims>
+inline ManiDesc make_mani(const Dims &dims) {
+  return make_mani(dims.r, dims.d, dims.n, dims.l, dims.b, dims.layout);
 }
 
 constexpr int kLongSplit = 8;  // workgroups per long row; the last one to arrive adds the slices in order

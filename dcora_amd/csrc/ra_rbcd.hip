@@ -119,7 +119,7 @@ int RaRbcdSession::init(const HostRADataset &ds, const dcora_rbcd_options &o) {
     int rc = device_precond_regularization(Qaa, o.device, &a.reg);  // ref src/Graph.cpp:1901-1960, per agent
     if (rc) return rc;
     a.prob.reset(new DeviceProblem);
-    dcora_dims dims{r, d, a.n, a.l, a.b};
+    dcora_dims dims{r, d, a.n, a.l, a.b, DCORA_LAYOUT_RA};  // an agent without ranges / landmarks keeps the RA ordering
     rc = a.prob->init(dims, Qaa, nullptr, a.reg, o.device, st);
     if (rc) return rc;
     rc = a.coupling.upload(C);
@@ -143,7 +143,7 @@ int RaRbcdSession::init(const HostRADataset &ds, const dcora_rbcd_options &o) {
   }
   if (o.world_size == 1) {  // the central evaluation of the one-process loop; ranks evaluate agent by agent
     central.reset(new DeviceProblem);
-    dcora_dims dims{r, d, n, l, b};
+    dcora_dims dims{r, d, n, l, b, DCORA_LAYOUT_RA};
     int rc = central->init(dims, Q, nullptr, -1.0, o.device, st);
     if (rc) return rc;
   }

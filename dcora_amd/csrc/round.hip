@@ -290,7 +290,7 @@ int round_align(const dcora_dims &dims, const double *X, const double *anchor, i
     set_last_error("round_align: need d <= r <= 16, d in {2,3}, n >= 1");
     return DCORA_ERR_BAD_ARG;
   }
-  const ManiDesc m = make_mani(dims.r, dims.d, dims.n, dims.l, dims.b);
+  const ManiDesc m = make_mani(dims);
   const int r = m.r, d = m.d;
   Frame f;
   std::vector<double> a((size_t)r * (d + 1));
@@ -345,7 +345,7 @@ int round_project_solution(const dcora_dims &dims, const double *X, double *out,
     set_last_error("round_project_solution: need d <= r <= 16, d in {2,3}, n >= 1");
     return DCORA_ERR_BAD_ARG;
   }
-  const ManiDesc m = make_mani(dims.r, dims.d, dims.n, dims.l, dims.b);
+  const ManiDesc m = make_mani(dims);
   const int r = m.r, d = m.d, k = m.k;
   DevBuf<double> dX, dG, dP;
   DevBuf<int> dcnt;

@@ -214,7 +214,7 @@ class Agent {
     Matrix YLift(r, d), Tid(d, d + 1);
     check_status(dcora_fixed_stiefel_variable((int)r, (int)d, YLift.data()), "Agent::initialize");
     for (unsigned a = 0; a < d; ++a) Tid(a, a) = 1.0;
-    dcora_dims dims{(int)r, (int)d, (int)n, (int)l, (int)b};
+    dcora_dims dims{(int)r, (int)d, (int)n, (int)l, (int)b, DCORA_LAYOUT_RA};
     ra_->X = Matrix(r, problem_dimension());
     check_status(dcora_agent_initialize_in_global_frame(&dims, Tid.data(), local.data(), YLift.data(), ra_->X.data()),
                  "Agent::initialize");
@@ -225,7 +225,7 @@ class Agent {
     if (!ra_) throw std::logic_error("Agent::getStatesInLocalFrame(3): the agent is on a pose graph");
     if (ra_->X.rows() == 0) return false;
     const unsigned d = dimension(), n = num_poses(), l = num_unit_spheres(), b = num_landmarks();
-    dcora_dims dims{(int)relaxation_rank(), (int)d, (int)n, (int)l, (int)b};
+    dcora_dims dims{(int)relaxation_rank(), (int)d, (int)n, (int)l, (int)b, DCORA_LAYOUT_RA};
     Matrix T(d, (size_t)(d + 1) * n), S(d, l), L(d, b);
     check_status(dcora_round_align_trajectory(&dims, ra_->X.data(), nullptr, 0, T.data(), l ? S.data() : nullptr,
                                               b ? L.data() : nullptr, params_.device),

@@ -62,7 +62,7 @@ inline G2ODataset read_g2o_file(const std::string &filename) {
 
 // ref src/DCORA_utils.cpp:1898-1931 / 1933-1982
 inline SparseMatrix constructDualCertificateMatrixPGO(const Matrix &X, const SparseMatrix &Q, unsigned d, unsigned n) {
-  dcora_dims dims{(int)X.rows(), (int)d, (int)n, 0, 0};
+  dcora_dims dims{(int)X.rows(), (int)d, (int)n, 0, 0, DCORA_LAYOUT_SE};
   dcora_csr_t h = nullptr;
   detail::check(dcora_cert_dual_matrix(&dims, X.data(), Q.rowptr.data(), Q.colidx.data(), Q.vals.data(), 0, &h),
                 "constructDualCertificateMatrixPGO");
@@ -70,7 +70,7 @@ inline SparseMatrix constructDualCertificateMatrixPGO(const Matrix &X, const Spa
 }
 inline SparseMatrix constructDualCertificateMatrixRASLAM(const Matrix &X, const SparseMatrix &Q, unsigned d, unsigned n,
                                                          unsigned l, unsigned b) {
-  dcora_dims dims{(int)X.rows(), (int)d, (int)n, (int)l, (int)b};
+  dcora_dims dims{(int)X.rows(), (int)d, (int)n, (int)l, (int)b, DCORA_LAYOUT_RA};
   dcora_csr_t h = nullptr;
   detail::check(dcora_cert_dual_matrix(&dims, X.data(), Q.rowptr.data(), Q.colidx.data(), Q.vals.data(), 0, &h),
                 "constructDualCertificateMatrixRASLAM");
@@ -95,7 +95,7 @@ inline bool fastVerification(const SparseMatrix &S, double eta, double *theta, V
 // ref src/DCORA_utils.cpp:2262-2289.  Tw0 is the lifted anchor pose [Y0 p0] (r x (d+1)).
 inline Matrix alignLiftedTrajectoryToFrame(const Matrix &liftedTrajectoryInit, const Matrix &Tw0, unsigned d,
                                            unsigned n, bool isGlobalAlignment) {
-  dcora_dims dims{(int)liftedTrajectoryInit.rows(), (int)d, (int)n, 0, 0};
+  dcora_dims dims{(int)liftedTrajectoryInit.rows(), (int)d, (int)n, 0, 0, DCORA_LAYOUT_SE};
   Matrix T(d, (size_t)(d + 1) * n);
   detail::check(dcora_round_align_trajectory(&dims, liftedTrajectoryInit.data(), Tw0.data(), isGlobalAlignment ? 1 : 0,
                                              T.data(), nullptr, nullptr, 0),
@@ -105,7 +105,7 @@ inline Matrix alignLiftedTrajectoryToFrame(const Matrix &liftedTrajectoryInit, c
 
 // ref src/DCORA_utils.cpp:1984-2031
 inline Matrix projectSolutionRASLAM(const Matrix &X, unsigned r, unsigned d, unsigned n, unsigned l, unsigned b) {
-  dcora_dims dims{(int)r, (int)d, (int)n, (int)l, (int)b};
+  dcora_dims dims{(int)r, (int)d, (int)n, (int)l, (int)b, DCORA_LAYOUT_RA};
   Matrix P(d, (size_t)(d + 1) * n + l + b);
   detail::check(dcora_round_project_solution_raslam(&dims, X.data(), P.data(), 0), "projectSolutionRASLAM");
   return P;

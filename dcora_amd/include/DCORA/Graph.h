@@ -54,7 +54,10 @@ class Graph {
   unsigned b() const { return b_; }  // landmarks
   unsigned k() const { return (d_ + 1) * n_ + l_ + b_; }
   GraphType graphType() const { return type_; }
-  bool isPGOCompatible() const { return l_ == 0 && b_ == 0; }
+  // ref src/Graph.cpp:68-75: by graph TYPE -- a range-aided graph that holds neither ranges nor landmarks still lives on
+  // the RA manifold (RA column ordering)
+  bool isPGOCompatible() const { return type_ == GraphType::PoseGraph; }
+  int layout() const { return type_ == GraphType::PoseGraph ? DCORA_LAYOUT_SE : DCORA_LAYOUT_RA; }
   // ref src/Graph.cpp (setMeasurements): the poses of this robot are those the measurements name
   void setMeasurements(const std::vector<RelativePosePoseMeasurement> &measurements) {
     meas_ = measurements;

@@ -15,12 +15,15 @@ struct ProblemData {
   Matrix G;              // Graph::linearMatrix() (may be empty = zero)
   double precond_reg = 0.1;  // 1e-1 for PGO (ref src/Graph.cpp:1906); < 0 = no preconditioner
   int device = 0;
+  int layout = DCORA_LAYOUT_AUTO;  // DCORA_LAYOUT_RA: the RA ordering also when l = b = 0 (a range-aided graph type)
 };
 
 class QuadraticProblem {
  public:
-  explicit QuadraticProblem(const ProblemData &pd) : r_(pd.r), d_(pd.d), n_(pd.n), l_(pd.l), b_(pd.b) {
-    dcora_dims dims{(int)pd.r, (int)pd.d, (int)pd.n, (int)pd.l, (int)pd.b};
+  explicit QuadraticProblem(const ProblemData &pd)
+      : r_(pd.r), d_(pd.d), n_(pd.n), l_(pd.l), b_(pd.b),
+        se_(pd.layout == DCORA_LAYOUT_RA ? false : (pd.l == 0 && pd.b == 0)) {
+    dcora_dims dims{(int)pd.r, (int)pd.d, (int)pd.n, (int)pd.l, (int)pd.b, pd.layout};
     check_status(dcora_problem_create(&dims, pd.Q.rowptr.data(), pd.Q.colidx.data(), pd.Q.vals.data(),
                                       pd.G.rows() ? pd.G.data() : nullptr, pd.precond_reg, pd.device, &h_),
                  "QuadraticProblem");
@@ -30,12 +33,13 @@ class QuadraticProblem {
   // the preconditioner (Q + reg I)^-1 with the Graph's regularisation (ref src/Graph.cpp:1901-1960) is built when
   // withPreconditioner is set (the local solver and escapeSaddle need it)
   explicit QuadraticProblem(const std::shared_ptr<Graph> &graph, bool withPreconditioner = false, int device = 0)
-      : r_(graph->r()), d_(graph->d()), n_(graph->n()), l_(graph->l()), b_(graph->b()), graph_(graph) {
+      : r_(graph->r()), d_(graph->d()), n_(graph->n()), l_(graph->l()), b_(graph->b()),
+        se_(graph->isPGOCompatible()), graph_(graph) {
     const SparseMatrix &Q = graph->quadraticMatrix();
     const Matrix G = graph->linearMatrix();
     bool has_G = false;
     for (size_t i = 0; i < G.rows() * G.cols() && !has_G; ++i) has_G = G.data()[i] != 0.0;
-    dcora_dims dims{(int)r_, (int)d_, (int)n_, (int)l_, (int)b_};
+    dcora_dims dims{(int)r_, (int)d_, (int)n_, (int)l_, (int)b_, graph->layout()};
     check_status(dcora_problem_create(&dims, Q.rowptr.data(), Q.colidx.data(), Q.vals.data(), has_G ? G.data() : nullptr,
                                       withPreconditioner ? graph->preconditionerRegularization(device) : -1.0, device,
                                       &h_),
@@ -51,7 +55,7 @@ class QuadraticProblem {
   unsigned int num_unit_spheres() const { return l_; }
   unsigned int num_landmarks() const { return b_; }
   unsigned int problem_dimension() const { return (d_ + 1) * n_ + l_ + b_; }
-  bool useSEManifold() const { return l_ == 0 && b_ == 0; }
+  bool useSEManifold() const { return se_; }  // by graph type, ref src/QuadraticProblem.cpp:19-34
 
   void setLinearTerm(const Matrix &G) { check_status(dcora_problem_set_linear_term(h_, G.data()), "setLinearTerm"); }
   double f(const Matrix &Y) const {
@@ -94,6 +98,7 @@ class QuadraticProblem {
 
  private:
   unsigned r_, d_, n_, l_, b_;
+  bool se_;
   std::shared_ptr<Graph> graph_;
   dcora_problem_t h_ = nullptr;
 };

@@ -45,13 +45,23 @@ const char *dcora_last_error(void);
 /* number of usable HIP devices (0 when there is none; never initialises more than the runtime) */
 int dcora_device_count(void);
 
-/* Manifold shape (ref src/manifold/LiftedManifold.cpp:18-89). */
+/* Manifold shape (ref src/manifold/LiftedManifold.cpp:18-89) and column ordering (ref src/manifold/LiftedVariable.cpp:
+ * 74-106 SE: pose i = columns [i (d+1), i (d+1) + d]; :257-295 RA: rotations | unit spheres | translations | landmarks).
+ * The reference chooses the manifold by GRAPH TYPE (ref src/Graph.cpp:68-75, src/QuadraticProblem.cpp:19-34): a
+ * RangeAidedSLAMGraph that happens to hold neither ranges nor landmarks still uses the RA ordering.  `layout` carries that
+ * choice; brace-initialising the first five members leaves it at DCORA_LAYOUT_AUTO. */
+enum {
+  DCORA_LAYOUT_AUTO = 0, /* SE ordering when l = b = 0, RA ordering otherwise */
+  DCORA_LAYOUT_SE = 1,   /* pose graph (l and b must be 0) */
+  DCORA_LAYOUT_RA = 2    /* range-aided ordering whatever l and b are */
+};
 typedef struct {
   int r; /* relaxation rank */
   int d; /* 2 or 3 */
   int n; /* poses (Stiefel blocks) */
   int l; /* unit spheres (oblique columns) */
   int b; /* landmarks */
+  int layout; /* DCORA_LAYOUT_* */
 } dcora_dims;
 
 /* ref include/DCORA/DCORA_types.h:152-168 ROptParameters (same defaults via dcora_ropt_params_default) */

@@ -30,7 +30,7 @@ static bool isApprox(const DCORA::Matrix &a, const DCORA::Matrix &b, double tol)
 }
 
 int main(int argc, char **argv) {
-  const double OPTIMIZATION_TOL = 1e-6;  // ref tests/testAgent.cpp
+  const double OPTIMIZATION_TOL = 1e-9;  // ref tests/testAgent.cpp:20
   for (int f = 1; f < argc; ++f) {
     const DCORA::PyFGDataset dataset = DCORA::read_pyfg_file(argv[f]);
     const DCORA::Measurements global_measurements = DCORA::getGlobalMeasurements(dataset);

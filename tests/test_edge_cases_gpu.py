@@ -155,3 +155,58 @@ def test_range_aided_layout_in_its_four_presence_cases(env, d, l, b):
         assert res["outer_iterations"] == reso["outer_iters"] and res["inner_iterations"] == reso["inner_iters"]
         assert abs(res["fOpt"] - reso["fOpt"]) <= 1e-9 * abs(reso["fOpt"])
         P.close()
+
+
+@pytest.mark.parametrize("d", [2, 3])
+def test_range_aided_ordering_without_ranges_or_landmarks(env, d):
+    """The reference picks the manifold by GRAPH TYPE (ref src/Graph.cpp:68-75, src/QuadraticProblem.cpp:19-34): a
+    RangeAidedSLAMGraph that holds only pose-pose measurements still orders its columns [R_1 .. R_n | t_1 .. t_n].
+    dims.layout = DCORA_LAYOUT_RA carries that; every operator must equal the SE-ordered oracle on the permuted
+    matrix (with l = b = 0 and layout AUTO the library would read the translation columns as rotation columns)."""
+    import scipy.sparse as sp
+    from dcora_amd import capi
+    da, orc = env
+    n = 12
+    k = (d + 1) * n
+    rng = np.random.default_rng(40 + d)
+    A = sp.random(3 * k, k, density=4.0 / k, random_state=np.random.RandomState(d), format="csr")
+    Qra = sp.csr_matrix(A.T @ A + 1e-3 * sp.identity(k))
+    perm = np.array([i * (d + 1) + c for i in range(n) for c in range(d)] + [i * (d + 1) + d for i in range(n)])
+    inv = np.argsort(perm)            # column of the RA ordering that sits at SE column j
+    Qse = sp.csr_matrix(Qra[inv][:, inv])
+    Qra.sort_indices()
+    Qse.sort_indices()
+    RA = capi.LAYOUT_RA
+    for r in (d, d + 3):
+        Xse = orc.project_to_manifold(r, d, n, rng.standard_normal((r, k)))
+        Vse = rng.standard_normal((r, k))
+        X, V = Xse[:, perm], Vse[:, perm]
+        P = da.QuadraticProblem(r, d, n, da.Csr.from_scipy(Qra), reg=0.05, layout=RA)
+        Po = orc.Problem(r, d, n, orc.CSR.from_scipy(Qse), reg=0.05)
+        assert np.isclose(P.f(X), Po.f(Xse), rtol=1e-12)
+        assert common.rel(P.RieGrad(X), Po.rgrad(Xse)[:, perm]) < 1e-12
+        Vt = orc.tangent_project(r, d, n, Xse, Vse)
+        assert common.rel(P.projectToTangentSpace(X, V), Vt[:, perm]) < 1e-13
+        assert common.rel(P.HessVec(X, Vt[:, perm]), Po.hess(Xse, Vt)[:, perm]) < 1e-11
+        assert common.rel(P.Retract(X, 0.2 * Vt[:, perm]), orc.retract(r, d, n, Xse, 0.2 * Vt)[:, perm]) < 1e-13
+        assert common.rel(P.PreCondition(X, Vt[:, perm]), Po.precondition(Xse, Vt)[:, perm]) < 1e-9
+        M = Xse + 0.3 * Vse
+        assert common.rel(da.manifold_project(r, d, n, M[:, perm], layout=RA),
+                          orc.project_to_manifold(r, d, n, M)[:, perm]) < 1e-12
+        S = da.dual_certificate(r, d, n, X, da.Csr.from_scipy(Qra), layout=RA).to_scipy()
+        So = orc.dual_certificate(r, d, n, Xse, orc.CSR.from_scipy(Qse)).to_scipy()
+        assert abs(S - So[perm][:, perm]).max() < 1e-9 * max(1.0, abs(So).max())
+        opt = da.QuadraticOptimizer(P)
+        Xs = opt.optimize(X)
+        res = opt.getOptResult()
+        Xo, reso = Po.optimize(Xse)
+        assert res["outer_iterations"] == reso["outer_iters"] and res["inner_iterations"] == reso["inner_iters"]
+        assert abs(res["fOpt"] - reso["fOpt"]) <= 1e-9 * abs(reso["fOpt"])
+        assert common.rel(Xs, Xo[:, perm]) < 1e-6
+        # the same dims without the flag is the SE ordering: a different problem on this matrix
+        Pse = da.QuadraticProblem(r, d, n, da.Csr.from_scipy(Qra), reg=0.05)
+        assert abs(Pse.f(X) - P.f(X)) <= 1e-12 * abs(P.f(X)) and common.rel(Pse.RieGrad(X), P.RieGrad(X)) > 1e-3
+        Pse.close()
+        P.close()
+    with pytest.raises(da.DcoraError):
+        da.QuadraticProblem(d, d, n, da.Csr.from_scipy(sp.identity(k + 3, format="csr")), l=3, layout=capi.LAYOUT_SE)
