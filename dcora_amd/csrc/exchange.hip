@@ -287,14 +287,15 @@ int Exchange::open_segment(const char *job_name, size_t bytes) {
       // a segment of another size under the name: a live job of another shape says so in its header (a stale one, or
       // one rank 0 is still creating, is waited out)
       if (fd >= 0 && (size_t)sb.st_size >= sizeof(ShmHeader)) {
-        void *hp = mmap(nullptr, sizeof(ShmHeader), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        void *hp = mmap(nullptr, sizeof(ShmHeader), PROT_READ, MAP_SHARED, fd, 0);
         if (hp != MAP_FAILED) {
           ShmHeader *h = (ShmHeader *)hp;
           const bool live = h->magic.load(std::memory_order_acquire) == kShmMagic && creator_alive(h);
           const bool other = live && (h->world != (uint32_t)world || h->R != (uint32_t)R_ || h->slot_doubles != slot_ ||
                                       h->total_bytes != bytes);
           if (other && since(t0) > 1.0) {  // (a second: a crashed job's segment is replaced by rank 0 within that)
-            h->failed.store(1);
+            // a LOCAL error only: the segment belongs to somebody else's live job and is not written to (raising its
+            // `failed` word took that healthy job down); this job's other ranks time out on DCORA_EXCHANGE_TIMEOUT_S
             munmap(hp, sizeof(ShmHeader));
             close(fd);
             return fail("segment " + name_ + " belongs to a job of another shape (a live job under the same name?)",
@@ -723,11 +724,18 @@ int Exchange::link_check() {
       why = "injected fault (dcora_debug_exchange_probe_fault)";
     }
     if (!mine && first_why.empty()) first_why = why;
-    ranks_[rank].probe.store(mine ? round : -round, std::memory_order_release);
+    // the vote carries the form of the wait this rank used (device_wait_ is rank-local: only ranks with a GPU of their
+    // own poll on the device), so that the step down below is taken from SHARED state and is the same on every rank
+    const int vote = 2 * round + (device_wait_ ? 1 : 0);
+    ranks_[rank].probe.store(mine ? vote : -vote, std::memory_order_release);
     int rc = barrier(30.0);
     if (rc) return rc;
-    bool all = true;
-    for (int q = 0; q < world; ++q) all = all && ranks_[q].probe.load(std::memory_order_acquire) == round;
+    bool all = true, any_device_wait = false;
+    for (int q = 0; q < world; ++q) {
+      const int v = ranks_[q].probe.load(std::memory_order_acquire);
+      all = all && v > 0 && v / 2 == round;
+      any_device_wait = any_device_wait || ((v < 0 ? -v : v) & 1);
+    }
     rc = barrier(30.0);  // nobody overwrites its vote before everybody has read the votes
     if (rc) return rc;
     link_rounds = round;
@@ -738,20 +746,18 @@ int Exchange::link_check() {
                        (mode == kExchangeIpc ? "IPC peer stores, host wait" : "shared host segment"));
       return DCORA_OK;
     }
-    // the same step on every rank (all read the same votes)
-    if (mode == kExchangeIpc && device_wait_) {
+    // the same step on every rank: it depends on the votes and on `mode` only (identical everywhere), never on this
+    // rank's own device_wait_ -- ranks that share a GPU wait on the host from the start while the others poll on the
+    // device, and a ladder keyed on the local flag sent them to different rungs (mixed transports, a spurious
+    // DCORA_ERR_EXCHANGE_LINK): device wait anywhere -> host wait everywhere -> staged with host wait everywhere
+    if (any_device_wait) {
+      if (device_wait_) link_gave_up_device_wait = 1;
       device_wait_ = false;
-      link_gave_up_device_wait = 1;
     } else if (mode == kExchangeIpc) {
       const char *force = env::exchange();
-      if (force && std::strcmp(force, "ipc") == 0) break;
+      if (force && std::strcmp(force, "ipc") == 0) break;  // (the environment of a job is the same on its ranks)
       mode = kExchangeStaged;
       link_gave_up_ipc = 1;
-      const char *wm = env::exchange_wait();
-      device_wait_ = wm ? std::strcmp(wm, "host") != 0 : device_wait_;
-    } else if (device_wait_) {
-      device_wait_ = false;
-      link_gave_up_device_wait = 1;
     } else {
       break;
     }

@@ -426,7 +426,8 @@ int RbcdSession::update_selected_agent(AgentDev &a, bool restart) {
             if (rc) return rc;
             nesterov(st, pb.m, 3, 0, -1, -1, alpha, gamma, Xg.p + off, Vg.p + off, Yg.p + off, XPrevg.p + off, nullptr,
                      Xres, cs);
-            a.last_skipped = false;
+            // last_skipped stays true: `success` of Agent::iterate is the FIRST updateX's result, the restart's is
+            // discarded (ref src/Agent.cpp:548-553), so iterate() returns false and readyToTerminate stays false
             solved = true;
           }
           if (!solved)
@@ -462,7 +463,8 @@ int RbcdSession::update_selected_agent(AgentDev &a, bool restart) {
           if (cache_complete(0)) {
             launch_spmm(st, r, a.coupling.view(), buf1(a.nbr[0].p), 0, nullptr, buf1(pb.G.p), 0, nullptr, Gate{});
           } else {
-            a.last_skipped = true;  // no G can be built from an incomplete cache: X = XPrev without the solve
+            // no G can be built from an incomplete cache: X = XPrev without the solve.  last_skipped is NOT raised: the
+            // first updateX of this iterate succeeded and that is what iterate() reports (ref src/Agent.cpp:548-553)
             plain_ok = false;
           }
         }

@@ -109,6 +109,66 @@ int main(int argc, char **argv) {
     EXPECT(threw);
     agent.reset();
     EXPECT(agent.num_poses() == 0 && !agent.getX(&Xgt));
+
+    // A RangeAidedSLAMGraph that holds ONLY the pose-pose measurements of the file: the reference decides the manifold
+    // by graph type (ref src/Graph.cpp:68-75), so the columns stay in the RA ordering [R_1 .. R_n | t_1 .. t_n] although
+    // l = b = 0 -- against the pose graph on the same measurements (SE ordering)
+    {
+      DCORA::RelativeMeasurements posesOnly;
+      for (const auto &m : global_measurements.relative_measurements.GetRelativePosePoseMeasurements())
+        posesOnly.push_back(m);
+      auto graphRA = std::make_shared<DCORA::Graph>(id, r + 1, d, DCORA::GraphType::RangeAidedSLAMGraph);
+      graphRA->setMeasurements(posesOnly);
+      auto graphSE = std::make_shared<DCORA::Graph>(id, r + 1, d);
+      graphSE->setMeasurements(posesOnly.GetRelativePosePoseMeasurements());
+      EXPECT(graphRA->l() == 0 && graphRA->b() == 0 && graphRA->n() == n && !graphRA->isPGOCompatible());
+      EXPECT(graphSE->isPGOCompatible() && graphSE->n() == n);
+      DCORA::QuadraticProblem pRA(graphRA, true), pSE(graphSE, true);
+      EXPECT(!pRA.useSEManifold() && pSE.useSEManifold());
+      // a point of the manifold in both orderings: the lifted ground truth, rotated a little pose by pose
+      const unsigned rr = r + 1;
+      DCORA::Matrix Xse(rr, (size_t)(d + 1) * n), Xra(rr, (size_t)(d + 1) * n);
+      for (unsigned i = 0; i < n; ++i) {
+        const double c = std::cos(0.1 * (i + 1)), sn = std::sin(0.1 * (i + 1));
+        for (unsigned col = 0; col <= d; ++col) {
+          double v[4] = {0, 0, 0, 0};
+          for (unsigned a = 0; a < d; ++a) v[a] = TrajectoryGroundTruth.getData()(a, (size_t)i * (d + 1) + col);
+          const double v0 = c * v[0] - sn * v[1], v1 = sn * v[0] + c * v[1];  // a rotation in the first plane
+          v[0] = v0;
+          v[1] = v1;
+          if (col == d) v[0] += 0.05 * i;
+          const size_t cra = col < d ? (size_t)i * d + col : (size_t)d * n + i;
+          for (unsigned a = 0; a < rr; ++a) Xse(a, (size_t)i * (d + 1) + col) = Xra(a, cra) = a < d ? v[a] : 0.0;
+        }
+      }
+      const double fSE = pSE.f(Xse), fRA = pRA.f(Xra);
+      EXPECT(fSE > 1e-3 && std::fabs(fSE - fRA) <= 1e-12 * fSE);
+      const DCORA::Matrix gSE = pSE.RieGrad(Xse), gRA = pRA.RieGrad(Xra);
+      double diff = 0, nrm = 0;
+      for (unsigned i = 0; i < n; ++i)
+        for (unsigned col = 0; col <= d; ++col) {
+          const size_t cra = col < d ? (size_t)i * d + col : (size_t)d * n + i;
+          for (unsigned a = 0; a < rr; ++a) {
+            const double e = gSE(a, (size_t)i * (d + 1) + col) - gRA(a, cra);
+            diff += e * e;
+            nrm += gSE(a, (size_t)i * (d + 1) + col) * gSE(a, (size_t)i * (d + 1) + col);
+          }
+        }
+      EXPECT(nrm > 1e-6 && std::sqrt(diff) <= 1e-11 * std::sqrt(nrm));
+      DCORA::QuadraticOptimizer oSE(&pSE), oRA(&pRA);
+      const DCORA::Matrix Yse = oSE.optimize(Xse), Yra = oRA.optimize(Xra);
+      EXPECT(pSE.f(Yse) < 0.5 * fSE && std::fabs(pSE.f(Yse) - pRA.f(Yra)) <= 1e-8 * fSE);
+      // the centralised agent of that type on those measurements: ground truth stays a fixed point
+      DCORA::Agent poseOnly(id, options);
+      poseOnly.setMeasurements(posesOnly);
+      const DCORA::PointArray none(d, 0);
+      poseOnly.initialize(&TrajectoryGroundTruth, &none, &none);
+      EXPECT(poseOnly.num_unit_spheres() == 0 && poseOnly.num_landmarks() == 0);
+      EXPECT(poseOnly.iterate());
+      DCORA::Matrix Tpo, Spo, Lpo;
+      EXPECT(poseOnly.getStatesInLocalFrame(&Tpo, &Spo, &Lpo));
+      EXPECT(isApprox(TrajectoryGroundTruthAligned.getData(), Tpo, OPTIMIZATION_TOL));
+    }
     std::printf("%s: d %u n %u l %u b %u ok\n", argv[f], d, n, l, b);
   }
   if (argc < 2) {

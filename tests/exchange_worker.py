@@ -15,6 +15,10 @@ def main():
     job, name = sys.argv[3], sys.argv[4]
     R, r, iters = int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7])
     out_dir, mode = sys.argv[8], sys.argv[9]
+    if os.environ.get("DCORA_TEST_WAIT_BY_RANK"):
+        # ranks that differ in the form of their wait (what ranks sharing a GPU beside ranks with a GPU of their own do by
+        # default): set before the library reads its environment
+        os.environ["DCORA_EXCHANGE_WAIT"] = os.environ["DCORA_TEST_WAIT_BY_RANK"].split(",")[rank]
     import common
     import dcora_amd as da
     ds = common.product_dataset(name)

@@ -256,12 +256,15 @@ def test_exchange_host_protocol_between_processes(built, tmp_path, world, R):
     assert not os.path.exists("/dev/shm/dcora_" + job)  # rank 0 unlinks the name once everybody is attached
 
 
-def test_exchange_host_protocol_refuses_a_mismatched_job(built, tmp_path):
-    """a rank that attaches with another shape (number of agents) is told so instead of reading foreign slots"""
+def test_exchange_host_protocol_refuses_a_mismatched_job(built, tmp_path, monkeypatch):
+    """a rank that attaches with another shape (number of agents) is told so instead of reading foreign slots -- and it
+    does NOT write into the segment it refused (under a shared name that segment may be an unrelated
+    live job's): the job it did not join gives up on its own timeout, DCORA_EXCHANGE_TIMEOUT_S"""
     import ctypes as C
     import multiprocessing as mp
     import uuid
     from dcora_amd import capi
+    monkeypatch.setenv("DCORA_EXCHANGE_TIMEOUT_S", "6")
     job = "cpu%s" % uuid.uuid4().hex[:10]
     ctx = mp.get_context("spawn")
     p = ctx.Process(target=_selftest_rank, args=(0, 2, job, 5, 3, str(tmp_path)))
@@ -270,7 +273,7 @@ def test_exchange_host_protocol_refuses_a_mismatched_job(built, tmp_path):
     rc = capi.lib().dcora_exchange_host_selftest(job.encode(), 1, 2, 6, 3, C.byref(cs))
     assert rc != 0 and b"another shape" in capi.lib().dcora_last_error()
     p.join(90)
-    assert p.exitcode is not None and p.exitcode != 0  # rank 0 sees the failure flag and gives up as well
+    assert p.exitcode is not None and p.exitcode != 0  # rank 0 times out waiting for its rank 1 (6 s here)
 
 
 def _late_rank0(world, job, R, rounds, tmpdir, delay):

@@ -266,6 +266,30 @@ def test_link_check_steps_down_together(tmp_path, faults, wait):
         assert np.array_equal(o["X"], X) and np.array_equal(o["selected"], sel)
 
 
+@pytest.mark.parametrize("faults", [0, 1, 2])
+def test_link_check_ladder_with_ranks_that_wait_differently(tmp_path, faults):
+    """the form of the wait is rank-local (ranks sharing a GPU spin on the host, the others poll on the
+    device).  The step down must come from the ranks' shared votes: rank 0 polling on the device and rank 1 waiting on
+    the host used to leave the ladder on different rungs (mixed transports, then DCORA_ERR_EXCHANGE_LINK).  Now: device
+    wait anywhere -> host wait everywhere -> staged, on every rank alike, and the run equals the single session."""
+    import dcora_amd as da
+    name, R, world, iters, r = "sphere2500", 5, 2, 5, 5
+    ds = common.product_dataset(name)
+    X0 = common.random_point(r, ds.d, ds.n, 11, lambda r_, d_, n_, M: da.manifold_project(r_, d_, n_, M))
+    cost, gn, sel, X = single(da, ds, R, r, iters, "greedy", X0)
+    res = run_ranks(str(tmp_path), world, name, R, r, iters, "greedy", X0, None, None,
+                    extra_env={"DCORA_TEST_PROBE_FAULT": str(faults), "DCORA_TEST_WAIT_BY_RANK": "device,host"})
+    for k, o in enumerate(res):
+        assert int(o["link_rounds"]) == faults + 1, (k, int(o["link_rounds"]))
+        assert int(o["mode"]) == (2 if faults == 2 else 1), (k, int(o["mode"]))
+        assert bool(o["link_no_ipc"]) == (faults == 2)
+        if faults == 0:
+            assert str(o["wait"]).startswith("device" if k == 0 else "host")
+        else:
+            assert str(o["wait"]).startswith("host")
+        assert np.array_equal(o["X"], X) and np.array_equal(o["selected"], sel)
+
+
 def test_link_check_that_cannot_pass_fails_fast_on_every_rank(tmp_path):
     """no transport passes the check: every rank returns DCORA_ERR_EXCHANGE_LINK within seconds -- never a hang in the
     first post"""
