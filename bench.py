@@ -844,15 +844,15 @@ def qapply_in_loop():
     """the block Q-apply as it runs INSIDE the RBCD loop of the 100k lattice (agent blocks of 12 500 poses, with the
     evaluation's epilogue fused in, plus one whole-graph launch per iteration): from the committed per-iteration
     breakdown of a kernel trace (tools/trace_c5.sh), not measured in this run"""
-    for tag in ("r04", "r03"):
+    for tag in ("r05", "r04", "r03"):
         path = os.path.join(ROOT, "profiles", "%s_c5_loop_breakdown.txt" % tag)
         if not os.path.exists(path):
             continue
         try:
             for line in open(path):
                 f = line.split()
-                if f and f[0] == "k_spmm_bsr2":
-                    return {"kernel": "k_spmm_bsr2 in the RBCD loop of the 100k lattice (8 agents)",
+                if f and f[0] in ("k_spmm_bsrq", "k_spmm_bsr2"):
+                    return {"kernel": "%s in the RBCD loop of the 100k lattice (8 agents)" % f[0],
                             "launches_per_rbcd_iteration": float(f[1]), "avg_launch_us": float(f[2]),
                             "us_per_rbcd_iteration": float(f[3]),
                             "note": "mostly agent blocks of 15 MB: launch-bound, not a bandwidth figure",

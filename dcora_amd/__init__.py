@@ -340,7 +340,7 @@ QuadraticProblem.precond_info = _precond_info
 def _qapply_info(self):
     info = np.zeros(4)
     check(capi.lib().dcora_problem_qapply_info(self.h, info))
-    return {"kernel": "k_spmm_bsr2" if info[0] else "k_spmm", "nnz": int(info[1]), "blocks": int(info[2]),
+    return {"kernel": "k_spmm_bsrq" if info[0] else "k_spmm", "nnz": int(info[1]), "blocks": int(info[2]),
             "stored_matrix_bytes": float(info[3])}
 
 

@@ -892,7 +892,7 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
   // f(x0), grad(x0) from buffer 0 (null gate: the control block of this solve does not exist yet)
   // cost + gradient of an evaluation in one launch where the kernel exists (small CSR blocks), else Q-apply + rgrad
   const bool gf = !has_bsr && Q.n_long == 0;
-  const bool gfb = has_bsr;       // large blocks: the same in one launch on the block structure (k_spmm_bsr2<.., GRAD>)
+  const bool gfb = has_bsr;       // large blocks: the same in one launch on the block structure (k_spmm_bsrq<.., GRAD>)
   const Buf2 kNoBuf{{nullptr, nullptr}};  // EG of the fused evaluation: nobody reads it, so it is not written
   const int nAe = gf ? nPB : nA;  // {<XQ,X>, <X,G>} partial slots of an evaluation
   int nG;

@@ -78,7 +78,7 @@ HostBsr bsr_from_csr(const HostCsr &A, int bs) {
       for (int p = A.rp[i]; p < A.rp[i + 1]; ++p) {
         const int bcj = A.ci[p] / bs, c = A.ci[p] - bcj * bs;
         const size_t pos = first + (std::lower_bound(cols.begin(), cols.end(), bcj) - cols.begin());
-        B.bv[pos * bs * bs + (size_t)a * bs + c] += A.v[p];
+        B.bv[pos * bs * bs + (size_t)c * bs + a] += A.v[p];  // entry (a, c) of the block at c bs + a
       }
     }
     B.bp[bi + 1] = (int)B.bc.size();

@@ -17,7 +17,9 @@ struct HostCsr {
   int nnz() const { return (int)ci.size(); }
 };
 
-// block-CSR with dense bs x bs blocks (row-major inside a block), pattern = union of the scalar entries' blocks
+// block-CSR with dense bs x bs blocks, pattern = union of the scalar entries' blocks.  Inside a block entry (a, c) --
+// scalar row block_row * bs + a, scalar column block_col * bs + c -- sits at c * bs + a (COLUMN-major): the lane that
+// owns column c of the neighbour's r x (d+1) block in the Q-apply reads the bs weights it needs as one contiguous run
 struct HostBsr {
   int nbrows = 0, bs = 0;
   std::vector<int> bp, bc;

@@ -10,6 +10,7 @@
 // dependent launches instead of six.  Per-pose arithmetic uses 8 lanes per pose: lane t
 // of a group owns row t of the pose's r x (d+1) block, d x d Gram matrices are reduced with 3 xor-shuffles.
 #include <algorithm>
+#include <stdexcept>
 #include <atomic>
 #include <type_traits>
 #include <vector>
@@ -711,7 +712,7 @@ __global__ __launch_bounds__(kBlock) void k_fused_hess_bsr(ManiDesc m, BsrDev A,
         for (int a = 0; a < DH; ++a) {
           double s = 0;
 #pragma unroll
-          for (int c = 0; c < DH; ++c) s += Bq[a * DH + c] * (beta * xd[q][c] - xz[q][c]);
+          for (int c = 0; c < DH; ++c) s += Bq[c * DH + a] * (beta * xd[q][c] - xz[q][c]);
           W.e[a] += s;
         }
       }
@@ -1604,43 +1605,14 @@ __global__ __launch_bounds__(kBlock) void k_g_nesterov(ManiDesc m, GNesterovArgs
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Q-apply on the block structure of the connection Laplacian: Y = X Q (+ G), Q in BSR with (d+1)^2 blocks.
-// 8 lanes per block row (pose): lane t gathers row t of the neighbour's r x (d+1) block once per matrix block
-// (4 loads of 8 B, the r lanes reading r contiguous doubles) and applies the whole (d+1)^2 block to it; block
-// values and column indices of the workgroup's 32 block rows are staged in LDS with coalesced loads and read back
-// as broadcasts.  Four times fewer gather instructions and ~25 % fewer bytes than the scalar-CSR kernel.
+// Q-apply on the block structure of the connection Laplacian: Y = X Q (+ G), Q in BSR with (d+1)^2 blocks stored
+// column-major.  History of the forms (all measured on the 100k lattice, r = 5, warm / cold us): LDS-staged blocks with 8
+// lanes per pose 27.4 / 33.9; the LDS-free 8-lanes-per-pose form (lane t = row t of the pose's block, four 8-byte gathers
+// and two 16-byte block loads per lane and block, the block's other rows by DPP quad broadcasts) 24.6 / 33.2 -- rounds
+// 2-4, unmoved by gather depth, software pipelining, non-temporal accesses, a symmetric store of the blocks, r lanes
+// per pose, 16-byte gathers of row pairs, a per-pose header, locality orderings and XCD-aware grids: it was bound by
+// the NUMBER of gather instructions (each serves 8 poses).  Round 5: the quad-per-pose form below, 22.6 / 27.5.
 // ------------------------------------------------------------------------------------------------------
-
-// matrix blocks whose neighbour rows are gathered together.  Measured on the 100k lattice, warm / cold us: 1: 28.2 / 35.7,
-// 2: 27.2 / 34.0, 3: 27.8 / 35.0, 4: 29.5 / 36.2, 6: 32.0 / 39.2, 8: 32.1 / 39.6 -- the registers of a deeper batch cost more
-// resident waves (94 VGPRs at 4, 74 at 2) than its loads in flight give back; forcing 7 or 8 waves per SIMD changes nothing.
-// Non-temporal loads of the block stream and of G and non-temporal stores of Y (they bypass the Infinity Cache): warm
-// 27.2 -> 36.8 us, cold 33.7 -> 37.1 us.  Per launch the kernel also moves 717 MB through LDS (every lane reads the
-// (d+1)^2 values of its block: 9 us of LDS time per CU) and issues 350 k gather instructions of 8+ lines each (another
-// 9 us of address-unit time), next to 21 us of HBM time at the measured triad rate: balanced, not HBM-bound alone.
-// (The first form staged block values and column indices of 32 block rows in LDS and read them back as broadcasts:
-// 27.4 / 33.9 us warm / cold on the 100k lattice, 717 MB through LDS per launch; replaced by the LDS-free form below,
-// which sums in the same order.)
-
-// Second form of the block Q-apply: no LDS.  The 8 lanes of a pose read the block themselves -- lane t loads row t & 3
-// of the (d+1)^2 block (32 bytes; the two quads of a pose load the same 128 bytes, which the address unit merges) -- and
-// every lane gets the rows it does not hold by DPP quad broadcasts (VALU, per SIMD) instead of 16 broadcast reads of LDS
-// per block (one LDS pipe per CU: 717 MB per launch on the 100k lattice).  No staging pass, no barrier.  The column
-// indices of up to 8 blocks of a pose come with one load and are handed round with ds_bpermute.  Same summation order
-// as the staged form had: bitwise the same result (checked before that form was deleted).  Measured on the 100k lattice, warm / cold us:
-// k_spmm_bsr 27.4 / 33.9; this form with 2 / 3 / 4 blocks gathered together 26.6 / 35.6, 24.8 / 33.1, 26.6 / 34.2;
-// with the rows of the next batch and G requested one step ahead (software pipeline, 114 instead of 80 VGPRs)
-// 26.9 / 33.3 (3 blocks), 27.0 / 32.6 (2 blocks): the cold figure does not move with the kernel's structure.
-// Every off-diagonal block stored once and read across by its mirror (Q is symmetric; 60 -> 37 MB of matrix, transposed
-// reads as four strided 8-byte loads, one more index per block): 29.0 / 36.2 -- and 28.8 / 38.3 with the same load code
-// on the unshared storage: the kernel is bound by the NUMBER of load instructions (each touches 8 poses' lines), about
-// 1.6 us per instruction and block step, not by the bytes; 16-byte loads of the block rows are what the 24.8 us rest on.
-// r lanes per pose instead of 8 (12 poses per wave at r = 5, a third fewer load instructions), the block rows handed
-// round with ds_bpermute because pose groups no longer align with DPP quads: 36 us warm -- 32 ds_bpermute per block cost
-// far more than the 32 DPP moves they replace.  The neighbour's block gathered by two 16-byte loads per lane (row
-// pairs of one column, redistributed inside the quad by DPP broadcasts and selects) instead of d + 1 loads of 8 bytes:
-// 30.4 us warm -- at odd r the 16-byte loads are not 16-byte aligned, and 32 more DPP moves and 16 selects per block.
-constexpr int kBsrGather2 = 3;
 template <int A_>
 __device__ __forceinline__ double quad_bcast(double v) {
   return dpp_move<A_ * 0x55>(v);  // quad_perm [A, A, A, A]
@@ -1659,20 +1631,74 @@ struct BsrGradOut {
   const int *agent_start = nullptr;
   int wg_per_agent = 0;
 };
-template <int D, bool DOTS, bool GRAD>
-__global__ __launch_bounds__(kBlock) void k_spmm_bsr2(int r, BsrDev A, Buf2 Xb, int selX,
-                                                      const double *__restrict__ G, Buf2 Yb, int selY,
-                                                      double *__restrict__ partials, Gate g, BsrGradOut go) {
+// ------------------------------------------------------------------------------------------------------
+// The block Q-apply (round 5): FOUR lanes per pose, lane c owns COLUMN c of the pose's r x (d+1) block.
+// A column is r contiguous doubles, so the neighbour's block arrives by ceil(r / 2) 16-byte loads per lane (8-byte
+// aligned; r = 5: 16 + 16 + 8 bytes) in instructions that serve 16 poses each, and the d + 1 weights lane c needs --
+// column c of the (d+1)^2 block, stored column-major -- are one contiguous run (two 16-byte loads, no duplicate loads by
+// a second quad, no DPP broadcast in the inner loop): 5 load instructions per 16 (pose, block) pairs where the
+// 8-lanes-per-pose form issues 6 per 8, and no idle lanes at r = 5.  Lane c accumulates ITS column's contribution to
+// all d + 1 output columns (r (d+1) sums in registers); the four partials of a pose meet once per pose in a quad
+// reduce-scatter (lane a ends with output column a), then G, the dots and the store run on contiguous columns again.
+// GRAD: the whole evaluation of an RTR iteration as the epilogue (E and Y columns handed round the quad by DPP).
+// ------------------------------------------------------------------------------------------------------
+typedef double q_v2f64u __attribute__((ext_vector_type(2), aligned(8)));
+template <int N>
+__device__ __forceinline__ void ld_run(const double *__restrict__ p, bool ok, double (&x)[N]) {
+#pragma unroll
+  for (int i = 0; i + 1 < N; i += 2) {
+    q_v2f64u v = {0.0, 0.0};
+    if (ok) v = *reinterpret_cast<const q_v2f64u *>(p + i);
+    x[i] = v.x;
+    x[i + 1] = v.y;
+  }
+  if (N & 1) x[N - 1] = ok ? p[N - 1] : 0.0;
+}
+template <int N>
+__device__ __forceinline__ void st_run(double *__restrict__ p, bool ok, const double (&x)[N]) {
+  if (!ok) return;
+#pragma unroll
+  for (int i = 0; i + 1 < N; i += 2) {
+    q_v2f64u v = {x[i], x[i + 1]};
+    *reinterpret_cast<q_v2f64u *>(p + i) = v;
+  }
+  if (N & 1) p[N - 1] = x[N - 1];
+}
+template <int A_>
+__device__ __forceinline__ int quad_bcast_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, A_ * 0x55, 0xF, 0xF, true);
+}
+__device__ __forceinline__ double quad_sum(double v) {
+  asm volatile("" : "+v"(v));
+  v += f_dpp<0xB1>(v);  // quad_perm [1,0,3,2]
+  asm volatile("" : "+v"(v));
+  v += f_dpp<0x4E>(v);  // quad_perm [2,3,0,1]
+  return v;
+}
+// Measured on the 100k lattice at r = 5, warm / cold us (gfx950, round 5): this form 22.6 / 27.5; its loads requested two
+// or one (pose, block) pair at a time instead of four 22.6-22.8 / 27.6; 256-thread workgroups 22.7 / 28.3; the pose's
+// own column of X and of G requested before the block loop (136 registers, 3 waves per SIMD) 23.6 / 27.6; half as many
+// workgroups of two passes each 25.1 / 30.1; forced to 5 or 6 waves per SIMD (176 / 320 bytes of scratch per lane)
+// 72 / 128 us.  The 8-lanes-per-pose form it replaces: 24.6 / 33.2.
+constexpr int kQBlock = 128;  // threads per workgroup: 32 poses, as the 8-lanes-per-pose kernels' workgroups hold
+template <int D, int R, bool DOTS, bool GRAD>
+__global__ __launch_bounds__(kQBlock) void k_spmm_bsrq(BsrDev A, Buf2 Xb, int selX, const double *__restrict__ G, Buf2 Yb,
+                                                       int selY, double *__restrict__ partials, Gate g, BsrGradOut go) {
   if (g.ctl && g.gate && f_gated(g.ctl, g.seq, g.gate)) return;
-  constexpr int DH = D + 1, BS = DH * DH;
+  constexpr int DH = D + 1, BS = DH * DH, PW = kQBlock / 4;
+  // (pose, block) pairs whose loads a lane requests together: the four column indices of one index load, two at a time
+  // at r >= 7 where four columns of the neighbours alone are 56-64 registers
+  constexpr int kQGather = R >= 7 ? 2 : 4;
   __shared__ double s_red[16];
   const int cur = g.ctl ? (g.ctl->cur & 1) : 0;
   const double *__restrict__ X = Xb.p[g.ctl ? ((cur ^ selX) & 1) : 0];
   double *__restrict__ Y = Yb.p[g.ctl ? ((cur ^ selY) & 1) : 0];
   double *__restrict__ RG = GRAD ? go.RG.p[g.ctl ? ((cur ^ selY) & 1) : 0] : nullptr;
   double *__restrict__ Sblk = GRAD ? go.S.p[g.ctl ? ((cur ^ selY) & 1) : 0] : nullptr;
-  const int t = threadIdx.x & (GW - 1);
-  const int rowq = min(t & 3, DH - 1);  // the block row this lane holds
+  const int c = threadIdx.x & 3;
+  const bool lane_on = c < DH;  // d = 2: the fourth lane of a quad carries zeros
+  const int cc = lane_on ? c : 0;
+  const bool odd = (c & 1) != 0, upper = (c & 2) != 0;
   double d0 = 0, d1 = 0, dg = 0;
   int range_lo = (int)((long)A.nbrows * blockIdx.x / gridDim.x);
   int range_hi = (int)((long)A.nbrows * (blockIdx.x + 1) / gridDim.x);
@@ -1682,116 +1708,120 @@ __global__ __launch_bounds__(kBlock) void k_spmm_bsr2(int r, BsrDev A, Buf2 Xb, 
     range_lo = lo + (int)((long)(hi - lo) * sl / go.wg_per_agent);
     range_hi = lo + (int)((long)(hi - lo) * (sl + 1) / go.wg_per_agent);
   }
-  const int npass = max(1, (range_hi - range_lo + kPosesPerBlock - 1) / kPosesPerBlock);
+  const int npass = max(1, (range_hi - range_lo + PW - 1) / PW);
   const int per_pass = (range_hi - range_lo + npass - 1) / npass;
   for (int pose0 = range_lo; pose0 < range_hi; pose0 += per_pass) {
     const int pend_pose = min(range_hi, pose0 + per_pass);
-    const int pose = pose0 + (threadIdx.x >> 3);
+    const int pose = pose0 + (threadIdx.x >> 2);
     const bool inr = pose < pend_pose;
-    const bool active = inr && (t < r);
+    const bool active = inr && lane_on;
     const int myb = inr ? A.bp[pose] : 0, mye = inr ? A.bp[pose + 1] : 0;
-    double acc[DH];
+    double acc[4][R];  // acc[a][.]: this lane's (column c's) part of output column a
 #pragma unroll
-    for (int a = 0; a < DH; ++a) acc[a] = 0;
-    for (int b0 = myb; b0 < mye; b0 += GW) {
-      const int nb = min(GW, mye - b0);
-      const int mybc = (t < nb) ? A.bc[b0 + t] : 0;
-      for (int q0 = 0; q0 < nb; q0 += kBsrGather2) {
-        double x[kBsrGather2][DH], brow[kBsrGather2][DH];
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int q = 0; q < kBsrGather2; ++q) {
-          const bool ok = q0 + q < nb;
-          const int qc = ok ? q0 + q : q0;
-          const int col = __shfl(mybc, qc, GW);
-          const size_t o = (size_t)col * DH * r + t;
+      for (int i = 0; i < R; ++i) acc[a][i] = 0.0;
+    for (int b0 = myb; b0 < mye; b0 += 4) {
+      const int nb = min(4, mye - b0);
+      const int mybc = (c < nb) ? A.bc[b0 + c] : 0;
 #pragma unroll
-          for (int c = 0; c < DH; ++c) x[q][c] = (ok && active) ? X[o + c * r] : 0.0;
-          const double *__restrict__ bp_ = A.bv + (size_t)(b0 + qc) * BS + rowq * DH;
-          if (DH == 4) {
-            const double2 u0 = *reinterpret_cast<const double2 *>(bp_);
-            const double2 u1 = *reinterpret_cast<const double2 *>(bp_ + 2);
-            brow[q][0] = u0.x;
-            brow[q][1] = u0.y;
-            brow[q][2] = u1.x;
-            brow[q][DH - 1] = u1.y;
-          } else {
+      for (int h = 0; h < 4; h += kQGather) {
+        double x[kQGather][R], w[kQGather][DH];
 #pragma unroll
-            for (int c = 0; c < DH; ++c) brow[q][c] = bp_[c];
-          }
+        for (int q = 0; q < kQGather; ++q) {
+          const bool ok = active && (h + q < nb);
+          const int col = (h + q == 0) ? quad_bcast_i<0>(mybc) : (h + q == 1) ? quad_bcast_i<1>(mybc)
+                        : (h + q == 2) ? quad_bcast_i<2>(mybc) : quad_bcast_i<3>(mybc);
+          ld_run<R>(X + ((size_t)col * DH + cc) * R, ok, x[q]);
+          ld_run<DH>(A.bv + (size_t)(b0 + h + q) * BS + cc * DH, ok, w[q]);
         }
 #pragma unroll
-        for (int q = 0; q < kBsrGather2; ++q) {
-          {
-            double s = 0;
+        for (int q = 0; q < kQGather; ++q)
 #pragma unroll
-            for (int c = 0; c < DH; ++c) s += quad_bcast<0>(brow[q][c]) * x[q][c];
-            acc[0] += s;
-          }
-          {
-            double s = 0;
+          for (int a = 0; a < DH; ++a)
 #pragma unroll
-            for (int c = 0; c < DH; ++c) s += quad_bcast<1>(brow[q][c]) * x[q][c];
-            acc[1] += s;
-          }
-          {
-            double s = 0;
-#pragma unroll
-            for (int c = 0; c < DH; ++c) s += quad_bcast<2>(brow[q][c]) * x[q][c];
-            acc[2] += s;
-          }
-          if (DH == 4) {
-            double s = 0;
-#pragma unroll
-            for (int c = 0; c < DH; ++c) s += quad_bcast<3>(brow[q][c]) * x[q][c];
-            acc[DH - 1] += s;
-          }
-        }
+            for (int i = 0; i < R; ++i) acc[a][i] += w[q][a] * x[q][i];
+        if (kQGather < 4) __builtin_amdgcn_sched_barrier(0);  // the next pair's loads stay behind this pair's sums
       }
     }
-    if (GRAD) {
-      // every lane of a group takes part in the group's sums; inactive lanes carry zeros
-      const size_t ob = (size_t)(inr ? pose : 0) * DH * r;
-      Row<D> Yr, E;
+    // quad reduce-scatter: lane a ends with output column a = the sum of the four lanes' acc[a][.]
+    double e[R];
 #pragma unroll
-      for (int a = 0; a < DH; ++a) {
-        const double x = active ? X[ob + t + a * r] : 0.0;
-        const double gg = (active && G) ? G[ob + t + a * r] : 0.0;
-        d0 += acc[a] * x;
-        d1 += x * gg;
-        Yr.e[a] = x;
-        E.e[a] = active ? acc[a] + gg : 0.0;
+    for (int i = 0; i < R; ++i) {
+      // pairs {0,1}, {2,3}: a lane keeps the column of its own parity and sends the other to its partner
+      const double keep0 = odd ? acc[1][i] : acc[0][i], send0 = odd ? acc[0][i] : acc[1][i];
+      const double keep1 = odd ? acc[3][i] : acc[2][i], send1 = odd ? acc[2][i] : acc[3][i];
+      const double t0 = keep0 + f_dpp<0xB1>(send0);  // columns (c & 1) over lanes c, c ^ 1
+      const double t1 = keep1 + f_dpp<0xB1>(send1);  // columns 2 + (c & 1)
+      const double keep = upper ? t1 : t0, send = upper ? t0 : t1;
+      e[i] = keep + f_dpp<0x4E>(send);
+    }
+    const size_t oc = ((size_t)(inr ? pose : 0) * DH + cc) * R;
+    double xo[R], gg[R];
+    if (DOTS || GRAD) ld_run<R>(X + oc, active, xo);
+    ld_run<R>(G + oc, active && G != nullptr, gg);
+    if (DOTS || GRAD) {
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        d0 += e[i] * xo[i];
+        d1 += xo[i] * gg[i];
       }
-      if (Y) st_row<D>(Y + ob, r, t, active, E);  // (nobody reads EG behind the fused evaluation: callers pass null)
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) e[i] = active ? e[i] + gg[i] : 0.0;
+    if (Y) st_run<R>(Y + oc, active, e);
+    if (GRAD) {
+      // columns of Y (= X_i) and E handed round the quad; every lane forms S = sym(Y^T E) over the rotation columns
+      double Yc[D][R], Ec[D][R];
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        Yc[0][i] = quad_bcast<0>(xo[i]);
+        Ec[0][i] = quad_bcast<0>(e[i]);
+        Yc[1][i] = quad_bcast<1>(xo[i]);
+        Ec[1][i] = quad_bcast<1>(e[i]);
+        if (D == 3) {
+          Yc[D - 1][i] = quad_bcast<2>(xo[i]);
+          Ec[D - 1][i] = quad_bcast<2>(e[i]);
+        }
+      }
       double S[D][D];
-      grp_sym_gram<D>(Yr, E, S);
-      if (Sblk && inr && t == 0)
 #pragma unroll
-        for (int a = 0; a < D; ++a)
+      for (int a = 0; a < D; ++a)
 #pragma unroll
-          for (int b = 0; b < D; ++b) Sblk[(size_t)pose * D * D + a + b * D] = S[a][b];
-      row_sub_AS<D>(E, Yr, S);
+        for (int b = a; b < D; ++b) {
+          double s = 0;
+#pragma unroll
+          for (int i = 0; i < R; ++i) s += 0.5 * (Yc[a][i] * Ec[b][i] + Yc[b][i] * Ec[a][i]);
+          S[a][b] = s;
+          S[b][a] = s;
+        }
+      if (Sblk && inr && c < D) {  // lane b stores column b of the D x D block
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+          const double s = (c == 0) ? S[a][0] : (c == 1) ? S[a][1] : S[a][D - 1];
+          Sblk[(size_t)pose * D * D + a + c * D] = s;
+        }
+      }
+      // RG column b = E column b - sum_a Y column a S[a][b] (rotation columns; the translation column stays)
+      if (c < D) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          double s = 0;
+#pragma unroll
+          for (int a = 0; a < D; ++a) s += Yc[a][i] * ((c == 0) ? S[a][0] : (c == 1) ? S[a][1] : S[a][D - 1]);
+          e[i] -= s;
+        }
+      }
       double pa = 0;
 #pragma unroll
-      for (int a = 0; a < DH; ++a) pa += E.e[a] * E.e[a];
+      for (int i = 0; i < R; ++i) pa += e[i] * e[i];
+      if (!active) pa = 0;
       dg += pa;
       if (go.posenorm) {
-        const double ps = grp_sum(pa);
-        if (inr && t == 0) go.posenorm[pose] = ps;
+        const double ps = quad_sum(pa);
+        if (inr && c == 0) go.posenorm[pose] = ps;
       }
-      if (RG) st_row<D>(RG + ob, r, t, active, E);
-    } else if (active) {
-      const size_t o = (size_t)pose * DH * r + t;
-#pragma unroll
-      for (int a = 0; a < DH; ++a) {
-        double y = acc[a];
-        if (DOTS) {
-          const double x = X[o + a * r];
-          d0 += acc[a] * x;
-          if (G) d1 += x * G[o + a * r];
-        }
-        if (G) y += G[o + a * r];
-        Y[o + a * r] = y;
-      }
+      if (RG) st_run<R>(RG + oc, active, e);
     }
   }
   if (DOTS) {
@@ -1803,8 +1833,8 @@ __global__ __launch_bounds__(kBlock) void k_spmm_bsr2(int r, BsrDev A, Buf2 Xb, 
     }
   }
   if (GRAD) {
-    const double c = f_block_sum(dg, s_red);
-    if (threadIdx.x == 0) go.pB[blockIdx.x] = c;
+    const double cs = f_block_sum(dg, s_red);
+    if (threadIdx.x == 0) go.pB[blockIdx.x] = cs;
   }
 }
 
@@ -1979,22 +2009,28 @@ int spmm_bsr_grid(int nbrows) {
   if (g > cap) g = cap;
   return (int)g;
 }
+// the quad-per-pose form for every (d, r) the block structure is built for (d <= r <= 8)
+template <bool DOTS, bool GRAD>
+static bool launch_bsrq(hipStream_t st, int grid, int r, int d, const BsrDev &A, Buf2 X, int selX, const double *G, Buf2 Y,
+                        int selY, double *partials, Gate g, const BsrGradOut &go) {
+#define DCORA_BSRQ(D_, R_)                                                                                              \
+  if (d == D_ && r == R_) {                                                                                             \
+    hipLaunchKernelGGL((k_spmm_bsrq<D_, R_, DOTS, GRAD>), dim3(grid), dim3(kQBlock), 0, st, A, X, selX, G, Y, selY, \
+                       partials, g, go);                                                                                \
+    return true;                                                                                                        \
+  }
+  DCORA_BSRQ(3, 3) DCORA_BSRQ(3, 4) DCORA_BSRQ(3, 5) DCORA_BSRQ(3, 6) DCORA_BSRQ(3, 7) DCORA_BSRQ(3, 8)
+  DCORA_BSRQ(2, 2) DCORA_BSRQ(2, 3) DCORA_BSRQ(2, 4) DCORA_BSRQ(2, 5) DCORA_BSRQ(2, 6) DCORA_BSRQ(2, 7) DCORA_BSRQ(2, 8)
+#undef DCORA_BSRQ
+  return false;
+}
 void launch_spmm_bsr(hipStream_t st, int r, int d, const BsrDev &A, Buf2 X, int selX, const double *G, Buf2 Y,
                      int selY, double *partials, Gate g) {
   const int grid = spmm_bsr_grid(A.nbrows);
   const BsrGradOut none{};
-  if (d == 3 && partials)
-    hipLaunchKernelGGL((k_spmm_bsr2<3, true, false>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials,
-                       g, none);
-  else if (d == 3)
-    hipLaunchKernelGGL((k_spmm_bsr2<3, false, false>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY,
-                       partials, g, none);
-  else if (partials)
-    hipLaunchKernelGGL((k_spmm_bsr2<2, true, false>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY, partials,
-                       g, none);
-  else
-    hipLaunchKernelGGL((k_spmm_bsr2<2, false, false>), dim3(grid), dim3(kBlock), 0, st, r, A, X, selX, G, Y, selY,
-                       partials, g, none);
+  const bool ok = partials ? launch_bsrq<true, false>(st, grid, r, d, A, X, selX, G, Y, selY, partials, g, none)
+                           : launch_bsrq<false, false>(st, grid, r, d, A, X, selX, G, Y, selY, partials, g, none);
+  if (!ok) throw std::logic_error("block Q-apply: no instantiation for this (d, r); the block structure is built for d <= r <= 8 only");
 }
 // EG = X Q + G, RG = Proj_X(EG), S blocks, partials {<XQ,X>, <X,G>} in pA (2 per block), |RG|^2 in pB (1 per block) and
 // the per-pose norms in ONE launch on the block structure of Q; returns the number of blocks
@@ -2015,10 +2051,8 @@ int launch_fused_grad_bsr(hipStream_t st, int r, int d, const BsrDev &A, Buf2 X,
     go.posenorm = nullptr;
     *wg_per_agent = wpa;
   }
-  if (d == 3)
-    hipLaunchKernelGGL((k_spmm_bsr2<3, true, true>), dim3(grid), dim3(kBlock), 0, st, r, A, X, sel, G, EG, sel, pA, g, go);
-  else
-    hipLaunchKernelGGL((k_spmm_bsr2<2, true, true>), dim3(grid), dim3(kBlock), 0, st, r, A, X, sel, G, EG, sel, pA, g, go);
+  if (!launch_bsrq<true, true>(st, grid, r, d, A, X, sel, G, EG, sel, pA, g, go))
+    throw std::logic_error("block evaluation: no instantiation for this (d, r); the block structure is built for d <= r <= 8 only");
   return grid;
 }
 

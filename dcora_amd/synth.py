@@ -80,3 +80,43 @@ def lattice_se3(nx=50, ny=50, nz=40, p_lc=0.4, sigma_t=0.1, sigma_r=0.2, seed=20
     kappa = 1.0 / (2 * sigma_r ** 2)    # 3 / (2 trace(inv(25 I))) = 12.5
     vals[:, 12], vals[:, 13], vals[:, 14] = kappa, tau, 1.0
     return Dataset(3, n, ids, vals)
+
+
+def lattice_se2(nx=96, ny=96, p_lc=0.5, sigma_t=0.1, sigma_r=0.1, seed=20250310):
+    """the planar twin of lattice_se3: an nx x ny lattice of SE(2) poses visited row by row in snake order (odometry), loop
+    closures between lattice-adjacent non-consecutive poses kept with probability p_lc; unit spacing, random heading"""
+    rng = np.random.default_rng(seed)
+    n = nx * ny
+    coords = np.empty((n, 2), dtype=np.int64)
+    idx = 0
+    for y in range(ny):
+        xs = range(nx) if y % 2 == 0 else range(nx - 1, -1, -1)
+        for x in xs:
+            coords[idx] = (x, y)
+            idx += 1
+    where = np.empty(n, dtype=np.int64)
+    where[coords[:, 0] + nx * coords[:, 1]] = np.arange(n)
+    th = rng.uniform(-np.pi, np.pi, n)
+    rot = lambda a: np.stack([np.stack([np.cos(a), -np.sin(a)], -1), np.stack([np.sin(a), np.cos(a)], -1)], -2)
+    Rgt, tgt = rot(th), coords.astype(np.float64)
+    src, dst = [np.arange(n - 1)], [np.arange(1, n)]
+    for axis, lim in ((0, nx), (1, ny)):
+        a = np.nonzero(coords[:, axis] + 1 < lim)[0]
+        c2 = coords[a].copy()
+        c2[:, axis] += 1
+        b = where[c2[:, 0] + nx * c2[:, 1]]
+        lo, hi = np.minimum(a, b), np.maximum(a, b)
+        keep = ((hi - lo) > 1) & (rng.random(len(a)) < p_lc)
+        src.append(lo[keep])
+        dst.append(hi[keep])
+    i, j = np.concatenate(src), np.concatenate(dst)
+    m = len(i)
+    Rij = np.transpose(Rgt[i], (0, 2, 1)) @ Rgt[j] @ rot(sigma_r * rng.standard_normal(m))
+    tij = np.einsum("mab,mb->ma", np.transpose(Rgt[i], (0, 2, 1)), tgt[j] - tgt[i]) + sigma_t * rng.standard_normal((m, 2))
+    ids = np.zeros((m, 4), np.int32)
+    ids[:, 1], ids[:, 3] = i, j
+    vals = np.zeros((m, 9))
+    vals[:, :4] = np.transpose(Rij, (0, 2, 1)).reshape(m, 4)  # column-major R
+    vals[:, 4:6] = tij
+    vals[:, 6], vals[:, 7], vals[:, 8] = 1.0 / sigma_r ** 2, 1.0 / sigma_t ** 2, 1.0
+    return Dataset(2, n, ids, vals)

@@ -324,10 +324,10 @@ def test_large_single_problem_reports_the_cost_of_its_iterates(env):
     ((1, 19, 29), 5, ("sparse", "k_spmm")),       # k = 2204: the first sparse one
     ((10, 10, 20), 5, ("sparse", "k_spmm")),      # k = 8000 (dense until round 4)
     ((13, 21, 30), 5, ("sparse", "k_spmm")),      # n = 8190: the last CSR Q-apply
-    ((16, 16, 32), 5, ("sparse", "k_spmm_bsr2")),  # n = 8192: the first block-CSR one
-    ((32, 32, 24), 5, ("sparse", "k_spmm_bsr2")),  # n = 24576: 2048 pose blocks, the last fused solve at r = 5
-    ((30, 41, 20), 5, ("sparse", "k_spmm_bsr2")),  # n = 24600: the first one on the generic path
-    ((16, 16, 32), 8, ("sparse", "k_spmm_bsr2")),  # r = 8: the widest fused rank
+    ((16, 16, 32), 5, ("sparse", "k_spmm_bsrq")),  # n = 8192: the first block-CSR one
+    ((32, 32, 24), 5, ("sparse", "k_spmm_bsrq")),  # n = 24576: 2048 pose blocks, the last fused solve at r = 5
+    ((30, 41, 20), 5, ("sparse", "k_spmm_bsrq")),  # n = 24600: the first one on the generic path
+    ((16, 16, 32), 8, ("sparse", "k_spmm_bsrq")),  # r = 8: the widest fused rank
     ((13, 21, 30), 9, ("sparse", "k_spmm")),      # r = 9: generic kernels
 ])
 def test_size_regimes_agree_with_an_independent_cost(env, dims, r, expect):
@@ -397,3 +397,45 @@ def test_c5_staircase_step_on_a_lattice_block(env):
     assert Xn is not None and Xno is not None and common.rel(Xn, Xno) < 1e-8
     assert P6.f(Xn) < 0.5 * out["cost"][-1]
     P6.close()
+
+
+@pytest.mark.parametrize("r", [2, 3, 5, 8])
+def test_planar_lattice_on_the_block_structure(env, r):
+    """the block-CSR kernels at d = 2 (3 x 3 blocks, three of a quad's four lanes at work) on a planar lattice large
+    enough to get them (9216 poses >= 8192): every operator against the oracle, the local solver's iteration counts, and
+    a few RBCD++ rounds (the fused evaluation epilogue of the block Q-apply) against the oracle's driver"""
+    da, orc = env
+    from dcora_amd import synth
+    ds = synth.lattice_se2()
+    assert ds.d == 2 and ds.n == 9216
+    dso = orc.Dataset(ds.d, ds.n, ds.ids, ds.vals)
+    k = 3 * ds.n
+    rng = np.random.default_rng(r)
+    Q, Qo = da.build_Q_pgo(ds), orc.build_Q_pgo(dso)
+    G = rng.standard_normal((r, k))
+    P = da.QuadraticProblem(r, 2, ds.n, Q, G=G)
+    assert P.qapply_info()["kernel"] == "k_spmm_bsrq"
+    Po = orc.Problem(r, 2, ds.n, Qo, G=G)
+    X = orc.project_to_manifold(r, 2, ds.n, rng.uniform(-1, 1, (r, k)))
+    V = orc.tangent_project(r, 2, ds.n, X, rng.standard_normal((r, k)))
+    assert abs(P.f(X) - Po.f(X)) <= 1e-12 * abs(Po.f(X))
+    assert common.rel(P.EucGrad(X), Po.egrad(X)) < 1e-13
+    assert common.rel(P.RieGrad(X), Po.rgrad(X)) < 1e-12
+    assert common.rel(P.HessVec(X, V), Po.hess(X, V)) < 1e-12
+    opt = da.QuadraticOptimizer(P, da.ROptParameters(RTR_iterations=3, RTR_tCG_iterations=10))
+    Xs = opt.optimize(X)
+    res = opt.getOptResult()
+    Xo, reso = Po.optimize(X, RTR_iterations=3, RTR_tCG_iterations=10)
+    assert res["outer_iterations"] == reso["outer_iters"] and res["inner_iterations"] == reso["inner_iters"]
+    assert abs(res["fOpt"] - reso["fOpt"]) <= 1e-9 * abs(reso["fOpt"]) and common.rel(Xs, Xo) < 1e-7
+    P.close()
+    if r in (3, 5):
+        X0 = orc.project_to_manifold(r, 2, ds.n, rng.uniform(-1, 1, (r, k)))
+        s = da.RbcdSession(ds, num_robots=1, r=r)   # one agent of 9216 poses: the block evaluation per agent
+        s.set_X(X0)
+        out = s.run(max_iters=3, rgrad_tol=0.0)
+        tr = orc.run_rbcd(dso, X0, num_robots=1, r_min=r, max_iters=3, staircase=0, rgrad_tol=0.0)
+        assert np.allclose(out["cost"], tr["cost"], rtol=1e-10, atol=0)
+        assert np.allclose(out["gradnorm"], tr["gradnorm"], rtol=1e-8, atol=0)
+        assert common.rel(s.get_X(), tr["X"]) < 1e-7
+        s.close()

@@ -18,7 +18,7 @@ pw = max(pick(W, r'^k_fused_pc<', 'WRITE_SIZE_median'), key=lambda x: x[2])
 out['k_fused_pc_bytes_per_launch'] = (2 * pf[3] + pw[3]) * 1024
 out['k_fused_pc_counters'] = {'FETCH_SIZE_KB_median': pf[3], 'WRITE_SIZE_KB_median': pw[3], 'launches': pf[2],
     'note': 'traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 FETCH_SIZE counts half of a 16-B/lane streaming read (MI355X_MICROARCH.md, HBM); bytes the kernel streams once 32.56 MB (dense inverse 32 MB + 7 r k vectors); the per-workgroup re-reads of r_old / H delta are L2 hits and do not reach the fabric counters; tools/pmc_run.py, tools/pmc_summarize.py, round 2'}
-sf, sw = pick(F, r'^k_spmm_bsr2?<', 'FETCH_SIZE_median'), pick(W, r'^k_spmm_bsr2?<', 'WRITE_SIZE_median')
+sf, sw = pick(F, r'^k_spmm_bsr[2q]?<', 'FETCH_SIZE_median'), pick(W, r'^k_spmm_bsr[2q]?<', 'WRITE_SIZE_median')
 out['k_spmm_bsr_lattice100k_counters'] = {'kernels': [x[0] for x in sf], 'FETCH_SIZE_KB': [x[3] for x in sf], 'WRITE_SIZE_KB': [x[3] for x in sw], 'launches': [x[2] for x in sf],
     'note': '8-B gathers and 16-B block-row loads mixed: (FETCH+WRITE)*1024 and (2*FETCH+WRITE)*1024 bracket the traffic; algorithmic (CSR convention) 124.1 MB'}
 # the replay of the lattice agent inside bench.roofline: the grids of k_sp_mtile<1, 8> launched most often
