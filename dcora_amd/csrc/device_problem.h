@@ -224,6 +224,11 @@ class DeviceProblem {
   DevBuf<double> X0, X1, EG0, EG1, RG0, RG1, S0, S1;
   DevBuf<double> delta, eta, Heta, res, z, Hd, W, Zt;
   DevBuf<double> delta2, res2, Zpart;  // fused path: ping-pong direction / residual, split-K slices
+  // the one-launch tCG run (k_tcg_run): eligible sizes on this device; switched off for good after a run that gave up
+  // (grid not co-resident) and while several solves run at the same time (the coloured mode: concurrent_solves)
+  bool tcg_run_ok = false;
+  bool concurrent_solves = false;
+  DevBuf<unsigned> tcg_sync;
   bool fused = false;                  // SE layout, r <= 8: three-launch tCG iteration (solver_fused.hip)
   bool group = false;                  // SE layout, r <= 8: 8-lanes-per-pose rgrad / retract kernels (any n)
   DevBuf<double> pA, pB, pC, p1, p2, p3, scal;

@@ -258,6 +258,16 @@ int DeviceProblem::init(const dcora_dims &dims, const HostCsr &Qh, const double 
     if (rc) return rc;
   }
   lap("precond");
+  // the one-launch tCG run: dense inverse, the whole residual in one LDS image, n / 2 workgroups co-resident
+  if (fused && has_precond && !sparse_precond && !has_bsr && Q.n_long == 0 && env::solver_tcg() >= 0) {
+    hipDeviceProp_t prop;
+    DCORA_HIP(hipGetDeviceProperties(&prop, device));
+    tcg_run_ok = tcg_run_supported(m, ldm, prop.multiProcessorCount, tcg_run_max_rows_nnz(m, Qh.rp.data()));
+    if (tcg_run_ok) {
+      DCORA_HIP(tcg_sync.alloc((size_t)tcg_run_sync_words()));
+      DCORA_HIP(hipMemsetAsync(tcg_sync.p, 0, sizeof(unsigned) * (size_t)tcg_run_sync_words(), st));
+    }
+  }
   return DCORA_OK;
 }
 
@@ -881,6 +891,12 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
   // gated no-op launches among 38 800, and waiting for a verdict there only opens gaps) and is not kept.
   // dense preconditioner: B and C are ONE launch (k_fused_pc); DCORA_SOLVER_BC=split keeps the three-launch form
   const bool pc = use_pc();
+  // dense one-launch form: the whole tCG run of an RTR iteration as ONE launch (k_tcg_run) where the grid is co-resident
+  // and no other solve shares the device's launch path; a run that gives up (tcg_abort_seq) switches the form off for
+  // this problem and the iteration is repeated on the launches
+  bool run_form = pc && tcg_run_ok && !concurrent_solves;
+  unsigned *sync_p = run_form ? tcg_sync.p : nullptr;
+  const int nsync = run_form ? tcg_run_sync_words() : 0;
   const int nZ = pc ? fused_pc_blocks(m) : nPB;  // <z, r> partial slots A sums in its prologue
   double *dbuf[2] = {delta.p, delta2.p};
   double *rbuf[2] = {res.p, res2.p};
@@ -906,7 +922,7 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
     ++seq;
     nG = enq_rgrad(Xb(), EGb(), RGb(), Sb(), 0, pB.p, Gate{});
   }
-  launch_rtr_init(st, pA.p, nAe, pB.p, nG, c, hf_dev, ++seq, ci);
+  launch_rtr_init(st, pA.p, nAe, pB.p, nG, c, hf_dev, ++seq, ci, sync_p, nsync);
   int last_pace_seq = seq;
   std::vector<int> fin_seq((size_t)std::max(1, max_inner));
   // The first kernel of an RTR iteration (z0 = P grad: B in "first" mode, or B + C in one launch) needs nothing the host
@@ -916,6 +932,12 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
   // for that round trip at every iteration (a loop that had ended leaves one gated no-op).  Returns its seq, < 0 when
   // the launch failed.
   auto enqueue_first = [&]() -> int {
+    if (run_form) {
+      if (launch_tcg_run(st, m, ldm, Mi, Qv, RGb(), Xb(), Sb(), dbuf[0], dbuf[1], Hd.p, eta.p, Heta.p, z.p, p1.p, p3.p,
+                         pC.p, tcg_sync.p, c, hf_dev, ++seq) < 0)
+        return -1;
+      return seq;
+    }
     if (pc) {
       if (launch_fused_pc(st, m, ldm, Mi, RGb(), Xb(), nullptr, nullptr, eta.p, Heta.p, nullptr, rbuf[0], z.p, nullptr,
                           0, p3.p, c, hf_dev, ++seq, 0, 1) < 0)
@@ -930,13 +952,34 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0;
   };
   int next_first_seq = time_is_up() ? 0 : enqueue_first();
+  auto run_gave_up = [&]() { return run_form && hf->tcg_abort_seq >= solve_first; };
   for (int outer = 0; outer < max_outer; ++outer) {
     if (next_first_seq < 0) {
       DCORA_HIP(hipStreamSynchronize(st));
       set_last_error("k_fused_pc could not be launched on this device");
       return DCORA_ERR_HIP;
     }
-    if (!spin_until([&] { return hf->last_seq_done >= last_pace_seq || outer_done(); }, 20.0)) return timed_out();
+    if (!spin_until([&] { return hf->last_seq_done >= last_pace_seq || outer_done() || run_gave_up(); }, 20.0))
+      return timed_out();
+    if (run_gave_up()) {
+      // The one-launch run of iteration `outer` (or the one before: its evaluation and decision were queued behind it)
+      // found its grid not co-resident and left; everything queued behind it was a no-op (outer_done_stamp).  Re-arm
+      // the control block, drop the form for this problem and take the iteration again on the launches: the run wrote
+      // nothing but scratch (eta, H eta, the trial point and the control block are written when a run ENDS).
+      DCORA_HIP(hipStreamSynchronize(st));
+      const int armed = INT_MAX;
+      DCORA_HIP(hipMemcpy(&c->outer_done_stamp, &armed, sizeof(int), hipMemcpyHostToDevice));
+      const bool before = hf->last_seq_done < last_pace_seq;  // the decision of iteration outer - 1 never ran
+      hf->tcg_abort_seq = 0;
+      tcg_run_ok = false;
+      run_form = false;
+      if (before) --outer;
+      next_first_seq = enqueue_first();
+      if (before) {
+        // the evaluation + decision of the repeated iteration follow below as usual
+      }
+      if (next_first_seq < 0) continue;
+    }
     if (outer_done()) break;
     if (next_first_seq == 0) break;  // the time bound had passed when this iteration's first kernel was due
     // z0 = P(grad): B in "first" mode streams the preconditioner over grad, C projects and forms <z0, r0>
@@ -954,7 +997,7 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
                             sparse_precond ? W.p : nullptr);
       }
     }
-    for (int j = 0; j < max_inner; ++j) {
+    for (int j = 0; j < max_inner && !run_form; ++j) {
       if (j >= kLookahead) {
         const int need = fin_seq[j - kLookahead];
         if (!spin_until(
@@ -1009,7 +1052,7 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
       enq_qapply(Xb(), 1, Gp, EGb(), 1, pA.p, Gate{c, ++seq, 1});
       nG = enq_rgrad(Xb(), EGb(), RGb(), Sb(), 1, pB.p, Gate{c, ++seq, 1});
     }
-    launch_rtr_decide(st, pA.p, nAe, pB.p, nG, pC.p, nR, c, hf_dev, ++seq);
+    launch_rtr_decide(st, pA.p, nAe, pB.p, nG, pC.p, nR, c, hf_dev, ++seq, sync_p, nsync);
     last_pace_seq = seq;
     if (outer + 1 < max_outer) next_first_seq = time_is_up() ? 0 : enqueue_first();
   }

@@ -22,6 +22,9 @@ int precond_mode() {
 bool generic_solver() {
   return is("DCORA_SOLVER", "generic");
 }
+int solver_tcg() {
+  return is("DCORA_SOLVER_TCG", "launch") ? -1 : is("DCORA_SOLVER_TCG", "run") ? 1 : 0;
+}
 int solver_bc() {
   static const int v = is("DCORA_SOLVER_BC", "pc") ? 1 : is("DCORA_SOLVER_BC", "split") ? -1 : 0;
   return v;

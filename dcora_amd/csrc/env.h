@@ -11,6 +11,7 @@ namespace env {
 bool init_timing();          // DCORA_INIT_TIMING: laps of the set-up paths on stderr
 int precond_mode();          // DCORA_PRECOND=dense|sparse -> 1 | 2 (0: chosen by size, kDensePrecondMaxK)
 bool generic_solver();       // DCORA_SOLVER=generic: the thread-per-variable path also where the fused kernels apply
+int solver_tcg();            // DCORA_SOLVER_TCG=launch|run -> -1 | +1: the dense tCG run as launches per iteration / as ONE launch (0: by size)
 int solver_bc();             // DCORA_SOLVER_BC=pc|split -> +1 | -1: one-launch / three-launch form of the dense tCG step
 bool factor_on_host();       // DCORA_FACTOR=host: sparse Cholesky of the preconditioner on host threads
 bool fill_on_host();         // DCORA_SP_FILL=host: stored weights formed by host threads and streamed in chunks

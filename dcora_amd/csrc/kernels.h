@@ -99,6 +99,7 @@ struct HostFlags {
   volatile int outer_done_seq;  // seq at which the RTR loop terminated (0 = running)
   volatile int go_seq;          // seq of the latest fused B (or B+C) kernel whose boundary test let the tCG run go on
   volatile int reject_seq;      // seq of the latest k_rtr_decide that rejected its step (the iterate did not move)
+  volatile int tcg_abort_seq;   // seq of a one-launch tCG run (k_tcg_run) that gave up: its grid was not co-resident
 };
 
 // Solver-aware launches carry (ctl, seq, gate): gate 0 = always run, 1 = skip once the RTR loop is done,
@@ -181,8 +182,9 @@ struct CtlInit {
   double tol = 0, Delta = 0, maxDelta = 0;
   int max_outer = 0, stop_on_accept = 0, max_inner = 0;
 };
+// tcg_sync (optional): the grid-step counters of the one-launch tCG run queued behind this kernel, zeroed here
 void launch_rtr_init(hipStream_t st, const double *pA, int npA, const double *pB, int npB, SolverCtl *ctl,
-                     HostFlags *hf, int seq, CtlInit ci = CtlInit());
+                     HostFlags *hf, int seq, CtlInit ci = CtlInit(), unsigned *tcg_sync = nullptr, int nsync = 0);
 void launch_tcg_begin(hipStream_t st, long nelem, Buf2 grad, double *eta, double *Heta, double *res,
                       SolverCtl *ctl, int seq);
 void launch_tcg_init(hipStream_t st, long nelem, const double *z, const double *p3, int np3, double *delta,
@@ -193,7 +195,7 @@ void launch_tcg_update1(hipStream_t st, long nelem, const double *delta, const d
 void launch_tcg_update2(hipStream_t st, long nelem, const double *z, double *delta, const double *p3, int np3,
                         SolverCtl *ctl, HostFlags *hf, int seq, int iter);
 void launch_rtr_decide(hipStream_t st, const double *pA, int npA, const double *pB, int npB, const double *pC,
-                       int npC, SolverCtl *ctl, HostFlags *hf, int seq);
+                       int npC, SolverCtl *ctl, HostFlags *hf, int seq, unsigned *tcg_sync = nullptr, int nsync = 0);
 
 // ---- plain vector helpers ------------------------------------------------------------------------------
 void launch_axpby(hipStream_t st, long nelem, double a, const double *x, double b, const double *y, double *out);
@@ -246,6 +248,16 @@ void launch_fused_precond(hipStream_t st, const ManiDesc &m, int ldm, const doub
                           HostFlags *hf, int seq, int iter, int first, SpFold sf = SpFold());
 // B + C in one launch (dense preconditioner): returns the number of <z, r> partial slots written to p3
 int fused_pc_blocks(const ManiDesc &m);
+// ONE launch per tCG run (k_tcg_run, solver_fused.hip): the dense one-launch B + C form's sizes with n / 2 workgroups
+// co-resident (cus = CUs of the device) and an even number of poses per k_fused_hess workgroup; max_rows_nnz: the most
+// CSR entries any workgroup's 2 (d+1) matrix rows hold.  tcg_run_sync_words: unsigned words of its grid-step counters.
+bool tcg_run_supported(const ManiDesc &m, int ldm, int cus, int max_rows_nnz);
+int tcg_run_sync_words();
+int tcg_run_max_rows_nnz(const ManiDesc &m, const int *rowptr);  // host CSR row pointers -> the figure above
+// returns the number of workgroups (= <z, r> and pC partial pairs), < 0 when the launch is refused
+int launch_tcg_run(hipStream_t st, const ManiDesc &m, int ldm, const double *Minv, const CsrDev &Q, Buf2 grad, Buf2 X,
+                   Buf2 S, double *d0, double *d1, double *Hd, double *eta, double *Heta, double *z, double *p1r,
+                   double *p3, double *pC, unsigned *sync, SolverCtl *ctl, HostFlags *hf, int seq);
 bool fused_pc_preferred(const ManiDesc &m, int ldm);  // sizes at which it beats B + C
 bool fused_pc_ready(const ManiDesc &m, int ldm);      // the current device grants the kernel its dynamic LDS
 int launch_fused_pc(hipStream_t st, const ManiDesc &m, int ldm, const double *Minv, Buf2 grad, Buf2 X,

@@ -1585,8 +1585,10 @@ void launch_dense_apply(hipStream_t st, int r, int k, int ldm, const double *Min
 // Every block recomputes the same scalars from the same partials; block 0 publishes them.
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_rtr_init(const double *pA, int npA, const double *pB, int npB,
-                                                     SolverCtl *ctl, HostFlags *hf, int seq, CtlInit ci) {
+                                                     SolverCtl *ctl, HostFlags *hf, int seq, CtlInit ci,
+                                                     unsigned *tcg_sync, int nsync) {
   __shared__ double s_red[16];
+  for (int i = threadIdx.x; i < nsync; i += kBlock) tcg_sync[i] = 0u;
   if (ci.enable && threadIdx.x == 0) {  // start-of-solve control block (saves the separate k_ctl_init launch)
     SolverCtl *c = ctl;
     c->f2 = c->rho = 0;
@@ -1773,9 +1775,10 @@ __global__ __launch_bounds__(kBlock) void k_tcg_update2(long nelem, const double
 // rho = (f1 - f2) / -(<eta, g> + 0.5 <eta, H eta>); accept iff rho > 0.1; radius update as RTRNewton
 __global__ __launch_bounds__(kBlock) void k_rtr_decide(const double *pA, int npA, const double *pB, int npB,
                                                        const double *pC, int npC, SolverCtl *ctl, HostFlags *hf,
-                                                       int seq) {
+                                                       int seq, unsigned *tcg_sync, int nsync) {
   if (gated(ctl, seq, 1)) return;
   __shared__ double s_red[20];
+  for (int i = threadIdx.x; i < nsync; i += kBlock) tcg_sync[i] = 0u;
   const double *const ps[5] = {pA, pA, pB, pC, pC};
   const int nps[5] = {npA, npA, npB, npC, npC}, sts[5] = {2, 2, 1, 2, 2}, offs[5] = {0, 1, 0, 0, 1};
   double sums[5];
@@ -1812,8 +1815,8 @@ __global__ __launch_bounds__(kBlock) void k_rtr_decide(const double *pA, int npA
 }
 
 void launch_rtr_init(hipStream_t st, const double *pA, int npA, const double *pB, int npB, SolverCtl *ctl,
-                     HostFlags *hf, int seq, CtlInit ci) {
-  hipLaunchKernelGGL(k_rtr_init, dim3(1), dim3(kBlock), 0, st, pA, npA, pB, npB, ctl, hf, seq, ci);
+                     HostFlags *hf, int seq, CtlInit ci, unsigned *tcg_sync, int nsync) {
+  hipLaunchKernelGGL(k_rtr_init, dim3(1), dim3(kBlock), 0, st, pA, npA, pB, npB, ctl, hf, seq, ci, tcg_sync, nsync);
 }
 void launch_tcg_begin(hipStream_t st, long nelem, Buf2 grad, double *eta, double *Heta, double *res,
                       SolverCtl *ctl, int seq) {
@@ -1836,8 +1839,9 @@ void launch_tcg_update2(hipStream_t st, long nelem, const double *z, double *del
                      seq, iter);
 }
 void launch_rtr_decide(hipStream_t st, const double *pA, int npA, const double *pB, int npB, const double *pC,
-                       int npC, SolverCtl *ctl, HostFlags *hf, int seq) {
-  hipLaunchKernelGGL(k_rtr_decide, dim3(1), dim3(kBlock), 0, st, pA, npA, pB, npB, pC, npC, ctl, hf, seq);
+                       int npC, SolverCtl *ctl, HostFlags *hf, int seq, unsigned *tcg_sync, int nsync) {
+  hipLaunchKernelGGL(k_rtr_decide, dim3(1), dim3(kBlock), 0, st, pA, npA, pB, npB, pC, npC, ctl, hf, seq, tcg_sync,
+                     nsync);
 }
 
 // ------------------------------------------------------------------------------------------------------

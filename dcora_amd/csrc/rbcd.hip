@@ -794,7 +794,9 @@ int RbcdSession::solve_block(AgentDev &a, std::string *err) {
   pb.st = a.own;
   Buf2 Xres{{nullptr, nullptr}};
   const SolverCtl *cs = nullptr;
+  pb.concurrent_solves = true;  // several solves share the device: no co-resident one-launch tCG run (k_tcg_run)
   int rc = pb.optimize_dev(opt.local, &Xres, &cs);
+  pb.concurrent_solves = false;
   if (!rc) {
     if (cs && group_kernels(pb.m)) {
       nesterov(a.own, pb.m, 3, 0, -1, -1, 0.0, 0.0, Xg.p + off, Vg.p + off, Yg.p + off, XPrevg.p + off, nullptr, Xres,

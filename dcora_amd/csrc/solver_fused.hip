@@ -1266,7 +1266,7 @@ __global__ __launch_bounds__(kPcBlock) void k_fused_pc(ManiDesc m, int ldm, int 
       eta[oown] = o_eta + step * o_d;
       Heta[oown] = o_Heta + step * o_h;
       if (!boundary) {
-        const double rr = o_r + alpha * o_h;
+        const double rr = fma(alpha, o_h, o_r);
         res_new[oown] = rr;
         s_R[lc * RM + t] = rr;
       }
@@ -1437,6 +1437,462 @@ __global__ __launch_bounds__(kPcBlock) void k_fused_pc(ManiDesc m, int ldm, int 
   }
   if (!first && iter + 1 >= c_max_inner) retract_tail();
 }
+
+// ------------------------------------------------------------------------------------------------------
+// ONE launch per tCG run (round 5): PC in "first" mode, then [A, PC] per iteration and the retraction of the step, all
+// inside one kernel of n / 2 workgroups (one per CU at the headline size: 250), with two grid-wide steps per iteration
+// instead of two kernel boundaries.  What it buys (tools/tcg_probe.hip, profiles/r05_persistent_tcg.txt): a grid step
+// among 250 resident workgroups costs 1.9 us where a kernel boundary costs 2.9 us of launch floor + the prologue's
+// round trips; the workgroup's 8 rows of the inverse stay in REGISTERS for the whole run (64 doubles per lane: 32 MB per
+// launch were streamed per iteration); the residual image stays in LDS and only H delta is gathered per iteration.
+// What it costs: everything the workgroups exchange inside the launch (z, delta, H delta, the partial sums) crosses the
+// XCDs' private L2s through the coherent level -- write-through stores and loads with sc1 -- and the grid must be
+// co-resident: the form is used only where n / 2 <= the CU count, never by concurrent solves (the coloured mode), and
+// every spin is bounded: a workgroup that waits longer than 2 ms raises an abort word, all workgroups leave, the kernels
+// queued behind the run become no-ops (outer_done_stamp) and the host repeats the RTR iteration on the launch form.
+// The arithmetic is the launch form's, term for term and sum for sum (same lane layouts, same partial-sum trees: the
+// <delta, H delta> partials are rebuilt from the workgroups' 16-lane row sums exactly as k_fused_hess's workgroups of
+// PB_A poses add them), so a run is bitwise the run of the launches: tests/test_kernel_forms_gpu.py.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kRunShards = 32, kRunCopies = 64, kRunStride = 32;  // sync words 128 B apart
+constexpr int kRunSyncWords = (kRunShards + 1 + kRunCopies + 1) * kRunStride;
+constexpr int kRunQCap = 1024;  // CSR entries of a workgroup's 2 (d+1) matrix rows staged in LDS once per run
+struct TcgRunArgs {
+  ManiDesc m;
+  int ldm;
+  const double *Minv;
+  CsrDev Q;
+  Buf2 grad, X, S;
+  double *d0, *d1, *Hd, *eta, *Heta, *z, *p1r, *p3, *pC;
+  unsigned *sync;  // zeroed by the single-block kernel in front of the run (k_rtr_init / k_rtr_decide)
+  SolverCtl *ctl;
+  HostFlags *hf;
+  int seq, pbA;    // pbA: poses per workgroup of k_fused_hess at this r (the tree its <delta, H delta> partials follow)
+};
+__device__ __forceinline__ double ld_coh(const double *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_coh(double *p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double2 pc_ld16_coh(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+  const pc_v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 16);  // aux bit 4: sc1 (agent scope)
+  return __builtin_bit_cast(double2, v);
+}
+// grid-wide step `step` (0, 1, 2, ...) of this launch: sharded arrival counters, the last arrival replicates the done
+// word, workgroup i polls copy i % 64.  false: this workgroup (or another one) gave up.
+__device__ __forceinline__ bool run_grid_step(unsigned *sync, unsigned step, int *s_ok) {
+  __builtin_amdgcn_s_waitcnt(0);  // this wave's write-through stores are acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned *shard = sync, *top = sync + kRunShards * kRunStride, *done = top + kRunStride,
+             *abort_w = done + kRunCopies * kRunStride;
+    const int i = blockIdx.x, G = gridDim.x, sh = i % kRunShards;
+    const unsigned in_shard = (unsigned)((G - sh + kRunShards - 1) / kRunShards), want = step + 1;
+    const unsigned a = __hip_atomic_fetch_add(shard + sh * kRunStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a + 1 == want * in_shard) {
+      const unsigned shards_used = (unsigned)(G < kRunShards ? G : kRunShards);
+      const unsigned b = __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (b + 1 == want * shards_used)
+        for (int c = 0; c < kRunCopies; ++c)
+          __hip_atomic_store(done + c * kRunStride, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const long long t0 = wall_clock64();
+    const unsigned *p = done + (i % kRunCopies) * kRunStride;
+    int ok = 1;
+    unsigned spins = 0;
+    while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+      __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 63u) == 0) {
+        if (__hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+          ok = 0;
+          break;
+        }
+        if (wall_clock64() - t0 > 200000) {  // 2 ms at 100 MHz: the grid is not co-resident
+          __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = 0;
+          break;
+        }
+      }
+    }
+    *s_ok = ok;
+  }
+  __syncthreads();
+  return *s_ok != 0;
+}
+
+template <int D, int R, int NS>
+__global__ __launch_bounds__(kPcBlock) void k_tcg_run(TcgRunArgs a) {
+  constexpr int DH = D + 1, PB = 2, NR = PB * DH, RM = R;
+  extern __shared__ double s_res[];  // the residual image, column-major as in memory: cpad * R doubles, kept for the run
+  __shared__ double s_P[NR * RM + 1][4 * kPcNW];
+  __shared__ double s_Z[NR * RM + 1], s_R[NR * RM], s_W[NR * RM], s_D[NR * RM], s_H[NR * RM];
+  __shared__ double s_red[16];
+  __shared__ int s_ci[kRunQCap];
+  __shared__ double s_v[kRunQCap];
+  __shared__ int s_ok;
+  SolverCtl *ctl = a.ctl;
+  const int seq = a.seq;
+  const int st_o = ctl->outer_done_stamp, cur = ctl->cur & 1;
+  if (seq > st_o) return;  // the RTR loop has ended: no-op (uniform over the grid)
+  const double c_Delta = ctl->Delta, c_ngf = ctl->ngf;
+  const int c_max_inner = ctl->max_inner;
+  const ManiDesc m = a.m;
+  constexpr int r = R;
+  const int k = m.k, ldm = a.ldm;
+  const int pose0 = blockIdx.x * PB;
+  const int npose = min(PB, m.n - pose0);
+  const int j0 = pose0 * DH, nrow = npose * DH;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int e = threadIdx.x;
+  const bool own = e < nrow * r;
+  const size_t oown = (size_t)j0 * r + e;
+  const int lc = e / r, t = e - lc * r;
+  const int g = threadIdx.x >> 3, tt = threadIdx.x & (GW - 1);
+  const bool pact = (g < npose) && (tt < r);
+  const size_t o = (size_t)(pose0 + min(g, npose - 1)) * DH * r;
+  const double *__restrict__ grad = a.grad.p[cur];
+  const double *__restrict__ X = a.X.p[cur];
+  const unsigned vec_bytes = (unsigned)((size_t)r * k * sizeof(double));
+  const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(grad), 0, vec_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(a.Hd, 0, vec_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<double *>(a.Minv), 0, (unsigned)((size_t)k * ldm * sizeof(double)), 0x00020000);
+  const unsigned voff_t = threadIdx.x * 16u, voff_l = (unsigned)lane * 16u;
+  // ---- once per run: the workgroup's rows of the inverse (registers), its matrix rows of Q (LDS), its poses ----
+  double2 mreg[NS][NR];
+#pragma unroll
+  for (int u = 0; u < NS; ++u)
+#pragma unroll
+    for (int q = 0; q < NR; ++q)
+      mreg[u][q] = pc_ld16(rs_m, voff_l, (unsigned)(((size_t)(j0 + q) * ldm + (size_t)(wave_u + kPcNW * u) * 128) * 8));
+  double2 xg[kPcSB];
+#pragma unroll
+  for (int u = 0; u < kPcSB; ++u) xg[u] = pc_ld16(rs_g, voff_t, (unsigned)u * kPcBlock * 16u);
+  const int pbeg = a.Q.rp[j0], pend = a.Q.rp[j0 + nrow];
+  for (int i = threadIdx.x; i < pend - pbeg; i += kPcBlock) {
+    s_ci[i] = a.Q.ci[pbeg + i];
+    s_v[i] = a.Q.v[pbeg + i];
+  }
+  const int myb = own ? a.Q.rp[j0 + lc] - pbeg : 0, mye = own ? a.Q.rp[j0 + lc + 1] - pbeg : 0;
+  Row<D> Y;
+  ld_row<D>(X + o, r, tt, pact, Y);
+  double S[D][D];
+  {
+    const double *__restrict__ Sblk = a.S.p[cur];
+#pragma unroll
+    for (int aa = 0; aa < D; ++aa)
+#pragma unroll
+      for (int b = 0; b < D; ++b) S[aa][b] = (g < npose) ? Sblk[(size_t)(pose0 + g) * D * D + aa + b * D] : 0.0;
+  }
+  double o_r = own ? grad[oown] : 0.0, o_eta = 0, o_Heta = 0, o_d = 0, o_h = 0;
+  // image geometry (one chunk: the host admits the form only where the whole residual fits)
+  const int cpad = ((k + 127) / 128) * 128;
+  const long Nc = (long)k * r;
+  const int npair = (int)((Nc + 1) >> 1);
+  const int nstep = cpad / 128;
+  // tCG scalars (the control block's, kept in registers by every thread: all of them see the same sums)
+  double zr = 0, dPd = 0, ePe = 0, ePd = 0, alpha = 0, ePen = 0;
+  const double n0 = c_ngf;
+  int status = 4, iters_done = 0;
+  unsigned gstep = 0;
+  double acc[NR][RM];
+  double nrm2 = 0;
+  // product of the workgroup's rows (registers) with the image, sums over the workgroup: s_Z
+  auto product = [&]() {
+#pragma unroll
+    for (int q = 0; q < NR; ++q)
+#pragma unroll
+      for (int tq = 0; tq < RM; ++tq) acc[q][tq] = 0;
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      const int sidx = wave_u + kPcNW * u;
+      if (sidx < nstep) {
+        const double *__restrict__ xs = s_res + (size_t)(sidx * 128 + 2 * lane) * r;
+        double x0[RM], x1[RM];
+#pragma unroll
+        for (int tq = 0; tq < RM; ++tq) {
+          x0[tq] = xs[tq];
+          x1[tq] = xs[r + tq];
+        }
+#pragma unroll
+        for (int tq = 0; tq < RM; ++tq)
+#pragma unroll
+          for (int q = 0; q < NR; ++q) acc[q][tq] = fma(x0[tq], mreg[u][q].x, fma(x1[tq], mreg[u][q].y, acc[q][tq]));
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NR; ++q)
+#pragma unroll
+      for (int tq = 0; tq < RM; ++tq) {
+        const double v = row16_sum_dpp(acc[q][tq]);
+        if ((lane & 15) == 0) s_P[q * RM + tq][wave * 4 + (lane >> 4)] = v;
+      }
+    {
+      const double v = row16_sum_dpp(nrm2);
+      if ((lane & 15) == 0) s_P[NR * RM][wave * 4 + (lane >> 4)] = v;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x <= NR * RM) {
+      double v = 0;
+#pragma unroll
+      for (int w = 0; w < 4 * kPcNW; ++w) v += s_P[threadIdx.x][w];
+      s_Z[threadIdx.x] = v;
+    }
+    __syncthreads();
+  };
+  // z = Proj_X(columns), partial <z, r> (wave 0 holds the per-pose lanes), published for the other workgroups
+  auto project_z = [&]() {
+    if (wave == 0) {
+      Row<D> Zr, Rr;
+#pragma unroll
+      for (int aa = 0; aa < DH; ++aa) {
+        Zr.e[aa] = pact ? s_Z[(g * DH + aa) * RM + tt] : 0.0;
+        Rr.e[aa] = pact ? s_R[(g * DH + aa) * RM + tt] : 0.0;
+      }
+      row_tangent<D>(Y, Zr);
+      if (pact)
+#pragma unroll
+        for (int aa = 0; aa < DH; ++aa) st_coh(a.z + o + aa * r + tt, Zr.e[aa]);
+      double zacc = 0;
+#pragma unroll
+      for (int aa = 0; aa < DH; ++aa) zacc += Zr.e[aa] * Rr.e[aa];
+      const double tot = f_wave_sum(zacc);
+      if (lane == 0) st_coh(a.p3 + blockIdx.x, tot);
+    }
+  };
+  // the end of a run: control block, eta / H eta, the step itself (k_fused_pc's retract_tail)
+  auto finish = [&]() {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      ctl->alpha = alpha;
+      ctl->e_Pe_n = ePen;
+      ctl->norm_r0 = n0;
+      ctl->z_r[0] = ctl->z_r[1] = zr;
+      ctl->d_Pd[0] = ctl->d_Pd[1] = dPd;
+      ctl->e_Pe[0] = ctl->e_Pe[1] = ePe;
+      ctl->e_Pd[0] = ctl->e_Pd[1] = ePd;
+      ctl->tcg_status = status;
+      ctl->tcg_iters = iters_done;
+      ctl->inner_total += iters_done;
+      ctl->tcg_done_stamp = seq;
+      f_host_store(&a.hf->tcg_done_seq, seq);
+      f_host_store(&a.hf->last_seq_done, seq);
+    }
+    __syncthreads();
+    double a0 = 0, a1 = 0;
+    if (own) {
+      a.eta[oown] = o_eta;
+      a.Heta[oown] = o_Heta;
+      const double gr = grad[oown];
+      a0 = o_eta * gr;
+      a1 = o_eta * o_Heta;
+      s_R[lc * RM + t] = o_eta;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      Row<D> Yn = Y;
+#pragma unroll
+      for (int aa = 0; aa < DH; ++aa) Yn.e[aa] += 1.0 * (pact ? s_R[(g * DH + aa) * RM + tt] : 0.0);
+      row_qf<D>(Yn);
+      st_row<D>(a.X.p[cur ^ 1] + o, r, tt, pact, Yn);
+    }
+    const double t0 = f_block_sum(a0, s_red);
+    const double t1 = f_block_sum(a1, s_red);
+    if (threadIdx.x == 0) {
+      a.pC[2 * blockIdx.x] = t0;
+      a.pC[2 * blockIdx.x + 1] = t1;
+    }
+  };
+  auto give_up = [&]() {  // the grid is not co-resident: later kernels of this solve become no-ops, the host repeats
+    if (threadIdx.x == 0) {
+      ctl->outer_done_stamp = seq - 1;
+      f_host_store(&a.hf->tcg_abort_seq, seq);
+    }
+  };
+  // ---- PC, first: z0 = Proj_X(grad Minv), res = grad, eta = H eta = 0 ----
+#pragma unroll
+  for (int u = 0; u < kPcSB; ++u) {
+    const int i = u * kPcBlock + (int)threadIdx.x;
+    if (i < npair) {
+      const double2 x = xg[u];
+      nrm2 = fma(x.x, x.x, nrm2);
+      nrm2 = fma(x.y, x.y, nrm2);
+      reinterpret_cast<double2 *>(s_res)[i] = x;
+    }
+  }
+  for (long i = 2L * npair + threadIdx.x; i < (long)cpad * r; i += kPcBlock) s_res[i] = 0.0;
+  if (own) s_R[lc * RM + t] = o_r;
+  __syncthreads();
+  product();
+  project_z();
+  if (c_max_inner <= 0) {  // (no inner iterations allowed: the launch form leaves eta = 0 behind as well)
+    status = 4;
+    finish();
+    return;
+  }
+  if (!run_grid_step(a.sync, gstep++, &s_ok)) return give_up();
+  // ---- the iterations ----
+  for (int iter = 0;; ++iter) {
+    const int par = iter & 1;
+    double *__restrict__ d_new = par ? a.d1 : a.d0;
+    const double *__restrict__ d_old = par ? a.d0 : a.d1;
+    // ======== A: delta = beta delta - z in the gather, H delta = Proj_X(delta Q - delta S), <delta, H delta> ========
+    {
+      const int np3 = gridDim.x;
+      const int l = lane;
+      const double pa = (l < np3) ? ld_coh(a.p3 + l) : 0.0, pb = (l + 64 < np3) ? ld_coh(a.p3 + l + 64) : 0.0;
+      const double pcc = (l + 128 < np3) ? ld_coh(a.p3 + l + 128) : 0.0, pd = (l + 192 < np3) ? ld_coh(a.p3 + l + 192) : 0.0;
+      const double z_r_new = f_wave_sum((pa + pb) + (pcc + pd));
+      double beta = 0;
+      if (iter > 0) beta = z_r_new / zr;
+      if (iter == 0) {
+        zr = z_r_new;
+        dPd = z_r_new;
+        ePe = 0;
+        ePd = 0;
+      } else {
+        const double c_ePd = ePd, c_alpha = alpha, c_dPd = dPd;
+        zr = z_r_new;
+        ePd = beta * (c_ePd + c_alpha * c_dPd);
+        dPd = z_r_new + beta * beta * c_dPd;
+        ePe = ePen;
+      }
+      double accw = 0, dn = 0;
+      if (own) {
+        const double z_own = ld_coh(a.z + oown);
+        for (int p = myb; p < mye; p += 8) {
+          double a8[8], b8[8], w8[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const bool ok = p + q < mye;
+            const size_t oo = ok ? (size_t)s_ci[p + q] * r + t : 0;
+            w8[q] = ok ? s_v[p + q] : 0.0;
+            b8[q] = ld_coh(a.z + oo);
+            a8[q] = (iter > 0) ? ld_coh(d_old + oo) : 0.0;
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) accw += w8[q] * (beta * a8[q] - b8[q]);
+        }
+        dn = (iter > 0) ? beta * o_d - z_own : -z_own;
+        st_coh(d_new + oown, dn);
+        o_d = dn;
+        s_W[e] = accw;
+        s_D[e] = dn;
+      }
+      __syncthreads();
+      if (wave == 0) {
+        Row<D> V, W;
+#pragma unroll
+        for (int aa = 0; aa < DH; ++aa) {
+          W.e[aa] = pact ? s_W[(g * DH + aa) * r + tt] : 0.0;
+          V.e[aa] = pact ? s_D[(g * DH + aa) * r + tt] : 0.0;
+        }
+        row_sub_AS<D>(W, V, S);
+        row_tangent<D>(Y, W);
+        if (pact)
+#pragma unroll
+          for (int aa = 0; aa < DH; ++aa) {
+            st_coh(a.Hd + o + aa * r + tt, W.e[aa]);
+            s_H[(g * DH + aa) * r + tt] = W.e[aa];
+          }
+        double dacc = 0;
+#pragma unroll
+        for (int aa = 0; aa < DH; ++aa) dacc += V.e[aa] * W.e[aa];
+        if (!pact) dacc = 0;
+        const double rs = row16_sum_dpp(dacc);  // the 16-lane row sum k_fused_hess's block sum starts from
+        if (lane == 0) st_coh(a.p1r + blockIdx.x, rs);
+      }
+      __syncthreads();
+      if (own) o_h = s_H[e];
+    }
+    if (!run_grid_step(a.sync, gstep++, &s_ok)) return give_up();
+    // ======== PC: step length, updates, z = Proj_X(res Minv), stopping rules ========
+    double2 xh[kPcSB];
+#pragma unroll
+    for (int u = 0; u < kPcSB; ++u) xh[u] = pc_ld16_coh(rs_h, voff_t, (unsigned)u * kPcBlock * 16u);
+    double d_Hd;
+    {
+      // k_fused_hess's partial of workgroup w: rows 2 w' .. of its pbA poses, wave by wave; then the wave sum over them
+      const int rows_per = a.pbA / 2, nrows = gridDim.x, nblk = (nrows + rows_per - 1) / rows_per;
+      double part = 0;
+      if (lane < nblk) {
+        const int b0 = lane * rows_per;
+        double wsum[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          double rs4[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int ri = w * 4 + q;
+            rs4[q] = (ri < rows_per && b0 + ri < nrows) ? ld_coh(a.p1r + b0 + ri) : 0.0;
+          }
+          wsum[w] = (rs4[0] + rs4[1]) + (rs4[2] + rs4[3]);
+        }
+        double tsum = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) tsum += wsum[w];
+        part = tsum;
+      }
+      d_Hd = f_wave_sum(part);
+    }
+    const double c_zr = zr, c_dPd = dPd, c_ePe = ePe, c_ePd = ePd;
+    alpha = c_zr / d_Hd;
+    const double e_Pe_new = c_ePe + 2.0 * alpha * c_ePd + alpha * alpha * c_dPd;
+    const bool boundary = (d_Hd <= 0) || (e_Pe_new >= c_Delta * c_Delta);
+    const double step =
+        boundary ? (-c_ePd + sqrt(c_ePd * c_ePd + c_dPd * (c_Delta * c_Delta - c_ePe))) / c_dPd : alpha;
+    ePen = e_Pe_new;
+    if (own) {
+      o_eta = o_eta + step * o_d;
+      o_Heta = o_Heta + step * o_h;
+    }
+    if (boundary) {
+      status = (d_Hd <= 0) ? 0 : 1;
+      iters_done = iter + 1;
+      finish();
+      return;
+    }
+    if (own) {
+      const double rr = fma(alpha, o_h, o_r);
+      o_r = rr;
+      s_R[lc * RM + t] = rr;
+    }
+    nrm2 = 0;
+#pragma unroll
+    for (int u = 0; u < kPcSB; ++u) {
+      const int i = u * kPcBlock + (int)threadIdx.x;
+      if (i < npair) {
+        double2 x = reinterpret_cast<double2 *>(s_res)[i];
+        x.x = fma(alpha, xh[u].x, x.x);
+        x.y = fma(alpha, xh[u].y, x.y);
+        nrm2 = fma(x.x, x.x, nrm2);
+        nrm2 = fma(x.y, x.y, nrm2);
+        reinterpret_cast<double2 *>(s_res)[i] = x;
+      }
+    }
+    __syncthreads();
+    product();
+    {
+      const double nr = sqrt(s_Z[NR * RM]);
+      const double kappa = 0.1, tempnum = n0;  // theta = 1
+      if (nr <= n0 * fmin(tempnum, kappa)) {
+        status = (kappa < tempnum) ? 2 : 3;
+        iters_done = iter + 1;
+        finish();
+        return;
+      }
+    }
+    project_z();
+    if (iter + 1 >= c_max_inner) {  // inner loop exhausted: status stays TR_MAXITER
+      iters_done = iter + 1;
+      finish();
+      return;
+    }
+    if (!run_grid_step(a.sync, gstep++, &s_ok)) return give_up();
+  }
+}
+
 
 // ------------------------------------------------------------------------------------------------------
 // RG = Proj_X(EG), S_i = sym(Y_i^T EG_i), partial |RG|^2
@@ -2200,6 +2656,62 @@ static int fused_pc_dispatch(hipStream_t st, const ManiDesc &m, int ldm, const d
 #undef DCORA_PC_R
 #undef DCORA_PC_FIXED_R
 #undef DCORA_PC
+}
+// ---- the one-launch tCG run ------------------------------------------------------------------------------
+constexpr int kRunNS = 4;  // 128-column steps per wave held in registers: k <= 4 * 4 * 128 = 2048
+int tcg_run_sync_words() { return kRunSyncWords; }
+int tcg_run_max_rows_nnz(const ManiDesc &m, const int *rp) {
+  const int dh = m.d + 1;
+  int worst = 0;
+  for (int p0 = 0; p0 < m.n; p0 += 2) {
+    const int j0 = p0 * dh, j1 = std::min(m.n, p0 + 2) * dh;
+    worst = std::max(worst, rp[j1] - rp[j0]);
+  }
+  return worst;
+}
+bool tcg_run_supported(const ManiDesc &m, int ldm, int cus, int max_rows_nnz) {
+  if (!m.se || m.d != 3 || m.r < 4 || m.r > 6) return false;    // instantiated ranks; r = 4, 5, 6: fused_pb even
+  if (fused_pb(m.r, m.d + 1) % 2 != 0) return false;               // row sums pair up with k_fused_hess's workgroups
+  if (!fused_pc_preferred(m, ldm) || fused_pc_pb(m) != 2) return false;
+  const int grid = (m.n + 1) / 2;
+  if (grid > cus || grid > 256) return false;                      // co-resident, <z, r> partials in one wave load
+  if (m.k > kRunNS * kPcNW * 128) return false;                    // the rows of the inverse fit the registers
+  const int rows_per = fused_pb(m.r, m.d + 1) / 2;
+  if ((grid + rows_per - 1) / rows_per > 64) return false;         // <delta, H delta> partials in one wave
+  return max_rows_nnz <= kRunQCap;
+}
+template <int R>
+static int tcg_run_launch(hipStream_t st, const TcgRunArgs &a) {
+  static std::atomic<unsigned long long> tried{0}, ok{0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+  const unsigned long long bit = 1ull << dev;
+  if (!(tried.load(std::memory_order_acquire) & bit)) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tcg_run<3, R, kRunNS>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, kPcLdsCap);
+    if (e == hipSuccess)
+      ok.fetch_or(bit, std::memory_order_release);
+    else
+      (void)hipGetLastError();
+    tried.fetch_or(bit, std::memory_order_release);
+  }
+  const int cpad = ((a.m.k + 127) / 128) * 128;
+  const size_t lds = (size_t)cpad * R * sizeof(double);
+  if (!(ok.load(std::memory_order_acquire) & bit) && lds > 40 * 1024) return -1;
+  const int grid = (a.m.n + 1) / 2;
+  hipLaunchKernelGGL((k_tcg_run<3, R, kRunNS>), dim3(grid), dim3(kPcBlock), lds, st, a);
+  if (hipGetLastError() != hipSuccess) return -1;
+  return grid;
+}
+int launch_tcg_run(hipStream_t st, const ManiDesc &m, int ldm, const double *Minv, const CsrDev &Q, Buf2 grad, Buf2 X,
+                   Buf2 S, double *d0, double *d1, double *Hd, double *eta, double *Heta, double *z, double *p1r,
+                   double *p3, double *pC, unsigned *sync, SolverCtl *ctl, HostFlags *hf, int seq) {
+  TcgRunArgs a{m, ldm, Minv, Q, grad, X, S, d0, d1, Hd, eta, Heta, z, p1r, p3, pC, sync, ctl, hf, seq,
+               fused_pb(m.r, m.d + 1)};
+  if (m.r == 4) return tcg_run_launch<4>(st, a);
+  if (m.r == 5) return tcg_run_launch<5>(st, a);
+  if (m.r == 6) return tcg_run_launch<6>(st, a);
+  return -1;
 }
 int launch_fused_pc(hipStream_t st, const ManiDesc &m, int ldm, const double *Minv, Buf2 grad, Buf2 X,
                     const double *delta, const double *Hd, double *eta, double *Heta, const double *res_old,

@@ -162,7 +162,11 @@ int main(int argc, char **argv) {
       // the default RTR (3 outer iterations from Delta = 100) reject its three steps -- the oracle's restatement of the
       // reference does the same on these measurements -- so the range-aided solve may hand back its input; it must never
       // ascend, and with room to shrink the radius it descends.
-      EXPECT(pSE.f(Yse) < fSE && pRA.f(Yra) <= fRA);
+      const double fYse = pSE.f(Yse), fYra = pRA.f(Yra);
+      if (!(fYse < fSE) || !(fYra <= fRA * (1.0 + 1e-12)))
+        std::fprintf(stderr, "pose-only graph: f %.17g -> SE %.17g, RA %.17g -> %.17g\n", fSE, fYse, fRA, fYra);
+      EXPECT(fYse < fSE);
+      EXPECT(fYra <= fRA * (1.0 + 1e-12));
       DCORA::ROptParameters longer;
       longer.RTR_iterations = 20;
       DCORA::QuadraticOptimizer oRA20(&pRA, longer);
