@@ -347,6 +347,16 @@ def _qapply_info(self):
 QuadraticProblem.qapply_info = _qapply_info
 
 
+def _solver_info(self):
+    """how the tCG iteration runs: 'three launches', 'two launches' or 'one launch per run' (k_tcg_run)"""
+    info = np.zeros(2)
+    check(capi.lib().dcora_problem_solver_info(self.h, info))
+    return {"tcg": {0: "three launches", 1: "two launches", 2: "one launch per run"}[int(info[0])]}
+
+
+QuadraticProblem.solver_info = _solver_info
+
+
 def time_qapply_rotating(problems, reps=60):
     """average launch time of the Q-apply over several problems in turn on one stream (HBM-cold when their bytes
     exceed the Infinity Cache)"""

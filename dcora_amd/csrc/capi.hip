@@ -252,6 +252,18 @@ int dcora_problem_qapply_info(dcora_problem_t p, double *info) {
   return DCORA_OK;
 }
 
+// how the dense tCG iteration runs on this problem: info[0] = 0 three launches or the sparse preconditioner, 1 = A + (B and C
+// in one launch), 2 = the whole tCG run in ONE launch (k_tcg_run; falls back to 1 for good after a run that gave up)
+int dcora_problem_solver_info(dcora_problem_t p, double *info) {
+  if (!p || !info) return bad("null");
+  const DeviceProblem &P = p->p;
+  info[0] = !P.use_pc() ? 0 : (P.tcg_run_ok ? 2 : 1);
+  return DCORA_OK;
+}
+int dcora_debug_tcg_run_fault(int runs) {
+  g_tcg_run_fault.store(runs < 0 ? 0 : runs);
+  return DCORA_OK;
+}
 int dcora_problem_time_precond(dcora_problem_t p, int reps, double *avg_ms, double *bytes) {
   return p ? p->p.time_precond(reps, avg_ms, bytes) : bad("null");
 }

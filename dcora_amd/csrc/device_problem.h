@@ -294,11 +294,11 @@ class DeviceProblem {
 
   int time_qapply(int reps, double *avg_ms, double *bytes);
   int time_precond(int reps, double *avg_ms, double *bytes);
+  bool use_pc() const;  // dense preconditioner, step + product + projection in one launch (k_fused_pc)
 
  private:
   int rtr_dev(const dcora_ropt_params &prm, dcora_ropt_result *res, double **Xres);
   int rtr_dev_fused(const dcora_ropt_params &prm);
-  bool use_pc() const;
   int rgd_dev(const dcora_ropt_params &prm, dcora_ropt_result *res, double **Xres);
   int seq_ = 0;            // launch sequence number, monotonic across solves (HostFlags words are never reset)
   bool pending_ = false;   // a fused solve has been enqueued and its statistics not yet fetched

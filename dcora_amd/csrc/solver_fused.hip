@@ -1468,6 +1468,7 @@ struct TcgRunArgs {
   SolverCtl *ctl;
   HostFlags *hf;
   int seq, pbA;    // pbA: poses per workgroup of k_fused_hess at this r (the tree its <delta, H delta> partials follow)
+  int fault;       // test hook (dcora_debug_tcg_run_fault): workgroup 0 leaves before the first grid step
 };
 __device__ __forceinline__ double ld_coh(const double *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1731,6 +1732,7 @@ __global__ __launch_bounds__(kPcBlock) void k_tcg_run(TcgRunArgs a) {
     finish();
     return;
   }
+  if (a.fault && blockIdx.x == 0) return;  // (test hook: the others wait in vain, give up after 2 ms and say so)
   if (!run_grid_step(a.sync, gstep++, &s_ok)) return give_up();
   // ---- the iterations ----
   for (int iter = 0;; ++iter) {
@@ -2660,6 +2662,7 @@ static int fused_pc_dispatch(hipStream_t st, const ManiDesc &m, int ldm, const d
 // ---- the one-launch tCG run ------------------------------------------------------------------------------
 constexpr int kRunNS = 4;  // 128-column steps per wave held in registers: k <= 4 * 4 * 128 = 2048
 int tcg_run_sync_words() { return kRunSyncWords; }
+std::atomic<int> g_tcg_run_fault{0};
 int tcg_run_max_rows_nnz(const ManiDesc &m, const int *rp) {
   const int dh = m.d + 1;
   int worst = 0;
@@ -2706,8 +2709,14 @@ static int tcg_run_launch(hipStream_t st, const TcgRunArgs &a) {
 int launch_tcg_run(hipStream_t st, const ManiDesc &m, int ldm, const double *Minv, const CsrDev &Q, Buf2 grad, Buf2 X,
                    Buf2 S, double *d0, double *d1, double *Hd, double *eta, double *Heta, double *z, double *p1r,
                    double *p3, double *pC, unsigned *sync, SolverCtl *ctl, HostFlags *hf, int seq) {
+  int fault = 0;
+  for (int left = g_tcg_run_fault.load(); left > 0;)
+    if (g_tcg_run_fault.compare_exchange_weak(left, left - 1)) {
+      fault = 1;
+      break;
+    }
   TcgRunArgs a{m, ldm, Minv, Q, grad, X, S, d0, d1, Hd, eta, Heta, z, p1r, p3, pC, sync, ctl, hf, seq,
-               fused_pb(m.r, m.d + 1)};
+               fused_pb(m.r, m.d + 1), fault};
   if (m.r == 4) return tcg_run_launch<4>(st, a);
   if (m.r == 5) return tcg_run_launch<5>(st, a);
   if (m.r == 6) return tcg_run_launch<6>(st, a);

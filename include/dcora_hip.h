@@ -110,6 +110,13 @@ int dcora_problem_hessvec(dcora_problem_t p, const double *X, const double *V, d
  * <V, H V> in ONE launch, k_spmm_dir_fix); dots[0] = <V, H V> from that kernel's partials, dots[1] = the same from the
  * two-launch form.  DCORA_ERR_UNSUPPORTED when the one-launch form does not apply (a long row on a manifold column). */
 int dcora_debug_hessvec_solver_form(dcora_problem_t p, const double *X, const double *V, double *out, double *dots);
+/* How the tCG iteration of the local solver runs on this problem: info[0] = 0 three launches per
+ * iteration (or the sparse preconditioner), 1 = two launches (Hessian product; step + dense preconditioner + projection),
+ * 2 = the whole tCG run of an RTR iteration in ONE launch (dense preconditioner, n / 2 workgroups co-resident). */
+int dcora_problem_solver_info(dcora_problem_t p, double *info);
+/* test hook: the next `runs` one-launch tCG runs of this process lose a workgroup before their first grid-wide step, as
+ * if the grid were not co-resident: the run must give up within milliseconds and the solve continue on the launches */
+int dcora_debug_tcg_run_fault(int runs);
 /* PreCondition (ref :70-84, 261-297) */
 int dcora_problem_precondition(dcora_problem_t p, const double *X, const double *V, double *out);
 /* Retract (ref :125-136, 236-259) */

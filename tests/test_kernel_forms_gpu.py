@@ -197,3 +197,88 @@ def test_lanczos_cycles_on_the_device_against_the_per_step_form(built, tmp_path)
         assert r_["two_i"][0] == 1 and abs(r_["two_i"][1] - 2.0) < 1e-12 and r_["two_i"][2] < 200, r_["two_i"]
         assert r_["diag"][0] == 1 and abs(r_["diag"][1] + 2.0) < 1e-7, r_["diag"]
         assert abs(abs(r_["diag_v"][0]) - 1.0) < 1e-6
+
+
+def _block_problem(da, name, R, b, r, seed=3):
+    """the local problem of agent b of a contiguous R-way split at a random point (with its linear term)"""
+    import bench
+    ds = common.product_dataset(name)
+    nb, ids, vals = bench.agent_block(ds, R, b)
+    rng = np.random.default_rng(seed)
+    k = (ds.d + 1) * nb
+    G = 0.3 * rng.standard_normal((r, k))
+    X = da.manifold_project(r, ds.d, nb, rng.uniform(-1, 1, (r, k)))
+    return ds.d, nb, da.build_Q_pgo(ds, n=nb, agent=b, ids=ids, vals=vals), G, X
+
+
+@pytest.mark.parametrize("name,R,r", [("sphere2500", 5, 5), ("sphere2500", 5, 4), ("sphere2500", 5, 6),
+                                      ("sphere2500", 8, 5), ("smallGrid3D", 1, 5), ("torus3D", 10, 5)])
+def test_one_launch_tcg_run_is_bitwise_the_launches(built, name, R, r):
+    """The dense tCG run as ONE launch (k_tcg_run: PC-first, [A, PC] per iteration and the retraction inside one kernel,
+    grid-wide steps instead of kernel boundaries) against the launches per iteration (DCORA_SOLVER_TCG=launch): the same
+    arithmetic term for term, so the same iterates BIT FOR BIT, the same iteration counts and exit reasons -- with the
+    default parameters (runs ended by the trust region), with long runs (residual rule, iteration cap) and at the
+    first / last agent of a split (a last workgroup of one pose where n is odd)."""
+    import dcora_amd as da
+    for b in sorted({0, R - 1}):
+        d, nb, Q, G, X = _block_problem(da, name, R, b, r)
+        for prm in (da.ROptParameters(), da.ROptParameters(RTR_iterations=8, RTR_tCG_iterations=60, gradnorm_tol=1e-9),
+                    da.ROptParameters(RTR_iterations=4, RTR_tCG_iterations=3)):
+            got = {}
+            for form in ("launch", None):
+                if form:
+                    os.environ["DCORA_SOLVER_TCG"] = form
+                try:
+                    P = da.QuadraticProblem(r, d, nb, Q, G=G)
+                finally:
+                    os.environ.pop("DCORA_SOLVER_TCG", None)
+                want = "two launches" if form else "one launch per run"
+                assert P.solver_info()["tcg"] == want, (name, R, r, b, P.solver_info())
+                opt = da.QuadraticOptimizer(P, prm)
+                Xs = opt.optimize(X)
+                res = opt.getOptResult()
+                got[form] = (Xs, res)
+                assert P.solver_info()["tcg"] == want   # (the run form did not give up)
+                P.close()
+            (Xa, ra), (Xb, rb) = got["launch"], got[None]
+            for key in ("outer_iterations", "inner_iterations", "fOpt", "gradNormOpt", "fInit", "tCGStatus"):
+                assert ra[key] == rb[key], (name, R, r, b, key, ra[key], rb[key])
+            assert ra["inner_iterations"] > 0
+            assert np.array_equal(Xa, Xb), np.abs(Xa - Xb).max()
+
+
+def test_one_launch_tcg_run_that_gives_up_falls_back_to_the_launches(built):
+    """a run whose grid is not co-resident (test hook: workgroup 0 leaves before the first grid step) gives up within
+    milliseconds, everything queued behind it is a no-op, the host repeats the RTR iteration on the launches and drops
+    the form for this problem: same result bit for bit, whichever iteration of the solve the fault hits"""
+    import dcora_amd as da
+    from dcora_amd import capi
+    d, nb, Q, G, X = _block_problem(da, "sphere2500", 5, 2, 5)
+    prm = da.ROptParameters(RTR_iterations=6, RTR_tCG_iterations=40, gradnorm_tol=1e-9)
+    os.environ["DCORA_SOLVER_TCG"] = "launch"
+    try:
+        P = da.QuadraticProblem(5, d, nb, Q, G=G)
+    finally:
+        os.environ.pop("DCORA_SOLVER_TCG", None)
+    opt = da.QuadraticOptimizer(P, prm)
+    Xref, ref = opt.optimize(X), opt.getOptResult()
+    P.close()
+    assert ref["outer_iterations"] >= 4
+    for healthy_runs in (0, 1, 3):
+        P = da.QuadraticProblem(5, d, nb, Q, G=G)
+        assert P.solver_info()["tcg"] == "one launch per run"
+        if healthy_runs:  # let that many runs of the solve pass first: a warm-up solve of `healthy_runs` RTR iterations
+            warm = da.QuadraticOptimizer(P, da.ROptParameters(RTR_iterations=healthy_runs, RTR_tCG_iterations=40,
+                                                               gradnorm_tol=1e-9))
+            warm.optimize(X)
+        assert capi.lib().dcora_debug_tcg_run_fault(1) == 0
+        opt = da.QuadraticOptimizer(P, prm)
+        Xs, res = opt.optimize(X), opt.getOptResult()
+        assert capi.lib().dcora_debug_tcg_run_fault(0) == 0
+        assert P.solver_info()["tcg"] == "two launches"   # dropped for good
+        for key in ("outer_iterations", "inner_iterations", "fOpt", "gradNormOpt", "tCGStatus"):
+            assert ref[key] == res[key], (healthy_runs, key, ref[key], res[key])
+        assert np.array_equal(Xref, Xs)
+        Xs2 = da.QuadraticOptimizer(P, prm).optimize(X)   # and the problem keeps working on the launches
+        assert np.array_equal(Xref, Xs2)
+        P.close()
