@@ -20,6 +20,19 @@
 namespace DCORA {
 
 constexpr unsigned int CENTRALIZED_AGENT_ID = 0;  // ref include/DCORA/DCORA_types.h:42
+constexpr unsigned int MAP_ID = 'M' - 'A';        // ref include/DCORA/DCORA_types.h:43-44: the passive map agent
+// ref include/DCORA/DCORA_types.h:236-308: states are named (robot, frame); one key type per kind of state
+struct LandmarkID : PoseID {
+  LandmarkID() = default;
+  LandmarkID(unsigned robot, unsigned frame) : PoseID(robot, frame) {}
+};
+struct UnitSphereID : PoseID {
+  UnitSphereID() = default;
+  UnitSphereID(unsigned robot, unsigned frame) : PoseID(robot, frame) {}
+};
+using PoseDict = std::map<PoseID, Matrix>;              // lifted pose, r x (d+1)
+using UnitSphereDict = std::map<UnitSphereID, Matrix>;  // lifted point, r x 1
+using LandmarkDict = std::map<LandmarkID, Matrix>;      // lifted point, r x 1
 
 enum class StateType { None, Pose, Landmark, UnitSphere };
 enum class MeasurementType { PosePrior, LandmarkPrior, PosePose, PoseLandmark, Range };
@@ -172,10 +185,43 @@ class RangeAidedArray {
       for (unsigned a = 0; a < d_; ++a) L.data()(a, i) = X_(a, (size_t)(d_ + 1) * n_ + l_ + i);
     return L;
   }
+  // single states (ref include/DCORA/manifold/Elements.h:330-470): pose i as [R_i t_i], points as columns
+  unsigned rows() const { return (unsigned)X_.rows(); }
+  Matrix pose(unsigned i) const {
+    Matrix T(rows(), d_ + 1);
+    for (unsigned a = 0; a < rows(); ++a) {
+      for (unsigned c = 0; c < d_; ++c) T(a, c) = X_(a, (size_t)i * d_ + c);
+      T(a, d_) = X_(a, (size_t)d_ * n_ + l_ + i);
+    }
+    return T;
+  }
+  Matrix unitSphere(unsigned i) const { return column((size_t)d_ * n_ + i); }
+  Matrix landmark(unsigned i) const { return column((size_t)(d_ + 1) * n_ + l_ + i); }
+  void setData(const Matrix &X) {
+    if (X.rows() != X_.rows() || X.cols() != X_.cols()) throw std::invalid_argument("RangeAidedArray::setData: shape");
+    X_ = X;
+  }
+
+ protected:
+  RangeAidedArray(unsigned rows, unsigned d, unsigned n, unsigned l, unsigned b)
+      : d_(d), n_(n), l_(l), b_(b), X_(rows, (size_t)(d + 1) * n + l + b) {}
+  Matrix column(size_t j) const {
+    Matrix v(rows(), 1);
+    for (unsigned a = 0; a < rows(); ++a) v(a, 0) = X_(a, j);
+    return v;
+  }
+
+ public:
 
  private:
   unsigned d_, n_, l_, b_;
   Matrix X_;
+};
+
+// the lifted counterpart (ref include/DCORA/manifold/Elements.h LiftedRangeAidedArray): r x k in the RA ordering
+class LiftedRangeAidedArray : public RangeAidedArray {
+ public:
+  LiftedRangeAidedArray(unsigned r, unsigned d, unsigned n, unsigned l, unsigned b) : RangeAidedArray(r, d, n, l, b) {}
 };
 
 // ref include/DCORA/Measurements.h:650-672, 818-870 (the members the drivers and tests read)
@@ -183,10 +229,19 @@ struct Measurements {
   RelativeMeasurements relative_measurements;
   std::shared_ptr<RangeAidedArray> ground_truth_init;
 };
+using RobotMeasurements = std::map<unsigned int, Measurements>;  // ref include/DCORA/Measurements.h:687
+struct LocalToGlobalStateDicts {                                  // ref include/DCORA/Measurements.h:700-706
+  std::map<PoseID, PoseID> poses;
+  std::map<LandmarkID, LandmarkID> landmarks;
+  std::map<UnitSphereID, UnitSphereID> unit_spheres;
+};
 struct PyFGDataset {
   unsigned int dim = 0;
   std::set<unsigned int> robot_IDs;
   Measurements measurements;  // in the numbering of the merged (centralised) problem
+  // owner robot of every pose / unit sphere / landmark of the merged problem ('A' = 0, ..., MAP_ID the map), as the
+  // reference splits a multi-robot file (ref src/DCORA_utils.cpp:1370-1512, src/Graph.cpp:584-616, 1092-1097)
+  std::vector<unsigned> pose_robot, sphere_robot, landmark_robot;
 };
 
 // ref src/DCORA_utils.cpp:437-1167: the file through the library's reader (dcora_radataset_load_pyfg)
@@ -232,7 +287,89 @@ inline PyFGDataset read_pyfg_file(const std::string &filename) {
   std::vector<int> pr((size_t)n + 1), sr((size_t)l + 1), lr((size_t)b + 1);
   dcora_radataset_ownership(h, pr.data(), sr.data(), lr.data());
   for (int i = 0; i < n; ++i) out.robot_IDs.insert((unsigned)pr[(size_t)i]);
+  out.pose_robot.assign(pr.begin(), pr.begin() + n);
+  out.sphere_robot.assign(sr.begin(), sr.begin() + l);
+  out.landmark_robot.assign(lr.begin(), lr.begin() + b);
+  for (int j = 0; j < b; ++j)
+    if ((unsigned)lr[(size_t)j] == MAP_ID) out.robot_IDs.insert(MAP_ID);  // landmarks without a robot letter: the map's
   dcora_radataset_destroy(h);
+  return out;
+}
+namespace detail {
+// position of state i among the states of its owner (the reference re-indexes every robot's states from zero)
+inline std::vector<unsigned> local_index(const std::vector<unsigned> &owner) {
+  std::map<unsigned, unsigned> next;
+  std::vector<unsigned> loc(owner.size());
+  for (size_t i = 0; i < owner.size(); ++i) loc[i] = next[owner[i]]++;
+  return loc;
+}
+}  // namespace detail
+// ref src/DCORA_utils.cpp:1370-1512: every robot's share of a multi-robot file -- the measurements that touch one of
+// its states, with (robot, local index) names, and its ground truth in ITS RA ordering
+inline RobotMeasurements getRobotMeasurements(const PyFGDataset &ds) {
+  const unsigned d = ds.dim;
+  const RangeAidedArray &gt = *ds.measurements.ground_truth_init;
+  const unsigned n = gt.n(), l = gt.l(), b = gt.b();
+  const std::vector<unsigned> lp = detail::local_index(ds.pose_robot), ls = detail::local_index(ds.sphere_robot),
+                              ll = detail::local_index(ds.landmark_robot);
+  auto owner = [&](StateType t, size_t i) { return t == StateType::Landmark ? ds.landmark_robot[i] : ds.pose_robot[i]; };
+  auto local = [&](StateType t, size_t i) { return t == StateType::Landmark ? ll[i] : lp[i]; };
+  RobotMeasurements out;
+  for (unsigned robot : ds.robot_IDs) {
+    Measurements &M = out[robot];
+    const RelativeMeasurements &rm = ds.measurements.relative_measurements;
+    for (RelativePosePoseMeasurement m : rm.GetRelativePosePoseMeasurements()) {
+      const unsigned o1 = ds.pose_robot[m.p1], o2 = ds.pose_robot[m.p2];
+      if (o1 != robot && o2 != robot) continue;
+      m.r1 = o1, m.r2 = o2, m.p1 = lp[m.p1], m.p2 = lp[m.p2];
+      M.relative_measurements.push_back(m);
+    }
+    for (RelativePoseLandmarkMeasurement m : rm.GetRelativePoseLandmarkMeasurements()) {
+      const unsigned o1 = ds.pose_robot[m.p1], o2 = ds.landmark_robot[m.p2];
+      if (o1 != robot && o2 != robot) continue;
+      m.r1 = o1, m.r2 = o2, m.p1 = lp[m.p1], m.p2 = ll[m.p2];
+      M.relative_measurements.push_back(m);
+    }
+    for (RangeMeasurement m : rm.GetRangeMeasurements()) {
+      const unsigned o1 = owner(m.stateType1, m.p1), o2 = owner(m.stateType2, m.p2);
+      if (o1 != robot && o2 != robot) continue;
+      m.r1 = o1, m.r2 = o2, m.p1 = local(m.stateType1, m.p1), m.p2 = local(m.stateType2, m.p2);
+      m.l = ls[m.l];  // the unit sphere belongs to the source's robot
+      M.relative_measurements.push_back(m);
+    }
+    unsigned na = 0, la = 0, ba = 0;
+    for (unsigned o : ds.pose_robot) na += o == robot;
+    for (unsigned o : ds.sphere_robot) la += o == robot;
+    for (unsigned o : ds.landmark_robot) ba += o == robot;
+    auto g = std::make_shared<RangeAidedArray>(d, na, la, ba);
+    const Matrix &G = gt.getData();
+    for (unsigned a = 0; a < d; ++a) {
+      for (unsigned i = 0; i < n; ++i)
+        if (ds.pose_robot[i] == robot) {
+          for (unsigned c = 0; c < d; ++c) g->data()(a, (size_t)lp[i] * d + c) = G(a, (size_t)i * d + c);
+          g->data()(a, (size_t)d * na + la + lp[i]) = G(a, (size_t)d * n + l + i);
+        }
+      for (unsigned s = 0; s < l; ++s)
+        if (ds.sphere_robot[s] == robot) g->data()(a, (size_t)d * na + ls[s]) = G(a, (size_t)d * n + s);
+      for (unsigned j = 0; j < b; ++j)
+        if (ds.landmark_robot[j] == robot)
+          g->data()(a, (size_t)(d + 1) * na + la + ll[j]) = G(a, (size_t)(d + 1) * n + l + j);
+    }
+    M.ground_truth_init = g;
+  }
+  return out;
+}
+// ref include/DCORA/DCORA_utils.h getLocalToGlobalStateMapping: (robot, local index) -> (CENTRALIZED_AGENT_ID, index in
+// the merged problem), the numbering getGlobalMeasurements uses
+inline LocalToGlobalStateDicts getLocalToGlobalStateMapping(const PyFGDataset &ds, bool /*reindex*/ = true) {
+  const std::vector<unsigned> lp = detail::local_index(ds.pose_robot), ls = detail::local_index(ds.sphere_robot),
+                              ll = detail::local_index(ds.landmark_robot);
+  LocalToGlobalStateDicts out;
+  for (size_t i = 0; i < lp.size(); ++i) out.poses[PoseID(ds.pose_robot[i], lp[i])] = PoseID(CENTRALIZED_AGENT_ID, (unsigned)i);
+  for (size_t i = 0; i < ls.size(); ++i)
+    out.unit_spheres[UnitSphereID(ds.sphere_robot[i], ls[i])] = UnitSphereID(CENTRALIZED_AGENT_ID, (unsigned)i);
+  for (size_t i = 0; i < ll.size(); ++i)
+    out.landmarks[LandmarkID(ds.landmark_robot[i], ll[i])] = LandmarkID(CENTRALIZED_AGENT_ID, (unsigned)i);
   return out;
 }
 // ref src/DCORA_utils.cpp:1169-1365: the reader above already numbers the file as one robot's problem
