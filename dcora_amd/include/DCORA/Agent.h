@@ -13,13 +13,20 @@
 //       ... getX of every agent, central evaluation, greedy selection ...
 //     }
 //
-// Object model.  The agents of one process share one device-resident session (one mirror of the lifted variable, one
-// stream): the Agents constructed with the same AgentParameters find each other through a process-wide registry, and
-// the session is created when the LAST robot of AgentParameters::robotIDs has been initialised -- from the union of the
-// measurements the agents were given, which must follow the driver's contiguous partition (equal pose counts, the last
-// robot takes the remainder; :56-118).  Robots that live in other processes are not this class's business: a rank of a
-// multi-process job creates its session with rank / world_size and exchanges through dcora_exchange_*.
+// Object model (pose graphs).  The agents of one process share one device-resident session (one mirror of the lifted
+// variable, one stream).  Agents that are constructed one by one, as the reference's driver does, meet through a TEAM
+// HANDLE THE CALLER OWNS -- `options.team = DCORA::makeAgentTeam();` once, the same handle in every robot's
+// AgentParameters: one added line, no process-wide state -- and the session is created when the LAST robot of
+// AgentParameters::robotIDs has been initialised, from the union of the measurements the agents were given, which must
+// follow the driver's contiguous partition (equal pose counts, the last robot takes the remainder; :56-118).  A single
+// robot needs no handle.  Robots that live in other processes are not this class's business: a rank of a multi-process
+// job creates its session with rank / world_size and exchanges through dcora_exchange_*.
 // AgentTeam::create(dataset, params) remains as the direct way to the same state.
+//
+// Range-aided graphs (GraphType::RangeAidedSLAMGraph): every Agent is self-contained, as the reference's is
+// (RangeAidedAgent.h) -- its measurements, its iterate in its own RA ordering, its acceleration, its caches of the
+// neighbours' public states; robots talk through the three dictionaries of getSharedStateDicts / updateNeighborStates
+// only.  MAP_ID is the passive map agent (ref src/Agent.cpp:541): one pose holding the lifting matrix, iterate() counts.
 //
 // updateNeighborStates hands poses to ONE agent: from then on that agent optimises against what it was handed (its own
 // plain / auxiliary caches on the device: stale poses are used as given, poses it does not require are ignored, an
@@ -35,8 +42,26 @@
 #include "DCORA_types.h"
 #include "Graph.h"
 #include "QuadraticOptimizer.h"
+#include "RangeAidedAgent.h"
 
 namespace DCORA {
+
+namespace detail {
+struct PendingTeam;
+}
+// the handle through which Agents constructed one by one form their team (pose graphs, several robots in one process)
+using AgentTeamHandle = std::shared_ptr<detail::PendingTeam>;
+inline AgentTeamHandle makeAgentTeam();
+
+// ref include/DCORA/Agent.h:149-200 (the fields the drivers read)
+enum class AgentState { WAIT_FOR_DATA, WAIT_FOR_INITIALIZATION, INITIALIZED };
+struct AgentStatus {
+  unsigned agentID = 0;
+  AgentState state = AgentState::WAIT_FOR_DATA;
+  unsigned instanceNumber = 0, iterationNumber = 0;
+  bool readyToTerminate = false;
+  double relativeChange = 0;
+};
 
 // ref include/DCORA/Agent.h:40-147 (the fields the RBCD loop reads)
 struct AgentParameters {
@@ -50,6 +75,7 @@ struct AgentParameters {
   std::string logDirectory;
   int device = 0;
   GraphType graphType = GraphType::PoseGraph;
+  AgentTeamHandle team;  // pose graphs, several robots: the caller's handle (makeAgentTeam()), the same in every robot's
   AgentParameters(unsigned dIn, unsigned rIn, const std::set<unsigned> &robotIDsIn,
                   GraphType graphTypeIn = GraphType::PoseGraph)
       : d(dIn), r(rIn), robotIDs(robotIDsIn), numRobots((unsigned)robotIDsIn.size()), graphType(graphTypeIn) {}
@@ -57,8 +83,6 @@ struct AgentParameters {
     for (unsigned i = 0; i < numRobotsIn; ++i) robotIDs.insert(i);
   }
 };
-
-using PoseDict = std::map<PoseID, Matrix>;  // a lifted pose is r x (d+1)
 
 class Agent;
 
@@ -105,32 +129,13 @@ class AgentTeam : public std::enable_shared_from_this<AgentTeam> {
 namespace detail {
 // Agents constructed one by one (the reference's shape) meet here until their team is complete
 struct PendingTeam {
-  explicit PendingTeam(const AgentParameters &p) : params(p) {}
-  AgentParameters params;
+  bool have_params = false;
+  AgentParameters params{3, 5, 1u};
   std::map<unsigned, std::vector<RelativePosePoseMeasurement>> odometry, private_lc, shared_lc;
   std::set<unsigned> constructed, initialized;
   std::shared_ptr<AgentTeam> team;
   std::mutex mu;
 };
-struct TeamKey {
-  unsigned d, r;
-  std::set<unsigned> ids;
-  bool accel;
-  bool operator<(const TeamKey &o) const {
-    if (d != o.d) return d < o.d;
-    if (r != o.r) return r < o.r;
-    if (accel != o.accel) return accel < o.accel;
-    return ids < o.ids;
-  }
-};
-inline std::map<TeamKey, std::weak_ptr<PendingTeam>> &team_registry() {
-  static std::map<TeamKey, std::weak_ptr<PendingTeam>> reg;
-  return reg;
-}
-inline std::mutex &team_registry_mutex() {
-  static std::mutex mu;
-  return mu;
-}
 }  // namespace detail
 
 class Agent {
@@ -142,36 +147,46 @@ class Agent {
   Agent(unsigned ID, const AgentParameters &params) : mID(ID), params_(params) {
     if (!params.robotIDs.count(ID)) throw std::invalid_argument("Agent: ID is not in AgentParameters::robotIDs");
     if (params.graphType == GraphType::RangeAidedSLAMGraph) {
-      // An agent on a range-aided graph that holds ALL measurements of its states: the centralised agent of the
-      // reference's CORA flow and tests (ref tests/testAgent.cpp:157-242, examples/SingleRobotExample_RASLAM.cpp).  It
-      // owns its Graph, problem and iterate; the robots of a multi-robot range-aided job share a device-resident
-      // session instead (dcora_ra_rbcd_*).
-      if (params.robotIDs.size() != 1)
-        throw std::invalid_argument("Agent: several robots on a RangeAidedSLAMGraph share a session (dcora_ra_rbcd_*)");
-      ra_ = std::make_shared<RangeAidedState>();
-      ra_->graph = std::make_shared<Graph>(ID, params.r, params.d, GraphType::RangeAidedSLAMGraph);
+      if (ID == MAP_ID) {  // the passive map agent: one pose that holds the lifting matrix (ref src/Agent.cpp:541)
+        map_agent_ = true;
+        return;
+      }
+      ra_ = std::make_shared<detail::RangeAidedAgentCore>(ID, params.d, params.r, params.numRobots, params.acceleration,
+                                                          params.restartInterval, params.localOptimizationParams,
+                                                          params.device);
       return;
     }
-    std::lock_guard<std::mutex> lk(detail::team_registry_mutex());
-    const detail::TeamKey key{params.d, params.r, params.robotIDs, params.acceleration};
-    std::shared_ptr<detail::PendingTeam> p = detail::team_registry()[key].lock();
-    if (!p || p->constructed.count(ID)) {  // none yet, or that team already has this robot: a new generation
-      p = std::make_shared<detail::PendingTeam>(params);
-      detail::team_registry()[key] = p;
+    std::shared_ptr<detail::PendingTeam> p = params.team;
+    if (!p) {
+      if (params.robotIDs.size() != 1)
+        throw std::invalid_argument(
+            "Agent: the robots of a pose graph that live in one process form their team through a handle the caller "
+            "owns: `options.team = DCORA::makeAgentTeam();` once, the same handle in every robot's AgentParameters");
+      p = makeAgentTeam();
     }
-    p->constructed.insert(ID);
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (!p->have_params) {
+      p->params = params;
+      p->params.team.reset();  // (the team does not keep itself alive)
+      p->have_params = true;
+    } else if (p->params.d != params.d || p->params.r != params.r || p->params.robotIDs != params.robotIDs ||
+               p->params.acceleration != params.acceleration) {
+      throw std::invalid_argument("Agent: the robots of one team must be constructed with the same d, r, robotIDs, acceleration");
+    }
+    if (!p->constructed.insert(ID).second) throw std::invalid_argument("Agent: this team already has that robot");
     pending_ = p;
   }
   unsigned getID() const { return mID; }
   unsigned relaxation_rank() const { return params_.r; }
   unsigned dimension() const { return params_.d; }
-  unsigned num_poses() const { return ra_ ? ra_->graph->n() : info().first; }
-  unsigned num_unit_spheres() const { return ra_ ? ra_->graph->l() : 0; }
-  unsigned num_landmarks() const { return ra_ ? ra_->graph->b() : 0; }
+  unsigned num_poses() const { return map_agent_ ? 1 : ra_ ? ra_->n() : info().first; }
+  unsigned num_unit_spheres() const { return ra_ ? ra_->l() : 0; }
+  unsigned num_landmarks() const { return ra_ ? ra_->b() : 0; }
   unsigned problem_dimension() const { return (dimension() + 1) * num_poses() + num_unit_spheres() + num_landmarks(); }
   unsigned instance_number() const { return 0; }
   unsigned iteration_number() const {
-    if (ra_) return ra_->iterations;
+    if (map_agent_) return map_iterations_;
+    if (ra_) return ra_->iterations();
     int it = 0;
     check_status(dcora_rbcd_agent_info(session(), (int)mID, nullptr, nullptr, &it), "iteration_number");
     return (unsigned)it;
@@ -190,8 +205,7 @@ class Agent {
   // ref include/DCORA/Agent.h:286-292: all relative measurements of a range-aided graph
   void setMeasurements(const RelativeMeasurements &measurements) {
     if (!ra_) throw std::logic_error("Agent::setMeasurements(RelativeMeasurements): the agent is on a pose graph");
-    ra_->graph->setMeasurements(measurements);
-    ra_->problem.reset();
+    ra_->setMeasurements(measurements);
   }
   // ref include/DCORA/Agent.h:315-330, src/Agent.cpp:396-458: the start point from an estimate of the states in the
   // robot's frame (the tests hand over the ground truth), lifted by the shared YLift
@@ -215,19 +229,19 @@ class Agent {
     check_status(dcora_fixed_stiefel_variable((int)r, (int)d, YLift.data()), "Agent::initialize");
     for (unsigned a = 0; a < d; ++a) Tid(a, a) = 1.0;
     dcora_dims dims{(int)r, (int)d, (int)n, (int)l, (int)b, DCORA_LAYOUT_RA};
-    ra_->X = Matrix(r, problem_dimension());
-    check_status(dcora_agent_initialize_in_global_frame(&dims, Tid.data(), local.data(), YLift.data(), ra_->X.data()),
+    Matrix X0(r, problem_dimension());
+    check_status(dcora_agent_initialize_in_global_frame(&dims, Tid.data(), local.data(), YLift.data(), X0.data()),
                  "Agent::initialize");
-    ra_->iterations = 0;
+    ra_->setX(X0);
   }
   // ref src/Agent.cpp:950-1034: the estimate rounded to SE(d)^n x (S^{d-1})^l x R^{d b} in the frame of the first pose
   bool getStatesInLocalFrame(Matrix *Trajectory, Matrix *UnitSpheres, Matrix *Landmarks) {
     if (!ra_) throw std::logic_error("Agent::getStatesInLocalFrame(3): the agent is on a pose graph");
-    if (ra_->X.rows() == 0) return false;
+    if (!ra_->initialized()) return false;
     const unsigned d = dimension(), n = num_poses(), l = num_unit_spheres(), b = num_landmarks();
     dcora_dims dims{(int)relaxation_rank(), (int)d, (int)n, (int)l, (int)b, DCORA_LAYOUT_RA};
     Matrix T(d, (size_t)(d + 1) * n), S(d, l), L(d, b);
-    check_status(dcora_round_align_trajectory(&dims, ra_->X.data(), nullptr, 0, T.data(), l ? S.data() : nullptr,
+    check_status(dcora_round_align_trajectory(&dims, ra_->X().data(), nullptr, 0, T.data(), l ? S.data() : nullptr,
                                               b ? L.data() : nullptr, params_.device),
                  "getStatesInLocalFrame");
     if (Trajectory) *Trajectory = T;
@@ -237,16 +251,19 @@ class Agent {
   }
   // ref src/Agent.cpp:598-648: back to the state before setMeasurements
   void reset() {
+    if (map_agent_) {
+      map_iterations_ = 0;
+      return;
+    }
     if (!ra_) return;
-    ra_->graph = std::make_shared<Graph>(mID, params_.r, params_.d, GraphType::RangeAidedSLAMGraph);
-    ra_->problem.reset();
-    ra_->X = Matrix();
-    ra_->iterations = 0;
+    ra_ = std::make_shared<detail::RangeAidedAgentCore>(mID, params_.d, params_.r, params_.numRobots, params_.acceleration,
+                                                        params_.restartInterval, params_.localOptimizationParams,
+                                                        params_.device);
   }
   // ref include/DCORA/Agent.h:315 (the trajectory / frame arguments of the reference's initialisation do not apply: the
   // driver sets X itself, :208-217).  The last robot to arrive forms the team.
   void initialize() {
-    if (!pending_) return;
+    if (!pending_) return;  // (range-aided agents and the map: nothing to do, the driver sets X itself)
     std::lock_guard<std::mutex> lk(pending_->mu);
     pending_->initialized.insert(mID);
     if (!pending_->team && pending_->initialized == pending_->params.robotIDs) form_team(*pending_);
@@ -270,19 +287,28 @@ class Agent {
   }
   // ref src/Agent.cpp:64-77 (also re-initialises the acceleration, :1178-1187)
   void setX(const Matrix &Xin) {
+    if (map_agent_) throw std::logic_error("Agent::setX: the map agent holds the lifting matrix");
     if (Xin.rows() != relaxation_rank() || Xin.cols() != problem_dimension())
       throw std::invalid_argument("Agent::setX: expected r x (d+1) n");
     if (ra_) {
-      ra_->X = Xin;
+      ra_->setX(Xin);
       return;
     }
     check_status(dcora_rbcd_agent_set_X(session(), (int)mID, Xin.data()), "setX");
   }
   // ref src/Agent.cpp:98-105
   bool getX(Matrix *Mout) {
+    if (map_agent_) {  // [YLift 0]: the fixed global frame, rotated by the lifting matrix
+      Matrix Y;
+      getLiftingMatrix(&Y);
+      *Mout = Matrix(relaxation_rank(), dimension() + 1);
+      for (unsigned c = 0; c < dimension(); ++c)
+        for (unsigned a = 0; a < relaxation_rank(); ++a) (*Mout)(a, c) = Y(a, c);
+      return true;
+    }
     if (ra_) {
-      *Mout = ra_->X;
-      return ra_->X.rows() != 0;
+      *Mout = ra_->X();
+      return ra_->initialized();
     }
     *Mout = Matrix(relaxation_rank(), problem_dimension());
     return dcora_rbcd_agent_get_X(session(), (int)mID, Mout->data()) == DCORA_OK;
@@ -290,23 +316,32 @@ class Agent {
   // ref src/Agent.cpp:535-596; false when the optimisation was skipped because a required neighbour pose has never
   // been handed over (ref :1243-1249)
   bool iterate(bool doOptimization = true) {
-    if (ra_) {
-      // no neighbours: updateX is one QuadraticOptimizer::optimize of the agent's own problem from X (ref :1216-1278)
-      if (ra_->X.rows() == 0) return false;
-      ++ra_->iterations;
-      if (!doOptimization) return true;
-      if (!ra_->problem) ra_->problem = std::make_shared<QuadraticProblem>(ra_->graph, true, params_.device);
-      QuadraticOptimizer opt(ra_->problem.get(), params_.localOptimizationParams);
-      ra_->X = opt.optimize(ra_->X);
+    if (map_agent_) {  // passive: the iteration counter advances, nothing else (ref src/Agent.cpp:535-541)
+      ++map_iterations_;
       return true;
     }
+    if (ra_) return ra_->iterate(doOptimization);
     check_status(dcora_rbcd_agent_iterate(session(), (int)mID, doOptimization ? 1 : 0), "iterate");
     int skipped = 0;
     check_status(dcora_rbcd_agent_last_skipped(session(), (int)mID, &skipped), "iterate");
     return !(doOptimization && skipped);
   }
   // ref src/Agent.cpp:113-152: my public poses (those with an inter-robot measurement), keyed (robot, local frame)
-  bool getSharedStateDicts(PoseDict *poseDict) {
+  bool getSharedStateDicts(PoseDict *poseDict, UnitSphereDict *unitSphereDict = nullptr,
+                           LandmarkDict *landmarkDict = nullptr) {
+    if (map_agent_) {  // the map shares nothing
+      poseDict->clear();
+      if (unitSphereDict) unitSphereDict->clear();
+      if (landmarkDict) landmarkDict->clear();
+      return true;
+    }
+    if (ra_) {
+      if (!ra_->initialized()) return false;
+      ra_->sharedStates(poseDict, unitSphereDict, landmarkDict);
+      return true;
+    }
+    if (unitSphereDict || landmarkDict)
+      throw std::invalid_argument("getSharedStateDicts: a pose graph has neither unit spheres nor landmarks");
     int cnt = 0;
     check_status(dcora_rbcd_public_count(session(), (int)mID, &cnt), "getSharedStateDicts");
     std::vector<int> idx((size_t)(cnt > 0 ? cnt : 1));
@@ -326,8 +361,17 @@ class Agent {
   }
   // ref src/Agent.cpp:844-906: the poses go into this agent's own cache on the device (the plain one, or the auxiliary
   // one it reads when it optimises from Y); the reference's CHECKs on the robot id and the shapes throw here
-  void updateNeighborStates(unsigned neighborID, const PoseDict &poseDict, bool areNeighborStatesAux = false) {
+  void updateNeighborStates(unsigned neighborID, const PoseDict &poseDict, bool areNeighborStatesAux = false,
+                            const UnitSphereDict &unitSphereDict = UnitSphereDict(),
+                            const LandmarkDict &landmarkDict = LandmarkDict()) {
     if (neighborID == mID) throw std::invalid_argument("updateNeighborStates: neighborID is this agent");
+    if (map_agent_) return;
+    if (ra_) {
+      ra_->updateNeighborStates(neighborID, poseDict, areNeighborStatesAux, unitSphereDict, landmarkDict);
+      return;
+    }
+    if (!unitSphereDict.empty() || !landmarkDict.empty())
+      throw std::invalid_argument("updateNeighborStates: a pose graph has neither unit spheres nor landmarks");
     if (poseDict.empty()) return;
     const unsigned r = relaxation_rank(), dh = dimension() + 1;
     std::vector<int> frames;
@@ -345,6 +389,15 @@ class Agent {
                                                   frames.data(), poses.data(), areNeighborStatesAux ? 1 : 0),
                  "updateNeighborStates");
   }
+  // ref include/DCORA/Agent.h:380-400: what the drivers pass around with the dictionaries
+  AgentStatus getStatus() {
+    AgentStatus st;
+    st.agentID = mID;
+    st.state = (map_agent_ || !ra_ || ra_->initialized()) ? AgentState::INITIALIZED : AgentState::WAIT_FOR_INITIALIZATION;
+    st.iterationNumber = iteration_number();
+    return st;
+  }
+  void setNeighborStatus(const AgentStatus &status) { neighbor_status_[status.agentID] = status; }
   // ref src/Agent.cpp:535 getSharedPose(index): pose `index` of this agent, r x (d+1)
   bool getSharedPose(unsigned index, Matrix *Mout) {
     Matrix X;
@@ -444,13 +497,10 @@ class Agent {
     p.team = t;
   }
 
-  struct RangeAidedState {  // the centralised agent of a range-aided graph
-    std::shared_ptr<Graph> graph;
-    std::shared_ptr<QuadraticProblem> problem;  // kept over the iterations: Q and its preconditioner do not change
-    Matrix X;
-    unsigned iterations = 0;
-  };
-  std::shared_ptr<RangeAidedState> ra_;
+  std::shared_ptr<detail::RangeAidedAgentCore> ra_;  // an agent on a range-aided graph (RangeAidedAgent.h)
+  bool map_agent_ = false;
+  unsigned map_iterations_ = 0;
+  std::map<unsigned, AgentStatus> neighbor_status_;
   unsigned mID;
   AgentParameters params_;
   mutable unsigned n_ = 0, first_pose_ = 0;
@@ -459,6 +509,8 @@ class Agent {
   std::shared_ptr<detail::PendingTeam> pending_;
   Matrix lifting_;
 };
+
+inline AgentTeamHandle makeAgentTeam() { return std::make_shared<detail::PendingTeam>(); }
 
 inline void AgentTeam::build_agents() {
   for (unsigned id = 0; id < params_.numRobots; ++id) agents.push_back(std::make_shared<Agent>(id, shared_from_this()));

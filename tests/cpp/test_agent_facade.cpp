@@ -164,8 +164,10 @@ int main(int argc, char **argv) {
   // ---- B: the driver's construction lines (:184-217) ----
   Trace trB;
   std::vector<DCORA::Agent *> agents;
+  const DCORA::AgentTeamHandle handle = DCORA::makeAgentTeam();  // the one line the facade adds: no process-wide registry
   for (unsigned robot = 0; robot < num_robots; ++robot) {
     DCORA::AgentParameters options(d, r, robot_IDs);
+    options.team = handle;
     options.acceleration = true;
     options.verbose = false;
     auto *agent = new DCORA::Agent(robot, options);

@@ -125,6 +125,19 @@ def test_cpp_range_aided_agent_facade(built):
 
 
 @pytest.mark.gpu
+def test_cpp_multi_robot_range_aided_agents_and_the_map_agent(built):
+    """the reference's testAgentMapRA and testAgentMultiAgentRA (ref tests/testAgent.cpp:244-456) through the facade at
+    the reference's 1e-9: every robot of a multi-robot pyfg file as its own Agent on a RangeAidedSLAMGraph (three-dictionary
+    getSharedStateDicts / updateNeighborStates, plain and auxiliary), one accelerated RBCD round per robot from the ground
+    truth, and the passive map agent"""
+    exe = os.path.join(common.HERE, "cpp", "_build", "test_ra_multiagent_facade")
+    assert os.path.exists(exe), "build() compiles tests/cpp/test_ra_multiagent_facade.cpp"
+    files = [common.plain_path("range_aided_slam_test_2d", ext="pyfg"), common.plain_path("range_aided_slam_test_3d", ext="pyfg")]
+    p = subprocess.run([exe] + files, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name,rank", [("smallGrid3D", 3), ("sphere2500", 5)])
 def test_cpp_staircase_driver_matches_the_python_driver(built, tmp_path, name, rank):
     """dcora_amd/examples/MultiRobotExample.cpp -- the reference's driver with the Riemannian staircase, as a C++
