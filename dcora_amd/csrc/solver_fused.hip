@@ -1469,7 +1469,20 @@ struct TcgRunArgs {
   HostFlags *hf;
   int seq, pbA;    // pbA: poses per workgroup of k_fused_hess at this r (the tree its <delta, H delta> partials follow)
   int fault;       // test hook (dcora_debug_tcg_run_fault): workgroup 0 leaves before the first grid step
+#ifdef DCORA_RUN_STAMPS
+  long long *stamps;  // profiling build only: wall_clock64 of workgroup 0 at the phase boundaries of a run
+#endif
 };
+#ifdef DCORA_RUN_STAMPS
+#define RUN_STAMP(i)                                                            \
+  do {                                                                          \
+    if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0 && (i) < 64) a.stamps[(i)] = wall_clock64(); \
+  } while (0)
+#else
+#define RUN_STAMP(i) \
+  do {                \
+  } while (0)
+#endif
 __device__ __forceinline__ double ld_coh(const double *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -1534,6 +1547,7 @@ __global__ __launch_bounds__(kPcBlock) void k_tcg_run(TcgRunArgs a) {
   __shared__ int s_ok;
   SolverCtl *ctl = a.ctl;
   const int seq = a.seq;
+  RUN_STAMP(0);
   const int st_o = ctl->outer_done_stamp, cur = ctl->cur & 1;
   if (seq > st_o) return;  // the RTR loop has ended: no-op (uniform over the grid)
   const double c_Delta = ctl->Delta, c_ngf = ctl->ngf;
@@ -1725,8 +1739,10 @@ __global__ __launch_bounds__(kPcBlock) void k_tcg_run(TcgRunArgs a) {
   for (long i = 2L * npair + threadIdx.x; i < (long)cpad * r; i += kPcBlock) s_res[i] = 0.0;
   if (own) s_R[lc * RM + t] = o_r;
   __syncthreads();
+  RUN_STAMP(1);
   product();
   project_z();
+  RUN_STAMP(2);
   if (c_max_inner <= 0) {  // (no inner iterations allowed: the launch form leaves eta = 0 behind as well)
     status = 4;
     finish();
@@ -1734,6 +1750,7 @@ __global__ __launch_bounds__(kPcBlock) void k_tcg_run(TcgRunArgs a) {
   }
   if (a.fault && blockIdx.x == 0) return;  // (test hook: the others wait in vain, give up after 2 ms and say so)
   if (!run_grid_step(a.sync, gstep++, &s_ok)) return give_up();
+  RUN_STAMP(3);
   // ---- the iterations ----
   for (int iter = 0;; ++iter) {
     const int par = iter & 1;
@@ -1741,6 +1758,22 @@ __global__ __launch_bounds__(kPcBlock) void k_tcg_run(TcgRunArgs a) {
     const double *__restrict__ d_old = par ? a.d0 : a.d1;
     // ======== A: delta = beta delta - z in the gather, H delta = Proj_X(delta Q - delta S), <delta, H delta> ========
     {
+      // the gather's loads first (their addresses do not depend on beta): one round trip through the coherent level for
+      // up to kRunGB entries of a matrix row, beside the partials' -- in chunks of 8 behind the partials' sum an
+      // iteration paid three to four dependent round trips here
+      constexpr int kRunGB = 24;
+      double ga[kRunGB], gz[kRunGB];
+      double z_own = 0;
+      if (own) {
+        z_own = ld_coh(a.z + oown);
+#pragma unroll
+        for (int q = 0; q < kRunGB; ++q) {
+          const bool ok = myb + q < mye;
+          const size_t oo = ok ? (size_t)s_ci[myb + q] * r + t : 0;
+          gz[q] = ld_coh(a.z + oo);
+          ga[q] = (iter > 0) ? ld_coh(d_old + oo) : 0.0;
+        }
+      }
       const int np3 = gridDim.x;
       const int l = lane;
       const double pa = (l < np3) ? ld_coh(a.p3 + l) : 0.0, pb = (l + 64 < np3) ? ld_coh(a.p3 + l + 64) : 0.0;
@@ -1762,8 +1795,12 @@ __global__ __launch_bounds__(kPcBlock) void k_tcg_run(TcgRunArgs a) {
       }
       double accw = 0, dn = 0;
       if (own) {
-        const double z_own = ld_coh(a.z + oown);
-        for (int p = myb; p < mye; p += 8) {
+#pragma unroll
+        for (int q = 0; q < kRunGB; ++q) {
+          const double w = (myb + q < mye) ? s_v[myb + q] : 0.0;  // (the weights come from LDS when they are used)
+          accw += w * (beta * ga[q] - gz[q]);
+        }
+        for (int p = myb + kRunGB; p < mye; p += 8) {
           double a8[8], b8[8], w8[8];
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
@@ -1808,7 +1845,9 @@ __global__ __launch_bounds__(kPcBlock) void k_tcg_run(TcgRunArgs a) {
       __syncthreads();
       if (own) o_h = s_H[e];
     }
+    RUN_STAMP(4 + 7 * iter);
     if (!run_grid_step(a.sync, gstep++, &s_ok)) return give_up();
+    RUN_STAMP(5 + 7 * iter);
     // ======== PC: step length, updates, z = Proj_X(res Minv), stopping rules ========
     double2 xh[kPcSB];
 #pragma unroll
@@ -1860,6 +1899,7 @@ __global__ __launch_bounds__(kPcBlock) void k_tcg_run(TcgRunArgs a) {
       o_r = rr;
       s_R[lc * RM + t] = rr;
     }
+    RUN_STAMP(6 + 7 * iter);
     nrm2 = 0;
 #pragma unroll
     for (int u = 0; u < kPcSB; ++u) {
@@ -1874,7 +1914,9 @@ __global__ __launch_bounds__(kPcBlock) void k_tcg_run(TcgRunArgs a) {
       }
     }
     __syncthreads();
+    RUN_STAMP(7 + 7 * iter);
     product();
+    RUN_STAMP(8 + 7 * iter);
     {
       const double nr = sqrt(s_Z[NR * RM]);
       const double kappa = 0.1, tempnum = n0;  // theta = 1
@@ -1891,7 +1933,9 @@ __global__ __launch_bounds__(kPcBlock) void k_tcg_run(TcgRunArgs a) {
       finish();
       return;
     }
+    RUN_STAMP(9 + 7 * iter);
     if (!run_grid_step(a.sync, gstep++, &s_ok)) return give_up();
+    RUN_STAMP(10 + 7 * iter);
   }
 }
 
@@ -2717,6 +2761,31 @@ int launch_tcg_run(hipStream_t st, const ManiDesc &m, int ldm, const double *Min
     }
   TcgRunArgs a{m, ldm, Minv, Q, grad, X, S, d0, d1, Hd, eta, Heta, z, p1r, p3, pC, sync, ctl, hf, seq,
                fused_pb(m.r, m.d + 1), fault};
+#ifdef DCORA_RUN_STAMPS
+  {
+    static long long *buf = nullptr;
+    if (!buf) (void)hipHostMalloc((void **)&buf, 64 * sizeof(long long), hipHostMallocMapped);
+    static int count = 0;
+    if (buf && count > 0) {  // the stamps of the run before (the stream is in order; racy by a run at most: a profile)
+      static double acc[64];
+      static int n = 0;
+      long long s0 = buf[0];
+      if (buf[3] > s0 && buf[5 + 7 * 3] > 0) {
+        for (int i = 0; i < 40; ++i) acc[i] += (double)(buf[i] - s0) * 0.01;
+        ++n;
+      }
+      for (int i = 0; i < 64; ++i) buf[i] = 0;
+      if (n == 500) {
+        fprintf(stderr, "k_tcg_run stamps (us from start, workgroup 0, mean of %d runs with >= 4 iterations):", n);
+        for (int i = 0; i < 34; ++i) fprintf(stderr, " %.2f", acc[i] / n);
+        fprintf(stderr, "\n");
+        n = -1000000;
+      }
+    }
+    ++count;
+    a.stamps = buf;
+  }
+#endif
   if (m.r == 4) return tcg_run_launch<4>(st, a);
   if (m.r == 5) return tcg_run_launch<5>(st, a);
   if (m.r == 6) return tcg_run_launch<6>(st, a);
