@@ -808,14 +808,14 @@ def committed_profile(nbytes):
     passes): NOT measured in this run, reported under their own key with their source"""
     import csv
     out = {"note": "read from committed rocprofv3 summaries, not measured in this run"}
-    for tag in ("r04", "r03", "r02", "r01"):
+    for tag in ("r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_kernel_stats_headline_loop.csv" % tag)
         if not os.path.exists(path):
             continue
         try:
             with open(path) as fh:
                 for row in csv.DictReader(fh):
-                    if "k_fused_pc" in row["Name"] or "k_fused_precond" in row["Name"]:
+                    if "k_tcg_run" in row["Name"] or "k_fused_pc" in row["Name"] or "k_fused_precond" in row["Name"]:
                         us = float(row["AverageNs"]) / 1e3
                         out["in_loop"] = {"avg_launch_us_all_launches": us, "launches": int(row["Calls"]),
                                           "min_us": float(row["MinNs"]) / 1e3,
@@ -826,13 +826,15 @@ def committed_profile(nbytes):
         except Exception:
             pass
         break
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json",
+                 "pmc_traffic.json"):
         pmc = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
                 out["traffic_bytes_per_launch"] = j.get("k_fused_pc_bytes_per_launch",
                                                          j.get("k_fused_precond_bytes_per_launch"))
+                out["traffic_bytes_per_launch_tcg_run"] = j.get("k_tcg_run_bytes_per_launch")
                 out["traffic_source"] = "profiles/" + name
             except Exception:
                 pass
@@ -874,7 +876,56 @@ def qapply_entry(P, ms, nbytes, extra=None):
     return e
 
 
-def roofline(da, ds, r, robots):
+def tcg_run_roofline(da, ds, r, robots, warmup, steps, sec8d_precond, nnz_block, kb):
+    """The dominant kernel of the timed loop since round 5: k_tcg_run, ONE launch per tCG run of an RTR iteration (z0 = P
+    grad, then Hessian product + step + dense preconditioner + projection per iteration, the retraction at the end).
+    Measured live: the timed window is replayed with HIP events recorded on the solver's stream around every launch
+    (dcora_rbcd_profile_tcg_runs); the tCG iterations inside the launches come from the solver's own statistics.
+    Algorithmic bytes per launch, SURVEY 8(d): iterations x bytes_tCG + one more preconditioner application (z0), with
+    bytes_tCG = bytes_QX + bytes_precond + 10 r k 8, bytes_QX = 12 nnz + 4 (k + 1) + 16 r k, bytes_precond =
+    2 nnz(L) 12 + 2 r k 8 (a sparse-factor solve)."""
+    X0 = initial_point(da, ds, r)
+    s = da.RbcdSession(ds, num_robots=robots, r=r)
+    try:
+        s.set_X(X0)
+        out = s.run(max_iters=warmup, rgrad_tol=0.0)
+        selected = int(out["selected"][-1]) if warmup > 0 else 0
+        selected = s.iterate(selected)[3]
+        s.profile_tcg_runs(True)
+        s.profile_tcg_read()
+        tcg = outer = 0
+        for _ in range(steps):
+            selected = s.iterate(selected)[3]
+            res = s.last_result()
+            tcg += int(res["inner_iterations"])
+            outer += int(res["outer_iterations"])
+        prof = s.profile_tcg_read()
+        s.profile_tcg_runs(False)
+    finally:
+        s.close()
+    if prof["launches"] < 1:
+        return None
+    rk8 = 8.0 * r * kb
+    bytes_qx = 12.0 * nnz_block + 4.0 * (kb + 1) + 2.0 * rk8
+    bytes_tcg = bytes_qx + sec8d_precond + 10.0 * rk8
+    it_per = tcg / prof["launches"]
+    alg = it_per * bytes_tcg + sec8d_precond + 3.0 * rk8
+    us = prof["total_us"] / prof["launches"]
+    wgs = (kb // (ds.d + 1) + 1) // 2
+    streamed = 8.0 * kb * kb + it_per * (wgs * rk8 + 6.0 * rk8) + 4.0 * rk8
+    ach = alg / (us * 1e-6) / 1e9
+    return {"kernel": "k_tcg_run (ONE launch per tCG run: z0 = P grad, then per iteration Hessian product, step, dense "
+                      "preconditioner and projection, the retraction at the end; %d workgroups, grid-wide steps inside), "
+                      "one agent, k=%d" % (wgs, kb),
+            "achieved": ach, "frac": ach / HBM_PEAK_GBPS, "avg_launch_us": us, "launches_timed": prof["launches"],
+            "tcg_iterations_per_launch": it_per, "rtr_outer_iterations": outer, "rbcd_iterations_replayed": steps,
+            "algorithmic_bytes_per_launch": alg, "algorithmic_bytes_per_tcg_iteration": bytes_tcg,
+            "bytes_streamed_per_launch": streamed, "frac_streamed": streamed / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+            "measured": "HIP events on the solver's stream around each of the %d k_tcg_run launches of a replay of the "
+                        "timed window (%d RBCD iterations), in this run" % (prof["launches"], steps)}
+
+
+def roofline(da, ds, r, robots, warmup=30, steps=100):
     """HIP-event timing, live in this run, of the kernels that carry the bytes of the loop, each on its own stream:
     - the dominant kernel of the timed loop: k_fused_pc (step, vector updates, the dense (Q_bb + 0.1 I)^-1 product and
       the projection of one tCG iteration of one agent in one launch);
@@ -919,13 +970,51 @@ def roofline(da, ds, r, robots):
             "measured": "HIP events on the solver's stream around 300 back-to-back launches of the kernel in its "
                         "in-loop form, in this run"}
     main["from_committed_profile"] = committed_profile(nbytes)
-    tb = main["from_committed_profile"].get("traffic_bytes_per_launch")
+    run_form = False
+    try:
+        run_form = Pb.solver_info()["tcg"] == "one launch per run"
+    except Exception:
+        pass
+    if run_form:
+        # the loop's dominant kernel is the one-launch tCG run; the two-launch form's PC kernel stays as a side entry
+        out["k_fused_pc_launch_form"] = {"kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                         "frac": ach / HBM_PEAK_GBPS, "avg_launch_us": ms * 1e3,
+                                         "note": "the launch per tCG iteration the coloured mode and the fall-back use"}
+        try:
+            tr = tcg_run_roofline(da, ds, r, robots, warmup, steps, 2.0 * pinfo["nnzL"] * 12 + 2.0 * r * kb * 8,
+                                  Pb.qapply_info()["nnz"], kb)
+        except Exception as e:  # noqa: BLE001
+            tr = None
+            main["tcg_run_error"] = str(e)
+        if tr:
+            for key in ("kernel", "achieved", "frac", "avg_launch_us", "algorithmic_bytes_per_launch", "frac_streamed",
+                        "measured"):
+                main[key] = tr[key]
+            main["frac_algorithmic"] = tr["frac"]
+            main["bytes_per_launch"] = tr["bytes_streamed_per_launch"]
+            main["achieved_streamed"] = tr["bytes_streamed_per_launch"] / (tr["avg_launch_us"] * 1e-6) / 1e9
+            main["tcg_run"] = tr
+            main["frac_note"] = ("`achieved` / `frac`: SURVEY 8(d)'s algorithmic bytes of the tCG iterations inside a launch "
+                                 "(Q-apply + sparse-factor preconditioner + 10 vector passes each) over the launch's HIP-event "
+                                 "time; `frac_streamed`: what the kernel moves by design (its rows of the dense inverse once "
+                                 "per run, H delta gathered by every workgroup per iteration); the loop is latency-bound at "
+                                 "k = 2000")
+            main["bytes_counted"] = ("streamed: 8 k^2 once per launch + per iteration (workgroups + 6) r k 8; "
+                                     "see tcg_run for the split")
+            main["survey_8d"] = {"formula": "iterations x (bytes_QX + bytes_precond + 10 r k 8) + bytes_precond + 3 r k 8",
+                                 "nnz_L": pinfo["nnzL"], "tcg_iterations_per_launch": tr["tcg_iterations_per_launch"]}
+            main["compact_note"] = ("k_tcg_run: SURVEY 8(d) bytes of the %.1f tCG iterations per launch / live HIP-event time; "
+                                    "frac_streamed = bytes moved by design; latency-bound at k=2000"
+                                    % tr["tcg_iterations_per_launch"])
+    tb = main["from_committed_profile"].get("traffic_bytes_per_launch_tcg_run") if run_form else \
+        main["from_committed_profile"].get("traffic_bytes_per_launch")
     if tb:
         main["traffic"] = tb
         main["traffic_note"] = ("HBM-side bytes per launch of this kernel from the committed rocprofv3 PMC passes (%s; "
                                 "FETCH_SIZE doubled per MI355X_MICROARCH.md + WRITE_SIZE), not collected in this run; "
                                 "%.1f x the algorithmic bytes: the dense inverse is streamed on purpose"
-                                % (main["from_committed_profile"].get("traffic_source"), tb / sec8d))
+                                % (main["from_committed_profile"].get("traffic_source"),
+                                   tb / main["algorithmic_bytes_per_launch"]))
     else:
         main["traffic_note"] = "no committed PMC pass found under profiles/"
     Pb.close()
@@ -1755,7 +1844,8 @@ def main():
         line["scaling_100k_lattice"] = scaling_block(1, line["strong_scaling"], None, None)
         emit(real_stdout, line)
         return
-    line["roofline"], line["roofline_qapply"] = roofline(da, ds, args.rank_r, args.robots)
+    line["roofline"], line["roofline_qapply"] = roofline(da, ds, args.rank_r, args.robots, args.warmup,
+                                                         min(args.steps, 100))
     if world == 1 and not multi:
         try:
             line["ms_to_certified_optimum"] = certified_run(args, da, torch, ds, not args.no_cpu_baseline)

@@ -608,6 +608,15 @@ class RbcdSession:
     def synchronize(self):
         check(capi.lib().dcora_rbcd_synchronize(self.h))
 
+    def profile_tcg_runs(self, enable=True):
+        """HIP events around every one-launch tCG run (k_tcg_run) of the agents while enabled (a measurement hook)"""
+        check(capi.lib().dcora_rbcd_profile_tcg_runs(self.h, int(enable)))
+
+    def profile_tcg_read(self):
+        out = np.zeros(2)
+        check(capi.lib().dcora_rbcd_profile_tcg_read(self.h, out))
+        return {"launches": int(out[0]), "total_us": float(out[1])}
+
 
 class Exchange:
     """neighbour exchange of public poses between the ranks of one node (dcora_exchange_*): the session must have been

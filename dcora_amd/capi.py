@@ -140,6 +140,8 @@ SIGNATURES = {
     "dcora_rbcd_agent_last_skipped": (C.c_int, [_vp, C.c_int, _PI]),
     "dcora_rbcd_agent_info": (C.c_int, [_vp, C.c_int, _PI, _PI, _PI]),
     "dcora_rbcd_last_result": (C.c_int, [_vp, C.POINTER(ROptResult)]),
+    "dcora_rbcd_profile_tcg_runs": (C.c_int, [_vp, C.c_int]),
+    "dcora_rbcd_profile_tcg_read": (C.c_int, [_vp, _dp]),
     "dcora_rbcd_X_device_ptr": (C.c_int, [_vp, C.POINTER(_vp)]),
     "dcora_rbcd_public_count": (C.c_int, [_vp, C.c_int, _PI]),
     "dcora_rbcd_public_indices": (C.c_int, [_vp, C.c_int, _ip]),

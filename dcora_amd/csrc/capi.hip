@@ -1054,6 +1054,28 @@ int dcora_rbcd_phase_selected(dcora_rbcd_t s, int selected) {
   DCORA_CATCH
 }
 int dcora_rbcd_phase_evaluate_dev(dcora_rbcd_t s, double *out_dev) { return s ? s->s.phase_evaluate_dev(out_dev) : bad("null"); }
+// measurement hook of bench.py's roofline: HIP events around the one-launch tCG runs of the session's agents
+int dcora_rbcd_profile_tcg_runs(dcora_rbcd_t s, int enable) {
+  if (!s) return bad("null");
+  for (auto &a : s->s.agents)
+    if (a.prob) a.prob->profile_tcg_runs = enable != 0;
+  return DCORA_OK;
+}
+int dcora_rbcd_profile_tcg_read(dcora_rbcd_t s, double *out2) {
+  if (!s || !out2) return bad("null");
+  DCORA_TRY
+  out2[0] = out2[1] = 0;
+  for (auto &a : s->s.agents) {
+    if (!a.prob) continue;
+    double n = 0, us = 0;
+    const int rc = a.prob->profile_tcg_read(&n, &us);
+    if (rc) return rc;
+    out2[0] += n;
+    out2[1] += us;
+  }
+  return DCORA_OK;
+  DCORA_CATCH
+}
 int dcora_rbcd_synchronize(dcora_rbcd_t s) {
   if (!s) return bad("null");
   DCORA_HIP(hipStreamSynchronize(s->s.st));

@@ -229,6 +229,11 @@ class DeviceProblem {
   bool tcg_run_ok = false;
   bool concurrent_solves = false;
   DevBuf<unsigned> tcg_sync;
+  // measurement (bench.py's roofline): HIP events on the solver's stream around every k_tcg_run launch while switched on
+  bool profile_tcg_runs = false;
+  std::vector<hipEvent_t> run_events;  // pairs (start, stop)
+  size_t run_events_used = 0;
+  int profile_tcg_read(double *launches, double *total_us);
   bool fused = false;                  // SE layout, r <= 8: three-launch tCG iteration (solver_fused.hip)
   bool group = false;                  // SE layout, r <= 8: 8-lanes-per-pose rgrad / retract kernels (any n)
   DevBuf<double> pA, pB, pC, p1, p2, p3, scal;

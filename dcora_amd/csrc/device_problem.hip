@@ -144,6 +144,7 @@ void host_flags_release(HostFlags *host, int slot) {
 
 DeviceProblem::~DeviceProblem() {
   if (st) (void)hipStreamSynchronize(st);  // nothing of this problem is in flight when its flag words are recycled
+  for (hipEvent_t e : run_events) (void)hipEventDestroy(e);
   host_flags_release(hf, hf_slot);
   if (own_stream && st) stream_release(device, st);
 }
@@ -840,6 +841,21 @@ int DeviceProblem::rtr_dev(const dcora_ropt_params &prm, dcora_ropt_result *res_
 //   B (step length + vector updates + |r|^2 + dense preconditioner slices)
 //   C (stopping rule + slice sum + tangent projection + <z,r>)
 // B + C as one launch (k_fused_pc) where that form wins; DCORA_SOLVER_BC = pc / split forces one or the other
+// sum of the HIP-event times of the k_tcg_run launches recorded since the last read (gated no-op launches included)
+int DeviceProblem::profile_tcg_read(double *launches, double *total_us) {
+  DCORA_HIP(hipSetDevice(device));
+  DCORA_HIP(hipStreamSynchronize(st));
+  double us = 0;
+  for (size_t i = 0; i + 1 < run_events_used; i += 2) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, run_events[i], run_events[i + 1]) == hipSuccess) us += 1e3 * ms;
+  }
+  *launches = (double)(run_events_used / 2);
+  *total_us = us;
+  run_events_used = 0;
+  return DCORA_OK;
+}
+
 bool DeviceProblem::use_pc() const {
   const int forced = env::solver_bc();
   if (sparse_precond || !has_precond) return false;
@@ -933,9 +949,21 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
   // the launch failed.
   auto enqueue_first = [&]() -> int {
     if (run_form) {
+      hipEvent_t e1 = nullptr;
+      if (profile_tcg_runs) {
+        while (run_events.size() < run_events_used + 2) {
+          hipEvent_t e = nullptr;
+          if (hipEventCreate(&e) != hipSuccess) return -1;
+          run_events.push_back(e);
+        }
+        (void)hipEventRecord(run_events[run_events_used], st);
+        e1 = run_events[run_events_used + 1];
+        run_events_used += 2;
+      }
       if (launch_tcg_run(st, m, ldm, Mi, Qv, RGb(), Xb(), Sb(), dbuf[0], dbuf[1], Hd.p, eta.p, Heta.p, z.p, p1.p, p3.p,
                          pC.p, tcg_sync.p, c, hf_dev, ++seq) < 0)
         return -1;
+      if (e1) (void)hipEventRecord(e1, st);
       return seq;
     }
     if (pc) {

@@ -354,6 +354,11 @@ int dcora_rbcd_phase_selected(dcora_rbcd_t s, int selected);
  * written to out_dev[2*b], out_dev[2*b+1] (device, 2*num_robots doubles, entries of non-hosted agents zero) */
 int dcora_rbcd_phase_evaluate_dev(dcora_rbcd_t s, double *out_dev);
 int dcora_rbcd_synchronize(dcora_rbcd_t s);
+/* Measurement hook (bench.py's `roofline`): while enabled, HIP events are recorded on the solver's stream around every
+ * one-launch tCG run (k_tcg_run) of the session's agents; _read waits for the stream, returns {launches, sum of their
+ * event times in us} since the last read and forgets them.  Not for timed regions: an event pair costs a few us. */
+int dcora_rbcd_profile_tcg_runs(dcora_rbcd_t s, int enable);
+int dcora_rbcd_profile_tcg_read(dcora_rbcd_t s, double *out2);
 
 /* ------------------------------------------------------------------------- *
  * Neighbour exchange between the ranks of one node (one process per GPU): the transport the reference leaves to its

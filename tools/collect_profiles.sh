@@ -2,7 +2,7 @@
 # collects the round's rocprofv3 summaries into gpurun_out/<tag> (run on the GPU box; tools/assemble_profiles.py <tag>
 # copies what is quoted into profiles/): collect_profiles.sh [tag]
 export TMPDIR=/tmp
-tag=${1:-r04}
+tag=${1:-r05}
 o=gpurun_out/$tag
 rm -rf $o; mkdir -p $o
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/headline -o t -- python3 bench.py --headline-only > $o/headline.log 2>&1
@@ -16,10 +16,12 @@ for c in FETCH_SIZE WRITE_SIZE; do
   f=$(find $o/$d -name "*counter_collection.csv" | head -1)
   python3 tools/pmc_summarize.py $f $c > $o/pmc_${c}_summary.csv
 done
-python3 bench.py > $o/bench.json 2> $o/bench.err
+python3 bench.py > $o/bench_line.json 2> $o/bench.err
+cp gpurun_out/bench_detail.json $o/bench.json
 echo "bench done" >&2
 # the N > 1 path rehearsed on ONE GPU (2 ranks over gloo, both on device 0): not a scaling figure
-DCORA_DIST_BACKEND=gloo python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 > $o/bench_2ranks_on_one_gpu.json 2> $o/bench_2ranks.err
+DCORA_DIST_BACKEND=gloo python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 > $o/bench_2ranks_line.json 2> $o/bench_2ranks.err
+cp gpurun_out/bench_detail.json $o/bench_2ranks_on_one_gpu.json
 # keep the merged output small
 find $o -name "*kernel_trace.csv" -delete; find $o -name "*counter_collection.csv" -delete
 ls -la $o
