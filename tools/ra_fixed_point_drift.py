@@ -18,8 +18,7 @@ for name in ("range_aided_slam_test_2d", "range_aided_slam_test_3d"):
     d, n, l, b = ra.d, ra.n, ra.l, ra.b
     print(name, "d n l b", d, n, l, b)
     # centralised problem at the ground truth
-    reg = da.ra_precond_regularization(ra) if hasattr(da, "ra_precond_regularization") else -1.0
-    P = da.QuadraticProblem(d, d, n, ra.Q, reg=-1.0, l=l, b=b)
+    P = da.QuadraticProblem(d, d, n, ra.Q, reg=da.precond_regularization(ra.Q), l=l, b=b)
     Po = orc.Problem(d, d, n, ro.Q, reg=1e-3, l=l, b=b)
     print("  f(gt) hip %.3e oracle %.3e   |rgrad| hip %.3e oracle %.3e" %
           (P.f(ra.gt), Po.f(ro.gt), P.RieGradNorm(ra.gt), np.linalg.norm(Po.rgrad(ro.gt))))
