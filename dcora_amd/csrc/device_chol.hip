@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <unistd.h>
 #include <cstdlib>
 #include <cstring>
 #include <list>
@@ -1409,6 +1410,12 @@ int device_chol_piecewise_factor(const HostCsr &A, int block, int top_unknowns, 
 
 int device_dense_spd_inverse(const HostCsr &A, int device, double *Minv, int ldm, bool *pd) {
   const int k = A.n;
+  const auto t_in = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (env::init_timing())
+      fprintf(stderr, "[dense inverse] %-10s at %7.2f ms\n", what,
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_in).count());
+  };
   DCORA_HIP(hipSetDevice(device));
   hipStream_t st = nullptr;
   int rc = stream_acquire(device, &st);
@@ -1428,6 +1435,7 @@ int device_dense_spd_inverse(const HostCsr &A, int device, double *Minv, int ldm
                o_fail = o_ci + up16(std::max<size_t>(1, nnz) * 4), o_list = o_fail + 16, total = o_list + 16;
   DevBuf<char> arena;
   DCORA_HIP(arena.alloc(total));
+  lap("arena");
   struct {
     double *p;
   } L{(double *)(arena.p + o_L)}, YT{(double *)(arena.p + o_YT)}, linv{(double *)(arena.p + o_linv)},
@@ -1471,9 +1479,11 @@ int device_dense_spd_inverse(const HostCsr &A, int device, double *Minv, int ldm
   }
   DCORA_LAUNCH_MMA(k_dense_lauum, dim3(nb * (nb + 1) / 2), st, k, YT.p, Minv, ldm);
   DCORA_HIP(hipGetLastError());
+  lap("enqueued");
   int failed = 0;
   DCORA_HIP(hipMemcpyAsync(&failed, fail.p, sizeof(int), hipMemcpyDeviceToHost, st));
   DCORA_HIP(hipStreamSynchronize(st));
+  lap("done");
   *pd = failed == 0;
   return DCORA_OK;
 }

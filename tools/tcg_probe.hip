@@ -70,7 +70,8 @@ __global__ __launch_bounds__(256) void k_persist(int iters, double *h, double *z
         g += __hip_atomic_load(z + (size_t)nb * kPer + (e % kPer), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    if (tid < kPer) __hip_atomic_store(h + (size_t)wg * kPer + tid, g + it + 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (the value every reader must see this iteration: it + 1 in every slot -- a stale line would show the iteration before)
+    if (tid < kPer) __hip_atomic_store(h + (size_t)wg * kPer + tid, (g != 0.123 ? 0.0 : 1.0) + it + 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!grid_step(s, 0, epoch, fail)) return;
     // ---- phase B ----
     double acc = 0;
@@ -104,7 +105,23 @@ __global__ __launch_bounds__(256) void k_persist(int iters, double *h, double *z
         }
       }
     }
+    else if (MODE == 4) {
+      // plain 16-byte loads behind ONE invalidate of the caches per wave (what a kernel boundary does for free)
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      for (int e = tid * 2; e < kN; e += 512) {
+        const double2 v = *reinterpret_cast<const double2 *>(h + e);
+        s_img[e] = v.x;
+        s_img[e + 1] = v.y;
+        acc += v.x + v.y;
+      }
+    }
     __syncthreads();
+    if (MODE >= 2) {
+      // every slot of h must hold it + 1: the block sum of the image says whether a stale value was read
+      double part = 0;
+      for (int e = tid; e < kN; e += 256) part += s_img[e];
+      if (fabs(part - (double)(it + 1) * ((kN - tid + 255) / 256)) > 1e-6) *fail = 2;
+    }
     if (MODE >= 2) acc += s_img[(tid * 37) % kN];
     if (tid < kPer) __hip_atomic_store(z + (size_t)wg * kPer + tid, acc * 1e-9 + it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     carry += acc;
@@ -152,7 +169,7 @@ void run(const char *name, int iters) {
   int f = 0;
   (void)hipMemcpy(&f, fail, 4, hipMemcpyDeviceToHost);
   printf("%-46s %3d iterations per launch: %7.1f us per launch, %6.2f us per tCG iteration (two grid steps)%s\n", name, iters,
-         ms * 1e3 / reps, ms * 1e3 / reps / iters, f ? "  TIMED OUT" : "");
+         ms * 1e3 / reps, ms * 1e3 / reps / iters, f == 1 ? "  TIMED OUT" : f == 2 ? "  STALE VALUES READ" : "");
   (void)hipFree(h); (void)hipFree(z); (void)hipFree(out); (void)hipFree(fail); (void)hipFree(pool);
 }
 
@@ -162,6 +179,7 @@ int main() {
     run<1>("+ neighbour gather (17 x 40 doubles)", iters);
     run<2>("+ all-gather of 80 KB, 8-byte agent loads", iters);
     run<3>("+ all-gather of 80 KB, 16-byte sc1 loads", iters);
+    run<4>("+ all-gather, acquire fence + plain loads", iters);
   }
   return 0;
 }
