@@ -74,6 +74,10 @@ int build_partitioned_inverse_auto(const HostCsr &A, int block, int nthreads, in
 // dense inverse of a small SPD matrix, entirely on the device: Minv (device, k rows of ldm >= k doubles, row-major,
 // both triangles) <- A^-1.  *pd = false (and Minv undefined) when A is not positive definite.
 int device_dense_spd_inverse(const HostCsr &A, int device, double *Minv, int ldm, bool *pd);
+// the same for a batch of matrices of EQUAL size in one set of launches (bitwise the single build per matrix); pd gets one
+// verdict for the whole batch (a failure anywhere: build one by one to find it)
+int device_dense_spd_inverse_batch(const std::vector<const HostCsr *> &As, int device, const std::vector<double *> &Minv,
+                                   int ldm, std::vector<char> *pd);
 
 // X = A^-1 B for a sparse SPD matrix and up to 16 right-hand sides (contiguous per unknown) through the partitioned
 // inverse built from the device factorisation and ONE replay on the device: the solver the chordal initialisation

@@ -553,7 +553,8 @@ __global__ __launch_bounds__(256) void k_chol_syrk(const PieceDev *__restrict__ 
 template <bool MMA>
 __global__ __launch_bounds__(256) void k_dense_trtri_finish(int k, int ib, double *__restrict__ YT,
                                                             const double *__restrict__ Linv,
-                                                            const InvJob *__restrict__ jobs = nullptr) {
+                                                            const InvJob *__restrict__ jobs = nullptr,
+                                                            int tstride = 1) {
   if (jobs) {
     const InvJob J = jobs[blockIdx.z];
     k = J.c;
@@ -565,7 +566,9 @@ __global__ __launch_bounds__(256) void k_dense_trtri_finish(int k, int ib, doubl
   __shared__ double Bs[NB][NB + 1];
   const int tid = threadIdx.x;
   const int i0 = ib * NB, ni = min(NB, k - i0);
-  const double *__restrict__ Li = Linv + (size_t)ib * NB * NB;
+  // (tstride: 64 x 64 blocks between the inverses of consecutive panels -- 1, or the batch size when the potrf of a batch
+  // of equal matrices stored them panel by panel)
+  const double *__restrict__ Li = Linv + (size_t)ib * NB * NB * tstride;
   if ((int)blockIdx.x == ib) {  // diagonal block: the transpose of the inverse of the diagonal block of L
     for (int e = tid; e < NB * NB; e += 256) {
       const int a = e >> 6, b = e & 63;
@@ -633,7 +636,7 @@ __global__ __launch_bounds__(256) void k_dense_lauum(int k, const double *__rest
     const InvJob J = jobs[blockIdx.z];
     if (J.mt < 0) return;
     k = J.c;
-    ldm = J.c;
+    if (ldm <= 0) ldm = J.c;  // (a batch of dense inverses passes its padded leading dimension)
     YT += J.yt;
     M += J.mt;
   }
@@ -991,9 +994,13 @@ size_t arena_keep_bytes() {
 
 }  // namespace
 
+namespace {
+void scratch_clear();  // the dense builds' recycled arenas (below)
+}
 void chol_cache_clear() {
   std::lock_guard<std::mutex> lk(g_mu);
   g_cache.clear();
+  scratch_clear();
 }
 
 namespace {
@@ -1408,6 +1415,50 @@ int device_chol_piecewise_factor(const HostCsr &A, int block, int top_unknowns, 
   return DCORA_OK;
 }
 
+// Scratch arenas of the dense builds, recycled process-wide: hipFree of a few hundred MB takes milliseconds (and waits for
+// the device), and sessions are created again and again (staircase levels, GNC rounds).  At most two idle arenas per
+// process are kept; chol_cache_clear() drops them.
+namespace {
+std::mutex g_scratch_mu;
+struct Scratch {
+  int device;
+  size_t bytes;
+  char *p;
+};
+std::vector<Scratch> g_scratch_idle;
+char *scratch_acquire(int device, size_t bytes) {
+  {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    for (size_t i = 0; i < g_scratch_idle.size(); ++i)
+      if (g_scratch_idle[i].device == device && g_scratch_idle[i].bytes >= bytes &&
+          g_scratch_idle[i].bytes <= 4 * bytes + (64u << 20)) {
+        char *p = g_scratch_idle[i].p;
+        g_scratch_idle.erase(g_scratch_idle.begin() + (long)i);
+        return p;
+      }
+  }
+  char *p = nullptr;
+  if (hipMalloc((void **)&p, bytes) != hipSuccess) return nullptr;
+  return p;
+}
+void scratch_release(int device, char *p, size_t bytes) {
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (g_scratch_idle.size() < 2) {
+      g_scratch_idle.push_back(Scratch{device, bytes, p});
+      return;
+    }
+  }
+  (void)hipFree(p);
+}
+void scratch_clear() {
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  for (Scratch &s : g_scratch_idle) (void)hipFree(s.p);
+  g_scratch_idle.clear();
+}
+}  // namespace
+
 int device_dense_spd_inverse(const HostCsr &A, int device, double *Minv, int ldm, bool *pd) {
   const int k = A.n;
   const auto t_in = std::chrono::steady_clock::now();
@@ -1433,8 +1484,16 @@ int device_dense_spd_inverse(const HostCsr &A, int device, double *Minv, int ldm
                o_v = o_linv + up16((size_t)nb * NB * NB * 8), o_logdet = o_v + up16(std::max<size_t>(1, nnz) * 8),
                o_piece = o_logdet + 16, o_rp = o_piece + up16(sizeof(PieceDev)), o_ci = o_rp + up16(((size_t)k + 1) * 4),
                o_fail = o_ci + up16(std::max<size_t>(1, nnz) * 4), o_list = o_fail + 16, total = o_list + 16;
-  DevBuf<char> arena;
-  DCORA_HIP(arena.alloc(total));
+  struct Arena {
+    int device;
+    size_t bytes;
+    char *p;
+    ~Arena() { scratch_release(device, p, bytes); }
+  } arena{device, total, scratch_acquire(device, total)};
+  if (!arena.p) {
+    set_last_error("dense inverse: out of device memory");
+    return DCORA_ERR_HIP;
+  }
   lap("arena");
   struct {
     double *p;
@@ -1485,6 +1544,109 @@ int device_dense_spd_inverse(const HostCsr &A, int device, double *Minv, int ldm
   DCORA_HIP(hipStreamSynchronize(st));
   lap("done");
   *pd = failed == 0;
+  return DCORA_OK;
+}
+
+// The same inverse for a BATCH of matrices of equal size in one set of launches (the agents of a session: five chains of
+// ~130 small dependent launches on five streams do not overlap on this part -- the hardware runs two or three queues at a
+// time, tools/stream_overlap.hip -- so five builds took 20 ms where one takes 3.5).  Every kernel of the single build
+// takes a list / job index: potrf one workgroup per matrix, the panel kernels a grid dimension over the matrices.  The
+// arithmetic per matrix is the single build's, kernel for kernel: the two give the same bits.
+int device_dense_spd_inverse_batch(const std::vector<const HostCsr *> &As, int device, const std::vector<double *> &Minv,
+                                   int ldm, std::vector<char> *pd) {
+  const int B = (int)As.size();
+  if (B == 0) return DCORA_OK;
+  const int k = As[0]->n;
+  for (const HostCsr *A : As)
+    if (A->n != k) {
+      set_last_error("dense inverse batch: matrices of different sizes");
+      return DCORA_ERR_BAD_ARG;
+    }
+  const auto t_in = std::chrono::steady_clock::now();
+  DCORA_HIP(hipSetDevice(device));
+  hipStream_t st = nullptr;
+  int rc = stream_acquire(device, &st);
+  if (rc) return rc;
+  struct Rel {
+    int device;
+    hipStream_t st;
+    ~Rel() { stream_release(device, st); }
+  } rel_guard{device, st};
+  const int nb = (k + NB - 1) / NB;
+  const size_t kk = (size_t)k * k;
+  size_t nnz_max = 1;
+  for (const HostCsr *A : As) nnz_max = std::max(nnz_max, A->ci.size());
+  auto up16 = [](size_t bytes) { return (bytes + 15) & ~(size_t)15; };
+  const size_t o_L = 0, o_YT = o_L + up16(B * kk * 8), o_tinv = o_YT + up16(B * kk * 8),
+               o_v = o_tinv + up16((size_t)B * nb * NB * NB * 8), o_logdet = o_v + up16(B * nnz_max * 8),
+               o_piece = o_logdet + 16, o_jobs = o_piece + up16(sizeof(PieceDev) * B),
+               o_rp = o_jobs + up16(sizeof(InvJob) * B), o_ci = o_rp + up16((size_t)B * (k + 1) * 4),
+               o_fail = o_ci + up16(B * nnz_max * 4), o_list = o_fail + 16, total = o_list + up16(4 * (size_t)B);
+  struct Arena {
+    int device;
+    size_t bytes;
+    char *p;
+    ~Arena() { scratch_release(device, p, bytes); }
+  } arena{device, total, scratch_acquire(device, total)};
+  if (!arena.p) {
+    set_last_error("dense inverse batch: out of device memory");
+    return DCORA_ERR_HIP;
+  }
+  double *L = (double *)(arena.p + o_L), *YT = (double *)(arena.p + o_YT), *tinv = (double *)(arena.p + o_tinv),
+         *v = (double *)(arena.p + o_v), *logdet = (double *)(arena.p + o_logdet);
+  int *rp = (int *)(arena.p + o_rp), *ci = (int *)(arena.p + o_ci), *fail = (int *)(arena.p + o_fail),
+      *list = (int *)(arena.p + o_list);
+  PieceDev *piece = (PieceDev *)(arena.p + o_piece);
+  InvJob *jobs = (InvJob *)(arena.p + o_jobs);
+  std::vector<PieceDev> hp((size_t)B);
+  std::vector<InvJob> hj((size_t)B);
+  std::vector<int> hl((size_t)B);
+  double *Mbase = Minv[0];
+  for (double *q : Minv) Mbase = std::min(Mbase, q);
+  for (int b = 0; b < B; ++b) {
+    hp[(size_t)b] = PieceDev{(long long)(b * kk), k, 0, -1, 0};
+    hj[(size_t)b] = InvJob{k, 0, (long long)(b * kk), (long long)k, (long long)(b * kk), (long long)b * NB * NB, 0,
+                          (long long)(Minv[(size_t)b] - Mbase)};
+    hl[(size_t)b] = b;
+    const HostCsr &A = *As[(size_t)b];
+    DCORA_HIP(hipMemcpyAsync(rp + (size_t)b * (k + 1), A.rp.data(), ((size_t)k + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+    DCORA_HIP(hipMemcpyAsync(ci + (size_t)b * nnz_max, A.ci.data(), A.ci.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    DCORA_HIP(hipMemcpyAsync(v + (size_t)b * nnz_max, A.v.data(), A.ci.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    DCORA_HIP(hipMemsetAsync(Minv[(size_t)b], 0, (size_t)k * ldm * sizeof(double), st));
+  }
+  DCORA_HIP(hipMemcpyAsync(piece, hp.data(), sizeof(PieceDev) * B, hipMemcpyHostToDevice, st));
+  DCORA_HIP(hipMemcpyAsync(jobs, hj.data(), sizeof(InvJob) * B, hipMemcpyHostToDevice, st));
+  DCORA_HIP(hipMemcpyAsync(list, hl.data(), sizeof(int) * B, hipMemcpyHostToDevice, st));
+  DCORA_HIP(hipMemsetAsync(L, 0, o_tinv, st));  // L and YT of every matrix
+  DCORA_HIP(hipMemsetAsync(fail, 0, sizeof(int), st));
+  DCORA_HIP(hipMemsetAsync(logdet, 0, sizeof(double), st));
+  for (int b = 0; b < B; ++b)
+    hipLaunchKernelGGL(k_dense_scatter, dim3(k), dim3(256), 0, st, k, rp + (size_t)b * (k + 1), ci + (size_t)b * nnz_max,
+                       v + (size_t)b * nnz_max, L + b * kk);
+  for (int p = 0; p < nb; ++p) {
+    const int j0 = p * NB, jb = std::min(NB, k - j0), rows = k - j0 - jb;
+    double *step_inv = tinv + (size_t)p * B * NB * NB;  // panel p of matrix b at (p B + b) 64 x 64 blocks
+    hipLaunchKernelGGL(k_chol_potrf, dim3(B), dim3(256), 0, st, piece, list, j0, L, step_inv, fail, logdet, 1);
+    if (rows > 0) {
+      const int T = (rows + NB - 1) / NB;
+      DCORA_LAUNCH_MMA(k_chol_trsm, dim3(T, B), st, piece, list, j0, L, step_inv, fail);
+      DCORA_LAUNCH_MMA(k_chol_syrk, dim3(T * (T + 1) / 2, B), st, piece, list, j0, j0 + NB, -1, 0, L, fail);
+    }
+  }
+  for (int ib = 0; ib < nb; ++ib) {
+    DCORA_LAUNCH_MMA(k_dense_trtri_finish, dim3(ib + 1, 1, B), st, 0, ib, YT, tinv, jobs, B);
+    if (ib + 1 < nb) DCORA_LAUNCH_MMA(k_dense_trtri_update, dim3(nb - ib - 1, ib + 1, B), st, 0, ib, L, 0LL, YT, jobs);
+  }
+  DCORA_LAUNCH_MMA(k_dense_lauum, dim3(nb * (nb + 1) / 2, 1, B), st, 0, YT, Mbase, ldm, jobs);
+  DCORA_HIP(hipGetLastError());
+  int failed = 0;
+  DCORA_HIP(hipMemcpyAsync(&failed, fail, sizeof(int), hipMemcpyDeviceToHost, st));
+  DCORA_HIP(hipStreamSynchronize(st));
+  // (one flag for the batch: a failure anywhere stops every later launch, the caller then builds one by one)
+  pd->assign((size_t)B, failed == 0 ? 1 : 0);
+  if (env::init_timing())
+    fprintf(stderr, "[dense inverse] batch of %d (k = %d) in %.2f ms\n", B, k,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_in).count());
   return DCORA_OK;
 }
 

@@ -197,6 +197,9 @@ void stream_release(int device, hipStream_t st);
 int host_flags_acquire(HostFlags **host, HostFlags **dev, int *slot);
 void host_flags_release(HostFlags *host, int slot);
 
+// dense inverses of several matrices in one batch of launches, left in the preconditioner cache (device_problem.hip)
+int precond_prebuild_dense(const std::vector<const HostCsr *> &Qs, double reg, int block, int device);
+
 class DeviceProblem {
  public:
   ManiDesc m{};

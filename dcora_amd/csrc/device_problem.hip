@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <thread>
 
@@ -284,6 +285,81 @@ int DeviceProblem::set_G_host(const double *Gh) {
   return DCORA_OK;
 }
 
+// The dense inverses of SEVERAL matrices (the agents of a session) built in one batch of launches and put into the cache,
+// so that the problems created next attach to them: matrices of equal size whose inverse is not cached yet and that would
+// take the dense form.  Best effort: whatever is not built here is built by the problem that needs it.
+int precond_prebuild_dense(const std::vector<const HostCsr *> &Qs, double reg, int block, int device) {
+  if (env::precond_mode() == 2 || env::factor_on_host() || env::precond_cache_mb() <= 0) return DCORA_OK;
+  std::map<int, std::vector<size_t>> by_k;
+  std::vector<PrecondKey> keys(Qs.size());
+  for (size_t i = 0; i < Qs.size(); ++i) {
+    const int k = Qs[i]->n;
+    const bool want_sparse = env::precond_mode() ? false : (k > kDensePrecondMaxK);
+    if (want_sparse || k < 1) continue;
+    keys[i] = make_precond_key(*Qs[i], reg, block, device, false);
+    PrecondEntry ent;
+    if (precond_cache_find(keys[i], &ent, false)) continue;
+    bool dup = false;  // (two agents with the same matrix: one build)
+    for (size_t j : by_k[k]) dup = dup || keys[j] == keys[i];
+    if (!dup) by_k[k].push_back(i);
+  }
+  DCORA_HIP(hipSetDevice(device));
+  for (auto &grp : by_k) {
+    const std::vector<size_t> &idx = grp.second;
+    if (idx.size() < 2) continue;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int k = grp.first, ldm = ((k + 127) / 128) * 128;
+    std::vector<HostCsr> Ms(idx.size());
+    std::vector<const HostCsr *> As;
+    std::vector<std::shared_ptr<DevBuf<double>>> bufs;
+    std::vector<double *> outs;
+    std::vector<long> nnzL(idx.size(), 0);
+    // host work per matrix (the shifted copy; nnz(L) of the SPARSE factor from the pattern, what SURVEY 8(d) prices the
+    // preconditioner by) on threads of its own, beside the device's batch
+    std::vector<std::thread> th;
+    for (size_t q = 0; q < idx.size(); ++q) Ms[q] = csr_shift_diag(*Qs[idx[q]], reg);
+    for (size_t q = 0; q < idx.size(); ++q)
+      th.emplace_back([&, q] {
+        CholSymbolic sym;
+        chol_symbolic(Ms[q], block, &sym);
+        long nz = 0;
+        for (const CholPiece &pc : sym.pieces) nz += (long)pc.c * (pc.c + 1) / 2 + (long)pc.m * pc.c;
+        nnzL[q] = nz;
+      });
+    struct Join {
+      std::vector<std::thread> &t;
+      ~Join() {
+        for (std::thread &x : t)
+          if (x.joinable()) x.join();
+      }
+    } join_guard{th};
+    for (size_t q = 0; q < idx.size(); ++q) {
+      auto buf = std::make_shared<DevBuf<double>>();
+      DCORA_HIP(buf->alloc((size_t)k * ldm + 16));
+      bufs.push_back(buf);
+      outs.push_back(buf->p);
+    }
+    for (const HostCsr &M : Ms) As.push_back(&M);
+    std::vector<char> pd;
+    const int rc = device_dense_spd_inverse_batch(As, device, outs, ldm, &pd);
+    if (rc) return rc;
+    for (std::thread &x : th) x.join();
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    for (size_t q = 0; q < idx.size(); ++q) {
+      if (!pd[q]) continue;  // not positive definite somewhere in the batch: the problems build (and report) one by one
+      PrecondEntry ent;
+      ent.ldm = ldm;
+      ent.dense = bufs[q];
+      ent.bytes = bufs[q]->n * sizeof(double);
+      ent.build_ms = ms / (double)idx.size();
+      ent.nnzL = nnzL[q];
+      ent.prebuilt = true;
+      precond_cache_insert(keys[idx[q]], ent);
+    }
+  }
+  return DCORA_OK;
+}
+
 // (Q + reg I)^-1 as a dense symmetric matrix in HBM: host sparse Cholesky once per Q (Q is reused across all
 // RBCD iterations and staircase levels), k independent solves on host threads, one upload.
 int DeviceProblem::build_preconditioner(const HostCsr &Qh, double reg) {
@@ -314,9 +390,10 @@ int DeviceProblem::build_preconditioner(const HostCsr &Qh, double reg) {
   // the inverse depends on Q + reg I only (not on r, not on G): built once per distinct matrix, shared afterwards
   const PrecondKey key = make_precond_key(Qh, reg, block, device, want_sparse);
   PrecondEntry ent;
-  precond_cache_hit = precond_cache_find(key, &ent);
+  const bool found = precond_cache_find(key, &ent);
+  precond_cache_hit = found && !ent.prebuilt;  // (an image built ahead for THIS problem is not a hit)
   DCORA_HIP(hipSetDevice(device));
-  if (!precond_cache_hit) {
+  if (!found) {
     if (env::init_timing())
       fprintf(stderr, "[precond] key + cache look-up %.1f ms\n",
               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());

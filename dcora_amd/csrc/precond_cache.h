@@ -44,9 +44,13 @@ struct PrecondEntry {
   long nnzL = 0;
   size_t bytes = 0;
   double build_ms = 0;
+  // built ahead of the problem that needs it (precond_prebuild_dense: the agents of a session in one batch): the first
+  // look-up that finds it is that problem's -- it counts as the MISS its build was, later ones as hits
+  bool prebuilt = false;
 };
 
-bool precond_cache_find(const PrecondKey &key, PrecondEntry *out);
+// count = false: a look that leaves the statistics alone (the batch builder asking what is there already)
+bool precond_cache_find(const PrecondKey &key, PrecondEntry *out, bool count = true);
 void precond_cache_insert(const PrecondKey &key, const PrecondEntry &e);
 // hits, misses, entries, bytes held
 void precond_cache_stats(double *stats4);

@@ -81,17 +81,24 @@ PrecondKey make_precond_key(const HostCsr &Q, double reg, int block, int device,
   return k;
 }
 
-bool precond_cache_find(const PrecondKey &key, PrecondEntry *out) {
+bool precond_cache_find(const PrecondKey &key, PrecondEntry *out, bool count) {
   if (budget() == 0) return false;
   std::lock_guard<std::mutex> lk(g_mu);
   for (auto it = g_lru.begin(); it != g_lru.end(); ++it)
     if (it->key == key) {
       g_lru.splice(g_lru.begin(), g_lru, it);
       *out = g_lru.front().e;
-      g_hits += 1;
+      if (count) {
+        if (g_lru.front().e.prebuilt) {
+          g_lru.front().e.prebuilt = false;  // claimed by the problem it was built for
+          g_misses += 1;
+        } else {
+          g_hits += 1;
+        }
+      }
       return true;
     }
-  g_misses += 1;
+  if (count) g_misses += 1;
   return false;
 }
 

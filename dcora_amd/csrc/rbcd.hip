@@ -157,13 +157,42 @@ int RbcdSession::init(const HostDataset &ds, const dcora_rbcd_options &o) {
       DCORA_HIP(hipMemcpy(a.public_cols.p, cols.data(), sizeof(int) * cols.size(), hipMemcpyHostToDevice));
     if (a.hosted) hosted_ids.push_back(b);
   }
+  // the pose / column offsets of the agents: uploaded before the builds (a copy queued behind them waited 16 ms)
+  cs[R] = dh * n;
+  {
+    std::vector<int> ps(R + 1);
+    for (int b = 0; b <= R; ++b) ps[b] = cs[b] / dh;
+    DCORA_HIP(pose_start.alloc(R + 1));
+    DCORA_HIP(col_start.alloc(R + 1));
+    DCORA_HIP(hipMemcpyAsync(pose_start.p, ps.data(), sizeof(int) * (R + 1), hipMemcpyHostToDevice, st));
+    DCORA_HIP(hipMemcpyAsync(col_start.p, cs.data(), sizeof(int) * (R + 1), hipMemcpyHostToDevice, st));
+    DCORA_HIP(hipStreamSynchronize(st));
+  }
+  DCORA_HIP(hipEventCreateWithFlags(&fork_ev_, hipEventDisableTiming));
   // The hosted agents' problems (Q_bb, its preconditioner: host factorisation + inverse image, coupling block) are
   // built side by side on host threads: the factorisation of one block is partly serial (the separators above the
   // sub-trees), so eight blocks of the 100k lattice take 9 s one after the other and 2-3 s together.
+  // Blocks small enough for the dense inverse: all hosted agents' matrices first, their inverses in ONE batch of launches
+  // (five builds on five streams do not overlap: precond_prebuild_dense), then the problems attach to the cached images
+  std::vector<HostCsr> Qbs((size_t)R);
+  if ((long)(n / R + 1) * dh <= kDensePrecondMaxK && hosted_ids.size() > 1) {
+    std::vector<const HostCsr *> ptrs;
+    {
+      std::vector<std::thread> th;  // (a matrix takes a millisecond of host work: side by side)
+      for (int b : hosted_ids) th.emplace_back([&, b] { Qbs[(size_t)b] = build_Q_pgo(d, agents[b].n, b, touching[b]); });
+      for (std::thread &t : th) t.join();
+    }
+    for (int b : hosted_ids) ptrs.push_back(&Qbs[(size_t)b]);
+    const int prc = precond_prebuild_dense(ptrs, 0.1, dh, o.device);
+    if (prc) return prc;
+    if (env::init_timing())
+      fprintf(stderr, "[session] dense inverses prebuilt after %.1f ms\n",
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  }
   auto build_agent = [&](int b, std::string *err) -> int {
     AgentDev &a = agents[b];
     if (hipSetDevice(o.device) != hipSuccess) return DCORA_ERR_HIP;
-    HostCsr Qb = build_Q_pgo(d, a.n, b, touching[b]);
+    HostCsr Qb = Qbs[(size_t)b].n > 0 ? std::move(Qbs[(size_t)b]) : build_Q_pgo(d, a.n, b, touching[b]);
     a.prob.reset(new DeviceProblem);
     dcora_dims dims{r, d, a.n, 0, 0};
     int rc = a.prob->init(dims, Qb, nullptr, 0.1, o.device, st);  // reg = 1e-1, ref src/Graph.cpp:1906
@@ -227,16 +256,6 @@ int RbcdSession::init(const HostDataset &ds, const dcora_rbcd_options &o) {
   if (init_timing)
     fprintf(stderr, "[session] agents built after %.1f ms\n",
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-  DCORA_HIP(hipEventCreateWithFlags(&fork_ev_, hipEventDisableTiming));
-  cs[R] = dh * n;
-  {
-    std::vector<int> ps(R + 1);
-    for (int b = 0; b <= R; ++b) ps[b] = cs[b] / dh;
-    DCORA_HIP(pose_start.alloc(R + 1));
-    DCORA_HIP(hipMemcpy(pose_start.p, ps.data(), sizeof(int) * (R + 1), hipMemcpyHostToDevice));
-  }
-  DCORA_HIP(col_start.alloc(R + 1));
-  DCORA_HIP(hipMemcpy(col_start.p, cs.data(), sizeof(int) * (R + 1), hipMemcpyHostToDevice));
   if (central_rc) {
     set_last_error(central_err);
     return central_rc;
