@@ -122,7 +122,7 @@ class RbcdSession : public ExchangeSession {
   int update_nonselected_agent(AgentDev &a, bool restart);
   int update_selected_agent(AgentDev &a, bool restart);
   hipEvent_t fork_ev_ = nullptr;
-  int solve_block(AgentDev &a, std::string *err);
+  int solve_block(AgentDev &a, std::string *err, bool serial = false);
 };
 
 }  // namespace dcora

@@ -800,7 +800,7 @@ int RbcdSession::agent_colours(int *colours, int *ncolours) const {
 
 // local solve of one agent on its own stream, from the G / X0 staged by iterate_set; the accepted iterate goes
 // back into the global mirror without a host round trip when the solver keeps its choice on the device
-int RbcdSession::solve_block(AgentDev &a, std::string *err) {
+int RbcdSession::solve_block(AgentDev &a, std::string *err, bool serial) {
   auto fail = [&](int rc) {
     if (err) *err = dcora_last_error();
     return rc;
@@ -810,15 +810,18 @@ int RbcdSession::solve_block(AgentDev &a, std::string *err) {
   const size_t off = (size_t)a.col0 * r;
   const size_t B = sizeof(double) * (size_t)pb.nelem();
   hipStream_t keep = pb.st;
-  pb.st = a.own;
+  // serial: the set's solves one after the other on the session's stream (each may then run its tCG runs as ONE launch,
+  // k_tcg_run); otherwise side by side on the agents' own streams, on the launches per iteration
+  hipStream_t run_on = serial ? st : a.own;
+  pb.st = run_on;
   Buf2 Xres{{nullptr, nullptr}};
   const SolverCtl *cs = nullptr;
-  pb.concurrent_solves = true;  // several solves share the device: no co-resident one-launch tCG run (k_tcg_run)
+  pb.concurrent_solves = !serial;  // several solves share the device: no co-resident one-launch tCG run
   int rc = pb.optimize_dev(opt.local, &Xres, &cs);
   pb.concurrent_solves = false;
   if (!rc) {
     if (cs && group_kernels(pb.m)) {
-      nesterov(a.own, pb.m, 3, 0, -1, -1, 0.0, 0.0, Xg.p + off, Vg.p + off, Yg.p + off, XPrevg.p + off, nullptr, Xres,
+      nesterov(run_on, pb.m, 3, 0, -1, -1, 0.0, 0.0, Xg.p + off, Vg.p + off, Yg.p + off, XPrevg.p + off, nullptr, Xres,
                cs);
     } else {
       if (cs) {
@@ -826,11 +829,11 @@ int RbcdSession::solve_block(AgentDev &a, std::string *err) {
         rc = pb.fetch_result(&tmp);
         Xres.p[0] = tmp.success && pb.result_index() ? pb.X1.p : pb.X0.p;
       }
-      if (!rc && hipMemcpyAsync(Xg.p + off, Xres.p[0], B, hipMemcpyDeviceToDevice, a.own) != hipSuccess)
+      if (!rc && hipMemcpyAsync(Xg.p + off, Xres.p[0], B, hipMemcpyDeviceToDevice, run_on) != hipSuccess)
         rc = DCORA_ERR_HIP;
     }
   }
-  if (!rc && hipEventRecord(a.done, a.own) != hipSuccess) rc = DCORA_ERR_HIP;
+  if (!rc && !serial && hipEventRecord(a.done, a.own) != hipSuccess) rc = DCORA_ERR_HIP;
   pb.st = keep;
   return rc ? fail(rc) : DCORA_OK;
 }
@@ -883,10 +886,27 @@ int RbcdSession::iterate_set(const int *set, int count, int allow_adjacent) {
     DCORA_HIP(hipMemcpyAsync(XPrevg.p + off, Xg.p + off, B, hipMemcpyDeviceToDevice, st));
     DCORA_HIP(hipMemcpyAsync(pb.X0.p, Xg.p + off, B, hipMemcpyDeviceToDevice, st));
   }
-  DCORA_HIP(hipEventRecord(fork_ev_, st));
-  for (AgentDev *a : work) DCORA_HIP(hipStreamWaitEvent(a->own, fork_ev_, 0));
+  // Blocks whose tCG runs fit ONE launch (dense preconditioner, n / 2 co-resident workgroups): one after the other on the
+  // session's stream -- 3 launches per RTR iteration each -- is faster on one device than side by side on the launches per
+  // iteration (sphere2500 / 5 agents: 2420 -> see DESIGN.md block updates/s); the staged G / start points make the order
+  // immaterial, and the two forms give the same bits.
+  bool serial = true;
+  for (AgentDev *a : work) serial = serial && a->prob->tcg_run_ok && a->prob->use_pc();
   std::vector<int> rcs(work.size(), DCORA_OK);
   std::vector<std::string> errs(work.size());
+  if (serial) {
+    for (size_t i = 0; i < work.size(); ++i) {
+      rcs[i] = solve_block(*work[i], &errs[i], true);
+      if (rcs[i]) {
+        set_last_error(errs[i]);
+        return rcs[i];
+      }
+    }
+    last_solver = work.back()->prob.get();
+    return DCORA_OK;
+  }
+  DCORA_HIP(hipEventRecord(fork_ev_, st));
+  for (AgentDev *a : work) DCORA_HIP(hipStreamWaitEvent(a->own, fork_ev_, 0));
   if (work.size() == 1) {
     rcs[0] = solve_block(*work[0], &errs[0]);
   } else {
