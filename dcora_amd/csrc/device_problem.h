@@ -129,8 +129,8 @@ struct SpImage {
   // hubs (PartInvHub): Schur complement data
   int nhub = 0;
   long hub_nnz = 0;
-  DevBuf<int> hub_idx, hub_ap, hub_apos;
-  DevBuf<double> hub_aval, hub_U, hub_Sinv;
+  DevBuf<int> hub_idx;
+  DevBuf<double> hub_U, hub_Sinv;
   // original unknown -> position in image 0 of the replay vector / position of its final value (-1 on a hub):
   // lets the caller's kernels write the right-hand side into y and read the result from it (SpFold, kernels.h)
   DevBuf<int> in_pos, out_pos;

@@ -145,7 +145,7 @@ struct SpFold {
   double *y = nullptr;
   const int *in_pos = nullptr, *out_pos = nullptr;
   // hubs (sparse_precond.h, PartInvHub; the generic-layout kernels only): in_pos / out_pos are -1 on a hub unknown,
-  // z = y1 - U x2 with x2 = Sinv (r(hub) - slices of k_sp_hub_dot), z(hub) = x2
+  // z = y1 - U x2 with x2 = Sinv (r(hub) - slices of hub_slice, sparse_precond.hip), z(hub) = x2
   int h = 0, hub_split = 0;
   const int *hub_idx = nullptr;
   const double *hub_U = nullptr, *hub_Sinv = nullptr, *hub_w = nullptr;

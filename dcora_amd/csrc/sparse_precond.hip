@@ -51,26 +51,31 @@ __global__ __launch_bounds__(kBlock) void k_sp_permute_out(int r, int k, const i
 // ---- hubs (PartInvHub): Schur complement on top of the replay ----
 struct HubDev {
   int h;
-  const int *idx, *ap, *apos;
-  const double *aval, *U, *Sinv;
-  double *w;  // h x r scratch: b2 - a^T y1
+  const int *idx;
+  const double *U, *Sinv;
+  double *w;  // h x kHubSplit x r scratch: the slices of a^T y1
 };
-// w(q, :) = R(hub_q, :) - sum_p a_q[p] y1(pos_p, :).  The sum over the hub's column (thousands of entries: a landmark
-// ranged from every pose) is split over kHubSplit workgroups per hub; each writes its partial to wpart[q][slice][t]
-// and k_sp_permute_out_hub adds the slices in a fixed order (one workgroup per hub took 27 us on tiers.pyfg).
+// w(q, :) = R(hub_q, :) - a_q^T y1 with y1 = A11^-1 r1, and a_q^T A11^-1 r1 = U(:, q)^T r1 (U = A11^-1 a is stored for
+// the correction anyway, A11 symmetric): the dot runs over the INPUT image of the replay -- dense, contiguous, and it
+// needs no level of the replay, so its workgroups ride in the replay's first launch (they were a launch of their own
+// after the last one: 5.1 us + a gap per tCG iteration on tiers.pyfg).  The sum over the k rows is split over kHubSplit
+// workgroups per hub; each writes its partial to w[q][slice][t] and the consumer adds the slices in a fixed order.
 constexpr int kHubSplit = 32;
-__global__ __launch_bounds__(kBlock) void k_sp_hub_dot(int r, HubDev H, const double *__restrict__ y, Gate g) {
-  if (sp_gated(g.ctl, g.seq, g.gate)) return;
-  __shared__ double s_part[kBlock];
-  const int q = blockIdx.x / kHubSplit, sl = blockIdx.x - q * kHubSplit;
-  const int RB = kBlock / r;
+struct HubIn {
+  int h = 0, k = 0;
+  const double *U = nullptr;
+  double *w = nullptr;
+};
+template <int NT>
+__device__ __forceinline__ void hub_slice(int r, const HubIn &H, const double *__restrict__ y0, int b, double *s_part) {
+  const int q = b / kHubSplit, sl = b - q * kHubSplit;
+  const int RB = NT / r;
   const int lj = threadIdx.x / r, t = threadIdx.x - lj * r;
-  const int beg = H.ap[q], end = H.ap[q + 1];
-  const int per = (end - beg + kHubSplit - 1) / kHubSplit;
-  const int lo = beg + sl * per, hi = min(end, lo + per);
+  const int per = (H.k + kHubSplit - 1) / kHubSplit;
+  const int lo = sl * per, hi = min(H.k, lo + per);
   double acc = 0;
   if (lj < RB)
-    for (int p = lo + lj; p < hi; p += RB) acc += H.aval[p] * y[(size_t)H.apos[p] * r + t];
+    for (int j = lo + lj; j < hi; j += RB) acc = fma(H.U[(size_t)j * H.h + q], y0[(size_t)j * r + t], acc);
   s_part[threadIdx.x] = (lj < RB) ? acc : 0.0;
   __syncthreads();
   if ((int)threadIdx.x < r) {
@@ -78,6 +83,12 @@ __global__ __launch_bounds__(kBlock) void k_sp_hub_dot(int r, HubDev H, const do
     for (int u = 0; u < RB; ++u) s += s_part[u * r + threadIdx.x];
     H.w[((size_t)q * kHubSplit + sl) * r + threadIdx.x] = s;
   }
+}
+// (a replay without launches: not produced by the builders, kept so that apply() never skips the hubs)
+__global__ __launch_bounds__(kBlock) void k_sp_hub_slices(int r, HubIn H, const double *__restrict__ y0, Gate g) {
+  if (sp_gated(g.ctl, g.seq, g.gate)) return;
+  __shared__ double s_part[kBlock];
+  hub_slice<kBlock>(r, H, y0, blockIdx.x, s_part);
 }
 // x2 = Sinv w (recomputed by every block: h r values);  Z[perm[j]] = y1[j] - U(j, :) x2;  Z[hub_q] = x2(q, :)
 __global__ __launch_bounds__(kBlock) void k_sp_permute_out_hub(int r, int k, const int *__restrict__ perm,
@@ -89,7 +100,7 @@ __global__ __launch_bounds__(kBlock) void k_sp_permute_out_hub(int r, int k, con
   __shared__ double s_w[64 * 16];
   const double *__restrict__ R = Rb.p[g.ctl ? (g.ctl->cur & 1) : 0];
   const int h = H.h;
-  for (int e = threadIdx.x; e < h * r; e += kBlock) {  // w = b2 - a^T y1: the slices of k_sp_hub_dot in order
+  for (int e = threadIdx.x; e < h * r; e += kBlock) {  // w = b2 - a^T y1: the slices of hub_slice in order
     const int q = e / r, t = e - q * r;
     double s = 0;
     for (int sl = 0; sl < kHubSplit; ++sl) s += H.w[((size_t)q * kHubSplit + sl) * r + t];
@@ -243,11 +254,17 @@ __device__ __forceinline__ void mt_load_sub(const __attribute__((address_space(4
 template <int NC, int U, bool HALF>
 __global__ __launch_bounds__(kMtBlock) void k_sp_mtile(const MWave *__restrict__ recs, const double *__restrict__ vals,
                                                         const int *__restrict__ idxs, double *__restrict__ y, int r,
-                                                        Gate g) {
+                                                        Gate g, int nhubwg, HubIn hub) {
   __shared__ double s_part[kMtWaves][NC * 2][64];
+  // the hubs' dots over the input image (first launch only: nothing has written it yet); they are long chains of few
+  // waves, so they take the grid's first workgroups (at its end they were a 3 us tail)
+  if ((int)blockIdx.x < nhubwg) {
+    if (!sp_gated(g.ctl, g.seq, g.gate)) hub_slice<kMtBlock>(r, hub, y, (int)blockIdx.x, &s_part[0][0][0]);
+    return;
+  }
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   typedef const __attribute__((address_space(4))) int *ConstInts;
-  ConstInts rp = (ConstInts)(recs + ((size_t)blockIdx.x * kMtWaves + wave));
+  ConstInts rp = (ConstInts)(recs + ((size_t)((int)blockIdx.x - nhubwg) * kMtWaves + wave));
   const int t_out = rp[0], t_carry = rp[1], t_nrows = rp[2], t_kind = rp[3], t_first = rp[4], t_n = rp[5], t_solo = rp[7];
   // the gate is tested AFTER the record has been requested: the two loads travel together
   if (sp_gated(g.ctl, g.seq, g.gate)) return;
@@ -315,16 +332,18 @@ __global__ __launch_bounds__(kMtBlock) void k_sp_mtile(const MWave *__restrict__
 }
 
 bool launch_mtile(hipStream_t st, int r, const SpLevel &lv, const MWave *recs, const double *vals, const int *idxs,
-                  double *y, Gate g) {
+                  double *y, Gate g, const HubIn &hub = HubIn()) {
   if (r < 1 || r > 16) return false;
-  if (lv.ntasks == 0) return true;
+  const int extra = hub.h * kHubSplit;
+  if (lv.ntasks + extra == 0) return true;
   const MWave *rp = recs + lv.task0;
+  const dim3 grid(lv.ntasks + extra);
   if (r <= 4)
-    hipLaunchKernelGGL((k_sp_mtile<1, 8, true>), dim3(lv.ntasks), dim3(kMtBlock), 0, st, rp, vals, idxs, y, r, g);
+    hipLaunchKernelGGL((k_sp_mtile<1, 8, true>), grid, dim3(kMtBlock), 0, st, rp, vals, idxs, y, r, g, extra, hub);
   else if (r <= 8)
-    hipLaunchKernelGGL((k_sp_mtile<1, 8, false>), dim3(lv.ntasks), dim3(kMtBlock), 0, st, rp, vals, idxs, y, r, g);
+    hipLaunchKernelGGL((k_sp_mtile<1, 8, false>), grid, dim3(kMtBlock), 0, st, rp, vals, idxs, y, r, g, extra, hub);
   else
-    hipLaunchKernelGGL((k_sp_mtile<2, 4, false>), dim3(lv.ntasks), dim3(kMtBlock), 0, st, rp, vals, idxs, y, r, g);
+    hipLaunchKernelGGL((k_sp_mtile<2, 4, false>), grid, dim3(kMtBlock), 0, st, rp, vals, idxs, y, r, g, extra, hub);
   return true;
 }
 
@@ -577,14 +596,6 @@ int SpImage::upload(const PartInvHost &P, DeviceWeightSink *streamed) {
     const PartInvHub &H = P.hub;
     DCORA_HIP(hub_idx.alloc(H.idx.size()));
     DCORA_HIP(hipMemcpy(hub_idx.p, H.idx.data(), H.idx.size() * sizeof(int), hipMemcpyHostToDevice));
-    DCORA_HIP(hub_ap.alloc(H.ap.size()));
-    DCORA_HIP(hipMemcpy(hub_ap.p, H.ap.data(), H.ap.size() * sizeof(int), hipMemcpyHostToDevice));
-    DCORA_HIP(hub_apos.alloc(std::max<size_t>(H.apos.size(), 1)));
-    DCORA_HIP(hub_aval.alloc(std::max<size_t>(H.aval.size(), 1)));
-    if (!H.apos.empty()) {
-      DCORA_HIP(hipMemcpy(hub_apos.p, H.apos.data(), H.apos.size() * sizeof(int), hipMemcpyHostToDevice));
-      DCORA_HIP(hipMemcpy(hub_aval.p, H.aval.data(), H.aval.size() * sizeof(double), hipMemcpyHostToDevice));
-    }
     DCORA_HIP(hub_U.alloc(H.U.size()));
     DCORA_HIP(hipMemcpy(hub_U.p, H.U.data(), H.U.size() * sizeof(double), hipMemcpyHostToDevice));
     DCORA_HIP(hub_Sinv.alloc(H.Sinv.size()));
@@ -596,8 +607,7 @@ int SpImage::upload(const PartInvHost &P, DeviceWeightSink *streamed) {
 size_t SpImage::device_bytes() const {
   return vals.n * sizeof(double) + (idxs.n + perm.n + out_off.n + in_pos.n + out_pos.n) * sizeof(int) +
          mwaves.n * sizeof(MWave) +
-         (hub_aval.n + hub_U.n + hub_Sinv.n) * sizeof(double) +
-         (hub_idx.n + hub_ap.n + hub_apos.n) * sizeof(int);
+         (hub_U.n + hub_Sinv.n) * sizeof(double) + hub_idx.n * sizeof(int);
 }
 
 int SparsePrecond::attach(std::shared_ptr<const SpImage> image, int rcap_) {
@@ -620,9 +630,8 @@ void SparsePrecond::apply(hipStream_t st, int r, Buf2 R, double *Z, Gate g, bool
                           const std::function<bool()> *after_first) const {
   const SpImage &I = *im;
   const int k = I.k, nhub = I.nhub;
-  const DevBuf<int> &perm = I.perm, &out_off = I.out_off, &hub_idx = I.hub_idx, &hub_ap = I.hub_ap, &hub_apos = I.hub_apos,
-                    &idxs = I.idxs;
-  const DevBuf<double> &vals = I.vals, &hub_aval = I.hub_aval, &hub_U = I.hub_U, &hub_Sinv = I.hub_Sinv;
+  const DevBuf<int> &perm = I.perm, &out_off = I.out_off, &hub_idx = I.hub_idx, &idxs = I.idxs;
+  const DevBuf<double> &vals = I.vals, &hub_U = I.hub_U, &hub_Sinv = I.hub_Sinv;
   const std::vector<SpLevel> &levels = I.levels;
   const long n = (long)r * k;
   const int grid = (int)std::min<long>((n + kBlock - 1) / kBlock, 2048);
@@ -637,15 +646,24 @@ void SparsePrecond::apply(hipStream_t st, int r, Buf2 R, double *Z, Gate g, bool
     hipLaunchKernelGGL(k_sp_permute_in, dim3(grid), dim3(kBlock), 0, st, r, k, perm.p, R, y.p, g);
     if (!go_on()) return;
   }
+  HubIn hin;
+  if (nhub > 0) {
+    hin.h = nhub;
+    hin.k = k;
+    hin.U = hub_U.p;
+    hin.w = hub_w.p;
+  }
+  if (levels.empty() && nhub > 0)
+    hipLaunchKernelGGL(k_sp_hub_slices, dim3(nhub * kHubSplit), dim3(kBlock), 0, st, r, hin, y.p, g);
+  bool first = true;
   for (const SpLevel &lv : levels) {
-    launch_mtile(st, r, lv, I.mwaves.p, vals.p, idxs.p, y.p, g);
+    launch_mtile(st, r, lv, I.mwaves.p, vals.p, idxs.p, y.p, g, first ? hin : HubIn());
+    first = false;
     if (!go_on()) return;
   }
-  if (levels_only && nhub == 0) return;
+  if (levels_only) return;  // the caller's kernel applies the hub correction while it reads y (fold_generic())
   if (nhub > 0) {
-    HubDev H{nhub, hub_idx.p, hub_ap.p, hub_apos.p, hub_aval.p, hub_U.p, hub_Sinv.p, hub_w.p};
-    hipLaunchKernelGGL(k_sp_hub_dot, dim3(nhub * kHubSplit), dim3(kBlock), 0, st, r, H, y.p, g);
-    if (levels_only) return;  // the caller's kernel applies the hub correction while it reads y (fold_generic())
+    HubDev H{nhub, hub_idx.p, hub_U.p, hub_Sinv.p, hub_w.p};
     hipLaunchKernelGGL(k_sp_permute_out_hub, dim3(grid), dim3(kBlock), 0, st, r, k, perm.p, out_off.p, y.p, Z, H, R, g);
   } else {
     hipLaunchKernelGGL(k_sp_permute_out, dim3(grid), dim3(kBlock), 0, st, r, k, perm.p, out_off.p, y.p, Z, g);
@@ -673,7 +691,7 @@ double SparsePrecond::bytes_per_apply(int r) const {
   const SpImage &I = *im;
   return 8.0 * I.weights_per_apply + 128.0 * I.nmwaves_total +
          16.0 * r * I.rows_total +
-         32.0 * r * (double)I.k + 12.0 * I.hub_nnz + 8.0 * (double)I.nhub * I.k;
+         32.0 * r * (double)I.k + 16.0 * (double)I.nhub * I.k + 8.0 * r * (double)I.nhub * I.k;
 }
 
 }  // namespace dcora
