@@ -113,6 +113,18 @@ __device__ __forceinline__ double fast_rsqrt(double d) {
   y = y * fma(-0.5 * d * y, y, 1.5);
   return y;
 }
+// 16 x 16 x 16 product on the matrix pipe (v_mfma_f64_16x16x4_f64, four steps): D += A B with A(i, k) = fa(i, k) and
+// B(k, j) = fb(k, j); at step s lane l feeds A(l & 15, 4 s + (l >> 4)) and B(4 s + (l >> 4), l & 15) and it receives
+// D((l >> 4) + 4 v, l & 15) in d[v].  A result can be the B operand of the next product as it stands: step s wants rows
+// 4 s + (l >> 4) of B, which is d[s].
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+template <class FA, class FB>
+__device__ __forceinline__ v4f64 mma16(v4f64 d, FA fa, FB fb) {
+  const int lane = threadIdx.x & 63, lo = lane & 15, hi = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) d = __builtin_amdgcn_mfma_f64_16x16x4f64(fa(lo, 4 * s + hi), fb(4 * s + hi, lo), d, 0, 0, 0);
+  return d;
+}
 __device__ __forceinline__ bool blocked_potrf64(double (*L)[NB + 1], int *s_bad, double *rd, double (*Dv)[16][17]) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if (tid == 0) *s_bad = 0;
@@ -171,64 +183,32 @@ __device__ __forceinline__ bool blocked_potrf64(double (*L)[NB + 1], int *s_bad,
     if (*s_bad) return false;
     const int nrem = NB - j0 - 16;
     if (nrem > 0) {
-      // panel: rows below times the transposed inverse of the block, X(a, k) = sum_{l <= k} B(a, l) Dinv(k, l); four
-      // threads per row (outputs k = q, q + 4, q + 8, q + 12), the row read before anyone overwrites it
-      double b[16], xo[4];
-      const int a = tid >> 2, q = tid & 3;
-      const bool on = a < nrem;
-      if (on) {
+      // Round 5: panel and trailing update on the matrix pipe, a 16 x 16 block per wave (the FMA forms of round 4 -- four
+      // threads per panel row, a 4 x 4 block of the update per thread -- sat on the LDS port: 6.7 us of the 45 us launch
+      // were the update, 14.6 the scalar LDS loops of update + inverse).
+      const int lo = lane & 15, hi = lane >> 4, r0 = j0 + 16, nbk = nrem >> 4;
+      // panel: rows below times the transposed inverse of the block, X(a, k) = sum_{l <= k} B(a, l) Dinv(k, l); a wave
+      // reads only the 16 rows it writes, and writes them after its products
+      if (wave < nbk) {
+        const int rw = r0 + 16 * wave, bq = j0 >> 4;
+        const v4f64 d = mma16(
+            v4f64{0, 0, 0, 0}, [&](int i, int k) { return L[rw + i][j0 + k]; },
+            [&](int k, int j) { return k <= j ? Dv[bq][j][k] : 0.0; });
 #pragma unroll
-        for (int l = 0; l < 16; ++l) b[l] = L[j0 + 16 + a][j0 + l];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int k = q + 4 * u;
-          double sacc = 0;
-#pragma unroll
-          for (int l = 0; l < 16; ++l) sacc += (l <= k) ? b[l] * Dv[j0 >> 4][k][l] : 0.0;
-          xo[u] = sacc;
-        }
+        for (int v = 0; v < 4; ++v) L[rw + hi + 4 * v][j0 + lo] = d[v];
       }
       __syncthreads();
-      if (on) {
+      // trailing update of the lower triangle by the rank-16 product of the panel with itself: the 6 / 3 / 1 lower blocks
+      // of the three steps dealt to the four waves (they read columns j0 .. j0 + 15 and write columns beyond)
+      for (int tb = wave; tb < nbk * (nbk + 1) / 2; tb += 4) {
+        const int bi = tb < 1 ? 0 : (tb < 3 ? 1 : 2), bj = tb - bi * (bi + 1) / 2;
+        const int ia = r0 + 16 * bi, ib = r0 + 16 * bj;
+        const v4f64 d = mma16(
+            v4f64{0, 0, 0, 0}, [&](int i, int k) { return L[ia + i][j0 + k]; },
+            [&](int k, int j) { return L[ib + j][j0 + k]; });
 #pragma unroll
-        for (int u = 0; u < 4; ++u) L[j0 + 16 + a][j0 + q + 4 * u] = xo[u];
-      }
-      __syncthreads();
-      // trailing update of the lower triangle by the rank-16 product of the panel with itself, a 4 x 4 block of it per
-      // thread: 8 LDS reads per 16 FMAs where one output per thread needed 32 (the update was 4.2 / 1.9 / 0.6 us of the
-      // three steps of a 45 us launch, on the LDS port)
-      {
-        const int nbk = nrem >> 2, nblocks = nbk * (nbk + 1) / 2;
-        if (tid < nblocks) {
-          int bi = (int)((sqrtf(8.0f * (float)tid + 1.0f) - 1.0f) * 0.5f);
-          while ((bi + 1) * (bi + 2) / 2 <= tid) ++bi;
-          while (bi * (bi + 1) / 2 > tid) --bi;
-          const int bj = tid - bi * (bi + 1) / 2;
-          const int ia = j0 + 16 + 4 * bi, ib = j0 + 16 + 4 * bj;
-          double acc[4][4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
-#pragma unroll
-          for (int l = 0; l < 16; ++l) {
-            double av[4], bv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              av[u] = L[ia + u][j0 + l];
-              bv[u] = L[ib + u][j0 + l];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-              for (int v = 0; v < 4; ++v) acc[u][v] += av[u] * bv[v];
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int v = 0; v < 4; ++v)
-              if (ib + v <= ia + u) L[ia + u][ib + v] -= acc[u][v];
-        }
+        for (int v = 0; v < 4; ++v)
+          if (ib + lo <= ia + hi + 4 * v) L[ia + hi + 4 * v][ib + lo] -= d[v];
       }
       __syncthreads();
     }
@@ -249,27 +229,27 @@ __device__ __forceinline__ void blocked_trtri64(double (*L)[NB + 1], double (*Li
     if (c_ <= a) Li[16 * bq + a][16 * bq + c_] = Dv[bq][a][c_];
   }
   __syncthreads();
-  // block (bi, bj), bi - bj = dist:  Li_ij = -Li_ii (sum_{bk = bj}^{bi - 1} L_i,bk Li_bk,j)
+  // block (bi, bj), bi - bj = dist:  Li_ij = -Li_ii (sum_{bk = bj}^{bi - 1} L_i,bk Li_bk,j): one wave per block, both
+  // products on the matrix pipe; the inner sum stays in registers (a result is the next product's B operand as it
+  // stands), so a distance costs one barrier where the FMA form of round 4 paid two and 32 LDS reads per output
+  const int wave = tid >> 6, lo = tid & 15, hi = (tid & 63) >> 4;
+  (void)Ts;
   for (int dist = 1; dist < 4; ++dist) {
-    const int nblk = 4 - dist;
-    for (int e = tid; e < nblk * 256; e += 256) {
-      const int q = e >> 8, a = (e >> 4) & 15, c_ = e & 15;
-      const int bj = q, bi = q + dist;
-      double sacc = 0;
+    if (wave < 4 - dist) {
+      const int bj = wave, bi = wave + dist;
+      v4f64 t{0, 0, 0, 0};
       for (int bk = bj; bk < bi; ++bk)
+        t = mma16(
+            t, [&](int i, int k) { return L[16 * bi + i][16 * bk + k]; },
+            [&](int k, int j) { return Li[16 * bk + k][16 * bj + j]; });
+      v4f64 d{0, 0, 0, 0};
 #pragma unroll
-        for (int l = 0; l < 16; ++l) sacc += L[16 * bi + a][16 * bk + l] * Li[16 * bk + l][16 * bj + c_];
-      Ts[16 * q + a][c_] = sacc;
-    }
-    __syncthreads();
-    for (int e = tid; e < nblk * 256; e += 256) {
-      const int q = e >> 8, a = (e >> 4) & 15, c_ = e & 15;
-      const int bj = q, bi = q + dist;
-      double sacc = 0;
+      for (int s = 0; s < 4; ++s) {
+        const int k = 4 * s + hi;
+        d = __builtin_amdgcn_mfma_f64_16x16x4f64(k <= lo ? Li[16 * bi + lo][16 * bi + k] : 0.0, t[s], d, 0, 0, 0);
+      }
 #pragma unroll
-      for (int l = 0; l < 16; ++l)
-        if (l <= a) sacc += Li[16 * bi + a][16 * bi + l] * Ts[16 * q + l][c_];
-      Li[16 * bi + a][16 * bj + c_] = -sacc;
+      for (int v = 0; v < 4; ++v) Li[16 * bi + hi + 4 * v][16 * bj + lo] = -d[v];
     }
     __syncthreads();
   }
@@ -324,7 +304,6 @@ __global__ __launch_bounds__(256) void k_chol_potrf(const PieceDev *__restrict__
 // for the workgroup against 64 of FMA).  MMA = true: v_mfma_f64_16x16x4_f64, every wave owns a 32 x 32 quadrant as
 // 2 x 2 blocks; 4 LDS reads per 4 MFMAs (8192 flop), the matrix pipe is the bound.  The two forms keep their 16 sums
 // per thread in acc[4][4] under different maps (acc_row / acc_col).
-typedef double v4f64 __attribute__((ext_vector_type(4)));
 template <bool MMA>
 __device__ __forceinline__ int acc_row(int u, int v) {
   if (MMA) return (int)(threadIdx.x >> 7) * 32 + (u >> 1) * 16 + (int)((threadIdx.x & 63) >> 4) + 4 * v;
