@@ -182,7 +182,7 @@ class SparsePrecond {
   // the same for the generic-layout kernels (k_tcg_update1 / k_tangent), which also apply the hub correction
   SpFold fold_generic() const;
   int attach(std::shared_ptr<const SpImage> image, int rcap);
-  int launches() const { return (int)im->levels.size() + 2 + (im->nhub > 0 ? 1 : 0); }
+  int launches() const { return (int)im->levels.size() + 2; }  // permutation in, the levels, permutation out
   // Z = R A^-1 for r <= rcap right-hand sides (r x k column-major); R is picked by ctl->cur when g.ctl is set.
   // levels_only: the right-hand side is already in y and the result is read from y (fold())
   // after_first: called once the first launch of the replay is enqueued; returning false ends the enqueue there (the
