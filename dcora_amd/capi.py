@@ -171,6 +171,7 @@ SIGNATURES = {
     "dcora_debug_exchange_leave_stale": (C.c_int, [C.c_char_p, C.c_int, C.c_int]),
     "dcora_debug_exchange_probe_fault": (C.c_int, [C.c_int]),
     "dcora_debug_tcg_run_fault": (C.c_int, [C.c_int]),
+    "dcora_debug_tcg_run_fault_at": (C.c_int, [C.c_int, C.c_int]),
     "dcora_problem_solver_info": (C.c_int, [_vp, _dp]),
     "dcora_ra_rbcd_create": (C.c_int, [_vp, C.POINTER(RbcdOptions), C.POINTER(_vp)]),
     "dcora_ra_rbcd_destroy": (C.c_int, [_vp]),

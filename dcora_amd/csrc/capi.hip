@@ -261,6 +261,12 @@ int dcora_problem_solver_info(dcora_problem_t p, double *info) {
   return DCORA_OK;
 }
 int dcora_debug_tcg_run_fault(int runs) {
+  g_tcg_run_fault_skip.store(0);
+  g_tcg_run_fault.store(runs < 0 ? 0 : runs);
+  return DCORA_OK;
+}
+int dcora_debug_tcg_run_fault_at(int skip, int runs) {
+  g_tcg_run_fault_skip.store(skip < 0 ? 0 : skip);
   g_tcg_run_fault.store(runs < 0 ? 0 : runs);
   return DCORA_OK;
 }

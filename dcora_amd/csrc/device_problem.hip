@@ -1058,14 +1058,25 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
   };
   int next_first_seq = time_is_up() ? 0 : enqueue_first();
   auto run_gave_up = [&]() { return run_form && hf->tcg_abort_seq >= solve_first; };
-  for (int outer = 0; outer < max_outer; ++outer) {
-    if (next_first_seq < 0) {
+  // The host runs ahead of the device by design, but it must not LEAVE while a one-launch run may still give up: the
+  // recovery below is the only place that repeats the iteration, and what the caller enqueues next builds on its
+  // result.  So with the run form the loop takes one more turn after the last iteration (`tail`), which only waits
+  // until that run has ended (its first workgroup raises last_seq_done when the run finishes; a run that finishes has
+  // not given up: run_grid_step) or has given up -- then the turn repeats the iteration on the launches like any other.
+  // (Round 5: without it a last iteration whose run gave up was lost without a trace -- a flaky bit difference between
+  // ranks sharing one GPU, where other ranks' waiting kernels keep the grid from being co-resident.)
+  int last_run_seq = 0;
+  for (int outer = 0; outer < max_outer || (run_form && last_run_seq > 0); ++outer) {
+    const bool tail = outer >= max_outer;
+    if (!tail && next_first_seq < 0) {
       DCORA_HIP(hipStreamSynchronize(st));
       set_last_error("k_fused_pc could not be launched on this device");
       return DCORA_ERR_HIP;
     }
-    if (!spin_until([&] { return hf->last_seq_done >= last_pace_seq || outer_done() || run_gave_up(); }, 20.0))
+    const int need_seq = tail ? last_run_seq : last_pace_seq;
+    if (!spin_until([&] { return hf->last_seq_done >= need_seq || outer_done() || run_gave_up(); }, 20.0))
       return timed_out();
+    if (tail && !run_gave_up()) break;
     if (run_gave_up()) {
       // The one-launch run of iteration `outer` (or the one before: its evaluation and decision were queued behind it)
       // found its grid not co-resident and left; everything queued behind it was a no-op (outer_done_stamp).  Re-arm
@@ -1089,6 +1100,7 @@ int DeviceProblem::rtr_dev_fused(const dcora_ropt_params &prm) {
     if (next_first_seq == 0) break;  // the time bound had passed when this iteration's first kernel was due
     // z0 = P(grad): B in "first" mode streams the preconditioner over grad, C projects and forms <z0, r0>
     const int tcg_first_seq = next_first_seq;
+    last_run_seq = run_form ? tcg_first_seq : 0;
     if (!pc) {
       // A rejected step (k_rtr_decide said so in reject_seq) left the iterate and its gradient where they were: z0 is
       // the one of the iteration before, whose unprojected form the finish kernel kept in W (free on this path) --

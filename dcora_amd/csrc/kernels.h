@@ -255,6 +255,7 @@ int fused_pc_blocks(const ManiDesc &m);
 bool tcg_run_supported(const ManiDesc &m, int ldm, int cus, int max_rows_nnz);
 int tcg_run_sync_words();
 extern std::atomic<int> g_tcg_run_fault;  // test hook: that many of the next runs lose workgroup 0 before the first step
+extern std::atomic<int> g_tcg_run_fault_skip;  // ... after this many launches of the run kernel that pass untouched
 int tcg_run_max_rows_nnz(const ManiDesc &m, const int *rowptr);  // host CSR row pointers -> the figure above
 // returns the number of workgroups (= <z, r> and pC partial pairs), < 0 when the launch is refused
 int launch_tcg_run(hipStream_t st, const ManiDesc &m, int ldm, const double *Minv, const CsrDev &Q, Buf2 grad, Buf2 X,

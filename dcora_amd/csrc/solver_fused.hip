@@ -1495,6 +1495,12 @@ __device__ __forceinline__ double2 pc_ld16_coh(__amdgpu_buffer_rsrc_t rs, unsign
 }
 // grid-wide step `step` (0, 1, 2, ...) of this launch: sharded arrival counters, the last arrival replicates the done
 // word, workgroup i polls copy i % 64.  false: this workgroup (or another one) gave up.
+// Giving up is decided on the SAME word that counts the completed shards (its top bit): a workgroup whose wait ran out
+// sets the bit by compare-and-swap only while the count is incomplete, and the arrival that completes the count
+// publishes the done word only if its own increment found the bit clear.  So either the step completes for everybody
+// or nobody passes it: a workgroup that was descheduled past its 2 ms while the others completed the step does not
+// abort a run the others go on to finish (seen with four ranks sharing one GPU, where waits of milliseconds are routine).
+constexpr unsigned kRunAbortBit = 0x80000000u;
 __device__ __forceinline__ bool run_grid_step(unsigned *sync, unsigned step, int *s_ok) {
   __builtin_amdgcn_s_waitcnt(0);  // this wave's write-through stores are acknowledged
   __syncthreads();
@@ -1503,15 +1509,15 @@ __device__ __forceinline__ bool run_grid_step(unsigned *sync, unsigned step, int
              *abort_w = done + kRunCopies * kRunStride;
     const int i = blockIdx.x, G = gridDim.x, sh = i % kRunShards;
     const unsigned in_shard = (unsigned)((G - sh + kRunShards - 1) / kRunShards), want = step + 1;
+    const unsigned shards_used = (unsigned)(G < kRunShards ? G : kRunShards);
     const unsigned a = __hip_atomic_fetch_add(shard + sh * kRunStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (a + 1 == want * in_shard) {
-      const unsigned shards_used = (unsigned)(G < kRunShards ? G : kRunShards);
       const unsigned b = __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (b + 1 == want * shards_used)
+      if (!(b & kRunAbortBit) && b + 1 == want * shards_used)
         for (int c = 0; c < kRunCopies; ++c)
           __hip_atomic_store(done + c * kRunStride, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    const long long t0 = wall_clock64();
+    long long t0 = wall_clock64();
     const unsigned *p = done + (i % kRunCopies) * kRunStride;
     int ok = 1;
     unsigned spins = 0;
@@ -1523,9 +1529,26 @@ __device__ __forceinline__ bool run_grid_step(unsigned *sync, unsigned step, int
           break;
         }
         if (wall_clock64() - t0 > 200000) {  // 2 ms at 100 MHz: the grid is not co-resident
-          __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok = 0;
-          break;
+          unsigned cur = __hip_atomic_load(top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          bool gave_up = false;
+          for (;;) {
+            if (cur & kRunAbortBit) {  // somebody else gave up
+              gave_up = true;
+              break;
+            }
+            if (cur >= want * shards_used) break;  // everybody has arrived: the done word is on its way
+            if (__hip_atomic_compare_exchange_strong(top, &cur, cur | kRunAbortBit, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT)) {
+              gave_up = true;
+              break;
+            }
+          }
+          if (gave_up) {
+            __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = 0;
+            break;
+          }
+          t0 = wall_clock64();
         }
       }
     }
@@ -2707,6 +2730,7 @@ static int fused_pc_dispatch(hipStream_t st, const ManiDesc &m, int ldm, const d
 constexpr int kRunNS = 4;  // 128-column steps per wave held in registers: k <= 4 * 4 * 128 = 2048
 int tcg_run_sync_words() { return kRunSyncWords; }
 std::atomic<int> g_tcg_run_fault{0};
+std::atomic<int> g_tcg_run_fault_skip{0};
 int tcg_run_max_rows_nnz(const ManiDesc &m, const int *rp) {
   const int dh = m.d + 1;
   int worst = 0;
@@ -2754,7 +2778,13 @@ int launch_tcg_run(hipStream_t st, const ManiDesc &m, int ldm, const double *Min
                    Buf2 S, double *d0, double *d1, double *Hd, double *eta, double *Heta, double *z, double *p1r,
                    double *p3, double *pC, unsigned *sync, SolverCtl *ctl, HostFlags *hf, int seq) {
   int fault = 0;
-  for (int left = g_tcg_run_fault.load(); left > 0;)
+  bool skipped = false;
+  for (int sk = g_tcg_run_fault_skip.load(); sk > 0;)
+    if (g_tcg_run_fault_skip.compare_exchange_weak(sk, sk - 1)) {
+      skipped = true;
+      break;
+    }
+  for (int left = skipped ? 0 : g_tcg_run_fault.load(); left > 0;)
     if (g_tcg_run_fault.compare_exchange_weak(left, left - 1)) {
       fault = 1;
       break;

@@ -117,6 +117,8 @@ int dcora_problem_solver_info(dcora_problem_t p, double *info);
 /* test hook: the next `runs` one-launch tCG runs of this process lose a workgroup before their first grid-wide step, as
  * if the grid were not co-resident: the run must give up within milliseconds and the solve continue on the launches */
 int dcora_debug_tcg_run_fault(int runs);
+/* the same after `skip` launches of the run kernel that pass untouched (to hit the LAST iteration of a solve) */
+int dcora_debug_tcg_run_fault_at(int skip, int runs);
 /* PreCondition (ref :70-84, 261-297) */
 int dcora_problem_precondition(dcora_problem_t p, const double *X, const double *V, double *out);
 /* Retract (ref :125-136, 236-259) */
