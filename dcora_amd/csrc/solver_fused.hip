@@ -2715,8 +2715,12 @@ static int fused_pc_dispatch(hipStream_t st, const ManiDesc &m, int ldm, const d
     if (pb == 2 && !multi) DCORA_PC_R(3, 2, false);
     if (pb == 2) DCORA_PC_R(3, 2, true);
     // four poses per thread with r only known at run time does not fit the register file (208 B/lane of scratch when
-    // it was instantiated): r > 7 takes the three-launch form, which fused_pc_preferred() chooses there anyway
-    DCORA_PC_FIXED_R(3, 4, true);
+    // it was instantiated), and neither does r = 7 (128 B/lane): r >= 7 beyond 768 poses takes the three-launch form,
+    // which fused_pc_preferred() chooses there anyway
+    if (m.r == 3) DCORA_PC(3, 4, 3, true);
+    if (m.r == 4) DCORA_PC(3, 4, 4, true);
+    if (m.r == 5) DCORA_PC(3, 4, 5, true);
+    if (m.r == 6) DCORA_PC(3, 4, 6, true);
     return -1;
   }
   if (pb == 2 && !multi) DCORA_PC(2, 2, 0, false);
