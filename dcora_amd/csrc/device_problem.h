@@ -167,7 +167,7 @@ class SparsePrecond {
  public:
   std::shared_ptr<const SpImage> im;  // the stored inverse (read-only)
   int rcap = 0;
-  DevBuf<double> y, hub_w;            // this problem's replay vector (two ping-pong images) and hub scratch
+  DevBuf<double> y, hub_w, hub_x2;    // this problem's replay vector (two ping-pong images) and hub scratch
   double weights_per_apply = 0;
   bool foldable() const { return im && im->nhub == 0 && im->in_pos.p != nullptr; }
   SpFold fold() const {

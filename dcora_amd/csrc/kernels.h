@@ -145,10 +145,11 @@ struct SpFold {
   double *y = nullptr;
   const int *in_pos = nullptr, *out_pos = nullptr;
   // hubs (sparse_precond.h, PartInvHub; the generic-layout kernels only): in_pos / out_pos are -1 on a hub unknown,
-  // z = y1 - U x2 with x2 = Sinv (r(hub) - slices of hub_slice, sparse_precond.hip), z(hub) = x2
-  int h = 0, hub_split = 0;
+  // z = y1 - U x2, z(hub) = x2, with x2 = Sinv (r(hub) - U^T r1) (h x r values) formed inside the replay's launches
+  // (hub_slice / hub_x2, sparse_precond.hip) -- the consumer reads it as it stands
+  int h = 0;
   const int *hub_idx = nullptr;
-  const double *hub_U = nullptr, *hub_Sinv = nullptr, *hub_w = nullptr;
+  const double *hub_U = nullptr, *hub_x2 = nullptr;
 };
 // out = Proj_X(V); partial <out, R> when R != null.  When p2 != null the prologue evaluates the tCG
 // residual stopping rule |r| <= |r0| min(|r0|^theta, kappa) from the np2 partials of |r|^2.

@@ -957,7 +957,7 @@ __global__ __launch_bounds__(kBlock) void k_tangent(ManiDesc m, Buf2 Xb, const d
   double pv = (p2 && (int)threadIdx.x < np2) ? p2[threadIdx.x] : 0.0;
   const double n0 = p2 ? ctl->norm_r0 : 0.0;
   const bool hub0 = folded && sf.h > 0 && (int)threadIdx.x < sf.h * r;
-  int hidx0 = hub0 ? sf.hub_idx[threadIdx.x / r] : 0;
+  double x2_0 = hub0 ? sf.hub_x2[threadIdx.x] : 0.0;
   const long it0 = (long)blockIdx.x * kBlock + threadIdx.x;
   int jp_pre[D], op_pre[D];
 #pragma unroll
@@ -976,7 +976,7 @@ __global__ __launch_bounds__(kBlock) void k_tangent(ManiDesc m, Buf2 Xb, const d
   }
 #pragma unroll
   for (int a = 0; a < D; ++a) asm volatile("" ::"v"(jp_pre[a]), "v"(op_pre[a]));
-  asm volatile("" ::"v"(pv), "v"(n0), "v"(hidx0), "s"(gw.outer), "s"(gw.tcg));
+  asm volatile("" ::"v"(pv), "v"(n0), "v"(x2_0), "s"(gw.outer), "s"(gw.tcg));
   if (gated(gw, ctl, seq, gate)) return;
   if (p2) {
     // ROPTLIB tCG_TR stopping rule (theta = 1, kappa = 0.1): |r| <= |r0| min(|r0|^theta, kappa)
@@ -997,34 +997,11 @@ __global__ __launch_bounds__(kBlock) void k_tangent(ManiDesc m, Buf2 Xb, const d
   }
   const double *X = pick(Xb, ctl, 0);
   // sparse preconditioner folded in (generic layout): V(col, t) is read from where the level replay left it, with the
-  // hub correction of k_sp_permute_out_hub; x2 = Sinv (R(hub) - a^T y1) is rebuilt by every workgroup
+  // hub correction of k_sp_permute_out_hub; x2 = Sinv (R(hub) - U^T r1) comes ready from the replay's second launch
+  // (round 4 rebuilt it here in every workgroup: two dependent rounds of loads and two barriers in front of the items)
   if (folded && sf.h > 0) {
-    // two steps with all slice loads of a step in flight together (same summation order as the one-loop form: every
-    // w(q2, t) is R minus its slices in slice order, every x2(q, t) the sum over q2 in order)
-    __shared__ double s_w[64 * 16];
-    for (int e = threadIdx.x; e < sf.h * r; e += kBlock) {
-      const int q2 = e / r, t = e - q2 * r;
-      const int hidx = (e == (int)threadIdx.x) ? hidx0 : sf.hub_idx[q2];
-      double w = R[(size_t)hidx * r + t];
-      const double *__restrict__ hw = sf.hub_w + (size_t)q2 * sf.hub_split * r + t;
-      int sl = 0;
-      for (; sl + 32 <= sf.hub_split; sl += 32) {  // (the split is 32: every slice of a hub in flight at once)
-        double v[32];
-#pragma unroll
-        for (int u = 0; u < 32; ++u) v[u] = hw[(size_t)(sl + u) * r];
-#pragma unroll
-        for (int u = 0; u < 32; ++u) w -= v[u];
-      }
-      for (; sl < sf.hub_split; ++sl) w -= hw[(size_t)sl * r];
-      s_w[e] = w;
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < sf.h * r; e += kBlock) {
-      const int q = e / r, t = e - q * r;
-      double s = 0;
-      for (int q2 = 0; q2 < sf.h; ++q2) s += sf.hub_Sinv[(size_t)q * sf.h + q2] * s_w[q2 * r + t];
-      s_x2[e] = s;
-    }
+    if (hub0) s_x2[threadIdx.x] = x2_0;
+    for (int e = threadIdx.x + kBlock; e < sf.h * r; e += kBlock) s_x2[e] = sf.hub_x2[e];
     __syncthreads();
   }
   // NC consecutive columns starting at col0: positions first (the thread's first item: requested in the prologue), then

@@ -52,8 +52,8 @@ __global__ __launch_bounds__(kBlock) void k_sp_permute_out(int r, int k, const i
 struct HubDev {
   int h;
   const int *idx;
-  const double *U, *Sinv;
-  double *w;  // h x kHubSplit x r scratch: the slices of a^T y1
+  const double *U;
+  const double *x2;  // h x r: Sinv (R(hub) - U^T r1), formed by hub_x2 below
 };
 // w(q, :) = R(hub_q, :) - a_q^T y1 with y1 = A11^-1 r1, and a_q^T A11^-1 r1 = U(:, q)^T r1 (U = A11^-1 a is stored for
 // the correction anyway, A11 symmetric): the dot runs over the INPUT image of the replay -- dense, contiguous, and it
@@ -63,8 +63,13 @@ struct HubDev {
 constexpr int kHubSplit = 32;
 struct HubIn {
   int h = 0, k = 0;
+  int stage = 0;  // 1: the slices of U^T r1 (replay's first launch); 2: x2 from the slices (one workgroup, second launch)
   const double *U = nullptr;
-  double *w = nullptr;
+  double *w = nullptr;  // h x kHubSplit x r slices
+  const int *idx = nullptr;
+  const double *Sinv = nullptr;
+  Buf2 R{{nullptr, nullptr}};
+  double *x2 = nullptr;
 };
 template <int NT>
 __device__ __forceinline__ void hub_slice(int r, const HubIn &H, const double *__restrict__ y0, int b, double *s_part) {
@@ -84,35 +89,47 @@ __device__ __forceinline__ void hub_slice(int r, const HubIn &H, const double *_
     H.w[((size_t)q * kHubSplit + sl) * r + threadIdx.x] = s;
   }
 }
-// (a replay without launches: not produced by the builders, kept so that apply() never skips the hubs)
-__global__ __launch_bounds__(kBlock) void k_sp_hub_slices(int r, HubIn H, const double *__restrict__ y0, Gate g) {
-  if (sp_gated(g.ctl, g.seq, g.gate)) return;
-  __shared__ double s_part[kBlock];
-  hub_slice<kBlock>(r, H, y0, blockIdx.x, s_part);
-}
-// x2 = Sinv w (recomputed by every block: h r values);  Z[perm[j]] = y1[j] - U(j, :) x2;  Z[hub_q] = x2(q, :)
-__global__ __launch_bounds__(kBlock) void k_sp_permute_out_hub(int r, int k, const int *__restrict__ perm,
-                                                               const int *__restrict__ out_off,
-                                                               const double *__restrict__ y,
-                                                               double *__restrict__ Z, HubDev H, Buf2 Rb, Gate g) {
-  if (sp_gated(g.ctl, g.seq, g.gate)) return;
-  __shared__ double s_x2[64 * 16];
-  __shared__ double s_w[64 * 16];
-  const double *__restrict__ R = Rb.p[g.ctl ? (g.ctl->cur & 1) : 0];
-  const int h = H.h;
-  for (int e = threadIdx.x; e < h * r; e += kBlock) {  // w = b2 - a^T y1: the slices of hub_slice in order
+// x2 = Sinv w with w(q, :) = R(hub_q, :) - the slices in slice order: h r values, ONE workgroup, riding in the replay's
+// second launch (the consumers -- k_tangent of the generic solver, k_sp_permute_out_hub -- rebuilt it in every workgroup:
+// two dependent rounds of loads and two barriers in front of their real work).  s_w: h * r doubles of LDS.
+template <int NT>
+__device__ __forceinline__ void hub_x2(int r, const HubIn &H, const SolverCtl *ctl, double *s_w) {
+  const double *__restrict__ R = H.R.p[ctl ? (ctl->cur & 1) : 0];
+  for (int e = threadIdx.x; e < H.h * r; e += NT) {
     const int q = e / r, t = e - q * r;
     double s = 0;
     for (int sl = 0; sl < kHubSplit; ++sl) s += H.w[((size_t)q * kHubSplit + sl) * r + t];
     s_w[e] = R[(size_t)H.idx[q] * r + t] - s;
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < h * r; e += kBlock) {
+  for (int e = threadIdx.x; e < H.h * r; e += NT) {
     const int q = e / r, t = e - q * r;
     double s = 0;
-    for (int q2 = 0; q2 < h; ++q2) s += H.Sinv[(size_t)q * h + q2] * s_w[q2 * r + t];
+    for (int q2 = 0; q2 < H.h; ++q2) s += H.Sinv[(size_t)q * H.h + q2] * s_w[q2 * r + t];
+    H.x2[e] = s;
+  }
+}
+// (a replay of fewer than two launches: the stage that found no launch to ride in)
+__global__ __launch_bounds__(kBlock) void k_sp_hub_stage(int r, HubIn H, const double *__restrict__ y0, Gate g) {
+  if (sp_gated(g.ctl, g.seq, g.gate)) return;
+  __shared__ double s_part[64 * 16];
+  if (H.stage == 1)
+    hub_slice<kBlock>(r, H, y0, blockIdx.x, s_part);
+  else
+    hub_x2<kBlock>(r, H, g.ctl, s_part);
+}
+// Z[perm[j]] = y1[j] - U(j, :) x2;  Z[hub_q] = x2(q, :)
+__global__ __launch_bounds__(kBlock) void k_sp_permute_out_hub(int r, int k, const int *__restrict__ perm,
+                                                               const int *__restrict__ out_off,
+                                                               const double *__restrict__ y,
+                                                               double *__restrict__ Z, HubDev H, Gate g) {
+  if (sp_gated(g.ctl, g.seq, g.gate)) return;
+  __shared__ double s_x2[64 * 16];
+  const int h = H.h;
+  for (int e = threadIdx.x; e < h * r; e += kBlock) {
+    const double s = H.x2[e];
     s_x2[e] = s;
-    if (blockIdx.x == 0) Z[(size_t)H.idx[q] * r + t] = s;
+    if (blockIdx.x == 0) Z[(size_t)H.idx[e / r] * r + (e - (e / r) * r)] = s;
   }
   __syncthreads();
   const long n = (long)r * k;
@@ -259,7 +276,12 @@ __global__ __launch_bounds__(kMtBlock) void k_sp_mtile(const MWave *__restrict__
   // the hubs' dots over the input image (first launch only: nothing has written it yet); they are long chains of few
   // waves, so they take the grid's first workgroups (at its end they were a 3 us tail)
   if ((int)blockIdx.x < nhubwg) {
-    if (!sp_gated(g.ctl, g.seq, g.gate)) hub_slice<kMtBlock>(r, hub, y, (int)blockIdx.x, &s_part[0][0][0]);
+    if (!sp_gated(g.ctl, g.seq, g.gate)) {
+      if (hub.stage == 1)
+        hub_slice<kMtBlock>(r, hub, y, (int)blockIdx.x, &s_part[0][0][0]);
+      else
+        hub_x2<kMtBlock>(r, hub, g.ctl, &s_part[0][0][0]);
+    }
     return;
   }
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
@@ -334,7 +356,7 @@ __global__ __launch_bounds__(kMtBlock) void k_sp_mtile(const MWave *__restrict__
 bool launch_mtile(hipStream_t st, int r, const SpLevel &lv, const MWave *recs, const double *vals, const int *idxs,
                   double *y, Gate g, const HubIn &hub = HubIn()) {
   if (r < 1 || r > 16) return false;
-  const int extra = hub.h * kHubSplit;
+  const int extra = hub.stage == 1 ? hub.h * kHubSplit : (hub.stage == 2 ? 1 : 0);
   if (lv.ntasks + extra == 0) return true;
   const MWave *rp = recs + lv.task0;
   const dim3 grid(lv.ntasks + extra);
@@ -622,6 +644,8 @@ int SparsePrecond::attach(std::shared_ptr<const SpImage> image, int rcap_) {
   if (im->nhub > 0) {
     DCORA_HIP(hub_w.alloc((size_t)im->nhub * kHubSplit * rcap));
     DCORA_HIP(hipMemset(hub_w.p, 0, (size_t)im->nhub * kHubSplit * rcap * sizeof(double)));
+    DCORA_HIP(hub_x2.alloc((size_t)im->nhub * rcap));
+    DCORA_HIP(hipMemset(hub_x2.p, 0, (size_t)im->nhub * rcap * sizeof(double)));
   }
   return DCORA_OK;
 }
@@ -632,6 +656,7 @@ void SparsePrecond::apply(hipStream_t st, int r, Buf2 R, double *Z, Gate g, bool
   const int k = I.k, nhub = I.nhub;
   const DevBuf<int> &perm = I.perm, &out_off = I.out_off, &hub_idx = I.hub_idx, &idxs = I.idxs;
   const DevBuf<double> &vals = I.vals, &hub_U = I.hub_U, &hub_Sinv = I.hub_Sinv;
+  const DevBuf<double> &hub_x2 = this->hub_x2;
   const std::vector<SpLevel> &levels = I.levels;
   const long n = (long)r * k;
   const int grid = (int)std::min<long>((n + kBlock - 1) / kBlock, 2048);
@@ -646,25 +671,37 @@ void SparsePrecond::apply(hipStream_t st, int r, Buf2 R, double *Z, Gate g, bool
     hipLaunchKernelGGL(k_sp_permute_in, dim3(grid), dim3(kBlock), 0, st, r, k, perm.p, R, y.p, g);
     if (!go_on()) return;
   }
+  // hubs: stage 1 (the slices of U^T r1 over the input image) rides in the first launch, stage 2 (x2 from the slices)
+  // in the second; a stage that finds no launch gets one of its own
   HubIn hin;
   if (nhub > 0) {
     hin.h = nhub;
     hin.k = k;
     hin.U = hub_U.p;
     hin.w = hub_w.p;
+    hin.idx = hub_idx.p;
+    hin.Sinv = hub_Sinv.p;
+    hin.R = R;
+    hin.x2 = hub_x2.p;
   }
+  auto stage = [&](int s) {
+    HubIn hs = hin;
+    hs.stage = s;
+    return hs;
+  };
   if (levels.empty() && nhub > 0)
-    hipLaunchKernelGGL(k_sp_hub_slices, dim3(nhub * kHubSplit), dim3(kBlock), 0, st, r, hin, y.p, g);
-  bool first = true;
+    hipLaunchKernelGGL(k_sp_hub_stage, dim3(nhub * kHubSplit), dim3(kBlock), 0, st, r, stage(1), y.p, g);
+  int li = 0;
   for (const SpLevel &lv : levels) {
-    launch_mtile(st, r, lv, I.mwaves.p, vals.p, idxs.p, y.p, g, first ? hin : HubIn());
-    first = false;
+    launch_mtile(st, r, lv, I.mwaves.p, vals.p, idxs.p, y.p, g, (nhub > 0 && li < 2) ? stage(li + 1) : HubIn());
+    ++li;
     if (!go_on()) return;
   }
+  if (nhub > 0 && levels.size() < 2) hipLaunchKernelGGL(k_sp_hub_stage, dim3(1), dim3(kBlock), 0, st, r, stage(2), y.p, g);
   if (levels_only) return;  // the caller's kernel applies the hub correction while it reads y (fold_generic())
   if (nhub > 0) {
-    HubDev H{nhub, hub_idx.p, hub_U.p, hub_Sinv.p, hub_w.p};
-    hipLaunchKernelGGL(k_sp_permute_out_hub, dim3(grid), dim3(kBlock), 0, st, r, k, perm.p, out_off.p, y.p, Z, H, R, g);
+    HubDev H{nhub, hub_idx.p, hub_U.p, hub_x2.p};
+    hipLaunchKernelGGL(k_sp_permute_out_hub, dim3(grid), dim3(kBlock), 0, st, r, k, perm.p, out_off.p, y.p, Z, H, g);
   } else {
     hipLaunchKernelGGL(k_sp_permute_out, dim3(grid), dim3(kBlock), 0, st, r, k, perm.p, out_off.p, y.p, Z, g);
   }
@@ -677,11 +714,9 @@ SpFold SparsePrecond::fold_generic() const {
   f.in_pos = im->in_pos.p;
   f.out_pos = im->out_pos.p;
   f.h = im->nhub;
-  f.hub_split = kHubSplit;
   f.hub_idx = im->hub_idx.p;
   f.hub_U = im->hub_U.p;
-  f.hub_Sinv = im->hub_Sinv.p;
-  f.hub_w = hub_w.p;
+  f.hub_x2 = hub_x2.p;
   return f;
 }
 
