@@ -215,8 +215,8 @@ __device__ __forceinline__ bool blocked_potrf64(double (*L)[NB + 1], int *s_bad,
   }
   return true;
 }
-// Li = L^-1 (both lower triangular in LDS); Ts: 48 x 17 doubles of scratch
-__device__ __forceinline__ void blocked_trtri64(double (*L)[NB + 1], double (*Li)[NB + 1], double (*Ts)[17],
+// Li = L^-1 (both lower triangular in LDS)
+__device__ __forceinline__ void blocked_trtri64(double (*L)[NB + 1], double (*Li)[NB + 1],
                                                 const double (*Dv)[16][17] /* inverses of the diagonal blocks */) {
   const int tid = threadIdx.x;
   for (int e = tid; e < NB * NB; e += 256) {
@@ -233,7 +233,6 @@ __device__ __forceinline__ void blocked_trtri64(double (*L)[NB + 1], double (*Li
   // products on the matrix pipe; the inner sum stays in registers (a result is the next product's B operand as it
   // stands), so a distance costs one barrier where the FMA form of round 4 paid two and 32 LDS reads per output
   const int wave = tid >> 6, lo = tid & 15, hi = (tid & 63) >> 4;
-  (void)Ts;
   for (int dist = 1; dist < 4; ++dist) {
     if (wave < 4 - dist) {
       const int bj = wave, bi = wave + dist;
@@ -268,7 +267,6 @@ __global__ __launch_bounds__(256) void k_chol_potrf(const PieceDev *__restrict__
   double *__restrict__ M = F + P.off + (long long)j0 * f + j0;
   __shared__ double L[NB][NB + 1];
   __shared__ double Li[NB][NB + 1];
-  __shared__ double Ts[48][17];
   __shared__ double rd[NB];
   __shared__ double Dv[4][16][17];
   __shared__ int s_bad;
@@ -292,7 +290,7 @@ __global__ __launch_bounds__(256) void k_chol_potrf(const PieceDev *__restrict__
     if (j <= r_) M[(long long)r_ * f + j] = L[r_][j];
   }
   if (!always_inv && P.m == 0 && j0 + jb >= P.c) return;  // nothing below the last panel of a root
-  blocked_trtri64(L, Li, Ts, Dv);
+  blocked_trtri64(L, Li, Dv);
   double *__restrict__ O = Linv + (size_t)blockIdx.x * NB * NB;
   for (int e = tid; e < NB * NB; e += 256) O[e] = Li[e >> 6][e & 63];
 }
