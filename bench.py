@@ -265,6 +265,7 @@ def compact_line(full, detail_path="gpurun_out/bench_detail.json", limit=LINE_LI
     if c5:
         ranks = c5.get("staircase_ranks") or {}
         line["config5_lattice100k"] = {"value": c5.get("value"), "unit": c5.get("unit"),
+                                       "hbm_frac": _g(c5, "hbm_roofline", "frac"),
                                        "staircase_ranks": {k: _g(v, "value") for k, v in ranks.items()},
                                        "cpu_port_value": _g(c5, "cpu_port", "value"),
                                        "error": _short(c5.get("error"), 120) if c5.get("error") else None}
@@ -1097,6 +1098,7 @@ def roofline(da, ds, r, robots, warmup=30, steps=100):
             "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
             "bytes_per_application": nbytes, "avg_application_us": ms * 1e3, "launches": info["launches"], "k": ka,
             "nnz_L": info["nnzL"], "survey_8d_bytes_precond": s8,
+            "nnz_Q_agent": int(Qa.nnz), "survey_8d_bytes_qapply_agent": 12.0 * Qa.nnz + 4.0 * (ka + 1) + 16.0 * r * ka,
             "survey_8d_frac": s8 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "dense_inverse_bytes_avoided": 8.0 * ka * ka,
             "by_rank": by_rank}
     except Exception as e:  # the headline line must not depend on the side measurement
@@ -1156,6 +1158,35 @@ def certified_run(args, da, torch, ds, with_cpu):
                            "cores": 1}
         res["relative_cost_difference"] = abs(res["final_cost_2f"] - tr["cost"][-1]) / abs(tr["cost"][-1])
     return res
+
+
+def config5_hbm_roofline(c5, rq, r=5):
+    """the RBCD loop of the 100k lattice as a fraction of the HBM roofline (north_star: "iterations/sec and fraction of the
+    HBM roofline"): SURVEY 8(d)'s ALGORITHMIC bytes of one RBCD iteration -- what its tCG iterations, RTR evaluations,
+    the whole-graph evaluation and the RBCD++ bookkeeping must move, counted from the solver statistics of the timed
+    stretch -- over the measured time per iteration.  Not a counter reading: the replay streams about 15 % more than the
+    8(d) figure of a sparse-factor solve, the small launches are latency-bound."""
+    a = (rq or {}).get("precond_sparse_lattice100k_agent") or {}
+    g = (rq or {}).get("qapply_lattice100k") or {}
+    w = c5.get("solver_work") or {}
+    need = (a.get("survey_8d_bytes_qapply_agent"), a.get("survey_8d_bytes_precond"), a.get("k"), g.get("bytes_per_launch"),
+            g.get("k"), w.get("tcg_per_iteration"), w.get("rtr_outer_per_iteration"), c5.get("ms_per_step"))
+    if any(x is None for x in need):
+        return None
+    b_qx, b_pc, ka, b_glob, kg, tcg, outer, ms = need
+    rk8 = 8.0 * r * ka
+    per_tcg = b_qx + b_pc + 10.0 * rk8              # Hessian product, preconditioner, the vector updates of an iteration
+    per_eval = b_qx + 1.0 * rk8                     # an evaluation of the agent's block: Q-apply with the linear term
+    per_outer = b_pc + 3.0 * rk8                    # z0 = P grad at the start of a tCG run
+    bookkeeping = 6.0 * 8.0 * r * kg                # RBCD++: X, V, Y of the whole graph read and written
+    total = tcg * per_tcg + (outer + 1.0) * per_eval + outer * per_outer + b_glob + bookkeeping
+    ach = total / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+            "algorithmic_bytes_per_rbcd_iteration": total,
+            "parts": {"tcg_iterations": tcg, "bytes_per_tcg_iteration": per_tcg, "rtr_iterations": outer,
+                      "bytes_per_evaluation": per_eval, "bytes_per_z0": per_outer, "whole_graph_evaluation": b_glob,
+                      "rbcdpp_bookkeeping": bookkeeping},
+            "note": "SURVEY 8(d) algorithmic bytes of one RBCD iteration (selected agent: 12 500 poses) / measured time"}
 
 
 def config5_run(da, with_cpu, iters=60, cpu_iters=4):
@@ -1866,6 +1897,9 @@ def main():
             # leave the GPU at a lower clock -- the same 60-iteration window read 877 instead of 1160 it/s after them)
             try:
                 line["config5_lattice100k"] = config5_run(da, not args.no_cpu_baseline)
+                hr = config5_hbm_roofline(line["config5_lattice100k"], line.get("roofline_qapply"))
+                if hr:
+                    line["config5_lattice100k"]["hbm_roofline"] = hr
             except Exception as e:
                 line["config5_lattice100k"] = {"error": str(e)}
             try:
