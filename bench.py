@@ -253,6 +253,7 @@ def compact_line(full, detail_path="gpurun_out/bench_detail.json", limit=LINE_LI
     c3 = full.get("config3_torus3D_8agents")
     if c3:
         line["config3_torus3D_8agents"] = {"value": c3.get("value"), "unit": c3.get("unit"),
+                                           "n_gpus": c3.get("n_gpus"), "cpu_port_value": _g(c3, "cpu_port", "value"),
                                            "error": _short(c3.get("error"), 120) if c3.get("error") else None}
     c4 = full.get("config4_tiers")
     if c4:
@@ -351,7 +352,7 @@ def parse():
     ap.add_argument("--no-coloured", action="store_true",
                     help="skip the coloured simultaneous-update measurements (agents solving on concurrent host threads): "
                          "rocprofv3 --kernel-trace of the WHOLE default run dies in its own buffers there (DESIGN.md 5)")
-    ap.add_argument("--no-config3", action="store_true", help="skip the torus3D 8-agent side measurement (N > 1)")
+    ap.add_argument("--no-config3", action="store_true", help="skip the torus3D 8-agent side measurement")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the timed loop (for a kernel trace of exactly that loop): no side measurements")
     ap.add_argument("--scaling-only", action="store_true",
@@ -1561,6 +1562,42 @@ def side_multi(da, torch, dist, rank, world, ds, R, r, workload, iters=60, sweep
     return res
 
 
+def config3_single(da, with_cpu, iters=200, cpu_iters=60):
+    """BASELINE.json config 3 (torus3D.g2o, 8 agents) with all agents on ONE GPU: the same RBCD++ loop as the headline
+    on the other split BASELINE names (k = 2500 per agent: the partitioned sparse preconditioner); a side measurement,
+    never `value`.  With N > 1 the same key holds the run with the agents spread over the ranks."""
+    from dcora_amd import datasets
+    ds = datasets.product_dataset("torus3D")
+    R, r = 8, 5
+    rng = np.random.default_rng(20250310)
+    X0 = da.manifold_project(r, ds.d, ds.n, rng.uniform(-1, 1, (r, (ds.d + 1) * ds.n)))
+    t0 = time.perf_counter()
+    s = da.RbcdSession(ds, num_robots=R, r=r)
+    setup_s = time.perf_counter() - t0
+    s.set_X(X0)
+    s.run(max_iters=5, rgrad_tol=0.0)
+    s.set_X(X0)
+    t0 = time.perf_counter()
+    out = s.run(max_iters=iters, rgrad_tol=0.0)
+    dt = time.perf_counter() - t0
+    s.close()
+    res = {"workload": "torus3D.g2o, 8 agents, r=5, RBCD++ (accel, restart 30), RTR 3x50 tCG; all agents on one GPU",
+           "n_gpus": 1, "iterations": iters, "value": iters / dt, "unit": "RBCD iterations/s",
+           "ms_per_step": 1e3 * dt / iters, "setup_s": setup_s, "cost_2f_first": float(out["cost"][0]),
+           "cost_2f_last": float(out["cost"][-1])}
+    if with_cpu:
+        from oracle import orc
+        dso = orc.Dataset(ds.d, ds.n, ds.ids, ds.vals)
+        tr = orc.run_rbcd(dso, X0, num_robots=R, r_min=r, max_iters=cpu_iters, staircase=0, rgrad_tol=0.0)
+        n = min(cpu_iters, iters)
+        res["cpu_port"] = {"iterations": int(tr["total_iters"]), "value": tr["total_iters"] / tr["rbcd_seconds"],
+                           "unit": "RBCD iterations/s", "cores": 1,
+                           "same_block_sequence": bool(np.array_equal(tr["selected"][:n], out["selected"][:n])),
+                           "max_relative_cost_difference":
+                               float(np.max(np.abs(tr["cost"][:n] - out["cost"][:n]) / np.abs(tr["cost"][:n])))}
+    return res
+
+
 def config5_multi(da, torch, dist, rank, world):
     from dcora_amd import synth
     ds = synth.lattice_se3()
@@ -1892,6 +1929,11 @@ def main():
                 line["psd_test"] = psd_test_block(da, ds)
             except Exception as e:
                 line["psd_test"] = {"error": str(e)}
+        if not args.no_config3:
+            try:
+                line["config3_torus3D_8agents"] = config3_single(da, not args.no_cpu_baseline)
+            except Exception as e:
+                line["config3_torus3D_8agents"] = {"error": str(e)}
         if not args.no_config5:
             # (the throughput windows first: the centralised solve and the 2 x 25 s of the distributed loop behind them
             # leave the GPU at a lower clock -- the same 60-iteration window read 877 instead of 1160 it/s after them)
