@@ -417,6 +417,13 @@ def is_psd(S, block=1):
     return bool(out.value)
 
 
+def cert_prepare(Q, d, n, l=0, b=0, block=1, device=0, layout=0):
+    """analysis of the PSD test of the dual certificate S = Q - Lambda ahead of time (dcora_cert_prepare): its pattern
+    is known from Q's; meant for another host thread while the agents iterate"""
+    dims = Dims(1, d, n, l, b, layout)
+    check(capi.lib().dcora_cert_prepare(C.byref(dims), Q.rp, Q.ci, block, device))
+
+
 def is_psd_device(S, block=1, device=0, info=False):
     """the PSD test with the numeric factorisation on the device (dcora_cert_is_psd_device)"""
     out = C.c_int()

@@ -170,6 +170,7 @@ SIGNATURES = {
     "dcora_exchange_host_selftest": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, _PD]),
     "dcora_debug_exchange_leave_stale": (C.c_int, [C.c_char_p, C.c_int, C.c_int]),
     "dcora_debug_exchange_probe_fault": (C.c_int, [C.c_int]),
+    "dcora_cert_prepare": (C.c_int, [C.POINTER(Dims), _ip, _ip, C.c_int, C.c_int]),
     "dcora_debug_tcg_run_fault": (C.c_int, [C.c_int]),
     "dcora_debug_tcg_run_fault_at": (C.c_int, [C.c_int, C.c_int]),
     "dcora_problem_solver_info": (C.c_int, [_vp, _dp]),

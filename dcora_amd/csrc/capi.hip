@@ -522,6 +522,38 @@ int dcora_cert_is_psd(int k, const int *rp, const int *ci, const double *v, int 
   return rc;
   DCORA_CATCH
 }
+int dcora_cert_prepare(const dcora_dims *dims, const int *rp, const int *ci, int block, int device) {
+  if (!dims || !rp || !ci) return bad("null");
+  if (!layout_ok(dims)) return bad("dims: layout SE needs l = b = 0");
+  const ManiDesc m = make_mani(*dims);
+  const int n = m.k;
+  if (n <= 0) return bad("empty pattern");
+  // the pattern dcora_cert_dual_matrix will hand to the PSD test: Q's entries, the d x d rotation blocks and the
+  // unit-sphere diagonal of Lambda (present in Q's pattern unless an entry of Q is structurally zero), every diagonal
+  std::vector<int> I, J;
+  I.reserve((size_t)rp[n] + (size_t)m.n * m.d * m.d + m.l);
+  J.reserve(I.capacity());
+  for (int i = 0; i < n; ++i)
+    for (int p = rp[i]; p < rp[i + 1]; ++p) {
+      I.push_back(i);
+      J.push_back(ci[p]);
+    }
+  for (int i = 0; i < m.n; ++i) {
+    const int c = m.rot_col(i);
+    for (int a = 0; a < m.d; ++a)
+      for (int b = 0; b < m.d; ++b) {
+        I.push_back(c + a);
+        J.push_back(c + b);
+      }
+  }
+  for (int i = 0; i < m.l; ++i) {
+    I.push_back(m.sphere_col(i));
+    J.push_back(m.sphere_col(i));
+  }
+  const std::vector<double> V(I.size(), 1.0);
+  const HostCsr A = csr_shift_diag(csr_from_coo(n, n, I, J, V), 1.0);
+  return device_chol_prepare(A, block < 1 ? 1 : block, device);
+}
 int dcora_cert_is_psd_device(int k, const int *rp, const int *ci, const double *v, int block, int device, int *is_psd,
                              double *info8) {
   DCORA_TRY

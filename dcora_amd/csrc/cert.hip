@@ -522,21 +522,80 @@ int device_dual_certificate(const dcora_dims &dims, const double *Xh, const Host
     return DCORA_ERR_NO_DEVICE;
   }
   DCORA_HIP(hipSetDevice(device));
-  // only what the two kernels need: Q, X, X Q and the Lambda blocks (no solver workspace)
-  DevCsr Qd;
-  int rc = Qd.upload(Q);
-  if (rc) return rc;
+  // only what the two kernels need: Q, X, X Q and the Lambda blocks (no solver workspace).  Q without long rows (a
+  // pose graph, or a range-aided one whose landmarks are ranged from few poses) goes into ONE recycled scratch block
+  // with the vectors: six allocations and six frees per certificate were 3 of its 5 ms at k = 10 000.
   const size_t N = (size_t)m.r * m.k;
   const size_t NL = (size_t)m.n * m.d * m.d + m.l;
-  DevBuf<double> dX, dXQ, dL;
-  DCORA_HIP(dX.alloc(N));
-  DCORA_HIP(dXQ.alloc(N));
-  DCORA_HIP(dL.alloc(NL + 1));
-  DCORA_HIP(hipMemcpy(dX.p, Xh, sizeof(double) * N, hipMemcpyHostToDevice));
-  launch_spmm(nullptr, m.r, Qd.view(), buf1(dX.p), 0, nullptr, buf1(dXQ.p), 0, nullptr, Gate{});
-  launch_lambda_blocks(nullptr, m, dX.p, dXQ.p, dL.p);
   std::vector<double> L(NL + 1);
-  DCORA_HIP(hipMemcpy(L.data(), dL.p, sizeof(double) * NL, hipMemcpyDeviceToHost));
+  bool long_rows = false;
+  for (int i = 0; i < Q.n && !long_rows; ++i) long_rows = Q.rp[i + 1] - Q.rp[i] > kLongRow;
+  if (!long_rows) {
+    auto up8 = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t nnz = (size_t)Q.nnz();
+    const size_t o_v = 0, o_x = o_v + up8(nnz * 8), o_xq = o_x + up8(N * 8), o_l = o_xq + up8(N * 8),
+                 o_rp = o_l + up8((NL + 1) * 8), o_ci = o_rp + up8((size_t)(Q.n + 1) * 4), total = o_ci + up8(nnz * 4);
+    struct Arena {
+      int device;
+      size_t bytes;
+      char *p;
+      ~Arena() { scratch_release(device, p, bytes); }
+    } ar{device, total, scratch_acquire(device, total)};
+    if (!ar.p) {
+      set_last_error("dual certificate: device allocation failed");
+      return DCORA_ERR_HIP;
+    }
+    double *dv = (double *)(ar.p + o_v), *dX = (double *)(ar.p + o_x), *dXQ = (double *)(ar.p + o_xq),
+           *dL = (double *)(ar.p + o_l);
+    int *drp = (int *)(ar.p + o_rp), *dci = (int *)(ar.p + o_ci);
+    // the inputs travel through ONE pinned block laid out like the device block (copies from pageable memory stall
+    // for tens of milliseconds now and then: device_chol.h), the Lambda blocks come back through its tail
+    struct Pin {
+      size_t bytes;
+      char *p;
+      ~Pin() { pinned_release(p, bytes); }
+    } pin{total, total <= ((size_t)256 << 20) ? pinned_acquire(total) : nullptr};
+    if (pin.p) {
+      std::memcpy(pin.p + o_v, Q.v.data(), nnz * 8);
+      std::memcpy(pin.p + o_x, Xh, sizeof(double) * N);
+      std::memcpy(pin.p + o_rp, Q.rp.data(), (size_t)(Q.n + 1) * 4);
+      std::memcpy(pin.p + o_ci, Q.ci.data(), nnz * 4);
+      DCORA_HIP(hipMemcpyAsync(dv, pin.p + o_v, o_xq - o_v, hipMemcpyHostToDevice, nullptr));
+      DCORA_HIP(hipMemcpyAsync(drp, pin.p + o_rp, total - o_rp, hipMemcpyHostToDevice, nullptr));
+    } else {
+      DCORA_HIP(hipMemcpyAsync(dv, Q.v.data(), nnz * 8, hipMemcpyHostToDevice, nullptr));
+      DCORA_HIP(hipMemcpyAsync(drp, Q.rp.data(), (size_t)(Q.n + 1) * 4, hipMemcpyHostToDevice, nullptr));
+      DCORA_HIP(hipMemcpyAsync(dci, Q.ci.data(), nnz * 4, hipMemcpyHostToDevice, nullptr));
+      DCORA_HIP(hipMemcpyAsync(dX, Xh, sizeof(double) * N, hipMemcpyHostToDevice, nullptr));
+    }
+    CsrDev Qv;
+    Qv.nrows = Q.n;
+    Qv.nnz = (int)nnz;
+    Qv.rp = drp;
+    Qv.ci = dci;
+    Qv.v = dv;
+    launch_spmm(nullptr, m.r, Qv, buf1(dX), 0, nullptr, buf1(dXQ), 0, nullptr, Gate{});
+    launch_lambda_blocks(nullptr, m, dX, dXQ, dL);
+    if (pin.p) {
+      DCORA_HIP(hipMemcpyAsync(pin.p + o_l, dL, sizeof(double) * NL, hipMemcpyDeviceToHost, nullptr));
+      DCORA_HIP(hipStreamSynchronize(nullptr));
+      std::memcpy(L.data(), pin.p + o_l, sizeof(double) * NL);
+    } else {
+      DCORA_HIP(hipMemcpy(L.data(), dL, sizeof(double) * NL, hipMemcpyDeviceToHost));
+    }
+  } else {
+    DevCsr Qd;
+    int rc = Qd.upload(Q);
+    if (rc) return rc;
+    DevBuf<double> dX, dXQ, dL;
+    DCORA_HIP(dX.alloc(N));
+    DCORA_HIP(dXQ.alloc(N));
+    DCORA_HIP(dL.alloc(NL + 1));
+    DCORA_HIP(hipMemcpy(dX.p, Xh, sizeof(double) * N, hipMemcpyHostToDevice));
+    launch_spmm(nullptr, m.r, Qd.view(), buf1(dX.p), 0, nullptr, buf1(dXQ.p), 0, nullptr, Gate{});
+    launch_lambda_blocks(nullptr, m, dX.p, dXQ.p, dL.p);
+    DCORA_HIP(hipMemcpy(L.data(), dL.p, sizeof(double) * NL, hipMemcpyDeviceToHost));
+  }
   // S = Q - Lambda.  Lambda is block diagonal on entries that Q's own pattern holds (the d x d rotation blocks
   // and the unit-sphere diagonal): subtract in place on a copy of Q; fall back to a merge when an entry is absent.
   {

@@ -86,4 +86,20 @@ std::function<bool(const HostCsr &, int, int, const double *, double *)> device_
 
 void chol_cache_clear();
 
+// The symbolic analysis, the device image and the arena of the factorisation of A's PATTERN (values ignored), left in
+// the cache: a later device_chol_is_pd of a matrix with this pattern starts with its numeric phase.  The certificate
+// S = Q - Lambda has Q's pattern, which is known before the solve starts: a driver prepares it on another host thread
+// while the agents iterate (dcora_cert_prepare).
+int device_chol_prepare(const HostCsr &A, int block, int device);
+
+// recycled device scratch (at most two idle arenas per process; chol_cache_clear() drops them): callers that need a few
+// temporary buffers per call take ONE block here instead of paying a hipMalloc / hipFree pair per buffer
+char *scratch_acquire(int device, size_t bytes);
+void scratch_release(int device, char *p, size_t bytes);
+// the same for pinned HOST memory (staging of small transfers): asynchronous copies from / to pageable memory -- a
+// std::vector, a variable on the stack -- stalled for 16 - 38 ms now and then on this stack (seen inside the certificate's
+// clock); through a pinned buffer they take their 0.1 ms.  nullptr when the allocation fails (callers fall back).
+char *pinned_acquire(size_t bytes);
+void pinned_release(char *p, size_t bytes);
+
 }  // namespace dcora

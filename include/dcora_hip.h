@@ -584,6 +584,13 @@ int dcora_problem_precond_info(dcora_problem_t p, double *info5);
  * 1901-1917).  A second dcora_problem_create / dcora_rbcd_create on the same matrix -- the next staircase level, a
  * problem re-created per update -- attaches to the resident image instead of factorising again.
  * info[4] = {hits, misses, entries, device bytes held}.  Budget: DCORA_PRECOND_CACHE_MB (default 8192, 0 = off). */
+/* addition of this library: the analysis of a certificate's PSD test ahead of time.  The dual certificate S = Q - Lambda
+ * has the sparsity pattern of Q, known before the agents start: a driver calls this on another host thread while they
+ * iterate; the symbolic analysis (ordering, fronts), its device image and the arena are left in the library's cache and
+ * dcora_cert_fast_verification / dcora_cert_is_psd_device of a matrix with this pattern begin with the numeric phase.
+ * dims as for dcora_cert_dual_matrix (r is not used); rp / ci: the CSR pattern of Q, both triangles; block as in the PSD
+ * test.  The pattern analysed is the one dcora_cert_dual_matrix produces: Q's, the blocks of Lambda, every diagonal. */
+int dcora_cert_prepare(const dcora_dims *dims, const int *rp, const int *ci, int block, int device);
 int dcora_precond_cache_info(double *info4);
 int dcora_precond_cache_clear(void);
 
