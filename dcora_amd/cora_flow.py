@@ -24,12 +24,20 @@ class ProductBackend:
         import dcora_amd as da
         self.da, self.ra, self.Q = da, ra, ra.Q
         self.reg = da.precond_regularization(ra.Q)
+        self._prep = None
 
     def problem(self, r):
         ra = self.ra
         return self.da.QuadraticProblem(r, ra.d, ra.n, self.Q, reg=self.reg, l=ra.l, b=ra.b)
 
     def optimize(self, P, X):
+        if self._prep is None:
+            # the PSD test of the certificate (S has Q's pattern) is analysed on another host thread during the first solve
+            import threading
+            ra = self.ra
+            self._prep = threading.Thread(target=self.da.cert_prepare, args=(self.Q, ra.d, ra.n),
+                                          kwargs=dict(l=ra.l, b=ra.b, block=1), daemon=True)
+            self._prep.start()
         opt = self.da.QuadraticOptimizer(P, self.da.ROptParameters(**PARAMS))
         Xo = opt.optimize(X)
         res = opt.getOptResult()
@@ -38,6 +46,8 @@ class ProductBackend:
     def certificate(self, r, X):
         ra = self.ra
         S = self.da.dual_certificate(r, ra.d, ra.n, X, self.Q, l=ra.l, b=ra.b)
+        if self._prep is not None:
+            self._prep.join()
         psd, theta, v, lmin = self.da.fast_verification(S, MIN_EIG_TOL, block=1)
         return psd, theta, v
 
