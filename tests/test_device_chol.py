@@ -140,6 +140,47 @@ def test_device_verdict_and_logdet_vs_scipy_and_oracle(built):
 
 
 @pytest.mark.gpu
+def test_certificate_analysis_prepared_ahead(built):
+    """dcora_cert_prepare: the PSD test of the dual certificate analysed from Q's pattern alone (on another thread, as
+    dcora_amd/driver.py does): the test that follows finds the analysis, and its verdict and log-determinant are those
+    of a test that analysed for itself; pose-graph (SE) and range-aided (RA, block 1) layouts"""
+    import threading
+    import dcora_amd as da
+    cases = []
+    ds, Q = _Q(da, "sphere2500")
+    X = common.random_point(5, ds.d, ds.n, 7, lambda r_, d_, n_, M: da.manifold_project(r_, d_, n_, M))
+    cases.append((da.build_Q_pgo(ds), dict(d=ds.d, n=ds.n, l=0, b=0), ds.d + 1, X, 5))
+    ra = da.RADataset(os.path.join(common.DATA, "range_aided_slam_test_3d.pyfg.gz"))
+    rng = np.random.default_rng(3)
+    cases.append((ra.Q, dict(d=ra.d, n=ra.n, l=ra.l, b=ra.b), 1, None, 4))
+    for Qc, dm, block, X, r in cases:
+        if X is None:
+            k = Qc.n
+            X = rng.standard_normal((r, k))
+        S = da.dual_certificate(r, dm["d"], dm["n"], X, Qc, l=dm["l"], b=dm["b"])
+        # S + shift I made positive definite WITHOUT touching the pattern (scipy's sum would drop S's explicit zeros;
+        # the library's own fastVerification shifts the diagonal in place as well)
+        Ssp = S.to_scipy()
+        shift = 10.0 * abs(Ssp).sum(axis=1).max()
+        A = da.Csr(S.n, S.rp.copy(), S.ci.copy(), S.v.copy())
+        rows = np.repeat(np.arange(S.n), np.diff(S.rp))
+        diag = np.flatnonzero(rows == S.ci)
+        assert diag.size == S.n
+        A.v[diag] += shift
+        da.chol_cache_clear()
+        pd0, info0 = da.is_psd_device(A, block, info=True)
+        assert pd0 and info0["symbolic_ms"] > 0.0
+        da.chol_cache_clear()
+        t = threading.Thread(target=da.cert_prepare, args=(Qc, dm["d"], dm["n"]),
+                             kwargs=dict(l=dm["l"], b=dm["b"], block=block))
+        t.start()
+        t.join()
+        pd1, info1 = da.is_psd_device(A, block, info=True)
+        assert pd1 and info1["symbolic_ms"] == 0.0, "the prepared analysis was not found"
+        assert abs(info1["logdet"] - info0["logdet"]) <= 1e-12 * abs(info0["logdet"])
+
+
+@pytest.mark.gpu
 def test_device_verdict_tiers_with_hub(built):
     import dcora_amd as da
     ra = da.RADataset(os.path.join(common.DATA, "tiers.pyfg.gz"))
