@@ -1534,7 +1534,7 @@ void pinned_release(char *p, size_t bytes) {
   bytes = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
   {
     std::lock_guard<std::mutex> lk(g_pinned_mu);
-    if (g_pinned_idle.size() < 3) {
+    if (bytes <= ((size_t)32 << 20) && g_pinned_idle.size() < 3) {  // (large ones go back: pinned memory is the host's)
       g_pinned_idle.push_back(Pinned{bytes, p});
       return;
     }
