@@ -956,7 +956,10 @@ int build_image(const HostCsr &A, int block, int top, int device, std::shared_pt
   DCORA_HIP(hipMemcpy(img->dest.p, S.a_dest.data(), S.a_dest.size() * sizeof(long long), hipMemcpyHostToDevice));
   DCORA_HIP(img->linv.alloc((size_t)max_level_count * NB * NB));
   DCORA_HIP(img->vals.alloc(S.a_dest.size()));
-  if (hipHostMalloc((void **)&img->vals_pinned, (S.a_dest.size() + 2) * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+  // (small problems only: there the stall of a pageable copy is the factorisation's whole time several times over; an
+  // image of the 100k lattice would pin 80 MB per cached pattern)
+  if (S.a_dest.size() * sizeof(double) <= ((size_t)32 << 20) &&
+      hipHostMalloc((void **)&img->vals_pinned, (S.a_dest.size() + 2) * sizeof(double), hipHostMallocDefault) != hipSuccess) {
     (void)hipGetLastError();
     img->vals_pinned = nullptr;  // the pageable copy below still works
   }
