@@ -101,7 +101,10 @@ def test_host_replay_with_level_groups_and_chained_records(built, g, extra, hubs
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("g,extra,hubs,r", [(14, 0, 0, 5), (18, 0, 0, 5), (16, 40, 2, 7), (16, 0, 1, 3), (12, 500, 0, 12)])
+@pytest.mark.parametrize("g,extra,hubs,r", [(14, 0, 0, 5), (18, 0, 0, 5), (16, 40, 2, 7), (16, 0, 1, 3), (12, 500, 0, 12),
+                                            # small graphs with hubs: the replay is ONE launch, so the second stage of the
+                                            # hubs' correction (x2 from the slices) runs as a launch of its own
+                                            (4, 0, 1, 3), (5, 0, 2, 5), (2, 0, 1, 3), (3, 0, 1, 4)])
 def test_device_replay_on_irregular_graphs_matches_oracle(sparse_env, g, extra, hubs, r):
     import dcora_amd as da
     from oracle import orc
